@@ -1,0 +1,82 @@
+/*
+ * lvm_oracle.h -- CPU ORACLE for the Eulerian video-magnification hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a plain-C, OpenCV-free restatement of the
+ * reference's per-frame magnifiers (reference: src/processing/MagnificationProcessor.cpp:17-67,
+ * src/processing/magnification/{MagnifyCore.hpp,SpatialFilter.cpp,TemporalFilter.cpp,
+ * RieszPyramid.cpp,ComplexMat.hpp}).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product (liblvm_hip.so) never links or calls it.
+ *
+ * PARITY STATUS: "parity unpinned" at the OpenCV boundary.  The reference has no tests,
+ * golden frames or fixtures, and its arithmetic lives in OpenCV 4 (vcpkg, un-vendored, absent
+ * here).  OpenCV primitives are restated from their published semantics (see DESIGN.md
+ * "Oracle").  The OpenCV-free slices of the reference (butterworth, getOptimalBufferSize)
+ * ARE pinned: they are compiled from /root/reference in place (oracle/Makefile ->
+ * oracle/_ref/) and checked against this restatement and tests/golden/.
+ */
+#ifndef LVM_ORACLE_H
+#define LVM_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference: IProcessor.hpp:10 (same numeric order as the enum class) */
+enum { LVMO_MODE_LAPLACE = 0, LVMO_MODE_PHASE = 1, LVMO_MODE_COLOR = 2, LVMO_MODE_NONE = 3 };
+
+/* reference: IProcessor.hpp:14-23 (+ a 64-bit key standing for PreprocessParams equality,
+ * IProcessor.hpp:26-41, which StructuralTracker compares: MagnifyCore.hpp:55-56) */
+typedef struct lvmo_params {
+    int32_t  mode;
+    int32_t  levels;
+    double   amplification;
+    double   coWavelength;
+    double   coLow;
+    double   coHigh;
+    double   chromAttenuation;
+    double   framerate;
+    uint64_t preprocess_key;
+} lvmo_params;
+
+typedef struct lvmo_ctx lvmo_ctx;
+
+lvmo_ctx* lvmo_create(void);
+void      lvmo_destroy(lvmo_ctx*);
+void      lvmo_reset(lvmo_ctx*);                     /* MagnificationProcessor.cpp:10-15 */
+void      lvmo_set_threads(int n);                   /* OpenMP threads for the timed baseline */
+/* MagnificationProcessor.cpp:17-67.  *produced==0 => caller shows the input frame. */
+int lvmo_process(lvmo_ctx*, const lvmo_params*, const uint8_t* in, int w, int h, int channels,
+                 ptrdiff_t in_stride, uint8_t* out, ptrdiff_t out_stride, int* produced);
+/* pre-quantisation float frame of the last produced output (interleaved, w*h*channels) */
+const float* lvmo_last_float(lvmo_ctx*, int* w, int* h, int* c);
+/* Colour mode: min/max used by the final rescale (MagnifyCore.hpp:200-203) */
+void lvmo_last_minmax(lvmo_ctx*, double* mn, double* mx);
+
+/* ---- primitives (exported for unit tests) ---------------------------------------------- */
+int  lvmo_max_levels(int w, int h);                                   /* SpatialFilter.cpp:5-11 */
+int  lvmo_optimal_buffer_size(int fps);                               /* TemporalFilter.cpp:82-94 */
+void lvmo_butterworth2(double Wn, double a[3], double b[3]);          /* TemporalFilter.cpp:280-297 (N=2) */
+void lvmo_laplace_gains(int w, int h, int levels, double amplification, double coWavelength,
+                        float* gains /* levels+1 */);                 /* MagnifyCore.hpp:114-134 */
+void lvmo_pyr_down(const float* src, int w, int h, int cn, float* dst);
+void lvmo_pyr_up(const float* src, int w, int h, int cn, float* dst, int dw, int dh);
+void lvmo_bgr2lab(const float* src, int npix, float* dst);
+void lvmo_lab2bgr(const float* src, int npix, float* dst);
+void lvmo_filter2d(const float* src, int w, int h, const float* k, int kw, int kh, float* dst);
+void lvmo_gauss_kernel(int n, double sigma, float* k);
+void lvmo_sep_filter(const float* src, int w, int h, const float* k, int n, float* dst);
+void lvmo_resize_linear(const float* src, int w, int h, int cn, float* dst, int dw, int dh);
+void lvmo_dft_rows(const float* src, int rows, int n, float* dst);    /* DFT_ROWS|DFT_SCALE, CCS */
+void lvmo_idft_rows(const float* src, int rows, int n, float* dst);   /* DFT_ROWS|DFT_SCALE, CCS */
+void lvmo_mul_spectrums_rows(const float* a, const float* b, int rows, int n, float* dst);
+void lvmo_ideal_filter(const float* win, int rows, int cols, int cn, double lo, double hi,
+                       double fps, float* dst, int full);             /* TemporalFilter.cpp:24-57 */
+void lvmo_riesz_kernels(float lp[81], float hp[81]);                  /* RieszPyramid.cpp:146-167 */
+float lvmo_cube_root(float v);
+const float* lvmo_gamma_tab(int inverse);  /* 1024*4 spline coefficients */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,267 @@
+"""ctypes binding of the CPU ORACLE (oracle/liblvm_oracle.so) and of the reference slices
+(oracle/_ref/libref_slices.so).
+
+TEST INFRASTRUCTURE ONLY: import from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never from the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+MODE_LAPLACE, MODE_PHASE, MODE_COLOR, MODE_NONE = 0, 1, 2, 3
+
+
+class Params(C.Structure):
+    """reference: src/processing/IProcessor.hpp:14-23 (+ preprocess key)."""
+    _fields_ = [("mode", C.c_int32), ("levels", C.c_int32), ("amplification", C.c_double),
+                ("coWavelength", C.c_double), ("coLow", C.c_double), ("coHigh", C.c_double),
+                ("chromAttenuation", C.c_double), ("framerate", C.c_double),
+                ("preprocess_key", C.c_uint64)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liblvm_oracle.so")
+    src = os.path.join(_HERE, "lvm_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+    return so
+
+
+_lib = None
+_ref = None
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+_u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+_f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.lvmo_create.restype = C.c_void_p
+        L.lvmo_destroy.argtypes = [C.c_void_p]
+        L.lvmo_reset.argtypes = [C.c_void_p]
+        L.lvmo_set_threads.argtypes = [C.c_int]
+        L.lvmo_process.argtypes = [C.c_void_p, C.POINTER(Params), _u8p, C.c_int, C.c_int, C.c_int,
+                                   C.c_ssize_t, _u8p, C.c_ssize_t, C.POINTER(C.c_int)]
+        L.lvmo_process.restype = C.c_int
+        L.lvmo_last_float.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.lvmo_last_float.restype = C.POINTER(C.c_float)
+        L.lvmo_last_minmax.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.lvmo_max_levels.argtypes = [C.c_int, C.c_int]
+        L.lvmo_optimal_buffer_size.argtypes = [C.c_int]
+        L.lvmo_butterworth2.argtypes = [C.c_double, _f64p, _f64p]
+        L.lvmo_laplace_gains.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _f32p]
+        L.lvmo_pyr_down.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _f32p]
+        L.lvmo_pyr_up.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int]
+        L.lvmo_bgr2lab.argtypes = [_f32p, C.c_int, _f32p]
+        L.lvmo_lab2bgr.argtypes = [_f32p, C.c_int, _f32p]
+        L.lvmo_filter2d.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f32p]
+        L.lvmo_gauss_kernel.argtypes = [C.c_int, C.c_double, _f32p]
+        L.lvmo_sep_filter.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, _f32p]
+        L.lvmo_resize_linear.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int]
+        L.lvmo_dft_rows.argtypes = [_f32p, C.c_int, C.c_int, _f32p]
+        L.lvmo_idft_rows.argtypes = [_f32p, C.c_int, C.c_int, _f32p]
+        L.lvmo_mul_spectrums_rows.argtypes = [_f32p, _f32p, C.c_int, C.c_int, _f32p]
+        L.lvmo_ideal_filter.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                        C.c_double, _f32p, C.c_int]
+        L.lvmo_riesz_kernels.argtypes = [_f32p, _f32p]
+        L.lvmo_cube_root.argtypes = [C.c_float]
+        L.lvmo_cube_root.restype = C.c_float
+        L.lvmo_gamma_tab.argtypes = [C.c_int]
+        L.lvmo_gamma_tab.restype = C.POINTER(C.c_float)
+        _lib = L
+    return _lib
+
+
+def ref_slices():
+    """The OpenCV-free slices of the reference compiled in place (None when absent)."""
+    global _ref
+    if _ref is None:
+        so = os.path.join(_HERE, "_ref", "libref_slices.so")
+        if not os.path.exists(so):
+            return None
+        R = C.CDLL(so)
+        R.ref_getOptimalBufferSize.argtypes = [C.c_int]
+        R.ref_butterworth.argtypes = [C.c_uint, C.c_double, _f64p, _f64p]
+        R.ref_motionHzToBlend.argtypes = [C.c_double, C.c_double]
+        R.ref_motionHzToBlend.restype = C.c_double
+        _ref = R
+    return _ref
+
+
+def make_params(mode, levels, amplification=0.0, coWavelength=0.0, coLow=0.0, coHigh=0.0,
+                chromAttenuation=0.0, framerate=30.0, preprocess_key=0):
+    return Params(mode, levels, amplification, coWavelength, coLow, coHigh, chromAttenuation,
+                  framerate, preprocess_key)
+
+
+class Oracle:
+    """Mirror of MagnificationProcessor (reference: MagnificationProcessor.hpp:13-23)."""
+
+    def __init__(self):
+        self._l = lib()
+        self._c = self._l.lvmo_create()
+
+    def close(self):
+        if self._c:
+            self._l.lvmo_destroy(self._c)
+            self._c = None
+
+    __del__ = close
+
+    def reset(self):
+        self._l.lvmo_reset(self._c)
+
+    def process(self, frame, params):
+        """frame: HxWx3 or HxW uint8.  Returns (out_u8, produced)."""
+        frame = np.ascontiguousarray(frame)
+        h, w = frame.shape[:2]
+        ch = 1 if frame.ndim == 2 else frame.shape[2]
+        out = np.empty_like(frame)
+        produced = C.c_int(0)
+        rc = self._l.lvmo_process(self._c, C.byref(params), frame.reshape(-1), w, h, ch, w * ch,
+                                  out.reshape(-1), w * ch, C.byref(produced))
+        if rc != 0:
+            raise RuntimeError("oracle error %d" % rc)
+        if not produced.value:
+            return frame, False
+        return out, True
+
+    def last_float(self):
+        w, h, c = C.c_int(), C.c_int(), C.c_int()
+        p = self._l.lvmo_last_float(self._c, C.byref(w), C.byref(h), C.byref(c))
+        n = w.value * h.value * c.value
+        a = np.ctypeslib.as_array(p, shape=(n,)).copy()
+        return a.reshape(h.value, w.value, c.value) if c.value > 1 else a.reshape(h.value, w.value)
+
+    def last_minmax(self):
+        a, b = C.c_double(), C.c_double()
+        self._l.lvmo_last_minmax(self._c, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+
+# ---- primitive wrappers (unit tests) ---------------------------------------------------------
+def _img(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    h, w = a.shape[:2]
+    cn = 1 if a.ndim == 2 else a.shape[2]
+    return a, w, h, cn
+
+
+def pyr_down(a):
+    a, w, h, cn = _img(a)
+    out = np.empty(((h + 1) // 2, (w + 1) // 2) + ((cn,) if a.ndim == 3 else ()), np.float32)
+    lib().lvmo_pyr_down(a.reshape(-1), w, h, cn, out.reshape(-1))
+    return out
+
+
+def pyr_up(a, dsize=None):
+    a, w, h, cn = _img(a)
+    dw, dh = dsize if dsize else (2 * w, 2 * h)
+    out = np.empty((dh, dw) + ((cn,) if a.ndim == 3 else ()), np.float32)
+    lib().lvmo_pyr_up(a.reshape(-1), w, h, cn, out.reshape(-1), dw, dh)
+    return out
+
+
+def bgr2lab(a):
+    a = np.ascontiguousarray(a, np.float32)
+    out = np.empty_like(a)
+    lib().lvmo_bgr2lab(a.reshape(-1), a.size // 3, out.reshape(-1))
+    return out
+
+
+def lab2bgr(a):
+    a = np.ascontiguousarray(a, np.float32)
+    out = np.empty_like(a)
+    lib().lvmo_lab2bgr(a.reshape(-1), a.size // 3, out.reshape(-1))
+    return out
+
+
+def filter2d(a, k):
+    a, w, h, _ = _img(a)
+    k = np.ascontiguousarray(k, np.float32)
+    out = np.empty_like(a)
+    lib().lvmo_filter2d(a.reshape(-1), w, h, k.reshape(-1), k.shape[1], k.shape[0], out.reshape(-1))
+    return out
+
+
+def gauss_kernel(n, sigma):
+    k = np.empty(n, np.float32)
+    lib().lvmo_gauss_kernel(n, sigma, k)
+    return k
+
+
+def sep_filter(a, k):
+    a, w, h, _ = _img(a)
+    k = np.ascontiguousarray(k, np.float32)
+    out = np.empty_like(a)
+    lib().lvmo_sep_filter(a.reshape(-1), w, h, k, k.size, out.reshape(-1))
+    return out
+
+
+def resize_linear(a, dsize):
+    a, w, h, cn = _img(a)
+    dw, dh = dsize
+    out = np.empty((dh, dw) + ((cn,) if a.ndim == 3 else ()), np.float32)
+    lib().lvmo_resize_linear(a.reshape(-1), w, h, cn, out.reshape(-1), dw, dh)
+    return out
+
+
+def dft_rows(a):
+    a = np.ascontiguousarray(a, np.float32)
+    out = np.empty_like(a)
+    lib().lvmo_dft_rows(a.reshape(-1), a.shape[0], a.shape[1], out.reshape(-1))
+    return out
+
+
+def idft_rows(a):
+    a = np.ascontiguousarray(a, np.float32)
+    out = np.empty_like(a)
+    lib().lvmo_idft_rows(a.reshape(-1), a.shape[0], a.shape[1], out.reshape(-1))
+    return out
+
+
+def mul_spectrums_rows(a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    out = np.empty_like(a)
+    lib().lvmo_mul_spectrums_rows(a.reshape(-1), b.reshape(-1), a.shape[0], a.shape[1], out.reshape(-1))
+    return out
+
+
+def ideal_filter(win, lo, hi, fps, full=False):
+    """win: rows x cols x cn float32."""
+    win = np.ascontiguousarray(win, np.float32)
+    rows, cols, cn = win.shape
+    out = np.empty_like(win)
+    lib().lvmo_ideal_filter(win.reshape(-1), rows, cols, cn, lo, hi, fps, out.reshape(-1), int(full))
+    return out
+
+
+def butterworth2(Wn):
+    a = np.zeros(3)
+    b = np.zeros(3)
+    lib().lvmo_butterworth2(Wn, a, b)
+    return a, b
+
+
+def laplace_gains(w, h, levels, amplification, coWavelength):
+    g = np.zeros(levels + 1, np.float32)
+    lib().lvmo_laplace_gains(w, h, levels, amplification, coWavelength, g)
+    return g
+
+
+def riesz_kernels():
+    lp = np.zeros(81, np.float32)
+    hp = np.zeros(81, np.float32)
+    lib().lvmo_riesz_kernels(lp, hp)
+    return lp.reshape(9, 9), hp.reshape(9, 9)
+
+
+def gamma_tab(inverse=False):
+    p = lib().lvmo_gamma_tab(int(inverse))
+    return np.ctypeslib.as_array(p, shape=(4096,)).copy()
