@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- magnified frames/s of the HIP magnification core on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--mode laplace|riesz|color] [--streams B]
+
+A "step" is one pass of the hot path (lvm_process_device: one frame for each of the B streams
+held by the context) over synthetic frames that are already resident in HBM; outputs stay in
+HBM.  Default workload = BASELINE.json configs[1]: Laplace motion, 1920x1080, 6 levels, IIR
+0.4-3 Hz, alpha 20, single stream, one MI355X.  With N > 1 (one rank per GPU, launched by
+torch.distributed.run) every rank runs its own independent stream(s): the path shards by
+stream with no data-path collective (weak scaling); RCCL is only used for the timing barrier
+and the max-over-ranks reduction.
+
+Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel, HIP-event timed on the
+launch stream) and `cpu_baseline` (the CPU oracle timed on this box's host cores, rank 0, N=1).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MODES = {"laplace": 1, "riesz": 2, "color": 3}  # -> BASELINE.json configs index
+
+
+def level_sizes(w, h, levels):
+    out = [(w, h)]
+    for _ in range(levels):
+        w, h = (w + 1) // 2, (h + 1) // 2
+        out.append((w, h))
+    return out
+
+
+def kernel_alg_bytes(mode, name, w, h, ch, levels, streams, T=0):
+    """Compulsory bytes one launch of kernel `name` moves (inputs read once + outputs written
+    once), for the kernel decomposition described in DESIGN.md.  None when not tabulated."""
+    n = [a * b for a, b in level_sizes(w, h, levels)]
+    P = ch * streams
+    if mode == "laplace":
+        if name == "lap_down0":
+            return streams * ch * n[0] + 4 * P * n[1]
+        if name == "lap_final":
+            return 2 * streams * ch * n[0] + 4 * P * n[1]
+        if name == "pyr_down":   # averaged over the L-1 launches
+            return sum(4 * P * (n[l] + n[l + 1]) for l in range(1, levels)) / max(levels - 1, 1)
+        if name in ("lap_up", "lap_seed"):
+            # G_l + G_{l+1} + cur_{l+1} read, hi/lo read+written, cur_l written
+            return sum(4 * P * (n[l] * 6 + 2 * n[l + 1]) for l in range(1, levels)) / max(levels - 1, 1)
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--mode", default="laplace", choices=list(MODES))
+    ap.add_argument("--streams", type=int, default=1, help="independent streams per GPU (one launch covers all)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--levels", type=int, default=0)
+    ap.add_argument("--ring", type=int, default=16, help="distinct input frames kept in HBM")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=60)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    lvm = importlib.import_module("live-video-magnification_amd")
+    cfg_idx = MODES[args.mode]
+    small = None
+    ck0, pk0 = lvm.synth.config(cfg_idx)
+    if args.width or args.height or args.levels:
+        small = (args.width or ck0["w"], args.height or ck0["h"], args.levels or pk0["levels"])
+    ck, pk = lvm.synth.config(cfg_idx, small)
+    w, h, levels, ch = ck["w"], ck["h"], pk["levels"], 3
+    B = args.streams
+
+    # ---- synthetic clip, staged in HBM: ring x B x h x w x 3 (stream s uses seed 1234 + s) ----
+    ring = args.ring
+    clips = [lvm.synth.Clip(seed=1234 + rank * B + s, **{k: v for k, v in ck.items() if k != "seed"}) for s in range(B)]
+    host = np.empty((ring, B, h, w, ch), np.uint8)
+    for t in range(ring):
+        for s in range(B):
+            host[t, s] = clips[s].frame(t)
+    d_in = torch.from_numpy(host).cuda()
+    d_out = torch.empty_like(d_in)
+    frame_bytes = h * w * ch
+
+    ctx = lvm.Context(local_rank, B)
+    if args.no_graph:
+        ctx.set_graph(False)
+    cp = lvm.LvmParams(pk["mode"], pk["levels"], pk["amplification"], pk["coWavelength"], pk["coLow"], pk["coHigh"],
+                       pk["chromAttenuation"], pk["framerate"], 0)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        t = i % ring
+        return ctx.process_device(cp, d_in[t].data_ptr(), w, h, ch, w * ch, frame_bytes, d_out[t].data_ptr(), w * ch,
+                                  frame_bytes, stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n = 0
+    for _ in range(args.warmup):
+        step(n); n += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(n); n += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    barrier()
+    fps = world * B * args.steps / dt
+
+    # ---- per-kernel timing pass (HIP events on the launch stream) -> roofline ----
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        ctx.profile(True)
+        for _ in range(args.profile_steps):
+            step(n); n += 1
+        torch.cuda.synchronize()
+        prof = ctx.profile_collect()
+        ctx.profile(False)
+        tot = sum(v[0] for v in prof.values()) or 1.0
+        T = lvm.load().lvm_optimal_buffer_size(int(pk["framerate"]))
+        for name, (ms, cnt) in prof.items():
+            avg_us = 1e3 * ms / max(cnt, 1)
+            ab = kernel_alg_bytes(args.mode, name, w, h, ch, levels, B, T)
+            kernels[name] = {"avg_us": round(avg_us, 3), "launches": cnt, "share": round(ms / tot, 4),
+                             "alg_bytes": ab, "gbs": (round(ab / (avg_us * 1e-6) / 1e9, 1) if ab else None)}
+        dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
+        k = kernels[dom]
+        if k["gbs"]:
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(k["gbs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                        "avg_us": k["avg_us"], "alg_bytes_per_launch": k["alg_bytes"]}
+    b_alg = lvm.load().lvm_algorithmic_bytes(pk["mode"], w, h, ch, levels, pk["framerate"])
+    frame_frac = b_alg * (fps / world) / (HBM_PEAK_GBS * 1e9)
+
+    # ---- CPU baseline: the oracle (CPU restatement of the reference) on this box's cores ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        o = po.Oracle()
+        P = po.make_params(**pk)
+        nthreads = os.cpu_count() or 1
+        po.lib().lvmo_set_threads(nthreads)
+        frames = [host[t % ring, 0] for t in range(4)]
+        for f in frames[:2]:
+            o.process(f, P)                       # first frame seeds, second warms caches
+        tc0 = time.perf_counter(); cnt = 0
+        while time.perf_counter() - tc0 < 12.0 and cnt < 400:
+            o.process(host[cnt % ring, 0], P); cnt += 1
+        cdt = time.perf_counter() - tc0
+        cpu = {"value": round(cnt / cdt, 3), "unit": "frames/s", "cores": nthreads, "kind": "port",
+               "sample": "%d frames of the same %dx%d L%d %s clip, CPU oracle (restatement of the reference; "
+                         "OpenCV unavailable), OpenMP over rows" % (cnt, w, h, levels, args.mode)}
+
+    if rank == 0:
+        out = {
+            "metric": "magnified frames/sec at 1080p, Laplace-motion 6 levels; % HBM roofline" if args.mode == "laplace"
+                      else "magnified frames/sec (%s)" % args.mode,
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s %dx%d, %d levels, %d stream(s)/GPU, device-resident u8 BGR in/out" %
+                                   (args.mode, w, h, levels, B),
+                       "baseline_config": cfg_idx, "streams_per_gpu": B, "ring_frames": ring},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "frame_alg_bytes": b_alg, "frame_roofline_frac": round(frame_frac, 5),
+            "kernels": kernels,
+        }
+        print(json.dumps(out))
+    ctx.close()
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,117 @@
+/*
+ * lvm_hip.h -- C ABI of liblvm_hip.so, the MI355X (gfx950) Eulerian video-magnification core.
+ *
+ * Drop-in boundary for the reference's magnification stage.  Every entry point cites the
+ * reference interface it replaces (paths relative to the reference's src/):
+ *
+ *   processing/IProcessor.hpp:50-60            IProcessor::process / reset   (the surface)
+ *   processing/MagnificationProcessor.cpp:17-67  process(): clamp levels, structural reset,
+ *                                              dispatch by mode, passthrough on !produced
+ *   processing/MagnificationProcessor.cpp:10-15  reset()
+ *   processing/magnification/MagnifyCore.hpp:83,163,209  magnifyMotion/Color/Riesz
+ *
+ * Plain pointers and sizes only; no torch / OpenCV / Qt types.  A context is
+ * thread-compatible (one thread at a time per context, any number of contexts concurrently --
+ * the reference runs a live chain and an export chain side by side, export/Exporter.cpp:204).
+ * All entry points return 0 on success, a negative lvm_status otherwise;
+ * lvm_last_error(ctx) gives the message.  After an error the context accepts lvm_reset()
+ * and continues (the reference's recovery path: processing/ProcessingChain.cpp:50-62).
+ */
+#ifndef LVM_HIP_H
+#define LVM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* processing/IProcessor.hpp:10 -- numeric order of `enum class MagnificationMode` */
+enum lvm_mode { LVM_MODE_LAPLACE = 0, LVM_MODE_PHASE = 1, LVM_MODE_COLOR = 2, LVM_MODE_NONE = 3 };
+
+enum lvm_status {
+    LVM_OK = 0,
+    LVM_ERR_INVALID = -1,   /* bad argument */
+    LVM_ERR_HIP = -2,       /* HIP runtime error (message in lvm_last_error) */
+    LVM_ERR_NO_DEVICE = -3, /* no gfx950 device / HIP runtime unavailable */
+    LVM_ERR_OOM = -4
+};
+
+/* processing/IProcessor.hpp:14-23 (MagnificationParams, algorithm units) plus a key that
+ * stands for PreprocessParams equality (IProcessor.hpp:26-41): the reference drops temporal
+ * state when the ROI/downscale changes even at equal size (MagnifyCore.hpp:55-56).          */
+typedef struct lvm_params {
+    int32_t  mode;              /* lvm_mode */
+    int32_t  levels;            /* clamped to [1, maxLevels(w,h)] like MagnificationProcessor.cpp:34 */
+    double   amplification;     /* alpha */
+    double   coWavelength;      /* Laplace: lambda_c (UI% * 10); Phase: 100 - UI% */
+    double   coLow;             /* Laplace: IIR blend in [0,1]; Phase/Color: Hz */
+    double   coHigh;
+    double   chromAttenuation;  /* Laplace only: gain on Lab a,b of the motion image */
+    double   framerate;         /* Color ideal filter + Riesz Butterworth */
+    uint64_t preprocess_key;    /* any value that changes iff PreprocessParams changes */
+} lvm_params;
+
+typedef struct lvm_ctx lvm_ctx;
+
+/* Replaces constructing a MagnificationProcessor (processing/ChainBuilder.cpp:15).
+ * n_streams >= 1 independent streams share one context: every per-stream buffer (temporal
+ * state, pyramids) is laid out [stream][...] and every kernel launch covers all of them.
+ * n_streams == 1 is the drop-in case.                                                       */
+int  lvm_create(int device, int n_streams, lvm_ctx** out);
+void lvm_destroy(lvm_ctx* ctx);
+
+/* IProcessor::reset (MagnificationProcessor.cpp:10-15): next frame behaves as the first. */
+int  lvm_reset(lvm_ctx* ctx);
+
+/* IProcessor::process on host memory (MagnificationProcessor.cpp:17-67), n_streams == 1.
+ * in : h rows of w*channels uint8 (BGR interleaved or gray), in_stride bytes per row.
+ * out: caller-allocated, same geometry; written only when *produced != 0.
+ * *produced == 0 <=> the reference returns the INPUT frame (mode None, frame too small,
+ * Color warm-up < 2 columns, Riesz first frame / re-init, Riesz on < 3 channels).
+ * Synchronous: H2D, kernels and D2H have completed on return; `in` is not retained.        */
+int  lvm_process(lvm_ctx* ctx, const lvm_params* p, const uint8_t* in, int w, int h,
+                 int channels, ptrdiff_t in_stride, uint8_t* out, ptrdiff_t out_stride,
+                 int* produced);
+
+/* Same contract on DEVICE memory for all n_streams streams at once: stream s reads
+ * d_in + s*in_stream_stride and writes d_out + s*out_stream_stride (bytes).  Work is enqueued
+ * on `hip_stream` (a hipStream_t; NULL = the context's own stream) and NOT synchronised:
+ * *produced is decided on the host before any kernel runs.                                 */
+int  lvm_process_device(lvm_ctx* ctx, const lvm_params* p, const uint8_t* d_in, int w, int h,
+                        int channels, ptrdiff_t in_stride, ptrdiff_t in_stream_stride,
+                        uint8_t* d_out, ptrdiff_t out_stride, ptrdiff_t out_stream_stride,
+                        int* produced, void* hip_stream);
+
+/* Wait for everything enqueued by lvm_process_device on the context's own stream. */
+int  lvm_synchronize(lvm_ctx* ctx);
+
+const char* lvm_last_error(lvm_ctx* ctx);
+
+/* processing/magnification/SpatialFilter.cpp:5-11 calculateMaxLevels */
+int  lvm_max_levels(int w, int h);
+/* processing/magnification/TemporalFilter.cpp:82-94 getOptimalBufferSize */
+int  lvm_optimal_buffer_size(int fps);
+/* processing/magnification/TemporalFilter.cpp:280-297 butterworth(N = 2, Wn) */
+void lvm_butterworth2(double Wn, double a[3], double b[3]);
+
+/* ---- instrumentation (not part of the reference surface) -------------------------------- */
+/* Keep the pre-quantisation float frame of stream 0 (parity metric).
+ * lvm_debug_read_float copies w*h*channels floats (interleaved like the u8 output).        */
+int  lvm_debug_keep_float(lvm_ctx* ctx, int on);
+int  lvm_debug_read_float(lvm_ctx* ctx, float* dst, size_t count);
+/* Per-kernel timing with HIP events recorded on the launch stream.  While enabled every
+ * kernel launch is bracketed by two events; lvm_profile_collect synchronises and folds them
+ * into per-kernel totals, readable with lvm_profile_entry (idx = 0..n-1).                   */
+int  lvm_profile_enable(lvm_ctx* ctx, int on);
+int  lvm_profile_collect(lvm_ctx* ctx);
+int  lvm_profile_entry(lvm_ctx* ctx, int idx, char* name, size_t name_cap, double* total_ms,
+                       long long* launches);
+/* Capture the per-frame launch sequence in a hipGraph and replay it (default on). */
+int  lvm_set_graph(lvm_ctx* ctx, int on);
+/* Algorithmic bytes per frame per stream for the current geometry/mode. */
+double lvm_algorithmic_bytes(int mode, int w, int h, int channels, int levels, double framerate);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

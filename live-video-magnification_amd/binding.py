@@ -1,0 +1,232 @@
+"""ctypes binding of the C ABI (include/lvm_hip.h) and a Python mirror of the reference's
+operator surface for this path:
+
+    reference                                              here
+    -----------------------------------------------------  ---------------------------------
+    MagnificationMode   (processing/IProcessor.hpp:10)      MagnificationMode
+    MagnificationParams (processing/IProcessor.hpp:14-23)   MagnificationParams
+    PreprocessParams    (processing/IProcessor.hpp:26-41)   PreprocessParams
+    ProcessorConfig     (processing/IProcessor.hpp:44-48)   ProcessorConfig
+    MagnificationProcessor::process / reset                 MagnificationProcessor.process / reset
+      (processing/MagnificationProcessor.cpp:10-67)
+
+The library is the hipcc/gfx950 build of csrc/ (liblvm_hip.so next to this file).  There is no
+CPU fallback: if the library or a GPU is missing, loading / creating a processor raises.
+"""
+import ctypes as C
+import dataclasses
+import enum
+import os
+import struct
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblvm_hip.so")
+
+
+class MagnificationMode(enum.IntEnum):
+    Laplace = 0
+    Phase = 1
+    Color = 2
+    None_ = 3
+
+
+@dataclasses.dataclass
+class MagnificationParams:
+    mode: int = MagnificationMode.Laplace
+    amplification: float = 0.0
+    coWavelength: float = 0.0
+    coLow: float = 0.0
+    coHigh: float = 0.0
+    chromAttenuation: float = 0.0
+    levels: int = 4
+    framerate: float = 30.0
+
+
+@dataclasses.dataclass
+class PreprocessParams:
+    downscale: int = 1
+    roiEnabled: bool = False
+    roiX: float = 0.0
+    roiY: float = 0.0
+    roiW: float = 1.0
+    roiH: float = 1.0
+
+    def key(self):
+        """64-bit value that changes iff the struct changes (operator==, IProcessor.hpp:36-39)."""
+        raw = struct.pack("<i?ffff", self.downscale, self.roiEnabled, self.roiX, self.roiY, self.roiW, self.roiH)
+        h = 0xcbf29ce484222325
+        for b in raw:
+            h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+        return 0 if self == PreprocessParams() else (h or 1)
+
+
+@dataclasses.dataclass
+class ProcessorConfig:
+    grayscale: bool = False
+    preprocess: PreprocessParams = dataclasses.field(default_factory=PreprocessParams)
+    magnification: MagnificationParams = dataclasses.field(default_factory=MagnificationParams)
+
+
+class LvmParams(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("levels", C.c_int32), ("amplification", C.c_double),
+                ("coWavelength", C.c_double), ("coLow", C.c_double), ("coHigh", C.c_double),
+                ("chromAttenuation", C.c_double), ("framerate", C.c_double),
+                ("preprocess_key", C.c_uint64)]
+
+
+class LvmError(RuntimeError):
+    pass
+
+
+SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process_device", "lvm_synchronize",
+           "lvm_last_error", "lvm_max_levels", "lvm_optimal_buffer_size", "lvm_butterworth2",
+           "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_profile_enable", "lvm_profile_collect",
+           "lvm_profile_entry", "lvm_set_graph", "lvm_algorithmic_bytes"]
+
+
+def bind(lib):
+    """Attach argtypes/restypes of include/lvm_hip.h to a loaded CDLL."""
+    vp = C.c_void_p
+    lib.lvm_create.argtypes = [C.c_int, C.c_int, C.POINTER(vp)]
+    lib.lvm_destroy.argtypes = [vp]
+    lib.lvm_destroy.restype = None
+    lib.lvm_reset.argtypes = [vp]
+    lib.lvm_process.argtypes = [vp, C.POINTER(LvmParams), vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t,
+                                vp, C.c_ssize_t, C.POINTER(C.c_int)]
+    lib.lvm_process_device.argtypes = [vp, C.POINTER(LvmParams), vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t,
+                                       C.c_ssize_t, vp, C.c_ssize_t, C.c_ssize_t, C.POINTER(C.c_int), vp]
+    lib.lvm_synchronize.argtypes = [vp]
+    lib.lvm_last_error.argtypes = [vp]
+    lib.lvm_last_error.restype = C.c_char_p
+    lib.lvm_max_levels.argtypes = [C.c_int, C.c_int]
+    lib.lvm_optimal_buffer_size.argtypes = [C.c_int]
+    lib.lvm_butterworth2.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.lvm_butterworth2.restype = None
+    lib.lvm_debug_keep_float.argtypes = [vp, C.c_int]
+    lib.lvm_debug_read_float.argtypes = [vp, vp, C.c_size_t]
+    lib.lvm_profile_enable.argtypes = [vp, C.c_int]
+    lib.lvm_profile_collect.argtypes = [vp]
+    lib.lvm_profile_entry.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double),
+                                      C.POINTER(C.c_longlong)]
+    lib.lvm_set_graph.argtypes = [vp, C.c_int]
+    lib.lvm_algorithmic_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
+    lib.lvm_algorithmic_bytes.restype = C.c_double
+    return lib
+
+
+_lib = None
+
+
+def load():
+    """Load liblvm_hip.so (the gfx950 build).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LvmError("liblvm_hip.so is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        try:
+            import torch  # noqa: F401  -- share torch's HIP runtime instance when torch is in the process
+        except Exception:
+            pass
+        _lib = bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def to_c_params(p, preprocess_key=0):
+    return LvmParams(int(p.mode), int(p.levels), float(p.amplification), float(p.coWavelength), float(p.coLow),
+                     float(p.coHigh), float(p.chromAttenuation), float(p.framerate), int(preprocess_key))
+
+
+class Context:
+    """Thin RAII wrapper over lvm_ctx."""
+
+    def __init__(self, device=0, n_streams=1, lib=None):
+        self.lib = lib if lib is not None else load()
+        h = C.c_void_p()
+        rc = self.lib.lvm_create(device, n_streams, C.byref(h))
+        if rc != 0:
+            raise LvmError("lvm_create failed (%d): no usable HIP device / out of memory; no CPU fallback" % rc)
+        self.h = h
+        self.n_streams = n_streams
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.lvm_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != 0:
+            raise LvmError("lvm error %d: %s" % (rc, self.lib.lvm_last_error(self.h).decode()))
+
+    def reset(self):
+        self._check(self.lib.lvm_reset(self.h))
+
+    def process(self, frame, cparams):
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        h, w = frame.shape[:2]
+        ch = 1 if frame.ndim == 2 else frame.shape[2]
+        out = np.empty_like(frame)
+        produced = C.c_int(0)
+        self._check(self.lib.lvm_process(self.h, C.byref(cparams), frame.ctypes.data, w, h, ch, w * ch,
+                                         out.ctypes.data, w * ch, C.byref(produced)))
+        return (out, True) if produced.value else (frame, False)
+
+    def process_device(self, cparams, d_in, w, h, ch, in_stride, in_sstride, d_out, out_stride, out_sstride,
+                       stream=0):
+        produced = C.c_int(0)
+        self._check(self.lib.lvm_process_device(self.h, C.byref(cparams), d_in, w, h, ch, in_stride, in_sstride,
+                                                d_out, out_stride, out_sstride, C.byref(produced), stream))
+        return bool(produced.value)
+
+    def synchronize(self):
+        self._check(self.lib.lvm_synchronize(self.h))
+
+    def keep_float(self, on=True):
+        self._check(self.lib.lvm_debug_keep_float(self.h, int(on)))
+
+    def read_float(self, shape):
+        a = np.empty(shape, np.float32)
+        self._check(self.lib.lvm_debug_read_float(self.h, a.ctypes.data, a.size))
+        return a
+
+    def profile(self, on=True):
+        self._check(self.lib.lvm_profile_enable(self.h, int(on)))
+
+    def profile_collect(self):
+        n = self.lib.lvm_profile_collect(self.h)
+        out = {}
+        for i in range(max(n, 0)):
+            name = C.create_string_buffer(64)
+            ms = C.c_double()
+            cnt = C.c_longlong()
+            self.lib.lvm_profile_entry(self.h, i, name, 64, C.byref(ms), C.byref(cnt))
+            out[name.value.decode()] = (ms.value, cnt.value)
+        return out
+
+    def set_graph(self, on):
+        self._check(self.lib.lvm_set_graph(self.h, int(on)))
+
+
+class MagnificationProcessor:
+    """Mirror of the reference stage (MagnificationProcessor.hpp:13-23): process(frame, cfg)
+    returns the magnified frame, or the input frame itself on passthrough; reset() drops all
+    temporal state.  `frame` is an HxWx3 (BGR) or HxW (gray) uint8 array."""
+
+    def __init__(self, device=0, lib=None):
+        self.ctx = Context(device, 1, lib)
+
+    def process(self, frame, cfg):
+        cp = to_c_params(cfg.magnification, cfg.preprocess.key())
+        out, _ = self.ctx.process(frame, cp)
+        return out
+
+    def process_ex(self, frame, cfg):
+        cp = to_c_params(cfg.magnification, cfg.preprocess.key())
+        return self.ctx.process(frame, cp)
+
+    def reset(self):
+        self.ctx.reset()

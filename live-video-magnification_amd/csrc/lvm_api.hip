@@ -1,0 +1,252 @@
+// lvm_api.hip -- C ABI of liblvm_hip.so (see include/lvm_hip.h) and the host-side logic of
+// the reference's MagnificationProcessor (processing/MagnificationProcessor.cpp:10-67):
+// level clamping, structural-change reset (MagnifyCore.hpp:45-80), dispatch by mode and the
+// passthrough rules.  No CPU fallback exists: without a usable HIP device every entry point
+// fails with LVM_ERR_NO_DEVICE.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "lvm_internal.h"
+
+struct lvm_ctx : lvm::Ctx {};
+
+namespace lvm {
+
+void prof_begin(Ctx* c, const char* name, hipStream_t s) {
+    int id = -1;
+    for (size_t i = 0; i < c->prof_totals.size(); ++i)
+        if (c->prof_totals[i].name == name) { id = (int)i; break; }
+    if (id < 0) { ProfTotal t; t.name = name; c->prof_totals.push_back(t); id = (int)c->prof_totals.size() - 1; }
+    ProfEvent e; e.name = id;
+    (void)hipEventCreate(&e.e0); (void)hipEventCreate(&e.e1);
+    (void)hipEventRecord(e.e0, s);
+    c->prof_events.push_back(e);
+}
+void prof_end(Ctx* c, hipStream_t s) { (void)hipEventRecord(c->prof_events.back().e1, s); }
+
+static void drop_state(Ctx* c) { delete c->state; c->state = nullptr; }
+static void tracker_disable(Ctx* c) { c->t_mode = LVM_MODE_NONE; c->t_levels = -1; c->t_channels = -1; c->t_w = c->t_h = 0; }
+
+static int ensure_float(Ctx* c, size_t count) {
+    if (count > c->float_cap) {
+        if (c->d_float) (void)hipFree(c->d_float);
+        c->d_float = nullptr; c->float_cap = 0;
+        LVM_HIP_TRY(c, hipMalloc((void**)&c->d_float, count * sizeof(float)));
+        c->float_cap = count;
+    }
+    c->float_count = count;
+    return LVM_OK;
+}
+
+// MagnificationProcessor::process (MagnificationProcessor.cpp:17-67) on device buffers
+static int process_device(Ctx* c, const lvm_params* p, const FrameIO& io, hipStream_t s, int* produced) {
+    *produced = 0;
+    if (p->mode == LVM_MODE_NONE || io.d_in == nullptr || io.w <= 0 || io.h <= 0) {      // :21-29
+        if (c->t_mode != LVM_MODE_NONE) { drop_state(c); tracker_disable(c); }
+        return LVM_OK;
+    }
+    if (p->mode < 0 || p->mode > LVM_MODE_NONE) { c->err = "invalid mode"; return LVM_ERR_INVALID; }
+    if (io.channels != 1 && io.channels != 3) { c->err = "channels must be 1 or 3"; return LVM_ERR_INVALID; }
+    if (io.d_out == nullptr) { c->err = "null output"; return LVM_ERR_INVALID; }
+    const int maxLevels = max_levels(io.w, io.h);                                       // :32-33
+    if (maxLevels < 1) return LVM_OK;
+    int levels = p->levels < 1 ? 1 : (p->levels > maxLevels ? maxLevels : p->levels);   // :34
+    if (levels > kMaxLevels) levels = kMaxLevels;
+    const bool change = p->mode != c->t_mode || levels != c->t_levels || io.w != c->t_w || io.h != c->t_h ||
+                        io.channels != c->t_channels || p->preprocess_key != c->t_pre;  // MagnifyCore.hpp:53-65
+    if (change) {
+        // buffers of the old geometry may still be in use by queued kernels
+        LVM_HIP_TRY(c, hipStreamSynchronize(s));
+        c->t_mode = p->mode; c->t_levels = levels; c->t_w = io.w; c->t_h = io.h;
+        c->t_channels = io.channels; c->t_pre = p->preprocess_key;
+        drop_state(c);                                                                  // :39-43
+    }
+    if (c->keep_float) {
+        const int rc = ensure_float(c, (size_t)io.w * io.h * io.channels);
+        if (rc != LVM_OK) return rc;
+    }
+    switch (p->mode) {                                                                  // :48-60
+    case LVM_MODE_LAPLACE: return laplace_process(c, *p, levels, io, s, produced);
+    case LVM_MODE_PHASE:   return riesz_process(c, *p, levels, io, s, produced);
+    case LVM_MODE_COLOR:   return color_process(c, *p, levels, io, s, produced);
+    default: break;
+    }
+    return LVM_OK;
+}
+
+}  // namespace lvm
+
+using lvm::Ctx;
+
+extern "C" {
+
+int lvm_create(int device, int n_streams, lvm_ctx** out) {
+    if (!out || n_streams < 1) return LVM_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return LVM_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return LVM_ERR_NO_DEVICE;
+    lvm_ctx* c = new (std::nothrow) lvm_ctx();
+    if (!c) return LVM_ERR_OOM;
+    c->device = device;
+    c->nstreams = n_streams;
+    float g[256], ig[4096];
+    lvm::build_lab_tables(g, ig, c->lab.fwd, c->lab.inv);
+    bool ok = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_gamma_u8, sizeof(g)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_invgamma, sizeof(ig)) == hipSuccess;
+    ok = ok && hipMemcpy(c->d_gamma_u8, g, sizeof(g), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(c->d_invgamma, ig, sizeof(ig), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { lvm_destroy(c); return LVM_ERR_HIP; }
+    c->lab.gamma_u8 = c->d_gamma_u8;
+    c->lab.invgamma = c->d_invgamma;
+    c->lab.a255 = (float)(1.0 / 255.0f);
+    *out = c;
+    return LVM_OK;
+}
+
+void lvm_destroy(lvm_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    (void)hipDeviceSynchronize();
+    delete c->state; c->state = nullptr;
+    for (auto& e : c->prof_events) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
+    if (c->d_gamma_u8) (void)hipFree(c->d_gamma_u8);
+    if (c->d_invgamma) (void)hipFree(c->d_invgamma);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_float) (void)hipFree(c->d_float);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int lvm_reset(lvm_ctx* c) {                       // MagnificationProcessor.cpp:10-15
+    if (!c) return LVM_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    (void)hipGetLastError();
+    lvm::drop_state(c);
+    lvm::tracker_disable(c);
+    c->t_pre = 0;
+    c->err.clear();
+    return LVM_OK;
+}
+
+int lvm_process_device(lvm_ctx* c, const lvm_params* p, const uint8_t* d_in, int w, int h, int channels,
+                       ptrdiff_t in_stride, ptrdiff_t in_stream_stride, uint8_t* d_out, ptrdiff_t out_stride,
+                       ptrdiff_t out_stream_stride, int* produced, void* hip_stream) {
+    if (!c || !p || !produced) return LVM_ERR_INVALID;
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    lvm::FrameIO io{d_in, in_stride, in_stream_stride, d_out, out_stride, out_stream_stride, w, h, channels};
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return lvm::process_device(c, p, io, s, produced);
+}
+
+int lvm_process(lvm_ctx* c, const lvm_params* p, const uint8_t* in, int w, int h, int channels, ptrdiff_t in_stride,
+                uint8_t* out, ptrdiff_t out_stride, int* produced) {
+    if (!c || !p || !produced) return LVM_ERR_INVALID;
+    *produced = 0;
+    if (c->nstreams != 1) { c->err = "lvm_process needs a 1-stream context"; return LVM_ERR_INVALID; }
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    if (p->mode == LVM_MODE_NONE || !in || w <= 0 || h <= 0) {
+        lvm::FrameIO io{nullptr, 0, 0, nullptr, 0, 0, w, h, channels};
+        return lvm::process_device(c, p, io, c->own_stream, produced);
+    }
+    if (!out || (channels != 1 && channels != 3) || in_stride < (ptrdiff_t)w * channels ||
+        out_stride < (ptrdiff_t)w * channels) { c->err = "bad frame arguments"; return LVM_ERR_INVALID; }
+    const size_t row = (size_t)w * channels, bytes = row * h;
+    if (bytes > c->stage_cap) {
+        if (c->d_in) (void)hipFree(c->d_in);
+        if (c->d_out) (void)hipFree(c->d_out);
+        c->d_in = c->d_out = nullptr; c->stage_cap = 0;
+        LVM_HIP_TRY(c, hipMalloc((void**)&c->d_in, bytes));
+        LVM_HIP_TRY(c, hipMalloc((void**)&c->d_out, bytes));
+        c->stage_cap = bytes;
+    }
+    hipStream_t s = c->own_stream;
+    LVM_HIP_TRY(c, hipMemcpy2DAsync(c->d_in, row, in, (size_t)in_stride, row, (size_t)h, hipMemcpyHostToDevice, s));
+    lvm::FrameIO io{c->d_in, (ptrdiff_t)row, (ptrdiff_t)bytes, c->d_out, (ptrdiff_t)row, (ptrdiff_t)bytes, w, h, channels};
+    const int rc = lvm::process_device(c, p, io, s, produced);
+    if (rc != LVM_OK) { (void)hipStreamSynchronize(s); return rc; }
+    if (*produced)
+        LVM_HIP_TRY(c, hipMemcpy2DAsync(out, (size_t)out_stride, c->d_out, row, row, (size_t)h, hipMemcpyDeviceToHost, s));
+    LVM_HIP_TRY(c, hipStreamSynchronize(s));
+    return LVM_OK;
+}
+
+int lvm_synchronize(lvm_ctx* c) {
+    if (!c) return LVM_ERR_INVALID;
+    LVM_HIP_TRY(c, hipStreamSynchronize(c->own_stream));
+    return LVM_OK;
+}
+
+const char* lvm_last_error(lvm_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int lvm_debug_keep_float(lvm_ctx* c, int on) { if (!c) return LVM_ERR_INVALID; c->keep_float = on != 0; return LVM_OK; }
+
+int lvm_debug_read_float(lvm_ctx* c, float* dst, size_t count) {
+    if (!c || !dst) return LVM_ERR_INVALID;
+    if (!c->d_float || count > c->float_count) { c->err = "no float frame kept"; return LVM_ERR_INVALID; }
+    LVM_HIP_TRY(c, hipDeviceSynchronize());
+    LVM_HIP_TRY(c, hipMemcpy(dst, c->d_float, count * sizeof(float), hipMemcpyDeviceToHost));
+    return LVM_OK;
+}
+
+int lvm_profile_enable(lvm_ctx* c, int on) {
+    if (!c) return LVM_ERR_INVALID;
+    c->profiling = on != 0;
+    return LVM_OK;
+}
+
+int lvm_profile_collect(lvm_ctx* c) {
+    if (!c) return LVM_ERR_INVALID;
+    LVM_HIP_TRY(c, hipDeviceSynchronize());
+    for (auto& e : c->prof_events) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) { c->prof_totals[e.name].ms += ms; c->prof_totals[e.name].n += 1; }
+        (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1);
+    }
+    c->prof_events.clear();
+    return (int)c->prof_totals.size();
+}
+
+int lvm_profile_entry(lvm_ctx* c, int idx, char* name, size_t cap, double* total_ms, long long* launches) {
+    if (!c || idx < 0 || idx >= (int)c->prof_totals.size()) return LVM_ERR_INVALID;
+    const auto& t = c->prof_totals[idx];
+    if (name && cap) { std::snprintf(name, cap, "%s", t.name.c_str()); }
+    if (total_ms) *total_ms = t.ms;
+    if (launches) *launches = t.n;
+    return LVM_OK;
+}
+
+int lvm_set_graph(lvm_ctx* c, int on) { if (!c) return LVM_ERR_INVALID; c->use_graph = on != 0; return LVM_OK; }
+
+// compulsory traffic only -- every input byte read once, every output byte
+// written once, every live persistent state word read once and written once.
+double lvm_algorithmic_bytes(int mode, int w, int h, int channels, int levels, double framerate) {
+    const int maxL = lvm::max_levels(w, h);
+    if (maxL < 1) return 0.0;
+    int L = levels < 1 ? 1 : (levels > maxL ? maxL : levels);
+    double n[lvm::kMaxLevels + 2];
+    int lw = w, lh = h;
+    for (int l = 0; l <= L && l <= lvm::kMaxLevels; ++l) { n[l] = (double)lw * lh; lw = (lw + 1) / 2; lh = (lh + 1) / 2; }
+    const double io = 2.0 * channels * n[0];
+    if (mode == LVM_MODE_LAPLACE) {
+        double s = 0; for (int l = 1; l <= L - 1; ++l) s += n[l];
+        return io + 16.0 * channels * s;             // 2 low-pass states x 4 B x (R + W) per channel
+    }
+    if (mode == LVM_MODE_PHASE) {
+        double s = 0; for (int l = 0; l <= L - 2; ++l) s += n[l];
+        return io + 88.0 * s;                        // 11 live floats per band pixel, R + W
+    }
+    if (mode == LVM_MODE_COLOR) {
+        const int T = lvm::optimal_buffer_size((int)framerate);
+        return io + 4.0 * channels * n[L] * T + 4.0 * channels * n[L];
+    }
+    return 0.0;
+}
+
+}  // extern "C"

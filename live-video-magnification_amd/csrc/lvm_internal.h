@@ -1,0 +1,199 @@
+// lvm_internal.h -- shared host/device declarations of liblvm_hip.so (gfx950 only).
+//
+// Arithmetic contract (DESIGN.md "Numerics"): float32 storage, every reference Mat-level
+// operation rounded on its own, FMA only where the reference's OpenCV inner loops use one
+// (filter taps).  The translation units are built with -ffp-contract=off and spell every
+// fused multiply-add as __builtin_fmaf, so results do not depend on compiler contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "lvm_hip.h"
+
+namespace lvm {
+
+constexpr int kMaxLevels = 24;
+
+// ---------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------
+// OpenCV borderInterpolate(p, len, BORDER_REFLECT_101)
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * len - 2 - p;
+    return p;
+}
+// convertTo(CV_8U): saturate_cast<uchar>(cvRound(v)), cvRound = round-half-even
+__device__ __forceinline__ uint8_t sat_u8(float v) {
+    if (!(v == v)) return 0;
+    float r = rintf(v);
+    r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
+    return (uint8_t)r;
+}
+
+// Lab conversion tables/coefficients (reference: MagnifyCore.hpp:90,152,219,275 call
+// cv::cvtColor COLOR_BGR2Lab / COLOR_Lab2BGR on float [0,1]; OpenCV 4 color_lab.cpp float path).
+struct LabCoef {
+    float fwd[9];             // BGR(linear) -> XYZ/white, row-major, column 0 multiplies B
+    float inv[9];             // XYZ -> BGR(linear), row 0 produces B
+    const float* gamma_u8;    // [256]  sRGB gamma of u8/255 (device)
+    const float* invgamma;    // [1024*4] cubic-spline coefficients of the inverse gamma (device)
+    float a255;               // float(1.0/255.0f)
+};
+
+// cv::cubeRoot (core/mathfuncs.cpp): exponent split + quartic rational polynomial in float64
+__device__ __forceinline__ float cv_cube_root(float value) {
+    int vi = __float_as_int(value);
+    int ix = vi & 0x7fffffff;
+    unsigned s = (unsigned)vi & 0x80000000u;
+    int ex = (ix >> 23) - 127;
+    int shx = ex % 3;
+    shx -= shx >= 0 ? 3 : 0;
+    ex = (ex - shx) / 3;
+    double fr = (double)__int_as_float((ix & ((1 << 23) - 1)) | ((shx + 127) << 23));
+    fr = (((((45.2548339756803022511987494 * fr + 192.2798368355061050458134625) * fr +
+             119.1654824285581628956914143) * fr + 13.43250139086239872172837314) * fr +
+           0.1636161226585754240958355063) /
+          ((((14.80884093219134573786480845 * fr + 151.9714051044435648658557668) * fr +
+             168.5254414101568283957668343) * fr + 33.9905941350215598754191872) * fr + 1.0));
+    unsigned r = (unsigned)__float_as_int((float)fr);
+    r = (r + ((unsigned)ex << 23) + s) & ((((unsigned)vi * 2u) != 0u) ? 0xffffffffu : 0u);
+    return __int_as_float((int)r);
+}
+
+// RGB2Lab_f scalar path on gamma-expanded B,G,R
+__device__ __forceinline__ void lin_bgr_to_lab(float B, float G, float R, const float* fw, float& L,
+                                               float& a, float& b) {
+    const float _a = 16.0f / 116.0f;
+    const float X = B * fw[0] + G * fw[1] + R * fw[2];
+    const float Y = B * fw[3] + G * fw[4] + R * fw[5];
+    const float Z = B * fw[6] + G * fw[7] + R * fw[8];
+    const float FX = X > 0.008856f ? cv_cube_root(X) : (7.787f * X + _a);
+    const float FY = Y > 0.008856f ? cv_cube_root(Y) : (7.787f * Y + _a);
+    const float FZ = Z > 0.008856f ? cv_cube_root(Z) : (7.787f * Z + _a);
+    L = Y > 0.008856f ? (116.f * FY - 16.f) : (903.3f * Y);
+    a = 500.f * (FX - FY);
+    b = 200.f * (FY - FZ);
+}
+// splineInterpolate (color_lab.cpp), 1024 knots
+__device__ __forceinline__ float spline1024(float x, const float* tab) {
+    int ix = (int)x;
+    ix = ix < 0 ? 0 : (ix > 1023 ? 1023 : ix);
+    x -= (float)ix;
+    const float* t = tab + ix * 4;
+    return ((t[3] * x + t[2]) * x + t[1]) * x + t[0];
+}
+__device__ __forceinline__ float clip01(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+// Lab2RGBfloat::process + inverse gamma; igt = inverse-gamma spline table (LDS or global)
+__device__ __forceinline__ void lab_to_bgr(float li, float ai, float bi, const float* iv,
+                                           const float* igt, float& o0, float& o1, float& o2) {
+    const float lThresh = 0.008856f * 903.3f;
+    const float fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
+    float y, fy;
+    if (li <= lThresh) { y = li / 903.3f; fy = 7.787f * y + 16.0f / 116.0f; }
+    else { fy = (li + 16.0f) / 116.0f; y = fy * fy * fy; }
+    float fx = ai / 500.0f + fy, fz = fy - bi / 200.0f;
+    fx = (fx <= fThresh) ? (fx - 16.0f / 116.0f) / 7.787f : fx * fx * fx;
+    fz = (fz <= fThresh) ? (fz - 16.0f / 116.0f) / 7.787f : fz * fz * fz;
+    const float c0 = iv[0] * fx + iv[1] * y + iv[2] * fz;
+    const float c1 = iv[3] * fx + iv[4] * y + iv[5] * fz;
+    const float c2 = iv[6] * fx + iv[7] * y + iv[8] * fz;
+    o0 = spline1024(clip01(c0) * 1024.f, igt);
+    o1 = spline1024(clip01(c1) * 1024.f, igt);
+    o2 = spline1024(clip01(c2) * 1024.f, igt);
+}
+
+// pyrUp horizontal pass for destination column gx from source row `s` whose element for
+// source column i sits at s[i - sx0] (OpenCV pyrUp_ border rules, see laplace.hip).
+__device__ __forceinline__ float pyrup_h(const float* s, int gx, int sx0, int sw) {
+    const int i = gx >> 1, li = i - sx0;
+    if ((gx & 1) == 0) {
+        if (i == 0) return s[li] * 6.f + s[li + 1] * 2.f;
+        if (i == sw - 1) return s[li - 1] + s[li] * 7.f;
+        return s[li - 1] + s[li] * 6.f + s[li + 1];
+    }
+    if (i == sw - 1) return s[li] * 8.f;
+    return (s[li] + s[li + 1]) * 4.f;
+}
+
+// ---------------------------------------------------------------------------------------
+// host-side context
+// ---------------------------------------------------------------------------------------
+struct ProfEvent { int name; hipEvent_t e0, e1; };
+struct ProfTotal { std::string name; double ms = 0; long long n = 0; };
+
+struct LevelGeom { int w, h; size_t n; };   // n = w*h
+
+struct Ctx;
+struct ModeState { virtual ~ModeState() {} };
+
+struct Ctx {
+    int device = 0;
+    int nstreams = 1;
+    hipStream_t own_stream = nullptr;
+    std::string err;
+    // StructuralTracker (reference: MagnifyCore.hpp:45-80)
+    int t_mode = LVM_MODE_NONE, t_levels = -1, t_channels = -1, t_w = 0, t_h = 0;
+    uint64_t t_pre = 0;
+    // constant tables
+    float* d_gamma_u8 = nullptr;
+    float* d_invgamma = nullptr;
+    LabCoef lab{};
+    // per-mode state (allocated for the tracked geometry)
+    ModeState* state = nullptr;
+    // host-path staging
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    size_t stage_cap = 0;
+    // instrumentation
+    bool keep_float = false;
+    float* d_float = nullptr; size_t float_cap = 0; size_t float_count = 0;
+    bool profiling = false;
+    std::vector<ProfEvent> prof_events;
+    std::vector<ProfTotal> prof_totals;
+    bool use_graph = true;
+};
+
+void prof_begin(Ctx* c, const char* name, hipStream_t s);
+void prof_end(Ctx* c, hipStream_t s);
+
+#define LVM_HIP_TRY(c, expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            (c)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                 \
+            return LVM_ERR_HIP;                                                           \
+        }                                                                                 \
+    } while (0)
+
+// Launch with optional event bracketing.  `nm` is the kernel's report name; template kernels
+// with several arguments are passed through a function-pointer variable.
+#define LVM_LAUNCH(c, nm, kern, grid, block, stream, ...)                                 \
+    do {                                                                                  \
+        if ((c)->profiling) lvm::prof_begin((c), nm, (stream));                           \
+        hipLaunchKernelGGL(kern, grid, block, 0, (stream), __VA_ARGS__);                  \
+        if ((c)->profiling) lvm::prof_end((c), (stream));                                 \
+    } while (0)
+
+struct FrameIO {
+    const uint8_t* d_in; ptrdiff_t in_stride, in_sstride;
+    uint8_t* d_out; ptrdiff_t out_stride, out_sstride;
+    int w, h, channels;
+};
+
+// mode entry points (laplace.hip / riesz.hip / color.hip).  Return LVM_OK or an error;
+// *produced follows the reference's passthrough rules.
+int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced);
+int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced);
+int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced);
+
+// host tables (lab_tables.cpp)
+void build_lab_tables(float gamma_u8[256], float invgamma[4096], float fwd[9], float inv[9]);
+void butterworth2(double Wn, double a[3], double b[3]);
+int max_levels(int w, int h);
+int optimal_buffer_size(int fps);
+
+}  // namespace lvm

@@ -597,7 +597,11 @@ void lvmo_ideal_filter(const float* win, int rows, int cols, int cn, double lo, 
         need[0] = mask[0] != 0.f;
         int j1 = n - 1;
         if (n % 2 == 0) { need[n - 1] = mask[n - 1] != 0.f; j1 = n - 2; }
-        for (int j = 1; j + 1 <= j1; j += 2) need[j] = need[j + 1] = (mask[j] != 0.f || mask[j + 1] != 0.f);
+        for (int j = 1; j + 1 <= j1; j += 2) {
+            const char v = (char)((mask[j] != 0.f) | (mask[j + 1] != 0.f));
+            need[j] = v;
+            need[j + 1] = v;
+        }
     }
 #pragma omp parallel
     {

@@ -1,0 +1,42 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def lvm():
+    import importlib
+    return importlib.import_module("live-video-magnification_amd")
+
+
+@pytest.fixture(scope="session")
+def po():
+    from oracle import pyoracle
+    pyoracle.lib()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def emu(lvm):
+    """The product sources compiled against the HIP emulation header (tests/emu): kernel-logic
+    checks on CPU.  Test infrastructure only."""
+    import ctypes
+    import subprocess
+    here = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call([os.path.join(here, "build_emu.sh")])
+    return lvm.bind(ctypes.CDLL(os.path.join(here, "_build", "liblvm_emu.so")))
+
+
+@pytest.fixture(scope="session")
+def hip(lvm):
+    """The gfx950 library through the C ABI; fails loudly when missing."""
+    return lvm.load()

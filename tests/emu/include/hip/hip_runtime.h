@@ -1,0 +1,83 @@
+// TEST INFRASTRUCTURE ONLY -- a tiny fiber-based emulation of the HIP subset used by
+// live-video-magnification_amd/csrc, so the *kernel logic* (tiling, border rules, operation
+// order) can be exercised by the CPU test-suite (`-m "not gpu"`) in a container without a GPU.
+// The build lives in tests/emu/_build/ and is only ever loaded by tests/; the product library
+// (liblvm_hip.so) is always the hipcc/gfx950 build and has no CPU path.
+// One workgroup runs at a time; its work-items are ucontext fibers and __syncthreads() yields
+// to a round-robin scheduler.  Device allocations are filled with 0xFF (NaN floats) so reads of
+// uninitialised memory surface in the parity checks.
+#pragma once
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+typedef struct ihipStream_t* hipStream_t;
+typedef struct ihipEvent_t* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipStreamNonBlocking = 1 };
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static thread_local
+#define __launch_bounds__(...)
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+
+namespace hipemu {
+struct State { dim3 tid, bid, bdim, gdim; };
+extern thread_local State st;
+void sync();
+void launch(const std::function<void()>& body, dim3 grid, dim3 block);
+float shfl(float v, int src_lane);
+}  // namespace hipemu
+#define threadIdx (hipemu::st.tid)
+#define blockIdx (hipemu::st.bid)
+#define blockDim (hipemu::st.bdim)
+#define gridDim (hipemu::st.gdim)
+static inline void __syncthreads() { hipemu::sync(); }
+
+template <class K, class... A>
+static inline void hipLaunchKernelGGL(K kern, dim3 grid, dim3 block, size_t, hipStream_t, A... args) {
+    hipemu::launch([=]() { kern(args...); }, grid, block);
+}
+
+static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned i; std::memcpy(&i, &f, 4); return i; }
+static inline float __uint_as_float(unsigned i) { float f; std::memcpy(&f, &i, 4); return f; }
+
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "hip-emu error"; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); if (!*p) return hipErrorOutOfMemory; std::memset(*p, 0xFF, n); return hipSuccess; }
+static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+static inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { std::memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { std::memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t wbytes, size_t h, hipMemcpyKind, hipStream_t = nullptr) {
+    for (size_t y = 0; y < h; ++y) std::memcpy((char*)d + y * dp, (const char*)s + y * sp, wbytes);
+    return hipSuccess;
+}
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)(uintptr_t)1; return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t)(uintptr_t)1; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }

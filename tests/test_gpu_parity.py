@@ -1,0 +1,109 @@
+"""Parity tests proper: the gfx950 library (liblvm_hip.so) through the C ABI vs the CPU oracle
+on the same seeded synthetic clips.  Tolerances (BASELINE.json north_star):
+float frame max|d|/max|ref| <= 1e-4, u8 frame <= 1 LSB with >= 99.9 % identical pixels,
+produced flags identical frame by frame."""
+import numpy as np
+import pytest
+
+from helpers import c_params, run_pair
+
+pytestmark = pytest.mark.gpu
+
+FLOAT_TOL = 1e-4
+
+
+@pytest.mark.parametrize("w,h,levels,ch", [(640, 360, 4, 3), (135, 77, 4, 3), (100, 64, 2, 1), (64, 48, 1, 3),
+                                            (323, 211, 5, 3)])
+def test_laplace_small(lvm, po, hip, w, h, levels, ch):
+    ck, pk = lvm.synth.config(0, (w, h, levels))
+    ck["channels"] = ch
+    clip = lvm.synth.Clip(**ck)
+    worst = run_pair(lvm, po, hip, clip, pk, 24 if w >= 640 else 10, FLOAT_TOL)
+    print("laplace", (w, h, levels, ch), "worst rel/u8/frac", worst)
+
+
+def test_laplace_cfg0_64_frames(lvm, po, hip):
+    """BASELINE.json configs[0]: 640x360, 4 levels, IIR 0.4-3 Hz (state drift included)."""
+    ck, pk = lvm.synth.config(0)
+    worst = run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 64, FLOAT_TOL)
+    print("cfg0 worst", worst)
+
+
+def test_laplace_1080p_full_size(lvm, po, hip):
+    """BASELINE.json configs[1] at full size: direct parity on a few frames plus size-independent
+    properties (first frame = Lab round trip, static clip => no motion, reset => replay)."""
+    ck, pk = lvm.synth.config(1)
+    clip = lvm.synth.Clip(**ck)
+    worst = run_pair(lvm, po, hip, clip, pk, 5, FLOAT_TOL)
+    print("1080p worst", worst)
+    ctx = lvm.Context(0, 1, hip)
+    cp = c_params(lvm, pk)
+    f0 = clip.frame(0)
+    out0, prod = ctx.process(f0, cp)
+    assert prod and np.abs(out0.astype(int) - f0.astype(int)).max() <= 1
+    outs = [ctx.process(clip.frame(t), cp)[0].copy() for t in range(1, 4)]
+    ctx.reset()
+    ctx.process(f0, cp)
+    again = [ctx.process(clip.frame(t), cp)[0].copy() for t in range(1, 4)]
+    for a, b in zip(outs, again):
+        assert np.array_equal(a, b)
+    static = lvm.synth.Clip(**dict(ck, amp_px=0.0))
+    ctx.reset()
+    for t in range(4):
+        f = static.frame(t)
+        out, _ = ctx.process(f, cp)
+        assert np.abs(out.astype(int) - f.astype(int)).max() <= 1
+    ctx.close()
+
+
+def test_laplace_param_change_and_reset(lvm, po, hip):
+    ck, pk = lvm.synth.config(0, (320, 180, 4))
+
+    def vary(t, p):
+        if t >= 4:
+            p["amplification"] = 35.0; p["coLow"] = 0.0
+        if t >= 8:
+            p["levels"] = 2
+        return p
+    run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 12, FLOAT_TOL, param_fn=vary)
+
+
+def test_laplace_batched_streams_device_path(lvm, po, hip):
+    """n_streams = 3 through lvm_process_device on device memory (torch tensors)."""
+    import torch
+    ck, pk = lvm.synth.config(0, (320, 180, 4))
+    clips = [lvm.synth.Clip(seed=1234 + s, **ck) for s in range(3)]
+    h, w = 180, 320
+    ctx = lvm.Context(0, 3, hip)
+    orcs = [po.Oracle() for _ in range(3)]
+    P = po.make_params(**pk)
+    cp = c_params(lvm, pk)
+    stream = torch.cuda.current_stream().cuda_stream
+    for t in range(8):
+        fin = np.stack([c.frame(t) for c in clips])
+        d_in = torch.from_numpy(fin).cuda()
+        d_out = torch.zeros_like(d_in)
+        assert ctx.process_device(cp, d_in.data_ptr(), w, h, 3, w * 3, w * h * 3, d_out.data_ptr(), w * 3, w * h * 3, stream)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        for s in range(3):
+            ref, _ = orcs[s].process(fin[s], P)
+            du = np.abs(ref.astype(int) - got[s].astype(int))
+            assert du.max() <= 1 and (du == 0).mean() >= 0.999
+    ctx.close()
+
+
+def test_passthrough_and_errors(lvm, po, hip):
+    ctx = lvm.Context(0, 1, hip)
+    f = np.full((40, 40, 3), 90, np.uint8)
+    out, produced = ctx.process(f, lvm.LvmParams(3, 4, 0, 0, 0, 0, 0, 30.0, 0))
+    assert not produced
+    tiny = np.full((5, 40, 3), 90, np.uint8)
+    _, produced = ctx.process(tiny, lvm.LvmParams(0, 4, 10, 100, 0.1, 0.4, 0, 30.0, 0))
+    assert not produced
+    with pytest.raises(lvm.LvmError):
+        ctx.process(np.zeros((32, 32, 2), np.uint8), lvm.LvmParams(0, 2, 10, 100, 0.1, 0.4, 0, 30.0, 0))
+    ctx.reset()                                    # the context keeps working after an error
+    _, produced = ctx.process(np.full((64, 64, 3), 7, np.uint8), lvm.LvmParams(0, 2, 10, 100, 0.1, 0.4, 0, 30.0, 0))
+    assert produced
+    ctx.close()
