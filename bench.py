@@ -172,7 +172,7 @@ def main():
         from oracle import pyoracle as po
         o = po.Oracle()
         P = po.make_params(**pk)
-        nthreads = os.cpu_count() or 1
+        nthreads = max(1, min(16, os.cpu_count() or 1))   # beyond ~16 threads fork/join over small levels dominates
         po.lib().lvmo_set_threads(nthreads)
         frames = [host[t % ring, 0] for t in range(4)]
         for f in frames[:2]:

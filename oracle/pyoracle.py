@@ -73,6 +73,8 @@ def lib():
         L.lvmo_cube_root.restype = C.c_float
         L.lvmo_gamma_tab.argtypes = [C.c_int]
         L.lvmo_gamma_tab.restype = C.POINTER(C.c_float)
+        # a few threads only: on many-core hosts OpenMP fork/join over tiny pyramid levels dominates
+        L.lvmo_set_threads(max(1, min(8, os.cpu_count() or 1)))
         _lib = L
     return _lib
 
