@@ -37,20 +37,47 @@ def level_sizes(w, h, levels):
 
 
 def kernel_alg_bytes(mode, name, w, h, ch, levels, streams, T=0):
-    """Compulsory bytes one launch of kernel `name` moves (inputs read once + outputs written
-    once), for the kernel decomposition described in DESIGN.md.  None when not tabulated."""
+    """Compulsory bytes one launch of kernel `name` moves (every input read once + every output
+    written once) for the kernel decomposition of DESIGN.md; kernels launched once per level are
+    averaged over their launches (rocprofv3 reports them under one symbol).  None = not tabulated."""
     n = [a * b for a, b in level_sizes(w, h, levels)]
+    S = streams
     P = ch * streams
+    avg = lambda xs: (sum(xs) / len(xs)) if xs else None  # noqa: E731
     if mode == "laplace":
-        if name == "lap_down0":
-            return streams * ch * n[0] + 4 * P * n[1]
-        if name == "lap_final":
-            return 2 * streams * ch * n[0] + 4 * P * n[1]
-        if name == "pyr_down":   # averaged over the L-1 launches
-            return sum(4 * P * (n[l] + n[l + 1]) for l in range(1, levels)) / max(levels - 1, 1)
-        if name in ("lap_up", "lap_seed"):
+        return {
+            "lap_down0": S * ch * n[0] + 4 * P * n[1],
+            "lap_final": 2 * S * ch * n[0] + 4 * P * n[1],
+            "pyr_down": avg([4 * P * (n[l] + n[l + 1]) for l in range(1, levels)]),
             # G_l + G_{l+1} + cur_{l+1} read, hi/lo read+written, cur_l written
-            return sum(4 * P * (n[l] * 6 + 2 * n[l + 1]) for l in range(1, levels)) / max(levels - 1, 1)
+            "lap_up": avg([4 * P * (n[l] * 6 + 2 * n[l + 1]) for l in range(1, levels)]),
+            "lap_seed": avg([4 * P * (n[l] * 3 + n[l + 1]) for l in range(1, levels)]),
+        }.get(name)
+    if mode == "riesz":
+        nb = levels - 1
+        return {
+            "rz_lab": S * (3 * n[0] + 4 * n[0]),
+            "rz_split": avg([4 * S * (2 * n[l] + n[l + 1]) for l in range(nb)]),
+            # band 4 + prior(3) R/W 24 + phase(2) R/W 16 + registers(8) R/W 64 + amp,tc,ts 12
+            "rz_phase": avg([120 * S * n[l] for l in range(nb)]),
+            "rz_seed": avg([(4 + 13 * 4) * S * n[l] for l in range(nb)]),
+            "rz_blur_amp": avg([28 * S * n[l] for l in range(nb)]),
+            "rz_collapse": avg([4 * S * (2 * n[l] + n[l + 1]) for l in range(1, nb)]),
+            "rz_final": S * (6 * n[0] + 4 * n[0] + 4 * n[1]),
+        }.get(name)
+    if mode == "color":
+        nL = n[levels]
+        nV = nL * 4 ** (levels - 1)
+        return {
+            "col_down0": S * ch * n[0] + 4 * P * n[1],
+            "pyr_down": avg([4 * P * (n[l] + n[l + 1]) for l in range(1, levels)]),
+            "col_append": 8 * ch * nL,
+            "col_dft": 4 * P * nL * (T + 1),
+            "col_norm": 8 * ch * nL,
+            "pyr_up": avg([4 * P * nL * (4 ** k + 4 ** (k + 1)) for k in range(levels - 1)]),
+            "col_minmax": S * ch * n[0] + 4 * P * nV,
+            "col_out": 2 * S * ch * n[0] + 4 * P * nV,
+        }.get(name)
     return None
 
 

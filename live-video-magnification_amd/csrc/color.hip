@@ -1,4 +1,422 @@
-#include "lvm_internal.h"
+// color.hip -- Gaussian-pyramid + ideal temporal band-pass colour magnification on gfx950.
+//
+// Replaces magcore::magnifyColor (reference: processing/magnification/MagnifyCore.hpp:163-206)
+// with buildGaussPyrFromImg / buildImgFromGaussPyr / img2tempMat / tempMat2img
+// (SpatialFilter.cpp:13-23, 40-50, 63-89) and idealFilter / createIdealBandpassFilter
+// (TemporalFilter.cpp:24-80).
+//
+// HBM layout per context: G_l[plane][h_l][w_l] (l = 1..L, unscaled [0,255] floats), the rolling
+// window win[slot][row] with row = plane * n_L + pixel (one "slot" per frame, ring buffer of
+// capacity >= getOptimalBufferSize(fps); lanes = rows, so every time step is one coalesced
+// load), the packed filtered spectrum Y[element][row], the up-chain images up_k[plane] of size
+// (w_L 2^k) x (h_L 2^k), two min/max pairs per stream and the bilinear resize tables.
+//
+// Launch sequence per frame:
+//   k_down0 + k_pyr_down x (L-1)   u8 -> float -> Gaussian pyramid (shared with laplace.hip)
+//   k_col_append                   smallest level -> window slot; resets the min/max cells
+//   k_col_dft                      per row: packed real DFT of the needed elements (float64 sums),
+//                                  0/1 mask applied as a packed complex spectrum (mulSpectrums),
+//                                  inverse transform of all T samples -> global min/max, keep column 1
+//   k_col_norm                     min-max normalise column 1, x alpha -> up_0
+//   k_pyr_up x (L-1)               up_k -> up_{k+1}
+//   k_col_out<false>               last pyrUp + bilinear resize + input add -> global min/max
+//   k_col_out<true>                same values again -> u8 with the min/max rescale
+#include <cmath>
+
+#include <vector>
+
+#include "pyramid.h"
+
 namespace lvm {
-int color_process(Ctx* c, const lvm_params&, int, const FrameIO&, hipStream_t, int* produced) { *produced = 0; c->err = "color: not built yet"; return LVM_ERR_INVALID; }
+
+// monotonic float <-> int key so that integer atomicMin/Max order floats
+__device__ __forceinline__ int fkey(float f) { const int b = __float_as_int(f); return b >= 0 ? b : b ^ 0x7fffffff; }
+__device__ __forceinline__ float fkey_inv(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff); }
+
+struct MinMax { int mn1, mx1, mn2, mx2; };   // per stream: ideal-filter range, output range
+
+__device__ __forceinline__ void block_minmax(float mn, float mx, int* gmn, int* gmx) {
+    __shared__ float s_mn[256], s_mx[256];
+    const int t = threadIdx.x;
+    s_mn[t] = mn; s_mx[t] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) {
+            s_mn[t] = s_mn[t + s] < s_mn[t] ? s_mn[t + s] : s_mn[t];
+            s_mx[t] = s_mx[t + s] > s_mx[t] ? s_mx[t + s] : s_mx[t];
+        }
+        __syncthreads();
+    }
+    if (t == 0) { atomicMin(gmn, fkey(s_mn[0])); atomicMax(gmx, fkey(s_mx[0])); }
 }
+
+// img2tempMat (SpatialFilter.cpp:63-84): one window column per frame
+__global__ __launch_bounds__(256) void k_col_append(const float* __restrict__ GL, float* __restrict__ win_slot, int rows,
+                                                    MinMax* mm, int nstreams) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < rows) win_slot[r] = GL[r];
+    if (blockIdx.x == 0 && (int)threadIdx.x < nstreams) {
+        MinMax m;
+        m.mn1 = m.mn2 = fkey(INFINITY); m.mx1 = m.mx2 = fkey(-INFINITY);
+        mm[threadIdx.x] = m;
+    }
+}
+
+// idealFilter (TemporalFilter.cpp:24-57) for one row per thread.  n = window length, slot0 = ring
+// index of the oldest column.  Packed (CCS) element x: [Re0, Re1, Im1, ..., Re(n/2) if n even].
+__global__ __launch_bounds__(256) void k_col_dft(const float* __restrict__ win, int slot0, int n, int cap, int rows,
+                                                 int rows_per_stream, int live_per_stream, double fl, double fh, const double* __restrict__ tw,
+                                                 float* __restrict__ Y, float* __restrict__ col1, MinMax* mm) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const bool live = r < rows && (r % rows_per_stream) < live_per_stream;   // padded rows never hold data
+    const double* cs = tw;
+    const double* sn = tw + n;
+    float vmin = INFINITY, vmax = -INFINITY;
+    if (live) {
+        auto m = [&](int x) { return (x >= fl && x <= fh) ? 1.0f : 0.0f; };          // :70-77
+        auto dot = [&](int bin, bool im) {                                            // dft(DFT_ROWS | DFT_SCALE)
+            double acc = 0;
+            for (int t = 0; t < n; ++t) {
+                int slot = slot0 + t; if (slot >= cap) slot -= cap;
+                const double v = (double)win[(size_t)slot * rows + r];
+                const int idx = (int)(((long long)bin * t) % n);
+                acc += im ? -v * sn[idx] : v * cs[idx];
+            }
+            return (float)(acc / n);
+        };
+        const int half = (n - 1) / 2;
+        // forward + mulSpectrums (packed complex product with the 0/1 mask), needed elements only
+        const float m0 = m(0);
+        const float y0 = m0 != 0.f ? dot(0, false) * m0 : 0.f;
+        if (m0 != 0.f) Y[r] = y0;
+        for (int k = 1; k <= half; ++k) {
+            const float ma = m(2 * k - 1), mb = m(2 * k);
+            if (ma == 0.f && mb == 0.f) continue;
+            const float a = dot(k, false), b = dot(k, true);
+            Y[(size_t)(2 * k - 1) * rows + r] = a * ma - b * mb;
+            Y[(size_t)(2 * k) * rows + r] = b * ma + a * mb;
+        }
+        float yl = 0.f;
+        const float ml = (n % 2 == 0) ? m(n - 1) : 0.f;
+        if (ml != 0.f) yl = dot(n / 2, false) * ml;
+        // idft(DFT_ROWS | DFT_SCALE) of every sample; only the range and column 1 are kept
+        for (int t = 0; t < n; ++t) {
+            double acc = y0;
+            for (int k = 1; k <= half; ++k) {
+                if (m(2 * k - 1) == 0.f && m(2 * k) == 0.f) continue;
+                const int idx = (int)(((long long)k * t) % n);
+                acc += 2.0 * ((double)Y[(size_t)(2 * k - 1) * rows + r] * cs[idx] - (double)Y[(size_t)(2 * k) * rows + r] * sn[idx]);
+            }
+            if (n % 2 == 0) acc += (t % 2 ? -1.0 : 1.0) * (double)yl;
+            const float v = (float)(acc / n);
+            vmin = v < vmin ? v : vmin; vmax = v > vmax ? v : vmax;
+            if (t == 1) col1[r] = v;                                                  // MagnifyCore.hpp:190-192
+        }
+    }
+    // blocks never straddle streams (rows_per_stream is padded to a multiple of 256 by the launcher)
+    const int sidx = (blockIdx.x * 256) / rows_per_stream;
+    block_minmax(vmin, vmax, &mm[sidx].mn1, &mm[sidx].mx1);
+}
+
+// normalize(0, 1, NORM_MINMAX) (TemporalFilter.cpp:55) of column 1, x amplification (MagnifyCore.hpp:185)
+__global__ __launch_bounds__(256) void k_col_norm(const float* __restrict__ col1, float* __restrict__ up0, int rows,
+                                                  int rows_per_stream, const MinMax* mm, float amp) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const MinMax m = mm[r / rows_per_stream];
+    const double mn = (double)fkey_inv(m.mn1), mx = (double)fkey_inv(m.mx1);
+    const double scale = (mx - mn > 2.220446049250313e-16) ? 1. / (mx - mn) : 0.;
+    const double shift = 0. - mn * scale;
+    const float fs = (float)scale, fsh = (float)shift;
+    up0[r] = (col1[r] * fs + fsh) * amp;
+}
+
+// ---- last pyrUp + resize(INTER_LINEAR) + input add (SpatialFilter.cpp:45-48, MagnifyCore.hpp:197-203)
+constexpr int CT_W = 64, CT_H = 16;                 // output tile
+constexpr int CU_W = 100, CU_H = 28;                // max extent of the pyrUp'ed tile (scale < 1.5)
+constexpr int CV_W = 54, CV_H = 18;                 // max extent of its source tile
+
+struct OutArgs {
+    const uint8_t* in; long in_stride, in_sstride;
+    uint8_t* out; long out_stride, out_sstride;
+    int w, h;
+    const float* V; int vw, vh;                     // source of the last pyrUp (planes); U = 2vw x 2vh
+    const int* xofs; const float* xa; const int* yofs; const float* ya;
+    MinMax* mm;
+    int tiles_x, tiles_y;
+    float* dbg;
+};
+
+template <int C, bool WRITE>
+__global__ __launch_bounds__(256) void k_col_out(OutArgs a) {
+    __shared__ float sv[CV_H][CV_W + 1];
+    __shared__ float hv[CV_H][CU_W + 1];
+    __shared__ float su[CU_H][CU_W + 1];
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
+    const int xe = (x0 + CT_W < a.w ? x0 + CT_W : a.w) - 1, ye = (y0 + CT_H < a.h ? y0 + CT_H : a.h) - 1;
+    const int uw = 2 * a.vw, uh = 2 * a.vh;
+    // U-tile extent needed by the bilinear taps of this output tile
+    const int ux0 = a.xofs[x0], uy0 = a.yofs[y0];
+    int ux1 = a.xofs[xe] + 1, uy1 = a.yofs[ye] + 1;
+    ux1 = ux1 < uw ? ux1 : uw - 1; uy1 = uy1 < uh ? uy1 : uh - 1;
+    const int nux = ux1 - ux0 + 1, nuy = uy1 - uy0 + 1;
+    // V-tile extent needed by pyrUp for those U pixels
+    const int vx0 = (ux0 >> 1) - 1, vy0 = (uy0 >> 1) - 1;
+    const int nvx = (ux1 >> 1) + 1 - vx0 + 1, nvy = (uy1 >> 1) + 1 - vy0 + 1;
+    float val[4][C];
+    for (int c = 0; c < C; ++c) {
+        const float* V = a.V + ((size_t)b * C + c) * a.vw * a.vh;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nvy * nvx; i += 256) {
+            const int ly = i / nvx, lx = i - ly * nvx;
+            int gy = vy0 + ly; gy = gy < 0 ? 1 : (gy >= a.vh ? a.vh - 1 : gy);
+            int gx = vx0 + lx; gx = gx < 0 ? 0 : (gx >= a.vw ? a.vw - 1 : gx);
+            sv[ly][lx] = V[(size_t)gy * a.vw + gx];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nvy * nux; i += 256) {
+            const int ly = i / nux, x = i - ly * nux;
+            hv[ly][x] = pyrup_h(&sv[ly][0], ux0 + x, vx0, a.vw);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nuy * nux; i += 256) {
+            const int y = i / nux, x = i - y * nux;
+            const int gy = uy0 + y, lj = (gy >> 1) - vy0;
+            su[y][x] = ((gy & 1) == 0) ? (hv[lj - 1][x] + hv[lj][x] * 6.f + hv[lj + 1][x]) * (1.f / 64.f)
+                                       : ((hv[lj][x] + hv[lj + 1][x]) * 4.f) * (1.f / 64.f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + k * 256;
+            const int y = i / CT_W, x = i - y * CT_W;
+            const int gx = x0 + x, gy = y0 + y;
+            float v = 0.f;
+            if (gx < a.w && gy < a.h) {
+                // resize INTER_LINEAR: horizontal then vertical, D = S0*b0 + S1*b1
+                const int sx0 = a.xofs[gx] - ux0, sx1 = (a.xofs[gx] + 1 < uw ? a.xofs[gx] + 1 : uw - 1) - ux0;
+                const int sy0 = a.yofs[gy] - uy0, sy1 = (a.yofs[gy] + 1 < uh ? a.yofs[gy] + 1 : uh - 1) - uy0;
+                const float a1 = a.xa[gx], a0 = 1.f - a1, b1 = a.ya[gy], b0 = 1.f - b1;
+                const float h0 = su[sy0][sx0] * a0 + su[sy0][sx1] * a1;
+                const float h1 = su[sy1][sx0] * a0 + su[sy1][sx1] * a1;
+                v = h0 * b0 + h1 * b1;
+            }
+            val[k][c] = v;
+        }
+    }
+    float vmin = INFINITY, vmax = -INFINITY;
+    double mn = 0, mx = 0;
+    float osc = 0.f, osh = 0.f;
+    if (WRITE) {   // convertTo(CV_8U, 255/(max-min), -min*255/(max-min)) (MagnifyCore.hpp:202)
+        mn = (double)fkey_inv(a.mm[b].mn2); mx = (double)fkey_inv(a.mm[b].mx2);
+        osc = (float)(255.0 / (mx - mn)); osh = (float)(-mn * 255.0 / (mx - mn));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = threadIdx.x + k * 256;
+        const int y = i / CT_W, x = i - y * CT_W;
+        const int gx = x0 + x, gy = y0 + y;
+        if (gx >= a.w || gy >= a.h) continue;
+        const uint8_t* p = a.in + (size_t)b * a.in_sstride + (size_t)gy * a.in_stride + (size_t)gx * C;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float o = (float)p[c] * 1.0f + val[k][c];                 // :169 (unscaled input), :197
+            if (WRITE) {
+                a.out[(size_t)b * a.out_sstride + (size_t)gy * a.out_stride + (size_t)gx * C + c] = sat_u8(o * osc + osh);
+                if (a.dbg && b == 0) a.dbg[((size_t)gy * a.w + gx) * C + c] = o;
+            } else {
+                vmin = o < vmin ? o : vmin; vmax = o > vmax ? o : vmax;
+            }
+        }
+    }
+    if (!WRITE) block_minmax(vmin, vmax, &a.mm[b].mn2, &a.mm[b].mx2);
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct ColorState : ModeState {
+    int levels = 0, planes = 0, channels = 0;
+    LevelGeom g[kMaxLevels + 1];
+    float* arena = nullptr;
+    float* G[kMaxLevels + 1] = {};
+    float* up[kMaxLevels + 1] = {};
+    float* col1 = nullptr;
+    int rows = 0, rows_ps = 0;       // padded rows (all streams) and per stream
+    float* win = nullptr; float* Y = nullptr; int cap = 0;
+    int n = 0, slot0 = 0;            // logical window: n columns starting at ring slot slot0
+    double* tw = nullptr; int tw_n = 0;
+    MinMax* mm = nullptr;
+    int *xofs = nullptr, *yofs = nullptr; float *xa = nullptr, *ya = nullptr;
+    ~ColorState() override {
+        void* p[] = {arena, win, Y, tw, mm, xofs, yofs, xa, ya};
+        for (void* q : p) if (q) (void)hipFree(q);
+    }
+};
+
+static void resize_tab(int d, int s, std::vector<int>& ofs, std::vector<float>& al) {   // cv::resize INTER_LINEAR tables
+    const double scale = 1. / ((double)d / s);
+    ofs.resize(d); al.resize(d);
+    for (int i = 0; i < d; ++i) {
+        float f = (float)((i + 0.5) * scale - 0.5);
+        int si = (int)std::floor(f);
+        f -= (float)si;
+        if (si < 0) { f = 0; si = 0; }
+        if (si >= s - 1) { f = 0; si = s - 1; }
+        ofs[i] = si; al[i] = f;
+    }
+}
+
+static int color_alloc(Ctx* c, ColorState* st, int w, int h, int channels, int levels) {
+    st->levels = levels; st->channels = channels; st->planes = c->nstreams * channels;
+    st->g[0] = {w, h, (size_t)w * h};
+    for (int l = 1; l <= levels; ++l) {
+        const int lw = (st->g[l - 1].w + 1) / 2, lh = (st->g[l - 1].h + 1) / 2;
+        st->g[l] = {lw, lh, (size_t)lw * lh};
+    }
+    auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
+    const size_t nL = st->g[levels].n;
+    st->rows_ps = (int)((nL * channels + 255) / 256 * 256);
+    st->rows = st->rows_ps * c->nstreams;
+    size_t total = 0;
+    for (int l = 1; l <= levels; ++l) total += pad(st->g[l].n * st->planes);
+    for (int k = 0; k < levels; ++k) total += pad((nL << (2 * k)) * st->planes);
+    total += pad((size_t)st->rows);
+    if (hipMalloc((void**)&st->arena, total * sizeof(float)) != hipSuccess) { st->arena = nullptr; c->err = "color: hipMalloc failed"; return LVM_ERR_OOM; }
+    float* p = st->arena;
+    for (int l = 1; l <= levels; ++l) { st->G[l] = p; p += pad(st->g[l].n * st->planes); }
+    for (int k = 0; k < levels; ++k) { st->up[k] = p; p += pad((nL << (2 * k)) * st->planes); }
+    st->col1 = p;
+    // resize tables from (w_L 2^L, h_L 2^L) to (w, h); equal sizes => identity taps (cv::resize copies)
+    const int UW = st->g[levels].w << levels, UH = st->g[levels].h << levels;
+    std::vector<int> xo, yo; std::vector<float> xa, ya;
+    resize_tab(w, UW, xo, xa); resize_tab(h, UH, yo, ya);
+    if (UW == w && UH == h) { for (int i = 0; i < w; ++i) { xo[i] = i; xa[i] = 0; } for (int i = 0; i < h; ++i) { yo[i] = i; ya[i] = 0; } }
+    LVM_HIP_TRY(c, hipMalloc((void**)&st->xofs, w * sizeof(int))); LVM_HIP_TRY(c, hipMalloc((void**)&st->xa, w * sizeof(float)));
+    LVM_HIP_TRY(c, hipMalloc((void**)&st->yofs, h * sizeof(int))); LVM_HIP_TRY(c, hipMalloc((void**)&st->ya, h * sizeof(float)));
+    LVM_HIP_TRY(c, hipMemcpy(st->xofs, xo.data(), w * sizeof(int), hipMemcpyHostToDevice));
+    LVM_HIP_TRY(c, hipMemcpy(st->xa, xa.data(), w * sizeof(float), hipMemcpyHostToDevice));
+    LVM_HIP_TRY(c, hipMemcpy(st->yofs, yo.data(), h * sizeof(int), hipMemcpyHostToDevice));
+    LVM_HIP_TRY(c, hipMemcpy(st->ya, ya.data(), h * sizeof(float), hipMemcpyHostToDevice));
+    LVM_HIP_TRY(c, hipMalloc((void**)&st->mm, sizeof(MinMax) * c->nstreams));
+    // the kernel's LDS tiles assume the resize never shrinks by more than 1.5 (true for every size
+    // calculateMaxLevels admits); verify the per-tile extents once
+    for (int x0 = 0; x0 < w; x0 += CT_W) { const int xe = (x0 + CT_W < w ? x0 + CT_W : w) - 1; if (xo[xe] + 1 - xo[x0] + 1 > CU_W) { c->err = "color: resize tile too wide"; return LVM_ERR_INVALID; } }
+    for (int y0 = 0; y0 < h; y0 += CT_H) { const int ye = (y0 + CT_H < h ? y0 + CT_H : h) - 1; if (yo[ye] + 1 - yo[y0] + 1 > CU_H) { c->err = "color: resize tile too tall"; return LVM_ERR_INVALID; } }
+    return LVM_OK;
+}
+
+// ring capacity >= needed columns; linearises the live columns on growth
+static int color_reserve(Ctx* c, ColorState* st, int need, hipStream_t s) {
+    if (need <= st->cap) return LVM_OK;
+    int ncap = 16;
+    while (ncap < need) ncap *= 2;
+    float *nw = nullptr, *ny = nullptr;
+    LVM_HIP_TRY(c, hipMalloc((void**)&nw, (size_t)ncap * st->rows * sizeof(float)));
+    LVM_HIP_TRY(c, hipMalloc((void**)&ny, (size_t)ncap * st->rows * sizeof(float)));
+    LVM_HIP_TRY(c, hipStreamSynchronize(s));
+    for (int t = 0; t < st->n; ++t) {
+        const int slot = (st->slot0 + t) % st->cap;
+        LVM_HIP_TRY(c, hipMemcpy(nw + (size_t)t * st->rows, st->win + (size_t)slot * st->rows, (size_t)st->rows * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    if (st->win) (void)hipFree(st->win);
+    if (st->Y) (void)hipFree(st->Y);
+    st->win = nw; st->Y = ny; st->cap = ncap; st->slot0 = 0;
+    return LVM_OK;
+}
+
+int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced) {
+    *produced = 0;
+    ColorState* st = static_cast<ColorState*>(c->state);
+    if (!st) {
+        st = new ColorState();
+        c->state = st;
+        const int rc = color_alloc(c, st, io.w, io.h, io.channels, levels);
+        if (rc != LVM_OK) return rc;
+    }
+    const int C = io.channels, NS = c->nstreams, w = io.w, h = io.h;
+    const dim3 blk(256);
+    // ---- Gaussian pyramid of the unscaled frame (:169-172) ----
+    {
+        const LevelGeom& g1 = st->g[1];
+        const dim3 grid0((g1.w + 31) / 32, (g1.h + 15) / 16, NS);
+        auto kd0 = (C == 3) ? k_down0<3, false> : k_down0<1, false>;
+        LVM_LAUNCH(c, "col_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, st->G[1], g1.w, g1.h, c->lab, 1.0f);
+        for (int l = 1; l < levels; ++l) {
+            const LevelGeom &a = st->g[l], &b = st->g[l + 1];
+            const dim3 grid((b.w + 31) / 32, (b.h + 15) / 16, st->planes);
+            LVM_LAUNCH(c, "pyr_down", k_pyr_down<1>, grid, blk, s, (const float*)st->G[l], a.w, a.h, st->G[l + 1], b.w, b.h);
+        }
+    }
+    // ---- rolling window (:175-176, SpatialFilter.cpp:63-84) ----
+    const int maxImages = optimal_buffer_size((int)p.framerate);
+    {
+        const int want = maxImages > 0 && maxImages <= 4096 ? maxImages + 1 : 0;
+        const int rc = color_reserve(c, st, st->n + 1 > want ? st->n + 1 : want, s);
+        if (rc != LVM_OK) return rc;
+    }
+    const int nL = (int)st->g[levels].n;
+    {
+        const int slot = (st->slot0 + st->n) % st->cap;
+        // rows are laid out per stream with padding: append stream by stream
+        for (int b = 0; b < NS; ++b) {
+            const dim3 grid((nL * C + 255) / 256);
+            LVM_LAUNCH(c, "col_append", k_col_append, grid, blk, s, (const float*)(st->G[levels] + (size_t)b * C * nL),
+                       st->win + (size_t)slot * st->rows + (size_t)b * st->rows_ps, nL * C, st->mm, b == 0 ? NS : 0);
+        }
+        st->n += 1;
+        if (st->n > maxImages && maxImages > 0) { st->slot0 = (st->slot0 + 1) % st->cap; st->n -= 1; }
+    }
+    if (st->n < 2) { LVM_HIP_TRY(c, hipGetLastError()); return LVM_OK; }            // :180
+    // ---- ideal band-pass over time (:183) ----
+    const int n = st->n;
+    if (st->tw_n != n) {   // twiddles cos/sin(2 pi k / n), float64, computed on the host like the oracle's
+        std::vector<double> t(2 * (size_t)n);
+        for (int k = 0; k < n; ++k) { t[k] = std::cos(2.0 * 3.1415926535897932384626433832795 * k / n); t[n + k] = std::sin(2.0 * 3.1415926535897932384626433832795 * k / n); }
+        LVM_HIP_TRY(c, hipStreamSynchronize(s));
+        if (st->tw) (void)hipFree(st->tw);
+        st->tw = nullptr;
+        LVM_HIP_TRY(c, hipMalloc((void**)&st->tw, t.size() * sizeof(double)));
+        LVM_HIP_TRY(c, hipMemcpy(st->tw, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+        st->tw_n = n;
+    }
+    double lo = p.coLow, hi = p.coHigh;
+    if (lo == 0.00) lo += 0.01;                                                       // TemporalFilter.cpp:26-27
+    const float width = (float)n;
+    const double fl = 2 * lo * width / p.framerate, fh = 2 * hi * width / p.framerate; // :65-66
+    {
+        const dim3 grid(st->rows / 256);
+        LVM_LAUNCH(c, "col_dft", k_col_dft, grid, blk, s, (const float*)st->win, st->slot0, n, st->cap, st->rows, st->rows_ps, nL * C, fl, fh,
+                   (const double*)st->tw, st->Y, st->col1, st->mm);
+    }
+    for (int b = 0; b < NS; ++b) {
+        const dim3 grid((nL * C + 255) / 256);
+        LVM_LAUNCH(c, "col_norm", k_col_norm, grid, blk, s, (const float*)(st->col1 + (size_t)b * st->rows_ps),
+                   st->up[0] + (size_t)b * C * nL, nL * C, st->rows_ps, (const MinMax*)(st->mm + b), (float)p.amplification);
+    }
+    // ---- up chain (SpatialFilter.cpp:40-50): L-1 generic pyrUps, the last one is fused below ----
+    int uw = st->g[levels].w, uh = st->g[levels].h;
+    for (int k = 0; k + 1 < levels; ++k) {
+        const dim3 grid((2 * uw + 63) / 64, (2 * uh + 15) / 16, st->planes);
+        LVM_LAUNCH(c, "pyr_up", k_pyr_up<1>, grid, blk, s, (const float*)st->up[k], uw, uh, st->up[k + 1], 2 * uw, 2 * uh);
+        uw *= 2; uh *= 2;
+    }
+    OutArgs a;
+    a.in = io.d_in; a.in_stride = (long)io.in_stride; a.in_sstride = (long)io.in_sstride;
+    a.out = io.d_out; a.out_stride = (long)io.out_stride; a.out_sstride = (long)io.out_sstride;
+    a.w = w; a.h = h; a.V = st->up[levels - 1]; a.vw = uw; a.vh = uh;
+    a.xofs = st->xofs; a.xa = st->xa; a.yofs = st->yofs; a.ya = st->ya; a.mm = st->mm;
+    a.tiles_x = (w + CT_W - 1) / CT_W; a.tiles_y = (h + CT_H - 1) / CT_H;
+    a.dbg = c->keep_float ? c->d_float : nullptr;
+    const dim3 grid(a.tiles_x, a.tiles_y, NS);
+    auto k1 = (C == 3) ? k_col_out<3, false> : k_col_out<1, false>;
+    auto k2 = (C == 3) ? k_col_out<3, true> : k_col_out<1, true>;
+    LVM_LAUNCH(c, "col_minmax", k1, grid, blk, s, a);
+    LVM_LAUNCH(c, "col_out", k2, grid, blk, s, a);
+    LVM_HIP_TRY(c, hipGetLastError());
+    *produced = 1;
+    return LVM_OK;
+}
+
+}  // namespace lvm

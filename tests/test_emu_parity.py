@@ -51,3 +51,56 @@ def test_laplace_emu_two_streams_are_independent(lvm, po, emu):
             ref, _ = orcs[s].process(fin[s], P)
             assert np.array_equal(ref, fout[s])
     ctx.close()
+
+
+# ---- Riesz (phase) ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,levels", [(96, 64, 3), (135, 77, 4), (64, 48, 1), (67, 131, 2), (160, 90, 5)])
+def test_riesz_emu_bit_exact(lvm, po, emu, w, h, levels):
+    ck, pk = lvm.synth.config(2, (w, h, levels))
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 6, 0.0, exact=True)
+
+
+def test_riesz_emu_cutoff_change_gray_and_reset(lvm, po, emu):
+    ck, pk = lvm.synth.config(2, (96, 64, 3))
+
+    def vary(t, p):
+        if t >= 3:
+            p["coLow"] = 1.0            # MagnifyCore.hpp:243-248: new coefficients, filters cleared, prior rebuilt
+        if t >= 5:
+            p["coHigh"] = 5.0
+        if t >= 7:
+            p["levels"] = 2             # structural change: re-init => passthrough frame
+        return p
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 10, 0.0, exact=True, param_fn=vary)
+    gray = lvm.synth.Clip(96, 64, channels=1)
+    run_pair(lvm, po, emu, gray, pk, 3, 0.0, exact=True)    # < 3 channels: always passthrough (:212)
+
+
+# ---- Colour ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,levels,ch,fps", [(96, 64, 3, 3, 60.0), (135, 77, 4, 3, 30.0), (64, 48, 1, 3, 7.0),
+                                                (67, 131, 2, 1, 15.0)])
+def test_color_emu_bit_exact(lvm, po, emu, w, h, levels, ch, fps):
+    ck, pk = lvm.synth.config(3, (w, h, levels))
+    ck["channels"] = ch; ck["fps"] = fps; pk["framerate"] = fps
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 20, 0.0, exact=True)
+
+
+def test_color_emu_wide_band_and_fps_change(lvm, po, emu):
+    ck, pk = lvm.synth.config(3, (64, 48, 2))
+    pk["coLow"] = 0.0; pk["coHigh"] = 40.0                   # every packed element passes (lo == 0 -> 0.01)
+
+    def vary(t, p):
+        if t >= 12:
+            p["framerate"] = 7.0                              # window cap shrinks 128 -> 16: one column dropped per frame
+        return p
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 24, 0.0, exact=True, param_fn=vary)
+
+
+def test_mode_switch_drops_state(lvm, po, emu):
+    ck, pk0 = lvm.synth.config(0, (96, 64, 3))
+    _, pk2 = lvm.synth.config(2, (96, 64, 3))
+    _, pk3 = lvm.synth.config(3, (96, 64, 3))
+
+    def vary(t, p):
+        return dict([pk0, pk2, pk3, pk0][(t // 3) % 4])
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk0, 12, 0.0, exact=True, param_fn=vary)

@@ -107,3 +107,53 @@ def test_passthrough_and_errors(lvm, po, hip):
     _, produced = ctx.process(np.full((64, 64, 3), 7, np.uint8), lvm.LvmParams(0, 2, 10, 100, 0.1, 0.4, 0, 30.0, 0))
     assert produced
     ctx.close()
+
+
+# ---- Riesz (phase) ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,levels", [(320, 180, 4), (135, 77, 4), (64, 48, 1), (323, 211, 5)])
+def test_riesz_small(lvm, po, hip, w, h, levels):
+    ck, pk = lvm.synth.config(2, (w, h, levels))
+    worst = run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 24, FLOAT_TOL)
+    print("riesz", (w, h, levels), "worst rel/u8/frac", worst)
+
+
+def test_riesz_64_frames_state_drift(lvm, po, hip):
+    ck, pk = lvm.synth.config(2, (640, 360, 5))
+    worst = run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 64, FLOAT_TOL)
+    print("riesz 640x360 L5 64 frames worst", worst)
+
+
+def test_riesz_1080p_full_size(lvm, po, hip):
+    """BASELINE.json configs[2] at full size, a few frames (the oracle needs ~0.5 s per frame)."""
+    ck, pk = lvm.synth.config(2)
+    worst = run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 5, FLOAT_TOL)
+    print("riesz 1080p worst", worst)
+
+
+def test_riesz_cutoff_change(lvm, po, hip):
+    ck, pk = lvm.synth.config(2, (320, 180, 4))
+
+    def vary(t, p):
+        if t >= 4:
+            p["coLow"] = 1.0
+        if t >= 7:
+            p["coHigh"] = 5.0
+        return p
+    run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 12, FLOAT_TOL, param_fn=vary)
+
+
+# ---- Colour ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("w,h,levels,ch,fps", [(320, 180, 4, 3, 60.0), (135, 77, 3, 3, 30.0), (67, 131, 2, 1, 15.0)])
+def test_color_small(lvm, po, hip, w, h, levels, ch, fps):
+    ck, pk = lvm.synth.config(3, (w, h, levels))
+    ck["channels"] = ch; ck["fps"] = fps; pk["framerate"] = fps
+    worst = run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 40, FLOAT_TOL)
+    print("color", (w, h, levels, ch, fps), "worst", worst)
+
+
+def test_color_1080p_window_fill(lvm, po, hip):
+    """BASELINE.json configs[3] geometry (1080p, 6 levels, fps 60 => T = 128): run past the point
+    where the window is full and starts rolling."""
+    ck, pk = lvm.synth.config(3)
+    worst = run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 134, FLOAT_TOL)
+    print("color 1080p worst", worst)
