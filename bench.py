@@ -170,7 +170,7 @@ def main():
     # ---- per-kernel timing pass (HIP events on the launch stream) -> roofline ----
     roofline = None
     kernels = {}
-    if rank == 0:
+    if rank == 0 and args.profile_steps > 0:
         ctx.profile(True)
         for _ in range(args.profile_steps):
             step(n); n += 1

@@ -99,6 +99,11 @@ void lvm_butterworth2(double Wn, double a[3], double b[3]);
  * lvm_debug_read_float copies w*h*channels floats (interleaved like the u8 output).        */
 int  lvm_debug_keep_float(lvm_ctx* ctx, int on);
 int  lvm_debug_read_float(lvm_ctx* ctx, float* dst, size_t count);
+/* Lab colour arithmetic flavour.  Default (0): float32 cube root (exp2/log2 + one Newton step) and
+ * reciprocal multiplies wherever the value only feeds well-conditioned math.  1: OpenCV's exact
+ * operation order everywhere (cv::cubeRoot in float64, true divisions) -- bit-faithful to the CPU
+ * oracle, used by the kernel-logic tests.  The Riesz L plane always uses the exact form.          */
+int  lvm_debug_exact_lab(lvm_ctx* ctx, int on);
 /* Per-kernel timing with HIP events recorded on the launch stream.  While enabled every
  * kernel launch is bracketed by two events; lvm_profile_collect synchronises and folds them
  * into per-kernel totals, readable with lvm_profile_entry (idx = 0..n-1).                   */

@@ -82,7 +82,7 @@ class LvmError(RuntimeError):
 
 SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process_device", "lvm_synchronize",
            "lvm_last_error", "lvm_max_levels", "lvm_optimal_buffer_size", "lvm_butterworth2",
-           "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_profile_enable", "lvm_profile_collect",
+           "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_profile_enable", "lvm_profile_collect",
            "lvm_profile_entry", "lvm_set_graph", "lvm_algorithmic_bytes"]
 
 
@@ -106,6 +106,7 @@ def bind(lib):
     lib.lvm_butterworth2.restype = None
     lib.lvm_debug_keep_float.argtypes = [vp, C.c_int]
     lib.lvm_debug_read_float.argtypes = [vp, vp, C.c_size_t]
+    lib.lvm_debug_exact_lab.argtypes = [vp, C.c_int]
     lib.lvm_profile_enable.argtypes = [vp, C.c_int]
     lib.lvm_profile_collect.argtypes = [vp]
     lib.lvm_profile_entry.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double),
@@ -192,6 +193,9 @@ class Context:
         a = np.empty(shape, np.float32)
         self._check(self.lib.lvm_debug_read_float(self.h, a.ctypes.data, a.size))
         return a
+
+    def exact_lab(self, on=True):
+        self._check(self.lib.lvm_debug_exact_lab(self.h, int(on)))
 
     def profile(self, on=True):
         self._check(self.lib.lvm_profile_enable(self.h, int(on)))

@@ -64,34 +64,48 @@ __global__ __launch_bounds__(256) void k_col_append(const float* __restrict__ GL
 
 // idealFilter (TemporalFilter.cpp:24-57) for one row per thread.  n = window length, slot0 = ring
 // index of the oldest column.  Packed (CCS) element x: [Re0, Re1, Im1, ..., Re(n/2) if n even].
+// The list of complex bins whose mask pair is not all-zero is built once per block in LDS; twiddle
+// indices (bin * t) mod n advance incrementally.  Sums run over t (forward) and over the needed
+// bins in ascending order (inverse) in float64, exactly like the oracle's direct evaluation.
+constexpr int kMaxBins = 2048;
 __global__ __launch_bounds__(256) void k_col_dft(const float* __restrict__ win, int slot0, int n, int cap, int rows,
                                                  int rows_per_stream, int live_per_stream, double fl, double fh, const double* __restrict__ tw,
                                                  float* __restrict__ Y, float* __restrict__ col1, MinMax* mm) {
+    __shared__ short s_bins[kMaxBins];
+    __shared__ int s_nb;
     const int r = blockIdx.x * 256 + threadIdx.x;
     const bool live = r < rows && (r % rows_per_stream) < live_per_stream;   // padded rows never hold data
     const double* cs = tw;
     const double* sn = tw + n;
+    const int half = (n - 1) / 2;
+    auto m = [&](int x) { return (x >= fl && x <= fh) ? 1.0f : 0.0f; };              // :70-77
+    if (threadIdx.x == 0) {
+        int nb = 0;
+        for (int k = 1; k <= half && nb < kMaxBins; ++k)
+            if (m(2 * k - 1) != 0.f || m(2 * k) != 0.f) s_bins[nb++] = (short)k;
+        s_nb = nb;
+    }
+    __syncthreads();
+    const int nb = s_nb;
     float vmin = INFINITY, vmax = -INFINITY;
     if (live) {
-        auto m = [&](int x) { return (x >= fl && x <= fh) ? 1.0f : 0.0f; };          // :70-77
         auto dot = [&](int bin, bool im) {                                            // dft(DFT_ROWS | DFT_SCALE)
             double acc = 0;
+            int idx = 0, slot = slot0;
             for (int t = 0; t < n; ++t) {
-                int slot = slot0 + t; if (slot >= cap) slot -= cap;
                 const double v = (double)win[(size_t)slot * rows + r];
-                const int idx = (int)(((long long)bin * t) % n);
                 acc += im ? -v * sn[idx] : v * cs[idx];
+                idx += bin; if (idx >= n) idx -= n;
+                if (++slot >= cap) slot -= cap;
             }
             return (float)(acc / n);
         };
-        const int half = (n - 1) / 2;
         // forward + mulSpectrums (packed complex product with the 0/1 mask), needed elements only
         const float m0 = m(0);
         const float y0 = m0 != 0.f ? dot(0, false) * m0 : 0.f;
-        if (m0 != 0.f) Y[r] = y0;
-        for (int k = 1; k <= half; ++k) {
+        for (int i = 0; i < nb; ++i) {
+            const int k = s_bins[i];
             const float ma = m(2 * k - 1), mb = m(2 * k);
-            if (ma == 0.f && mb == 0.f) continue;
             const float a = dot(k, false), b = dot(k, true);
             Y[(size_t)(2 * k - 1) * rows + r] = a * ma - b * mb;
             Y[(size_t)(2 * k) * rows + r] = b * ma + a * mb;
@@ -102,9 +116,9 @@ __global__ __launch_bounds__(256) void k_col_dft(const float* __restrict__ win, 
         // idft(DFT_ROWS | DFT_SCALE) of every sample; only the range and column 1 are kept
         for (int t = 0; t < n; ++t) {
             double acc = y0;
-            for (int k = 1; k <= half; ++k) {
-                if (m(2 * k - 1) == 0.f && m(2 * k) == 0.f) continue;
-                const int idx = (int)(((long long)k * t) % n);
+            for (int i = 0; i < nb; ++i) {
+                const int k = s_bins[i];
+                const int idx = (int)(((unsigned)k * (unsigned)t) % (unsigned)n);
                 acc += 2.0 * ((double)Y[(size_t)(2 * k - 1) * rows + r] * cs[idx] - (double)Y[(size_t)(2 * k) * rows + r] * sn[idx]);
             }
             if (n % 2 == 0) acc += (t % 2 ? -1.0 : 1.0) * (double)yl;
@@ -341,7 +355,7 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
     {
         const LevelGeom& g1 = st->g[1];
         const dim3 grid0((g1.w + 31) / 32, (g1.h + 15) / 16, NS);
-        auto kd0 = (C == 3) ? k_down0<3, false> : k_down0<1, false>;
+        auto kd0 = (C == 3) ? k_down0<3, false, true> : k_down0<1, false, true>;
         LVM_LAUNCH(c, "col_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, st->G[1], g1.w, g1.h, c->lab, 1.0f);
         for (int l = 1; l < levels; ++l) {
             const LevelGeom &a = st->g[l], &b = st->g[l + 1];

@@ -72,18 +72,17 @@ __global__ __launch_bounds__(256) void k_lap_up(UpArgs a) {
 // Final level: out = u8(Lab2BGR(Lab(in) + [1, ca, ca] * pyrUp(cur_1))).  MOTION = false is
 // the first frame / L == 1 case (motion image is identically zero).  Persistent workgroups
 // walk over (stream, tile); the inverse-gamma spline table lives in LDS.
-template <int C, bool MOTION>
+template <int C, bool MOTION, bool EXACT>
 __global__ __launch_bounds__(256) void k_lap_final(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                    uint8_t* __restrict__ out, long out_stride, long out_sstride,
                                                    int w, int h, const float* __restrict__ cur1, int w1, int h1,
                                                    LabCoef lab, float ca, int tiles_x, int tiles_y, int nstreams,
                                                    float* __restrict__ dbg) {
-    __shared__ float s_igt[C == 3 ? 4096 : 4];
+    __shared__ __attribute__((aligned(16))) float s_igt[C == 3 ? 4096 : 4];
+    __shared__ float s_gam[C == 3 ? 256 : 1];
     __shared__ float s_c[C][US_H][US_W + 1];
     __shared__ float h_c[C][US_H][UT_W + 1];
-    if (C == 3) {
-        for (int i = threadIdx.x; i < 4096; i += 256) s_igt[i] = lab.invgamma[i];
-    }
+    if (C == 3) { load_invgamma(s_igt, lab.invgamma); load_gamma_u8(s_gam, lab.gamma_u8); }
     __syncthreads();
     const int ntiles = tiles_x * tiles_y * nstreams;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -111,7 +110,7 @@ __global__ __launch_bounds__(256) void k_lap_final(const uint8_t* __restrict__ i
             uint8_t* q = dst + (size_t)gy * out_stride + (size_t)gx * C;
             if (C == 3) {
                 float L, a, bb;
-                lin_bgr_to_lab(lab.gamma_u8[p[0]], lab.gamma_u8[p[1]], lab.gamma_u8[p[2]], lab.fwd, L, a, bb);
+                lin_bgr_to_lab<EXACT>(s_gam[p[0]], s_gam[C == 3 ? p[1] : 0], s_gam[C == 3 ? p[2] : 0], lab.fwd, L, a, bb);
                 if (MOTION) {
                     const float m0 = pyrup_v(h_c[0], x, gy, sy0);
                     const float m1 = pyrup_v(h_c[C > 1 ? 1 : 0], x, gy, sy0) * ca;   // MagnifyCore.hpp:143-144
@@ -119,7 +118,7 @@ __global__ __launch_bounds__(256) void k_lap_final(const uint8_t* __restrict__ i
                     L = L + m0; a = a + m1; bb = bb + m2;                            // :148
                 }
                 float o0, o1, o2;
-                lab_to_bgr(L, a, bb, lab.inv, s_igt, o0, o1, o2);                    // :152
+                lab_to_bgr<EXACT>(L, a, bb, lab.inv, s_igt, o0, o1, o2);                    // :152
                 if (dbg && b == 0) {
                     float* d = dbg + ((size_t)gy * w + gx) * 3;
                     d[0] = o0; d[1] = o1; d[2] = o2;
@@ -209,7 +208,7 @@ int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, 
     if (levels >= 2) {
         const LevelGeom& g1 = st->g[1];
         const dim3 grid0((g1.w + DT_W - 1) / DT_W, (g1.h + DT_H - 1) / DT_H, NS);
-        auto kd0 = (C == 3) ? k_down0<3, true> : k_down0<1, false>;
+        auto kd0 = (C == 3) ? (c->exact_lab ? k_down0<3, true, true> : k_down0<3, true, false>) : k_down0<1, false, true>;
         LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
                    st->G[1], g1.w, g1.h, c->lab, c->lab.a255);
         for (int l = 1; l < levels; ++l) {
@@ -244,8 +243,9 @@ int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, 
         const float ca = (float)p.chromAttenuation;
         const float* cur1 = motion ? st->cur[1] : nullptr;
         const int w1 = st->g[1].w, h1 = st->g[1].h;
-        auto kf = (C == 3) ? (motion ? k_lap_final<3, true> : k_lap_final<3, false>)
-                           : (motion ? k_lap_final<1, true> : k_lap_final<1, false>);
+        auto kf = (C == 3) ? (motion ? (c->exact_lab ? k_lap_final<3, true, true> : k_lap_final<3, true, false>)
+                                     : (c->exact_lab ? k_lap_final<3, false, true> : k_lap_final<3, false, false>))
+                           : (motion ? k_lap_final<1, true, true> : k_lap_final<1, false, true>);
         LVM_LAUNCH(c, "lap_final", kf, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
                    (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, tx, ty, NS, dbg);
     }

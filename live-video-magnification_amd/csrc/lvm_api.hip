@@ -187,6 +187,8 @@ const char* lvm_last_error(lvm_ctx* c) { return c ? c->err.c_str() : "null conte
 
 int lvm_debug_keep_float(lvm_ctx* c, int on) { if (!c) return LVM_ERR_INVALID; c->keep_float = on != 0; return LVM_OK; }
 
+int lvm_debug_exact_lab(lvm_ctx* c, int on) { if (!c) return LVM_ERR_INVALID; c->exact_lab = on != 0; return LVM_OK; }
+
 int lvm_debug_read_float(lvm_ctx* c, float* dst, size_t count) {
     if (!c || !dst) return LVM_ERR_INVALID;
     if (!c->d_float || count > c->float_count) { c->err = "no float frame kept"; return LVM_ERR_INVALID; }

@@ -65,46 +65,74 @@ __device__ __forceinline__ float cv_cube_root(float value) {
     return __int_as_float((int)r);
 }
 
+// Cube root used by the forward Lab conversion.  EXACT = cv::cubeRoot (float64 rational polynomial,
+// the oracle's arithmetic); otherwise exp2(log2(x)/3) refined by one Newton step, all float32,
+// relative error ~1e-7 (L moves by < 2e-5 of its 0..100 range) at ~1/8 of the instruction count.
+template <bool EXACT>
+__device__ __forceinline__ float lab_cbrt(float x) {
+    if (EXACT) return cv_cube_root(x);
+    const float y = exp2f(log2f(x) * 0.33333334f);
+    const float y2 = y * y;
+    return y - __fdividef(y2 * y - x, 3.0f * y2);
+}
 // RGB2Lab_f scalar path on gamma-expanded B,G,R
+template <bool EXACT>
 __device__ __forceinline__ void lin_bgr_to_lab(float B, float G, float R, const float* fw, float& L,
                                                float& a, float& b) {
     const float _a = 16.0f / 116.0f;
     const float X = B * fw[0] + G * fw[1] + R * fw[2];
     const float Y = B * fw[3] + G * fw[4] + R * fw[5];
     const float Z = B * fw[6] + G * fw[7] + R * fw[8];
-    const float FX = X > 0.008856f ? cv_cube_root(X) : (7.787f * X + _a);
-    const float FY = Y > 0.008856f ? cv_cube_root(Y) : (7.787f * Y + _a);
-    const float FZ = Z > 0.008856f ? cv_cube_root(Z) : (7.787f * Z + _a);
+    const float FX = X > 0.008856f ? lab_cbrt<EXACT>(X) : (7.787f * X + _a);
+    const float FY = Y > 0.008856f ? lab_cbrt<EXACT>(Y) : (7.787f * Y + _a);
+    const float FZ = Z > 0.008856f ? lab_cbrt<EXACT>(Z) : (7.787f * Z + _a);
     L = Y > 0.008856f ? (116.f * FY - 16.f) : (903.3f * Y);
     a = 500.f * (FX - FY);
     b = 200.f * (FY - FZ);
 }
-// splineInterpolate (color_lab.cpp), 1024 knots
+// splineInterpolate (color_lab.cpp), 1024 knots; tab is 16-byte aligned (one 128-bit read per knot)
 __device__ __forceinline__ float spline1024(float x, const float* tab) {
     int ix = (int)x;
     ix = ix < 0 ? 0 : (ix > 1023 ? 1023 : ix);
     x -= (float)ix;
-    const float* t = tab + ix * 4;
-    return ((t[3] * x + t[2]) * x + t[1]) * x + t[0];
+    const float4 t = *reinterpret_cast<const float4*>(tab + ix * 4);
+    return ((t.w * x + t.z) * x + t.y) * x + t.x;
 }
 __device__ __forceinline__ float clip01(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
-// Lab2RGBfloat::process + inverse gamma; igt = inverse-gamma spline table (LDS or global)
+// Lab2RGBfloat::process + inverse gamma; igt = inverse-gamma spline table (LDS).  EXACT keeps
+// OpenCV's divisions by 903.3 / 116 / 500 / 200 / 7.787; otherwise they are reciprocal multiplies.
+template <bool EXACT>
 __device__ __forceinline__ void lab_to_bgr(float li, float ai, float bi, const float* iv,
                                            const float* igt, float& o0, float& o1, float& o2) {
     const float lThresh = 0.008856f * 903.3f;
     const float fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
-    float y, fy;
-    if (li <= lThresh) { y = li / 903.3f; fy = 7.787f * y + 16.0f / 116.0f; }
-    else { fy = (li + 16.0f) / 116.0f; y = fy * fy * fy; }
-    float fx = ai / 500.0f + fy, fz = fy - bi / 200.0f;
-    fx = (fx <= fThresh) ? (fx - 16.0f / 116.0f) / 7.787f : fx * fx * fx;
-    fz = (fz <= fThresh) ? (fz - 16.0f / 116.0f) / 7.787f : fz * fz * fz;
+    float y, fy, fx, fz;
+    if (EXACT) {
+        if (li <= lThresh) { y = li / 903.3f; fy = 7.787f * y + 16.0f / 116.0f; }
+        else { fy = (li + 16.0f) / 116.0f; y = fy * fy * fy; }
+        fx = ai / 500.0f + fy; fz = fy - bi / 200.0f;
+        fx = (fx <= fThresh) ? (fx - 16.0f / 116.0f) / 7.787f : fx * fx * fx;
+        fz = (fz <= fThresh) ? (fz - 16.0f / 116.0f) / 7.787f : fz * fz * fz;
+    } else {
+        if (li <= lThresh) { y = li * (1.0f / 903.3f); fy = 7.787f * y + 16.0f / 116.0f; }
+        else { fy = (li + 16.0f) * (1.0f / 116.0f); y = fy * fy * fy; }
+        fx = ai * (1.0f / 500.0f) + fy; fz = fy - bi * (1.0f / 200.0f);
+        fx = (fx <= fThresh) ? (fx - 16.0f / 116.0f) * (1.0f / 7.787f) : fx * fx * fx;
+        fz = (fz <= fThresh) ? (fz - 16.0f / 116.0f) * (1.0f / 7.787f) : fz * fz * fz;
+    }
     const float c0 = iv[0] * fx + iv[1] * y + iv[2] * fz;
     const float c1 = iv[3] * fx + iv[4] * y + iv[5] * fz;
     const float c2 = iv[6] * fx + iv[7] * y + iv[8] * fz;
     o0 = spline1024(clip01(c0) * 1024.f, igt);
     o1 = spline1024(clip01(c1) * 1024.f, igt);
     o2 = spline1024(clip01(c2) * 1024.f, igt);
+}
+// cooperative loads of the two Lab tables into LDS (256 threads)
+__device__ __forceinline__ void load_gamma_u8(float* s_gam, const float* g) { s_gam[threadIdx.x] = g[threadIdx.x]; }
+__device__ __forceinline__ void load_invgamma(float* s_igt, const float* g) {
+    const float4* src = reinterpret_cast<const float4*>(g);
+    float4* dst = reinterpret_cast<float4*>(s_igt);
+    for (int i = threadIdx.x; i < 1024; i += 256) dst[i] = src[i];
 }
 
 // pyrUp horizontal pass for destination column gx from source row `s` whose element for
@@ -155,6 +183,7 @@ struct Ctx {
     std::vector<ProfEvent> prof_events;
     std::vector<ProfTotal> prof_totals;
     bool use_graph = true;
+    bool exact_lab = false;   // debug: OpenCV-order Lab arithmetic everywhere (bit-faithful to the oracle)
 };
 
 void prof_begin(Ctx* c, const char* name, hipStream_t s);

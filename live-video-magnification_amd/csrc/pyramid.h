@@ -42,14 +42,16 @@ __device__ __forceinline__ void pyrdown_tile(float (&s_src)[C][DS_H][DS_W], floa
 
 // u8 frame -> float (Lab for C == 3, x/255 for C == 1; SCALE255 = false keeps [0,255] for the
 // colour mode, MagnifyCore.hpp:169) -> pyrDown -> level-1 planes.
-template <int C, bool LAB>
+template <int C, bool LAB, bool EXACT>
 __global__ __launch_bounds__(256) void k_down0(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                int w, int h, float* __restrict__ G1, int w1, int h1,
                                                LabCoef lab, float scale) {
     __shared__ float s_src[C][DS_H][DS_W];
     __shared__ float s_row[C][DS_H][DT_W];
+    __shared__ float s_gam[LAB ? 256 : 1];
     const int tid = threadIdx.x;
     const int b = blockIdx.z;
+    if (LAB) { load_gamma_u8(s_gam, lab.gamma_u8); __syncthreads(); }
     const int ox0 = blockIdx.x * DT_W, oy0 = blockIdx.y * DT_H;
     const uint8_t* src = in + (size_t)b * in_sstride;
     for (int i = tid; i < DS_H * DS_W; i += 256) {
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void k_down0(const uint8_t* __restrict__ in, l
         const uint8_t* p = src + (size_t)gy * in_stride + (size_t)gx * C;
         if (LAB) {
             float L, a, bb;
-            lin_bgr_to_lab(lab.gamma_u8[p[0]], lab.gamma_u8[p[1]], lab.gamma_u8[p[2]], lab.fwd, L, a, bb);
+            lin_bgr_to_lab<EXACT>(s_gam[p[0]], s_gam[LAB ? p[1] : 0], s_gam[LAB ? p[2] : 0], lab.fwd, L, a, bb);
             s_src[0][ly][lx] = L; s_src[C > 1 ? 1 : 0][ly][lx] = a; s_src[C > 2 ? 2 : 0][ly][lx] = bb;
         } else {
 #pragma unroll

@@ -54,11 +54,15 @@ __device__ const float kHp9[81] = {
 // ---- u8 BGR -> L plane (MagnifyCore.hpp:218-222) ---------------------------------------------
 __global__ __launch_bounds__(256) void k_rz_lab(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                 int w, int h, float* __restrict__ Lp, LabCoef lab) {
+    __shared__ float s_gam[256];
+    load_gamma_u8(s_gam, lab.gamma_u8);
+    __syncthreads();
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
     if (x >= w) return;
     const uint8_t* p = in + (size_t)b * in_sstride + (size_t)y * in_stride + (size_t)x * 3;
     float L, a, bb;
-    lin_bgr_to_lab(lab.gamma_u8[p[0]], lab.gamma_u8[p[1]], lab.gamma_u8[p[2]], lab.fwd, L, a, bb);
+    // always the exact cube root: L feeds the ill-conditioned acos(q0/|q|) step (DESIGN.md "Numerics")
+    lin_bgr_to_lab<true>(s_gam[p[0]], s_gam[p[1]], s_gam[p[2]], lab.fwd, L, a, bb);
     Lp[((size_t)b * h + y) * w + x] = L;
 }
 
@@ -294,15 +298,17 @@ __global__ __launch_bounds__(256) void k_rz_collapse(const float* __restrict__ b
 }
 
 // level-0 collapse (or plain L plane when there are no bands) + Lab2BGR + u8 (MagnifyCore.hpp:272-277)
-template <bool BANDS>
+template <bool BANDS, bool EXACT>
 __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                   uint8_t* __restrict__ out, long out_stride, long out_sstride, int w, int h,
                                                   const float* __restrict__ bandA, const float* __restrict__ resn, int nw,
                                                   int nh, LabCoef lab, int tiles_x, int tiles_y, int nstreams,
                                                   float* __restrict__ dbg) {
-    __shared__ float s_igt[4096];
+    __shared__ __attribute__((aligned(16))) float s_igt[4096];
+    __shared__ float s_gam[256];
     __shared__ float sb[SS_H][SS_W + 1], su[SS_H][SS_W + 1];
-    for (int i = threadIdx.x; i < 4096; i += 256) s_igt[i] = lab.invgamma[i];
+    load_invgamma(s_igt, lab.invgamma);
+    load_gamma_u8(s_gam, lab.gamma_u8);
     __syncthreads();
     const int ntiles = tiles_x * tiles_y * nstreams;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -323,10 +329,11 @@ __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in
             const uint8_t* p = src + (size_t)gy * in_stride + (size_t)gx * 3;
             uint8_t* q = dst + (size_t)gy * out_stride + (size_t)gx * 3;
             float L, a, bb;
-            lin_bgr_to_lab(lab.gamma_u8[p[0]], lab.gamma_u8[p[1]], lab.gamma_u8[p[2]], lab.fwd, L, a, bb);
+            // without bands L itself is the output luminance: keep it exact then
+            lin_bgr_to_lab<EXACT || !BANDS>(s_gam[p[0]], s_gam[p[1]], s_gam[p[2]], lab.fwd, L, a, bb);
             if (BANDS) L = collapse_px(sb, su, x, y, gx, gy);
             float o0, o1, o2;
-            lab_to_bgr(L, a, bb, lab.inv, s_igt, o0, o1, o2);
+            lab_to_bgr<EXACT>(L, a, bb, lab.inv, s_igt, o0, o1, o2);
             if (dbg && b == 0) { float* d = dbg + ((size_t)gy * w + gx) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
             q[0] = sat_u8(o0 * 255.0f + lab.a255);
             q[1] = sat_u8(o1 * 255.0f + lab.a255);
@@ -468,12 +475,14 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         const int ntiles = tx * ty * NS;
         const dim3 grid(ntiles < 2048 ? ntiles : 2048);
         float* dbg = c->keep_float ? c->d_float : nullptr;
+        auto kfb = c->exact_lab ? k_rz_final<true, true> : k_rz_final<true, false>;
+        auto kfn = c->exact_lab ? k_rz_final<false, true> : k_rz_final<false, false>;
         if (nb >= 1)
-            LVM_LAUNCH(c, "rz_final", k_rz_final<true>, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
+            LVM_LAUNCH(c, "rz_final", kfb, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
                        (long)io.out_stride, (long)io.out_sstride, w, h, (const float*)st->f[0][F_BANDA], resn, st->g[1].w, st->g[1].h,
                        c->lab, tx, ty, NS, dbg);
         else
-            LVM_LAUNCH(c, "rz_final", k_rz_final<false>, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
+            LVM_LAUNCH(c, "rz_final", kfn, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
                        (long)io.out_stride, (long)io.out_sstride, w, h, (const float*)nullptr, (const float*)nullptr, 0, 0,
                        c->lab, tx, ty, NS, dbg);
     }

@@ -51,6 +51,8 @@ static inline void hipLaunchKernelGGL(K kern, dim3 grid, dim3 block, size_t, hip
     hipemu::launch([=]() { kern(args...); }, grid, block);
 }
 
+struct float4 { float x, y, z, w; };
+static inline float __fdividef(float a, float b) { return a / b; }
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned i; std::memcpy(&i, &f, 4); return i; }

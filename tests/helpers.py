@@ -8,7 +8,7 @@ def c_params(lvm, pk, key=0):
 
 
 def run_pair(lvm, po, lib, clip, pk, nframes, float_tol, n_streams=1, u8_max=1, u8_frac=0.999, exact=False,
-             param_fn=None):
+             param_fn=None, exact_lab=None):
     """Feeds the same frames to the CPU oracle and to the library behind the C ABI `lib`
     (gfx950 build or the CPU emulation build) and checks, frame by frame:
       (i)   produced / passthrough flags identical,
@@ -18,6 +18,7 @@ def run_pair(lvm, po, lib, clip, pk, nframes, float_tol, n_streams=1, u8_max=1, 
     P = po.make_params(**pk)
     ctx = lvm.Context(0, n_streams, lib)
     ctx.keep_float(True)
+    ctx.exact_lab(exact if exact_lab is None else exact_lab)   # bit-exact checks need OpenCV-order Lab math
     orc = po.Oracle()
     worst = [0.0, 0, 1.0]
     try:

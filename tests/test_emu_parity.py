@@ -39,6 +39,7 @@ def test_laplace_emu_two_streams_are_independent(lvm, po, emu):
     clips = [lvm.synth.Clip(seed=1234 + s, **ck) for s in range(2)]
     h, w = 64, 96
     ctx = lvm.Context(0, 2, emu)
+    ctx.exact_lab(True)
     orcs = [po.Oracle(), po.Oracle()]
     P = po.make_params(**pk)
     cp = c_params(lvm, pk)
@@ -104,3 +105,11 @@ def test_mode_switch_drops_state(lvm, po, emu):
     def vary(t, p):
         return dict([pk0, pk2, pk3, pk0][(t // 3) % 4])
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk0, 12, 0.0, exact=True, param_fn=vary)
+
+
+def test_fast_lab_flavour_stays_within_tolerance(lvm, po, emu):
+    """Default arithmetic (float32 cube root, reciprocal multiplies) vs the oracle: within the
+    1e-4 / 1 LSB parity bar for every mode."""
+    for idx in (0, 2, 3):
+        ck, pk = lvm.synth.config(idx, (96, 64, 3))
+        run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 8, 1e-4, exact=False, exact_lab=False)
