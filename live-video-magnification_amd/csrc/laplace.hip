@@ -138,6 +138,184 @@ __global__ __launch_bounds__(256) void k_lap_final(const uint8_t* __restrict__ i
 }
 
 // ------------------------------------------------------------------------------------------
+// Vectorised first/last kernels (3-channel frames whose width, strides and base pointers are
+// multiples of 4: every group of 4 pixels is then three aligned dwords).  Same arithmetic and
+// operation order as k_down0 / k_lap_final; only the data movement differs: one 12-byte load or
+// store per 4 pixels instead of 12 byte accesses, 128-bit LDS reads, no per-pixel index math.
+// ------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) Px4 { uint32_t a, b, c; };   // 4 BGR pixels
+
+__device__ __forceinline__ void unpack_px4(const Px4 v, int (&B)[4], int (&G)[4], int (&R)[4]) {
+    B[0] = v.a & 255; G[0] = (v.a >> 8) & 255; R[0] = (v.a >> 16) & 255;
+    B[1] = v.a >> 24; G[1] = v.b & 255; R[1] = (v.b >> 8) & 255;
+    B[2] = (v.b >> 16) & 255; G[2] = v.b >> 24; R[2] = v.c & 255;
+    B[3] = (v.c >> 8) & 255; G[3] = (v.c >> 16) & 255; R[3] = v.c >> 24;
+}
+
+// u8 BGR -> Lab -> pyrDown -> G_1.  Output tile 32x16; the Lab source tile (35 rows x 72 columns
+// starting at source column 64*tx - 4) is staged planar in LDS with a +2 column offset so that the
+// 8 floats a pair of adjacent outputs needs are two aligned 128-bit reads; the vertical pass
+// slides a 5-row register window (no intermediate LDS image).
+constexpr int D0_ROWS = 2 * DT_H + 3, D0_GROUPS = 18, D0_PITCH = 76;
+template <bool EXACT>
+__global__ __launch_bounds__(256) void k_down0_v4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
+                                                  int w, int h, float* __restrict__ G1, int w1, int h1, LabCoef lab) {
+    __shared__ __attribute__((aligned(16))) float s_src[3][D0_ROWS][D0_PITCH];
+    __shared__ float s_gam[256];
+    load_gamma_u8(s_gam, lab.gamma_u8);
+    __syncthreads();
+    const int b = blockIdx.z;
+    const int ox0 = blockIdx.x * DT_W, oy0 = blockIdx.y * DT_H;
+    const int sx0 = 2 * ox0 - 4, sy0 = 2 * oy0 - 2;
+    const uint8_t* src = in + (size_t)b * in_sstride;
+    for (int i = threadIdx.x; i < D0_ROWS * D0_GROUPS; i += 256) {
+        const int r = i / D0_GROUPS, g = i - r * D0_GROUPS;
+        const int gy = reflect101(sy0 + r, h), gx0 = sx0 + 4 * g;
+        int Bv[4], Gv[4], Rv[4];
+        if (gx0 >= 0 && gx0 + 3 < w) {
+            unpack_px4(*reinterpret_cast<const Px4*>(src + (size_t)gy * in_stride + (size_t)gx0 * 3), Bv, Gv, Rv);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const uint8_t* p = src + (size_t)gy * in_stride + (size_t)reflect101(gx0 + k, w) * 3;
+                Bv[k] = p[0]; Gv[k] = p[1]; Rv[k] = p[2];
+            }
+        }
+        float L[4], A[4], Bb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lin_bgr_to_lab<EXACT>(s_gam[Bv[k]], s_gam[Gv[k]], s_gam[Rv[k]], lab.fwd, L[k], A[k], Bb[k]);
+        float* d0 = &s_src[0][r][4 * g + 2];
+        float* d1 = &s_src[1][r][4 * g + 2];
+        float* d2 = &s_src[2][r][4 * g + 2];
+        *reinterpret_cast<float2*>(d0) = make_float2(L[0], L[1]); *reinterpret_cast<float2*>(d0 + 2) = make_float2(L[2], L[3]);
+        *reinterpret_cast<float2*>(d1) = make_float2(A[0], A[1]); *reinterpret_cast<float2*>(d1 + 2) = make_float2(A[2], A[3]);
+        *reinterpret_cast<float2*>(d2) = make_float2(Bb[0], Bb[1]); *reinterpret_cast<float2*>(d2 + 2) = make_float2(Bb[2], Bb[3]);
+    }
+    __syncthreads();
+    if (threadIdx.x < 192) {
+        const int pair = threadIdx.x & 15, seg = (threadIdx.x >> 4) & 3, ch = threadIdx.x >> 6;
+        const int x = 2 * pair;                       // tile-local output column (and x + 1)
+        float w0a = 0, w1a = 0, w2a = 0, w3a = 0, w0b = 0, w1b = 0, w2b = 0, w3b = 0;
+        float* dst = G1 + ((size_t)b * 3 + ch) * ((size_t)w1 * h1);
+#pragma unroll
+        for (int rr = 0; rr < 11; ++rr) {
+            const float* row = &s_src[ch][8 * seg + rr][4 * pair + 4];
+            const float4 u = *reinterpret_cast<const float4*>(row);
+            const float4 v = *reinterpret_cast<const float4*>(row + 4);
+            // taps of output x: u.x u.y u.z u.w v.x ; of output x+1: u.z u.w v.x v.y v.z
+            const float ha = u.z * 6.f + (u.y + u.w) * 4.f + u.x + v.x;
+            const float hb = v.x * 6.f + (u.w + v.y) * 4.f + u.z + v.z;
+            if (rr >= 4 && (rr & 1) == 0) {
+                const int gy = oy0 + 4 * seg + (rr - 4) / 2, gx = ox0 + x;
+                const float oa = (w2a * 6.f + (w1a + w3a) * 4.f + w0a + ha) * (1.f / 256.f);
+                const float ob = (w2b * 6.f + (w1b + w3b) * 4.f + w0b + hb) * (1.f / 256.f);
+                if (gy < h1) {
+                    if (gx < w1) dst[(size_t)gy * w1 + gx] = oa;
+                    if (gx + 1 < w1) dst[(size_t)gy * w1 + gx + 1] = ob;
+                }
+            }
+            w0a = w1a; w1a = w2a; w2a = w3a; w3a = ha;
+            w0b = w1b; w1b = w2b; w2b = w3b; w3b = hb;
+        }
+    }
+}
+
+// pyrUp horizontal pass for 4 consecutive destination columns gx0..gx0+3 (gx0 even) from the source
+// values s[i0-1..i0+2], i0 = gx0/2 (indices outside the plane are never used by the border rules)
+__device__ __forceinline__ float4 pyrup_h4(float sm1, float s0, float s1, float s2, int i0, int sw) {
+    float4 o;
+    o.x = (i0 == 0) ? s0 * 6.f + s1 * 2.f : ((i0 == sw - 1) ? sm1 + s0 * 7.f : sm1 + s0 * 6.f + s1);
+    o.y = (i0 == sw - 1) ? s0 * 8.f : (s0 + s1) * 4.f;
+    const int i1 = i0 + 1;
+    o.z = (i1 == sw - 1) ? s0 + s1 * 7.f : s0 + s1 * 6.f + s2;     // i1 >= 1 always
+    o.w = (i1 == sw - 1) ? s1 * 8.f : (s1 + s2) * 4.f;
+    return o;
+}
+
+template <bool MOTION, bool EXACT>
+__global__ __launch_bounds__(256) void k_lap_final_v4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
+                                                      uint8_t* __restrict__ out, long out_stride, long out_sstride,
+                                                      int w, int h, const float* __restrict__ cur1, int w1, int h1,
+                                                      LabCoef lab, float ca, int tiles_x, int tiles_y, int nstreams,
+                                                      float* __restrict__ dbg) {
+    __shared__ __attribute__((aligned(16))) float s_igt[4096];
+    __shared__ float s_gam[256];
+    __shared__ __attribute__((aligned(16))) float h_c[3][US_H][UT_W];
+    load_invgamma(s_igt, lab.invgamma);
+    load_gamma_u8(s_gam, lab.gamma_u8);
+    __syncthreads();
+    const int ntiles = tiles_x * tiles_y * nstreams;
+    const int ty_l = threadIdx.x >> 4, xg = threadIdx.x & 15;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int b = t / (tiles_x * tiles_y);
+        const int r = t - b * (tiles_x * tiles_y);
+        const int ty = r / tiles_x, tx = r - ty * tiles_x;
+        const int x0 = tx * UT_W, y0 = ty * UT_H;
+        const int sy0 = y0 / 2 - 1;
+        if (MOTION) {
+            for (int i = threadIdx.x; i < 3 * US_H * 16; i += 256) {
+                const int c = i / (US_H * 16), rem = i - c * (US_H * 16);
+                const int ly = rem >> 4, g = rem & 15;
+                const int gx0 = x0 + 4 * g;
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gx0 < w) {
+                    int gy = sy0 + ly;
+                    gy = gy < 0 ? 1 : (gy >= h1 ? h1 - 1 : gy);
+                    const float* row = cur1 + ((size_t)b * 3 + c) * ((size_t)w1 * h1) + (size_t)gy * w1;
+                    const int i0 = gx0 >> 1;
+                    const float sm1 = row[i0 > 0 ? i0 - 1 : 0], s0 = row[i0], s1 = row[i0 + 1 < w1 ? i0 + 1 : w1 - 1],
+                                s2 = row[i0 + 2 < w1 ? i0 + 2 : w1 - 1];
+                    o = pyrup_h4(sm1, s0, s1, s2, i0, w1);
+                }
+                *reinterpret_cast<float4*>(&h_c[c][ly][4 * g]) = o;
+            }
+            __syncthreads();
+        }
+        const int gx = x0 + 4 * xg, gy = y0 + ty_l;
+        if (gx < w && gy < h) {
+            int Bv[4], Gv[4], Rv[4];
+            unpack_px4(*reinterpret_cast<const Px4*>(in + (size_t)b * in_sstride + (size_t)gy * in_stride + (size_t)gx * 3), Bv, Gv, Rv);
+            float m[3][4];
+            if (MOTION) {
+                const int lj = (gy >> 1) - sy0;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float4 r0 = *reinterpret_cast<const float4*>(&h_c[c][lj - 1][4 * xg]);
+                    const float4 r1 = *reinterpret_cast<const float4*>(&h_c[c][lj][4 * xg]);
+                    const float4 r2 = *reinterpret_cast<const float4*>(&h_c[c][lj + 1][4 * xg]);
+                    if ((gy & 1) == 0) {
+                        m[c][0] = (r0.x + r1.x * 6.f + r2.x) * (1.f / 64.f); m[c][1] = (r0.y + r1.y * 6.f + r2.y) * (1.f / 64.f);
+                        m[c][2] = (r0.z + r1.z * 6.f + r2.z) * (1.f / 64.f); m[c][3] = (r0.w + r1.w * 6.f + r2.w) * (1.f / 64.f);
+                    } else {
+                        m[c][0] = ((r1.x + r2.x) * 4.f) * (1.f / 64.f); m[c][1] = ((r1.y + r2.y) * 4.f) * (1.f / 64.f);
+                        m[c][2] = ((r1.z + r2.z) * 4.f) * (1.f / 64.f); m[c][3] = ((r1.w + r2.w) * 4.f) * (1.f / 64.f);
+                    }
+                }
+            }
+            uint32_t ob[12];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float L, a, bb;
+                lin_bgr_to_lab<EXACT>(s_gam[Bv[k]], s_gam[Gv[k]], s_gam[Rv[k]], lab.fwd, L, a, bb);
+                if (MOTION) { L = L + m[0][k]; a = a + m[1][k] * ca; bb = bb + m[2][k] * ca; }
+                float o0, o1, o2;
+                lab_to_bgr<EXACT>(L, a, bb, lab.inv, s_igt, o0, o1, o2);
+                if (dbg && b == 0) { float* d = dbg + ((size_t)gy * w + gx + k) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
+                ob[3 * k] = sat_u8(o0 * 255.0f + lab.a255);
+                ob[3 * k + 1] = sat_u8(o1 * 255.0f + lab.a255);
+                ob[3 * k + 2] = sat_u8(o2 * 255.0f + lab.a255);
+            }
+            Px4 q;
+            q.a = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
+            q.b = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
+            q.c = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
+            *reinterpret_cast<Px4*>(out + (size_t)b * out_sstride + (size_t)gy * out_stride + (size_t)gx * 3) = q;
+        }
+        if (MOTION) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 struct LaplaceState : ModeState {
@@ -203,14 +381,24 @@ int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, 
     const dim3 blk(256);
     const bool first = !st->seeded;
     float* dbg = c->keep_float ? c->d_float : nullptr;
+    // 4-pixel (12-byte) vector I/O needs dword-aligned pixel groups
+    const bool vec4 = C == 3 && io.w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 &&
+                      io.out_stride % 4 == 0 && io.out_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0 &&
+                      ((uintptr_t)io.d_out % 4) == 0;
 
     // ---- down sweep: Gaussian pyramid G_1..G_L (needed when any live band exists) ----
     if (levels >= 2) {
         const LevelGeom& g1 = st->g[1];
         const dim3 grid0((g1.w + DT_W - 1) / DT_W, (g1.h + DT_H - 1) / DT_H, NS);
-        auto kd0 = (C == 3) ? (c->exact_lab ? k_down0<3, true, true> : k_down0<3, true, false>) : k_down0<1, false, true>;
-        LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
-                   st->G[1], g1.w, g1.h, c->lab, c->lab.a255);
+        if (vec4) {
+            auto kd0 = c->exact_lab ? k_down0_v4<true> : k_down0_v4<false>;
+            LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
+                       st->G[1], g1.w, g1.h, c->lab);
+        } else {
+            auto kd0 = (C == 3) ? (c->exact_lab ? k_down0<3, true, true> : k_down0<3, true, false>) : k_down0<1, false, true>;
+            LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
+                       st->G[1], g1.w, g1.h, c->lab, c->lab.a255);
+        }
         for (int l = 1; l < levels; ++l) {
             const LevelGeom &a = st->g[l], &b = st->g[l + 1];
             const dim3 grid((b.w + DT_W - 1) / DT_W, (b.h + DT_H - 1) / DT_H, st->planes);
@@ -243,10 +431,12 @@ int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, 
         const float ca = (float)p.chromAttenuation;
         const float* cur1 = motion ? st->cur[1] : nullptr;
         const int w1 = st->g[1].w, h1 = st->g[1].h;
+        auto kf4 = motion ? (c->exact_lab ? k_lap_final_v4<true, true> : k_lap_final_v4<true, false>)
+                          : (c->exact_lab ? k_lap_final_v4<false, true> : k_lap_final_v4<false, false>);
         auto kf = (C == 3) ? (motion ? (c->exact_lab ? k_lap_final<3, true, true> : k_lap_final<3, true, false>)
                                      : (c->exact_lab ? k_lap_final<3, false, true> : k_lap_final<3, false, false>))
                            : (motion ? k_lap_final<1, true, true> : k_lap_final<1, false, true>);
-        LVM_LAUNCH(c, "lap_final", kf, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
+        LVM_LAUNCH(c, "lap_final", vec4 ? kf4 : kf, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
                    (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, tx, ty, NS, dbg);
     }
     LVM_HIP_TRY(c, hipGetLastError());

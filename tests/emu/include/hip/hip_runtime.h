@@ -51,7 +51,10 @@ static inline void hipLaunchKernelGGL(K kern, dim3 grid, dim3 block, size_t, hip
     hipemu::launch([=]() { kern(args...); }, grid, block);
 }
 
+struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
+static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
+static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
