@@ -168,22 +168,38 @@ __global__ __launch_bounds__(256) void k_down0_v4(const uint8_t* __restrict__ in
     const int ox0 = blockIdx.x * DT_W, oy0 = blockIdx.y * DT_H;
     const int sx0 = 2 * ox0 - 4, sy0 = 2 * oy0 - 2;
     const uint8_t* src = in + (size_t)b * in_sstride;
-    for (int i = threadIdx.x; i < D0_ROWS * D0_GROUPS; i += 256) {
+    // all global loads of this thread are issued before the first use (3 pixel groups per thread)
+    constexpr int NG = (D0_ROWS * D0_GROUPS + 255) / 256;
+    Px4 pv[NG];
+    int prow[NG], pgy[NG], pgx[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        const int i = threadIdx.x + k * 256;
         const int r = i / D0_GROUPS, g = i - r * D0_GROUPS;
-        const int gy = reflect101(sy0 + r, h), gx0 = sx0 + 4 * g;
+        prow[k] = i < D0_ROWS * D0_GROUPS ? r : -1;
+        pgy[k] = reflect101(sy0 + (r < D0_ROWS ? r : 0), h);
+        pgx[k] = sx0 + 4 * g;
+        pv[k].a = pv[k].b = pv[k].c = 0;
+        if (prow[k] >= 0 && pgx[k] >= 0 && pgx[k] + 3 < w)
+            pv[k] = *reinterpret_cast<const Px4*>(src + (size_t)pgy[k] * in_stride + (size_t)pgx[k] * 3);
+    }
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        if (prow[k] < 0) continue;
+        const int r = prow[k], gy = pgy[k], gx0 = pgx[k], g = (gx0 - sx0) >> 2;
         int Bv[4], Gv[4], Rv[4];
         if (gx0 >= 0 && gx0 + 3 < w) {
-            unpack_px4(*reinterpret_cast<const Px4*>(src + (size_t)gy * in_stride + (size_t)gx0 * 3), Bv, Gv, Rv);
+            unpack_px4(pv[k], Bv, Gv, Rv);
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint8_t* p = src + (size_t)gy * in_stride + (size_t)reflect101(gx0 + k, w) * 3;
-                Bv[k] = p[0]; Gv[k] = p[1]; Rv[k] = p[2];
+            for (int q = 0; q < 4; ++q) {
+                const uint8_t* p = src + (size_t)gy * in_stride + (size_t)reflect101(gx0 + q, w) * 3;
+                Bv[q] = p[0]; Gv[q] = p[1]; Rv[q] = p[2];
             }
         }
         float L[4], A[4], Bb[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) lin_bgr_to_lab<EXACT>(s_gam[Bv[k]], s_gam[Gv[k]], s_gam[Rv[k]], lab.fwd, L[k], A[k], Bb[k]);
+        for (int q = 0; q < 4; ++q) lin_bgr_to_lab<EXACT>(s_gam[Bv[q]], s_gam[Gv[q]], s_gam[Rv[q]], lab.fwd, L[q], A[q], Bb[q]);
         float* d0 = &s_src[0][r][4 * g + 2];
         float* d1 = &s_src[1][r][4 * g + 2];
         float* d2 = &s_src[2][r][4 * g + 2];
@@ -232,49 +248,75 @@ __device__ __forceinline__ float4 pyrup_h4(float sm1, float s0, float s1, float 
     return o;
 }
 
+// Persistent 1024-thread workgroups (one per CU): the two Lab tables are loaded into LDS once per
+// CU; each 256-thread quarter walks over its own 64x16 tiles.
+constexpr int FQ = 4;   // tiles in flight per workgroup
 template <bool MOTION, bool EXACT>
-__global__ __launch_bounds__(256) void k_lap_final_v4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
-                                                      uint8_t* __restrict__ out, long out_stride, long out_sstride,
-                                                      int w, int h, const float* __restrict__ cur1, int w1, int h1,
-                                                      LabCoef lab, float ca, int tiles_x, int tiles_y, int nstreams,
-                                                      float* __restrict__ dbg) {
+__global__ __launch_bounds__(1024) void k_lap_final_v4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
+                                                       uint8_t* __restrict__ out, long out_stride, long out_sstride,
+                                                       int w, int h, const float* __restrict__ cur1, int w1, int h1,
+                                                       LabCoef lab, float ca, int tiles_x, int tiles_y, int nstreams,
+                                                       float* __restrict__ dbg) {
     __shared__ __attribute__((aligned(16))) float s_igt[4096];
     __shared__ float s_gam[256];
-    __shared__ __attribute__((aligned(16))) float h_c[3][US_H][UT_W];
-    load_invgamma(s_igt, lab.invgamma);
-    load_gamma_u8(s_gam, lab.gamma_u8);
+    __shared__ __attribute__((aligned(16))) float h_all[FQ][3][US_H][UT_W];
+    const int q = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    {
+        const float4* src = reinterpret_cast<const float4*>(lab.invgamma);
+        reinterpret_cast<float4*>(s_igt)[threadIdx.x] = src[threadIdx.x];
+        if (threadIdx.x < 256) s_gam[threadIdx.x] = lab.gamma_u8[threadIdx.x];
+    }
     __syncthreads();
+    float (&h_c)[3][US_H][UT_W] = h_all[q];
     const int ntiles = tiles_x * tiles_y * nstreams;
-    const int ty_l = threadIdx.x >> 4, xg = threadIdx.x & 15;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const int b = t / (tiles_x * tiles_y);
-        const int r = t - b * (tiles_x * tiles_y);
+    const int ty_l = tid >> 4, xg = tid & 15;
+    for (int t0 = blockIdx.x * FQ; t0 < ntiles; t0 += gridDim.x * FQ) {
+        const int t = t0 + q;
+        const bool tile_ok = t < ntiles;
+        const int b = tile_ok ? t / (tiles_x * tiles_y) : 0;
+        const int r = tile_ok ? t - b * (tiles_x * tiles_y) : 0;
         const int ty = r / tiles_x, tx = r - ty * tiles_x;
         const int x0 = tx * UT_W, y0 = ty * UT_H;
         const int sy0 = y0 / 2 - 1;
+        const int gx = x0 + 4 * xg, gy = y0 + ty_l;
+        const bool px_ok = tile_ok && gx < w && gy < h;
+        Px4 pin; pin.a = pin.b = pin.c = 0;
+        if (px_ok) pin = *reinterpret_cast<const Px4*>(in + (size_t)b * in_sstride + (size_t)gy * in_stride + (size_t)gx * 3);
         if (MOTION) {
-            for (int i = threadIdx.x; i < 3 * US_H * 16; i += 256) {
-                const int c = i / (US_H * 16), rem = i - c * (US_H * 16);
-                const int ly = rem >> 4, g = rem & 15;
-                const int gx0 = x0 + 4 * g;
-                float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gx0 < w) {
-                    int gy = sy0 + ly;
-                    gy = gy < 0 ? 1 : (gy >= h1 ? h1 - 1 : gy);
-                    const float* row = cur1 + ((size_t)b * 3 + c) * ((size_t)w1 * h1) + (size_t)gy * w1;
-                    const int i0 = gx0 >> 1;
-                    const float sm1 = row[i0 > 0 ? i0 - 1 : 0], s0 = row[i0], s1 = row[i0 + 1 < w1 ? i0 + 1 : w1 - 1],
-                                s2 = row[i0 + 2 < w1 ? i0 + 2 : w1 - 1];
-                    o = pyrup_h4(sm1, s0, s1, s2, i0, w1);
+            // 480 horizontal-pass tasks per tile: two per thread, loads first
+            float sv[2][4]; int si0[2], sdst[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int i = tid + k * 256;
+                sdst[k] = -1; si0[k] = 0;
+                sv[k][0] = sv[k][1] = sv[k][2] = sv[k][3] = 0.f;
+                if (tile_ok && i < 3 * US_H * 16) {
+                    const int c = i / (US_H * 16), rem = i - c * (US_H * 16);
+                    const int ly = rem >> 4, g = rem & 15;
+                    const int gx0 = x0 + 4 * g;
+                    sdst[k] = (c * US_H + ly) * UT_W + 4 * g;
+                    if (gx0 < w) {
+                        int sy = sy0 + ly;
+                        sy = sy < 0 ? 1 : (sy >= h1 ? h1 - 1 : sy);
+                        const float* row = cur1 + ((size_t)b * 3 + c) * ((size_t)w1 * h1) + (size_t)sy * w1;
+                        const int i0 = gx0 >> 1;
+                        si0[k] = i0;
+                        sv[k][0] = row[i0 > 0 ? i0 - 1 : 0]; sv[k][1] = row[i0];
+                        sv[k][2] = row[i0 + 1 < w1 ? i0 + 1 : w1 - 1]; sv[k][3] = row[i0 + 2 < w1 ? i0 + 2 : w1 - 1];
+                    } else si0[k] = -1;
                 }
-                *reinterpret_cast<float4*>(&h_c[c][ly][4 * g]) = o;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (sdst[k] < 0) continue;
+                const float4 o = si0[k] >= 0 ? pyrup_h4(sv[k][0], sv[k][1], sv[k][2], sv[k][3], si0[k], w1) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&h_c[0][0][0] + sdst[k]) = o;
             }
             __syncthreads();
         }
-        const int gx = x0 + 4 * xg, gy = y0 + ty_l;
-        if (gx < w && gy < h) {
+        if (px_ok) {
             int Bv[4], Gv[4], Rv[4];
-            unpack_px4(*reinterpret_cast<const Px4*>(in + (size_t)b * in_sstride + (size_t)gy * in_stride + (size_t)gx * 3), Bv, Gv, Rv);
+            unpack_px4(pin, Bv, Gv, Rv);
             float m[3][4];
             if (MOTION) {
                 const int lj = (gy >> 1) - sy0;
@@ -305,13 +347,108 @@ __global__ __launch_bounds__(256) void k_lap_final_v4(const uint8_t* __restrict_
                 ob[3 * k + 1] = sat_u8(o1 * 255.0f + lab.a255);
                 ob[3 * k + 2] = sat_u8(o2 * 255.0f + lab.a255);
             }
-            Px4 q;
-            q.a = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
-            q.b = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
-            q.c = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
-            *reinterpret_cast<Px4*>(out + (size_t)b * out_sstride + (size_t)gy * out_stride + (size_t)gx * 3) = q;
+            Px4 qo;
+            qo.a = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
+            qo.b = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
+            qo.c = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
+            *reinterpret_cast<Px4*>(out + (size_t)b * out_sstride + (size_t)gy * out_stride + (size_t)gx * 3) = qo;
         }
         if (MOTION) __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Tail kernel: every pyramid level from T upwards (G_T has at most kTailMax pixels) is handled by
+// ONE workgroup per plane, entirely in LDS: pyrDown T->T+1->..->L, then the fused band / IIR /
+// gain / collapse steps for l = L-1..T.  Replaces 2(L-T) tiny launches, each of which is pure
+// launch + latency (5-6 us on MI355X for a few hundred pixels).  Same arithmetic as k_pyr_down /
+// k_lap_up.  LDS pool (floats): G_{T+1..L} | cur_{T+1..L-1} | tmpA | tmpB.
+// ------------------------------------------------------------------------------------------
+constexpr int kTailMax = 8192;          // pixels of G_T
+constexpr int kTailLevels = 8;
+constexpr int kTailPool = (kTailMax / 4 + kTailMax / 16 + kTailMax / 32 + 64) * 2 + kTailMax;   // see laplace_tail_plan
+struct TailArgs {
+    const float* GT;                    // G_T planes (global)
+    float* curT;                        // cur_T planes (global, output)
+    float* hi[kTailLevels]; float* lo[kTailLevels];   // states of levels T..L-1 (global planes)
+    int w[kTailLevels + 1], h[kTailLevels + 1];       // geometry of levels T..L
+    int offG[kTailLevels + 1], offC[kTailLevels + 1]; // LDS offsets of G_{T+k}, cur_{T+k} (k >= 1)
+    int offA, offB;                     // two temporaries
+    float gain[kTailLevels];
+    float aHi, bHi, aLo, bLo;
+    int n;                              // number of down steps = L - T (>= 1)
+};
+
+__device__ __forceinline__ float tail_src(const float* s, int w, int h, int y, int x) { return s[(size_t)y * w + x]; }
+
+template <bool SEED>
+__global__ __launch_bounds__(256) void k_lap_tail(TailArgs a) {
+    __shared__ float pool[kTailPool];
+    const int tid = threadIdx.x;
+    const size_t plane = blockIdx.x;
+    // ---- down sweep ----
+    for (int k = 0; k < a.n; ++k) {
+        const int w = a.w[k], h = a.h[k], dw = a.w[k + 1], dh = a.h[k + 1];
+        const float* src = (k == 0) ? a.GT + plane * ((size_t)w * h) : pool + a.offG[k];
+        float* tmp = pool + a.offA;                       // h x dw horizontal results
+        for (int i = tid; i < h * dw; i += 256) {
+            const int y = i / dw, x = i - y * dw;
+            const float* s = src + (size_t)y * w;
+            const int x0 = reflect101(2 * x - 2, w), x1 = reflect101(2 * x - 1, w), x2 = 2 * x,
+                      x3 = reflect101(2 * x + 1, w), x4 = reflect101(2 * x + 2, w);
+            tmp[i] = s[x2] * 6.f + (s[x1] + s[x3]) * 4.f + s[x0] + s[x4];
+        }
+        __syncthreads();
+        float* dst = pool + a.offG[k + 1];
+        for (int i = tid; i < dh * dw; i += 256) {
+            const int y = i / dw, x = i - y * dw;
+            const float r0 = tmp[reflect101(2 * y - 2, h) * dw + x], r1 = tmp[reflect101(2 * y - 1, h) * dw + x],
+                        r2 = tmp[(2 * y) * dw + x], r3 = tmp[reflect101(2 * y + 1, h) * dw + x],
+                        r4 = tmp[reflect101(2 * y + 2, h) * dw + x];
+            dst[i] = (r2 * 6.f + (r1 + r3) * 4.f + r0 + r4) * (1.f / 256.f);
+        }
+        __syncthreads();
+    }
+    // ---- up sweep: level index k = n-1..0 (pyramid level T+k) ----
+    for (int k = a.n - 1; k >= 0; --k) {
+        const int w = a.w[k], h = a.h[k], sw = a.w[k + 1], sh = a.h[k + 1];
+        const float* Gn = pool + a.offG[k + 1];
+        const bool has_cur = !SEED && (k + 1 <= a.n - 1);
+        const float* Cn = pool + a.offC[k + 1];
+        float* tA = pool + a.offA;                        // sh x w horizontal pyrUp of G_{k+1}
+        float* tB = pool + a.offB;                        // same for cur_{k+1}
+        for (int i = tid; i < sh * w; i += 256) {
+            const int y = i / w, x = i - y * w;
+            tA[i] = pyrup_h(Gn + (size_t)y * sw, x, 0, sw);
+            if (has_cur) tB[i] = pyrup_h(Cn + (size_t)y * sw, x, 0, sw);
+        }
+        __syncthreads();
+        const float* Gl = (k == 0) ? a.GT + plane * ((size_t)w * h) : pool + a.offG[k];
+        float* hi = a.hi[k] + plane * ((size_t)w * h);
+        float* lo = a.lo[k] + plane * ((size_t)w * h);
+        float* cur = (k == 0) ? a.curT + plane * ((size_t)w * h) : pool + a.offC[k];
+        for (int i = tid; i < h * w; i += 256) {
+            const int y = i / w, x = i - y * w;
+            const int j = y >> 1;
+            const int jm = j == 0 ? 1 : j - 1, jp = j == sh - 1 ? sh - 1 : j + 1;
+            const float upG = ((y & 1) == 0) ? (tA[jm * w + x] + tA[j * w + x] * 6.f + tA[jp * w + x]) * (1.f / 64.f)
+                                             : ((tA[j * w + x] + tA[jp * w + x]) * 4.f) * (1.f / 64.f);
+            const float band = Gl[i] - upG;
+            if (SEED) {
+                hi[i] = band; lo[i] = band;
+            } else {
+                const float t1 = hi[i] * a.aHi + band * a.bHi;
+                const float t2 = lo[i] * a.aLo + band * a.bLo;
+                hi[i] = t1; lo[i] = t2;
+                const float m = (t1 - t2) * a.gain[k];
+                float up = 0.f;
+                if (has_cur)
+                    up = ((y & 1) == 0) ? (tB[jm * w + x] + tB[j * w + x] * 6.f + tB[jp * w + x]) * (1.f / 64.f)
+                                        : ((tB[j * w + x] + tB[jp * w + x]) * 4.f) * (1.f / 64.f);
+                cur[i] = up + m;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -325,8 +462,13 @@ struct LaplaceState : ModeState {
     float* G[kMaxLevels + 1] = {};
     float *hi[kMaxLevels + 1] = {}, *lo[kMaxLevels + 1] = {}, *cur[kMaxLevels + 1] = {};
     bool seeded = false;
+    int tailT = 0;                       // first level handled by k_lap_tail (0 = tail disabled)
+    TailArgs tail{};
+    bool steady(const lvm_params&) const override { return seeded; }
     ~LaplaceState() override { if (arena) (void)hipFree(arena); }
 };
+
+static void laplace_tail_plan(LaplaceState* st);
 
 static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, int levels) {
     st->levels = levels;
@@ -353,7 +495,34 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
         st->lo[l] = p; p += pad(st->g[l].n * st->planes);
         st->cur[l] = p; p += pad(st->g[l].n * st->planes);
     }
+    laplace_tail_plan(st);
     return LVM_OK;
+}
+
+// Decide which levels the tail kernel covers and lay out its LDS pool.
+static void laplace_tail_plan(LaplaceState* st) {
+    const int L = st->levels;
+    st->tailT = 0;
+    int T = 1;
+    while (T <= L - 1 && st->g[T].n > (size_t)kTailMax) ++T;
+    if (T > L - 1 || L - T > kTailLevels || L - T < 1) return;      // nothing small enough / too deep
+    TailArgs& a = st->tail;
+    a.n = L - T;
+    int off = 0;
+    for (int k = 0; k <= a.n; ++k) { a.w[k] = st->g[T + k].w; a.h[k] = st->g[T + k].h; }
+    for (int k = 1; k <= a.n; ++k) { a.offG[k] = off; off += (int)st->g[T + k].n; }
+    for (int k = 1; k <= a.n - 1; ++k) { a.offC[k] = off; off += (int)st->g[T + k].n; }
+    a.offC[a.n] = 0; a.offG[0] = 0; a.offC[0] = 0;
+    // temporaries: max over steps of h_k*w_{k+1} (down) and h_{k+1}*w_k (up); both <= n_T/2 + slack
+    int tmp = 0;
+    for (int k = 0; k < a.n; ++k) {
+        const int d = a.h[k] * a.w[k + 1], u = a.h[k + 1] * a.w[k];
+        tmp = d > tmp ? d : tmp; tmp = u > tmp ? u : tmp;
+    }
+    a.offA = off; off += tmp;
+    a.offB = off; off += tmp;
+    if (off > kTailPool) return;
+    st->tailT = T;
 }
 
 // MagnifyCore.hpp:114-134 (all float/double conversions as in the reference)
@@ -399,7 +568,8 @@ int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, 
             LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
                        st->G[1], g1.w, g1.h, c->lab, c->lab.a255);
         }
-        for (int l = 1; l < levels; ++l) {
+        const int down_end = st->tailT ? st->tailT : levels;          // the tail builds G_{T+1..L} itself
+        for (int l = 1; l < down_end; ++l) {
             const LevelGeom &a = st->g[l], &b = st->g[l + 1];
             const dim3 grid((b.w + DT_W - 1) / DT_W, (b.h + DT_H - 1) / DT_H, st->planes);
             LVM_LAUNCH(c, "pyr_down", k_pyr_down<0>, grid, blk, s, (const float*)st->G[l], a.w, a.h, st->G[l + 1], b.w, b.h);
@@ -410,7 +580,18 @@ int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, 
     laplace_gains(io.w, io.h, levels, p.amplification, p.coWavelength, gains);
     double cLo = p.coLow, cHi = p.coHigh;
     if (cLo == 0) cLo = 0.01;                                            // TemporalFilter.cpp:11-12
-    for (int l = levels - 1; l >= 1; --l) {
+    int up_start = levels - 1;
+    if (st->tailT) {
+        TailArgs& t = st->tail;
+        const int T = st->tailT;
+        t.GT = st->G[T]; t.curT = st->cur[T];
+        for (int k = 0; k < t.n; ++k) { t.hi[k] = st->hi[T + k]; t.lo[k] = st->lo[T + k]; t.gain[k] = gains[T + k]; }
+        t.aHi = (float)(1 - cHi); t.bHi = (float)cHi; t.aLo = (float)(1 - cLo); t.bLo = (float)cLo;
+        if (first) LVM_LAUNCH(c, "lap_tail_seed", k_lap_tail<true>, dim3(st->planes), blk, s, t);
+        else LVM_LAUNCH(c, "lap_tail", k_lap_tail<false>, dim3(st->planes), blk, s, t);
+        up_start = T - 1;
+    }
+    for (int l = up_start; l >= 1; --l) {
         UpArgs a;
         a.Gl = st->G[l]; a.Gn = st->G[l + 1];
         a.curn = (l + 1 <= levels - 1) ? st->cur[l + 1] : nullptr;
@@ -436,7 +617,9 @@ int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, 
         auto kf = (C == 3) ? (motion ? (c->exact_lab ? k_lap_final<3, true, true> : k_lap_final<3, true, false>)
                                      : (c->exact_lab ? k_lap_final<3, false, true> : k_lap_final<3, false, false>))
                            : (motion ? k_lap_final<1, true, true> : k_lap_final<1, false, true>);
-        LVM_LAUNCH(c, "lap_final", vec4 ? kf4 : kf, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
+        const int groups = (ntiles + FQ - 1) / FQ;
+        const dim3 grid4(groups < 256 ? groups : 256), blk4(1024);
+        LVM_LAUNCH(c, "lap_final", vec4 ? kf4 : kf, vec4 ? grid4 : grid, vec4 ? blk4 : blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
                    (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, tx, ty, NS, dbg);
     }
     LVM_HIP_TRY(c, hipGetLastError());

@@ -157,7 +157,15 @@ struct ProfTotal { std::string name; double ms = 0; long long n = 0; };
 struct LevelGeom { int w, h; size_t n; };   // n = w*h
 
 struct Ctx;
-struct ModeState { virtual ~ModeState() {} };
+struct ModeState {
+    virtual ~ModeState() {}
+    // true when the next frame with parameters `p` issues a fixed launch sequence (no allocation, no
+    // host synchronisation, no per-frame varying kernel argument) and produces an output: such frames
+    // may be captured in a hipGraph and replayed.
+    virtual bool steady(const lvm_params& p) const { (void)p; return false; }
+};
+
+struct GraphEntry { std::vector<uint8_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int produced = 0; };
 
 struct Ctx {
     int device = 0;
@@ -183,6 +191,7 @@ struct Ctx {
     std::vector<ProfEvent> prof_events;
     std::vector<ProfTotal> prof_totals;
     bool use_graph = true;
+    std::vector<GraphEntry> graphs;   // steady-state launch sequences, keyed by every kernel-visible input
     bool exact_lab = false;   // debug: OpenCV-order Lab arithmetic everywhere (bit-faithful to the oracle)
 };
 

@@ -356,6 +356,9 @@ struct RieszState : ModeState {
     bool inited = false;
     double lo_freq = 0, hi_freq = 0, fps = 0;
     double la[3] = {}, lb[3] = {}, ha[3] = {}, hb[3] = {};
+    bool steady(const lvm_params& p) const override {
+        return inited && lo_freq == p.coLow && hi_freq == p.coHigh && !std::isnan(la[0]) && !std::isnan(ha[0]);
+    }
     ~RieszState() override { if (arena) (void)hipFree(arena); }
 };
 enum { F_BAND, F_P, F_R1, F_R2, F_PHC, F_PHS, F_LO0C, F_LO0S, F_LO1C, F_LO1S, F_HI0C, F_HI0S, F_HI1C, F_HI1S, F_AMP, F_TC, F_TS, F_BANDA, F_COUNT };

@@ -11,7 +11,8 @@ from helpers import c_params, run_pair
 
 
 @pytest.mark.parametrize("w,h,levels,ch", [(160, 90, 3, 3), (135, 77, 4, 3), (100, 64, 2, 1), (64, 48, 1, 3),
-                                            (67, 131, 3, 3), (40, 23, 2, 3)])
+                                            (67, 131, 3, 3), (40, 23, 2, 3), (320, 180, 4, 3), (404, 300, 5, 3),
+                                            (330, 200, 6, 3)])
 def test_laplace_emu_bit_exact(lvm, po, emu, w, h, levels, ch):
     ck, pk = lvm.synth.config(0, (w, h, levels))
     ck["channels"] = ch
