@@ -381,27 +381,34 @@ struct TailArgs {
 
 __device__ __forceinline__ float tail_src(const float* s, int w, int h, int y, int x) { return s[(size_t)y * w + x]; }
 
+// i = y * w + x for 0 <= i < 2^20, w < 2^12: (i + 0.5) / w is at least 0.5 / w away from an integer,
+// far more than the float error of the product, so the truncation is exact
+__device__ __forceinline__ int row_of(int i, float inv_w) { return (int)(((float)i + 0.5f) * inv_w); }
+
+constexpr int TAIL_THREADS = 1024;
 template <bool SEED>
-__global__ __launch_bounds__(256) void k_lap_tail(TailArgs a) {
+__global__ __launch_bounds__(TAIL_THREADS) void k_lap_tail(TailArgs a) {
     __shared__ float pool[kTailPool];
     const int tid = threadIdx.x;
     const size_t plane = blockIdx.x;
     // ---- down sweep ----
     for (int k = 0; k < a.n; ++k) {
         const int w = a.w[k], h = a.h[k], dw = a.w[k + 1], dh = a.h[k + 1];
-        const float* src = (k == 0) ? a.GT + plane * ((size_t)w * h) : pool + a.offG[k];
-        float* tmp = pool + a.offA;                       // h x dw horizontal results
-        for (int i = tid; i < h * dw; i += 256) {
-            const int y = i / dw, x = i - y * dw;
+        const float inv_dw = 1.0f / (float)dw;
+        const float* __restrict__ src = (k == 0) ? a.GT + plane * ((size_t)w * h) : pool + a.offG[k];
+        float* __restrict__ tmp = pool + a.offA;                       // h x dw horizontal results
+#pragma unroll 4
+        for (int i = tid; i < h * dw; i += TAIL_THREADS) {
+            const int y = row_of(i, inv_dw), x = i - y * dw;
             const float* s = src + (size_t)y * w;
             const int x0 = reflect101(2 * x - 2, w), x1 = reflect101(2 * x - 1, w), x2 = 2 * x,
                       x3 = reflect101(2 * x + 1, w), x4 = reflect101(2 * x + 2, w);
             tmp[i] = s[x2] * 6.f + (s[x1] + s[x3]) * 4.f + s[x0] + s[x4];
         }
         __syncthreads();
-        float* dst = pool + a.offG[k + 1];
-        for (int i = tid; i < dh * dw; i += 256) {
-            const int y = i / dw, x = i - y * dw;
+        float* __restrict__ dst = pool + a.offG[k + 1];
+        for (int i = tid; i < dh * dw; i += TAIL_THREADS) {
+            const int y = row_of(i, inv_dw), x = i - y * dw;
             const float r0 = tmp[reflect101(2 * y - 2, h) * dw + x], r1 = tmp[reflect101(2 * y - 1, h) * dw + x],
                         r2 = tmp[(2 * y) * dw + x], r3 = tmp[reflect101(2 * y + 1, h) * dw + x],
                         r4 = tmp[reflect101(2 * y + 2, h) * dw + x];
@@ -412,23 +419,25 @@ __global__ __launch_bounds__(256) void k_lap_tail(TailArgs a) {
     // ---- up sweep: level index k = n-1..0 (pyramid level T+k) ----
     for (int k = a.n - 1; k >= 0; --k) {
         const int w = a.w[k], h = a.h[k], sw = a.w[k + 1], sh = a.h[k + 1];
-        const float* Gn = pool + a.offG[k + 1];
+        const float inv_w = 1.0f / (float)w;
+        const float* __restrict__ Gn = pool + a.offG[k + 1];
         const bool has_cur = !SEED && (k + 1 <= a.n - 1);
-        const float* Cn = pool + a.offC[k + 1];
-        float* tA = pool + a.offA;                        // sh x w horizontal pyrUp of G_{k+1}
-        float* tB = pool + a.offB;                        // same for cur_{k+1}
-        for (int i = tid; i < sh * w; i += 256) {
-            const int y = i / w, x = i - y * w;
+        const float* __restrict__ Cn = pool + a.offC[k + 1];
+        float* __restrict__ tA = pool + a.offA;                        // sh x w horizontal pyrUp of G_{k+1}
+        float* __restrict__ tB = pool + a.offB;                        // same for cur_{k+1}
+        for (int i = tid; i < sh * w; i += TAIL_THREADS) {
+            const int y = row_of(i, inv_w), x = i - y * w;
             tA[i] = pyrup_h(Gn + (size_t)y * sw, x, 0, sw);
             if (has_cur) tB[i] = pyrup_h(Cn + (size_t)y * sw, x, 0, sw);
         }
         __syncthreads();
-        const float* Gl = (k == 0) ? a.GT + plane * ((size_t)w * h) : pool + a.offG[k];
-        float* hi = a.hi[k] + plane * ((size_t)w * h);
-        float* lo = a.lo[k] + plane * ((size_t)w * h);
-        float* cur = (k == 0) ? a.curT + plane * ((size_t)w * h) : pool + a.offC[k];
-        for (int i = tid; i < h * w; i += 256) {
-            const int y = i / w, x = i - y * w;
+        const float* __restrict__ Gl = (k == 0) ? a.GT + plane * ((size_t)w * h) : pool + a.offG[k];
+        float* __restrict__ hi = a.hi[k] + plane * ((size_t)w * h);
+        float* __restrict__ lo = a.lo[k] + plane * ((size_t)w * h);
+        float* __restrict__ cur = (k == 0) ? a.curT + plane * ((size_t)w * h) : pool + a.offC[k];
+#pragma unroll 4
+        for (int i = tid; i < h * w; i += TAIL_THREADS) {
+            const int y = row_of(i, inv_w), x = i - y * w;
             const int j = y >> 1;
             const int jm = j == 0 ? 1 : j - 1, jp = j == sh - 1 ? sh - 1 : j + 1;
             const float upG = ((y & 1) == 0) ? (tA[jm * w + x] + tA[j * w + x] * 6.f + tA[jp * w + x]) * (1.f / 64.f)
@@ -587,8 +596,8 @@ int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, 
         t.GT = st->G[T]; t.curT = st->cur[T];
         for (int k = 0; k < t.n; ++k) { t.hi[k] = st->hi[T + k]; t.lo[k] = st->lo[T + k]; t.gain[k] = gains[T + k]; }
         t.aHi = (float)(1 - cHi); t.bHi = (float)cHi; t.aLo = (float)(1 - cLo); t.bLo = (float)cLo;
-        if (first) LVM_LAUNCH(c, "lap_tail_seed", k_lap_tail<true>, dim3(st->planes), blk, s, t);
-        else LVM_LAUNCH(c, "lap_tail", k_lap_tail<false>, dim3(st->planes), blk, s, t);
+        if (first) LVM_LAUNCH(c, "lap_tail_seed", k_lap_tail<true>, dim3(st->planes), dim3(TAIL_THREADS), s, t);
+        else LVM_LAUNCH(c, "lap_tail", k_lap_tail<false>, dim3(st->planes), dim3(TAIL_THREADS), s, t);
         up_start = T - 1;
     }
     for (int l = up_start; l >= 1; --l) {
