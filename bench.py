@@ -124,7 +124,8 @@ def main():
 
     # ---- synthetic clip, staged in HBM: ring x B x h x w x 3 (stream s uses seed 1234 + s) ----
     ring = args.ring
-    clips = [lvm.synth.Clip(seed=1234 + rank * B + s, **{k: v for k, v in ck.items() if k != "seed"}) for s in range(B)]
+    ids = lvm.sharding.stream_ids(rank, world, B)
+    clips = [lvm.synth.Clip(seed=lvm.sharding.stream_seed(i), **{k: v for k, v in ck.items() if k != "seed"}) for i in ids]
     host = np.empty((ring, B, h, w, ch), np.uint8)
     for t in range(ring):
         for s in range(B):
@@ -145,27 +146,13 @@ def main():
         return ctx.process_device(cp, d_in[t].data_ptr(), w, h, ch, w * ch, frame_bytes, d_out[t].data_ptr(), w * ch,
                                   frame_bytes, stream)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     n = 0
     for _ in range(args.warmup):
         step(n); n += 1
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(n); n += 1
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    barrier()
-    fps = world * B * args.steps / dt
+    base = n
+    dt = lvm.sharding.timed_steps(lambda i: step(base + i), args.steps, dist, torch.cuda.synchronize, torch.device("cuda", local_rank))
+    n += args.steps
+    fps = lvm.sharding.aggregate_fps(world, B, args.steps, dt)
 
     # ---- per-kernel timing pass (HIP events on the launch stream) -> roofline ----
     roofline = None

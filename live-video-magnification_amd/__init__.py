@@ -8,4 +8,4 @@ Import with importlib (the directory name contains a hyphen):
 """
 from .binding import (Context, LvmError, LvmParams, MagnificationMode, MagnificationParams,  # noqa: F401
                       MagnificationProcessor, PreprocessParams, ProcessorConfig, bind, load, to_c_params)
-from . import synth  # noqa: F401
+from . import sharding, synth  # noqa: F401

@@ -1,0 +1,41 @@
+"""The OpenCV-free C++ host wrapper (live-video-magnification_amd/host/lvm.hpp) compiles against
+include/lvm_hip.h and links to liblvm_hip.so; run without a GPU it must fail loudly (exception),
+never fall back to a CPU path."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "live-video-magnification_amd")
+
+SRC = r'''
+#include <cstdio>
+#include <vector>
+#include "lvm.hpp"
+int main() {
+    try {
+        lvm::Magnifier m(0, 1);
+        lvm::MagnificationParams p; p.mode = lvm::MagnificationMode::Laplace; p.levels = 2; p.amplification = 10;
+        p.coWavelength = 100; p.coLow = 0.1; p.coHigh = 0.4;
+        std::vector<unsigned char> in(64 * 48 * 3, 90), out(in.size());
+        bool produced = m.process(p, 0, in.data(), 64, 48, 3, 64 * 3, out.data(), 64 * 3);
+        std::printf("produced=%d first=%d\n", (int)produced, (int)out[0]);
+        m.reset();
+    } catch (const lvm::Error& e) { std::printf("lvm::Error %d: %s\n", e.status(), e.what()); return 3; }
+    return 0;
+}
+'''
+
+
+def test_cpp_wrapper_compiles_links_and_fails_loudly_without_gpu(tmp_path):
+    src = tmp_path / "t.cpp"
+    src.write_text(SRC)
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", str(src), "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(PKG, "host"), "-L", PKG, "-llvm_hip", "-Wl,-rpath," + PKG,
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    import torch
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and "produced=1" in r.stdout, r.stdout + r.stderr
+    else:
+        assert r.returncode == 3 and "lvm::Error -3" in r.stdout, r.stdout + r.stderr
