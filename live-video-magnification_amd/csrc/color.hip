@@ -50,86 +50,171 @@ __device__ __forceinline__ void block_minmax(float mn, float mx, int* gmn, int* 
     if (t == 0) { atomicMin(gmn, fkey(s_mn[0])); atomicMax(gmx, fkey(s_mx[0])); }
 }
 
-// img2tempMat (SpatialFilter.cpp:63-84): one window column per frame
-__global__ __launch_bounds__(256) void k_col_append(const float* __restrict__ GL, float* __restrict__ win_slot, int rows,
-                                                    MinMax* mm, int nstreams) {
+// img2tempMat (SpatialFilter.cpp:63-84): one window column per frame.  Window layout: win[row][slot]
+// (time-contiguous per row, ring of `cap` slots) so that a wave reads one row's history as one
+// contiguous run.
+__global__ __launch_bounds__(256) void k_col_append(const float* __restrict__ GL, float* __restrict__ win_rows, int rows,
+                                                    int cap, int slot, MinMax* mm, int nstreams) {
     const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r < rows) win_slot[r] = GL[r];
+    if (r < rows) win_rows[(size_t)r * cap + slot] = GL[r];
     if (blockIdx.x == 0 && (int)threadIdx.x < nstreams) {
         MinMax m;
         m.mn1 = m.mn2 = fkey(INFINITY); m.mx1 = m.mx2 = fkey(-INFINITY);
         mm[threadIdx.x] = m;
     }
 }
+// ring growth: copy the n live columns of every row into a larger ring, oldest column first
+__global__ __launch_bounds__(256) void k_col_regrow(const float* __restrict__ ow, int ocap, int slot0, int n,
+                                                    float* __restrict__ nw, int ncap, int rows) {
+    const int r = blockIdx.x, t0 = threadIdx.x;
+    if (r >= rows) return;
+    for (int t = t0; t < n; t += 256) nw[(size_t)r * ncap + t] = ow[(size_t)r * ocap + (slot0 + t) % ocap];
+}
 
-// idealFilter (TemporalFilter.cpp:24-57) for one row per thread.  n = window length, slot0 = ring
+// idealFilter (TemporalFilter.cpp:24-57): one WAVE per window row.  n = window length, slot0 = ring
 // index of the oldest column.  Packed (CCS) element x: [Re0, Re1, Im1, ..., Re(n/2) if n even].
-// The list of complex bins whose mask pair is not all-zero is built once per block in LDS; twiddle
-// indices (bin * t) mod n advance incrementally.  Sums run over t (forward) and over the needed
-// bins in ascending order (inverse) in float64, exactly like the oracle's direct evaluation.
-constexpr int kMaxBins = 2048;
-__global__ __launch_bounds__(256) void k_col_dft(const float* __restrict__ win, int slot0, int n, int cap, int rows,
-                                                 int rows_per_stream, int live_per_stream, double fl, double fh, const double* __restrict__ tw,
-                                                 float* __restrict__ Y, float* __restrict__ col1, MinMax* mm) {
-    __shared__ short s_bins[kMaxBins];
-    __shared__ int s_nb;
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    const bool live = r < rows && (r % rows_per_stream) < live_per_stream;   // padded rows never hold data
+// Entry list (built once per workgroup): the DC element, every complex bin whose mask pair is not
+// all-zero, the Nyquist element -- only those can be non-zero after mulSpectrums with the 0/1 mask.
+// Forward: lane j owns entry j and runs the float64 sum over t = 0..n-1 in order (samples are LDS
+// broadcasts).  Inverse: lane owns output samples t, t+64, ... and sums the entries in ascending
+// bin order.  Both are the oracle's summation orders, so results are order-faithful.
+constexpr int kDftMaxN = 1024;             // window lengths above this use k_col_dft_serial
+constexpr int kDftRows = 4;                // rows (waves) per workgroup
+struct DftEntry { short bin; short kind; };   // kind 0 = complex bin, 1 = DC, 2 = Nyquist
+__global__ __launch_bounds__(256) void k_col_dft(const float* __restrict__ win, int slot0, int n, int cap,
+                                                 int rows_per_stream, int live_per_stream, double fl, double fh,
+                                                 const double* __restrict__ tw, float* __restrict__ col1, MinMax* mm) {
+    __shared__ double s_tw[2 * kDftMaxN];
+    __shared__ float s_row[kDftRows][kDftMaxN];
+    __shared__ float s_y[kDftRows][kDftMaxN + 2];
+    __shared__ DftEntry s_ent[kDftMaxN / 2 + 2];
+    __shared__ int s_ne;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    auto m = [&](int x) { return (x >= fl && x <= fh) ? 1.0f : 0.0f; };              // :70-77
+    for (int i = threadIdx.x; i < 2 * n; i += 256) s_tw[i] = tw[i];
+    if (threadIdx.x == 0) {
+        int ne = 0;
+        const int half = (n - 1) / 2;
+        if (m(0) != 0.f) { s_ent[ne].bin = 0; s_ent[ne].kind = 1; ++ne; }
+        for (int k = 1; k <= half; ++k)
+            if (m(2 * k - 1) != 0.f || m(2 * k) != 0.f) { s_ent[ne].bin = (short)k; s_ent[ne].kind = 0; ++ne; }
+        if (n % 2 == 0 && m(n - 1) != 0.f) { s_ent[ne].bin = (short)(n / 2); s_ent[ne].kind = 2; ++ne; }
+        s_ne = ne;
+    }
+    __syncthreads();
+    const int ne = s_ne;
+    const double* cs = s_tw;
+    const double* sn = s_tw + n;
+    float vmin = INFINITY, vmax = -INFINITY;
+    const int iters = (live_per_stream + gridDim.x * kDftRows - 1) / (gridDim.x * kDftRows);
+    for (int it = 0; it < iters; ++it) {
+        const int r = (it * gridDim.x + blockIdx.x) * kDftRows + wv;
+        const bool live = r < live_per_stream;
+        const size_t grow = (size_t)b * rows_per_stream + (live ? r : 0);
+        if (live) {
+            const float* wr = win + grow * cap;
+            for (int t = lane; t < n; t += 64) { int slot = slot0 + t; if (slot >= cap) slot -= cap; s_row[wv][t] = wr[slot]; }
+        }
+        __syncthreads();
+        if (live) {
+            for (int j = lane; j < ne; j += 64) {                                     // dft + mulSpectrums
+                const int k = s_ent[j].bin, kind = s_ent[j].kind;
+                double ar = 0, ai = 0;
+                int idx = 0;
+                for (int t = 0; t < n; ++t) {
+                    const double v = (double)s_row[wv][t];
+                    ar += v * cs[idx];
+                    ai += -v * sn[idx];
+                    idx += k; if (idx >= n) idx -= n;
+                }
+                const float a = (float)(ar / n), bq = (float)(ai / n);
+                if (kind == 0) {
+                    const float ma = m(2 * k - 1), mb = m(2 * k);
+                    s_y[wv][2 * j] = a * ma - bq * mb;
+                    s_y[wv][2 * j + 1] = bq * ma + a * mb;
+                } else {
+                    s_y[wv][2 * j] = a * (kind == 1 ? m(0) : m(n - 1));
+                    s_y[wv][2 * j + 1] = 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        if (live) {
+            const bool has_dc = ne > 0 && s_ent[0].kind == 1;
+            const bool has_ny = ne > 0 && s_ent[ne - 1].kind == 2;
+            const int j0 = has_dc ? 1 : 0, j1 = has_ny ? ne - 1 : ne;
+            for (int t = lane; t < n; t += 64) {                                      // idft, every sample
+                double acc = has_dc ? s_y[wv][0] : 0.f;
+                for (int j = j0; j < j1; ++j) {
+                    const int k = s_ent[j].bin;
+                    const int idx = (int)(((unsigned)k * (unsigned)t) % (unsigned)n);
+                    acc += 2.0 * ((double)s_y[wv][2 * j] * cs[idx] - (double)s_y[wv][2 * j + 1] * sn[idx]);
+                }
+                if (n % 2 == 0) acc += (t % 2 ? -1.0 : 1.0) * (double)(has_ny ? s_y[wv][2 * (ne - 1)] : 0.f);
+                const float v = (float)(acc / n);
+                vmin = v < vmin ? v : vmin; vmax = v > vmax ? v : vmax;
+                if (t == 1) col1[grow] = v;                                           // MagnifyCore.hpp:190-192
+            }
+        }
+        __syncthreads();
+    }
+    block_minmax(vmin, vmax, &mm[b].mn1, &mm[b].mx1);
+}
+
+// Serial fallback for very long windows (n > kDftMaxN): one thread per row, same arithmetic.
+__global__ __launch_bounds__(256) void k_col_dft_serial(const float* __restrict__ win, int slot0, int n, int cap,
+                                                        int rows_per_stream, int live_per_stream, double fl, double fh,
+                                                        const double* __restrict__ tw, float* __restrict__ Y, float* __restrict__ col1,
+                                                        MinMax* mm) {
+    const int r = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    const bool live = r < live_per_stream;
+    const size_t grow = (size_t)b * rows_per_stream + (live ? r : 0);
     const double* cs = tw;
     const double* sn = tw + n;
     const int half = (n - 1) / 2;
-    auto m = [&](int x) { return (x >= fl && x <= fh) ? 1.0f : 0.0f; };              // :70-77
-    if (threadIdx.x == 0) {
-        int nb = 0;
-        for (int k = 1; k <= half && nb < kMaxBins; ++k)
-            if (m(2 * k - 1) != 0.f || m(2 * k) != 0.f) s_bins[nb++] = (short)k;
-        s_nb = nb;
-    }
-    __syncthreads();
-    const int nb = s_nb;
+    auto m = [&](int x) { return (x >= fl && x <= fh) ? 1.0f : 0.0f; };
     float vmin = INFINITY, vmax = -INFINITY;
     if (live) {
-        auto dot = [&](int bin, bool im) {                                            // dft(DFT_ROWS | DFT_SCALE)
+        const float* wr = win + grow * cap;
+        float* Yr = Y + grow * cap;
+        auto dot = [&](int bin, bool im) {
             double acc = 0;
             int idx = 0, slot = slot0;
             for (int t = 0; t < n; ++t) {
-                const double v = (double)win[(size_t)slot * rows + r];
+                const double v = (double)wr[slot];
                 acc += im ? -v * sn[idx] : v * cs[idx];
                 idx += bin; if (idx >= n) idx -= n;
                 if (++slot >= cap) slot -= cap;
             }
             return (float)(acc / n);
         };
-        // forward + mulSpectrums (packed complex product with the 0/1 mask), needed elements only
         const float m0 = m(0);
         const float y0 = m0 != 0.f ? dot(0, false) * m0 : 0.f;
-        for (int i = 0; i < nb; ++i) {
-            const int k = s_bins[i];
+        for (int k = 1; k <= half; ++k) {
             const float ma = m(2 * k - 1), mb = m(2 * k);
-            const float a = dot(k, false), b = dot(k, true);
-            Y[(size_t)(2 * k - 1) * rows + r] = a * ma - b * mb;
-            Y[(size_t)(2 * k) * rows + r] = b * ma + a * mb;
+            if (ma == 0.f && mb == 0.f) continue;
+            const float a = dot(k, false), bq = dot(k, true);
+            Yr[2 * k - 1] = a * ma - bq * mb;
+            Yr[2 * k] = bq * ma + a * mb;
         }
         float yl = 0.f;
         const float ml = (n % 2 == 0) ? m(n - 1) : 0.f;
         if (ml != 0.f) yl = dot(n / 2, false) * ml;
-        // idft(DFT_ROWS | DFT_SCALE) of every sample; only the range and column 1 are kept
         for (int t = 0; t < n; ++t) {
             double acc = y0;
-            for (int i = 0; i < nb; ++i) {
-                const int k = s_bins[i];
-                const int idx = (int)(((unsigned)k * (unsigned)t) % (unsigned)n);
-                acc += 2.0 * ((double)Y[(size_t)(2 * k - 1) * rows + r] * cs[idx] - (double)Y[(size_t)(2 * k) * rows + r] * sn[idx]);
+            for (int k = 1; k <= half; ++k) {
+                if (m(2 * k - 1) == 0.f && m(2 * k) == 0.f) continue;
+                const int idx = (int)(((unsigned long long)k * (unsigned long long)t) % (unsigned long long)n);
+                acc += 2.0 * ((double)Yr[2 * k - 1] * cs[idx] - (double)Yr[2 * k] * sn[idx]);
             }
             if (n % 2 == 0) acc += (t % 2 ? -1.0 : 1.0) * (double)yl;
             const float v = (float)(acc / n);
             vmin = v < vmin ? v : vmin; vmax = v > vmax ? v : vmax;
-            if (t == 1) col1[r] = v;                                                  // MagnifyCore.hpp:190-192
+            if (t == 1) col1[grow] = v;
         }
     }
-    // blocks never straddle streams (rows_per_stream is padded to a multiple of 256 by the launcher)
-    const int sidx = (blockIdx.x * 256) / rows_per_stream;
-    block_minmax(vmin, vmax, &mm[sidx].mn1, &mm[sidx].mx1);
+    block_minmax(vmin, vmax, &mm[b].mn1, &mm[b].mx1);
 }
 
 // normalize(0, 1, NORM_MINMAX) (TemporalFilter.cpp:55) of column 1, x amplification (MagnifyCore.hpp:185)
@@ -329,11 +414,8 @@ static int color_reserve(Ctx* c, ColorState* st, int need, hipStream_t s) {
     float *nw = nullptr, *ny = nullptr;
     LVM_HIP_TRY(c, hipMalloc((void**)&nw, (size_t)ncap * st->rows * sizeof(float)));
     LVM_HIP_TRY(c, hipMalloc((void**)&ny, (size_t)ncap * st->rows * sizeof(float)));
+    if (st->n > 0) hipLaunchKernelGGL(k_col_regrow, dim3(st->rows), dim3(256), 0, s, (const float*)st->win, st->cap, st->slot0, st->n, nw, ncap, st->rows);
     LVM_HIP_TRY(c, hipStreamSynchronize(s));
-    for (int t = 0; t < st->n; ++t) {
-        const int slot = (st->slot0 + t) % st->cap;
-        LVM_HIP_TRY(c, hipMemcpy(nw + (size_t)t * st->rows, st->win + (size_t)slot * st->rows, (size_t)st->rows * sizeof(float), hipMemcpyDeviceToDevice));
-    }
     if (st->win) (void)hipFree(st->win);
     if (st->Y) (void)hipFree(st->Y);
     st->win = nw; st->Y = ny; st->cap = ncap; st->slot0 = 0;
@@ -355,8 +437,15 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
     {
         const LevelGeom& g1 = st->g[1];
         const dim3 grid0((g1.w + 31) / 32, (g1.h + 15) / 16, NS);
-        auto kd0 = (C == 3) ? k_down0<3, false, true> : k_down0<1, false, true>;
-        LVM_LAUNCH(c, "col_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, st->G[1], g1.w, g1.h, c->lab, 1.0f);
+        const bool vec4 = C == 3 && w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0;
+        if (vec4) {
+            auto kv = k_down0_v4<false, true>;
+            LVM_LAUNCH(c, "col_down0", kv, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h,
+                       st->G[1], g1.w, g1.h, c->lab);
+        } else {
+            auto kd0 = (C == 3) ? k_down0<3, false, true> : k_down0<1, false, true>;
+            LVM_LAUNCH(c, "col_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, st->G[1], g1.w, g1.h, c->lab, 1.0f);
+        }
         for (int l = 1; l < levels; ++l) {
             const LevelGeom &a = st->g[l], &b = st->g[l + 1];
             const dim3 grid((b.w + 31) / 32, (b.h + 15) / 16, st->planes);
@@ -377,7 +466,7 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         for (int b = 0; b < NS; ++b) {
             const dim3 grid((nL * C + 255) / 256);
             LVM_LAUNCH(c, "col_append", k_col_append, grid, blk, s, (const float*)(st->G[levels] + (size_t)b * C * nL),
-                       st->win + (size_t)slot * st->rows + (size_t)b * st->rows_ps, nL * C, st->mm, b == 0 ? NS : 0);
+                       st->win + (size_t)b * st->rows_ps * st->cap, nL * C, st->cap, slot, st->mm, b == 0 ? NS : 0);
         }
         st->n += 1;
         if (st->n > maxImages && maxImages > 0) { st->slot0 = (st->slot0 + 1) % st->cap; st->n -= 1; }
@@ -400,9 +489,16 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
     const float width = (float)n;
     const double fl = 2 * lo * width / p.framerate, fh = 2 * hi * width / p.framerate; // :65-66
     {
-        const dim3 grid(st->rows / 256);
-        LVM_LAUNCH(c, "col_dft", k_col_dft, grid, blk, s, (const float*)st->win, st->slot0, n, st->cap, st->rows, st->rows_ps, nL * C, fl, fh,
-                   (const double*)st->tw, st->Y, st->col1, st->mm);
+        const int live = nL * C;
+        if (n <= kDftMaxN) {
+            int gx = (live + kDftRows - 1) / kDftRows;
+            gx = gx < 1024 ? gx : 1024;
+            LVM_LAUNCH(c, "col_dft", k_col_dft, dim3(gx, NS), blk, s, (const float*)st->win, st->slot0, n, st->cap, st->rows_ps, live, fl, fh,
+                       (const double*)st->tw, st->col1, st->mm);
+        } else {
+            LVM_LAUNCH(c, "col_dft", k_col_dft_serial, dim3((live + 255) / 256, NS), blk, s, (const float*)st->win, st->slot0, n, st->cap,
+                       st->rows_ps, live, fl, fh, (const double*)st->tw, st->Y, st->col1, st->mm);
+        }
     }
     for (int b = 0; b < NS; ++b) {
         const dim3 grid((nL * C + 255) / 256);

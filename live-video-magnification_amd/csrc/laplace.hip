@@ -143,99 +143,6 @@ __global__ __launch_bounds__(256) void k_lap_final(const uint8_t* __restrict__ i
 // operation order as k_down0 / k_lap_final; only the data movement differs: one 12-byte load or
 // store per 4 pixels instead of 12 byte accesses, 128-bit LDS reads, no per-pixel index math.
 // ------------------------------------------------------------------------------------------
-struct __attribute__((packed, aligned(4))) Px4 { uint32_t a, b, c; };   // 4 BGR pixels
-
-__device__ __forceinline__ void unpack_px4(const Px4 v, int (&B)[4], int (&G)[4], int (&R)[4]) {
-    B[0] = v.a & 255; G[0] = (v.a >> 8) & 255; R[0] = (v.a >> 16) & 255;
-    B[1] = v.a >> 24; G[1] = v.b & 255; R[1] = (v.b >> 8) & 255;
-    B[2] = (v.b >> 16) & 255; G[2] = v.b >> 24; R[2] = v.c & 255;
-    B[3] = (v.c >> 8) & 255; G[3] = (v.c >> 16) & 255; R[3] = v.c >> 24;
-}
-
-// u8 BGR -> Lab -> pyrDown -> G_1.  Output tile 32x16; the Lab source tile (35 rows x 72 columns
-// starting at source column 64*tx - 4) is staged planar in LDS with a +2 column offset so that the
-// 8 floats a pair of adjacent outputs needs are two aligned 128-bit reads; the vertical pass
-// slides a 5-row register window (no intermediate LDS image).
-constexpr int D0_ROWS = 2 * DT_H + 3, D0_GROUPS = 18, D0_PITCH = 76;
-template <bool EXACT>
-__global__ __launch_bounds__(256) void k_down0_v4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
-                                                  int w, int h, float* __restrict__ G1, int w1, int h1, LabCoef lab) {
-    __shared__ __attribute__((aligned(16))) float s_src[3][D0_ROWS][D0_PITCH];
-    __shared__ float s_gam[256];
-    load_gamma_u8(s_gam, lab.gamma_u8);
-    __syncthreads();
-    const int b = blockIdx.z;
-    const int ox0 = blockIdx.x * DT_W, oy0 = blockIdx.y * DT_H;
-    const int sx0 = 2 * ox0 - 4, sy0 = 2 * oy0 - 2;
-    const uint8_t* src = in + (size_t)b * in_sstride;
-    // all global loads of this thread are issued before the first use (3 pixel groups per thread)
-    constexpr int NG = (D0_ROWS * D0_GROUPS + 255) / 256;
-    Px4 pv[NG];
-    int prow[NG], pgy[NG], pgx[NG];
-#pragma unroll
-    for (int k = 0; k < NG; ++k) {
-        const int i = threadIdx.x + k * 256;
-        const int r = i / D0_GROUPS, g = i - r * D0_GROUPS;
-        prow[k] = i < D0_ROWS * D0_GROUPS ? r : -1;
-        pgy[k] = reflect101(sy0 + (r < D0_ROWS ? r : 0), h);
-        pgx[k] = sx0 + 4 * g;
-        pv[k].a = pv[k].b = pv[k].c = 0;
-        if (prow[k] >= 0 && pgx[k] >= 0 && pgx[k] + 3 < w)
-            pv[k] = *reinterpret_cast<const Px4*>(src + (size_t)pgy[k] * in_stride + (size_t)pgx[k] * 3);
-    }
-#pragma unroll
-    for (int k = 0; k < NG; ++k) {
-        if (prow[k] < 0) continue;
-        const int r = prow[k], gy = pgy[k], gx0 = pgx[k], g = (gx0 - sx0) >> 2;
-        int Bv[4], Gv[4], Rv[4];
-        if (gx0 >= 0 && gx0 + 3 < w) {
-            unpack_px4(pv[k], Bv, Gv, Rv);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint8_t* p = src + (size_t)gy * in_stride + (size_t)reflect101(gx0 + q, w) * 3;
-                Bv[q] = p[0]; Gv[q] = p[1]; Rv[q] = p[2];
-            }
-        }
-        float L[4], A[4], Bb[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) lin_bgr_to_lab<EXACT>(s_gam[Bv[q]], s_gam[Gv[q]], s_gam[Rv[q]], lab.fwd, L[q], A[q], Bb[q]);
-        float* d0 = &s_src[0][r][4 * g + 2];
-        float* d1 = &s_src[1][r][4 * g + 2];
-        float* d2 = &s_src[2][r][4 * g + 2];
-        *reinterpret_cast<float2*>(d0) = make_float2(L[0], L[1]); *reinterpret_cast<float2*>(d0 + 2) = make_float2(L[2], L[3]);
-        *reinterpret_cast<float2*>(d1) = make_float2(A[0], A[1]); *reinterpret_cast<float2*>(d1 + 2) = make_float2(A[2], A[3]);
-        *reinterpret_cast<float2*>(d2) = make_float2(Bb[0], Bb[1]); *reinterpret_cast<float2*>(d2 + 2) = make_float2(Bb[2], Bb[3]);
-    }
-    __syncthreads();
-    if (threadIdx.x < 192) {
-        const int pair = threadIdx.x & 15, seg = (threadIdx.x >> 4) & 3, ch = threadIdx.x >> 6;
-        const int x = 2 * pair;                       // tile-local output column (and x + 1)
-        float w0a = 0, w1a = 0, w2a = 0, w3a = 0, w0b = 0, w1b = 0, w2b = 0, w3b = 0;
-        float* dst = G1 + ((size_t)b * 3 + ch) * ((size_t)w1 * h1);
-#pragma unroll
-        for (int rr = 0; rr < 11; ++rr) {
-            const float* row = &s_src[ch][8 * seg + rr][4 * pair + 4];
-            const float4 u = *reinterpret_cast<const float4*>(row);
-            const float4 v = *reinterpret_cast<const float4*>(row + 4);
-            // taps of output x: u.x u.y u.z u.w v.x ; of output x+1: u.z u.w v.x v.y v.z
-            const float ha = u.z * 6.f + (u.y + u.w) * 4.f + u.x + v.x;
-            const float hb = v.x * 6.f + (u.w + v.y) * 4.f + u.z + v.z;
-            if (rr >= 4 && (rr & 1) == 0) {
-                const int gy = oy0 + 4 * seg + (rr - 4) / 2, gx = ox0 + x;
-                const float oa = (w2a * 6.f + (w1a + w3a) * 4.f + w0a + ha) * (1.f / 256.f);
-                const float ob = (w2b * 6.f + (w1b + w3b) * 4.f + w0b + hb) * (1.f / 256.f);
-                if (gy < h1) {
-                    if (gx < w1) dst[(size_t)gy * w1 + gx] = oa;
-                    if (gx + 1 < w1) dst[(size_t)gy * w1 + gx + 1] = ob;
-                }
-            }
-            w0a = w1a; w1a = w2a; w2a = w3a; w3a = ha;
-            w0b = w1b; w1b = w2b; w2b = w3b; w3b = hb;
-        }
-    }
-}
-
 // pyrUp horizontal pass for 4 consecutive destination columns gx0..gx0+3 (gx0 even) from the source
 // values s[i0-1..i0+2], i0 = gx0/2 (indices outside the plane are never used by the border rules)
 __device__ __forceinline__ float4 pyrup_h4(float sm1, float s0, float s1, float s2, int i0, int sw) {
@@ -569,7 +476,7 @@ int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, 
         const LevelGeom& g1 = st->g[1];
         const dim3 grid0((g1.w + DT_W - 1) / DT_W, (g1.h + DT_H - 1) / DT_H, NS);
         if (vec4) {
-            auto kd0 = c->exact_lab ? k_down0_v4<true> : k_down0_v4<false>;
+            auto kd0 = c->exact_lab ? k_down0_v4<true, true> : k_down0_v4<true, false>;
             LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
                        st->G[1], g1.w, g1.h, c->lab);
         } else {
