@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--ring", type=int, default=16, help="distinct input frames kept in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--pipeline", type=int, default=1, help="cross-frame pipeline depth of lvm_process_device (0 or 1)")
     ap.add_argument("--profile-steps", type=int, default=60)
     args = ap.parse_args()
 
@@ -137,6 +138,7 @@ def main():
     ctx = lvm.Context(local_rank, B)
     if args.no_graph:
         ctx.set_graph(False)
+    ctx.set_pipeline(args.pipeline)
     cp = lvm.LvmParams(pk["mode"], pk["levels"], pk["amplification"], pk["coWavelength"], pk["coLow"], pk["coHigh"],
                        pk["chromAttenuation"], pk["framerate"], 0)
     stream = torch.cuda.current_stream().cuda_stream
@@ -150,7 +152,8 @@ def main():
     for _ in range(args.warmup):
         step(n); n += 1
     base = n
-    dt = lvm.sharding.timed_steps(lambda i: step(base + i), args.steps, dist, torch.cuda.synchronize, torch.device("cuda", local_rank))
+    dt = lvm.sharding.timed_steps(lambda i: step(base + i), args.steps, dist, torch.cuda.synchronize, torch.device("cuda", local_rank),
+                                  finish=lambda: ctx.flush(stream))
     n += args.steps
     fps = lvm.sharding.aggregate_fps(world, B, args.steps, dt)
 
@@ -158,6 +161,8 @@ def main():
     roofline = None
     kernels = {}
     if rank == 0 and args.profile_steps > 0:
+        ctx.flush(stream)
+        ctx.set_pipeline(0)           # per-kernel event timing uses the plain schedule
         ctx.profile(True)
         for _ in range(args.profile_steps):
             step(n); n += 1
@@ -208,7 +213,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d, %d levels, %d stream(s)/GPU, device-resident u8 BGR in/out" %
                                    (args.mode, w, h, levels, B),
-                       "baseline_config": cfg_idx, "streams_per_gpu": B, "ring_frames": ring},
+                       "baseline_config": cfg_idx, "streams_per_gpu": B, "ring_frames": ring,
+                       "pipeline_depth": args.pipeline, "hip_graph": not args.no_graph},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "frame_alg_bytes": b_alg, "frame_roofline_frac": round(frame_frac, 5),

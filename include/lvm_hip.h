@@ -82,6 +82,17 @@ int  lvm_process_device(lvm_ctx* ctx, const lvm_params* p, const uint8_t* d_in, 
                         uint8_t* d_out, ptrdiff_t out_stride, ptrdiff_t out_stream_stride,
                         int* produced, void* hip_stream);
 
+/* Cross-frame software pipeline for lvm_process_device (throughput mode, default depth 0).
+ * depth 1 (implemented for the Laplace mode; other modes ignore it): a call enqueues the
+ * down-sweep of ITS frame on an internal second stream concurrently with the up-sweep + output of
+ * the PREVIOUS frame, so the output of call t is written (into the d_out given at call t) when
+ * call t+1 -- or lvm_flush -- has been enqueued.  d_in / d_out of a call must stay valid until
+ * then.  Results are identical to depth 0; only the schedule differs.  lvm_process (host path) and
+ * the reference shim always run at depth 0.                                                   */
+int  lvm_set_pipeline(lvm_ctx* ctx, int depth);
+/* Enqueue whatever the pipeline still holds on `hip_stream` (NULL = the context's own stream). */
+int  lvm_flush(lvm_ctx* ctx, void* hip_stream);
+
 /* Wait for everything enqueued by lvm_process_device on the context's own stream. */
 int  lvm_synchronize(lvm_ctx* ctx);
 

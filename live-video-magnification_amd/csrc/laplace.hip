@@ -20,6 +20,8 @@
 //   k_lap_final           out = u8(Lab2BGR(Lab(u8 in) + [1,ca,ca] * pyrUp(cur_1)))
 // All stencils are LDS-staged tiles; pyrDown/pyrUp follow OpenCV's border rules and operation
 // order exactly (see the per-kernel comments) so the result is order-faithful to the oracle.
+#include <cstring>
+
 #include "pyramid.h"
 
 namespace lvm {
@@ -378,9 +380,27 @@ struct LaplaceState : ModeState {
     float* G[kMaxLevels + 1] = {};
     float *hi[kMaxLevels + 1] = {}, *lo[kMaxLevels + 1] = {}, *cur[kMaxLevels + 1] = {};
     bool seeded = false;
+    float* Gp[2][kMaxLevels + 1] = {};    // Gaussian pyramid, double-buffered by frame parity (pipelined mode)
+    float* curT[2] = {};                  // cur_T written by the tail kernel, double-buffered likewise
+    struct Pending { bool valid = false; FrameIO io{}; lvm_params p{}; int par = 0; } pending;
+    int par = 0, depth = 0;
     int tailT = 0;                       // first level handled by k_lap_tail (0 = tail disabled)
     TailArgs tail{};
-    bool steady(const lvm_params&) const override { return seeded; }
+    bool steady(const lvm_params&) const override { return seeded && (depth == 0 || pending.valid); }
+    void advance(const lvm_params& p, const FrameIO& io) override {
+        if (depth == 0) return;
+        pending.valid = true; pending.io = io; pending.p = p; pending.par = par;
+        par ^= 1;
+    }
+    size_t key_extra(uint8_t* buf, size_t cap) const override {
+        struct { FrameIO io; lvm_params p; int par, cur, depth; } k;
+        std::memset(&k, 0, sizeof(k));
+        if (pending.valid) { k.io = pending.io; k.p = pending.p; k.par = pending.par; }
+        k.cur = par; k.depth = depth;
+        if (sizeof(k) > cap) return 0;
+        std::memcpy(buf, &k, sizeof(k));
+        return sizeof(k);
+    }
     ~LaplaceState() override { if (arena) (void)hipFree(arena); }
 };
 
@@ -396,8 +416,8 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     }
     size_t total = 0;
     auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
-    for (int l = 1; l <= levels; ++l) total += pad(st->g[l].n * st->planes);
-    for (int l = 1; l < levels; ++l) total += 3 * pad(st->g[l].n * st->planes);
+    for (int l = 1; l <= levels; ++l) total += 2 * pad(st->g[l].n * st->planes);
+    for (int l = 1; l < levels; ++l) total += 5 * pad(st->g[l].n * st->planes);
     if (total == 0) total = 64;
     if (hipMalloc((void**)&st->arena, total * sizeof(float)) != hipSuccess) {
         c->err = "laplace: hipMalloc failed";
@@ -405,13 +425,19 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
         return LVM_ERR_OOM;
     }
     float* p = st->arena;
-    for (int l = 1; l <= levels; ++l) { st->G[l] = p; p += pad(st->g[l].n * st->planes); }
+    for (int q = 0; q < 2; ++q)
+        for (int l = 1; l <= levels; ++l) { st->Gp[q][l] = p; p += pad(st->g[l].n * st->planes); }
+    for (int l = 1; l <= levels; ++l) st->G[l] = st->Gp[0][l];
     for (int l = 1; l < levels; ++l) {
         st->hi[l] = p; p += pad(st->g[l].n * st->planes);
         st->lo[l] = p; p += pad(st->g[l].n * st->planes);
         st->cur[l] = p; p += pad(st->g[l].n * st->planes);
     }
     laplace_tail_plan(st);
+    if (st->tailT) {
+        st->curT[0] = p; p += pad(st->g[st->tailT].n * st->planes);
+        st->curT[1] = p; p += pad(st->g[st->tailT].n * st->planes);
+    }
     return LVM_OK;
 }
 
@@ -454,63 +480,65 @@ static void laplace_gains(int w, int h, int levels, double amplification, double
     }
 }
 
-int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced) {
-    LaplaceState* st = static_cast<LaplaceState*>(c->state);
-    if (!st) {
-        st = new LaplaceState();
-        c->state = st;
-        const int rc = laplace_alloc(c, st, io.w, io.h, io.channels, levels);
-        if (rc != LVM_OK) return rc;
-    }
-    const int C = io.channels, NS = c->nstreams;
-    const dim3 blk(256);
-    const bool first = !st->seeded;
-    float* dbg = c->keep_float ? c->d_float : nullptr;
-    // 4-pixel (12-byte) vector I/O needs dword-aligned pixel groups
-    const bool vec4 = C == 3 && io.w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 &&
-                      io.out_stride % 4 == 0 && io.out_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0 &&
-                      ((uintptr_t)io.d_out % 4) == 0;
+static bool lap_vec4(const FrameIO& io) {   // 4-pixel (12-byte) vector I/O needs dword-aligned pixel groups
+    return io.channels == 3 && io.w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 &&
+           io.out_stride % 4 == 0 && io.out_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0 &&
+           ((uintptr_t)io.d_out % 4) == 0;
+}
 
-    // ---- down sweep: Gaussian pyramid G_1..G_L (needed when any live band exists) ----
-    if (levels >= 2) {
-        const LevelGeom& g1 = st->g[1];
-        const dim3 grid0((g1.w + DT_W - 1) / DT_W, (g1.h + DT_H - 1) / DT_H, NS);
-        if (vec4) {
-            auto kd0 = c->exact_lab ? k_down0_v4<true, true> : k_down0_v4<true, false>;
-            LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
-                       st->G[1], g1.w, g1.h, c->lab);
-        } else {
-            auto kd0 = (C == 3) ? (c->exact_lab ? k_down0<3, true, true> : k_down0<3, true, false>) : k_down0<1, false, true>;
-            LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
-                       st->G[1], g1.w, g1.h, c->lab, c->lab.a255);
-        }
-        const int down_end = st->tailT ? st->tailT : levels;          // the tail builds G_{T+1..L} itself
-        for (int l = 1; l < down_end; ++l) {
-            const LevelGeom &a = st->g[l], &b = st->g[l + 1];
-            const dim3 grid((b.w + DT_W - 1) / DT_W, (b.h + DT_H - 1) / DT_H, st->planes);
-            LVM_LAUNCH(c, "pyr_down", k_pyr_down<0>, grid, blk, s, (const float*)st->G[l], a.w, a.h, st->G[l + 1], b.w, b.h);
-        }
+// Stage B of a frame: u8 -> Lab -> Gaussian pyramid G_1..G_T (parity buffer `par`) and, when the tail
+// kernel is enabled, everything that happens at the levels >= T (their IIR states, cur_T[par]).
+static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, int par, bool first, hipStream_t s) {
+    const int C = io.channels, NS = c->nstreams, levels = st->levels;
+    const dim3 blk(256);
+    if (levels < 2) return;
+    float** G = st->Gp[par];
+    const LevelGeom& g1 = st->g[1];
+    const dim3 grid0((g1.w + DT_W - 1) / DT_W, (g1.h + DT_H - 1) / DT_H, NS);
+    if (lap_vec4(io)) {
+        auto kd0 = c->exact_lab ? k_down0_v4<true, true> : k_down0_v4<true, false>;
+        LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
+                   G[1], g1.w, g1.h, c->lab);
+    } else {
+        auto kd0 = (C == 3) ? (c->exact_lab ? k_down0<3, true, true> : k_down0<3, true, false>) : k_down0<1, false, true>;
+        LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
+                   G[1], g1.w, g1.h, c->lab, c->lab.a255);
     }
-    // ---- up sweep ----
-    float gains[kMaxLevels + 2];
-    laplace_gains(io.w, io.h, levels, p.amplification, p.coWavelength, gains);
-    double cLo = p.coLow, cHi = p.coHigh;
-    if (cLo == 0) cLo = 0.01;                                            // TemporalFilter.cpp:11-12
-    int up_start = levels - 1;
+    const int down_end = st->tailT ? st->tailT : levels;          // the tail builds G_{T+1..L} itself
+    for (int l = 1; l < down_end; ++l) {
+        const LevelGeom &a = st->g[l], &b = st->g[l + 1];
+        const dim3 grid((b.w + DT_W - 1) / DT_W, (b.h + DT_H - 1) / DT_H, st->planes);
+        LVM_LAUNCH(c, "pyr_down", k_pyr_down<0>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b.w, b.h);
+    }
     if (st->tailT) {
+        float gains[kMaxLevels + 2];
+        laplace_gains(io.w, io.h, levels, p.amplification, p.coWavelength, gains);
+        double cLo = p.coLow, cHi = p.coHigh;
+        if (cLo == 0) cLo = 0.01;                                        // TemporalFilter.cpp:11-12
         TailArgs& t = st->tail;
         const int T = st->tailT;
-        t.GT = st->G[T]; t.curT = st->cur[T];
+        t.GT = G[T]; t.curT = st->curT[par];
         for (int k = 0; k < t.n; ++k) { t.hi[k] = st->hi[T + k]; t.lo[k] = st->lo[T + k]; t.gain[k] = gains[T + k]; }
         t.aHi = (float)(1 - cHi); t.bHi = (float)cHi; t.aLo = (float)(1 - cLo); t.bLo = (float)cLo;
         if (first) LVM_LAUNCH(c, "lap_tail_seed", k_lap_tail<true>, dim3(st->planes), dim3(TAIL_THREADS), s, t);
         else LVM_LAUNCH(c, "lap_tail", k_lap_tail<false>, dim3(st->planes), dim3(TAIL_THREADS), s, t);
-        up_start = T - 1;
     }
+}
+
+// Stage A of a frame: the fused band/IIR/collapse steps of the levels below T and the final kernel.
+static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, int par, bool first, hipStream_t s) {
+    const int C = io.channels, NS = c->nstreams, levels = st->levels;
+    const dim3 blk(256);
+    float** G = st->Gp[par];
+    float gains[kMaxLevels + 2];
+    laplace_gains(io.w, io.h, levels, p.amplification, p.coWavelength, gains);
+    double cLo = p.coLow, cHi = p.coHigh;
+    if (cLo == 0) cLo = 0.01;                                            // TemporalFilter.cpp:11-12
+    const int up_start = st->tailT ? st->tailT - 1 : levels - 1;
     for (int l = up_start; l >= 1; --l) {
         UpArgs a;
-        a.Gl = st->G[l]; a.Gn = st->G[l + 1];
-        a.curn = (l + 1 <= levels - 1) ? st->cur[l + 1] : nullptr;
+        a.Gl = G[l]; a.Gn = G[l + 1];
+        a.curn = (l + 1 <= levels - 1) ? ((st->tailT && l + 1 == st->tailT) ? st->curT[par] : st->cur[l + 1]) : nullptr;
         a.hi = st->hi[l]; a.lo = st->lo[l]; a.cur = st->cur[l];
         a.w = st->g[l].w; a.h = st->g[l].h; a.wn = st->g[l + 1].w; a.hn = st->g[l + 1].h;
         a.aHi = (float)(1 - cHi); a.bHi = (float)cHi; a.aLo = (float)(1 - cLo); a.bLo = (float)cLo;
@@ -519,24 +547,69 @@ int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, 
         if (first) LVM_LAUNCH(c, "lap_seed", k_lap_up<true>, grid, blk, s, a);
         else LVM_LAUNCH(c, "lap_up", k_lap_up<false>, grid, blk, s, a);
     }
-    // ---- final ----
-    {
-        const int tx = (io.w + UT_W - 1) / UT_W, ty = (io.h + UT_H - 1) / UT_H;
-        const int ntiles = tx * ty * NS;
-        const dim3 grid(ntiles < 2048 ? ntiles : 2048);
-        const bool motion = !first && levels >= 2;
-        const float ca = (float)p.chromAttenuation;
-        const float* cur1 = motion ? st->cur[1] : nullptr;
-        const int w1 = st->g[1].w, h1 = st->g[1].h;
-        auto kf4 = motion ? (c->exact_lab ? k_lap_final_v4<true, true> : k_lap_final_v4<true, false>)
-                          : (c->exact_lab ? k_lap_final_v4<false, true> : k_lap_final_v4<false, false>);
-        auto kf = (C == 3) ? (motion ? (c->exact_lab ? k_lap_final<3, true, true> : k_lap_final<3, true, false>)
-                                     : (c->exact_lab ? k_lap_final<3, false, true> : k_lap_final<3, false, false>))
-                           : (motion ? k_lap_final<1, true, true> : k_lap_final<1, false, true>);
-        const int groups = (ntiles + FQ - 1) / FQ;
-        const dim3 grid4(groups < 256 ? groups : 256), blk4(1024);
-        LVM_LAUNCH(c, "lap_final", vec4 ? kf4 : kf, vec4 ? grid4 : grid, vec4 ? blk4 : blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
-                   (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, tx, ty, NS, dbg);
+    const int tx = (io.w + UT_W - 1) / UT_W, ty = (io.h + UT_H - 1) / UT_H;
+    const int ntiles = tx * ty * NS;
+    const dim3 grid(ntiles < 2048 ? ntiles : 2048);
+    const bool motion = !first && levels >= 2;
+    const float ca = (float)p.chromAttenuation;
+    const float* cur1 = motion ? ((st->tailT == 1) ? st->curT[par] : st->cur[1]) : nullptr;
+    const int w1 = st->g[1].w, h1 = st->g[1].h;
+    float* dbg = c->keep_float ? c->d_float : nullptr;
+    auto kf4 = motion ? (c->exact_lab ? k_lap_final_v4<true, true> : k_lap_final_v4<true, false>)
+                      : (c->exact_lab ? k_lap_final_v4<false, true> : k_lap_final_v4<false, false>);
+    auto kf = (C == 3) ? (motion ? (c->exact_lab ? k_lap_final<3, true, true> : k_lap_final<3, true, false>)
+                                 : (c->exact_lab ? k_lap_final<3, false, true> : k_lap_final<3, false, false>))
+                       : (motion ? k_lap_final<1, true, true> : k_lap_final<1, false, true>);
+    const int groups = (ntiles + FQ - 1) / FQ;
+    const dim3 grid4(groups < 256 ? groups : 256), blk4(1024);
+    const bool vec4 = lap_vec4(io);
+    LVM_LAUNCH(c, "lap_final", vec4 ? kf4 : kf, vec4 ? grid4 : grid, vec4 ? blk4 : blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
+               (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, tx, ty, NS, dbg);
+}
+
+// Emits stage A of the pending frame (pipelined mode): its output lands in the d_out it was given.
+int laplace_flush(Ctx* c, hipStream_t s) {
+    LaplaceState* st = dynamic_cast<LaplaceState*>(c->state);
+    if (!st || !st->pending.valid) return LVM_OK;
+    lap_stage_a(c, st, st->pending.p, st->pending.io, st->pending.par, false, s);
+    st->pending.valid = false;
+    LVM_HIP_TRY(c, hipGetLastError());
+    return LVM_OK;
+}
+
+int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced) {
+    LaplaceState* st = static_cast<LaplaceState*>(c->state);
+    if (!st) {
+        st = new LaplaceState();
+        c->state = st;
+        const int rc = laplace_alloc(c, st, io.w, io.h, io.channels, levels);
+        if (rc != LVM_OK) return rc;
+    }
+    const bool first = !st->seeded;
+    st->depth = c->pipeline_depth;
+    if (first || c->pipeline_depth == 0 || !c->aux_stream) {
+        // plain schedule: both stages of this frame back to back on the caller's stream
+        if (st->pending.valid) { const int rc = laplace_flush(c, s); if (rc != LVM_OK) return rc; }
+        lap_stage_b(c, st, p, io, 0, first, s);
+        lap_stage_a(c, st, p, io, 0, first, s);
+        st->par = 1;
+    } else {
+        // depth-1 software pipeline across frames: stage B of THIS frame runs on the auxiliary stream
+        // concurrently with stage A of the PREVIOUS frame.  The two touch disjoint buffers: G_1..G_T and
+        // cur_T are double-buffered by frame parity, the IIR states are split at level T.
+        const int par = st->par;
+        if (st->pending.valid) {
+            LVM_HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+            LVM_HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+            lap_stage_b(c, st, p, io, par, false, c->aux_stream);
+            LVM_HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
+            lap_stage_a(c, st, st->pending.p, st->pending.io, st->pending.par, false, s);
+            LVM_HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
+        } else {
+            lap_stage_b(c, st, p, io, par, false, s);
+        }
+        st->pending.valid = true; st->pending.io = io; st->pending.p = p; st->pending.par = par;
+        st->par = par ^ 1;
     }
     LVM_HIP_TRY(c, hipGetLastError());
     st->seeded = true;

@@ -50,15 +50,17 @@ static int run_mode(Ctx* c, const lvm_params* p, int levels, const FrameIO& io, 
 // A sequence is captured the second time its key is seen; capture failure permanently falls back to
 // plain launches for this context.
 static int run_mode_graphed(Ctx* c, const lvm_params* p, int levels, const FrameIO& io, hipStream_t s, int* produced) {
-    struct Key { FrameIO io; lvm_params p; int levels; int exact; float* dbg; } k;
+    struct Key { FrameIO io; lvm_params p; int levels; int exact; float* dbg; size_t nx; uint8_t extra[256]; } k;
     std::memset(&k, 0, sizeof(k));
     k.io = io; k.p = *p; k.levels = levels; k.exact = c->exact_lab ? 1 : 0; k.dbg = c->keep_float ? c->d_float : nullptr;
+    k.nx = c->state->key_extra(k.extra, sizeof(k.extra));
     const uint8_t* kb = reinterpret_cast<const uint8_t*>(&k);
     GraphEntry* e = nullptr;
     for (auto& g : c->graphs)
         if (g.key.size() == sizeof(k) && std::memcmp(g.key.data(), kb, sizeof(k)) == 0) { e = &g; break; }
     if (e && e->exec) {
         LVM_HIP_TRY(c, hipGraphLaunch(e->exec, s));
+        c->state->advance(*p, io);
         *produced = e->produced;
         return LVM_OK;
     }
@@ -126,6 +128,7 @@ static int process_device(Ctx* c, const lvm_params* p, const FrameIO& io, hipStr
                         io.channels != c->t_channels || p->preprocess_key != c->t_pre;  // MagnifyCore.hpp:53-65
     if (change) {
         // buffers of the old geometry may still be in use by queued kernels
+        if (c->t_mode == LVM_MODE_LAPLACE) (void)laplace_flush(c, s);   // pipelined mode: do not lose the pending frame
         LVM_HIP_TRY(c, hipStreamSynchronize(s));
         c->t_mode = p->mode; c->t_levels = levels; c->t_w = io.w; c->t_h = io.h;
         c->t_channels = io.channels; c->t_pre = p->preprocess_key;
@@ -159,6 +162,9 @@ int lvm_create(int device, int n_streams, lvm_ctx** out) {
     float g[256], ig[4096];
     lvm::build_lab_tables(g, ig, c->lab.fwd, c->lab.inv);
     bool ok = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_gamma_u8, sizeof(g)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_invgamma, sizeof(ig)) == hipSuccess;
     ok = ok && hipMemcpy(c->d_gamma_u8, g, sizeof(g), hipMemcpyHostToDevice) == hipSuccess;
@@ -184,6 +190,9 @@ void lvm_destroy(lvm_ctx* c) {
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_float) (void)hipFree(c->d_float);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -234,7 +243,10 @@ int lvm_process(lvm_ctx* c, const lvm_params* p, const uint8_t* in, int w, int h
     hipStream_t s = c->own_stream;
     LVM_HIP_TRY(c, hipMemcpy2DAsync(c->d_in, row, in, (size_t)in_stride, row, (size_t)h, hipMemcpyHostToDevice, s));
     lvm::FrameIO io{c->d_in, (ptrdiff_t)row, (ptrdiff_t)bytes, c->d_out, (ptrdiff_t)row, (ptrdiff_t)bytes, w, h, channels};
+    const int saved_depth = c->pipeline_depth;
+    c->pipeline_depth = 0;                       // the synchronous surface completes its own frame
     const int rc = lvm::process_device(c, p, io, s, produced);
+    c->pipeline_depth = saved_depth;
     if (rc != LVM_OK) { (void)hipStreamSynchronize(s); return rc; }
     if (*produced)
         LVM_HIP_TRY(c, hipMemcpy2DAsync(out, (size_t)out_stride, c->d_out, row, row, (size_t)h, hipMemcpyDeviceToHost, s));
@@ -286,6 +298,26 @@ int lvm_profile_entry(lvm_ctx* c, int idx, char* name, size_t cap, double* total
     if (name && cap) { std::snprintf(name, cap, "%s", t.name.c_str()); }
     if (total_ms) *total_ms = t.ms;
     if (launches) *launches = t.n;
+    return LVM_OK;
+}
+
+int lvm_set_pipeline(lvm_ctx* c, int depth) {
+    if (!c || depth < 0 || depth > 1) return LVM_ERR_INVALID;
+    if (depth != c->pipeline_depth) {
+        LVM_HIP_TRY(c, hipDeviceSynchronize());
+        if (c->t_mode == LVM_MODE_LAPLACE) (void)lvm::laplace_flush(c, c->own_stream);
+        LVM_HIP_TRY(c, hipDeviceSynchronize());
+        lvm::drop_graphs(c);
+        c->pipeline_depth = depth;
+    }
+    return LVM_OK;
+}
+
+int lvm_flush(lvm_ctx* c, void* hip_stream) {
+    if (!c) return LVM_ERR_INVALID;
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    if (c->t_mode == LVM_MODE_LAPLACE) return lvm::laplace_flush(c, s);
     return LVM_OK;
 }
 

@@ -178,12 +178,22 @@ struct ProfTotal { std::string name; double ms = 0; long long n = 0; };
 struct LevelGeom { int w, h; size_t n; };   // n = w*h
 
 struct Ctx;
+struct FrameIO {
+    const uint8_t* d_in; ptrdiff_t in_stride, in_sstride;
+    uint8_t* d_out; ptrdiff_t out_stride, out_sstride;
+    int w, h, channels;
+};
+
 struct ModeState {
     virtual ~ModeState() {}
     // true when the next frame with parameters `p` issues a fixed launch sequence (no allocation, no
     // host synchronisation, no per-frame varying kernel argument) and produces an output: such frames
     // may be captured in a hipGraph and replayed.
     virtual bool steady(const lvm_params& p) const { (void)p; return false; }
+    // extra bytes for the graph key (mode-private values kernels of the sequence can see)
+    virtual size_t key_extra(uint8_t* buf, size_t cap) const { (void)buf; (void)cap; return 0; }
+    // host-side bookkeeping of one steady frame when its launches come from a replayed graph
+    virtual void advance(const lvm_params& p, const FrameIO& io) { (void)p; (void)io; }
 };
 
 struct GraphEntry { std::vector<uint8_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int produced = 0; };
@@ -213,6 +223,9 @@ struct Ctx {
     std::vector<ProfTotal> prof_totals;
     bool use_graph = true;
     std::vector<GraphEntry> graphs;   // steady-state launch sequences, keyed by every kernel-visible input
+    int pipeline_depth = 0;           // 0 = every call completes its own frame; 1 = outputs lag one call (Laplace)
+    hipStream_t aux_stream = nullptr; // second stream of the cross-frame pipeline
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool exact_lab = false;   // debug: OpenCV-order Lab arithmetic everywhere (bit-faithful to the oracle)
 };
 
@@ -237,14 +250,11 @@ void prof_end(Ctx* c, hipStream_t s);
         if ((c)->profiling) lvm::prof_end((c), (stream));                                 \
     } while (0)
 
-struct FrameIO {
-    const uint8_t* d_in; ptrdiff_t in_stride, in_sstride;
-    uint8_t* d_out; ptrdiff_t out_stride, out_sstride;
-    int w, h, channels;
-};
+
 
 // mode entry points (laplace.hip / riesz.hip / color.hip).  Return LVM_OK or an error;
 // *produced follows the reference's passthrough rules.
+int laplace_flush(Ctx* c, hipStream_t s);
 int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced);
 int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced);
 int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced);

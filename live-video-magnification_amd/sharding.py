@@ -25,7 +25,7 @@ def barrier(dist, sync=None):
         sync()
 
 
-def timed_steps(step, steps, dist=None, sync=None, device=None):
+def timed_steps(step, steps, dist=None, sync=None, device=None, finish=None):
     """Runs `steps` calls of step(i) bracketed by barrier + device sync on both sides and returns
     the MAX elapsed seconds over all ranks (the job is as slow as its slowest rank)."""
     import torch
@@ -33,6 +33,8 @@ def timed_steps(step, steps, dist=None, sync=None, device=None):
     t0 = time.perf_counter()
     for i in range(steps):
         step(i)
+    if finish:
+        finish()          # e.g. drain a software pipeline: its work belongs to the timed region
     if sync:
         sync()
     dt = time.perf_counter() - t0

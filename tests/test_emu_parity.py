@@ -114,3 +114,36 @@ def test_fast_lab_flavour_stays_within_tolerance(lvm, po, emu):
     for idx in (0, 2, 3):
         ck, pk = lvm.synth.config(idx, (96, 64, 3))
         run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 8, 1e-4, exact=False, exact_lab=False)
+
+
+def _pipelined_clip(lvm, po, lib, w, h, levels, nframes, ring=4):
+    """lvm_process_device with pipeline depth 1 over a ring of in/out buffers + flush: every frame's
+    output must equal the oracle's (and therefore the depth-0 schedule's) bit for bit."""
+    ck, pk = lvm.synth.config(0, (w, h, levels))
+    clip = lvm.synth.Clip(**ck)
+    P = po.make_params(**pk)
+    cp = c_params(lvm, pk)
+    ctx = lvm.Context(0, 1, lib)
+    ctx.exact_lab(True)
+    ctx.set_pipeline(1)
+    orc = po.Oracle()
+    ins = [np.zeros((h, w, 3), np.uint8) for _ in range(ring)]
+    outs = [np.zeros((h, w, 3), np.uint8) for _ in range(ring)]
+    refs = {}
+    for t in range(nframes):
+        k = t % ring
+        if t >= ring:        # slot k is about to be reused: frame t-ring must already be complete
+            assert np.array_equal(outs[k], refs[t - ring]), "frame %d" % (t - ring)
+        ins[k][...] = clip.frame(t)
+        refs[t], _ = orc.process(ins[k].copy(), P)
+        assert ctx.process_device(cp, ins[k].ctypes.data, w, h, 3, w * 3, w * h * 3, outs[k].ctypes.data, w * 3, w * h * 3)
+    ctx.flush()
+    ctx.synchronize()
+    for t in range(max(0, nframes - ring), nframes):
+        assert np.array_equal(outs[t % ring], refs[t]), "frame %d" % t
+    ctx.close()
+
+
+@pytest.mark.parametrize("w,h,levels", [(160, 90, 3), (320, 180, 4), (135, 77, 4), (64, 48, 1)])
+def test_laplace_emu_pipelined_schedule(lvm, po, emu, w, h, levels):
+    _pipelined_clip(lvm, po, emu, w, h, levels, 11)

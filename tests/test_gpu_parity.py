@@ -157,3 +157,44 @@ def test_color_1080p_window_fill(lvm, po, hip):
     ck, pk = lvm.synth.config(3)
     worst = run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 134, FLOAT_TOL)
     print("color 1080p worst", worst)
+
+
+# ---- cross-frame pipeline + hipGraph replay ----------------------------------------------------------
+@pytest.mark.parametrize("w,h,levels,graph", [(640, 360, 4, True), (640, 360, 4, False), (1920, 1080, 6, True)])
+def test_laplace_pipelined_device_path(lvm, po, hip, w, h, levels, graph):
+    """lvm_process_device at pipeline depth 1 (stage B of frame t+1 on a second stream, concurrent
+    with stage A of frame t) over a ring of device buffers; outputs must match the oracle."""
+    import torch
+    ck, pk = lvm.synth.config(0, (w, h, levels))
+    clip = lvm.synth.Clip(**ck)
+    P = po.make_params(**pk)
+    cp = c_params(lvm, pk)
+    ring, nframes = 4, 22 if w < 1000 else 10
+    ctx = lvm.Context(0, 1, hip)
+    ctx.set_graph(graph)
+    ctx.set_pipeline(1)
+    orc = po.Oracle()
+    d_in = torch.zeros((ring, h, w, 3), dtype=torch.uint8, device="cuda")
+    d_out = torch.zeros_like(d_in)
+    stream = torch.cuda.current_stream().cuda_stream
+    refs = {}
+
+    def check(t):
+        got = d_out[t % ring].cpu().numpy()
+        du = np.abs(refs[t].astype(int) - got.astype(int))
+        assert du.max() <= 1 and (du == 0).mean() >= 0.999, "frame %d: max %d, identical %.5f" % (t, du.max(), (du == 0).mean())
+
+    for t in range(nframes):
+        k = t % ring
+        if t >= ring:
+            torch.cuda.synchronize()
+            check(t - ring)
+        f = clip.frame(t)
+        refs[t], _ = orc.process(f, P)
+        d_in[k].copy_(torch.from_numpy(f).cuda())
+        assert ctx.process_device(cp, d_in[k].data_ptr(), w, h, 3, w * 3, w * h * 3, d_out[k].data_ptr(), w * 3, w * h * 3, stream)
+    ctx.flush(stream)
+    torch.cuda.synchronize()
+    for t in range(nframes - ring, nframes):
+        check(t)
+    ctx.close()
