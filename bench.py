@@ -143,10 +143,15 @@ def main():
                        pk["chromAttenuation"], pk["framerate"], 0)
     stream = torch.cuda.current_stream().cuda_stream
 
+    in_ptrs = [d_in[t].data_ptr() for t in range(ring)]
+    out_ptrs = [d_out[t].data_ptr() for t in range(ring)]
+    fast = ctx.make_stepper(cp, w, h, ch, w * ch, frame_bytes, w * ch, frame_bytes, stream)
+
     def step(i):
         t = i % ring
-        return ctx.process_device(cp, d_in[t].data_ptr(), w, h, ch, w * ch, frame_bytes, d_out[t].data_ptr(), w * ch,
-                                  frame_bytes, stream)
+        rc = fast(in_ptrs[t], out_ptrs[t])
+        if rc != 0:
+            ctx._check(rc)
 
     n = 0
     for _ in range(args.warmup):

@@ -191,6 +191,21 @@ class Context:
     def flush(self, stream=0):
         self._check(self.lib.lvm_flush(self.h, stream))
 
+    def make_stepper(self, cparams, w, h, ch, in_stride, in_sstride, out_stride, out_sstride, stream=0):
+        """Returns f(d_in_ptr, d_out_ptr) -> rc with every constant argument pre-converted (the per-call
+        Python overhead of the generic wrapper is comparable to a whole frame's GPU time)."""
+        fn = self.lib.lvm_process_device
+        h_ctx, p_ref, produced = self.h, C.byref(cparams), C.c_int(0)
+        p_prod = C.byref(produced)
+        cw, chh, cch = C.c_int(w), C.c_int(h), C.c_int(ch)
+        a, b2, c2, d = C.c_ssize_t(in_stride), C.c_ssize_t(in_sstride), C.c_ssize_t(out_stride), C.c_ssize_t(out_sstride)
+        st = C.c_void_p(stream)
+        self._keep = (cparams, produced)
+
+        def step(d_in, d_out):
+            return fn(h_ctx, p_ref, d_in, cw, chh, cch, a, b2, d_out, c2, d, p_prod, st)
+        return step
+
     def synchronize(self):
         self._check(self.lib.lvm_synchronize(self.h))
 
