@@ -214,7 +214,8 @@ def main():
             "metric": "magnified frames/sec at 1080p, Laplace-motion 6 levels; % HBM roofline" if args.mode == "laplace"
                       else "magnified frames/sec (%s)" % args.mode,
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 5), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * dt / args.steps, 5),
+            "host_enqueue_ms_per_step": round(1e3 * getattr(lvm.sharding.timed_steps, "host_seconds", 0.0) / args.steps, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d, %d levels, %d stream(s)/GPU, device-resident u8 BGR in/out" %
                                    (args.mode, w, h, levels, B),

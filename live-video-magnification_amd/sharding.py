@@ -35,6 +35,7 @@ def timed_steps(step, steps, dist=None, sync=None, device=None, finish=None):
         step(i)
     if finish:
         finish()          # e.g. drain a software pipeline: its work belongs to the timed region
+    timed_steps.host_seconds = time.perf_counter() - t0   # host-side enqueue time (before the device drains)
     if sync:
         sync()
     dt = time.perf_counter() - t0
