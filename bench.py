@@ -93,8 +93,8 @@ def main():
     ap.add_argument("--levels", type=int, default=0)
     ap.add_argument("--ring", type=int, default=16, help="distinct input frames kept in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=1, help="cross-frame pipeline depth of lvm_process_device (0 or 1)")
+    ap.add_argument("--graph", action="store_true", help="replay steady-state frames from a captured hipGraph")
+    ap.add_argument("--pipeline", type=int, default=0, help="cross-frame pipeline depth of lvm_process_device (0 or 1)")
     ap.add_argument("--profile-steps", type=int, default=60)
     args = ap.parse_args()
 
@@ -136,8 +136,7 @@ def main():
     frame_bytes = h * w * ch
 
     ctx = lvm.Context(local_rank, B)
-    if args.no_graph:
-        ctx.set_graph(False)
+    ctx.set_graph(bool(args.graph))
     ctx.set_pipeline(args.pipeline)
     cp = lvm.LvmParams(pk["mode"], pk["levels"], pk["amplification"], pk["coWavelength"], pk["coLow"], pk["coHigh"],
                        pk["chromAttenuation"], pk["framerate"], 0)
@@ -220,7 +219,7 @@ def main():
             "config": {"workload": "%s %dx%d, %d levels, %d stream(s)/GPU, device-resident u8 BGR in/out" %
                                    (args.mode, w, h, levels, B),
                        "baseline_config": cfg_idx, "streams_per_gpu": B, "ring_frames": ring,
-                       "pipeline_depth": args.pipeline, "hip_graph": not args.no_graph},
+                       "pipeline_depth": args.pipeline, "hip_graph": bool(args.graph)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "frame_alg_bytes": b_alg, "frame_roofline_frac": round(frame_frac, 5),

@@ -122,7 +122,8 @@ int  lvm_profile_enable(lvm_ctx* ctx, int on);
 int  lvm_profile_collect(lvm_ctx* ctx);
 int  lvm_profile_entry(lvm_ctx* ctx, int idx, char* name, size_t name_cap, double* total_ms,
                        long long* launches);
-/* Capture the per-frame launch sequence in a hipGraph and replay it (default on). */
+/* Capture the steady-state launch sequence in a hipGraph and replay it (default off: on MI355X /
+ * ROCm 7.2 the plain schedule is already GPU-bound and replay measured ~5 us/frame slower). */
 int  lvm_set_graph(lvm_ctx* ctx, int on);
 /* Algorithmic bytes per frame per stream for the current geometry/mode. */
 double lvm_algorithmic_bytes(int mode, int w, int h, int channels, int levels, double framerate);

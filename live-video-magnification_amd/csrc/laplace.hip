@@ -252,9 +252,15 @@ __global__ __launch_bounds__(1024) void k_lap_final_v4(const uint8_t* __restrict
                 float o0, o1, o2;
                 lab_to_bgr<EXACT>(L, a, bb, lab.inv, s_igt, o0, o1, o2);
                 if (dbg && b == 0) { float* d = dbg + ((size_t)gy * w + gx + k) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
-                ob[3 * k] = sat_u8(o0 * 255.0f + lab.a255);
-                ob[3 * k + 1] = sat_u8(o1 * 255.0f + lab.a255);
-                ob[3 * k + 2] = sat_u8(o2 * 255.0f + lab.a255);
+                if (EXACT) {
+                    ob[3 * k] = sat_u8(o0 * 255.0f + lab.a255);
+                    ob[3 * k + 1] = sat_u8(o1 * 255.0f + lab.a255);
+                    ob[3 * k + 2] = sat_u8(o2 * 255.0f + lab.a255);
+                } else {   // same value: fma(o, 255, 1/255) differs from mul+add only below the rounding step
+                    ob[3 * k] = sat_u8_fast(o0 * 255.0f + lab.a255);
+                    ob[3 * k + 1] = sat_u8_fast(o1 * 255.0f + lab.a255);
+                    ob[3 * k + 2] = sat_u8_fast(o2 * 255.0f + lab.a255);
+                }
             }
             Px4 qo;
             qo.a = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
@@ -505,10 +511,27 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
                    G[1], g1.w, g1.h, c->lab, c->lab.a255);
     }
     const int down_end = st->tailT ? st->tailT : levels;          // the tail builds G_{T+1..L} itself
-    for (int l = 1; l < down_end; ++l) {
-        const LevelGeom &a = st->g[l], &b = st->g[l + 1];
-        const dim3 grid((b.w + DT_W - 1) / DT_W, (b.h + DT_H - 1) / DT_H, st->planes);
-        LVM_LAUNCH(c, "pyr_down", k_pyr_down<0>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b.w, b.h);
+    int l = 1;
+    while (l < down_end) {          // G_l -> next levels, three (or two) per launch when possible
+        const int left = down_end - l;
+        if (left >= 3) {
+            const LevelGeom &a = st->g[l], &b1 = st->g[l + 1], &b2 = st->g[l + 2], &b3 = st->g[l + 3];
+            const dim3 grid((b3.w + ML_T - 1) / ML_T, (b3.h + ML_T - 1) / ML_T, st->planes);
+            LVM_LAUNCH(c, "pyr_down3", k_pyr_down_multi<3>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b1.w, b1.h,
+                       G[l + 2], b2.w, b2.h, G[l + 3], b3.w, b3.h);
+            l += 3;
+        } else if (left == 2) {
+            const LevelGeom &a = st->g[l], &b1 = st->g[l + 1], &b2 = st->g[l + 2];
+            const dim3 grid((b2.w + ML_T - 1) / ML_T, (b2.h + ML_T - 1) / ML_T, st->planes);
+            LVM_LAUNCH(c, "pyr_down2", k_pyr_down_multi<2>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b1.w, b1.h,
+                       G[l + 2], b2.w, b2.h, (float*)nullptr, 0, 0);
+            l += 2;
+        } else {
+            const LevelGeom &a = st->g[l], &b = st->g[l + 1];
+            const dim3 grid((b.w + DT_W - 1) / DT_W, (b.h + DT_H - 1) / DT_H, st->planes);
+            LVM_LAUNCH(c, "pyr_down", k_pyr_down<0>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b.w, b.h);
+            l += 1;
+        }
     }
     if (st->tailT) {
         float gains[kMaxLevels + 2];

@@ -107,13 +107,18 @@ __device__ __forceinline__ void lin_bgr_to_lab(float B, float G, float R, const 
 template <bool EXACT>
 __device__ __forceinline__ float spline1024(float x, const float* tab) {
     int ix = (int)x;
-    ix = ix < 0 ? 0 : (ix > 1023 ? 1023 : ix);
+    if (EXACT) ix = ix < 0 ? 0 : (ix > 1023 ? 1023 : ix);
+    else ix = ix > 1023 ? 1023 : ix;              // x was clamped to [0, 1024] by the caller
     x -= (float)ix;
     const float4 t = *reinterpret_cast<const float4*>(tab + ix * 4);
     if (EXACT) return ((t.w * x + t.z) * x + t.y) * x + t.x;
     return __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(t.w, x, t.z), x, t.y), x, t.x);
 }
 __device__ __forceinline__ float clip01(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+// same clamp as one v_med3_f32 (inputs are finite on the fast path)
+__device__ __forceinline__ float clip01_fast(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 1.f); }
+// convertTo(CV_8U) for finite input: round-half-even, clamp, convert (3 instructions)
+__device__ __forceinline__ uint32_t sat_u8_fast(float v) { return (uint32_t)__builtin_amdgcn_fmed3f(rintf(v), 0.f, 255.f); }
 // Lab2RGBfloat::process + inverse gamma; igt = inverse-gamma spline table (LDS).  EXACT keeps
 // OpenCV's divisions by 903.3 / 116 / 500 / 200 / 7.787 and its unfused products; otherwise
 // reciprocal multiplies, fma chains and selects.
@@ -144,9 +149,15 @@ __device__ __forceinline__ void lab_to_bgr(float li, float ai, float bi, const f
         c1 = __builtin_fmaf(iv[3], fx, __builtin_fmaf(iv[4], y, iv[5] * fz));
         c2 = __builtin_fmaf(iv[6], fx, __builtin_fmaf(iv[7], y, iv[8] * fz));
     }
-    o0 = spline1024<EXACT>(clip01(c0) * 1024.f, igt);
-    o1 = spline1024<EXACT>(clip01(c1) * 1024.f, igt);
-    o2 = spline1024<EXACT>(clip01(c2) * 1024.f, igt);
+    if (EXACT) {
+        o0 = spline1024<true>(clip01(c0) * 1024.f, igt);
+        o1 = spline1024<true>(clip01(c1) * 1024.f, igt);
+        o2 = spline1024<true>(clip01(c2) * 1024.f, igt);
+    } else {
+        o0 = spline1024<false>(clip01_fast(c0) * 1024.f, igt);
+        o1 = spline1024<false>(clip01_fast(c1) * 1024.f, igt);
+        o2 = spline1024<false>(clip01_fast(c2) * 1024.f, igt);
+    }
 }
 // cooperative loads of the two Lab tables into LDS (256 threads)
 __device__ __forceinline__ void load_gamma_u8(float* s_gam, const float* g) { s_gam[threadIdx.x] = g[threadIdx.x]; }
@@ -221,7 +232,7 @@ struct Ctx {
     bool profiling = false;
     std::vector<ProfEvent> prof_events;
     std::vector<ProfTotal> prof_totals;
-    bool use_graph = true;
+    bool use_graph = false;           // measured on MI355X/ROCm 7.2: plain launches are GPU-bound already and graph replay adds ~5 us/frame
     std::vector<GraphEntry> graphs;   // steady-state launch sequences, keyed by every kernel-visible input
     int pipeline_depth = 0;           // 0 = every call completes its own frame; 1 = outputs lag one call (Laplace)
     hipStream_t aux_stream = nullptr; // second stream of the cross-frame pipeline

@@ -226,6 +226,112 @@ __global__ __launch_bounds__(256) void k_down0_v4(const uint8_t* __restrict__ in
     }
 }
 
+// ---- three pyramid levels in one launch ------------------------------------------------------
+// G_l -> G_{l+1}, G_{l+2}, G_{l+3} (NL = 2 or 3 output levels).  A workgroup owns an 8x8 tile of the
+// coarsest output (16x16 / 32x32 of the finer ones) and recomputes the halos it needs: the G_l
+// region (<= 85x85) is staged in LDS once, every intermediate level lives only in LDS.  Halo
+// positions outside an image are never computed: readers apply REFLECT_101 at that level and the
+// mirrored position is always inside the stored (clipped) region.  Replaces NL launches that are
+// each launch/latency-bound (6-7 us on MI355X) by one.
+constexpr int ML_T = 8;                       // owned tile of the coarsest level
+template <int NL>
+__global__ __launch_bounds__(256) void k_pyr_down_multi(const float* __restrict__ src, int w0, int h0,
+                                                        float* __restrict__ d1, int w1, int h1,
+                                                        float* __restrict__ d2, int w2, int h2,
+                                                        float* __restrict__ d3, int w3, int h3) {
+    constexpr int T3 = ML_T, T2 = (NL == 3) ? 2 * ML_T : ML_T, T1 = 2 * T2;   // owned tile sizes per level
+    constexpr int R2 = (NL == 3) ? 2 * T3 + 3 : T2;          // stored extent of level l+2
+    constexpr int R1 = 2 * R2 + 3;                           // stored extent of level l+1
+    constexpr int R0 = 2 * R1 + 3;                           // staged extent of level l
+    __shared__ float s0[R0][R0 + 1];
+    __shared__ float ht[R0][R1 + 1];                         // horizontal temporaries (reused per level)
+    __shared__ float s1[R1][R1 + 1];
+    __shared__ float s2[R2][R2 + 1];
+    const int tid = threadIdx.x;
+    const size_t pl = blockIdx.z;
+    const float* sp = src + pl * ((size_t)w0 * h0);
+    // origins (may be negative / beyond the image; stored regions are clipped to the image)
+    const int o2x = (NL == 3) ? 2 * (blockIdx.x * T3) - 2 : blockIdx.x * T2, o2y = (NL == 3) ? 2 * (blockIdx.y * T3) - 2 : blockIdx.y * T2;
+    const int o1x = 2 * o2x - 2, o1y = 2 * o2y - 2;
+    const int o0x = 2 * o1x - 2, o0y = 2 * o1y - 2;
+    // stage level l (REFLECT_101 of the source image)
+    for (int i = tid; i < R0 * R0; i += 256) {
+        const int ly = i / R0, lx = i - ly * R0;
+        s0[ly][lx] = sp[(size_t)reflect101(o0y + ly, h0) * w0 + reflect101(o0x + lx, w0)];
+    }
+    __syncthreads();
+    // level l+1: local (ly, lx) <-> image (o1y + ly, o1x + lx); source local = 2*l + {0..4}
+    for (int i = tid; i < R0 * R1; i += 256) {
+        const int ly = i / R1, x = i - ly * R1;
+        const float* s = &s0[ly][2 * x];
+        ht[ly][x] = s[2] * 6.f + (s[1] + s[3]) * 4.f + s[0] + s[4];
+    }
+    __syncthreads();
+    for (int i = tid; i < R1 * R1; i += 256) {
+        const int y = i / R1, x = i - y * R1;
+        const float v = (ht[2 * y + 2][x] * 6.f + (ht[2 * y + 1][x] + ht[2 * y + 3][x]) * 4.f + ht[2 * y][x] + ht[2 * y + 4][x]) * (1.f / 256.f);
+        s1[y][x] = v;
+        const int gx = o1x + x, gy = o1y + y;
+        const int ox = gx - (int)blockIdx.x * T1, oy = gy - (int)blockIdx.y * T1;       // owned part
+        if (ox >= 0 && ox < T1 && oy >= 0 && oy < T1 && gx < w1 && gy < h1) d1[pl * ((size_t)w1 * h1) + (size_t)gy * w1 + gx] = v;
+    }
+    __syncthreads();
+    // level l+2 from s1 with REFLECT_101 at level l+1 (mirrored coordinates stay inside the stored region)
+    for (int i = tid; i < R1 * R2; i += 256) {
+        const int ly = i / R2, x = i - ly * R2;
+        const int gx = o2x + x;
+        float v = 0.f;
+        const int gy1 = o1y + ly;
+        if (gx >= 0 && gx < w2 && gy1 >= 0 && gy1 < h1) {
+            const float* s = &s1[ly][0];
+            const int c0 = reflect101(2 * gx - 2, w1) - o1x, c1 = reflect101(2 * gx - 1, w1) - o1x, c2 = 2 * gx - o1x,
+                      c3 = reflect101(2 * gx + 1, w1) - o1x, c4 = reflect101(2 * gx + 2, w1) - o1x;
+            v = s[c2] * 6.f + (s[c1] + s[c3]) * 4.f + s[c0] + s[c4];
+        }
+        ht[ly][x] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < R2 * R2; i += 256) {
+        const int y = i / R2, x = i - y * R2;
+        const int gx = o2x + x, gy = o2y + y;
+        float v = 0.f;
+        if (gx >= 0 && gx < w2 && gy >= 0 && gy < h2) {
+            const int r0 = reflect101(2 * gy - 2, h1) - o1y, r1 = reflect101(2 * gy - 1, h1) - o1y, r2 = 2 * gy - o1y,
+                      r3 = reflect101(2 * gy + 1, h1) - o1y, r4 = reflect101(2 * gy + 2, h1) - o1y;
+            v = (ht[r2][x] * 6.f + (ht[r1][x] + ht[r3][x]) * 4.f + ht[r0][x] + ht[r4][x]) * (1.f / 256.f);
+            const int ox = gx - (int)blockIdx.x * T2, oy = gy - (int)blockIdx.y * T2;
+            if (ox >= 0 && ox < T2 && oy >= 0 && oy < T2) d2[pl * ((size_t)w2 * h2) + (size_t)gy * w2 + gx] = v;
+        }
+        s2[y][x] = v;
+    }
+    if (NL == 3) {
+        __syncthreads();
+        for (int i = tid; i < R2 * T3; i += 256) {
+            const int ly = i / T3, x = i - ly * T3;
+            const int gx = blockIdx.x * T3 + x, gy2 = o2y + ly;
+            float v = 0.f;
+            if (gx < w3 && gy2 >= 0 && gy2 < h2) {
+                const float* s = &s2[ly][0];
+                const int c0 = reflect101(2 * gx - 2, w2) - o2x, c1 = reflect101(2 * gx - 1, w2) - o2x, c2 = 2 * gx - o2x,
+                          c3 = reflect101(2 * gx + 1, w2) - o2x, c4 = reflect101(2 * gx + 2, w2) - o2x;
+                v = s[c2] * 6.f + (s[c1] + s[c3]) * 4.f + s[c0] + s[c4];
+            }
+            ht[ly][x] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < T3 * T3; i += 256) {
+            const int y = i / T3, x = i - y * T3;
+            const int gx = blockIdx.x * T3 + x, gy = blockIdx.y * T3 + y;
+            if (gx < w3 && gy < h3) {
+                const int r0 = reflect101(2 * gy - 2, h2) - o2y, r1 = reflect101(2 * gy - 1, h2) - o2y, r2 = 2 * gy - o2y,
+                          r3 = reflect101(2 * gy + 1, h2) - o2y, r4 = reflect101(2 * gy + 2, h2) - o2y;
+                d3[pl * ((size_t)w3 * h3) + (size_t)gy * w3 + gx] =
+                    (ht[r2][x] * 6.f + (ht[r1][x] + ht[r3][x]) * 4.f + ht[r0][x] + ht[r4][x]) * (1.f / 256.f);
+            }
+        }
+    }
+}
+
 // generic pyrUp of float planes (dsize = dw x dh, 2n or 2n-1); blockIdx.z = plane
 template <int TU>
 __global__ __launch_bounds__(256) void k_pyr_up(const float* __restrict__ src, int sw, int sh,

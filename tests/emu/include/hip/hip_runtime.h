@@ -57,6 +57,7 @@ static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y;
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
+static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return a < b ? (b < c ? b : (a < c ? c : a)) : (a < c ? a : (b < c ? c : b)); }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }

@@ -147,3 +147,11 @@ def _pipelined_clip(lvm, po, lib, w, h, levels, nframes, ring=4):
 @pytest.mark.parametrize("w,h,levels", [(160, 90, 3), (320, 180, 4), (135, 77, 4), (64, 48, 1)])
 def test_laplace_emu_pipelined_schedule(lvm, po, emu, w, h, levels):
     _pipelined_clip(lvm, po, emu, w, h, levels, 11)
+
+
+@pytest.mark.parametrize("w,h,levels", [(1000, 760, 6), (800, 600, 4), (1001, 763, 5)])
+def test_laplace_emu_fused_multi_level_pyrdown(lvm, po, emu, w, h, levels):
+    """Sizes large enough that the tail starts at level 3-4, so G_1 -> G_2..G_4 goes through the
+    fused k_pyr_down_multi<2|3> kernel (vector and generic first/last kernels)."""
+    ck, pk = lvm.synth.config(0, (w, h, levels))
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 3, 0.0, exact=True)

@@ -198,3 +198,24 @@ def test_laplace_pipelined_device_path(lvm, po, hip, w, h, levels, graph):
     for t in range(nframes - ring, nframes):
         check(t)
     ctx.close()
+
+
+def test_graph_replay_matches(lvm, po, hip):
+    """hipGraph capture/replay of steady-state frames (opt-in) gives the same frames."""
+    for idx in (0, 2):
+        ck, pk = lvm.synth.config(idx, (320, 180, 4))
+        clip = lvm.synth.Clip(**ck)
+        P = po.make_params(**pk)
+        ctx = lvm.Context(0, 1, hip)
+        ctx.set_graph(True)
+        orc = po.Oracle()
+        cp = c_params(lvm, pk)
+        for t in range(14):
+            f = clip.frame(t)
+            ref, pr = orc.process(f, P)
+            out, pg = ctx.process(f, cp)
+            assert pr == pg
+            if pr:
+                du = np.abs(ref.astype(int) - out.astype(int))
+                assert du.max() <= 1 and (du == 0).mean() >= 0.998
+        ctx.close()
