@@ -59,9 +59,9 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, streams, T=0):
             "rz_lab": S * (3 * n[0] + 4 * n[0]),
             "rz_split": avg([4 * S * (2 * n[l] + n[l + 1]) for l in range(nb)]),
             # band 4 + prior(3) R/W 24 + phase(2) R/W 16 + registers(8) R/W 64 + amp,tc,ts 12
-            "rz_phase": avg([120 * S * n[l] for l in range(nb)]),
-            "rz_seed": avg([(4 + 13 * 4) * S * n[l] for l in range(nb)]),
-            "rz_blur_amp": avg([28 * S * n[l] for l in range(nb)]),
+            "rz_phase": sum(120 * S * n[l] for l in range(nb)),          # one launch covers every band level
+            "rz_seed": sum((4 + 13 * 4) * S * n[l] for l in range(nb)),
+            "rz_blur_amp": sum(28 * S * n[l] for l in range(nb)),
             "rz_collapse": avg([4 * S * (2 * n[l] + n[l + 1]) for l in range(1, nb)]),
             "rz_final": S * (6 * n[0] + 4 * n[0] + 4 * n[1]),
         }.get(name)

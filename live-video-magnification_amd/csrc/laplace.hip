@@ -20,6 +20,7 @@
 //   k_lap_final           out = u8(Lab2BGR(Lab(u8 in) + [1,ca,ca] * pyrUp(cur_1)))
 // All stencils are LDS-staged tiles; pyrDown/pyrUp follow OpenCV's border rules and operation
 // order exactly (see the per-kernel comments) so the result is order-faithful to the oracle.
+#include <cstdlib>
 #include <cstring>
 
 #include "pyramid.h"
@@ -390,6 +391,7 @@ struct LaplaceState : ModeState {
     float* curT[2] = {};                  // cur_T written by the tail kernel, double-buffered likewise
     struct Pending { bool valid = false; FrameIO io{}; lvm_params p{}; int par = 0; } pending;
     int par = 0, depth = 0;
+    int fuse_down = 2;                    // pyramid levels per pyrDown launch (LVM_FUSE_DOWN=2|3 selects the fused kernels)
     int tailT = 0;                       // first level handled by k_lap_tail (0 = tail disabled)
     TailArgs tail{};
     bool steady(const lvm_params&) const override { return seeded && (depth == 0 || pending.valid); }
@@ -440,6 +442,7 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
         st->cur[l] = p; p += pad(st->g[l].n * st->planes);
     }
     laplace_tail_plan(st);
+    if (const char* e = std::getenv("LVM_FUSE_DOWN")) st->fuse_down = std::atoi(e);
     if (st->tailT) {
         st->curT[0] = p; p += pad(st->g[st->tailT].n * st->planes);
         st->curT[1] = p; p += pad(st->g[st->tailT].n * st->planes);
@@ -514,13 +517,13 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     int l = 1;
     while (l < down_end) {          // G_l -> next levels, three (or two) per launch when possible
         const int left = down_end - l;
-        if (left >= 3) {
+        if (left >= 3 && st->fuse_down >= 3) {
             const LevelGeom &a = st->g[l], &b1 = st->g[l + 1], &b2 = st->g[l + 2], &b3 = st->g[l + 3];
             const dim3 grid((b3.w + ML_T - 1) / ML_T, (b3.h + ML_T - 1) / ML_T, st->planes);
             LVM_LAUNCH(c, "pyr_down3", k_pyr_down_multi<3>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b1.w, b1.h,
                        G[l + 2], b2.w, b2.h, G[l + 3], b3.w, b3.h);
             l += 3;
-        } else if (left == 2) {
+        } else if (left >= 2 && st->fuse_down >= 2) {
             const LevelGeom &a = st->g[l], &b1 = st->g[l + 1], &b2 = st->g[l + 2];
             const dim3 grid((b2.w + ML_T - 1) / ML_T, (b2.h + ML_T - 1) / ML_T, st->planes);
             LVM_LAUNCH(c, "pyr_down2", k_pyr_down_multi<2>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b1.w, b1.h,

@@ -83,40 +83,106 @@ __device__ __forceinline__ float conv9(const float (&s)[SS_H][SS_W + 1], int lx,
     return acc;
 }
 
-__global__ __launch_bounds__(256) void k_rz_split(const float* __restrict__ oct, int w, int h,
-                                                  float* __restrict__ band, float* __restrict__ next, int nw, int nh) {
-    __shared__ float s[SS_H][SS_W + 1];
-    const int x0 = blockIdx.x * ST_W, y0 = blockIdx.y * ST_H;
-    const float* src = oct + (size_t)blockIdx.z * w * h;
-    for (int i = threadIdx.x; i < SS_H * SS_W; i += 256) {
-        const int ly = i / SS_W, lx = i - ly * SS_W;
+// Register-blocked variants: tile 64x16 (+ halo 4), row pitch 72 floats so that the 12 (16) floats a
+// thread needs per kernel row are three (four) aligned 128-bit LDS reads.  Each output keeps its own
+// accumulator and receives its 81 taps in row-major order, exactly like conv9.
+constexpr int CW = 64, CH = 16, CSW = CW + 2 * SH, CSH = CH + 2 * SH;
+
+// 4 adjacent outputs (lx..lx+3, ly), lx % 4 == 0
+__device__ __forceinline__ void conv9x4(const float (&s)[CSH][CSW], int lx, int ly, const float* k, float kscale, float (&o)[4]) {
+    o[0] = o[1] = o[2] = o[3] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float4 a = *reinterpret_cast<const float4*>(&s[ly + i][lx]);
+        const float4 b = *reinterpret_cast<const float4*>(&s[ly + i][lx + 4]);
+        const float4 c = *reinterpret_cast<const float4*>(&s[ly + i][lx + 8]);
+        const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const float kv = k[i * 9 + j] * kscale;   // x2 is exact
+            if (kv != 0.f) {
+                o[0] = __builtin_fmaf(kv, v[j], o[0]); o[1] = __builtin_fmaf(kv, v[j + 1], o[1]);
+                o[2] = __builtin_fmaf(kv, v[j + 2], o[2]); o[3] = __builtin_fmaf(kv, v[j + 3], o[3]);
+            }
+        }
+    }
+}
+// 4 outputs at every second column (lx, lx+2, lx+4, lx+6), lx % 8 == 0 (the decimated low-pass)
+__device__ __forceinline__ void conv9x4s2(const float (&s)[CSH][CSW], int lx, int ly, const float* k, float kscale, float (&o)[4]) {
+    o[0] = o[1] = o[2] = o[3] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float4 a = *reinterpret_cast<const float4*>(&s[ly + i][lx]);
+        const float4 b = *reinterpret_cast<const float4*>(&s[ly + i][lx + 4]);
+        const float4 c = *reinterpret_cast<const float4*>(&s[ly + i][lx + 8]);
+        const float4 d = *reinterpret_cast<const float4*>(&s[ly + i][lx + 12]);
+        const float v[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const float kv = k[i * 9 + j] * kscale;
+            if (kv != 0.f) {
+                o[0] = __builtin_fmaf(kv, v[j], o[0]); o[1] = __builtin_fmaf(kv, v[j + 2], o[1]);
+                o[2] = __builtin_fmaf(kv, v[j + 4], o[2]); o[3] = __builtin_fmaf(kv, v[j + 6], o[3]);
+            }
+        }
+    }
+}
+__device__ __forceinline__ void stage_reflect(float (&s)[CSH][CSW], const float* __restrict__ src, int w, int h, int x0, int y0) {
+    for (int i = threadIdx.x; i < CSH * CSW; i += 256) {
+        const int ly = i / CSW, lx = i - ly * CSW;
         s[ly][lx] = src[(size_t)reflect101(y0 - SH + ly, h) * w + reflect101(x0 - SH + lx, w)];
     }
+}
+
+__global__ __launch_bounds__(256) void k_rz_split(const float* __restrict__ oct, int w, int h,
+                                                  float* __restrict__ band, float* __restrict__ next, int nw, int nh) {
+    __shared__ __attribute__((aligned(16))) float s[CSH][CSW];
+    const int x0 = blockIdx.x * CW, y0 = blockIdx.y * CH;
+    stage_reflect(s, oct + (size_t)blockIdx.z * w * h, w, h, x0, y0);
     __syncthreads();
-    for (int i = threadIdx.x; i < ST_H * ST_W; i += 256) {
-        const int y = i / ST_W, x = i - y * ST_W;
+    {   // high-pass band at every pixel: 4 per thread
+        const int y = threadIdx.x >> 4, x = (threadIdx.x & 15) * 4;
         const int gx = x0 + x, gy = y0 + y;
-        if (gx < w && gy < h) band[((size_t)blockIdx.z * h + gy) * w + gx] = conv9(s, x, y, kHp9, 1.0f);   // :227
+        if (gx < w && gy < h) {
+            float o[4];
+            conv9x4(s, x, y, kHp9, 1.0f, o);                                          // :227
+            float* d = band + ((size_t)blockIdx.z * h + gy) * w + gx;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) if (gx + m < w) d[m] = o[m];
+        }
     }
-    for (int i = threadIdx.x; i < (ST_H / 2) * (ST_W / 2); i += 256) {
-        const int y = (i / (ST_W / 2)) * 2, x = (i % (ST_W / 2)) * 2;
+    if (threadIdx.x < 64) {   // 2 x low-pass at even pixels only: 32 x 8 per tile, 4 per thread
+        const int v = threadIdx.x >> 3, q = threadIdx.x & 7;
+        const int y = 2 * v, x = 8 * q;
         const int gx = x0 + x, gy = y0 + y;
-        if (gx < w && gy < h)
-            next[((size_t)blockIdx.z * nh + gy / 2) * nw + gx / 2] = conv9(s, x, y, kLp9, 2.0f);            // :232-234
+        if (gx < w && gy < h) {
+            float o[4];
+            conv9x4s2(s, x, y, kLp9, 2.0f, o);                                        // :232-234
+            float* d = next + ((size_t)blockIdx.z * nh + gy / 2) * nw + gx / 2;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) if (gx + 2 * m < w) d[m] = o[m];
+        }
     }
 }
 
 // ---- phase difference + amplitude + temporal filters -----------------------------------------
 // RieszPyramidLevel::build (:66-78), computePhaseDifferenceAndAmplitude (:81-111),
 // RieszTemporalFilter::IIRTemporalFilter (TemporalFilter.cpp:340-351), *old = *cur (:267).
-struct PhaseArgs {
+constexpr int kMaxBands = 12;
+struct PhaseLv {                       // one band level
     const float* band;                 // current band
     float *P, *R1p, *R2p;              // prior (read), then overwritten with current
     float *phc, *phs;                  // accumulated phase
     float *lo0c, *lo0s, *lo1c, *lo1s;  // low-cutoff filter registers
     float *hi0c, *hi0s, *hi1c, *hi1s;  // high-cutoff filter registers
     float *amp, *tc, *ts;              // outputs
-    int w, h;
+    int w, h, tx, ty, block0;          // geometry, tiles per stream, first workgroup of this level
+};
+// All band levels in ONE launch: the levels are independent in this stage, and the small ones are
+// pure launch latency on their own.
+struct PhaseArgs {
+    PhaseLv lv[kMaxBands];
+    int nlv;
     double la1, la2, lb0, lb1, lb2, ha1, ha2, hb0, hb1, hb2;
     int mode;                          // 0 = normal, 1 = seed with zero Riesz pair (init), 2 = seed with actual pair
 };
@@ -130,10 +196,15 @@ __device__ __forceinline__ float arc_cos(float x) {
 }
 __device__ __forceinline__ float mul_sd(float x, double s) { return (float)((double)x * s); }
 
-__global__ __launch_bounds__(256) void k_rz_phase(PhaseArgs a) {
+__global__ __launch_bounds__(256) void k_rz_phase(PhaseArgs aa) {
     __shared__ float s[PT_H + 4][PT_W + 4 + 1];
-    const int x0 = blockIdx.x * PT_W, y0 = blockIdx.y * PT_H;
-    const size_t pl = (size_t)blockIdx.z * a.w * a.h;
+    int lvl = 0;
+    while (lvl + 1 < aa.nlv && (int)blockIdx.x >= aa.lv[lvl + 1].block0) ++lvl;
+    const PhaseLv& a = aa.lv[lvl];
+    const int t = blockIdx.x - a.block0;
+    const int bs = t / (a.tx * a.ty), tr = t - bs * (a.tx * a.ty);
+    const int x0 = (tr % a.tx) * PT_W, y0 = (tr / a.tx) * PT_H;
+    const size_t pl = (size_t)bs * a.w * a.h;
     for (int i = threadIdx.x; i < (PT_H + 4) * (PT_W + 4); i += 256) {
         const int ly = i / (PT_W + 4), lx = i - ly * (PT_W + 4);
         s[ly][lx] = a.band[pl + (size_t)reflect101(y0 - 2 + ly, a.h) * a.w + reflect101(x0 - 2 + lx, a.w)];
@@ -153,10 +224,10 @@ __global__ __launch_bounds__(256) void k_rz_phase(PhaseArgs a) {
     r2 = __builtin_fmaf(-0.48f, s[y + 1][x + 2], r2);
     r2 = __builtin_fmaf(0.48f, s[y + 3][x + 2], r2);
     r2 = __builtin_fmaf(0.2f, s[y + 4][x + 2], r2);
-    if (a.mode != 0) {   // seed: prior <- current (Riesz pair zeroed by RieszPyramid::init), filters cleared
+    if (aa.mode != 0) {   // seed: prior <- current (Riesz pair zeroed by RieszPyramid::init), filters cleared
         a.P[idx] = p;
-        a.R1p[idx] = a.mode == 1 ? 0.f : r1;
-        a.R2p[idx] = a.mode == 1 ? 0.f : r2;
+        a.R1p[idx] = aa.mode == 1 ? 0.f : r1;
+        a.R2p[idx] = aa.mode == 1 ? 0.f : r2;
         a.phc[idx] = 0.f; a.phs[idx] = 0.f;
         a.lo0c[idx] = 0.f; a.lo0s[idx] = 0.f; a.lo1c[idx] = 0.f; a.lo1s[idx] = 0.f;
         a.hi0c[idx] = 0.f; a.hi0s[idx] = 0.f; a.hi1c[idx] = 0.f; a.hi1s[idx] = 0.f;
@@ -179,18 +250,18 @@ __global__ __launch_bounds__(256) void k_rz_phase(PhaseArgs a) {
     // their own copy of the accumulated phase in the reference, the copies are always equal.
     const float phc = a.phc[idx] + dc, phs = a.phs[idx] + ds;
     a.phc[idx] = phc; a.phs[idx] = phs;
-    const float ylc = mul_sd(phc, a.lb0) + a.lo0c[idx];
-    const float yls = mul_sd(phs, a.lb0) + a.lo0s[idx];
-    a.lo0c[idx] = (mul_sd(phc, a.lb1) + a.lo1c[idx]) - mul_sd(ylc, a.la1);
-    a.lo0s[idx] = (mul_sd(phs, a.lb1) + a.lo1s[idx]) - mul_sd(yls, a.la1);
-    a.lo1c[idx] = mul_sd(phc, a.lb2) - mul_sd(ylc, a.la2);
-    a.lo1s[idx] = mul_sd(phs, a.lb2) - mul_sd(yls, a.la2);
-    const float yhc = mul_sd(phc, a.hb0) + a.hi0c[idx];
-    const float yhs = mul_sd(phs, a.hb0) + a.hi0s[idx];
-    a.hi0c[idx] = (mul_sd(phc, a.hb1) + a.hi1c[idx]) - mul_sd(yhc, a.ha1);
-    a.hi0s[idx] = (mul_sd(phs, a.hb1) + a.hi1s[idx]) - mul_sd(yhs, a.ha1);
-    a.hi1c[idx] = mul_sd(phc, a.hb2) - mul_sd(yhc, a.ha2);
-    a.hi1s[idx] = mul_sd(phs, a.hb2) - mul_sd(yhs, a.ha2);
+    const float ylc = mul_sd(phc, aa.lb0) + a.lo0c[idx];
+    const float yls = mul_sd(phs, aa.lb0) + a.lo0s[idx];
+    a.lo0c[idx] = (mul_sd(phc, aa.lb1) + a.lo1c[idx]) - mul_sd(ylc, aa.la1);
+    a.lo0s[idx] = (mul_sd(phs, aa.lb1) + a.lo1s[idx]) - mul_sd(yls, aa.la1);
+    a.lo1c[idx] = mul_sd(phc, aa.lb2) - mul_sd(ylc, aa.la2);
+    a.lo1s[idx] = mul_sd(phs, aa.lb2) - mul_sd(yls, aa.la2);
+    const float yhc = mul_sd(phc, aa.hb0) + a.hi0c[idx];
+    const float yhs = mul_sd(phs, aa.hb0) + a.hi0s[idx];
+    a.hi0c[idx] = (mul_sd(phc, aa.hb1) + a.hi1c[idx]) - mul_sd(yhc, aa.ha1);
+    a.hi0s[idx] = (mul_sd(phs, aa.hb1) + a.hi1s[idx]) - mul_sd(yhs, aa.ha1);
+    a.hi1c[idx] = mul_sd(phc, aa.hb2) - mul_sd(yhc, aa.ha2);
+    a.hi1s[idx] = mul_sd(phs, aa.hb2) - mul_sd(yhs, aa.ha2);
     a.amp[idx] = am;
     a.tc[idx] = (yhc - ylc) * am;                                      // RieszPyramid.cpp:118-120
     a.ts[idx] = (yhs - yls) * am;
@@ -201,19 +272,24 @@ __global__ __launch_bounds__(256) void k_rz_phase(PhaseArgs a) {
 // GaussianBlur(13x13, sigma 3) of amp (RieszPyramid.cpp:110), sepFilter2D of c, s (:121-124),
 // then RieszPyramidLevel::amplify (:129-144).  Tile 32x32, halo 6.
 constexpr int BT = 32, BH = 6, BS = BT + 2 * BH;
-struct BlurArgs {
-    const float *amp, *tc, *ts, *band, *R1, *R2;
-    float* bandA;
-    int w, h;
+struct BlurLv { const float *amp, *tc, *ts, *band, *R1, *R2; float* bandA; int w, h, tx, ty, block0; };
+struct BlurArgs {                      // all band levels in one launch (independent in this stage)
+    BlurLv lv[kMaxBands];
+    int nlv;
     float g[13];
     float alpha, thr;
 };
 
-__global__ __launch_bounds__(256) void k_rz_blur_amp(BlurArgs a) {
+__global__ __launch_bounds__(256) void k_rz_blur_amp(BlurArgs aa) {
     __shared__ float s[3][BS][BS + 1];
     __shared__ float hr[3][BS][BT + 1];
-    const int x0 = blockIdx.x * BT, y0 = blockIdx.y * BT;
-    const size_t pl = (size_t)blockIdx.z * a.w * a.h;
+    int lvl = 0;
+    while (lvl + 1 < aa.nlv && (int)blockIdx.x >= aa.lv[lvl + 1].block0) ++lvl;
+    const BlurLv& a = aa.lv[lvl];
+    const int t = blockIdx.x - a.block0;
+    const int bs = t / (a.tx * a.ty), tr = t - bs * (a.tx * a.ty);
+    const int x0 = (tr % a.tx) * BT, y0 = (tr / a.tx) * BT;
+    const size_t pl = (size_t)bs * a.w * a.h;
     for (int i = threadIdx.x; i < BS * BS; i += 256) {
         const int ly = i / BS, lx = i - ly * BS;
         const size_t si = pl + (size_t)reflect101(y0 - BH + ly, a.h) * a.w + reflect101(x0 - BH + lx, a.w);
@@ -224,9 +300,9 @@ __global__ __launch_bounds__(256) void k_rz_blur_amp(BlurArgs a) {
     for (int i = threadIdx.x; i < 3 * BS * BT; i += 256) {
         const int f = i / (BS * BT), r = i - f * (BS * BT);
         const int ly = r / BT, x = r - ly * BT;
-        float acc = a.g[0] * s[f][ly][x];
+        float acc = aa.g[0] * s[f][ly][x];
 #pragma unroll
-        for (int j = 1; j < 13; ++j) acc = __builtin_fmaf(a.g[j], s[f][ly][x + j], acc);
+        for (int j = 1; j < 13; ++j) acc = __builtin_fmaf(aa.g[j], s[f][ly][x + j], acc);
         hr[f][ly][x] = acc;
     }
     __syncthreads();
@@ -237,16 +313,16 @@ __global__ __launch_bounds__(256) void k_rz_blur_amp(BlurArgs a) {
         float v[3];
 #pragma unroll
         for (int f = 0; f < 3; ++f) {   // SymmColumnFilter: centre, then fma(kj, S[+j] + S[-j])
-            float acc = a.g[6] * hr[f][y + BH][x];
+            float acc = aa.g[6] * hr[f][y + BH][x];
 #pragma unroll
-            for (int j = 1; j <= 6; ++j) acc = __builtin_fmaf(a.g[6 + j], hr[f][y + BH + j][x] + hr[f][y + BH - j][x], acc);
+            for (int j = 1; j <= 6; ++j) acc = __builtin_fmaf(aa.g[6 + j], hr[f][y + BH + j][x] + hr[f][y + BH - j][x], acc);
             v[f] = acc;
         }
         const size_t idx = pl + (size_t)gy * a.w + gx;
         const float c = v[1] / v[0], sn = v[2] / v[0];                 // :125-126
         const float magV = sqrtf(c * c + sn * sn);                     // :133-134
-        float magV2 = magV * a.alpha;                                  // :135
-        magV2 = magV2 > a.thr ? a.thr : magV2;                         // :136 THRESH_TRUNC
+        float magV2 = magV * aa.alpha;                                  // :135
+        magV2 = magV2 > aa.thr ? aa.thr : magV2;                         // :136 THRESH_TRUNC
         const float cp = cosf(magV2), sp = sinf(magV2);                // :138
         float pair = (a.R1[idx] * c + a.R2[idx] * sn) / magV;          // :139-140
         if (pair != pair) pair = 0.f;                                  // :141
@@ -258,11 +334,11 @@ __global__ __launch_bounds__(256) void k_rz_blur_amp(BlurArgs a) {
 // res_l = filter2D(zero-injected nearest-upsample of res_{l+1}, 2 lp9) + filter2D(bandA_l, hp9).
 // The zero-injected image is non-zero only at even (x,y) (REFLECT_101 keeps parity), so only taps
 // with j == x and i == y (mod 2) are visited -- in the same row-major order as the full sum.
-__device__ __forceinline__ void collapse_stage(float (&sb)[SS_H][SS_W + 1], float (&su)[SS_H][SS_W + 1],
+__device__ __forceinline__ void collapse_stage(float (&sb)[CSH][CSW], float (&su)[CSH][CSW],
                                                const float* __restrict__ bandA, const float* __restrict__ resn,
                                                int w, int h, int nw, int nh, int x0, int y0) {
-    for (int i = threadIdx.x; i < SS_H * SS_W; i += 256) {
-        const int ly = i / SS_W, lx = i - ly * SS_W;
+    for (int i = threadIdx.x; i < CSH * CSW; i += 256) {
+        const int ly = i / CSW, lx = i - ly * CSW;
         const int yr = reflect101(y0 - SH + ly, h), xr = reflect101(x0 - SH + lx, w);
         sb[ly][lx] = bandA[(size_t)yr * w + xr];
         float u = 0.f;
@@ -273,32 +349,59 @@ __device__ __forceinline__ void collapse_stage(float (&sb)[SS_H][SS_W + 1], floa
         su[ly][lx] = u;
     }
 }
-__device__ __forceinline__ float collapse_px(const float (&sb)[SS_H][SS_W + 1], const float (&su)[SS_H][SS_W + 1],
-                                             int x, int y, int gx, int gy) {
-    float lp = 0.f;
-    const int i0 = gy & 1, j0 = gx & 1;   // (gy + i - 4) even <=> i == gy (mod 2)
-    for (int i = i0; i < 9; i += 2)
-        for (int j = j0; j < 9; j += 2) lp = __builtin_fmaf(kLp9[i * 9 + j] * 2.0f, su[y + i][x + j], lp);
-    const float hp = conv9(sb, x, y, kHp9, 1.0f);
-    return lp + hp;                                                     // :322
+// 4 adjacent outputs (lx..lx+3, ly), lx % 4 == 0; gx0 = image column of lx (even, tiles start at
+// multiples of 64), gy = image row.  Polyphase low-pass of the zero-injected image + high-pass.
+__device__ __forceinline__ void collapse_px4(const float (&sb)[CSH][CSW], const float (&su)[CSH][CSW],
+                                             int lx, int ly, int gy, float (&o)[4]) {
+    float lp[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool odd = (gy & 1) != 0;                 // rows i == gy (mod 2)
+#pragma unroll
+    for (int ii = 0; ii < 5; ++ii) {
+        const int ie = 2 * ii, io = 2 * ii + 1 < 9 ? 2 * ii + 1 : 8;
+        const int i = odd ? io : ie;
+        const bool row_ok = !(odd && ii == 4);      // odd rows: i = 1,3,5,7 only
+        const float4 a = *reinterpret_cast<const float4*>(&su[ly + i][lx]);
+        const float4 b = *reinterpret_cast<const float4*>(&su[ly + i][lx + 4]);
+        const float4 c = *reinterpret_cast<const float4*>(&su[ly + i][lx + 8]);
+        const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+        if (row_ok) {
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {           // output m (column parity m & 1) uses taps j == m (mod 2)
+                const float kv = (odd ? kLp9[io * 9 + j] : kLp9[ie * 9 + j]) * 2.0f;
+                if ((j & 1) == 0) { lp[0] = __builtin_fmaf(kv, v[j], lp[0]); lp[2] = __builtin_fmaf(kv, v[j + 2], lp[2]); }
+                else { lp[1] = __builtin_fmaf(kv, v[j + 1], lp[1]); lp[3] = __builtin_fmaf(kv, v[j + 3], lp[3]); }
+            }
+        }
+    }
+    float hp[4];
+    conv9x4(sb, lx, ly, kHp9, 1.0f, hp);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) o[m] = lp[m] + hp[m];                                 // :322
 }
 
 __global__ __launch_bounds__(256) void k_rz_collapse(const float* __restrict__ bandA, const float* __restrict__ resn,
                                                      float* __restrict__ res, int w, int h, int nw, int nh) {
-    __shared__ float sb[SS_H][SS_W + 1], su[SS_H][SS_W + 1];
-    const int x0 = blockIdx.x * ST_W, y0 = blockIdx.y * ST_H;
+    __shared__ __attribute__((aligned(16))) float sb[CSH][CSW];
+    __shared__ __attribute__((aligned(16))) float su[CSH][CSW];
+    const int x0 = blockIdx.x * CW, y0 = blockIdx.y * CH;
     const size_t pl = (size_t)blockIdx.z * w * h, pn = (size_t)blockIdx.z * nw * nh;
     collapse_stage(sb, su, bandA + pl, resn + pn, w, h, nw, nh, x0, y0);
     __syncthreads();
-    for (int i = threadIdx.x; i < ST_H * ST_W; i += 256) {
-        const int y = i / ST_W, x = i - y * ST_W;
-        const int gx = x0 + x, gy = y0 + y;
-        if (gx < w && gy < h) res[pl + (size_t)gy * w + gx] = collapse_px(sb, su, x, y, gx, gy);
+    const int y = threadIdx.x >> 4, x = (threadIdx.x & 15) * 4;
+    const int gx = x0 + x, gy = y0 + y;
+    if (gx < w && gy < h) {
+        float o[4];
+        collapse_px4(sb, su, x, y, gy, o);
+        float* d = res + pl + (size_t)gy * w + gx;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) if (gx + m < w) d[m] = o[m];
     }
 }
 
-// level-0 collapse (or plain L plane when there are no bands) + Lab2BGR + u8 (MagnifyCore.hpp:272-277)
-template <bool BANDS, bool EXACT>
+// level-0 collapse (or plain L plane when there are no bands) + Lab2BGR + u8 (MagnifyCore.hpp:272-277).
+// 4 pixels per thread; VEC = the frame's 4-pixel groups are dword aligned (12-byte loads/stores).
+struct __attribute__((packed, aligned(4))) RzPx4 { uint32_t a, b, c; };
+template <bool BANDS, bool EXACT, bool VEC>
 __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                   uint8_t* __restrict__ out, long out_stride, long out_sstride, int w, int h,
                                                   const float* __restrict__ bandA, const float* __restrict__ resn, int nw,
@@ -306,38 +409,65 @@ __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in
                                                   float* __restrict__ dbg) {
     __shared__ __attribute__((aligned(16))) float s_igt[4096];
     __shared__ float s_gam[256];
-    __shared__ float sb[SS_H][SS_W + 1], su[SS_H][SS_W + 1];
+    __shared__ __attribute__((aligned(16))) float sb[CSH][CSW];
+    __shared__ __attribute__((aligned(16))) float su[CSH][CSW];
     load_invgamma(s_igt, lab.invgamma);
     load_gamma_u8(s_gam, lab.gamma_u8);
     __syncthreads();
     const int ntiles = tiles_x * tiles_y * nstreams;
+    const int y = threadIdx.x >> 4, x = (threadIdx.x & 15) * 4;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int b = t / (tiles_x * tiles_y);
         const int r = t - b * (tiles_x * tiles_y);
         const int ty = r / tiles_x, tx = r - ty * tiles_x;
-        const int x0 = tx * ST_W, y0 = ty * ST_H;
+        const int x0 = tx * CW, y0 = ty * CH;
+        const int gx = x0 + x, gy = y0 + y;
+        const bool ok = gx < w && gy < h;
+        const uint8_t* p = in + (size_t)b * in_sstride + (size_t)(ok ? gy : 0) * in_stride + (size_t)(ok ? gx : 0) * 3;
+        uint32_t pb[12];
+        if (ok) {
+            if (VEC) {
+                const RzPx4 v = *reinterpret_cast<const RzPx4*>(p);
+                pb[0] = v.a & 255; pb[1] = (v.a >> 8) & 255; pb[2] = (v.a >> 16) & 255; pb[3] = v.a >> 24;
+                pb[4] = v.b & 255; pb[5] = (v.b >> 8) & 255; pb[6] = (v.b >> 16) & 255; pb[7] = v.b >> 24;
+                pb[8] = v.c & 255; pb[9] = (v.c >> 8) & 255; pb[10] = (v.c >> 16) & 255; pb[11] = v.c >> 24;
+            } else {
+#pragma unroll
+                for (int m = 0; m < 12; ++m) pb[m] = (gx + m / 3 < w) ? p[m] : 0;
+            }
+        }
         if (BANDS) {
             collapse_stage(sb, su, bandA + (size_t)b * w * h, resn + (size_t)b * nw * nh, w, h, nw, nh, x0, y0);
             __syncthreads();
         }
-        const uint8_t* src = in + (size_t)b * in_sstride;
-        uint8_t* dst = out + (size_t)b * out_sstride;
-        for (int i = threadIdx.x; i < ST_H * ST_W; i += 256) {
-            const int y = i / ST_W, x = i - y * ST_W;
-            const int gx = x0 + x, gy = y0 + y;
-            if (gx >= w || gy >= h) continue;
-            const uint8_t* p = src + (size_t)gy * in_stride + (size_t)gx * 3;
-            uint8_t* q = dst + (size_t)gy * out_stride + (size_t)gx * 3;
-            float L, a, bb;
-            // without bands L itself is the output luminance: keep it exact then
-            lin_bgr_to_lab<EXACT || !BANDS>(s_gam[p[0]], s_gam[p[1]], s_gam[p[2]], lab.fwd, L, a, bb);
-            if (BANDS) L = collapse_px(sb, su, x, y, gx, gy);
-            float o0, o1, o2;
-            lab_to_bgr<EXACT>(L, a, bb, lab.inv, s_igt, o0, o1, o2);
-            if (dbg && b == 0) { float* d = dbg + ((size_t)gy * w + gx) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
-            q[0] = sat_u8(o0 * 255.0f + lab.a255);
-            q[1] = sat_u8(o1 * 255.0f + lab.a255);
-            q[2] = sat_u8(o2 * 255.0f + lab.a255);
+        if (ok) {
+            float Lc[4] = {0.f, 0.f, 0.f, 0.f};
+            if (BANDS) collapse_px4(sb, su, x, y, gy, Lc);
+            uint32_t ob[12];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float L, a, bb;
+                // without bands L itself is the output luminance: keep it exact then
+                lin_bgr_to_lab<EXACT || !BANDS>(s_gam[pb[3 * m]], s_gam[pb[3 * m + 1]], s_gam[pb[3 * m + 2]], lab.fwd, L, a, bb);
+                if (BANDS) L = Lc[m];
+                float o0, o1, o2;
+                lab_to_bgr<EXACT>(L, a, bb, lab.inv, s_igt, o0, o1, o2);
+                if (dbg && b == 0 && gx + m < w) { float* d = dbg + ((size_t)gy * w + gx + m) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
+                ob[3 * m] = sat_u8(o0 * 255.0f + lab.a255);
+                ob[3 * m + 1] = sat_u8(o1 * 255.0f + lab.a255);
+                ob[3 * m + 2] = sat_u8(o2 * 255.0f + lab.a255);
+            }
+            uint8_t* q = out + (size_t)b * out_sstride + (size_t)gy * out_stride + (size_t)gx * 3;
+            if (VEC) {
+                RzPx4 qo;
+                qo.a = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
+                qo.b = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
+                qo.c = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
+                *reinterpret_cast<RzPx4*>(q) = qo;
+            } else {
+#pragma unroll
+                for (int m = 0; m < 12; ++m) if (gx + m / 3 < w) q[m] = (uint8_t)ob[m];
+            }
         }
         if (BANDS) __syncthreads();
     }
@@ -411,24 +541,29 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
     }
     for (int l = 0; l < nb; ++l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
-        const dim3 grid((a.w + ST_W - 1) / ST_W, (a.h + ST_H - 1) / ST_H, NS);
+        const dim3 grid((a.w + CW - 1) / CW, (a.h + CH - 1) / CH, NS);
         LVM_LAUNCH(c, "rz_split", k_rz_split, grid, blk, s, (const float*)st->oct[l], a.w, a.h, st->f[l][F_BAND], st->oct[l + 1], b.w, b.h);
     }
     auto launch_phase = [&](int mode) {
+        if (nb < 1) return;
+        PhaseArgs a;
+        a.nlv = nb; a.mode = mode;
+        a.la1 = st->la[1]; a.la2 = st->la[2]; a.lb0 = st->lb[0]; a.lb1 = st->lb[1]; a.lb2 = st->lb[2];
+        a.ha1 = st->ha[1]; a.ha2 = st->ha[2]; a.hb0 = st->hb[0]; a.hb1 = st->hb[1]; a.hb2 = st->hb[2];
+        int blocks = 0;
         for (int l = 0; l < nb; ++l) {
-            PhaseArgs a;
+            PhaseLv& v = a.lv[l];
             float** f = st->f[l];
-            a.band = f[F_BAND]; a.P = f[F_P]; a.R1p = f[F_R1]; a.R2p = f[F_R2]; a.phc = f[F_PHC]; a.phs = f[F_PHS];
-            a.lo0c = f[F_LO0C]; a.lo0s = f[F_LO0S]; a.lo1c = f[F_LO1C]; a.lo1s = f[F_LO1S];
-            a.hi0c = f[F_HI0C]; a.hi0s = f[F_HI0S]; a.hi1c = f[F_HI1C]; a.hi1s = f[F_HI1S];
-            a.amp = f[F_AMP]; a.tc = f[F_TC]; a.ts = f[F_TS];
-            a.w = st->g[l].w; a.h = st->g[l].h;
-            a.la1 = st->la[1]; a.la2 = st->la[2]; a.lb0 = st->lb[0]; a.lb1 = st->lb[1]; a.lb2 = st->lb[2];
-            a.ha1 = st->ha[1]; a.ha2 = st->ha[2]; a.hb0 = st->hb[0]; a.hb1 = st->hb[1]; a.hb2 = st->hb[2];
-            a.mode = mode;
-            const dim3 grid((a.w + PT_W - 1) / PT_W, (a.h + PT_H - 1) / PT_H, NS);
-            LVM_LAUNCH(c, mode ? "rz_seed" : "rz_phase", k_rz_phase, grid, blk, s, a);
+            v.band = f[F_BAND]; v.P = f[F_P]; v.R1p = f[F_R1]; v.R2p = f[F_R2]; v.phc = f[F_PHC]; v.phs = f[F_PHS];
+            v.lo0c = f[F_LO0C]; v.lo0s = f[F_LO0S]; v.lo1c = f[F_LO1C]; v.lo1s = f[F_LO1S];
+            v.hi0c = f[F_HI0C]; v.hi0s = f[F_HI0S]; v.hi1c = f[F_HI1C]; v.hi1s = f[F_HI1S];
+            v.amp = f[F_AMP]; v.tc = f[F_TC]; v.ts = f[F_TS];
+            v.w = st->g[l].w; v.h = st->g[l].h;
+            v.tx = (v.w + PT_W - 1) / PT_W; v.ty = (v.h + PT_H - 1) / PT_H;
+            v.block0 = blocks;
+            blocks += v.tx * v.ty * NS;
         }
+        LVM_LAUNCH(c, mode ? "rz_seed" : "rz_phase", k_rz_phase, dim3(blocks), blk, s, a);
     };
     // first frame ever, or degenerate coefficients: init and pass the frame through (:226-240)
     if (!st->inited || std::isnan(st->la[0]) || std::isnan(st->ha[0])) {
@@ -455,31 +590,43 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         for (int i = 0; i < 13; ++i) gk[i] = (float)(t[i] * sum);
     }
     const double PI_PERCENT = 3.1415926535897932384626433832795 / 100.0;
-    for (int l = nb - 1; l >= 0; --l) {
+    if (nb >= 1) {
         BlurArgs a;
-        float** f = st->f[l];
-        a.amp = f[F_AMP]; a.tc = f[F_TC]; a.ts = f[F_TS]; a.band = f[F_BAND]; a.R1 = f[F_R1]; a.R2 = f[F_R2]; a.bandA = f[F_BANDA];
-        a.w = st->g[l].w; a.h = st->g[l].h;
+        a.nlv = nb;
         for (int i = 0; i < 13; ++i) a.g[i] = gk[i];
         a.alpha = (float)p.amplification; a.thr = (float)(p.coWavelength * PI_PERCENT);
-        const dim3 grid((a.w + BT - 1) / BT, (a.h + BT - 1) / BT, NS);
-        LVM_LAUNCH(c, "rz_blur_amp", k_rz_blur_amp, grid, blk, s, a);
+        int blocks = 0;
+        for (int l = 0; l < nb; ++l) {
+            BlurLv& v = a.lv[l];
+            float** f = st->f[l];
+            v.amp = f[F_AMP]; v.tc = f[F_TC]; v.ts = f[F_TS]; v.band = f[F_BAND]; v.R1 = f[F_R1]; v.R2 = f[F_R2]; v.bandA = f[F_BANDA];
+            v.w = st->g[l].w; v.h = st->g[l].h;
+            v.tx = (v.w + BT - 1) / BT; v.ty = (v.h + BT - 1) / BT;
+            v.block0 = blocks;
+            blocks += v.tx * v.ty * NS;
+        }
+        LVM_LAUNCH(c, "rz_blur_amp", k_rz_blur_amp, dim3(blocks), blk, s, a);
     }
     // collapse (:270): res_{L-1} = residual octave
     const float* resn = st->oct[levels - 1];
     for (int l = nb - 1; l >= 1; --l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
-        const dim3 grid((a.w + ST_W - 1) / ST_W, (a.h + ST_H - 1) / ST_H, NS);
+        const dim3 grid((a.w + CW - 1) / CW, (a.h + CH - 1) / CH, NS);
         LVM_LAUNCH(c, "rz_collapse", k_rz_collapse, grid, blk, s, (const float*)st->f[l][F_BANDA], resn, st->res[l], a.w, a.h, b.w, b.h);
         resn = st->res[l];
     }
     {
-        const int tx = (w + ST_W - 1) / ST_W, ty = (h + ST_H - 1) / ST_H;
+        const int tx = (w + CW - 1) / CW, ty = (h + CH - 1) / CH;
         const int ntiles = tx * ty * NS;
         const dim3 grid(ntiles < 2048 ? ntiles : 2048);
         float* dbg = c->keep_float ? c->d_float : nullptr;
-        auto kfb = c->exact_lab ? k_rz_final<true, true> : k_rz_final<true, false>;
-        auto kfn = c->exact_lab ? k_rz_final<false, true> : k_rz_final<false, false>;
+        const bool vec = w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && io.out_stride % 4 == 0 &&
+                         io.out_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0 && ((uintptr_t)io.d_out % 4) == 0;
+        const bool ex = c->exact_lab;
+        auto kfb = vec ? (ex ? k_rz_final<true, true, true> : k_rz_final<true, false, true>)
+                       : (ex ? k_rz_final<true, true, false> : k_rz_final<true, false, false>);
+        auto kfn = vec ? (ex ? k_rz_final<false, true, true> : k_rz_final<false, false, true>)
+                       : (ex ? k_rz_final<false, true, false> : k_rz_final<false, false, false>);
         if (nb >= 1)
             LVM_LAUNCH(c, "rz_final", kfb, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
                        (long)io.out_stride, (long)io.out_sstride, w, h, (const float*)st->f[0][F_BANDA], resn, st->g[1].w, st->g[1].h,
