@@ -216,8 +216,11 @@ __global__ __launch_bounds__(256) void k_down0_v4(const uint8_t* __restrict__ in
                 const float oa = (w2a * 6.f + (w1a + w3a) * 4.f + w0a + ha) * (1.f / 256.f);
                 const float ob = (w2b * 6.f + (w1b + w3b) * 4.f + w0b + hb) * (1.f / 256.f);
                 if (gy < h1) {
-                    if (gx < w1) dst[(size_t)gy * w1 + gx] = oa;
-                    if (gx + 1 < w1) dst[(size_t)gy * w1 + gx + 1] = ob;
+                    if ((w1 & 1) == 0 && gx + 1 < w1) *reinterpret_cast<float2*>(&dst[(size_t)gy * w1 + gx]) = make_float2(oa, ob);
+                    else {
+                        if (gx < w1) dst[(size_t)gy * w1 + gx] = oa;
+                        if (gx + 1 < w1) dst[(size_t)gy * w1 + gx + 1] = ob;
+                    }
                 }
             }
             w0a = w1a; w1a = w2a; w2a = w3a; w3a = ha;

@@ -88,10 +88,13 @@ __device__ __forceinline__ float conv9(const float (&s)[SS_H][SS_W + 1], int lx,
 // accumulator and receives its 81 taps in row-major order, exactly like conv9.
 constexpr int CW = 64, CH = 16, CSW = CW + 2 * SH, CSH = CH + 2 * SH;
 
-// 4 adjacent outputs (lx..lx+3, ly), lx % 4 == 0
-__device__ __forceinline__ void conv9x4(const float (&s)[CSH][CSW], int lx, int ly, const float* k, float kscale, float (&o)[4]) {
+// 4 adjacent outputs (lx..lx+3, ly), lx % 4 == 0.  The row loop stays rolled: the 9 coefficients of a
+// row are scalar loads indexed by the (uniform) row counter, and only one row of samples (12 VGPRs) is
+// live at a time -- fully unrolled, the compiler hoists all 27 row reads and needs > 160 VGPRs.
+// Zero taps are multiplied too (fma(0, v, acc) == acc for finite v), the order is unchanged.
+__device__ __forceinline__ void conv9x4(const float (&s)[CSH][CSW], int lx, int ly, const float* __restrict__ k, float kscale, float (&o)[4]) {
     o[0] = o[1] = o[2] = o[3] = 0.f;
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < 9; ++i) {
         const float4 a = *reinterpret_cast<const float4*>(&s[ly + i][lx]);
         const float4 b = *reinterpret_cast<const float4*>(&s[ly + i][lx + 4]);
@@ -100,17 +103,15 @@ __device__ __forceinline__ void conv9x4(const float (&s)[CSH][CSW], int lx, int 
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const float kv = k[i * 9 + j] * kscale;   // x2 is exact
-            if (kv != 0.f) {
-                o[0] = __builtin_fmaf(kv, v[j], o[0]); o[1] = __builtin_fmaf(kv, v[j + 1], o[1]);
-                o[2] = __builtin_fmaf(kv, v[j + 2], o[2]); o[3] = __builtin_fmaf(kv, v[j + 3], o[3]);
-            }
+            o[0] = __builtin_fmaf(kv, v[j], o[0]); o[1] = __builtin_fmaf(kv, v[j + 1], o[1]);
+            o[2] = __builtin_fmaf(kv, v[j + 2], o[2]); o[3] = __builtin_fmaf(kv, v[j + 3], o[3]);
         }
     }
 }
 // 4 outputs at every second column (lx, lx+2, lx+4, lx+6), lx % 8 == 0 (the decimated low-pass)
-__device__ __forceinline__ void conv9x4s2(const float (&s)[CSH][CSW], int lx, int ly, const float* k, float kscale, float (&o)[4]) {
+__device__ __forceinline__ void conv9x4s2(const float (&s)[CSH][CSW], int lx, int ly, const float* __restrict__ k, float kscale, float (&o)[4]) {
     o[0] = o[1] = o[2] = o[3] = 0.f;
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < 9; ++i) {
         const float4 a = *reinterpret_cast<const float4*>(&s[ly + i][lx]);
         const float4 b = *reinterpret_cast<const float4*>(&s[ly + i][lx + 4]);
@@ -120,10 +121,8 @@ __device__ __forceinline__ void conv9x4s2(const float (&s)[CSH][CSW], int lx, in
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const float kv = k[i * 9 + j] * kscale;
-            if (kv != 0.f) {
-                o[0] = __builtin_fmaf(kv, v[j], o[0]); o[1] = __builtin_fmaf(kv, v[j + 2], o[1]);
-                o[2] = __builtin_fmaf(kv, v[j + 4], o[2]); o[3] = __builtin_fmaf(kv, v[j + 6], o[3]);
-            }
+            o[0] = __builtin_fmaf(kv, v[j], o[0]); o[1] = __builtin_fmaf(kv, v[j + 2], o[1]);
+            o[2] = __builtin_fmaf(kv, v[j + 4], o[2]); o[3] = __builtin_fmaf(kv, v[j + 6], o[3]);
         }
     }
 }
@@ -135,7 +134,7 @@ __device__ __forceinline__ void stage_reflect(float (&s)[CSH][CSW], const float*
 }
 
 __global__ __launch_bounds__(256) void k_rz_split(const float* __restrict__ oct, int w, int h,
-                                                  float* __restrict__ band, float* __restrict__ next, int nw, int nh) {
+                                                     float* __restrict__ band, float* __restrict__ next, int nw, int nh) {
     __shared__ __attribute__((aligned(16))) float s[CSH][CSW];
     const int x0 = blockIdx.x * CW, y0 = blockIdx.y * CH;
     stage_reflect(s, oct + (size_t)blockIdx.z * w * h, w, h, x0, y0);
@@ -147,8 +146,11 @@ __global__ __launch_bounds__(256) void k_rz_split(const float* __restrict__ oct,
             float o[4];
             conv9x4(s, x, y, kHp9, 1.0f, o);                                          // :227
             float* d = band + ((size_t)blockIdx.z * h + gy) * w + gx;
+            if ((w & 3) == 0) *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);   // gx % 4 == 0, planes 256-B aligned
+            else {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) if (gx + m < w) d[m] = o[m];
+                for (int m = 0; m < 4; ++m) if (gx + m < w) d[m] = o[m];
+            }
         }
     }
     if (threadIdx.x < 64) {   // 2 x low-pass at even pixels only: 32 x 8 per tile, 4 per thread
@@ -159,8 +161,11 @@ __global__ __launch_bounds__(256) void k_rz_split(const float* __restrict__ oct,
             float o[4];
             conv9x4s2(s, x, y, kLp9, 2.0f, o);                                        // :232-234
             float* d = next + ((size_t)blockIdx.z * nh + gy / 2) * nw + gx / 2;
+            if ((nw & 3) == 0 && gx + 6 < w) *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+            else {
 #pragma unroll
-            for (int m = 0; m < 4; ++m) if (gx + 2 * m < w) d[m] = o[m];
+                for (int m = 0; m < 4; ++m) if (gx + 2 * m < w) d[m] = o[m];
+            }
         }
     }
 }
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(256) void k_rz_phase(PhaseArgs aa) {
 // ---- 3 x separable Gaussian-13 + amplify ------------------------------------------------------
 // GaussianBlur(13x13, sigma 3) of amp (RieszPyramid.cpp:110), sepFilter2D of c, s (:121-124),
 // then RieszPyramidLevel::amplify (:129-144).  Tile 32x32, halo 6.
-constexpr int BT = 32, BH = 6, BS = BT + 2 * BH;
+constexpr int BT = 32, BTH = 16, BH = 6, BS = BT + 2 * BH, BSH = BTH + 2 * BH;
 struct BlurLv { const float *amp, *tc, *ts, *band, *R1, *R2; float* bandA; int w, h, tx, ty, block0; };
 struct BlurArgs {                      // all band levels in one launch (independent in this stage)
     BlurLv lv[kMaxBands];
@@ -281,24 +286,24 @@ struct BlurArgs {                      // all band levels in one launch (indepen
 };
 
 __global__ __launch_bounds__(256) void k_rz_blur_amp(BlurArgs aa) {
-    __shared__ float s[3][BS][BS + 1];
-    __shared__ float hr[3][BS][BT + 1];
+    __shared__ float s[3][BSH][BS + 1];
+    __shared__ float hr[3][BSH][BT + 1];
     int lvl = 0;
     while (lvl + 1 < aa.nlv && (int)blockIdx.x >= aa.lv[lvl + 1].block0) ++lvl;
     const BlurLv& a = aa.lv[lvl];
     const int t = blockIdx.x - a.block0;
     const int bs = t / (a.tx * a.ty), tr = t - bs * (a.tx * a.ty);
-    const int x0 = (tr % a.tx) * BT, y0 = (tr / a.tx) * BT;
+    const int x0 = (tr % a.tx) * BT, y0 = (tr / a.tx) * BTH;
     const size_t pl = (size_t)bs * a.w * a.h;
-    for (int i = threadIdx.x; i < BS * BS; i += 256) {
+    for (int i = threadIdx.x; i < BSH * BS; i += 256) {
         const int ly = i / BS, lx = i - ly * BS;
         const size_t si = pl + (size_t)reflect101(y0 - BH + ly, a.h) * a.w + reflect101(x0 - BH + lx, a.w);
         s[0][ly][lx] = a.amp[si]; s[1][ly][lx] = a.tc[si]; s[2][ly][lx] = a.ts[si];
     }
     __syncthreads();
     // RowFilter: acc = k0*S0; acc = fma(kj, Sj, acc), left to right
-    for (int i = threadIdx.x; i < 3 * BS * BT; i += 256) {
-        const int f = i / (BS * BT), r = i - f * (BS * BT);
+    for (int i = threadIdx.x; i < 3 * BSH * BT; i += 256) {
+        const int f = i / (BSH * BT), r = i - f * (BSH * BT);
         const int ly = r / BT, x = r - ly * BT;
         float acc = aa.g[0] * s[f][ly][x];
 #pragma unroll
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(256) void k_rz_blur_amp(BlurArgs aa) {
         hr[f][ly][x] = acc;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < BT * BT; i += 256) {
+    for (int i = threadIdx.x; i < BTH * BT; i += 256) {
         const int y = i / BT, x = i - y * BT;
         const int gx = x0 + x, gy = y0 + y;
         if (gx >= a.w || gy >= a.h) continue;
@@ -354,23 +359,18 @@ __device__ __forceinline__ void collapse_stage(float (&sb)[CSH][CSW], float (&su
 __device__ __forceinline__ void collapse_px4(const float (&sb)[CSH][CSW], const float (&su)[CSH][CSW],
                                              int lx, int ly, int gy, float (&o)[4]) {
     float lp[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool odd = (gy & 1) != 0;                 // rows i == gy (mod 2)
-#pragma unroll
-    for (int ii = 0; ii < 5; ++ii) {
-        const int ie = 2 * ii, io = 2 * ii + 1 < 9 ? 2 * ii + 1 : 8;
-        const int i = odd ? io : ie;
-        const bool row_ok = !(odd && ii == 4);      // odd rows: i = 1,3,5,7 only
+    const int i0 = gy & 1;                          // rows i == gy (mod 2): 0,2,4,6,8 or 1,3,5,7
+#pragma unroll 1
+    for (int i = i0; i < 9; i += 2) {
         const float4 a = *reinterpret_cast<const float4*>(&su[ly + i][lx]);
         const float4 b = *reinterpret_cast<const float4*>(&su[ly + i][lx + 4]);
         const float4 c = *reinterpret_cast<const float4*>(&su[ly + i][lx + 8]);
         const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
-        if (row_ok) {
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {           // output m (column parity m & 1) uses taps j == m (mod 2)
-                const float kv = (odd ? kLp9[io * 9 + j] : kLp9[ie * 9 + j]) * 2.0f;
-                if ((j & 1) == 0) { lp[0] = __builtin_fmaf(kv, v[j], lp[0]); lp[2] = __builtin_fmaf(kv, v[j + 2], lp[2]); }
-                else { lp[1] = __builtin_fmaf(kv, v[j + 1], lp[1]); lp[3] = __builtin_fmaf(kv, v[j + 3], lp[3]); }
-            }
+        for (int j = 0; j < 9; ++j) {               // output m (column parity m & 1) uses taps j == m (mod 2)
+            const float kv = kLp9[i * 9 + j] * 2.0f;
+            if ((j & 1) == 0) { lp[0] = __builtin_fmaf(kv, v[j], lp[0]); lp[2] = __builtin_fmaf(kv, v[j + 2], lp[2]); }
+            else { lp[1] = __builtin_fmaf(kv, v[j + 1], lp[1]); lp[3] = __builtin_fmaf(kv, v[j + 3], lp[3]); }
         }
     }
     float hp[4];
@@ -393,8 +393,11 @@ __global__ __launch_bounds__(256) void k_rz_collapse(const float* __restrict__ b
         float o[4];
         collapse_px4(sb, su, x, y, gy, o);
         float* d = res + pl + (size_t)gy * w + gx;
+        if ((w & 3) == 0) *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+        else {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) if (gx + m < w) d[m] = o[m];
+            for (int m = 0; m < 4; ++m) if (gx + m < w) d[m] = o[m];
+        }
     }
 }
 
@@ -601,7 +604,7 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
             float** f = st->f[l];
             v.amp = f[F_AMP]; v.tc = f[F_TC]; v.ts = f[F_TS]; v.band = f[F_BAND]; v.R1 = f[F_R1]; v.R2 = f[F_R2]; v.bandA = f[F_BANDA];
             v.w = st->g[l].w; v.h = st->g[l].h;
-            v.tx = (v.w + BT - 1) / BT; v.ty = (v.h + BT - 1) / BT;
+            v.tx = (v.w + BT - 1) / BT; v.ty = (v.h + BTH - 1) / BTH;
             v.block0 = blocks;
             blocks += v.tx * v.ty * NS;
         }

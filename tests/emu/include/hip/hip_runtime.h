@@ -56,6 +56,7 @@ struct float4 { float x, y, z, w; };
 static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 static inline float __fdividef(float a, float b) { return a / b; }
+static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return a < b ? (b < c ? b : (a < c ? c : a)) : (a < c ? a : (b < c ? c : b)); }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
