@@ -88,13 +88,12 @@ __device__ __forceinline__ float conv9(const float (&s)[SS_H][SS_W + 1], int lx,
 // accumulator and receives its 81 taps in row-major order, exactly like conv9.
 constexpr int CW = 64, CH = 16, CSW = CW + 2 * SH, CSH = CH + 2 * SH;
 
-// 4 adjacent outputs (lx..lx+3, ly), lx % 4 == 0.  The row loop stays rolled: the 9 coefficients of a
-// row are scalar loads indexed by the (uniform) row counter, and only one row of samples (12 VGPRs) is
-// live at a time -- fully unrolled, the compiler hoists all 27 row reads and needs > 160 VGPRs.
-// Zero taps are multiplied too (fma(0, v, acc) == acc for finite v), the order is unchanged.
-__device__ __forceinline__ void conv9x4(const float (&s)[CSH][CSW], int lx, int ly, const float* __restrict__ k, float kscale, float (&o)[4]) {
+// 4 adjacent outputs (lx..lx+3, ly), lx % 4 == 0.  Fully unrolled: the 81 coefficients become
+// immediates and zero taps vanish (measured faster than a rolled row loop with scalar coefficient
+// loads, despite the higher register count).
+__device__ __forceinline__ void conv9x4(const float (&s)[CSH][CSW], int lx, int ly, const float* k, float kscale, float (&o)[4]) {
     o[0] = o[1] = o[2] = o[3] = 0.f;
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < 9; ++i) {
         const float4 a = *reinterpret_cast<const float4*>(&s[ly + i][lx]);
         const float4 b = *reinterpret_cast<const float4*>(&s[ly + i][lx + 4]);
@@ -103,15 +102,17 @@ __device__ __forceinline__ void conv9x4(const float (&s)[CSH][CSW], int lx, int 
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const float kv = k[i * 9 + j] * kscale;   // x2 is exact
-            o[0] = __builtin_fmaf(kv, v[j], o[0]); o[1] = __builtin_fmaf(kv, v[j + 1], o[1]);
-            o[2] = __builtin_fmaf(kv, v[j + 2], o[2]); o[3] = __builtin_fmaf(kv, v[j + 3], o[3]);
+            if (kv != 0.f) {
+                o[0] = __builtin_fmaf(kv, v[j], o[0]); o[1] = __builtin_fmaf(kv, v[j + 1], o[1]);
+                o[2] = __builtin_fmaf(kv, v[j + 2], o[2]); o[3] = __builtin_fmaf(kv, v[j + 3], o[3]);
+            }
         }
     }
 }
 // 4 outputs at every second column (lx, lx+2, lx+4, lx+6), lx % 8 == 0 (the decimated low-pass)
-__device__ __forceinline__ void conv9x4s2(const float (&s)[CSH][CSW], int lx, int ly, const float* __restrict__ k, float kscale, float (&o)[4]) {
+__device__ __forceinline__ void conv9x4s2(const float (&s)[CSH][CSW], int lx, int ly, const float* k, float kscale, float (&o)[4]) {
     o[0] = o[1] = o[2] = o[3] = 0.f;
-#pragma unroll 1
+#pragma unroll
     for (int i = 0; i < 9; ++i) {
         const float4 a = *reinterpret_cast<const float4*>(&s[ly + i][lx]);
         const float4 b = *reinterpret_cast<const float4*>(&s[ly + i][lx + 4]);
@@ -121,8 +122,10 @@ __device__ __forceinline__ void conv9x4s2(const float (&s)[CSH][CSW], int lx, in
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const float kv = k[i * 9 + j] * kscale;
-            o[0] = __builtin_fmaf(kv, v[j], o[0]); o[1] = __builtin_fmaf(kv, v[j + 2], o[1]);
-            o[2] = __builtin_fmaf(kv, v[j + 4], o[2]); o[3] = __builtin_fmaf(kv, v[j + 6], o[3]);
+            if (kv != 0.f) {
+                o[0] = __builtin_fmaf(kv, v[j], o[0]); o[1] = __builtin_fmaf(kv, v[j + 2], o[1]);
+                o[2] = __builtin_fmaf(kv, v[j + 4], o[2]); o[3] = __builtin_fmaf(kv, v[j + 6], o[3]);
+            }
         }
     }
 }
@@ -359,18 +362,23 @@ __device__ __forceinline__ void collapse_stage(float (&sb)[CSH][CSW], float (&su
 __device__ __forceinline__ void collapse_px4(const float (&sb)[CSH][CSW], const float (&su)[CSH][CSW],
                                              int lx, int ly, int gy, float (&o)[4]) {
     float lp[4] = {0.f, 0.f, 0.f, 0.f};
-    const int i0 = gy & 1;                          // rows i == gy (mod 2): 0,2,4,6,8 or 1,3,5,7
-#pragma unroll 1
-    for (int i = i0; i < 9; i += 2) {
+    const bool odd = (gy & 1) != 0;                 // rows i == gy (mod 2)
+#pragma unroll
+    for (int ii = 0; ii < 5; ++ii) {
+        const int ie = 2 * ii, io = 2 * ii + 1 < 9 ? 2 * ii + 1 : 8;
+        const int i = odd ? io : ie;
+        const bool row_ok = !(odd && ii == 4);      // odd rows: i = 1,3,5,7 only
         const float4 a = *reinterpret_cast<const float4*>(&su[ly + i][lx]);
         const float4 b = *reinterpret_cast<const float4*>(&su[ly + i][lx + 4]);
         const float4 c = *reinterpret_cast<const float4*>(&su[ly + i][lx + 8]);
         const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+        if (row_ok) {
 #pragma unroll
-        for (int j = 0; j < 9; ++j) {               // output m (column parity m & 1) uses taps j == m (mod 2)
-            const float kv = kLp9[i * 9 + j] * 2.0f;
-            if ((j & 1) == 0) { lp[0] = __builtin_fmaf(kv, v[j], lp[0]); lp[2] = __builtin_fmaf(kv, v[j + 2], lp[2]); }
-            else { lp[1] = __builtin_fmaf(kv, v[j + 1], lp[1]); lp[3] = __builtin_fmaf(kv, v[j + 3], lp[3]); }
+            for (int j = 0; j < 9; ++j) {           // output m (column parity m & 1) uses taps j == m (mod 2)
+                const float kv = (odd ? kLp9[io * 9 + j] : kLp9[ie * 9 + j]) * 2.0f;
+                if ((j & 1) == 0) { lp[0] = __builtin_fmaf(kv, v[j], lp[0]); lp[2] = __builtin_fmaf(kv, v[j + 2], lp[2]); }
+                else { lp[1] = __builtin_fmaf(kv, v[j + 1], lp[1]); lp[3] = __builtin_fmaf(kv, v[j + 3], lp[3]); }
+            }
         }
     }
     float hp[4];
