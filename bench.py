@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--ring", type=int, default=16, help="distinct input frames kept in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay steady-state frames from a captured hipGraph")
+    ap.add_argument("--frames-per-call", type=int, default=8, help="consecutive frames of the stream(s) handed to one lvm_process_device_frames call (1 = per-frame calls)")
     ap.add_argument("--pipeline", type=int, default=0, help="cross-frame pipeline depth of lvm_process_device (0 or 1)")
     ap.add_argument("--profile-steps", type=int, default=60)
     args = ap.parse_args()
@@ -152,12 +153,40 @@ def main():
         if rc != 0:
             ctx._check(rc)
 
+    # temporal batches: one call = T consecutive ring frames (frame stride = B * frame_bytes)
+    T = max(1, min(args.frames_per_call, ring))
+    fn_frames = ctx.lib.lvm_process_device_frames
+    import ctypes as C
+    prod_arr = (C.c_int * T)()
+    p_ref = C.byref(cp)
+
+    def run_frames(first, count):
+        """process `count` frames starting at global frame index `first`, in calls of at most T frames
+        that never wrap around the ring"""
+        i = first
+        end = first + count
+        while i < end:
+            t = i % ring
+            nf = min(T, end - i, ring - t)
+            if nf == 1:
+                step(i)
+            else:
+                rc = fn_frames(ctx.h, p_ref, nf, in_ptrs[t], w, h, ch, w * ch, frame_bytes, frame_bytes * B, out_ptrs[t], w * ch,
+                               frame_bytes, frame_bytes * B, prod_arr, stream)
+                if rc != 0:
+                    ctx._check(rc)
+            i += nf
+
     n = 0
-    for _ in range(args.warmup):
-        step(n); n += 1
+    run_frames(0, args.warmup); n += args.warmup
     base = n
-    dt = lvm.sharding.timed_steps(lambda i: step(base + i), args.steps, dist, torch.cuda.synchronize, torch.device("cuda", local_rank),
-                                  finish=lambda: ctx.flush(stream))
+    if T > 1:
+        # K steps (frames) issued as ceil(K / T) batched calls; timed_steps sees it as one "step" of K frames
+        dt = lvm.sharding.timed_steps(lambda i: run_frames(base, args.steps), 1, dist, torch.cuda.synchronize,
+                                      torch.device("cuda", local_rank), finish=lambda: ctx.flush(stream))
+    else:
+        dt = lvm.sharding.timed_steps(lambda i: step(base + i), args.steps, dist, torch.cuda.synchronize, torch.device("cuda", local_rank),
+                                      finish=lambda: ctx.flush(stream))
     n += args.steps
     fps = lvm.sharding.aggregate_fps(world, B, args.steps, dt)
 
@@ -168,16 +197,16 @@ def main():
         ctx.flush(stream)
         ctx.set_pipeline(0)           # per-kernel event timing uses the plain schedule
         ctx.profile(True)
-        for _ in range(args.profile_steps):
-            step(n); n += 1
+        run_frames(n, args.profile_steps); n += args.profile_steps
         torch.cuda.synchronize()
         prof = ctx.profile_collect()
         ctx.profile(False)
         tot = sum(v[0] for v in prof.values()) or 1.0
-        T = lvm.load().lvm_optimal_buffer_size(int(pk["framerate"]))
+        Twin = lvm.load().lvm_optimal_buffer_size(int(pk["framerate"]))
         for name, (ms, cnt) in prof.items():
             avg_us = 1e3 * ms / max(cnt, 1)
-            ab = kernel_alg_bytes(args.mode, name, w, h, ch, levels, B, T)
+            # a launch of the temporally batched schedule covers T_frames frames of every stream
+            ab = kernel_alg_bytes(args.mode, name, w, h, ch, levels, B * (T if args.mode == 'laplace' else 1), Twin)
             kernels[name] = {"avg_us": round(avg_us, 3), "launches": cnt, "share": round(ms / tot, 4),
                              "alg_bytes": ab, "gbs": (round(ab / (avg_us * 1e-6) / 1e9, 1) if ab else None)}
         dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
@@ -219,7 +248,7 @@ def main():
             "config": {"workload": "%s %dx%d, %d levels, %d stream(s)/GPU, device-resident u8 BGR in/out" %
                                    (args.mode, w, h, levels, B),
                        "baseline_config": cfg_idx, "streams_per_gpu": B, "ring_frames": ring,
-                       "pipeline_depth": args.pipeline, "hip_graph": bool(args.graph)},
+                       "frames_per_call": T, "pipeline_depth": args.pipeline, "hip_graph": bool(args.graph)},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "frame_alg_bytes": b_alg, "frame_roofline_frac": round(frame_frac, 5),

@@ -82,6 +82,18 @@ int  lvm_process_device(lvm_ctx* ctx, const lvm_params* p, const uint8_t* d_in, 
                         uint8_t* d_out, ptrdiff_t out_stride, ptrdiff_t out_stream_stride,
                         int* produced, void* hip_stream);
 
+/* n_frames CONSECUTIVE frames of every stream in one call -- the export / offline case
+ * (export/Exporter.cpp:216-259 feeds its chain frame after frame from a file).  Frame f of stream s
+ * is read at d_in + f*in_frame_stride + s*in_stream_stride and written likewise.  Semantically this
+ * IS n_frames calls of lvm_process_device in order (produced[f] per frame); when the mode has a
+ * temporally batched schedule (Laplace: stateless kernels take the frames as a batch dimension, the
+ * IIR kernels walk over them in order with their state in registers) the frames share launches.  */
+int  lvm_process_device_frames(lvm_ctx* ctx, const lvm_params* p, int n_frames, const uint8_t* d_in,
+                               int w, int h, int channels, ptrdiff_t in_stride,
+                               ptrdiff_t in_stream_stride, ptrdiff_t in_frame_stride, uint8_t* d_out,
+                               ptrdiff_t out_stride, ptrdiff_t out_stream_stride,
+                               ptrdiff_t out_frame_stride, int* produced, void* hip_stream);
+
 /* Cross-frame software pipeline for lvm_process_device (throughput mode, default depth 0).
  * depth 1 (implemented for the Laplace mode; other modes ignore it): a call enqueues the
  * down-sweep of ITS frame on an internal second stream concurrently with the up-sweep + output of

@@ -80,7 +80,7 @@ class LvmError(RuntimeError):
     pass
 
 
-SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process_device", "lvm_set_pipeline", "lvm_flush", "lvm_synchronize",
+SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process_device", "lvm_process_device_frames", "lvm_set_pipeline", "lvm_flush", "lvm_synchronize",
            "lvm_last_error", "lvm_max_levels", "lvm_optimal_buffer_size", "lvm_butterworth2",
            "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_profile_enable", "lvm_profile_collect",
            "lvm_profile_entry", "lvm_set_graph", "lvm_algorithmic_bytes"]
@@ -98,6 +98,9 @@ def bind(lib):
     lib.lvm_process_device.argtypes = [vp, C.POINTER(LvmParams), vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t,
                                        C.c_ssize_t, vp, C.c_ssize_t, C.c_ssize_t, C.POINTER(C.c_int), vp]
     lib.lvm_synchronize.argtypes = [vp]
+    lib.lvm_process_device_frames.argtypes = [vp, C.POINTER(LvmParams), C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t,
+                                              C.c_ssize_t, C.c_ssize_t, vp, C.c_ssize_t, C.c_ssize_t, C.c_ssize_t,
+                                              C.POINTER(C.c_int), vp]
     lib.lvm_set_pipeline.argtypes = [vp, C.c_int]
     lib.lvm_flush.argtypes = [vp, vp]
     lib.lvm_last_error.argtypes = [vp]
@@ -184,6 +187,13 @@ class Context:
         self._check(self.lib.lvm_process_device(self.h, C.byref(cparams), d_in, w, h, ch, in_stride, in_sstride,
                                                 d_out, out_stride, out_sstride, C.byref(produced), stream))
         return bool(produced.value)
+
+    def process_device_frames(self, cparams, n_frames, d_in, w, h, ch, in_stride, in_sstride, in_fstride, d_out,
+                              out_stride, out_sstride, out_fstride, stream=0):
+        produced = (C.c_int * n_frames)()
+        self._check(self.lib.lvm_process_device_frames(self.h, C.byref(cparams), n_frames, d_in, w, h, ch, in_stride, in_sstride,
+                                                       in_fstride, d_out, out_stride, out_sstride, out_fstride, produced, stream))
+        return [bool(x) for x in produced]
 
     def set_pipeline(self, depth):
         self._check(self.lib.lvm_set_pipeline(self.h, int(depth)))

@@ -28,17 +28,22 @@
 namespace lvm {
 
 struct UpArgs {
-    const float* Gl;    // G_l            [planes][h][w]
-    const float* Gn;    // G_{l+1}        [planes][hn][wn]
+    const float* Gl;    // G_l            [frame][planes][h][w]
+    const float* Gn;    // G_{l+1}        [frame][planes][hn][wn]
     const float* curn;  // cur_{l+1} or nullptr (top live level: pyrUp of the zeroed residual)
     float* hi; float* lo;  // IIR states  [planes][h*w]
-    float* cur;         // cur_l
+    float* cur;         // cur_l          [frame][planes][h*w]
     int w, h, wn, hn;
     float aHi, bHi, aLo, bLo, gain;
+    int nt;             // frames handled by this launch, in temporal order (1 = per-frame mode)
+    long fsl, fsn;      // frame strides (floats) of the level-l and level-(l+1) arrays
 };
 
 // Fused band + temporal IIR + gain + collapse step of one level.  SEED = first frame: both
 // low-pass states are seeded with the band (MagnifyCore.hpp:100-103) and nothing else happens.
+// With nt > 1 the workgroup walks over nt consecutive frames of the stream: every thread owns the
+// same 4 pixels for all frames and keeps their two low-pass states in registers, so the state is
+// read and written once per launch instead of once per frame.
 template <bool SEED>
 __global__ __launch_bounds__(256) void k_lap_up(UpArgs a) {
     __shared__ float s_g[US_H][US_W + 1], s_c[US_H][US_W + 1];
@@ -47,29 +52,52 @@ __global__ __launch_bounds__(256) void k_lap_up(UpArgs a) {
     const int sx0 = x0 / 2 - 1, sy0 = y0 / 2 - 1;
     const size_t pn = (size_t)blockIdx.z * a.wn * a.hn, pl = (size_t)blockIdx.z * a.w * a.h;
     const bool has_cur = !SEED && a.curn != nullptr;
-    pyrup_stage(s_g, a.Gn + pn, a.wn, a.hn, sx0, sy0);
-    if (has_cur) pyrup_stage(s_c, a.curn + pn, a.wn, a.hn, sx0, sy0);
-    __syncthreads();
-    pyrup_hpass(h_g, s_g, x0, sx0, a.wn, a.w);
-    if (has_cur) pyrup_hpass(h_c, s_c, x0, sx0, a.wn, a.w);
-    __syncthreads();
-    for (int i = threadIdx.x; i < UT_H * UT_W; i += 256) {
+    constexpr int NP = UT_H * UT_W / 256;
+    float hi_r[NP], lo_r[NP];
+    size_t idx_r[NP];
+    bool ok[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int i = threadIdx.x + k * 256;
         const int y = i / UT_W, x = i - y * UT_W;
         const int gx = x0 + x, gy = y0 + y;
-        if (gx >= a.w || gy >= a.h) continue;
-        const size_t idx = pl + (size_t)gy * a.w + gx;
-        const float band = a.Gl[idx] - pyrup_v(h_g, x, gy, sy0);        // SpatialFilter.cpp:33
-        if (SEED) {
-            a.hi[idx] = band; a.lo[idx] = band;
-        } else {
-            const float t1 = a.hi[idx] * a.aHi + band * a.bHi;          // TemporalFilter.cpp:16
-            const float t2 = a.lo[idx] * a.aLo + band * a.bLo;          // :17
-            a.hi[idx] = t1; a.lo[idx] = t2;
-            const float m = (t1 - t2) * a.gain;                         // :21, MagnifyCore.hpp:129-132
-            const float up = has_cur ? pyrup_v(h_c, x, gy, sy0) : 0.f;
-            a.cur[idx] = up + m;                                        // SpatialFilter.cpp:58
+        ok[k] = gx < a.w && gy < a.h;
+        idx_r[k] = pl + (size_t)(ok[k] ? gy : 0) * a.w + (ok[k] ? gx : 0);
+        hi_r[k] = lo_r[k] = 0.f;
+        if (!SEED && ok[k]) { hi_r[k] = a.hi[idx_r[k]]; lo_r[k] = a.lo[idx_r[k]]; }
+    }
+    for (int t = 0; t < a.nt; ++t) {
+        if (t > 0) __syncthreads();
+        pyrup_stage(s_g, a.Gn + (size_t)t * a.fsn + pn, a.wn, a.hn, sx0, sy0);
+        if (has_cur) pyrup_stage(s_c, a.curn + (size_t)t * a.fsn + pn, a.wn, a.hn, sx0, sy0);
+        __syncthreads();
+        pyrup_hpass(h_g, s_g, x0, sx0, a.wn, a.w);
+        if (has_cur) pyrup_hpass(h_c, s_c, x0, sx0, a.wn, a.w);
+        __syncthreads();
+        const float* Gl = a.Gl + (size_t)t * a.fsl;
+        float* cur = a.cur + (size_t)t * a.fsl;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            if (!ok[k]) continue;
+            const int i = threadIdx.x + k * 256;
+            const int y = i / UT_W, x = i - y * UT_W;
+            const int gy = y0 + y;
+            const float band = Gl[idx_r[k]] - pyrup_v(h_g, x, gy, sy0);     // SpatialFilter.cpp:33
+            if (SEED) {
+                hi_r[k] = band; lo_r[k] = band;
+            } else {
+                const float t1 = hi_r[k] * a.aHi + band * a.bHi;            // TemporalFilter.cpp:16
+                const float t2 = lo_r[k] * a.aLo + band * a.bLo;            // :17
+                hi_r[k] = t1; lo_r[k] = t2;
+                const float m = (t1 - t2) * a.gain;                         // :21, MagnifyCore.hpp:129-132
+                const float up = has_cur ? pyrup_v(h_c, x, gy, sy0) : 0.f;
+                cur[idx_r[k]] = up + m;                                     // SpatialFilter.cpp:58
+            }
         }
     }
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+        if (ok[k]) { a.hi[idx_r[k]] = hi_r[k]; a.lo[idx_r[k]] = lo_r[k]; }
 }
 
 // Final level: out = u8(Lab2BGR(Lab(in) + [1, ca, ca] * pyrUp(cur_1))).  MOTION = false is
@@ -293,6 +321,8 @@ struct TailArgs {
     float gain[kTailLevels];
     float aHi, bHi, aLo, bLo;
     int n;                              // number of down steps = L - T (>= 1)
+    int nt;                             // frames handled by this launch, in temporal order
+    long fsT;                           // frame stride (floats) of the level-T arrays (G_T, cur_T)
 };
 
 __device__ __forceinline__ float tail_src(const float* s, int w, int h, int y, int x) { return s[(size_t)y * w + x]; }
@@ -307,11 +337,14 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_lap_tail(TailArgs a) {
     __shared__ float pool[kTailPool];
     const int tid = threadIdx.x;
     const size_t plane = blockIdx.x;
+    for (int t = 0; t < a.nt; ++t) {     // frames in temporal order; the states of frame t-1 were written by this workgroup
+    const float* GTt = a.GT + (size_t)t * a.fsT;
+    float* curTt = a.curT + (size_t)t * a.fsT;
     // ---- down sweep ----
     for (int k = 0; k < a.n; ++k) {
         const int w = a.w[k], h = a.h[k], dw = a.w[k + 1], dh = a.h[k + 1];
         const float inv_dw = 1.0f / (float)dw;
-        const float* __restrict__ src = (k == 0) ? a.GT + plane * ((size_t)w * h) : pool + a.offG[k];
+        const float* __restrict__ src = (k == 0) ? GTt + plane * ((size_t)w * h) : pool + a.offG[k];
         float* __restrict__ tmp = pool + a.offA;                       // h x dw horizontal results
 #pragma unroll 4
         for (int i = tid; i < h * dw; i += TAIL_THREADS) {
@@ -347,10 +380,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_lap_tail(TailArgs a) {
             if (has_cur) tB[i] = pyrup_h(Cn + (size_t)y * sw, x, 0, sw);
         }
         __syncthreads();
-        const float* __restrict__ Gl = (k == 0) ? a.GT + plane * ((size_t)w * h) : pool + a.offG[k];
+        const float* __restrict__ Gl = (k == 0) ? GTt + plane * ((size_t)w * h) : pool + a.offG[k];
         float* __restrict__ hi = a.hi[k] + plane * ((size_t)w * h);
         float* __restrict__ lo = a.lo[k] + plane * ((size_t)w * h);
-        float* __restrict__ cur = (k == 0) ? a.curT + plane * ((size_t)w * h) : pool + a.offC[k];
+        float* __restrict__ cur = (k == 0) ? curTt + plane * ((size_t)w * h) : pool + a.offC[k];
 #pragma unroll 4
         for (int i = tid; i < h * w; i += TAIL_THREADS) {
             const int y = row_of(i, inv_w), x = i - y * w;
@@ -375,6 +408,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_lap_tail(TailArgs a) {
         }
         __syncthreads();
     }
+    }   // frames
 }
 
 // ------------------------------------------------------------------------------------------
@@ -391,6 +425,9 @@ struct LaplaceState : ModeState {
     float* curT[2] = {};                  // cur_T written by the tail kernel, double-buffered likewise
     struct Pending { bool valid = false; FrameIO io{}; lvm_params p{}; int par = 0; } pending;
     int par = 0, depth = 0;
+    // temporal batching (lvm_process_device_frames): pyramids / accumulators of up to tcap frames
+    int tcap = 0; float* tarena = nullptr;
+    float* Gt[kMaxLevels + 1] = {}; float* curt[kMaxLevels + 1] = {};
     int fuse_down = 2;                    // pyramid levels per pyrDown launch (LVM_FUSE_DOWN=2|3 selects the fused kernels)
     int tailT = 0;                       // first level handled by k_lap_tail (0 = tail disabled)
     TailArgs tail{};
@@ -409,7 +446,7 @@ struct LaplaceState : ModeState {
         std::memcpy(buf, &k, sizeof(k));
         return sizeof(k);
     }
-    ~LaplaceState() override { if (arena) (void)hipFree(arena); }
+    ~LaplaceState() override { if (arena) (void)hipFree(arena); if (tarena) (void)hipFree(tarena); }
 };
 
 static void laplace_tail_plan(LaplaceState* st);
@@ -497,11 +534,16 @@ static bool lap_vec4(const FrameIO& io) {   // 4-pixel (12-byte) vector I/O need
 
 // Stage B of a frame: u8 -> Lab -> Gaussian pyramid G_1..G_T (parity buffer `par`) and, when the tail
 // kernel is enabled, everything that happens at the levels >= T (their IIR states, cur_T[par]).
-static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, int par, bool first, hipStream_t s) {
-    const int C = io.channels, NS = c->nstreams, levels = st->levels;
+struct LapBufs { float** G; float** cur; float* curT; int nt; };   // nt frames laid out [frame][stream][channel]
+static LapBufs lap_bufs_frame(LaplaceState* st, int par) { return LapBufs{st->Gp[par], st->cur, st->curT[par], 1}; }
+
+static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, const LapBufs& B, bool first, hipStream_t s) {
+    const int C = io.channels, levels = st->levels;
+    const int NS = c->nstreams * B.nt;        // stateless kernels: a frame of the batch is just one more stream
+    const int planes = st->planes * B.nt;
     const dim3 blk(256);
     if (levels < 2) return;
-    float** G = st->Gp[par];
+    float** G = B.G;
     const LevelGeom& g1 = st->g[1];
     const dim3 grid0((g1.w + DT_W - 1) / DT_W, (g1.h + DT_H - 1) / DT_H, NS);
     if (lap_vec4(io)) {
@@ -519,19 +561,19 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         const int left = down_end - l;
         if (left >= 3 && st->fuse_down >= 3) {
             const LevelGeom &a = st->g[l], &b1 = st->g[l + 1], &b2 = st->g[l + 2], &b3 = st->g[l + 3];
-            const dim3 grid((b3.w + ML_T - 1) / ML_T, (b3.h + ML_T - 1) / ML_T, st->planes);
+            const dim3 grid((b3.w + ML_T - 1) / ML_T, (b3.h + ML_T - 1) / ML_T, planes);
             LVM_LAUNCH(c, "pyr_down3", k_pyr_down_multi<3>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b1.w, b1.h,
                        G[l + 2], b2.w, b2.h, G[l + 3], b3.w, b3.h);
             l += 3;
         } else if (left >= 2 && st->fuse_down >= 2) {
             const LevelGeom &a = st->g[l], &b1 = st->g[l + 1], &b2 = st->g[l + 2];
-            const dim3 grid((b2.w + ML_T - 1) / ML_T, (b2.h + ML_T - 1) / ML_T, st->planes);
+            const dim3 grid((b2.w + ML_T - 1) / ML_T, (b2.h + ML_T - 1) / ML_T, planes);
             LVM_LAUNCH(c, "pyr_down2", k_pyr_down_multi<2>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b1.w, b1.h,
                        G[l + 2], b2.w, b2.h, (float*)nullptr, 0, 0);
             l += 2;
         } else {
             const LevelGeom &a = st->g[l], &b = st->g[l + 1];
-            const dim3 grid((b.w + DT_W - 1) / DT_W, (b.h + DT_H - 1) / DT_H, st->planes);
+            const dim3 grid((b.w + DT_W - 1) / DT_W, (b.h + DT_H - 1) / DT_H, planes);
             LVM_LAUNCH(c, "pyr_down", k_pyr_down<0>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b.w, b.h);
             l += 1;
         }
@@ -543,7 +585,8 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         if (cLo == 0) cLo = 0.01;                                        // TemporalFilter.cpp:11-12
         TailArgs& t = st->tail;
         const int T = st->tailT;
-        t.GT = G[T]; t.curT = st->curT[par];
+        t.GT = G[T]; t.curT = B.curT;
+        t.nt = B.nt; t.fsT = (long)st->planes * (long)st->g[T].n;
         for (int k = 0; k < t.n; ++k) { t.hi[k] = st->hi[T + k]; t.lo[k] = st->lo[T + k]; t.gain[k] = gains[T + k]; }
         t.aHi = (float)(1 - cHi); t.bHi = (float)cHi; t.aLo = (float)(1 - cLo); t.bLo = (float)cLo;
         if (first) LVM_LAUNCH(c, "lap_tail_seed", k_lap_tail<true>, dim3(st->planes), dim3(TAIL_THREADS), s, t);
@@ -552,10 +595,11 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
 }
 
 // Stage A of a frame: the fused band/IIR/collapse steps of the levels below T and the final kernel.
-static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, int par, bool first, hipStream_t s) {
-    const int C = io.channels, NS = c->nstreams, levels = st->levels;
+static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, const LapBufs& B, bool first, hipStream_t s) {
+    const int C = io.channels, levels = st->levels;
+    const int NS = c->nstreams * B.nt;
     const dim3 blk(256);
-    float** G = st->Gp[par];
+    float** G = B.G;
     float gains[kMaxLevels + 2];
     laplace_gains(io.w, io.h, levels, p.amplification, p.coWavelength, gains);
     double cLo = p.coLow, cHi = p.coHigh;
@@ -564,8 +608,9 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     for (int l = up_start; l >= 1; --l) {
         UpArgs a;
         a.Gl = G[l]; a.Gn = G[l + 1];
-        a.curn = (l + 1 <= levels - 1) ? ((st->tailT && l + 1 == st->tailT) ? st->curT[par] : st->cur[l + 1]) : nullptr;
-        a.hi = st->hi[l]; a.lo = st->lo[l]; a.cur = st->cur[l];
+        a.curn = (l + 1 <= levels - 1) ? ((st->tailT && l + 1 == st->tailT) ? B.curT : B.cur[l + 1]) : nullptr;
+        a.hi = st->hi[l]; a.lo = st->lo[l]; a.cur = B.cur[l];
+        a.nt = B.nt; a.fsl = (long)st->planes * (long)st->g[l].n; a.fsn = (long)st->planes * (long)st->g[l + 1].n;
         a.w = st->g[l].w; a.h = st->g[l].h; a.wn = st->g[l + 1].w; a.hn = st->g[l + 1].h;
         a.aHi = (float)(1 - cHi); a.bHi = (float)cHi; a.aLo = (float)(1 - cLo); a.bLo = (float)cLo;
         a.gain = gains[l];
@@ -578,7 +623,7 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     const dim3 grid(ntiles < 2048 ? ntiles : 2048);
     const bool motion = !first && levels >= 2;
     const float ca = (float)p.chromAttenuation;
-    const float* cur1 = motion ? ((st->tailT == 1) ? st->curT[par] : st->cur[1]) : nullptr;
+    const float* cur1 = motion ? ((st->tailT == 1) ? B.curT : B.cur[1]) : nullptr;
     const int w1 = st->g[1].w, h1 = st->g[1].h;
     float* dbg = c->keep_float ? c->d_float : nullptr;
     auto kf4 = motion ? (c->exact_lab ? k_lap_final_v4<true, true> : k_lap_final_v4<true, false>)
@@ -597,10 +642,44 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
 int laplace_flush(Ctx* c, hipStream_t s) {
     LaplaceState* st = dynamic_cast<LaplaceState*>(c->state);
     if (!st || !st->pending.valid) return LVM_OK;
-    lap_stage_a(c, st, st->pending.p, st->pending.io, st->pending.par, false, s);
+    lap_stage_a(c, st, st->pending.p, st->pending.io, lap_bufs_frame(st, st->pending.par), false, s);
     st->pending.valid = false;
     LVM_HIP_TRY(c, hipGetLastError());
     return LVM_OK;
+}
+
+// Temporal batch: nt consecutive frames of every stream in one pass (the reference's export loop,
+// export/Exporter.cpp:216-259, sees its frames in exactly this order).  Frame f of stream b lives at
+// d_in + (f * n_streams + b) * in_sstride.  Preconditions (checked by the caller): state seeded,
+// pipeline depth 0.  Kernels and arithmetic are those of the per-frame path.
+int laplace_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int nt, hipStream_t s) {
+    LaplaceState* st = static_cast<LaplaceState*>(c->state);
+    const int levels = st->levels;
+    if (nt > st->tcap) {
+        LVM_HIP_TRY(c, hipStreamSynchronize(s));
+        if (st->tarena) (void)hipFree(st->tarena);
+        st->tarena = nullptr; st->tcap = 0;
+        auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
+        size_t total = 64;
+        for (int l = 1; l <= levels; ++l) total += pad(st->g[l].n * st->planes * nt);
+        for (int l = 1; l < levels; ++l) total += pad(st->g[l].n * st->planes * nt);
+        if (hipMalloc((void**)&st->tarena, total * sizeof(float)) != hipSuccess) { st->tarena = nullptr; c->err = "laplace: hipMalloc (frames) failed"; return LVM_ERR_OOM; }
+        float* q = st->tarena;
+        for (int l = 1; l <= levels; ++l) { st->Gt[l] = q; q += pad(st->g[l].n * st->planes * nt); }
+        for (int l = 1; l < levels; ++l) { st->curt[l] = q; q += pad(st->g[l].n * st->planes * nt); }
+        st->tcap = nt;
+    }
+    if (st->pending.valid) { const int rc = laplace_flush(c, s); if (rc != LVM_OK) return rc; }
+    LapBufs B{st->Gt, st->curt, st->tailT ? st->curt[st->tailT] : nullptr, nt};
+    lap_stage_b(c, st, p, io, B, false, s);
+    lap_stage_a(c, st, p, io, B, false, s);
+    LVM_HIP_TRY(c, hipGetLastError());
+    return LVM_OK;
+}
+
+bool laplace_can_batch(const Ctx* c) {
+    const LaplaceState* st = dynamic_cast<const LaplaceState*>(c->state);
+    return st && st->seeded && c->pipeline_depth == 0;
 }
 
 int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced) {
@@ -616,8 +695,8 @@ int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, 
     if (first || c->pipeline_depth == 0 || !c->aux_stream) {
         // plain schedule: both stages of this frame back to back on the caller's stream
         if (st->pending.valid) { const int rc = laplace_flush(c, s); if (rc != LVM_OK) return rc; }
-        lap_stage_b(c, st, p, io, 0, first, s);
-        lap_stage_a(c, st, p, io, 0, first, s);
+        lap_stage_b(c, st, p, io, lap_bufs_frame(st, 0), first, s);
+        lap_stage_a(c, st, p, io, lap_bufs_frame(st, 0), first, s);
         st->par = 1;
     } else {
         // depth-1 software pipeline across frames: stage B of THIS frame runs on the auxiliary stream
@@ -627,12 +706,12 @@ int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, 
         if (st->pending.valid) {
             LVM_HIP_TRY(c, hipEventRecord(c->ev_fork, s));
             LVM_HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-            lap_stage_b(c, st, p, io, par, false, c->aux_stream);
+            lap_stage_b(c, st, p, io, lap_bufs_frame(st, par), false, c->aux_stream);
             LVM_HIP_TRY(c, hipEventRecord(c->ev_join, c->aux_stream));
-            lap_stage_a(c, st, st->pending.p, st->pending.io, st->pending.par, false, s);
+            lap_stage_a(c, st, st->pending.p, st->pending.io, lap_bufs_frame(st, st->pending.par), false, s);
             LVM_HIP_TRY(c, hipStreamWaitEvent(s, c->ev_join, 0));
         } else {
-            lap_stage_b(c, st, p, io, par, false, s);
+            lap_stage_b(c, st, p, io, lap_bufs_frame(st, par), false, s);
         }
         st->pending.valid = true; st->pending.io = io; st->pending.p = p; st->pending.par = par;
         st->par = par ^ 1;

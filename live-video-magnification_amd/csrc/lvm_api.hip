@@ -219,6 +219,38 @@ int lvm_process_device(lvm_ctx* c, const lvm_params* p, const uint8_t* d_in, int
     return lvm::process_device(c, p, io, s, produced);
 }
 
+int lvm_process_device_frames(lvm_ctx* c, const lvm_params* p, int n_frames, const uint8_t* d_in, int w, int h, int channels,
+                              ptrdiff_t in_stride, ptrdiff_t in_stream_stride, ptrdiff_t in_frame_stride, uint8_t* d_out,
+                              ptrdiff_t out_stride, ptrdiff_t out_stream_stride, ptrdiff_t out_frame_stride, int* produced,
+                              void* hip_stream) {
+    if (!c || !p || !produced || n_frames < 1) return LVM_ERR_INVALID;
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    int f = 0;
+    while (f < n_frames) {
+        lvm::FrameIO io{d_in ? d_in + (size_t)f * in_frame_stride : nullptr, in_stride, in_stream_stride,
+                        d_out ? d_out + (size_t)f * out_frame_stride : nullptr, out_stride, out_stream_stride, w, h, channels};
+        // temporal batch: same structural key as the tracked state, steady Laplace state, frames laid
+        // out [frame][stream]; everything else (first frames, other modes, odd layouts) goes frame by frame
+        const int left = n_frames - f;
+        const int maxL = lvm::max_levels(w, h);
+        const int lv = maxL < 1 ? 0 : (p->levels < 1 ? 1 : (p->levels > maxL ? maxL : p->levels));
+        const bool same = p->mode == LVM_MODE_LAPLACE && c->t_mode == LVM_MODE_LAPLACE && lv == c->t_levels && w == c->t_w &&
+                          h == c->t_h && channels == c->t_channels && p->preprocess_key == c->t_pre && d_in && d_out;
+        if (left >= 2 && same && lvm::laplace_can_batch(c) && in_frame_stride == in_stream_stride * c->nstreams &&
+            out_frame_stride == out_stream_stride * c->nstreams) {
+            const int rc = lvm::laplace_process_frames(c, *p, io, left, s);
+            if (rc != LVM_OK) return rc;
+            for (int k = f; k < n_frames; ++k) produced[k] = 1;
+            return LVM_OK;
+        }
+        const int rc = lvm::process_device(c, p, io, s, &produced[f]);
+        if (rc != LVM_OK) return rc;
+        ++f;
+    }
+    return LVM_OK;
+}
+
 int lvm_process(lvm_ctx* c, const lvm_params* p, const uint8_t* in, int w, int h, int channels, ptrdiff_t in_stride,
                 uint8_t* out, ptrdiff_t out_stride, int* produced) {
     if (!c || !p || !produced) return LVM_ERR_INVALID;

@@ -266,6 +266,8 @@ void prof_end(Ctx* c, hipStream_t s);
 // mode entry points (laplace.hip / riesz.hip / color.hip).  Return LVM_OK or an error;
 // *produced follows the reference's passthrough rules.
 int laplace_flush(Ctx* c, hipStream_t s);
+int laplace_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int nt, hipStream_t s);
+bool laplace_can_batch(const Ctx* c);
 int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced);
 int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced);
 int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced);

@@ -155,3 +155,42 @@ def test_laplace_emu_fused_multi_level_pyrdown(lvm, po, emu, w, h, levels):
     fused k_pyr_down_multi<2|3> kernel (vector and generic first/last kernels)."""
     ck, pk = lvm.synth.config(0, (w, h, levels))
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 3, 0.0, exact=True)
+
+
+def _frames_clip(lvm, po, lib, idx, w, h, levels, n_streams, calls):
+    """lvm_process_device_frames: batches of consecutive frames (sizes in `calls`) of n_streams streams
+    must give exactly the frames the oracle produces one by one."""
+    ck, pk = lvm.synth.config(idx, (w, h, levels))
+    clips = [lvm.synth.Clip(seed=1234 + s, **ck) for s in range(n_streams)]
+    P = po.make_params(**pk)
+    cp = c_params(lvm, pk)
+    ctx = lvm.Context(0, n_streams, lib)
+    ctx.exact_lab(True)
+    orcs = [po.Oracle() for _ in range(n_streams)]
+    t = 0
+    fb = w * h * 3
+    for nf in calls:
+        fin = np.stack([np.stack([c.frame(t + f) for c in clips]) for f in range(nf)])      # [frame][stream][h][w][3]
+        fout = np.zeros_like(fin)
+        produced = ctx.process_device_frames(cp, nf, fin.ctypes.data, w, h, 3, w * 3, fb, fb * n_streams,
+                                             fout.ctypes.data, w * 3, fb, fb * n_streams)
+        ctx.synchronize()
+        for f in range(nf):
+            for s_ in range(n_streams):
+                ref, pr = orcs[s_].process(fin[f, s_], P)
+                assert produced[f] == pr, (t + f, produced[f], pr)
+                if pr:
+                    assert np.array_equal(ref, fout[f, s_]), "frame %d stream %d" % (t + f, s_)
+        t += nf
+    ctx.close()
+
+
+@pytest.mark.parametrize("w,h,levels,ns,calls", [(160, 90, 3, 1, (1, 4, 3, 1, 5)), (320, 180, 4, 1, (5, 6)),
+                                                  (135, 77, 4, 2, (3, 3, 2)), (404, 300, 5, 1, (2, 7)), (64, 48, 1, 1, (3, 3))])
+def test_laplace_emu_temporal_batches(lvm, po, emu, w, h, levels, ns, calls):
+    _frames_clip(lvm, po, emu, 0, w, h, levels, ns, calls)
+
+
+def test_frames_api_other_modes_fall_back_frame_by_frame(lvm, po, emu):
+    _frames_clip(lvm, po, emu, 2, 96, 64, 3, 1, (4, 3))
+    _frames_clip(lvm, po, emu, 3, 96, 64, 3, 1, (4, 3))
