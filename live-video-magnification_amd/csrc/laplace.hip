@@ -52,7 +52,8 @@ __global__ __launch_bounds__(256) void k_lap_up(UpArgs a) {
     const int sx0 = x0 / 2 - 1, sy0 = y0 / 2 - 1;
     const size_t pn = (size_t)blockIdx.z * a.wn * a.hn, pl = (size_t)blockIdx.z * a.w * a.h;
     const bool has_cur = !SEED && a.curn != nullptr;
-    constexpr int NP = UT_H * UT_W / 256;
+    constexpr int NP = UT_H * UT_W / 256;                 // pixels per thread
+    constexpr int NS = (US_H * US_W + 255) / 256;         // staged source elements per thread
     float hi_r[NP], lo_r[NP];
     size_t idx_r[NP];
     bool ok[NP];
@@ -66,15 +67,47 @@ __global__ __launch_bounds__(256) void k_lap_up(UpArgs a) {
         hi_r[k] = lo_r[k] = 0.f;
         if (!SEED && ok[k]) { hi_r[k] = a.hi[idx_r[k]]; lo_r[k] = a.lo[idx_r[k]]; }
     }
+    // source-tile elements this thread stages (same for every frame): vertical border map row -1 -> 1,
+    // row >= hn -> hn-1; columns clamped (the border columns are handled by pyrup_h's formulas)
+    size_t soff[NS]; int sdst[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const int i = threadIdx.x + k * 256;
+        sdst[k] = -1; soff[k] = pn;
+        if (i < US_H * US_W) {
+            const int ly = i / US_W, lx = i - ly * US_W;
+            int gy = sy0 + ly; gy = gy < 0 ? 1 : (gy >= a.hn ? a.hn - 1 : gy);
+            int gx = sx0 + lx; gx = gx < 0 ? 0 : (gx >= a.wn ? a.wn - 1 : gx);
+            soff[k] = pn + (size_t)gy * a.wn + gx;
+            sdst[k] = ly * (US_W + 1) + lx;
+        }
+    }
+    // software pipeline over the frames: the global loads of frame t+1 are in flight while frame t is
+    // filtered (registers rg/rc/gl hold the next frame)
+    float rg[NS], rc[NS], gl[NP];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) { rg[k] = a.Gn[soff[k]]; rc[k] = has_cur ? a.curn[soff[k]] : 0.f; }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) gl[k] = a.Gl[idx_r[k]];
     for (int t = 0; t < a.nt; ++t) {
         if (t > 0) __syncthreads();
-        pyrup_stage(s_g, a.Gn + (size_t)t * a.fsn + pn, a.wn, a.hn, sx0, sy0);
-        if (has_cur) pyrup_stage(s_c, a.curn + (size_t)t * a.fsn + pn, a.wn, a.hn, sx0, sy0);
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+            if (sdst[k] >= 0) { (&s_g[0][0])[sdst[k]] = rg[k]; if (has_cur) (&s_c[0][0])[sdst[k]] = rc[k]; }
+        float glc[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) glc[k] = gl[k];
         __syncthreads();
+        if (t + 1 < a.nt) {
+            const size_t on = (size_t)(t + 1) * a.fsn, ol = (size_t)(t + 1) * a.fsl;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) { rg[k] = a.Gn[on + soff[k]]; rc[k] = has_cur ? a.curn[on + soff[k]] : 0.f; }
+#pragma unroll
+            for (int k = 0; k < NP; ++k) gl[k] = a.Gl[ol + idx_r[k]];
+        }
         pyrup_hpass(h_g, s_g, x0, sx0, a.wn, a.w);
         if (has_cur) pyrup_hpass(h_c, s_c, x0, sx0, a.wn, a.w);
         __syncthreads();
-        const float* Gl = a.Gl + (size_t)t * a.fsl;
         float* cur = a.cur + (size_t)t * a.fsl;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -82,7 +115,7 @@ __global__ __launch_bounds__(256) void k_lap_up(UpArgs a) {
             const int i = threadIdx.x + k * 256;
             const int y = i / UT_W, x = i - y * UT_W;
             const int gy = y0 + y;
-            const float band = Gl[idx_r[k]] - pyrup_v(h_g, x, gy, sy0);     // SpatialFilter.cpp:33
+            const float band = glc[k] - pyrup_v(h_g, x, gy, sy0);           // SpatialFilter.cpp:33
             if (SEED) {
                 hi_r[k] = band; lo_r[k] = band;
             } else {
@@ -555,7 +588,8 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
                    G[1], g1.w, g1.h, c->lab, c->lab.a255);
     }
-    const int down_end = st->tailT ? st->tailT : levels;          // the tail builds G_{T+1..L} itself
+    const bool use_tail = st->tailT && B.nt == 1;                  // batched frames: every level gets many workgroups anyway
+    const int down_end = use_tail ? st->tailT : levels;            // the tail builds G_{T+1..L} itself
     int l = 1;
     while (l < down_end) {          // G_l -> next levels, three (or two) per launch when possible
         const int left = down_end - l;
@@ -578,7 +612,7 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
             l += 1;
         }
     }
-    if (st->tailT) {
+    if (use_tail) {
         float gains[kMaxLevels + 2];
         laplace_gains(io.w, io.h, levels, p.amplification, p.coWavelength, gains);
         double cLo = p.coLow, cHi = p.coHigh;
@@ -604,11 +638,12 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     laplace_gains(io.w, io.h, levels, p.amplification, p.coWavelength, gains);
     double cLo = p.coLow, cHi = p.coHigh;
     if (cLo == 0) cLo = 0.01;                                            // TemporalFilter.cpp:11-12
-    const int up_start = st->tailT ? st->tailT - 1 : levels - 1;
+    const bool use_tail = st->tailT && B.nt == 1;
+    const int up_start = use_tail ? st->tailT - 1 : levels - 1;
     for (int l = up_start; l >= 1; --l) {
         UpArgs a;
         a.Gl = G[l]; a.Gn = G[l + 1];
-        a.curn = (l + 1 <= levels - 1) ? ((st->tailT && l + 1 == st->tailT) ? B.curT : B.cur[l + 1]) : nullptr;
+        a.curn = (l + 1 <= levels - 1) ? ((use_tail && l + 1 == st->tailT) ? B.curT : B.cur[l + 1]) : nullptr;
         a.hi = st->hi[l]; a.lo = st->lo[l]; a.cur = B.cur[l];
         a.nt = B.nt; a.fsl = (long)st->planes * (long)st->g[l].n; a.fsn = (long)st->planes * (long)st->g[l + 1].n;
         a.w = st->g[l].w; a.h = st->g[l].h; a.wn = st->g[l + 1].w; a.hn = st->g[l + 1].h;
@@ -623,7 +658,7 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     const dim3 grid(ntiles < 2048 ? ntiles : 2048);
     const bool motion = !first && levels >= 2;
     const float ca = (float)p.chromAttenuation;
-    const float* cur1 = motion ? ((st->tailT == 1) ? B.curT : B.cur[1]) : nullptr;
+    const float* cur1 = motion ? ((use_tail && st->tailT == 1) ? B.curT : B.cur[1]) : nullptr;
     const int w1 = st->g[1].w, h1 = st->g[1].h;
     float* dbg = c->keep_float ? c->d_float : nullptr;
     auto kf4 = motion ? (c->exact_lab ? k_lap_final_v4<true, true> : k_lap_final_v4<true, false>)
