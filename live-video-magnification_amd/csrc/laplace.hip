@@ -667,7 +667,7 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
                                  : (c->exact_lab ? k_lap_final<3, false, true> : k_lap_final<3, false, false>))
                        : (motion ? k_lap_final<1, true, true> : k_lap_final<1, false, true>);
     const int groups = (ntiles + FQ - 1) / FQ;
-    const dim3 grid4(groups < 256 ? groups : 256), blk4(1024);
+    const dim3 grid4(groups < 512 ? groups : 512), blk4(1024);   // two 1024-thread workgroups per CU (LDS 2 x 48 KB): 32 waves hide the LDS/global latency
     const bool vec4 = lap_vec4(io);
     LVM_LAUNCH(c, "lap_final", vec4 ? kf4 : kf, vec4 ? grid4 : grid, vec4 ? blk4 : blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
                (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, tx, ty, NS, dbg);

@@ -235,14 +235,18 @@ int lvm_process_device_frames(lvm_ctx* c, const lvm_params* p, int n_frames, con
         const int left = n_frames - f;
         const int maxL = lvm::max_levels(w, h);
         const int lv = maxL < 1 ? 0 : (p->levels < 1 ? 1 : (p->levels > maxL ? maxL : p->levels));
-        const bool same = p->mode == LVM_MODE_LAPLACE && c->t_mode == LVM_MODE_LAPLACE && lv == c->t_levels && w == c->t_w &&
-                          h == c->t_h && channels == c->t_channels && p->preprocess_key == c->t_pre && d_in && d_out;
-        if (left >= 2 && same && lvm::laplace_can_batch(c) && in_frame_stride == in_stream_stride * c->nstreams &&
-            out_frame_stride == out_stream_stride * c->nstreams) {
-            const int rc = lvm::laplace_process_frames(c, *p, io, left, s);
-            if (rc != LVM_OK) return rc;
-            for (int k = f; k < n_frames; ++k) produced[k] = 1;
-            return LVM_OK;
+        const bool same = p->mode == c->t_mode && lv == c->t_levels && w == c->t_w && h == c->t_h && channels == c->t_channels &&
+                          p->preprocess_key == c->t_pre && d_in && d_out;
+        const bool layout = in_frame_stride == in_stream_stride * c->nstreams && out_frame_stride == out_stream_stride * c->nstreams;
+        if (left >= 2 && same && layout) {
+            int rc = 1;
+            if (p->mode == LVM_MODE_LAPLACE && lvm::laplace_can_batch(c)) rc = lvm::laplace_process_frames(c, *p, io, left, s);
+            else if (p->mode == LVM_MODE_PHASE && channels >= 3 && lvm::riesz_can_batch(c, *p)) rc = lvm::riesz_process_frames(c, *p, io, left, s);
+            if (rc <= 0) {
+                if (rc != LVM_OK) return rc;
+                for (int k = f; k < n_frames; ++k) produced[k] = 1;
+                return LVM_OK;
+            }
         }
         const int rc = lvm::process_device(c, p, io, s, &produced[f]);
         if (rc != LVM_OK) return rc;

@@ -268,6 +268,8 @@ void prof_end(Ctx* c, hipStream_t s);
 int laplace_flush(Ctx* c, hipStream_t s);
 int laplace_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int nt, hipStream_t s);
 bool laplace_can_batch(const Ctx* c);
+int riesz_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int nt, hipStream_t s);
+bool riesz_can_batch(const Ctx* c, const lvm_params& p);
 int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced);
 int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced);
 int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced);

@@ -183,8 +183,11 @@ struct PhaseLv {                       // one band level
     float *phc, *phs;                  // accumulated phase
     float *lo0c, *lo0s, *lo1c, *lo1s;  // low-cutoff filter registers
     float *hi0c, *hi0s, *hi1c, *hi1s;  // high-cutoff filter registers
-    float *amp, *tc, *ts;              // outputs
+    float *amp, *tc, *ts;              // per-frame outputs
+    float *R1c, *R2c;                  // per-frame Riesz pair of the current band (read by the amplify step);
+                                       // aliases R1p / R2p in per-frame mode
     int w, h, tx, ty, block0;          // geometry, tiles per stream, first workgroup of this level
+    long fs;                           // frame stride (floats) of band / amp / tc / ts / R1c / R2c
 };
 // All band levels in ONE launch: the levels are independent in this stage, and the small ones are
 // pure launch latency on their own.
@@ -193,6 +196,7 @@ struct PhaseArgs {
     int nlv;
     double la1, la2, lb0, lb1, lb2, ha1, ha2, hb0, hb1, hb2;
     int mode;                          // 0 = normal, 1 = seed with zero Riesz pair (init), 2 = seed with actual pair
+    int nt;                            // frames handled by this launch, in temporal order
 };
 constexpr int PT_W = 32, PT_H = 8;
 
@@ -204,76 +208,106 @@ __device__ __forceinline__ float arc_cos(float x) {
 }
 __device__ __forceinline__ float mul_sd(float x, double s) { return (float)((double)x * s); }
 
+// With nt > 1 the workgroup walks over nt consecutive frames: the 13 state values of a pixel (prior
+// band + Riesz pair, accumulated phase, 8 filter registers) stay in registers and move through HBM
+// once per launch instead of once per frame; the band tile of frame t+1 is prefetched while frame t
+// is processed.
 __global__ __launch_bounds__(256) void k_rz_phase(PhaseArgs aa) {
     __shared__ float s[PT_H + 4][PT_W + 4 + 1];
     int lvl = 0;
     while (lvl + 1 < aa.nlv && (int)blockIdx.x >= aa.lv[lvl + 1].block0) ++lvl;
     const PhaseLv& a = aa.lv[lvl];
-    const int t = blockIdx.x - a.block0;
-    const int bs = t / (a.tx * a.ty), tr = t - bs * (a.tx * a.ty);
+    const int tq = blockIdx.x - a.block0;
+    const int bs = tq / (a.tx * a.ty), tr = tq - bs * (a.tx * a.ty);
     const int x0 = (tr % a.tx) * PT_W, y0 = (tr / a.tx) * PT_H;
     const size_t pl = (size_t)bs * a.w * a.h;
-    for (int i = threadIdx.x; i < (PT_H + 4) * (PT_W + 4); i += 256) {
-        const int ly = i / (PT_W + 4), lx = i - ly * (PT_W + 4);
-        s[ly][lx] = a.band[pl + (size_t)reflect101(y0 - 2 + ly, a.h) * a.w + reflect101(x0 - 2 + lx, a.w)];
+    constexpr int NSE = ((PT_H + 4) * (PT_W + 4) + 255) / 256;
+    size_t soff[NSE]; int sdst[NSE]; float pre[NSE];
+#pragma unroll
+    for (int k = 0; k < NSE; ++k) {
+        const int i = threadIdx.x + k * 256;
+        sdst[k] = -1; soff[k] = pl;
+        if (i < (PT_H + 4) * (PT_W + 4)) {
+            const int ly = i / (PT_W + 4), lx = i - ly * (PT_W + 4);
+            soff[k] = pl + (size_t)reflect101(y0 - 2 + ly, a.h) * a.w + reflect101(x0 - 2 + lx, a.w);
+            sdst[k] = ly * (PT_W + 4 + 1) + lx;
+        }
+        pre[k] = a.band[soff[k]];
     }
-    __syncthreads();
     const int x = threadIdx.x % PT_W, y = threadIdx.x / PT_W;
     const int gx = x0 + x, gy = y0 + y;
-    if (gx >= a.w || gy >= a.h) return;
-    const size_t idx = pl + (size_t)gy * a.w + gx;
-    const float p = s[y + 2][x + 2];
-    // filter2D with [-0.2 -0.48 0 0.48 0.2] (1x5) and its transpose: non-zero taps, fma chain
-    float r1 = __builtin_fmaf(-0.2f, s[y + 2][x], 0.f);
-    r1 = __builtin_fmaf(-0.48f, s[y + 2][x + 1], r1);
-    r1 = __builtin_fmaf(0.48f, s[y + 2][x + 3], r1);
-    r1 = __builtin_fmaf(0.2f, s[y + 2][x + 4], r1);
-    float r2 = __builtin_fmaf(-0.2f, s[y][x + 2], 0.f);
-    r2 = __builtin_fmaf(-0.48f, s[y + 1][x + 2], r2);
-    r2 = __builtin_fmaf(0.48f, s[y + 3][x + 2], r2);
-    r2 = __builtin_fmaf(0.2f, s[y + 4][x + 2], r2);
-    if (aa.mode != 0) {   // seed: prior <- current (Riesz pair zeroed by RieszPyramid::init), filters cleared
-        a.P[idx] = p;
-        a.R1p[idx] = aa.mode == 1 ? 0.f : r1;
-        a.R2p[idx] = aa.mode == 1 ? 0.f : r2;
-        a.phc[idx] = 0.f; a.phs[idx] = 0.f;
-        a.lo0c[idx] = 0.f; a.lo0s[idx] = 0.f; a.lo1c[idx] = 0.f; a.lo1s[idx] = 0.f;
-        a.hi0c[idx] = 0.f; a.hi0s[idx] = 0.f; a.hi1c[idx] = 0.f; a.hi1s[idx] = 0.f;
-        return;
+    const bool ok = gx < a.w && gy < a.h;
+    const size_t idx = pl + (size_t)(ok ? gy : 0) * a.w + (ok ? gx : 0);
+    float Pp = 0.f, R1 = 0.f, R2 = 0.f, phc = 0.f, phs = 0.f;
+    float lo0c = 0.f, lo0s = 0.f, lo1c = 0.f, lo1s = 0.f, hi0c = 0.f, hi0s = 0.f, hi1c = 0.f, hi1s = 0.f;
+    if (aa.mode == 0 && ok) {
+        Pp = a.P[idx]; R1 = a.R1p[idx]; R2 = a.R2p[idx]; phc = a.phc[idx]; phs = a.phs[idx];
+        lo0c = a.lo0c[idx]; lo0s = a.lo0s[idx]; lo1c = a.lo1c[idx]; lo1s = a.lo1s[idx];
+        hi0c = a.hi0c[idx]; hi0s = a.hi0s[idx]; hi1c = a.hi1c[idx]; hi1s = a.hi1s[idx];
     }
-    const float Pp = a.P[idx], R1 = a.R1p[idx], R2 = a.R2p[idx];
-    const float q0 = (p * Pp + r1 * R1) + r2 * R2;                     // :82-84
-    const float np = p * (-1.f);
-    const float q1 = R1 * np + r1 * Pp;                                // :86
-    const float q2 = R2 * np + r2 * Pp;
-    const float xy = q1 * q1 + q2 * q2;                                // :89
-    const float ampq = sqrtf(q0 * q0 + xy);                            // :91
-    const float phi = arc_cos(q0 / ampq);                              // :93-97
-    const float sxy = sqrtf(xy);                                       // :99-100
-    float dc = (q1 / sxy) * phi, ds = (q2 / sxy) * phi;                // :102-104
-    if (dc != dc) dc = 0.f;                                            // :105-106
-    if (ds != ds) ds = 0.f;
-    const float am = sqrtf(ampq);                                      // :108
-    // IIRTemporalFilter for the low and the high cutoff (TemporalFilter.cpp:343-350); both keep
-    // their own copy of the accumulated phase in the reference, the copies are always equal.
-    const float phc = a.phc[idx] + dc, phs = a.phs[idx] + ds;
+    for (int t = 0; t < aa.nt; ++t) {
+        if (t > 0) __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NSE; ++k) if (sdst[k] >= 0) (&s[0][0])[sdst[k]] = pre[k];
+        __syncthreads();
+        if (t + 1 < aa.nt) {
+#pragma unroll
+            for (int k = 0; k < NSE; ++k) pre[k] = a.band[(size_t)(t + 1) * a.fs + soff[k]];
+        }
+        if (!ok) continue;
+        const size_t fidx = (size_t)t * a.fs + idx;
+        const float p = s[y + 2][x + 2];
+        // filter2D with [-0.2 -0.48 0 0.48 0.2] (1x5) and its transpose: non-zero taps, fma chain
+        float r1 = __builtin_fmaf(-0.2f, s[y + 2][x], 0.f);
+        r1 = __builtin_fmaf(-0.48f, s[y + 2][x + 1], r1);
+        r1 = __builtin_fmaf(0.48f, s[y + 2][x + 3], r1);
+        r1 = __builtin_fmaf(0.2f, s[y + 2][x + 4], r1);
+        float r2 = __builtin_fmaf(-0.2f, s[y][x + 2], 0.f);
+        r2 = __builtin_fmaf(-0.48f, s[y + 1][x + 2], r2);
+        r2 = __builtin_fmaf(0.48f, s[y + 3][x + 2], r2);
+        r2 = __builtin_fmaf(0.2f, s[y + 4][x + 2], r2);
+        if (aa.mode != 0) {   // seed: prior <- current (Riesz pair zeroed by RieszPyramid::init), filters cleared
+            Pp = p; R1 = aa.mode == 1 ? 0.f : r1; R2 = aa.mode == 1 ? 0.f : r2;
+            continue;
+        }
+        const float q0 = (p * Pp + r1 * R1) + r2 * R2;                     // :82-84
+        const float np = p * (-1.f);
+        const float q1 = R1 * np + r1 * Pp;                                // :86
+        const float q2 = R2 * np + r2 * Pp;
+        const float xy = q1 * q1 + q2 * q2;                                // :89
+        const float ampq = sqrtf(q0 * q0 + xy);                            // :91
+        const float phi = arc_cos(q0 / ampq);                              // :93-97
+        const float sxy = sqrtf(xy);                                       // :99-100
+        float dc = (q1 / sxy) * phi, ds = (q2 / sxy) * phi;                // :102-104
+        if (dc != dc) dc = 0.f;                                            // :105-106
+        if (ds != ds) ds = 0.f;
+        const float am = sqrtf(ampq);                                      // :108
+        // IIRTemporalFilter for the low and the high cutoff (TemporalFilter.cpp:343-350); both keep
+        // their own copy of the accumulated phase in the reference, the copies are always equal.
+        phc = phc + dc; phs = phs + ds;
+        const float ylc = mul_sd(phc, aa.lb0) + lo0c;
+        const float yls = mul_sd(phs, aa.lb0) + lo0s;
+        lo0c = (mul_sd(phc, aa.lb1) + lo1c) - mul_sd(ylc, aa.la1);
+        lo0s = (mul_sd(phs, aa.lb1) + lo1s) - mul_sd(yls, aa.la1);
+        lo1c = mul_sd(phc, aa.lb2) - mul_sd(ylc, aa.la2);
+        lo1s = mul_sd(phs, aa.lb2) - mul_sd(yls, aa.la2);
+        const float yhc = mul_sd(phc, aa.hb0) + hi0c;
+        const float yhs = mul_sd(phs, aa.hb0) + hi0s;
+        hi0c = (mul_sd(phc, aa.hb1) + hi1c) - mul_sd(yhc, aa.ha1);
+        hi0s = (mul_sd(phs, aa.hb1) + hi1s) - mul_sd(yhs, aa.ha1);
+        hi1c = mul_sd(phc, aa.hb2) - mul_sd(yhc, aa.ha2);
+        hi1s = mul_sd(phs, aa.hb2) - mul_sd(yhs, aa.ha2);
+        a.amp[fidx] = am;
+        a.tc[fidx] = (yhc - ylc) * am;                                     // RieszPyramid.cpp:118-120
+        a.ts[fidx] = (yhs - yls) * am;
+        if (a.R1c != a.R1p) { a.R1c[fidx] = r1; a.R2c[fidx] = r2; }        // batched frames keep their own pair
+        Pp = p; R1 = r1; R2 = r2;                                          // MagnifyCore.hpp:267
+    }
+    if (!ok) return;
+    a.P[idx] = Pp; a.R1p[idx] = R1; a.R2p[idx] = R2;
     a.phc[idx] = phc; a.phs[idx] = phs;
-    const float ylc = mul_sd(phc, aa.lb0) + a.lo0c[idx];
-    const float yls = mul_sd(phs, aa.lb0) + a.lo0s[idx];
-    a.lo0c[idx] = (mul_sd(phc, aa.lb1) + a.lo1c[idx]) - mul_sd(ylc, aa.la1);
-    a.lo0s[idx] = (mul_sd(phs, aa.lb1) + a.lo1s[idx]) - mul_sd(yls, aa.la1);
-    a.lo1c[idx] = mul_sd(phc, aa.lb2) - mul_sd(ylc, aa.la2);
-    a.lo1s[idx] = mul_sd(phs, aa.lb2) - mul_sd(yls, aa.la2);
-    const float yhc = mul_sd(phc, aa.hb0) + a.hi0c[idx];
-    const float yhs = mul_sd(phs, aa.hb0) + a.hi0s[idx];
-    a.hi0c[idx] = (mul_sd(phc, aa.hb1) + a.hi1c[idx]) - mul_sd(yhc, aa.ha1);
-    a.hi0s[idx] = (mul_sd(phs, aa.hb1) + a.hi1s[idx]) - mul_sd(yhs, aa.ha1);
-    a.hi1c[idx] = mul_sd(phc, aa.hb2) - mul_sd(yhc, aa.ha2);
-    a.hi1s[idx] = mul_sd(phs, aa.hb2) - mul_sd(yhs, aa.ha2);
-    a.amp[idx] = am;
-    a.tc[idx] = (yhc - ylc) * am;                                      // RieszPyramid.cpp:118-120
-    a.ts[idx] = (yhs - yls) * am;
-    a.P[idx] = p; a.R1p[idx] = r1; a.R2p[idx] = r2;                    // MagnifyCore.hpp:267
+    a.lo0c[idx] = lo0c; a.lo0s[idx] = lo0s; a.lo1c[idx] = lo1c; a.lo1s[idx] = lo1s;
+    a.hi0c[idx] = hi0c; a.hi0s[idx] = hi0s; a.hi1c[idx] = hi1c; a.hi1s[idx] = hi1s;
 }
 
 // ---- 3 x separable Gaussian-13 + amplify ------------------------------------------------------
@@ -487,22 +521,27 @@ __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+constexpr int F_ALL_N = 21;
 struct RieszState : ModeState {
     int levels = 0;
     LevelGeom g[kMaxLevels + 1];
     float* arena = nullptr;
     float* oct[kMaxLevels + 1] = {};
     float* res[kMaxLevels + 1] = {};
-    float* f[kMaxLevels + 1][19] = {};   // per band level: band,P,R1p,R2p,phc,phs,lo0c,lo0s,lo1c,lo1s,hi0c,hi0s,hi1c,hi1s,amp,tc,ts,bandA
+    float* f[kMaxLevels + 1][F_ALL_N] = {};
+    // temporal batching: per-frame fields (band, amp, tc, ts, bandA, R1c, R2c), octaves and collapse results of tcap frames
+    int tcap = 0; float* tarena = nullptr;
+    float* ft[kMaxLevels + 1][F_ALL_N] = {}; float* oct_t[kMaxLevels + 1] = {}; float* res_t[kMaxLevels + 1] = {};   // per band level: band,P,R1p,R2p,phc,phs,lo0c,lo0s,lo1c,lo1s,hi0c,hi0s,hi1c,hi1s,amp,tc,ts,bandA
     bool inited = false;
     double lo_freq = 0, hi_freq = 0, fps = 0;
     double la[3] = {}, lb[3] = {}, ha[3] = {}, hb[3] = {};
     bool steady(const lvm_params& p) const override {
         return inited && lo_freq == p.coLow && hi_freq == p.coHigh && !std::isnan(la[0]) && !std::isnan(ha[0]);
     }
-    ~RieszState() override { if (arena) (void)hipFree(arena); }
+    ~RieszState() override { if (arena) (void)hipFree(arena); if (tarena) (void)hipFree(tarena); }
 };
-enum { F_BAND, F_P, F_R1, F_R2, F_PHC, F_PHS, F_LO0C, F_LO0S, F_LO1C, F_LO1S, F_HI0C, F_HI0S, F_HI1C, F_HI1S, F_AMP, F_TC, F_TS, F_BANDA, F_COUNT };
+enum { F_BAND, F_P, F_R1, F_R2, F_PHC, F_PHS, F_LO0C, F_LO0S, F_LO1C, F_LO1S, F_HI0C, F_HI0S, F_HI1C, F_HI1S, F_AMP, F_TC, F_TS, F_BANDA, F_COUNT,
+       F_R1C = F_COUNT, F_R2C, F_ALL };   // F_R1C / F_R2C: per-frame Riesz pair (aliases F_R1 / F_R2 in per-frame mode)
 
 static int riesz_alloc(Ctx* c, RieszState* st, int w, int h, int levels) {
     st->levels = levels;
@@ -523,12 +562,106 @@ static int riesz_alloc(Ctx* c, RieszState* st, int w, int h, int levels) {
     for (int l = 0; l < levels; ++l) { st->oct[l] = p; p += pad(st->g[l].n * NS); st->res[l] = p; p += pad(st->g[l].n * NS); }
     for (int l = 0; l < levels - 1; ++l)
         for (int k = 0; k < F_COUNT; ++k) { st->f[l][k] = p; p += pad(st->g[l].n * NS); }
+    for (int l = 0; l < levels - 1; ++l) { st->f[l][F_R1C] = st->f[l][F_R1]; st->f[l][F_R2C] = st->f[l][F_R2]; }
     return LVM_OK;
 }
 
 static void riesz_coeffs(double frq, double fps, double a[3], double b[3]) {   // TemporalFilter.cpp:324-327
     const double Wn = fps == 0.0 ? 0.0 : frq / (fps / 2.0);
     butterworth2(Wn, a, b);
+}
+
+// One buffer set = where the per-frame arrays of nt frames live ([frame][stream] planes).
+struct RzBufs { float** oct; float** res; float* (*pf)[F_ALL_N]; int nt; };
+
+// pyramid of the nt frames: L plane + 9x9 split chain
+static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B, hipStream_t s) {
+    const int NZ = c->nstreams * B.nt, w = io.w, h = io.h, nb = st->levels - 1;
+    const dim3 blk(256);
+    LVM_LAUNCH(c, "rz_lab", k_rz_lab, dim3((w + 255) / 256, h, NZ), blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, B.oct[0], c->lab);
+    for (int l = 0; l < nb; ++l) {
+        const LevelGeom &a = st->g[l], &b = st->g[l + 1];
+        const dim3 grid((a.w + CW - 1) / CW, (a.h + CH - 1) / CH, NZ);
+        LVM_LAUNCH(c, "rz_split", k_rz_split, grid, blk, s, (const float*)B.oct[l], a.w, a.h, B.pf[l][F_BAND], B.oct[l + 1], b.w, b.h);
+    }
+}
+
+static void rz_phase(Ctx* c, RieszState* st, const RzBufs& B, int mode, hipStream_t s) {
+    const int NS = c->nstreams, nb = st->levels - 1;
+    if (nb < 1) return;
+    PhaseArgs a;
+    a.nlv = nb; a.mode = mode; a.nt = B.nt;
+    a.la1 = st->la[1]; a.la2 = st->la[2]; a.lb0 = st->lb[0]; a.lb1 = st->lb[1]; a.lb2 = st->lb[2];
+    a.ha1 = st->ha[1]; a.ha2 = st->ha[2]; a.hb0 = st->hb[0]; a.hb1 = st->hb[1]; a.hb2 = st->hb[2];
+    int blocks = 0;
+    for (int l = 0; l < nb; ++l) {
+        PhaseLv& v = a.lv[l];
+        float** f = st->f[l];          // state planes
+        float** q = B.pf[l];           // per-frame planes
+        v.band = q[F_BAND]; v.P = f[F_P]; v.R1p = f[F_R1]; v.R2p = f[F_R2]; v.phc = f[F_PHC]; v.phs = f[F_PHS];
+        v.lo0c = f[F_LO0C]; v.lo0s = f[F_LO0S]; v.lo1c = f[F_LO1C]; v.lo1s = f[F_LO1S];
+        v.hi0c = f[F_HI0C]; v.hi0s = f[F_HI0S]; v.hi1c = f[F_HI1C]; v.hi1s = f[F_HI1S];
+        v.amp = q[F_AMP]; v.tc = q[F_TC]; v.ts = q[F_TS]; v.R1c = q[F_R1C]; v.R2c = q[F_R2C];
+        v.w = st->g[l].w; v.h = st->g[l].h;
+        v.tx = (v.w + PT_W - 1) / PT_W; v.ty = (v.h + PT_H - 1) / PT_H;
+        v.block0 = blocks;
+        v.fs = (long)NS * (long)st->g[l].n;
+        blocks += v.tx * v.ty * NS;
+    }
+    LVM_LAUNCH(c, mode ? "rz_seed" : "rz_phase", k_rz_phase, dim3(blocks), dim3(256), s, a);
+}
+
+// amplify + collapse + output of the nt frames (RieszPyramid.cpp:248-252, 304-325; MagnifyCore.hpp:269-277)
+static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO& io, const RzBufs& B, hipStream_t s) {
+    const int NZ = c->nstreams * B.nt, w = io.w, h = io.h, levels = st->levels, nb = levels - 1;
+    const dim3 blk(256);
+    if (nb >= 1) {
+        BlurArgs a;
+        a.nlv = nb;
+        double t[13], sum = 0;   // getGaussianKernel(13, 3, CV_32F)
+        for (int i = 0; i < 13; ++i) { const double x = i - 6.0; t[i] = std::exp(-0.5 / 9.0 * x * x); sum += t[i]; }
+        sum = 1.0 / sum;
+        for (int i = 0; i < 13; ++i) a.g[i] = (float)(t[i] * sum);
+        const double PI_PERCENT = 3.1415926535897932384626433832795 / 100.0;
+        a.alpha = (float)p.amplification; a.thr = (float)(p.coWavelength * PI_PERCENT);
+        int blocks = 0;
+        for (int l = 0; l < nb; ++l) {
+            BlurLv& v = a.lv[l];
+            float** q = B.pf[l];
+            v.amp = q[F_AMP]; v.tc = q[F_TC]; v.ts = q[F_TS]; v.band = q[F_BAND]; v.R1 = q[F_R1C]; v.R2 = q[F_R2C]; v.bandA = q[F_BANDA];
+            v.w = st->g[l].w; v.h = st->g[l].h;
+            v.tx = (v.w + BT - 1) / BT; v.ty = (v.h + BTH - 1) / BTH;
+            v.block0 = blocks;
+            blocks += v.tx * v.ty * NZ;
+        }
+        LVM_LAUNCH(c, "rz_blur_amp", k_rz_blur_amp, dim3(blocks), blk, s, a);
+    }
+    const float* resn = B.oct[levels - 1];       // res_{L-1} = residual octave
+    for (int l = nb - 1; l >= 1; --l) {
+        const LevelGeom &a = st->g[l], &b = st->g[l + 1];
+        const dim3 grid((a.w + CW - 1) / CW, (a.h + CH - 1) / CH, NZ);
+        LVM_LAUNCH(c, "rz_collapse", k_rz_collapse, grid, blk, s, (const float*)B.pf[l][F_BANDA], resn, B.res[l], a.w, a.h, b.w, b.h);
+        resn = B.res[l];
+    }
+    const int tx = (w + CW - 1) / CW, ty = (h + CH - 1) / CH;
+    const int ntiles = tx * ty * NZ;
+    const dim3 grid(ntiles < 2048 ? ntiles : 2048);
+    float* dbg = c->keep_float ? c->d_float : nullptr;
+    const bool vec = w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && io.out_stride % 4 == 0 &&
+                     io.out_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0 && ((uintptr_t)io.d_out % 4) == 0;
+    const bool ex = c->exact_lab;
+    auto kfb = vec ? (ex ? k_rz_final<true, true, true> : k_rz_final<true, false, true>)
+                   : (ex ? k_rz_final<true, true, false> : k_rz_final<true, false, false>);
+    auto kfn = vec ? (ex ? k_rz_final<false, true, true> : k_rz_final<false, false, true>)
+                   : (ex ? k_rz_final<false, true, false> : k_rz_final<false, false, false>);
+    if (nb >= 1)
+        LVM_LAUNCH(c, "rz_final", kfb, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
+                   (long)io.out_stride, (long)io.out_sstride, w, h, (const float*)B.pf[0][F_BANDA], resn, st->g[1].w, st->g[1].h,
+                   c->lab, tx, ty, NZ, dbg);
+    else
+        LVM_LAUNCH(c, "rz_final", kfn, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
+                   (long)io.out_stride, (long)io.out_sstride, w, h, (const float*)nullptr, (const float*)nullptr, 0, 0,
+                   c->lab, tx, ty, NZ, dbg);
 }
 
 int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced) {
@@ -541,47 +674,14 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         const int rc = riesz_alloc(c, st, io.w, io.h, levels);
         if (rc != LVM_OK) return rc;
     }
-    const int NS = c->nstreams, w = io.w, h = io.h;
-    const dim3 blk(256);
-    const int nb = levels - 1;   // number of band levels
-
-    // L plane + pyramid of the current frame (needed by every path below)
-    {
-        const dim3 grid((w + 255) / 256, h, NS);
-        LVM_LAUNCH(c, "rz_lab", k_rz_lab, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, st->oct[0], c->lab);
-    }
-    for (int l = 0; l < nb; ++l) {
-        const LevelGeom &a = st->g[l], &b = st->g[l + 1];
-        const dim3 grid((a.w + CW - 1) / CW, (a.h + CH - 1) / CH, NS);
-        LVM_LAUNCH(c, "rz_split", k_rz_split, grid, blk, s, (const float*)st->oct[l], a.w, a.h, st->f[l][F_BAND], st->oct[l + 1], b.w, b.h);
-    }
-    auto launch_phase = [&](int mode) {
-        if (nb < 1) return;
-        PhaseArgs a;
-        a.nlv = nb; a.mode = mode;
-        a.la1 = st->la[1]; a.la2 = st->la[2]; a.lb0 = st->lb[0]; a.lb1 = st->lb[1]; a.lb2 = st->lb[2];
-        a.ha1 = st->ha[1]; a.ha2 = st->ha[2]; a.hb0 = st->hb[0]; a.hb1 = st->hb[1]; a.hb2 = st->hb[2];
-        int blocks = 0;
-        for (int l = 0; l < nb; ++l) {
-            PhaseLv& v = a.lv[l];
-            float** f = st->f[l];
-            v.band = f[F_BAND]; v.P = f[F_P]; v.R1p = f[F_R1]; v.R2p = f[F_R2]; v.phc = f[F_PHC]; v.phs = f[F_PHS];
-            v.lo0c = f[F_LO0C]; v.lo0s = f[F_LO0S]; v.lo1c = f[F_LO1C]; v.lo1s = f[F_LO1S];
-            v.hi0c = f[F_HI0C]; v.hi0s = f[F_HI0S]; v.hi1c = f[F_HI1C]; v.hi1s = f[F_HI1S];
-            v.amp = f[F_AMP]; v.tc = f[F_TC]; v.ts = f[F_TS];
-            v.w = st->g[l].w; v.h = st->g[l].h;
-            v.tx = (v.w + PT_W - 1) / PT_W; v.ty = (v.h + PT_H - 1) / PT_H;
-            v.block0 = blocks;
-            blocks += v.tx * v.ty * NS;
-        }
-        LVM_LAUNCH(c, mode ? "rz_seed" : "rz_phase", k_rz_phase, dim3(blocks), blk, s, a);
-    };
+    const RzBufs B{st->oct, st->res, st->f, 1};
+    rz_build(c, st, io, B, s);               // L plane + pyramid of the current frame (needed by every path below)
     // first frame ever, or degenerate coefficients: init and pass the frame through (:226-240)
     if (!st->inited || std::isnan(st->la[0]) || std::isnan(st->ha[0])) {
         st->lo_freq = p.coLow; st->hi_freq = p.coHigh; st->fps = p.framerate;
         riesz_coeffs(st->lo_freq, st->fps, st->la, st->lb);
         riesz_coeffs(st->hi_freq, st->fps, st->ha, st->hb);
-        launch_phase(1);
+        rz_phase(c, st, B, 1, s);
         st->inited = true;
         LVM_HIP_TRY(c, hipGetLastError());
         return LVM_OK;
@@ -590,66 +690,47 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
     bool reseed = false;
     if (st->lo_freq != p.coLow) { st->lo_freq = p.coLow; riesz_coeffs(st->lo_freq, st->fps, st->la, st->lb); reseed = true; }
     if (st->hi_freq != p.coHigh) { st->hi_freq = p.coHigh; riesz_coeffs(st->hi_freq, st->fps, st->ha, st->hb); reseed = true; }
-    if (reseed) launch_phase(2);
-    launch_phase(0);                                                             // :256-267
-    // amplify (:269)
-    float gk[13];
-    {
-        double t[13], sum = 0;   // getGaussianKernel(13, 3, CV_32F)
-        for (int i = 0; i < 13; ++i) { const double x = i - 6.0; t[i] = std::exp(-0.5 / 9.0 * x * x); sum += t[i]; }
-        sum = 1.0 / sum;
-        for (int i = 0; i < 13; ++i) gk[i] = (float)(t[i] * sum);
-    }
-    const double PI_PERCENT = 3.1415926535897932384626433832795 / 100.0;
-    if (nb >= 1) {
-        BlurArgs a;
-        a.nlv = nb;
-        for (int i = 0; i < 13; ++i) a.g[i] = gk[i];
-        a.alpha = (float)p.amplification; a.thr = (float)(p.coWavelength * PI_PERCENT);
-        int blocks = 0;
-        for (int l = 0; l < nb; ++l) {
-            BlurLv& v = a.lv[l];
-            float** f = st->f[l];
-            v.amp = f[F_AMP]; v.tc = f[F_TC]; v.ts = f[F_TS]; v.band = f[F_BAND]; v.R1 = f[F_R1]; v.R2 = f[F_R2]; v.bandA = f[F_BANDA];
-            v.w = st->g[l].w; v.h = st->g[l].h;
-            v.tx = (v.w + BT - 1) / BT; v.ty = (v.h + BTH - 1) / BTH;
-            v.block0 = blocks;
-            blocks += v.tx * v.ty * NS;
-        }
-        LVM_LAUNCH(c, "rz_blur_amp", k_rz_blur_amp, dim3(blocks), blk, s, a);
-    }
-    // collapse (:270): res_{L-1} = residual octave
-    const float* resn = st->oct[levels - 1];
-    for (int l = nb - 1; l >= 1; --l) {
-        const LevelGeom &a = st->g[l], &b = st->g[l + 1];
-        const dim3 grid((a.w + CW - 1) / CW, (a.h + CH - 1) / CH, NS);
-        LVM_LAUNCH(c, "rz_collapse", k_rz_collapse, grid, blk, s, (const float*)st->f[l][F_BANDA], resn, st->res[l], a.w, a.h, b.w, b.h);
-        resn = st->res[l];
-    }
-    {
-        const int tx = (w + CW - 1) / CW, ty = (h + CH - 1) / CH;
-        const int ntiles = tx * ty * NS;
-        const dim3 grid(ntiles < 2048 ? ntiles : 2048);
-        float* dbg = c->keep_float ? c->d_float : nullptr;
-        const bool vec = w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && io.out_stride % 4 == 0 &&
-                         io.out_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0 && ((uintptr_t)io.d_out % 4) == 0;
-        const bool ex = c->exact_lab;
-        auto kfb = vec ? (ex ? k_rz_final<true, true, true> : k_rz_final<true, false, true>)
-                       : (ex ? k_rz_final<true, true, false> : k_rz_final<true, false, false>);
-        auto kfn = vec ? (ex ? k_rz_final<false, true, true> : k_rz_final<false, false, true>)
-                       : (ex ? k_rz_final<false, true, false> : k_rz_final<false, false, false>);
-        if (nb >= 1)
-            LVM_LAUNCH(c, "rz_final", kfb, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
-                       (long)io.out_stride, (long)io.out_sstride, w, h, (const float*)st->f[0][F_BANDA], resn, st->g[1].w, st->g[1].h,
-                       c->lab, tx, ty, NS, dbg);
-        else
-            LVM_LAUNCH(c, "rz_final", kfn, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
-                       (long)io.out_stride, (long)io.out_sstride, w, h, (const float*)nullptr, (const float*)nullptr, 0, 0,
-                       c->lab, tx, ty, NS, dbg);
-    }
+    if (reseed) rz_phase(c, st, B, 2, s);
+    rz_phase(c, st, B, 0, s);                                                    // :256-267
+    rz_finish(c, st, p, io, B, s);                                               // :269-277
     LVM_HIP_TRY(c, hipGetLastError());
     *produced = 1;
     return LVM_OK;
+}
+
+// Temporal batch (see laplace_process_frames): nt consecutive frames, steady state only.
+int riesz_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int nt, hipStream_t s) {
+    RieszState* st = static_cast<RieszState*>(c->state);
+    const int levels = st->levels, NS = c->nstreams;
+    if (nt > st->tcap) {
+        LVM_HIP_TRY(c, hipStreamSynchronize(s));
+        if (st->tarena) (void)hipFree(st->tarena);
+        st->tarena = nullptr; st->tcap = 0;
+        auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
+        static const int kPer[] = {F_BAND, F_AMP, F_TC, F_TS, F_BANDA, F_R1C, F_R2C};
+        size_t total = 64;
+        for (int l = 0; l < levels; ++l) total += 2 * pad(st->g[l].n * NS * nt);
+        for (int l = 0; l < levels - 1; ++l) total += 7 * pad(st->g[l].n * NS * nt);
+        if (hipMalloc((void**)&st->tarena, total * sizeof(float)) != hipSuccess) { st->tarena = nullptr; c->err = "riesz: hipMalloc (frames) failed"; return LVM_ERR_OOM; }
+        float* q = st->tarena;
+        for (int l = 0; l < levels; ++l) { st->oct_t[l] = q; q += pad(st->g[l].n * NS * nt); st->res_t[l] = q; q += pad(st->g[l].n * NS * nt); }
+        for (int l = 0; l < levels - 1; ++l) {
+            for (int k = 0; k < F_ALL_N; ++k) st->ft[l][k] = st->f[l][k];          // state planes are shared
+            for (int k : kPer) { st->ft[l][k] = q; q += pad(st->g[l].n * NS * nt); }
+        }
+        st->tcap = nt;
+    }
+    const RzBufs B{st->oct_t, st->res_t, st->ft, nt};
+    rz_build(c, st, io, B, s);
+    rz_phase(c, st, B, 0, s);
+    rz_finish(c, st, p, io, B, s);
+    LVM_HIP_TRY(c, hipGetLastError());
+    return LVM_OK;
+}
+
+bool riesz_can_batch(const Ctx* c, const lvm_params& p) {
+    const RieszState* st = dynamic_cast<const RieszState*>(c->state);
+    return st && st->steady(p);
 }
 
 }  // namespace lvm

@@ -249,3 +249,33 @@ def test_laplace_temporal_batches_device(lvm, po, hip, w, h, levels, ns, nf):
                 assert du.max() <= 1 and (du == 0).mean() >= 0.999, (t + f, s_, du.max(), (du == 0).mean())
         t += nf
     ctx.close()
+
+
+@pytest.mark.parametrize("w,h,levels,ns,nf", [(640, 360, 5, 1, 8), (1920, 1080, 6, 1, 4), (320, 180, 4, 2, 5)])
+def test_riesz_temporal_batches_device(lvm, po, hip, w, h, levels, ns, nf):
+    import torch
+    ck, pk = lvm.synth.config(2, (w, h, levels))
+    clips = [lvm.synth.Clip(seed=1234 + s, **ck) for s in range(ns)]
+    P = po.make_params(**pk)
+    cp = c_params(lvm, pk)
+    ctx = lvm.Context(0, ns, hip)
+    orcs = [po.Oracle() for _ in range(ns)]
+    stream = torch.cuda.current_stream().cuda_stream
+    fb = w * h * 3
+    t = 0
+    for call in range(3):
+        fin = np.stack([np.stack([c.frame(t + f) for c in clips]) for f in range(nf)])
+        d_in = torch.from_numpy(fin).cuda()
+        d_out = torch.zeros_like(d_in)
+        produced = ctx.process_device_frames(cp, nf, d_in.data_ptr(), w, h, 3, w * 3, fb, fb * ns, d_out.data_ptr(), w * 3, fb, fb * ns, stream)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        for f in range(nf):
+            for s_ in range(ns):
+                ref, pr = orcs[s_].process(fin[f, s_], P)
+                assert produced[f] == pr
+                if pr:
+                    du = np.abs(ref.astype(int) - got[f, s_].astype(int))
+                    assert du.max() <= 1 and (du == 0).mean() >= 0.999, (t + f, s_, du.max(), (du == 0).mean())
+        t += nf
+    ctx.close()
