@@ -322,13 +322,9 @@ struct BlurArgs {                      // all band levels in one launch (indepen
     float alpha, thr;
 };
 
-// Register-blocked: a thread produces 4 adjacent outputs per pass from aligned 128-bit LDS reads (row
-// pass: a 16-float window; column pass: 13 rows of 4 floats); every output keeps its own accumulator and
-// OpenCV's tap order (row: left to right; column: centre, then symmetric pairs).
-constexpr int BSP = BS;                 // staged row pitch (44 floats, 16-byte multiple)
 __global__ __launch_bounds__(256) void k_rz_blur_amp(BlurArgs aa) {
-    __shared__ __attribute__((aligned(16))) float s[3][BSH][BSP];
-    __shared__ __attribute__((aligned(16))) float hr[3][BSH][BT];
+    __shared__ float s[3][BSH][BS + 1];
+    __shared__ float hr[3][BSH][BT + 1];
     int lvl = 0;
     while (lvl + 1 < aa.nlv && (int)blockIdx.x >= aa.lv[lvl + 1].block0) ++lvl;
     const BlurLv& a = aa.lv[lvl];
@@ -342,57 +338,37 @@ __global__ __launch_bounds__(256) void k_rz_blur_amp(BlurArgs aa) {
         s[0][ly][lx] = a.amp[si]; s[1][ly][lx] = a.tc[si]; s[2][ly][lx] = a.ts[si];
     }
     __syncthreads();
-    // RowFilter: acc = k0*S0; acc = fma(kj, Sj, acc), left to right -- 4 outputs per task
-    for (int i = threadIdx.x; i < 3 * BSH * (BT / 4); i += 256) {
-        const int f = i / (BSH * (BT / 4)), r = i - f * (BSH * (BT / 4));
-        const int ly = r / (BT / 4), x = (r - ly * (BT / 4)) * 4;
-        const float4 q0 = *reinterpret_cast<const float4*>(&s[f][ly][x]);
-        const float4 q1 = *reinterpret_cast<const float4*>(&s[f][ly][x + 4]);
-        const float4 q2 = *reinterpret_cast<const float4*>(&s[f][ly][x + 8]);
-        const float4 q3 = *reinterpret_cast<const float4*>(&s[f][ly][x + 12]);
-        const float v[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-        float acc[4];
+    // RowFilter: acc = k0*S0; acc = fma(kj, Sj, acc), left to right
+    for (int i = threadIdx.x; i < 3 * BSH * BT; i += 256) {
+        const int f = i / (BSH * BT), r = i - f * (BSH * BT);
+        const int ly = r / BT, x = r - ly * BT;
+        float acc = aa.g[0] * s[f][ly][x];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) acc[m] = aa.g[0] * v[m];
-#pragma unroll
-        for (int j = 1; j < 13; ++j)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = __builtin_fmaf(aa.g[j], v[m + j], acc[m]);
-        *reinterpret_cast<float4*>(&hr[f][ly][x]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        for (int j = 1; j < 13; ++j) acc = __builtin_fmaf(aa.g[j], s[f][ly][x + j], acc);
+        hr[f][ly][x] = acc;
     }
     __syncthreads();
-    {   // column pass + amplify: 2 adjacent outputs per thread (all 256 threads busy), 64-bit LDS reads
-        const int y = threadIdx.x / (BT / 2), x = (threadIdx.x - y * (BT / 2)) * 2;
+    for (int i = threadIdx.x; i < BTH * BT; i += 256) {
+        const int y = i / BT, x = i - y * BT;
         const int gx = x0 + x, gy = y0 + y;
-        if (gx < a.w && gy < a.h) {
-            float v[3][2];
+        if (gx >= a.w || gy >= a.h) continue;
+        float v[3];
 #pragma unroll
-            for (int f = 0; f < 3; ++f) {   // SymmColumnFilter: centre, then fma(kj, S[+j] + S[-j])
-                const float2 cc = *reinterpret_cast<const float2*>(&hr[f][y + BH][x]);
-                float acc0 = aa.g[6] * cc.x, acc1 = aa.g[6] * cc.y;
+        for (int f = 0; f < 3; ++f) {   // SymmColumnFilter: centre, then fma(kj, S[+j] + S[-j])
+            float acc = aa.g[6] * hr[f][y + BH][x];
 #pragma unroll
-                for (int j = 1; j <= 6; ++j) {
-                    const float2 up = *reinterpret_cast<const float2*>(&hr[f][y + BH + j][x]);
-                    const float2 dn = *reinterpret_cast<const float2*>(&hr[f][y + BH - j][x]);
-                    acc0 = __builtin_fmaf(aa.g[6 + j], up.x + dn.x, acc0);
-                    acc1 = __builtin_fmaf(aa.g[6 + j], up.y + dn.y, acc1);
-                }
-                v[f][0] = acc0; v[f][1] = acc1;
-            }
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                if (gx + m >= a.w) continue;
-                const size_t idx = pl + (size_t)gy * a.w + gx + m;
-                const float c = v[1][m] / v[0][m], sn = v[2][m] / v[0][m];      // :125-126
-                const float magV = sqrtf(c * c + sn * sn);                     // :133-134
-                float magV2 = magV * aa.alpha;                                  // :135
-                magV2 = magV2 > aa.thr ? aa.thr : magV2;                        // :136 THRESH_TRUNC
-                const float cp = cosf(magV2), sp = sinf(magV2);                // :138
-                float pair = (a.R1[idx] * c + a.R2[idx] * sn) / magV;          // :139-140
-                if (pair != pair) pair = 0.f;                                  // :141
-                a.bandA[idx] = a.band[idx] * cp - pair * sp;                   // :143
-            }
+            for (int j = 1; j <= 6; ++j) acc = __builtin_fmaf(aa.g[6 + j], hr[f][y + BH + j][x] + hr[f][y + BH - j][x], acc);
+            v[f] = acc;
         }
+        const size_t idx = pl + (size_t)gy * a.w + gx;
+        const float c = v[1] / v[0], sn = v[2] / v[0];                 // :125-126
+        const float magV = sqrtf(c * c + sn * sn);                     // :133-134
+        float magV2 = magV * aa.alpha;                                  // :135
+        magV2 = magV2 > aa.thr ? aa.thr : magV2;                         // :136 THRESH_TRUNC
+        const float cp = cosf(magV2), sp = sinf(magV2);                // :138
+        float pair = (a.R1[idx] * c + a.R2[idx] * sn) / magV;          // :139-140
+        if (pair != pair) pair = 0.f;                                  // :141
+        a.bandA[idx] = a.band[idx] * cp - pair * sp;                   // :143
     }
 }
 
