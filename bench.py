@@ -97,6 +97,8 @@ def main():
     ap.add_argument("--frames-per-call", type=int, default=8, help="consecutive frames of the stream(s) handed to one lvm_process_device_frames call (1 = per-frame calls)")
     ap.add_argument("--pipeline", type=int, default=0, help="cross-frame pipeline depth of lvm_process_device (0 or 1)")
     ap.add_argument("--profile-steps", type=int, default=60)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (smoke-testing the N > 1 path)")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import numpy as np
@@ -107,12 +109,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     lvm = importlib.import_module("live-video-magnification_amd")
     cfg_idx = MODES[args.mode]
@@ -177,13 +184,14 @@ def main():
                     ctx._check(rc)
             i += nf
 
+    red_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
     n = 0
     run_frames(0, args.warmup); n += args.warmup
     base = n
     if T > 1:
         # K steps (frames) issued as ceil(K / T) batched calls; timed_steps sees it as one "step" of K frames
         dt = lvm.sharding.timed_steps(lambda i: run_frames(base, args.steps), 1, dist, torch.cuda.synchronize,
-                                      torch.device("cuda", local_rank), finish=lambda: ctx.flush(stream))
+                                      red_dev, finish=lambda: ctx.flush(stream))
     else:
         dt = lvm.sharding.timed_steps(lambda i: step(base + i), args.steps, dist, torch.cuda.synchronize, torch.device("cuda", local_rank),
                                       finish=lambda: ctx.flush(stream))
