@@ -185,6 +185,8 @@ def main():
             i += nf
 
     red_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
+    if args.mode == "color":   # the rolling window must be full before the steady state starts
+        args.warmup = max(args.warmup, lvm.load().lvm_optimal_buffer_size(int(pk["framerate"])) + 16)
     n = 0
     run_frames(0, args.warmup); n += args.warmup
     base = n
@@ -214,7 +216,7 @@ def main():
         for name, (ms, cnt) in prof.items():
             avg_us = 1e3 * ms / max(cnt, 1)
             # a launch of the temporally batched schedule covers T_frames frames of every stream
-            ab = kernel_alg_bytes(args.mode, name, w, h, ch, levels, B * (T if args.mode in ('laplace', 'riesz') else 1), Twin)
+            ab = kernel_alg_bytes(args.mode, name, w, h, ch, levels, B * T, Twin)
             kernels[name] = {"avg_us": round(avg_us, 3), "launches": cnt, "share": round(ms / tot, 4),
                              "alg_bytes": ab, "gbs": (round(ab / (avg_us * 1e-6) / 1e9, 1) if ab else None)}
         dom = max(prof.items(), key=lambda kv: kv[1][0])[0]

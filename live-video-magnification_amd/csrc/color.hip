@@ -53,14 +53,16 @@ __device__ __forceinline__ void block_minmax(float mn, float mx, int* gmn, int* 
 // img2tempMat (SpatialFilter.cpp:63-84): one window column per frame.  Window layout: win[row][slot]
 // (time-contiguous per row, ring of `cap` slots) so that a wave reads one row's history as one
 // contiguous run.
-__global__ __launch_bounds__(256) void k_col_append(const float* __restrict__ GL, float* __restrict__ win_rows, int rows,
-                                                    int cap, int slot, MinMax* mm, int nstreams) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r < rows) win_rows[(size_t)r * cap + slot] = GL[r];
-    if (blockIdx.x == 0 && (int)threadIdx.x < nstreams) {
+// grid (row blocks, streams, frames): frame f of the batch goes to ring slot (slot + f) mod cap
+__global__ __launch_bounds__(256) void k_col_append(const float* __restrict__ GL, float* __restrict__ win, int rows,
+                                                    int rows_per_stream, int cap, int slot, MinMax* mm, int nstreams) {
+    const int r = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, f = blockIdx.z;
+    int sl = slot + f; if (sl >= cap) sl -= cap;
+    if (r < rows) win[((size_t)b * rows_per_stream + r) * cap + sl] = GL[((size_t)f * nstreams + b) * rows + r];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         MinMax m;
         m.mn1 = m.mn2 = fkey(INFINITY); m.mx1 = m.mx2 = fkey(-INFINITY);
-        mm[threadIdx.x] = m;
+        mm[f * nstreams + b] = m;
     }
 }
 // ring growth: copy the n live columns of every row into a larger ring, oldest column first
@@ -90,7 +92,10 @@ __global__ __launch_bounds__(256) void k_col_dft(const float* __restrict__ win, 
     __shared__ DftEntry s_ent[kDftMaxN / 2 + 2];
     __shared__ int s_ne;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int b = blockIdx.y;
+    const int b = blockIdx.y, fr = blockIdx.z;              // stream, frame of the batch
+    slot0 += fr; if (slot0 >= cap) slot0 -= cap;            // frame fr sees the window shifted by fr columns
+    col1 += (size_t)fr * gridDim.y * rows_per_stream;
+    mm += fr * gridDim.y;
     auto m = [&](int x) { return (x >= fl && x <= fh) ? 1.0f : 0.0f; };              // :70-77
     for (int i = threadIdx.x; i < 2 * n; i += 256) s_tw[i] = tw[i];
     if (threadIdx.x == 0) {
@@ -218,11 +223,13 @@ __global__ __launch_bounds__(256) void k_col_dft_serial(const float* __restrict_
 }
 
 // normalize(0, 1, NORM_MINMAX) (TemporalFilter.cpp:55) of column 1, x amplification (MagnifyCore.hpp:185)
+// grid (row blocks, streams * frames)
 __global__ __launch_bounds__(256) void k_col_norm(const float* __restrict__ col1, float* __restrict__ up0, int rows,
                                                   int rows_per_stream, const MinMax* mm, float amp) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.x * 256 + threadIdx.x, z = blockIdx.y;
     if (r >= rows) return;
-    const MinMax m = mm[r / rows_per_stream];
+    col1 += (size_t)z * rows_per_stream; up0 += (size_t)z * rows;
+    const MinMax m = mm[z];
     const double mn = (double)fkey_inv(m.mn1), mx = (double)fkey_inv(m.mx1);
     const double scale = (mx - mn > 2.220446049250313e-16) ? 1. / (mx - mn) : 0.;
     const double shift = 0. - mn * scale;
@@ -345,11 +352,14 @@ struct ColorState : ModeState {
     int rows = 0, rows_ps = 0;       // padded rows (all streams) and per stream
     float* win = nullptr; float* Y = nullptr; int cap = 0;
     int n = 0, slot0 = 0;            // logical window: n columns starting at ring slot slot0
+    int max_images = 0;
     double* tw = nullptr; int tw_n = 0;
     MinMax* mm = nullptr;
     int *xofs = nullptr, *yofs = nullptr; float *xa = nullptr, *ya = nullptr;
+    // temporal batching
+    int tcap = 0; float* tarena = nullptr; float* Gt[kMaxLevels + 1] = {}; float* upt[kMaxLevels + 1] = {}; float* col1t = nullptr; MinMax* mmt = nullptr;
     ~ColorState() override {
-        void* p[] = {arena, win, Y, tw, mm, xofs, yofs, xa, ya};
+        void* p[] = {arena, win, Y, tw, mm, xofs, yofs, xa, ya, tarena, mmt};
         for (void* q : p) if (q) (void)hipFree(q);
     }
 };
@@ -422,6 +432,90 @@ static int color_reserve(Ctx* c, ColorState* st, int need, hipStream_t s) {
     return LVM_OK;
 }
 
+struct ColBufs { float** G; float** up; float* col1; MinMax* mm; int nt; };   // nt frames laid out [frame][stream]
+
+// Gaussian pyramid of the unscaled frames (MagnifyCore.hpp:169-172)
+static void col_down(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs& B, hipStream_t s) {
+    const int C = io.channels, NZ = c->nstreams * B.nt, planes = st->planes * B.nt, w = io.w, h = io.h, levels = st->levels;
+    const dim3 blk(256);
+    const LevelGeom& g1 = st->g[1];
+    const dim3 grid0((g1.w + 31) / 32, (g1.h + 15) / 16, NZ);
+    const bool vec4 = C == 3 && w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0;
+    if (vec4) {
+        auto kv = k_down0_v4<false, true>;
+        LVM_LAUNCH(c, "col_down0", kv, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, B.G[1], g1.w, g1.h, c->lab);
+    } else {
+        auto kd0 = (C == 3) ? k_down0<3, false, true> : k_down0<1, false, true>;
+        LVM_LAUNCH(c, "col_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, B.G[1], g1.w, g1.h, c->lab, 1.0f);
+    }
+    int l = 1;
+    while (l < levels) {            // two pyramid levels per launch while possible
+        if (levels - l >= 2) {
+            const LevelGeom &a = st->g[l], &b1 = st->g[l + 1], &b2 = st->g[l + 2];
+            const dim3 grid((b2.w + ML_T - 1) / ML_T, (b2.h + ML_T - 1) / ML_T, planes);
+            LVM_LAUNCH(c, "pyr_down2", k_pyr_down_multi<2>, grid, blk, s, (const float*)B.G[l], a.w, a.h, B.G[l + 1], b1.w, b1.h, B.G[l + 2],
+                       b2.w, b2.h, (float*)nullptr, 0, 0);
+            l += 2;
+        } else {
+            const LevelGeom &a = st->g[l], &b = st->g[l + 1];
+            const dim3 grid((b.w + 31) / 32, (b.h + 15) / 16, planes);
+            LVM_LAUNCH(c, "pyr_down", k_pyr_down<1>, grid, blk, s, (const float*)B.G[l], a.w, a.h, B.G[l + 1], b.w, b.h);
+            l += 1;
+        }
+    }
+}
+
+// window append (nt columns) + ideal band-pass + normalisation of column 1 for every frame of the batch;
+// slot = ring slot of the first new column, slot0 = window start seen by the first frame, n = window length
+static int col_filter(Ctx* c, ColorState* st, const lvm_params& p, const ColBufs& B, int slot, int slot0, int n, hipStream_t s) {
+    const int C = st->channels, NS = c->nstreams, levels = st->levels;
+    const int nL = (int)st->g[levels].n, live = nL * C;
+    const dim3 blk(256);
+    LVM_LAUNCH(c, "col_append", k_col_append, dim3((live + 255) / 256, NS, B.nt), blk, s, (const float*)B.G[levels], st->win, live,
+               st->rows_ps, st->cap, slot, B.mm, NS);
+    if (n < 2) return LVM_OK;
+    double lo = p.coLow, hi = p.coHigh;
+    if (lo == 0.00) lo += 0.01;                                                       // TemporalFilter.cpp:26-27
+    const float width = (float)n;
+    const double fl = 2 * lo * width / p.framerate, fh = 2 * hi * width / p.framerate; // :65-66
+    if (n <= kDftMaxN) {
+        int gx = (live + kDftRows - 1) / kDftRows;
+        gx = gx < 1024 ? gx : 1024;
+        LVM_LAUNCH(c, "col_dft", k_col_dft, dim3(gx, NS, B.nt), blk, s, (const float*)st->win, slot0, n, st->cap, st->rows_ps, live, fl, fh,
+                   (const double*)st->tw, B.col1, B.mm);
+    } else {   // very long windows: serial kernel, one frame per launch
+        LVM_LAUNCH(c, "col_dft", k_col_dft_serial, dim3((live + 255) / 256, NS), blk, s, (const float*)st->win, slot0, n, st->cap,
+                   st->rows_ps, live, fl, fh, (const double*)st->tw, st->Y, B.col1, B.mm);
+    }
+    LVM_LAUNCH(c, "col_norm", k_col_norm, dim3((live + 255) / 256, NS * B.nt), blk, s, (const float*)B.col1, B.up[0], live, st->rows_ps,
+               (const MinMax*)B.mm, (float)p.amplification);
+    return LVM_OK;
+}
+
+// up chain (SpatialFilter.cpp:40-50) + output (MagnifyCore.hpp:197-203)
+static void col_up_out(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs& B, hipStream_t s) {
+    const int C = io.channels, NZ = c->nstreams * B.nt, planes = st->planes * B.nt, levels = st->levels;
+    const dim3 blk(256);
+    int uw = st->g[levels].w, uh = st->g[levels].h;
+    for (int k = 0; k + 1 < levels; ++k) {      // L-1 generic pyrUps, the last one is fused into k_col_out
+        const dim3 grid((2 * uw + 63) / 64, (2 * uh + 15) / 16, planes);
+        LVM_LAUNCH(c, "pyr_up", k_pyr_up<1>, grid, blk, s, (const float*)B.up[k], uw, uh, B.up[k + 1], 2 * uw, 2 * uh);
+        uw *= 2; uh *= 2;
+    }
+    OutArgs a;
+    a.in = io.d_in; a.in_stride = (long)io.in_stride; a.in_sstride = (long)io.in_sstride;
+    a.out = io.d_out; a.out_stride = (long)io.out_stride; a.out_sstride = (long)io.out_sstride;
+    a.w = io.w; a.h = io.h; a.V = B.up[levels - 1]; a.vw = uw; a.vh = uh;
+    a.xofs = st->xofs; a.xa = st->xa; a.yofs = st->yofs; a.ya = st->ya; a.mm = B.mm;
+    a.tiles_x = (io.w + CT_W - 1) / CT_W; a.tiles_y = (io.h + CT_H - 1) / CT_H;
+    a.dbg = c->keep_float ? c->d_float : nullptr;
+    const dim3 grid(a.tiles_x, a.tiles_y, NZ);
+    auto k1 = (C == 3) ? k_col_out<3, false> : k_col_out<1, false>;
+    auto k2 = (C == 3) ? k_col_out<3, true> : k_col_out<1, true>;
+    LVM_LAUNCH(c, "col_minmax", k1, grid, blk, s, a);
+    LVM_LAUNCH(c, "col_out", k2, grid, blk, s, a);
+}
+
 int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced) {
     *produced = 0;
     ColorState* st = static_cast<ColorState*>(c->state);
@@ -431,50 +525,20 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         const int rc = color_alloc(c, st, io.w, io.h, io.channels, levels);
         if (rc != LVM_OK) return rc;
     }
-    const int C = io.channels, NS = c->nstreams, w = io.w, h = io.h;
-    const dim3 blk(256);
-    // ---- Gaussian pyramid of the unscaled frame (:169-172) ----
-    {
-        const LevelGeom& g1 = st->g[1];
-        const dim3 grid0((g1.w + 31) / 32, (g1.h + 15) / 16, NS);
-        const bool vec4 = C == 3 && w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0;
-        if (vec4) {
-            auto kv = k_down0_v4<false, true>;
-            LVM_LAUNCH(c, "col_down0", kv, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h,
-                       st->G[1], g1.w, g1.h, c->lab);
-        } else {
-            auto kd0 = (C == 3) ? k_down0<3, false, true> : k_down0<1, false, true>;
-            LVM_LAUNCH(c, "col_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, st->G[1], g1.w, g1.h, c->lab, 1.0f);
-        }
-        for (int l = 1; l < levels; ++l) {
-            const LevelGeom &a = st->g[l], &b = st->g[l + 1];
-            const dim3 grid((b.w + 31) / 32, (b.h + 15) / 16, st->planes);
-            LVM_LAUNCH(c, "pyr_down", k_pyr_down<1>, grid, blk, s, (const float*)st->G[l], a.w, a.h, st->G[l + 1], b.w, b.h);
-        }
-    }
+    const ColBufs B{st->G, st->up, st->col1, st->mm, 1};
+    col_down(c, st, io, B, s);
     // ---- rolling window (:175-176, SpatialFilter.cpp:63-84) ----
     const int maxImages = optimal_buffer_size((int)p.framerate);
+    st->max_images = maxImages;
     {
-        const int want = maxImages > 0 && maxImages <= 4096 ? maxImages + 1 : 0;
+        const int want = maxImages > 0 && maxImages <= 4096 ? maxImages + 17 : 0;      // room for temporal batches
         const int rc = color_reserve(c, st, st->n + 1 > want ? st->n + 1 : want, s);
         if (rc != LVM_OK) return rc;
     }
-    const int nL = (int)st->g[levels].n;
-    {
-        const int slot = (st->slot0 + st->n) % st->cap;
-        // rows are laid out per stream with padding: append stream by stream
-        for (int b = 0; b < NS; ++b) {
-            const dim3 grid((nL * C + 255) / 256);
-            LVM_LAUNCH(c, "col_append", k_col_append, grid, blk, s, (const float*)(st->G[levels] + (size_t)b * C * nL),
-                       st->win + (size_t)b * st->rows_ps * st->cap, nL * C, st->cap, slot, st->mm, b == 0 ? NS : 0);
-        }
-        st->n += 1;
-        if (st->n > maxImages && maxImages > 0) { st->slot0 = (st->slot0 + 1) % st->cap; st->n -= 1; }
-    }
-    if (st->n < 2) { LVM_HIP_TRY(c, hipGetLastError()); return LVM_OK; }            // :180
-    // ---- ideal band-pass over time (:183) ----
-    const int n = st->n;
-    if (st->tw_n != n) {   // twiddles cos/sin(2 pi k / n), float64, computed on the host like the oracle's
+    const int slot = (st->slot0 + st->n) % st->cap;
+    int n = st->n + 1, slot0 = st->slot0;
+    if (n > maxImages && maxImages > 0) { slot0 = (slot0 + 1) % st->cap; n -= 1; }
+    if (n >= 2 && st->tw_n != n) {   // twiddles cos/sin(2 pi k / n), float64, computed on the host like the oracle's
         std::vector<double> t(2 * (size_t)n);
         for (int k = 0; k < n; ++k) { t[k] = std::cos(2.0 * 3.1415926535897932384626433832795 * k / n); t[n + k] = std::sin(2.0 * 3.1415926535897932384626433832795 * k / n); }
         LVM_HIP_TRY(c, hipStreamSynchronize(s));
@@ -484,48 +548,57 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         LVM_HIP_TRY(c, hipMemcpy(st->tw, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
         st->tw_n = n;
     }
-    double lo = p.coLow, hi = p.coHigh;
-    if (lo == 0.00) lo += 0.01;                                                       // TemporalFilter.cpp:26-27
-    const float width = (float)n;
-    const double fl = 2 * lo * width / p.framerate, fh = 2 * hi * width / p.framerate; // :65-66
-    {
-        const int live = nL * C;
-        if (n <= kDftMaxN) {
-            int gx = (live + kDftRows - 1) / kDftRows;
-            gx = gx < 1024 ? gx : 1024;
-            LVM_LAUNCH(c, "col_dft", k_col_dft, dim3(gx, NS), blk, s, (const float*)st->win, st->slot0, n, st->cap, st->rows_ps, live, fl, fh,
-                       (const double*)st->tw, st->col1, st->mm);
-        } else {
-            LVM_LAUNCH(c, "col_dft", k_col_dft_serial, dim3((live + 255) / 256, NS), blk, s, (const float*)st->win, st->slot0, n, st->cap,
-                       st->rows_ps, live, fl, fh, (const double*)st->tw, st->Y, st->col1, st->mm);
-        }
-    }
-    for (int b = 0; b < NS; ++b) {
-        const dim3 grid((nL * C + 255) / 256);
-        LVM_LAUNCH(c, "col_norm", k_col_norm, grid, blk, s, (const float*)(st->col1 + (size_t)b * st->rows_ps),
-                   st->up[0] + (size_t)b * C * nL, nL * C, st->rows_ps, (const MinMax*)(st->mm + b), (float)p.amplification);
-    }
-    // ---- up chain (SpatialFilter.cpp:40-50): L-1 generic pyrUps, the last one is fused below ----
-    int uw = st->g[levels].w, uh = st->g[levels].h;
-    for (int k = 0; k + 1 < levels; ++k) {
-        const dim3 grid((2 * uw + 63) / 64, (2 * uh + 15) / 16, st->planes);
-        LVM_LAUNCH(c, "pyr_up", k_pyr_up<1>, grid, blk, s, (const float*)st->up[k], uw, uh, st->up[k + 1], 2 * uw, 2 * uh);
-        uw *= 2; uh *= 2;
-    }
-    OutArgs a;
-    a.in = io.d_in; a.in_stride = (long)io.in_stride; a.in_sstride = (long)io.in_sstride;
-    a.out = io.d_out; a.out_stride = (long)io.out_stride; a.out_sstride = (long)io.out_sstride;
-    a.w = w; a.h = h; a.V = st->up[levels - 1]; a.vw = uw; a.vh = uh;
-    a.xofs = st->xofs; a.xa = st->xa; a.yofs = st->yofs; a.ya = st->ya; a.mm = st->mm;
-    a.tiles_x = (w + CT_W - 1) / CT_W; a.tiles_y = (h + CT_H - 1) / CT_H;
-    a.dbg = c->keep_float ? c->d_float : nullptr;
-    const dim3 grid(a.tiles_x, a.tiles_y, NS);
-    auto k1 = (C == 3) ? k_col_out<3, false> : k_col_out<1, false>;
-    auto k2 = (C == 3) ? k_col_out<3, true> : k_col_out<1, true>;
-    LVM_LAUNCH(c, "col_minmax", k1, grid, blk, s, a);
-    LVM_LAUNCH(c, "col_out", k2, grid, blk, s, a);
+    const int rc = col_filter(c, st, p, B, slot, slot0, n, s);
+    if (rc != LVM_OK) return rc;
+    st->n = n; st->slot0 = slot0;
+    if (st->n < 2) { LVM_HIP_TRY(c, hipGetLastError()); return LVM_OK; }            // :180
+    col_up_out(c, st, io, B, s);
     LVM_HIP_TRY(c, hipGetLastError());
     *produced = 1;
+    return LVM_OK;
+}
+
+// Temporal batch: nt consecutive frames; only in the steady state of the rolling window (full window, so
+// its length -- and with it the twiddle table and the mask -- is the same for every frame of the batch).
+bool color_can_batch(const Ctx* c, const lvm_params& p, int nt) {
+    const ColorState* st = dynamic_cast<const ColorState*>(c->state);
+    if (!st) return false;
+    const int maxImages = optimal_buffer_size((int)p.framerate);
+    return maxImages > 0 && st->max_images == maxImages && st->n == maxImages && st->tw_n == st->n && st->n <= kDftMaxN &&
+           st->cap >= st->n + nt;
+}
+
+int color_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int nt, hipStream_t s) {
+    ColorState* st = static_cast<ColorState*>(c->state);
+    const int levels = st->levels, NS = c->nstreams;
+    if (nt > st->tcap) {
+        LVM_HIP_TRY(c, hipStreamSynchronize(s));
+        if (st->tarena) (void)hipFree(st->tarena);
+        if (st->mmt) (void)hipFree(st->mmt);
+        st->tarena = nullptr; st->mmt = nullptr; st->tcap = 0;
+        auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
+        const size_t nL = st->g[levels].n;
+        size_t total = 64;
+        for (int l = 1; l <= levels; ++l) total += pad(st->g[l].n * st->planes * nt);
+        for (int k = 0; k < levels; ++k) total += pad((nL << (2 * k)) * st->planes * nt);
+        total += pad((size_t)st->rows * nt);
+        if (hipMalloc((void**)&st->tarena, total * sizeof(float)) != hipSuccess) { st->tarena = nullptr; c->err = "color: hipMalloc (frames) failed"; return LVM_ERR_OOM; }
+        LVM_HIP_TRY(c, hipMalloc((void**)&st->mmt, sizeof(MinMax) * NS * nt));
+        float* q = st->tarena;
+        for (int l = 1; l <= levels; ++l) { st->Gt[l] = q; q += pad(st->g[l].n * st->planes * nt); }
+        for (int k = 0; k < levels; ++k) { st->upt[k] = q; q += pad((nL << (2 * k)) * st->planes * nt); }
+        st->col1t = q;
+        st->tcap = nt;
+    }
+    const ColBufs B{st->Gt, st->upt, st->col1t, st->mmt, nt};
+    col_down(c, st, io, B, s);
+    // frame f appends at slot (slot0 + n + f) and, the window being full, sees it start at slot0 + f + 1
+    const int slot = (st->slot0 + st->n) % st->cap, slot0 = (st->slot0 + 1) % st->cap;
+    const int rc = col_filter(c, st, p, B, slot, slot0, st->n, s);
+    if (rc != LVM_OK) return rc;
+    st->slot0 = (st->slot0 + nt) % st->cap;
+    col_up_out(c, st, io, B, s);
+    LVM_HIP_TRY(c, hipGetLastError());
     return LVM_OK;
 }
 

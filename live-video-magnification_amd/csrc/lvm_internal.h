@@ -270,6 +270,8 @@ int laplace_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int n
 bool laplace_can_batch(const Ctx* c);
 int riesz_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int nt, hipStream_t s);
 bool riesz_can_batch(const Ctx* c, const lvm_params& p);
+int color_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int nt, hipStream_t s);
+bool color_can_batch(const Ctx* c, const lvm_params& p, int nt);
 int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced);
 int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced);
 int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced);

@@ -468,9 +468,20 @@ __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in
         const int x0 = tx * CW, y0 = ty * CH;
         const int gx = x0 + x, gy = y0 + y;
         const bool ok = gx < w && gy < h;
-        const uint8_t* p = in + (size_t)b * in_sstride + (size_t)(ok ? gy : 0) * in_stride + (size_t)(ok ? gx : 0) * 3;
-        uint32_t pb[12];
+        // phase A: collapse (register-heavy 9x9 taps); its 4 results go through LDS so that the register
+        // allocation of phase B (colour math) does not add to it
+        if (BANDS) {
+            collapse_stage(sb, su, bandA + (size_t)b * w * h, resn + (size_t)b * nw * nh, w, h, nw, nh, x0, y0);
+            __syncthreads();
+            float Lc[4] = {0.f, 0.f, 0.f, 0.f};
+            if (ok) collapse_px4(sb, su, x, y, gy, Lc);
+            __syncthreads();                                   // all reads of sb/su done: reuse sb rows 0..15 for the results
+            *reinterpret_cast<float4*>(&sb[y][x]) = make_float4(Lc[0], Lc[1], Lc[2], Lc[3]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (ok) {
+            const uint8_t* p = in + (size_t)b * in_sstride + (size_t)gy * in_stride + (size_t)gx * 3;
+            uint32_t pb[12];
             if (VEC) {
                 const RzPx4 v = *reinterpret_cast<const RzPx4*>(p);
                 pb[0] = v.a & 255; pb[1] = (v.a >> 8) & 255; pb[2] = (v.a >> 16) & 255; pb[3] = v.a >> 24;
@@ -480,14 +491,9 @@ __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in
 #pragma unroll
                 for (int m = 0; m < 12; ++m) pb[m] = (gx + m / 3 < w) ? p[m] : 0;
             }
-        }
-        if (BANDS) {
-            collapse_stage(sb, su, bandA + (size_t)b * w * h, resn + (size_t)b * nw * nh, w, h, nw, nh, x0, y0);
-            __syncthreads();
-        }
-        if (ok) {
-            float Lc[4] = {0.f, 0.f, 0.f, 0.f};
-            if (BANDS) collapse_px4(sb, su, x, y, gy, Lc);
+            float4 Lq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (BANDS) Lq = *reinterpret_cast<const float4*>(&sb[y][x]);   // written by this very thread
+            const float Lc[4] = {Lq.x, Lq.y, Lq.z, Lq.w};
             uint32_t ob[12];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {

@@ -157,10 +157,12 @@ def test_laplace_emu_fused_multi_level_pyrdown(lvm, po, emu, w, h, levels):
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 3, 0.0, exact=True)
 
 
-def _frames_clip(lvm, po, lib, idx, w, h, levels, n_streams, calls):
+def _frames_clip(lvm, po, lib, idx, w, h, levels, n_streams, calls, over=None, clip_over=None):
     """lvm_process_device_frames: batches of consecutive frames (sizes in `calls`) of n_streams streams
     must give exactly the frames the oracle produces one by one."""
     ck, pk = lvm.synth.config(idx, (w, h, levels))
+    pk.update(over or {})
+    ck.update(clip_over or {})
     clips = [lvm.synth.Clip(seed=1234 + s, **ck) for s in range(n_streams)]
     P = po.make_params(**pk)
     cp = c_params(lvm, pk)
@@ -199,3 +201,10 @@ def test_frames_api_other_modes_fall_back_frame_by_frame(lvm, po, emu):
 @pytest.mark.parametrize("w,h,levels,ns,calls", [(96, 64, 3, 1, (2, 5, 3)), (135, 77, 4, 2, (3, 4)), (160, 90, 5, 1, (6, 2)), (64, 48, 1, 1, (4,))])
 def test_riesz_emu_temporal_batches(lvm, po, emu, w, h, levels, ns, calls):
     _frames_clip(lvm, po, emu, 2, w, h, levels, ns, calls)
+
+
+@pytest.mark.parametrize("w,h,levels,ns,calls", [(64, 48, 2, 1, (18, 5, 7, 3)), (40, 30, 1, 2, (20, 6)), (80, 52, 3, 1, (17, 16, 9))])
+def test_color_emu_temporal_batches(lvm, po, emu, w, h, levels, ns, calls):
+    """fps 7 -> the window caps at 16 columns: once it is full the remaining frames of a call share
+    launches (every frame of a batch sees the ring shifted by one column)."""
+    _frames_clip(lvm, po, emu, 3, w, h, levels, ns, calls, over={"framerate": 7.0, "coLow": 0.4, "coHigh": 2.0}, clip_over={"fps": 7.0})

@@ -279,3 +279,35 @@ def test_riesz_temporal_batches_device(lvm, po, hip, w, h, levels, ns, nf):
                     assert du.max() <= 1 and (du == 0).mean() >= 0.999, (t + f, s_, du.max(), (du == 0).mean())
         t += nf
     ctx.close()
+
+
+def test_color_temporal_batches_device(lvm, po, hip):
+    """Colour mode, fps 15 (window of 32 columns): per-frame until the window is full, then batches."""
+    import torch
+    w, h, levels, ns = 320, 180, 4, 2
+    ck, pk = lvm.synth.config(3, (w, h, levels))
+    ck["fps"] = 15.0; pk["framerate"] = 15.0; pk["coLow"] = 0.5; pk["coHigh"] = 2.0
+    clips = [lvm.synth.Clip(seed=1234 + s, **ck) for s in range(ns)]
+    P = po.make_params(**pk)
+    cp = c_params(lvm, pk)
+    ctx = lvm.Context(0, ns, hip)
+    orcs = [po.Oracle() for _ in range(ns)]
+    stream = torch.cuda.current_stream().cuda_stream
+    fb = w * h * 3
+    t = 0
+    for nf in (34, 8, 13, 5):
+        fin = np.stack([np.stack([c.frame(t + f) for c in clips]) for f in range(nf)])
+        d_in = torch.from_numpy(fin).cuda()
+        d_out = torch.zeros_like(d_in)
+        produced = ctx.process_device_frames(cp, nf, d_in.data_ptr(), w, h, 3, w * 3, fb, fb * ns, d_out.data_ptr(), w * 3, fb, fb * ns, stream)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        for f in range(nf):
+            for s_ in range(ns):
+                ref, pr = orcs[s_].process(fin[f, s_], P)
+                assert produced[f] == pr, (t + f, produced[f], pr)
+                if pr:
+                    du = np.abs(ref.astype(int) - got[f, s_].astype(int))
+                    assert du.max() <= 1 and (du == 0).mean() >= 0.999, (t + f, s_, du.max(), (du == 0).mean())
+        t += nf
+    ctx.close()
