@@ -339,6 +339,100 @@ __global__ __launch_bounds__(256) void k_col_out(OutArgs a) {
     if (!WRITE) block_minmax(vmin, vmax, &a.mm[b].mn2, &a.mm[b].mx2);
 }
 
+// Vectorised variant for the common geometry: 3 channels, dword-aligned 4-pixel groups and a width
+// the up-chain reproduces exactly (w == 2 * vw, so the horizontal resize taps are the identity).
+// The pyrUp horizontal pass reads V straight from global memory (4 floats per 4 outputs), its result
+// is the only LDS tile; the vertical pyrUp pass and the vertical bilinear taps are evaluated per pixel.
+constexpr int CO_ROWS = 18;            // source rows of V a 16-row output tile can touch (scale < 1.5)
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_col_out_v4(OutArgs a) {
+    __shared__ __attribute__((aligned(16))) float hv[3][CO_ROWS][CT_W];
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
+    const int ye = (y0 + CT_H < a.h ? y0 + CT_H : a.h) - 1;
+    const int uh = 2 * a.vh;
+    const int uy0 = a.yofs[y0];
+    int uy1 = a.yofs[ye] + 1; uy1 = uy1 < uh ? uy1 : uh - 1;
+    const int vy0 = (uy0 >> 1) - 1;
+    const int nvy = (uy1 >> 1) + 1 - vy0 + 1;
+    for (int i = threadIdx.x; i < 3 * nvy * 16; i += 256) {
+        const int c = i / (nvy * 16), rem = i - c * (nvy * 16);
+        const int ly = rem >> 4, g = rem & 15;
+        const int gx0 = x0 + 4 * g;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gx0 < a.w) {
+            int gy = vy0 + ly; gy = gy < 0 ? 1 : (gy >= a.vh ? a.vh - 1 : gy);
+            const float* row = a.V + ((size_t)b * 3 + c) * ((size_t)a.vw * a.vh) + (size_t)gy * a.vw;
+            const int i0 = gx0 >> 1;
+            const float sm1 = row[i0 > 0 ? i0 - 1 : 0], s0 = row[i0], s1 = row[i0 + 1 < a.vw ? i0 + 1 : a.vw - 1],
+                        s2 = row[i0 + 2 < a.vw ? i0 + 2 : a.vw - 1];
+            o.x = (i0 == 0) ? s0 * 6.f + s1 * 2.f : ((i0 == a.vw - 1) ? sm1 + s0 * 7.f : sm1 + s0 * 6.f + s1);
+            o.y = (i0 == a.vw - 1) ? s0 * 8.f : (s0 + s1) * 4.f;
+            o.z = (i0 + 1 == a.vw - 1) ? s0 + s1 * 7.f : s0 + s1 * 6.f + s2;
+            o.w = (i0 + 1 == a.vw - 1) ? s1 * 8.f : (s1 + s2) * 4.f;
+        }
+        *reinterpret_cast<float4*>(&hv[c][ly][4 * g]) = o;
+    }
+    __syncthreads();
+    const int ty = threadIdx.x >> 4, xg = threadIdx.x & 15;
+    const int gx = x0 + 4 * xg, gy = y0 + ty;
+    float vmin = INFINITY, vmax = -INFINITY;
+    if (gx < a.w && gy < a.h) {
+        const int sy0 = a.yofs[gy], sy1 = sy0 + 1 < uh ? sy0 + 1 : uh - 1;
+        const float b1 = a.ya[gy], b0 = 1.f - b1;
+        auto urow = [&](int c, int uy) {       // pyrUp vertical pass for U row uy, 4 columns
+            const int lj = (uy >> 1) - vy0;
+            const float4 r0 = *reinterpret_cast<const float4*>(&hv[c][lj - 1][4 * xg]);
+            const float4 r1 = *reinterpret_cast<const float4*>(&hv[c][lj][4 * xg]);
+            const float4 r2 = *reinterpret_cast<const float4*>(&hv[c][lj + 1][4 * xg]);
+            float4 u;
+            if ((uy & 1) == 0) {
+                u.x = (r0.x + r1.x * 6.f + r2.x) * (1.f / 64.f); u.y = (r0.y + r1.y * 6.f + r2.y) * (1.f / 64.f);
+                u.z = (r0.z + r1.z * 6.f + r2.z) * (1.f / 64.f); u.w = (r0.w + r1.w * 6.f + r2.w) * (1.f / 64.f);
+            } else {
+                u.x = ((r1.x + r2.x) * 4.f) * (1.f / 64.f); u.y = ((r1.y + r2.y) * 4.f) * (1.f / 64.f);
+                u.z = ((r1.z + r2.z) * 4.f) * (1.f / 64.f); u.w = ((r1.w + r2.w) * 4.f) * (1.f / 64.f);
+            }
+            return u;
+        };
+        float val[3][4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float4 u0 = urow(c, sy0), u1 = urow(c, sy1);
+            // resize INTER_LINEAR: horizontal taps are (1, 0) here: h = S*1 + S'*0; vertical D = S0*b0 + S1*b1
+            val[c][0] = u0.x * b0 + u1.x * b1; val[c][1] = u0.y * b0 + u1.y * b1;
+            val[c][2] = u0.z * b0 + u1.z * b1; val[c][3] = u0.w * b0 + u1.w * b1;
+        }
+        const Px4 pin = *reinterpret_cast<const Px4*>(a.in + (size_t)b * a.in_sstride + (size_t)gy * a.in_stride + (size_t)gx * 3);
+        int Bv[4], Gv[4], Rv[4];
+        unpack_px4(pin, Bv, Gv, Rv);
+        float osc = 0.f, osh = 0.f;
+        if (WRITE) {   // convertTo(CV_8U, 255/(max-min), -min*255/(max-min)) (MagnifyCore.hpp:202)
+            const double mn = (double)fkey_inv(a.mm[b].mn2), mx = (double)fkey_inv(a.mm[b].mx2);
+            osc = (float)(255.0 / (mx - mn)); osh = (float)(-mn * 255.0 / (mx - mn));
+        }
+        uint32_t ob[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float o0 = (float)Bv[k] * 1.0f + val[0][k], o1 = (float)Gv[k] * 1.0f + val[1][k], o2 = (float)Rv[k] * 1.0f + val[2][k];
+            if (WRITE) {
+                ob[3 * k] = sat_u8(o0 * osc + osh); ob[3 * k + 1] = sat_u8(o1 * osc + osh); ob[3 * k + 2] = sat_u8(o2 * osc + osh);
+                if (a.dbg && b == 0) { float* d = a.dbg + ((size_t)gy * a.w + gx + k) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
+            } else {
+                vmin = fminf(vmin, fminf(o0, fminf(o1, o2))); vmax = fmaxf(vmax, fmaxf(o0, fmaxf(o1, o2)));
+            }
+        }
+        if (WRITE) {
+            Px4 q;
+            q.a = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
+            q.b = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
+            q.c = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
+            *reinterpret_cast<Px4*>(a.out + (size_t)b * a.out_sstride + (size_t)gy * a.out_stride + (size_t)gx * 3) = q;
+        }
+    }
+    if (!WRITE) block_minmax(vmin, vmax, &a.mm[b].mn2, &a.mm[b].mx2);
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -353,6 +447,7 @@ struct ColorState : ModeState {
     float* win = nullptr; float* Y = nullptr; int cap = 0;
     int n = 0, slot0 = 0;            // logical window: n columns starting at ring slot slot0
     int max_images = 0;
+    bool co_rows_ok = false;         // the vectorised output kernel's LDS tile covers every output tile
     double* tw = nullptr; int tw_n = 0;
     MinMax* mm = nullptr;
     int *xofs = nullptr, *yofs = nullptr; float *xa = nullptr, *ya = nullptr;
@@ -412,7 +507,13 @@ static int color_alloc(Ctx* c, ColorState* st, int w, int h, int channels, int l
     // the kernel's LDS tiles assume the resize never shrinks by more than 1.5 (true for every size
     // calculateMaxLevels admits); verify the per-tile extents once
     for (int x0 = 0; x0 < w; x0 += CT_W) { const int xe = (x0 + CT_W < w ? x0 + CT_W : w) - 1; if (xo[xe] + 1 - xo[x0] + 1 > CU_W) { c->err = "color: resize tile too wide"; return LVM_ERR_INVALID; } }
-    for (int y0 = 0; y0 < h; y0 += CT_H) { const int ye = (y0 + CT_H < h ? y0 + CT_H : h) - 1; if (yo[ye] + 1 - yo[y0] + 1 > CU_H) { c->err = "color: resize tile too tall"; return LVM_ERR_INVALID; } }
+    st->co_rows_ok = true;
+    for (int y0 = 0; y0 < h; y0 += CT_H) {
+        const int ye = (y0 + CT_H < h ? y0 + CT_H : h) - 1;
+        if (yo[ye] + 1 - yo[y0] + 1 > CU_H) { c->err = "color: resize tile too tall"; return LVM_ERR_INVALID; }
+        int u1 = yo[ye] + 1; u1 = u1 < UH ? u1 : UH - 1;
+        if ((u1 >> 1) + 1 - ((yo[y0] >> 1) - 1) + 1 > CO_ROWS) st->co_rows_ok = false;
+    }
     return LVM_OK;
 }
 
@@ -510,10 +611,18 @@ static void col_up_out(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs&
     a.tiles_x = (io.w + CT_W - 1) / CT_W; a.tiles_y = (io.h + CT_H - 1) / CT_H;
     a.dbg = c->keep_float ? c->d_float : nullptr;
     const dim3 grid(a.tiles_x, a.tiles_y, NZ);
-    auto k1 = (C == 3) ? k_col_out<3, false> : k_col_out<1, false>;
-    auto k2 = (C == 3) ? k_col_out<3, true> : k_col_out<1, true>;
-    LVM_LAUNCH(c, "col_minmax", k1, grid, blk, s, a);
-    LVM_LAUNCH(c, "col_out", k2, grid, blk, s, a);
+    const bool vec4 = C == 3 && io.w == 2 * uw && io.w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 &&
+                      io.out_stride % 4 == 0 && io.out_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0 && ((uintptr_t)io.d_out % 4) == 0 &&
+                      st->co_rows_ok;
+    if (vec4) {
+        LVM_LAUNCH(c, "col_minmax", k_col_out_v4<false>, grid, blk, s, a);
+        LVM_LAUNCH(c, "col_out", k_col_out_v4<true>, grid, blk, s, a);
+    } else {
+        auto k1 = (C == 3) ? k_col_out<3, false> : k_col_out<1, false>;
+        auto k2 = (C == 3) ? k_col_out<3, true> : k_col_out<1, true>;
+        LVM_LAUNCH(c, "col_minmax", k1, grid, blk, s, a);
+        LVM_LAUNCH(c, "col_out", k2, grid, blk, s, a);
+    }
 }
 
 int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced) {
