@@ -2,11 +2,15 @@
 """bench.py -- magnified frames/s of the HIP magnification core on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--mode laplace|riesz|color] [--streams B]
+                    [--frames-per-call T]
 
-A "step" is one pass of the hot path (lvm_process_device: one frame for each of the B streams
-held by the context) over synthetic frames that are already resident in HBM; outputs stay in
-HBM.  Default workload = BASELINE.json configs[1]: Laplace motion, 1920x1080, 6 levels, IIR
-0.4-3 Hz, alpha 20, single stream, one MI355X.  With N > 1 (one rank per GPU, launched by
+A "step" is one frame of the hot path for each of the B streams held by the context, over
+synthetic frames that are already resident in HBM; outputs stay in HBM.  The K steps are issued
+through lvm_process_device_frames in calls of T consecutive frames of the same stream(s) -- the
+reference's export loop (export/Exporter.cpp:216-259) sees its frames in exactly this order; the
+result of every frame is what K per-frame calls give (T = 1 selects those: the live, one-frame
+latency schedule).  Default workload = BASELINE.json configs[1]: Laplace motion, 1920x1080,
+6 levels, IIR 0.4-3 Hz, alpha 20, single stream, one MI355X.  With N > 1 (one rank per GPU, launched by
 torch.distributed.run) every rank runs its own independent stream(s): the path shards by
 stream with no data-path collective (weak scaling); RCCL is only used for the timing barrier
 and the max-over-ranks reduction.
@@ -91,10 +95,10 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--levels", type=int, default=0)
-    ap.add_argument("--ring", type=int, default=16, help="distinct input frames kept in HBM")
+    ap.add_argument("--ring", type=int, default=32, help="distinct input frames kept in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay steady-state frames from a captured hipGraph")
-    ap.add_argument("--frames-per-call", type=int, default=8, help="consecutive frames of the stream(s) handed to one lvm_process_device_frames call (1 = per-frame calls)")
+    ap.add_argument("--frames-per-call", type=int, default=16, help="consecutive frames of the stream(s) handed to one lvm_process_device_frames call (1 = per-frame calls)")
     ap.add_argument("--pipeline", type=int, default=0, help="cross-frame pipeline depth of lvm_process_device (0 or 1)")
     ap.add_argument("--profile-steps", type=int, default=60)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (smoke-testing the N > 1 path)")
