@@ -225,9 +225,17 @@ def main():
                              "alg_bytes": ab, "gbs": (round(ab / (avg_us * 1e-6) / 1e9, 1) if ab else None)}
         dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
         k = kernels[dom]
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 passes, committed under profiles/)
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.mode)))
+            if pm.get("key") == "%s|%dx%d|L%d|B%d|T%d" % (args.mode, w, h, levels, B, T):
+                traffic = pm["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
         if k["gbs"]:
             roofline = {"bound": "hbm", "kernel": dom, "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(k["gbs"] / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(k["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "avg_us": k["avg_us"], "alg_bytes_per_launch": k["alg_bytes"]}
     b_alg = lvm.load().lvm_algorithmic_bytes(pk["mode"], w, h, ch, levels, pk["framerate"])
     frame_frac = b_alg * (fps / world) / (HBM_PEAK_GBS * 1e9)
