@@ -44,7 +44,8 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, streams, T=0):
     """Compulsory bytes one launch of kernel `name` moves (every input read once + every output
     written once) for the kernel decomposition of DESIGN.md; kernels launched once per level are
     averaged over their launches (rocprofv3 reports them under one symbol).  None = not tabulated."""
-    n = [a * b for a, b in level_sizes(w, h, levels)]
+    sizes = level_sizes(w, h, levels)
+    n = [a * b for a, b in sizes]
     S = streams
     P = ch * streams
     avg = lambda xs: (sum(xs) / len(xs)) if xs else None  # noqa: E731
@@ -53,6 +54,9 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, streams, T=0):
             "lap_down0": S * ch * n[0] + 4 * P * n[1],
             "lap_final": 2 * S * ch * n[0] + 4 * P * n[1],
             "pyr_down": avg([4 * P * (n[l] + n[l + 1]) for l in range(1, levels)]),
+            # the wave-strip pyrDown serves the levels with >= 2^20 plane-pixels per launch (laplace.hip)
+            "pyr_down_rows": avg([4 * P * (n[l] + n[l + 1]) for l in range(1, levels)
+                                  if sizes[l][0] % 4 == 0 and n[l] * P >= (1 << 20)]),
             # G_l + G_{l+1} + cur_{l+1} read, hi/lo read+written, cur_l written
             "lap_up": avg([4 * P * (n[l] * 6 + 2 * n[l + 1]) for l in range(1, levels)]),
             "lap_seed": avg([4 * P * (n[l] * 3 + n[l + 1]) for l in range(1, levels)]),

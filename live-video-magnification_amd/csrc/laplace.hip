@@ -44,7 +44,7 @@ struct UpArgs {
 // With nt > 1 the workgroup walks over nt consecutive frames of the stream: every thread owns the
 // same 4 pixels for all frames and keeps their two low-pass states in registers, so the state is
 // read and written once per launch instead of once per frame.
-template <bool SEED>
+template <bool SEED, int D>
 __global__ __launch_bounds__(256) void k_lap_up(UpArgs a) {
     __shared__ float s_g[US_H][US_W + 1], s_c[US_H][US_W + 1];
     __shared__ float h_g[US_H][UT_W + 1], h_c[US_H][UT_W + 1];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_lap_up(UpArgs a) {
     constexpr int NP = UT_H * UT_W / 256;                 // pixels per thread
     constexpr int NS = (US_H * US_W + 255) / 256;         // staged source elements per thread
     float hi_r[NP], lo_r[NP];
-    size_t idx_r[NP];
+    unsigned idx_r[NP];                                   // offsets inside the plane (uniform plane/frame bases stay scalar)
     bool ok[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -63,74 +63,92 @@ __global__ __launch_bounds__(256) void k_lap_up(UpArgs a) {
         const int y = i / UT_W, x = i - y * UT_W;
         const int gx = x0 + x, gy = y0 + y;
         ok[k] = gx < a.w && gy < a.h;
-        idx_r[k] = pl + (size_t)(ok[k] ? gy : 0) * a.w + (ok[k] ? gx : 0);
+        idx_r[k] = (unsigned)((ok[k] ? gy : 0) * a.w + (ok[k] ? gx : 0));
         hi_r[k] = lo_r[k] = 0.f;
-        if (!SEED && ok[k]) { hi_r[k] = a.hi[idx_r[k]]; lo_r[k] = a.lo[idx_r[k]]; }
+        if (!SEED && ok[k]) { hi_r[k] = (a.hi + pl)[idx_r[k]]; lo_r[k] = (a.lo + pl)[idx_r[k]]; }
     }
     // source-tile elements this thread stages (same for every frame): vertical border map row -1 -> 1,
     // row >= hn -> hn-1; columns clamped (the border columns are handled by pyrup_h's formulas)
-    size_t soff[NS]; int sdst[NS];
+    unsigned soff[NS]; int sdst[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
         const int i = threadIdx.x + k * 256;
-        sdst[k] = -1; soff[k] = pn;
+        sdst[k] = -1; soff[k] = 0;
         if (i < US_H * US_W) {
             const int ly = i / US_W, lx = i - ly * US_W;
             int gy = sy0 + ly; gy = gy < 0 ? 1 : (gy >= a.hn ? a.hn - 1 : gy);
             int gx = sx0 + lx; gx = gx < 0 ? 0 : (gx >= a.wn ? a.wn - 1 : gx);
-            soff[k] = pn + (size_t)gy * a.wn + gx;
+            soff[k] = (unsigned)(gy * a.wn + gx);
             sdst[k] = ly * (US_W + 1) + lx;
         }
     }
-    // software pipeline over the frames: the global loads of frame t+1 are in flight while frame t is
-    // filtered (registers rg/rc/gl hold the next frame)
-    float rg[NS], rc[NS], gl[NP];
+    // software pipeline over the frames, D deep: the global loads of frames t+1..t+D are in flight while
+    // frame t is filtered (register slot t % D holds a frame until it is staged into LDS).  The coarse
+    // levels have too few workgroups to hide a ~2 us load behind other waves, so their launches use a
+    // deeper ring; the arithmetic is the same for every D.
+    // (the launch code picks a D that divides nt; refills past the last frame re-read the last frame, so
+    //  every slot is refilled unconditionally and the ring stays in fixed registers)
+    float rg[D][NS], rc[D][NS], gl[D][NP];
 #pragma unroll
-    for (int k = 0; k < NS; ++k) { rg[k] = a.Gn[soff[k]]; rc[k] = has_cur ? a.curn[soff[k]] : 0.f; }
+    for (int d = 0; d < D; ++d) {
+        const float* Gn = a.Gn + pn + (size_t)d * a.fsn;
+        const float* Cn = has_cur ? a.curn + pn + (size_t)d * a.fsn : nullptr;
+        const float* Gl = a.Gl + pl + (size_t)d * a.fsl;
 #pragma unroll
-    for (int k = 0; k < NP; ++k) gl[k] = a.Gl[idx_r[k]];
-    for (int t = 0; t < a.nt; ++t) {
-        if (t > 0) __syncthreads();
+        for (int k = 0; k < NS; ++k) { rg[d][k] = Gn[soff[k]]; rc[d][k] = has_cur ? Cn[soff[k]] : 0.f; }
 #pragma unroll
-        for (int k = 0; k < NS; ++k)
-            if (sdst[k] >= 0) { (&s_g[0][0])[sdst[k]] = rg[k]; if (has_cur) (&s_c[0][0])[sdst[k]] = rc[k]; }
-        float glc[NP];
+        for (int k = 0; k < NP; ++k) gl[d][k] = Gl[idx_r[k]];
+    }
+    for (int t0 = 0; t0 < a.nt; t0 += D) {
 #pragma unroll
-        for (int k = 0; k < NP; ++k) glc[k] = gl[k];
-        __syncthreads();
-        if (t + 1 < a.nt) {
-            const size_t on = (size_t)(t + 1) * a.fsn, ol = (size_t)(t + 1) * a.fsl;
+        for (int d = 0; d < D; ++d) {
+            const int t = t0 + d;
+            // (no barrier needed here: the staging arrays were last read before the mid barrier of frame
+            //  t-1, and the h arrays are rewritten only after the barrier below)
 #pragma unroll
-            for (int k = 0; k < NS; ++k) { rg[k] = a.Gn[on + soff[k]]; rc[k] = has_cur ? a.curn[on + soff[k]] : 0.f; }
+            for (int k = 0; k < NS; ++k)
+                if (sdst[k] >= 0) { (&s_g[0][0])[sdst[k]] = rg[d][k]; if (has_cur) (&s_c[0][0])[sdst[k]] = rc[d][k]; }
+            float glc[NP];
 #pragma unroll
-            for (int k = 0; k < NP; ++k) gl[k] = a.Gl[ol + idx_r[k]];
-        }
-        pyrup_hpass(h_g, s_g, x0, sx0, a.wn, a.w);
-        if (has_cur) pyrup_hpass(h_c, s_c, x0, sx0, a.wn, a.w);
-        __syncthreads();
-        float* cur = a.cur + (size_t)t * a.fsl;
+            for (int k = 0; k < NP; ++k) glc[k] = gl[d][k];
+            __syncthreads();
+            {
+                const int tn = t + D < a.nt ? t + D : a.nt - 1;
+                const float* Gn = a.Gn + pn + (size_t)tn * a.fsn;
+                const float* Cn = has_cur ? a.curn + pn + (size_t)tn * a.fsn : nullptr;
+                const float* Gl = a.Gl + pl + (size_t)tn * a.fsl;
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            if (!ok[k]) continue;
-            const int i = threadIdx.x + k * 256;
-            const int y = i / UT_W, x = i - y * UT_W;
-            const int gy = y0 + y;
-            const float band = glc[k] - pyrup_v(h_g, x, gy, sy0);           // SpatialFilter.cpp:33
-            if (SEED) {
-                hi_r[k] = band; lo_r[k] = band;
-            } else {
-                const float t1 = hi_r[k] * a.aHi + band * a.bHi;            // TemporalFilter.cpp:16
-                const float t2 = lo_r[k] * a.aLo + band * a.bLo;            // :17
-                hi_r[k] = t1; lo_r[k] = t2;
-                const float m = (t1 - t2) * a.gain;                         // :21, MagnifyCore.hpp:129-132
-                const float up = has_cur ? pyrup_v(h_c, x, gy, sy0) : 0.f;
-                cur[idx_r[k]] = up + m;                                     // SpatialFilter.cpp:58
+                for (int k = 0; k < NS; ++k) { rg[d][k] = Gn[soff[k]]; rc[d][k] = has_cur ? Cn[soff[k]] : 0.f; }
+#pragma unroll
+                for (int k = 0; k < NP; ++k) gl[d][k] = Gl[idx_r[k]];
+            }
+            pyrup_hpass(h_g, s_g, x0, sx0, a.wn, a.w);
+            if (has_cur) pyrup_hpass(h_c, s_c, x0, sx0, a.wn, a.w);
+            __syncthreads();
+            float* cur = a.cur + pl + (size_t)t * a.fsl;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if (!ok[k]) continue;
+                const int i = threadIdx.x + k * 256;
+                const int y = i / UT_W, x = i - y * UT_W;
+                const int gy = y0 + y;
+                const float band = glc[k] - pyrup_v(h_g, x, gy, sy0);           // SpatialFilter.cpp:33
+                if (SEED) {
+                    hi_r[k] = band; lo_r[k] = band;
+                } else {
+                    const float t1 = hi_r[k] * a.aHi + band * a.bHi;            // TemporalFilter.cpp:16
+                    const float t2 = lo_r[k] * a.aLo + band * a.bLo;            // :17
+                    hi_r[k] = t1; lo_r[k] = t2;
+                    const float m = (t1 - t2) * a.gain;                         // :21, MagnifyCore.hpp:129-132
+                    const float up = has_cur ? pyrup_v(h_c, x, gy, sy0) : 0.f;
+                    cur[idx_r[k]] = up + m;                                     // SpatialFilter.cpp:58
+                }
             }
         }
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k)
-        if (ok[k]) { a.hi[idx_r[k]] = hi_r[k]; a.lo[idx_r[k]] = lo_r[k]; }
+        if (ok[k]) { (a.hi + pl)[idx_r[k]] = hi_r[k]; (a.lo + pl)[idx_r[k]] = lo_r[k]; }
 }
 
 // Final level: out = u8(Lab2BGR(Lab(in) + [1, ca, ca] * pyrUp(cur_1))).  MOTION = false is
@@ -219,118 +237,138 @@ __device__ __forceinline__ float4 pyrup_h4(float sm1, float s0, float s1, float 
     return o;
 }
 
-// Persistent 1024-thread workgroups (one per CU): the two Lab tables are loaded into LDS once per
-// CU; each 256-thread quarter walks over its own 64x16 tiles.
-constexpr int FQ = 4;   // tiles in flight per workgroup
+// Persistent 512-thread workgroups; the two Lab tables are loaded into LDS once per workgroup and
+// nothing else is shared: every WAVE walks over its own strips of 256 x `rows` output pixels, one
+// lane per group of 4 pixels, with no barrier inside the loop.  A lane computes the horizontal pyrUp
+// pass of the cur_1 rows it needs straight from global memory (cur_1 was just written by k_lap_up and
+// sits in L2) and slides a three-row register window down the strip for the vertical pass; the row
+// parity is uniform across the wave, so only the formula of that parity is executed.
+constexpr int FIN_THREADS = 512;
+struct Row3 { float4 c[3]; };            // horizontal-pass results of one source row, 3 channels x 4 columns
 template <bool MOTION, bool EXACT>
-__global__ __launch_bounds__(1024) void k_lap_final_v4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
+__global__ __launch_bounds__(FIN_THREADS) void k_lap_final_v4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                        uint8_t* __restrict__ out, long out_stride, long out_sstride,
                                                        int w, int h, const float* __restrict__ cur1, int w1, int h1,
-                                                       LabCoef lab, float ca, int tiles_x, int tiles_y, int nstreams,
-                                                       float* __restrict__ dbg) {
+                                                       LabCoef lab, float ca, int strips_x, int strips_y, int nstreams,
+                                                       int rows, float* __restrict__ dbg) {
     __shared__ __attribute__((aligned(16))) float s_igt[4096];
     __shared__ float s_gam[256];
-    __shared__ __attribute__((aligned(16))) float h_all[FQ][3][US_H][UT_W];
-    const int q = threadIdx.x >> 8, tid = threadIdx.x & 255;
     {
         const float4* src = reinterpret_cast<const float4*>(lab.invgamma);
-        reinterpret_cast<float4*>(s_igt)[threadIdx.x] = src[threadIdx.x];
+        for (int i = threadIdx.x; i < 1024; i += FIN_THREADS) reinterpret_cast<float4*>(s_igt)[i] = src[i];
         if (threadIdx.x < 256) s_gam[threadIdx.x] = lab.gamma_u8[threadIdx.x];
     }
     __syncthreads();
-    float (&h_c)[3][US_H][UT_W] = h_all[q];
-    const int ntiles = tiles_x * tiles_y * nstreams;
-    const int ty_l = tid >> 4, xg = tid & 15;
-    for (int t0 = blockIdx.x * FQ; t0 < ntiles; t0 += gridDim.x * FQ) {
-        const int t = t0 + q;
-        const bool tile_ok = t < ntiles;
-        const int b = tile_ok ? t / (tiles_x * tiles_y) : 0;
-        const int r = tile_ok ? t - b * (tiles_x * tiles_y) : 0;
-        const int ty = r / tiles_x, tx = r - ty * tiles_x;
-        const int x0 = tx * UT_W, y0 = ty * UT_H;
-        const int sy0 = y0 / 2 - 1;
-        const int gx = x0 + 4 * xg, gy = y0 + ty_l;
-        const bool px_ok = tile_ok && gx < w && gy < h;
-        Px4 pin; pin.a = pin.b = pin.c = 0;
-        if (px_ok) pin = *reinterpret_cast<const Px4*>(in + (size_t)b * in_sstride + (size_t)gy * in_stride + (size_t)gx * 3);
-        if (MOTION) {
-            // 480 horizontal-pass tasks per tile: two per thread, loads first
-            float sv[2][4]; int si0[2], sdst[2];
+    constexpr int WAVES = FIN_THREADS / 64;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int ntasks = strips_x * strips_y * nstreams;
+    for (int task = blockIdx.x * WAVES + wave; task < ntasks; task += gridDim.x * WAVES) {
+        const int b = task / (strips_x * strips_y);
+        const int r = task - b * (strips_x * strips_y);
+        const int ty = r / strips_x, tx = r - ty * strips_x;
+        const int gx = tx * 256 + 4 * lane, y0 = ty * rows;        // rows is even: y0 is even
+        if (gx >= w) continue;
+        // uniform (scalar) bases + 32-bit lane offsets
+        const uint8_t* src = in + (size_t)b * in_sstride;
+        uint8_t* dst = out + (size_t)b * out_sstride;
+        const unsigned xoff = (unsigned)gx * 3u;
+        const float* pl = cur1 + (size_t)b * 3 * ((size_t)w1 * h1);
+        const int i0 = gx >> 1;
+        const unsigned cm1 = 4u * (i0 > 0 ? i0 - 1 : 0), c00 = 4u * i0, cp1 = 4u * (i0 + 1 < w1 ? i0 + 1 : w1 - 1), cp2 = 4u * (i0 + 2 < w1 ? i0 + 2 : w1 - 1);   // byte offsets
+        const size_t pstride = (size_t)w1 * h1;
+        // horizontal pass of source row sy (vertical border map: row -1 -> 1, row h1 -> h1 - 1); the row
+        // base is uniform, the four column offsets are per-lane byte offsets
+        auto hrow = [&](int sy) __attribute__((always_inline)) {
+            Row3 o;
+            sy = sy < 0 ? 1 : (sy >= h1 ? h1 - 1 : sy);
+            const char* row = reinterpret_cast<const char*>(pl + (size_t)sy * w1);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int i = tid + k * 256;
-                sdst[k] = -1; si0[k] = 0;
-                sv[k][0] = sv[k][1] = sv[k][2] = sv[k][3] = 0.f;
-                if (tile_ok && i < 3 * US_H * 16) {
-                    const int c = i / (US_H * 16), rem = i - c * (US_H * 16);
-                    const int ly = rem >> 4, g = rem & 15;
-                    const int gx0 = x0 + 4 * g;
-                    sdst[k] = (c * US_H + ly) * UT_W + 4 * g;
-                    if (gx0 < w) {
-                        int sy = sy0 + ly;
-                        sy = sy < 0 ? 1 : (sy >= h1 ? h1 - 1 : sy);
-                        const float* row = cur1 + ((size_t)b * 3 + c) * ((size_t)w1 * h1) + (size_t)sy * w1;
-                        const int i0 = gx0 >> 1;
-                        si0[k] = i0;
-                        sv[k][0] = row[i0 > 0 ? i0 - 1 : 0]; sv[k][1] = row[i0];
-                        sv[k][2] = row[i0 + 1 < w1 ? i0 + 1 : w1 - 1]; sv[k][3] = row[i0 + 2 < w1 ? i0 + 2 : w1 - 1];
-                    } else si0[k] = -1;
-                }
+            for (int c = 0; c < 3; ++c) {
+                const char* rc = row + c * pstride * sizeof(float);
+                o.c[c] = pyrup_h4(*reinterpret_cast<const float*>(rc + cm1), *reinterpret_cast<const float*>(rc + c00),
+                                  *reinterpret_cast<const float*>(rc + cp1), *reinterpret_cast<const float*>(rc + cp2), i0, w1);
             }
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                if (sdst[k] < 0) continue;
-                const float4 o = si0[k] >= 0 ? pyrup_h4(sv[k][0], sv[k][1], sv[k][2], sv[k][3], si0[k], w1) : make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(&h_c[0][0][0] + sdst[k]) = o;
-            }
-            __syncthreads();
-        }
-        if (px_ok) {
+            return o;
+        };
+        const int yend = (y0 + rows < h) ? y0 + rows : h;
+        int gy = y0, j = y0 >> 1;
+        // one output row: colour math of 4 pixels; m = the motion image of the row (EXACT: scaled by 1/64 as
+        // pyrUp does; otherwise the unscaled vertical sum, whose power-of-two scale `msc` is folded into the
+        // add -- fma(m, 2^-k, L) rounds exactly like L + m * 2^-k)
+        auto emit = [&](const Px4 pin, const float (&m)[3][4], const float msc) __attribute__((always_inline)) {
             int Bv[4], Gv[4], Rv[4];
             unpack_px4(pin, Bv, Gv, Rv);
-            float m[3][4];
-            if (MOTION) {
-                const int lj = (gy >> 1) - sy0;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float4 r0 = *reinterpret_cast<const float4*>(&h_c[c][lj - 1][4 * xg]);
-                    const float4 r1 = *reinterpret_cast<const float4*>(&h_c[c][lj][4 * xg]);
-                    const float4 r2 = *reinterpret_cast<const float4*>(&h_c[c][lj + 1][4 * xg]);
-                    if ((gy & 1) == 0) {
-                        m[c][0] = (r0.x + r1.x * 6.f + r2.x) * (1.f / 64.f); m[c][1] = (r0.y + r1.y * 6.f + r2.y) * (1.f / 64.f);
-                        m[c][2] = (r0.z + r1.z * 6.f + r2.z) * (1.f / 64.f); m[c][3] = (r0.w + r1.w * 6.f + r2.w) * (1.f / 64.f);
-                    } else {
-                        m[c][0] = ((r1.x + r2.x) * 4.f) * (1.f / 64.f); m[c][1] = ((r1.y + r2.y) * 4.f) * (1.f / 64.f);
-                        m[c][2] = ((r1.z + r2.z) * 4.f) * (1.f / 64.f); m[c][3] = ((r1.w + r2.w) * 4.f) * (1.f / 64.f);
-                    }
-                }
-            }
-            uint32_t ob[12];
+            float ov[12];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float L, a, bb;
                 lin_bgr_to_lab<EXACT>(s_gam[Bv[k]], s_gam[Gv[k]], s_gam[Rv[k]], lab.fwd, L, a, bb);
-                if (MOTION) { L = L + m[0][k]; a = a + m[1][k] * ca; bb = bb + m[2][k] * ca; }
+                if (MOTION) {
+                    if (EXACT) { L = L + m[0][k]; a = a + m[1][k] * ca; bb = bb + m[2][k] * ca; }
+                    else {
+                        L = __builtin_fmaf(m[0][k], msc, L);
+                        a = __builtin_fmaf(m[1][k], msc * ca, a); bb = __builtin_fmaf(m[2][k], msc * ca, bb);
+                    }
+                }
                 float o0, o1, o2;
                 lab_to_bgr<EXACT>(L, a, bb, lab.inv, s_igt, o0, o1, o2);
                 if (dbg && b == 0) { float* d = dbg + ((size_t)gy * w + gx + k) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
                 if (EXACT) {
-                    ob[3 * k] = sat_u8(o0 * 255.0f + lab.a255);
-                    ob[3 * k + 1] = sat_u8(o1 * 255.0f + lab.a255);
-                    ob[3 * k + 2] = sat_u8(o2 * 255.0f + lab.a255);
-                } else {   // same value: fma(o, 255, 1/255) differs from mul+add only below the rounding step
-                    ob[3 * k] = sat_u8_fast(o0 * 255.0f + lab.a255);
-                    ob[3 * k + 1] = sat_u8_fast(o1 * 255.0f + lab.a255);
-                    ob[3 * k + 2] = sat_u8_fast(o2 * 255.0f + lab.a255);
+                    ov[3 * k] = o0 * 255.0f + lab.a255; ov[3 * k + 1] = o1 * 255.0f + lab.a255; ov[3 * k + 2] = o2 * 255.0f + lab.a255;
+                } else {   // fma(o, 255, 1/255) differs from mul + add only far below the rounding step
+                    ov[3 * k] = __builtin_fmaf(o0, 255.0f, lab.a255); ov[3 * k + 1] = __builtin_fmaf(o1, 255.0f, lab.a255);
+                    ov[3 * k + 2] = __builtin_fmaf(o2, 255.0f, lab.a255);
                 }
             }
             Px4 qo;
-            qo.a = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
-            qo.b = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
-            qo.c = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
-            *reinterpret_cast<Px4*>(out + (size_t)b * out_sstride + (size_t)gy * out_stride + (size_t)gx * 3) = qo;
+            qo.a = pack_u8x4(ov[0], ov[1], ov[2], ov[3]);
+            qo.b = pack_u8x4(ov[4], ov[5], ov[6], ov[7]);
+            qo.c = pack_u8x4(ov[8], ov[9], ov[10], ov[11]);
+            *reinterpret_cast<Px4*>(dst + (size_t)gy * out_stride + xoff) = qo;
+        };
+        // two output rows (2j, 2j+1) from the window rows A = j-1, B = j, C = j+1; afterwards A holds row
+        // j+2, i.e. the window has rotated to (B, C, A).  Returns false when the strip is finished.
+        auto step = [&](Row3& A, const Row3& B, const Row3& C) __attribute__((always_inline)) {
+            const Px4 pe = *reinterpret_cast<const Px4*>(src + (size_t)gy * in_stride + xoff);
+            const bool has_odd = gy + 1 < yend;
+            Px4 po = pe;
+            if (has_odd) po = *reinterpret_cast<const Px4*>(src + (size_t)(gy + 1) * in_stride + xoff);
+            float m[3][4] = {};
+            if (MOTION) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float sc = EXACT ? (1.f / 64.f) : 1.f;           // (x * 1.f folds away)
+                    m[c][0] = (A.c[c].x + B.c[c].x * 6.f + C.c[c].x) * sc; m[c][1] = (A.c[c].y + B.c[c].y * 6.f + C.c[c].y) * sc;
+                    m[c][2] = (A.c[c].z + B.c[c].z * 6.f + C.c[c].z) * sc; m[c][3] = (A.c[c].w + B.c[c].w * 6.f + C.c[c].w) * sc;
+                }
+            }
+            const bool more = gy + 2 < yend;
+            if (MOTION && more) A = hrow(j + 2);                 // in flight during the colour math of both rows
+            emit(pe, m, 1.f / 64.f);
+            ++gy;
+            if (!has_odd) return false;
+            if (MOTION) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (EXACT) {
+                        m[c][0] = ((B.c[c].x + C.c[c].x) * 4.f) * (1.f / 64.f); m[c][1] = ((B.c[c].y + C.c[c].y) * 4.f) * (1.f / 64.f);
+                        m[c][2] = ((B.c[c].z + C.c[c].z) * 4.f) * (1.f / 64.f); m[c][3] = ((B.c[c].w + C.c[c].w) * 4.f) * (1.f / 64.f);
+                    } else {
+                        m[c][0] = B.c[c].x + C.c[c].x; m[c][1] = B.c[c].y + C.c[c].y; m[c][2] = B.c[c].z + C.c[c].z; m[c][3] = B.c[c].w + C.c[c].w;
+                    }
+                }
+            }
+            emit(po, m, 1.f / 16.f);
+            ++gy; ++j;
+            return more;
+        };
+        Row3 r0{}, r1{}, r2{};
+        if (MOTION) { r0 = hrow(j - 1); r1 = hrow(j); r2 = hrow(j + 1); }
+        while (true) {
+            if (!step(r0, r1, r2)) break;
+            if (!step(r1, r2, r0)) break;
+            if (!step(r2, r0, r1)) break;
         }
-        if (MOTION) __syncthreads();
     }
 }
 
@@ -461,6 +499,10 @@ struct LaplaceState : ModeState {
     // temporal batching (lvm_process_device_frames): pyramids / accumulators of up to tcap frames
     int tcap = 0; float* tarena = nullptr;
     float* Gt[kMaxLevels + 1] = {}; float* curt[kMaxLevels + 1] = {};
+    long fin_min_tasks = 2048;            // strips are shortened until a launch has this many of them (LVM_FIN_MIN_TASKS)
+    long rows_min_elems = 1 << 20;        // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
+    int fin_rows = 4;                     // rows per wave strip of k_lap_final_v4 (LVM_FIN_ROWS, power of two)
+    int up_depth = 8;                     // frame-loop prefetch depth of k_lap_up at the coarse levels (LVM_UP_DEPTH=1|2|4|8)
     int fuse_down = 2;                    // pyramid levels per pyrDown launch (LVM_FUSE_DOWN=2|3 selects the fused kernels)
     int tailT = 0;                       // first level handled by k_lap_tail (0 = tail disabled)
     TailArgs tail{};
@@ -513,6 +555,10 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     }
     laplace_tail_plan(st);
     if (const char* e = std::getenv("LVM_FUSE_DOWN")) st->fuse_down = std::atoi(e);
+    if (const char* e = std::getenv("LVM_UP_DEPTH")) st->up_depth = std::atoi(e);
+    if (const char* e = std::getenv("LVM_ROWS_MIN_ELEMS")) st->rows_min_elems = std::atol(e);
+    if (const char* e = std::getenv("LVM_FIN_MIN_TASKS")) st->fin_min_tasks = std::atol(e);
+    if (const char* e = std::getenv("LVM_FIN_ROWS")) { const int v = std::atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) st->fin_rows = v; }
     if (st->tailT) {
         st->curT[0] = p; p += pad(st->g[st->tailT].n * st->planes);
         st->curT[1] = p; p += pad(st->g[st->tailT].n * st->planes);
@@ -593,7 +639,19 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     int l = 1;
     while (l < down_end) {          // G_l -> next levels, three (or two) per launch when possible
         const int left = down_end - l;
-        if (left >= 3 && st->fuse_down >= 3) {
+        if (st->g[l].w % 4 == 0 && (long)st->g[l].n * planes >= st->rows_min_elems) {
+            // large planes (temporal batches / many streams): barrier-free wave strips, one level per launch
+            const LevelGeom &a = st->g[l], &b = st->g[l + 1];
+            const int sx = (b.w + 127) / 128;
+            int rows = 16;
+            while (rows > 4 && (long)sx * ((b.h + rows - 1) / rows) * planes < 8192) rows >>= 1;
+            const int sy = (b.h + rows - 1) / rows;
+            const long ntasks = (long)sx * sy * planes;
+            const dim3 grid((unsigned)((ntasks + PD_THREADS / 64 - 1) / (PD_THREADS / 64)));
+            LVM_LAUNCH(c, "pyr_down_rows", k_pyr_down_rows<0>, grid, dim3(PD_THREADS), s, (const float*)G[l], a.w, a.h, G[l + 1], b.w, b.h,
+                       sx, sy, (int)ntasks, rows);
+            l += 1;
+        } else if (left >= 3 && st->fuse_down >= 3) {
             const LevelGeom &a = st->g[l], &b1 = st->g[l + 1], &b2 = st->g[l + 2], &b3 = st->g[l + 3];
             const dim3 grid((b3.w + ML_T - 1) / ML_T, (b3.h + ML_T - 1) / ML_T, planes);
             LVM_LAUNCH(c, "pyr_down3", k_pyr_down_multi<3>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b1.w, b1.h,
@@ -650,8 +708,15 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         a.aHi = (float)(1 - cHi); a.bHi = (float)cHi; a.aLo = (float)(1 - cLo); a.bLo = (float)cLo;
         a.gain = gains[l];
         const dim3 grid((a.w + UT_W - 1) / UT_W, (a.h + UT_H - 1) / UT_H, st->planes);
-        if (first) LVM_LAUNCH(c, "lap_seed", k_lap_up<true>, grid, blk, s, a);
-        else LVM_LAUNCH(c, "lap_up", k_lap_up<false>, grid, blk, s, a);
+        // prefetch depth of the frame loop: coarse levels (few workgroups) need several frames in flight
+        const long blocks = (long)grid.x * grid.y * grid.z;
+        int depth = (blocks >= 1024) ? 1 : st->up_depth;
+        while (depth > 1 && a.nt % depth != 0) depth >>= 1;           // the ring depth must divide the frame count
+        if (first) LVM_LAUNCH(c, "lap_seed", (k_lap_up<true, 1>), grid, blk, s, a);
+        else if (depth == 1) LVM_LAUNCH(c, "lap_up", (k_lap_up<false, 1>), grid, blk, s, a);
+        else if (depth == 2) LVM_LAUNCH(c, "lap_up", (k_lap_up<false, 2>), grid, blk, s, a);
+        else if (depth <= 4) LVM_LAUNCH(c, "lap_up", (k_lap_up<false, 4>), grid, blk, s, a);
+        else LVM_LAUNCH(c, "lap_up", (k_lap_up<false, 8>), grid, blk, s, a);
     }
     const int tx = (io.w + UT_W - 1) / UT_W, ty = (io.h + UT_H - 1) / UT_H;
     const int ntiles = tx * ty * NS;
@@ -666,11 +731,21 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     auto kf = (C == 3) ? (motion ? (c->exact_lab ? k_lap_final<3, true, true> : k_lap_final<3, true, false>)
                                  : (c->exact_lab ? k_lap_final<3, false, true> : k_lap_final<3, false, false>))
                        : (motion ? k_lap_final<1, true, true> : k_lap_final<1, false, true>);
-    const int groups = (ntiles + FQ - 1) / FQ;
-    const dim3 grid4(groups < 512 ? groups : 512), blk4(1024);   // two 1024-thread workgroups per CU (LDS 2 x 48 KB): 32 waves hide the LDS/global latency
-    const bool vec4 = lap_vec4(io);
-    LVM_LAUNCH(c, "lap_final", vec4 ? kf4 : kf, vec4 ? grid4 : grid, vec4 ? blk4 : blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
-               (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, tx, ty, NS, dbg);
+    if (lap_vec4(io)) {
+        // wave strips of 256 x rows pixels; shorter strips when there are few of them (per-frame calls)
+        const int sx = (io.w + 255) / 256;
+        int rows = st->fin_rows;
+        while (rows > 2 && (long)sx * ((io.h + rows - 1) / rows) * NS < st->fin_min_tasks) rows >>= 1;
+        const int sy = (io.h + rows - 1) / rows;
+        const int waves = FIN_THREADS / 64;
+        const long groups = ((long)sx * sy * NS + waves - 1) / waves;
+        const dim3 grid4((unsigned)(groups < 1024 ? groups : 1024)), blk4(FIN_THREADS);
+        LVM_LAUNCH(c, "lap_final", kf4, grid4, blk4, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
+                   (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, sx, sy, NS, rows, dbg);
+    } else {
+        LVM_LAUNCH(c, "lap_final", kf, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
+                   (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, tx, ty, NS, dbg);
+    }
 }
 
 // Emits stage A of the pending frame (pipelined mode): its output lands in the d_out it was given.

@@ -35,6 +35,16 @@ __device__ __forceinline__ uint8_t sat_u8(float v) {
     return (uint8_t)r;
 }
 
+// Four convertTo(CV_8U) results packed into one dword.  v_cvt_pk_u8_f32 converts with round-half-even,
+// saturates to [0, 255] and maps NaN to 0 (checked on gfx950 with tools/probe_isa.hip), i.e. it IS
+// saturate_cast<uchar>(cvRound(v)), and it writes the byte in place: 4 instructions per dword.
+__device__ __forceinline__ uint32_t pack_u8x4(float v0, float v1, float v2, float v3) {
+    uint32_t r = __builtin_amdgcn_cvt_pk_u8_f32(v0, 0, 0);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(v1, 1, r);
+    r = __builtin_amdgcn_cvt_pk_u8_f32(v2, 2, r);
+    return __builtin_amdgcn_cvt_pk_u8_f32(v3, 3, r);
+}
+
 // Lab conversion tables/coefficients (reference: MagnifyCore.hpp:90,152,219,275 call
 // cv::cvtColor COLOR_BGR2Lab / COLOR_Lab2BGR on float [0,1]; OpenCV 4 color_lab.cpp float path).
 struct LabCoef {
@@ -93,8 +103,8 @@ __device__ __forceinline__ void lin_bgr_to_lab(float B, float G, float R, const 
         X = __builtin_fmaf(B, fw[0], __builtin_fmaf(G, fw[1], R * fw[2]));
         Y = __builtin_fmaf(B, fw[3], __builtin_fmaf(G, fw[4], R * fw[5]));
         Z = __builtin_fmaf(B, fw[6], __builtin_fmaf(G, fw[7], R * fw[8]));
-        const float cx = lab_cbrt<false>(X > 0.008856f ? X : 1.0f), cy = lab_cbrt<false>(Y > 0.008856f ? Y : 1.0f),
-                    cz = lab_cbrt<false>(Z > 0.008856f ? Z : 1.0f);
+        // (X, Y, Z >= 0: the cube root of a value under the threshold is finite and discarded below)
+        const float cx = lab_cbrt<false>(X), cy = lab_cbrt<false>(Y), cz = lab_cbrt<false>(Z);
         FX = X > 0.008856f ? cx : __builtin_fmaf(7.787f, X, _a);
         FY = Y > 0.008856f ? cy : __builtin_fmaf(7.787f, Y, _a);
         FZ = Z > 0.008856f ? cz : __builtin_fmaf(7.787f, Z, _a);
@@ -106,17 +116,25 @@ __device__ __forceinline__ void lin_bgr_to_lab(float B, float G, float R, const 
 // splineInterpolate (color_lab.cpp), 1024 knots; tab is 16-byte aligned (one 128-bit read per knot)
 template <bool EXACT>
 __device__ __forceinline__ float spline1024(float x, const float* tab) {
-    int ix = (int)x;
-    if (EXACT) ix = ix < 0 ? 0 : (ix > 1023 ? 1023 : ix);
-    else ix = ix > 1023 ? 1023 : ix;              // x was clamped to [0, 1024] by the caller
-    x -= (float)ix;
+    if (EXACT) {
+        int ix = (int)x;
+        ix = ix < 0 ? 0 : (ix > 1023 ? 1023 : ix);
+        x -= (float)ix;
+        const float4 t = *reinterpret_cast<const float4*>(tab + ix * 4);
+        return ((t.w * x + t.z) * x + t.y) * x + t.x;
+    }
+    // x was clamped to [0, 1024) by the caller: knot = trunc(x), argument = fract(x) (one v_fract_f32)
+    const int ix = (int)x;
+    const float fr = __builtin_amdgcn_fractf(x);
     const float4 t = *reinterpret_cast<const float4*>(tab + ix * 4);
-    if (EXACT) return ((t.w * x + t.z) * x + t.y) * x + t.x;
-    return __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(t.w, x, t.z), x, t.y), x, t.x);
+    return __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(t.w, fr, t.z), fr, t.y), fr, t.x);
 }
 __device__ __forceinline__ float clip01(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
 // same clamp as one v_med3_f32 (inputs are finite on the fast path)
 __device__ __forceinline__ float clip01_fast(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 1.f); }
+// clamp to [0, 1): the largest float below 1 instead of 1 moves the inverse-gamma result by < 1e-7 and
+// lets spline1024 skip the knot clamp
+__device__ __forceinline__ float clip01_open(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 0.99999994f); }
 // convertTo(CV_8U) for finite input: round-half-even, clamp, convert (3 instructions)
 __device__ __forceinline__ uint32_t sat_u8_fast(float v) { return (uint32_t)__builtin_amdgcn_fmed3f(rintf(v), 0.f, 255.f); }
 // Lab2RGBfloat::process + inverse gamma; igt = inverse-gamma spline table (LDS).  EXACT keeps
@@ -154,9 +172,9 @@ __device__ __forceinline__ void lab_to_bgr(float li, float ai, float bi, const f
         o1 = spline1024<true>(clip01(c1) * 1024.f, igt);
         o2 = spline1024<true>(clip01(c2) * 1024.f, igt);
     } else {
-        o0 = spline1024<false>(clip01_fast(c0) * 1024.f, igt);
-        o1 = spline1024<false>(clip01_fast(c1) * 1024.f, igt);
-        o2 = spline1024<false>(clip01_fast(c2) * 1024.f, igt);
+        o0 = spline1024<false>(clip01_open(c0) * 1024.f, igt);
+        o1 = spline1024<false>(clip01_open(c1) * 1024.f, igt);
+        o2 = spline1024<false>(clip01_open(c2) * 1024.f, igt);
     }
 }
 // cooperative loads of the two Lab tables into LDS (256 threads)

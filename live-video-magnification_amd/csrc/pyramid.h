@@ -229,6 +229,65 @@ __global__ __launch_bounds__(256) void k_down0_v4(const uint8_t* __restrict__ in
     }
 }
 
+// ---- pyrDown of large float planes: wave strips, no LDS ---------------------------------------------
+// Every wave owns a strip of 128 output columns x `rows` output rows of one plane; a lane produces two
+// adjacent outputs per row.  The 7 source values a lane needs from a source row (columns 2x-2 .. 2x+4)
+// come straight from global memory as an aligned 8-byte + 16-byte + 4-byte load (the overlap between
+// neighbouring lanes is served by the vector L1), the horizontal results slide down the strip in a
+// 5-row register window, and there is no barrier and no index division anywhere.  Requires w % 4 == 0
+// (16-byte aligned column groups); arithmetic and operation order are those of pyrdown_tile.
+constexpr int PD_THREADS = 256;
+template <int TU>
+__global__ __launch_bounds__(PD_THREADS) void k_pyr_down_rows(const float* __restrict__ src, int w, int h,
+                                                              float* __restrict__ dst, int dw, int dh,
+                                                              int strips_x, int strips_y, int ntasks, int rows) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int task = blockIdx.x * (PD_THREADS / 64) + wave;
+    if (task >= ntasks) return;
+    const int pl = task / (strips_x * strips_y);
+    const int r = task - pl * (strips_x * strips_y);
+    const int ty = r / strips_x, tx = r - ty * strips_x;
+    const int ox = tx * 128 + 2 * lane, oy0 = ty * rows;
+    if (ox >= dw) return;
+    const float* sp = src + (size_t)pl * ((size_t)w * h);
+    float* dp = dst + (size_t)pl * ((size_t)dw * dh);
+    const int c = 2 * ox;                                  // centre column of the first output
+    const bool interior = c >= 2 && c + 4 < w;
+    // byte offsets of the taps (edge lanes: REFLECT_101 per tap)
+    unsigned off[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) off[k] = 4u * (unsigned)reflect101(c - 2 + k, w);
+    const unsigned offc = 4u * (unsigned)c;
+    auto hpair = [&](int sy, float& ha, float& hb) __attribute__((always_inline)) {
+        const char* row = reinterpret_cast<const char*>(sp + (size_t)reflect101(sy, h) * w);
+        float t[7];
+        if (interior) {
+            const float2 a = *reinterpret_cast<const float2*>(row + offc - 8);
+            const float4 m = *reinterpret_cast<const float4*>(row + offc);
+            t[0] = a.x; t[1] = a.y; t[2] = m.x; t[3] = m.y; t[4] = m.z; t[5] = m.w;
+            t[6] = *reinterpret_cast<const float*>(row + offc + 16);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) t[k] = *reinterpret_cast<const float*>(row + off[k]);
+        }
+        ha = t[2] * 6.f + (t[1] + t[3]) * 4.f + t[0] + t[4];
+        hb = t[4] * 6.f + (t[3] + t[5]) * 4.f + t[2] + t[6];
+    };
+    const int yend = oy0 + rows < dh ? oy0 + rows : dh;
+    float a0, a1, a2, a3, a4, b0, b1, b2, b3, b4;
+    hpair(2 * oy0 - 2, a0, b0); hpair(2 * oy0 - 1, a1, b1); hpair(2 * oy0, a2, b2);
+    const bool pair_store = (dw & 1) == 0;
+    for (int oy = oy0; oy < yend; ++oy) {
+        hpair(2 * oy + 1, a3, b3); hpair(2 * oy + 2, a4, b4);
+        const float va = (a2 * 6.f + (a1 + a3) * 4.f + a0 + a4) * (1.f / 256.f);
+        const float vb = (b2 * 6.f + (b1 + b3) * 4.f + b0 + b4) * (1.f / 256.f);
+        float* q = dp + (size_t)oy * dw + ox;
+        if (pair_store) *reinterpret_cast<float2*>(q) = make_float2(va, vb);
+        else { q[0] = va; if (ox + 1 < dw) q[1] = vb; }
+        a0 = a2; a1 = a3; a2 = a4; b0 = b2; b1 = b3; b2 = b4;
+    }
+}
+
 // ---- three pyramid levels in one launch ------------------------------------------------------
 // G_l -> G_{l+1}, G_{l+2}, G_{l+3} (NL = 2 or 3 output levels).  A workgroup owns an 8x8 tile of the
 // coarsest output (16x16 / 32x32 of the finer ones) and recomputes the halos it needs: the G_l

@@ -60,6 +60,13 @@ static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
 static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return a < b ? (b < c ? b : (a < c ? c : a)) : (a < c ? a : (b < c ? c : b)); }
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
+static inline float __builtin_amdgcn_fractf(float x) { float f = x - floorf(x); return f < 0.99999994f ? f : 0.99999994f; }   // v_fract_f32
+static inline unsigned __builtin_amdgcn_cvt_pk_u8_f32(float v, unsigned byte, unsigned old) {   // RNE, saturating, NaN -> 0
+    float r = (v == v) ? nearbyintf(v) : 0.f;
+    r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
+    return (old & ~(0xffu << (8 * byte))) | ((unsigned)r << (8 * byte));
+}
+static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }   // only ever applied to wave-uniform values
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned i; std::memcpy(&i, &f, 4); return i; }

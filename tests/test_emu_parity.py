@@ -157,6 +157,26 @@ def test_laplace_emu_fused_multi_level_pyrdown(lvm, po, emu, w, h, levels):
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 3, 0.0, exact=True)
 
 
+@pytest.mark.parametrize("rows", [4, 8, 16])
+def test_laplace_emu_final_kernel_strip_heights(lvm, po, emu, rows, monkeypatch):
+    """k_lap_final_v4 walks strips of `rows` output rows per wave (the launch code shortens them for small
+    frames): force the long strips, on a height that leaves a partial last strip and a width with a
+    partly filled last wave."""
+    monkeypatch.setenv("LVM_FIN_ROWS", str(rows))
+    monkeypatch.setenv("LVM_FIN_MIN_TASKS", "0")
+    ck, pk = lvm.synth.config(0, (328, 90 + 2 * rows + 3, 3))
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0, exact=True)
+
+
+@pytest.mark.parametrize("w,h,levels", [(328, 109, 3), (1000, 760, 5), (520, 77, 4)])
+def test_laplace_emu_wave_strip_pyrdown(lvm, po, emu, w, h, levels, monkeypatch):
+    """k_pyr_down_rows (the pyrDown of large planes) forced onto every level whose width allows it:
+    edge lanes, partial strips, odd heights."""
+    monkeypatch.setenv("LVM_ROWS_MIN_ELEMS", "0")
+    ck, pk = lvm.synth.config(0, (w, h, levels))
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 3, 0.0, exact=True)
+
+
 def _frames_clip(lvm, po, lib, idx, w, h, levels, n_streams, calls, over=None, clip_over=None):
     """lvm_process_device_frames: batches of consecutive frames (sizes in `calls`) of n_streams streams
     must give exactly the frames the oracle produces one by one."""
@@ -188,7 +208,8 @@ def _frames_clip(lvm, po, lib, idx, w, h, levels, n_streams, calls, over=None, c
 
 
 @pytest.mark.parametrize("w,h,levels,ns,calls", [(160, 90, 3, 1, (1, 4, 3, 1, 5)), (320, 180, 4, 1, (5, 6)),
-                                                  (135, 77, 4, 2, (3, 3, 2)), (404, 300, 5, 1, (2, 7)), (64, 48, 1, 1, (3, 3))])
+                                                  (135, 77, 4, 2, (3, 3, 2)), (404, 300, 5, 1, (2, 7)), (64, 48, 1, 1, (3, 3)),
+                                                  (200, 120, 4, 1, (1, 11, 17, 9))])   # deeper than the prefetch ring of k_lap_up
 def test_laplace_emu_temporal_batches(lvm, po, emu, w, h, levels, ns, calls):
     _frames_clip(lvm, po, emu, 0, w, h, levels, ns, calls)
 
