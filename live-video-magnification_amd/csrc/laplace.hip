@@ -151,6 +151,138 @@ __global__ __launch_bounds__(256) void k_lap_up(UpArgs a) {
         if (ok[k]) { (a.hi + pl)[idx_r[k]] = hi_r[k]; (a.lo + pl)[idx_r[k]] = lo_r[k]; }
 }
 
+// pyrUp horizontal pass for 4 consecutive destination columns gx0..gx0+3 (gx0 even) from the source
+// values s[i0-1..i0+2], i0 = gx0/2 (indices outside the plane are never used by the border rules)
+__device__ __forceinline__ float4 pyrup_h4(float sm1, float s0, float s1, float s2, int i0, int sw) {
+    float4 o;
+    o.x = (i0 == 0) ? s0 * 6.f + s1 * 2.f : ((i0 == sw - 1) ? sm1 + s0 * 7.f : sm1 + s0 * 6.f + s1);
+    o.y = (i0 == sw - 1) ? s0 * 8.f : (s0 + s1) * 4.f;
+    const int i1 = i0 + 1;
+    o.z = (i1 == sw - 1) ? s0 + s1 * 7.f : s0 + s1 * 6.f + s2;     // i1 >= 1 always
+    o.w = (i1 == sw - 1) ? s1 * 8.f : (s1 + s2) * 4.f;
+    return o;
+}
+
+// The same fused step without LDS and without barriers (levels whose width is a multiple of W, steady
+// state).  A lane owns a block of W x 2 pixels of one plane for all nt frames: it keeps their two
+// low-pass states in registers, computes the horizontal pyrUp pass of the three rows of G_{l+1} and
+// cur_{l+1} it needs straight from global memory and reads / writes level l as 4W-byte vectors.  The raw
+// loads of the next D frames are kept in flight in a register ring (D divides nt; refills past the
+// last frame re-read the last frame so that every slot is refilled unconditionally).
+// W = 4 serves the large levels; W = 2 the coarse ones, where a launch is only a few hundred waves and
+// the length of the dependent instruction stream per frame, not throughput, sets the time.
+template <int W> struct UpRaw { float g[3][W / 2 + 2]; float c[3][W / 2 + 2]; float gl[2][W]; };
+template <int W, int D>
+__global__ __launch_bounds__(256) void k_lap_up_rows(UpArgs a, int gw, int ngroups) {
+    constexpr int NT = W / 2 + 2;                        // source taps per row: columns i0-1 .. i0+W/2
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi >= ngroups) return;
+    const int plane = blockIdx.y;
+    const int gy = gi / gw, gxg = gi - gy * gw;
+    const int gx = gxg * W, y0 = gy * 2;
+    const bool has_cur = a.curn != nullptr;
+    const bool row1 = y0 + 1 < a.h;                      // the second row of the block exists
+    const size_t pn = (size_t)plane * a.wn * a.hn, pl = (size_t)plane * a.w * a.h;
+    const int i0 = gx >> 1, j0 = y0 >> 1;
+    unsigned soff[3][NT];                                // byte offsets of the taps inside the level-(l+1) plane
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        int sy = j0 - 1 + q; sy = sy < 0 ? 1 : (sy >= a.hn ? a.hn - 1 : sy);       // vertical border map
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            int sx = i0 - 1 + k; sx = sx < 0 ? 0 : (sx >= a.wn ? a.wn - 1 : sx);
+            soff[q][k] = 4u * (unsigned)(sy * a.wn + sx);
+        }
+    }
+    const unsigned loff0 = 4u * (unsigned)(y0 * a.w + gx), loff1 = row1 ? loff0 + 4u * (unsigned)a.w : loff0;
+    float hi_r[2][W], lo_r[2][W];
+    {
+        const char* H = reinterpret_cast<const char*>(a.hi + pl); const char* Lo = reinterpret_cast<const char*>(a.lo + pl);
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            hi_r[0][k] = *reinterpret_cast<const float*>(H + loff0 + 4 * k); lo_r[0][k] = *reinterpret_cast<const float*>(Lo + loff0 + 4 * k);
+            hi_r[1][k] = *reinterpret_cast<const float*>(H + loff1 + 4 * k); lo_r[1][k] = *reinterpret_cast<const float*>(Lo + loff1 + 4 * k);
+        }
+    }
+    auto load = [&](int t, UpRaw<W>& r) __attribute__((always_inline)) {
+        const char* Gn = reinterpret_cast<const char*>(a.Gn + pn + (size_t)t * a.fsn);
+        const char* Cn = reinterpret_cast<const char*>((has_cur ? a.curn : a.Gn) + pn + (size_t)t * a.fsn);
+        const char* Gl = reinterpret_cast<const char*>(a.Gl + pl + (size_t)t * a.fsl);
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                r.g[q][k] = *reinterpret_cast<const float*>(Gn + soff[q][k]);
+                r.c[q][k] = has_cur ? *reinterpret_cast<const float*>(Cn + soff[q][k]) : 0.f;
+            }
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            r.gl[0][k] = *reinterpret_cast<const float*>(Gl + loff0 + 4 * k);
+            r.gl[1][k] = *reinterpret_cast<const float*>(Gl + loff1 + 4 * k);
+        }
+    };
+    // horizontal pyrUp pass of one source row for the W destination columns gx .. gx+W-1
+    auto hpass = [&](const float (&sv)[NT], float (&o)[W]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < W / 2; ++k) {
+            const int i = i0 + k;                        // source column of the destination pair (2i, 2i+1)
+            const float sm1 = sv[k], s0 = sv[k + 1], s1 = sv[k + 2];
+            o[2 * k] = (i == 0) ? s0 * 6.f + s1 * 2.f : ((i == a.wn - 1) ? sm1 + s0 * 7.f : sm1 + s0 * 6.f + s1);
+            o[2 * k + 1] = (i == a.wn - 1) ? s0 * 8.f : (s0 + s1) * 4.f;
+        }
+    };
+    auto filter = [&](int t, const UpRaw<W>& r) __attribute__((always_inline)) {
+        float hg[3][W], hc[3][W];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            hpass(r.g[q], hg[q]);
+            if (has_cur) hpass(r.c[q], hc[q]);
+        }
+        float o[2][W];
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int k = 0; k < W; ++k) {
+                const float upg = y == 0 ? (hg[0][k] + hg[1][k] * 6.f + hg[2][k]) * (1.f / 64.f) : ((hg[1][k] + hg[2][k]) * 4.f) * (1.f / 64.f);
+                const float band = r.gl[y][k] - upg;                             // SpatialFilter.cpp:33
+                const float t1 = hi_r[y][k] * a.aHi + band * a.bHi;              // TemporalFilter.cpp:16
+                const float t2 = lo_r[y][k] * a.aLo + band * a.bLo;              // :17
+                hi_r[y][k] = t1; lo_r[y][k] = t2;
+                const float m = (t1 - t2) * a.gain;                              // :21, MagnifyCore.hpp:129-132
+                const float up = has_cur ? (y == 0 ? (hc[0][k] + hc[1][k] * 6.f + hc[2][k]) * (1.f / 64.f) : ((hc[1][k] + hc[2][k]) * 4.f) * (1.f / 64.f)) : 0.f;
+                o[y][k] = up + m;                                                // SpatialFilter.cpp:58
+            }
+        char* cur = reinterpret_cast<char*>(a.cur + pl + (size_t)t * a.fsl);
+#pragma unroll
+        for (int k = 0; k < W; ++k) *reinterpret_cast<float*>(cur + loff0 + 4 * k) = o[0][k];
+        if (row1) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) *reinterpret_cast<float*>(cur + loff1 + 4 * k) = o[1][k];
+        }
+    };
+    UpRaw<W> ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) load(d < a.nt ? d : a.nt - 1, ring[d]);
+    for (int t0 = 0; t0 < a.nt; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int t = t0 + d;
+            const UpRaw<W> cur = ring[d];
+            load(t + D < a.nt ? t + D : a.nt - 1, ring[d]);
+            filter(t, cur);
+        }
+    }
+    {
+        char* H = reinterpret_cast<char*>(a.hi + pl); char* Lo = reinterpret_cast<char*>(a.lo + pl);
+#pragma unroll
+        for (int k = 0; k < W; ++k) { *reinterpret_cast<float*>(H + loff0 + 4 * k) = hi_r[0][k]; *reinterpret_cast<float*>(Lo + loff0 + 4 * k) = lo_r[0][k]; }
+        if (row1) {
+#pragma unroll
+            for (int k = 0; k < W; ++k) { *reinterpret_cast<float*>(H + loff1 + 4 * k) = hi_r[1][k]; *reinterpret_cast<float*>(Lo + loff1 + 4 * k) = lo_r[1][k]; }
+        }
+    }
+}
+
 // Final level: out = u8(Lab2BGR(Lab(in) + [1, ca, ca] * pyrUp(cur_1))).  MOTION = false is
 // the first frame / L == 1 case (motion image is identically zero).  Persistent workgroups
 // walk over (stream, tile); the inverse-gamma spline table lives in LDS.
@@ -225,18 +357,6 @@ __global__ __launch_bounds__(256) void k_lap_final(const uint8_t* __restrict__ i
 // operation order as k_down0 / k_lap_final; only the data movement differs: one 12-byte load or
 // store per 4 pixels instead of 12 byte accesses, 128-bit LDS reads, no per-pixel index math.
 // ------------------------------------------------------------------------------------------
-// pyrUp horizontal pass for 4 consecutive destination columns gx0..gx0+3 (gx0 even) from the source
-// values s[i0-1..i0+2], i0 = gx0/2 (indices outside the plane are never used by the border rules)
-__device__ __forceinline__ float4 pyrup_h4(float sm1, float s0, float s1, float s2, int i0, int sw) {
-    float4 o;
-    o.x = (i0 == 0) ? s0 * 6.f + s1 * 2.f : ((i0 == sw - 1) ? sm1 + s0 * 7.f : sm1 + s0 * 6.f + s1);
-    o.y = (i0 == sw - 1) ? s0 * 8.f : (s0 + s1) * 4.f;
-    const int i1 = i0 + 1;
-    o.z = (i1 == sw - 1) ? s0 + s1 * 7.f : s0 + s1 * 6.f + s2;     // i1 >= 1 always
-    o.w = (i1 == sw - 1) ? s1 * 8.f : (s1 + s2) * 4.f;
-    return o;
-}
-
 // Persistent 512-thread workgroups; the two Lab tables are loaded into LDS once per workgroup and
 // nothing else is shared: every WAVE walks over its own strips of 256 x `rows` output pixels, one
 // lane per group of 4 pixels, with no barrier inside the loop.  A lane computes the horizontal pyrUp
@@ -501,6 +621,8 @@ struct LaplaceState : ModeState {
     float* Gt[kMaxLevels + 1] = {}; float* curt[kMaxLevels + 1] = {};
     long fin_min_tasks = 2048;            // strips are shortened until a launch has this many of them (LVM_FIN_MIN_TASKS)
     long rows_min_elems = 1 << 20;        // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
+    int up_rows = 1;                      // barrier-free k_lap_up_rows for the steady state (LVM_UP_ROWS=0: tiled k_lap_up)
+    long up_w4_min = 65536;               // lanes a launch must have for 4-pixel-wide blocks, else 2-pixel-wide (LVM_UP_W4_MIN)
     int fin_rows = 4;                     // rows per wave strip of k_lap_final_v4 (LVM_FIN_ROWS, power of two)
     int up_depth = 8;                     // frame-loop prefetch depth of k_lap_up at the coarse levels (LVM_UP_DEPTH=1|2|4|8)
     int fuse_down = 2;                    // pyramid levels per pyrDown launch (LVM_FUSE_DOWN=2|3 selects the fused kernels)
@@ -556,6 +678,8 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     laplace_tail_plan(st);
     if (const char* e = std::getenv("LVM_FUSE_DOWN")) st->fuse_down = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_DEPTH")) st->up_depth = std::atoi(e);
+    if (const char* e = std::getenv("LVM_UP_ROWS")) st->up_rows = std::atoi(e);
+    if (const char* e = std::getenv("LVM_UP_W4_MIN")) st->up_w4_min = std::atol(e);
     if (const char* e = std::getenv("LVM_ROWS_MIN_ELEMS")) st->rows_min_elems = std::atol(e);
     if (const char* e = std::getenv("LVM_FIN_MIN_TASKS")) st->fin_min_tasks = std::atol(e);
     if (const char* e = std::getenv("LVM_FIN_ROWS")) { const int v = std::atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) st->fin_rows = v; }
@@ -712,6 +836,21 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         const long blocks = (long)grid.x * grid.y * grid.z;
         int depth = (blocks >= 1024) ? 1 : st->up_depth;
         while (depth > 1 && a.nt % depth != 0) depth >>= 1;           // the ring depth must divide the frame count
+        if (!first && st->up_rows && a.w % 2 == 0) {
+            // barrier-free W x 2 blocks per lane: W = 4 for large levels, W = 2 where the launch is small
+            const long planes = st->planes;
+            const bool w4 = a.w % 4 == 0 && (long)(a.w / 4) * ((a.h + 1) / 2) * planes >= st->up_w4_min;
+            const int W = w4 ? 4 : 2;
+            const int gw = a.w / W;
+            const long ngroups = (long)gw * ((a.h + 1) / 2);
+            const dim3 g2((unsigned)((ngroups + 255) / 256), (unsigned)planes);
+            int depth = w4 ? 2 : 4;
+            while (depth > 1 && a.nt % depth != 0) depth >>= 1;
+            auto kr = w4 ? (depth == 2 ? k_lap_up_rows<4, 2> : k_lap_up_rows<4, 1>)
+                         : (depth == 4 ? k_lap_up_rows<2, 4> : (depth == 2 ? k_lap_up_rows<2, 2> : k_lap_up_rows<2, 1>));
+            LVM_LAUNCH(c, "lap_up", kr, g2, blk, s, a, gw, (int)ngroups);
+            continue;
+        }
         if (first) LVM_LAUNCH(c, "lap_seed", (k_lap_up<true, 1>), grid, blk, s, a);
         else if (depth == 1) LVM_LAUNCH(c, "lap_up", (k_lap_up<false, 1>), grid, blk, s, a);
         else if (depth == 2) LVM_LAUNCH(c, "lap_up", (k_lap_up<false, 2>), grid, blk, s, a);

@@ -214,6 +214,21 @@ def test_laplace_emu_temporal_batches(lvm, po, emu, w, h, levels, ns, calls):
     _frames_clip(lvm, po, emu, 0, w, h, levels, ns, calls)
 
 
+@pytest.mark.parametrize("w4min", ["0", "1000000000"])
+@pytest.mark.parametrize("w,h,levels,calls", [(328, 109, 3, (1, 4, 8, 2, 3)), (200, 120, 4, (1, 16, 6))])
+def test_laplace_emu_block_up_kernel_variants(lvm, po, emu, w, h, levels, calls, w4min, monkeypatch):
+    """k_lap_up_rows with 4-pixel-wide blocks forced on (w4min = 0) or off, over batch lengths that select
+    every ring depth (4, 2, 1), on odd heights (half-filled last block row)."""
+    monkeypatch.setenv("LVM_UP_W4_MIN", w4min)
+    _frames_clip(lvm, po, emu, 0, w, h, levels, 1, calls)
+
+
+def test_laplace_emu_tiled_up_kernel_still_matches(lvm, po, emu, monkeypatch):
+    """LVM_UP_ROWS=0 selects the LDS-tiled k_lap_up (the kernel odd-width levels always use)."""
+    monkeypatch.setenv("LVM_UP_ROWS", "0")
+    _frames_clip(lvm, po, emu, 0, 200, 120, 4, 1, (1, 8, 5))
+
+
 def test_frames_api_other_modes_fall_back_frame_by_frame(lvm, po, emu):
     _frames_clip(lvm, po, emu, 2, 96, 64, 3, 1, (4, 3))
     _frames_clip(lvm, po, emu, 3, 96, 64, 3, 1, (4, 3))
