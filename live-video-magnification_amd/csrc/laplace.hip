@@ -22,6 +22,7 @@
 // order exactly (see the per-kernel comments) so the result is order-faithful to the oracle.
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "pyramid.h"
 
@@ -169,8 +170,9 @@ __device__ __forceinline__ float4 pyrup_h4(float sm1, float s0, float s1, float 
 // cur_{l+1} it needs straight from global memory and reads / writes level l as 4W-byte vectors.  The raw
 // loads of the next D frames are kept in flight in a register ring (D divides nt; refills past the
 // last frame re-read the last frame so that every slot is refilled unconditionally).
-// W = 4 serves the large levels; W = 2 the coarse ones, where a launch is only a few hundred waves and
-// the length of the dependent instruction stream per frame, not throughput, sets the time.
+// Used with W = 2 for the coarse levels, where a launch is only a few hundred waves and the length of
+// the dependent instruction stream per frame, not throughput, sets the time (W = 4 measured slower
+// everywhere: 167 registers at ring depth 2).
 template <int W> struct UpRaw { float g[3][W / 2 + 2]; float c[3][W / 2 + 2]; float gl[2][W]; };
 template <int W, int D>
 __global__ __launch_bounds__(256) void k_lap_up_rows(UpArgs a, int gw, int ngroups) {
@@ -622,9 +624,11 @@ struct LaplaceState : ModeState {
     long fin_min_tasks = 2048;            // strips are shortened until a launch has this many of them (LVM_FIN_MIN_TASKS)
     long rows_min_elems = 1 << 20;        // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
     int up_rows = 1;                      // barrier-free k_lap_up_rows for the steady state (LVM_UP_ROWS=0: tiled k_lap_up)
-    long up_w4_min = 65536;               // lanes a launch must have for 4-pixel-wide blocks, else 2-pixel-wide (LVM_UP_W4_MIN)
+    long up_rows_max_blocks = 1024;       // launches with fewer tiled workgroups than this use k_lap_up_rows (LVM_UP_ROWS_MAX_BLOCKS)
     int fin_rows = 4;                     // rows per wave strip of k_lap_final_v4 (LVM_FIN_ROWS, power of two)
     int up_depth = 8;                     // frame-loop prefetch depth of k_lap_up at the coarse levels (LVM_UP_DEPTH=1|2|4|8)
+    int chunks = 4;                       // temporal batches: chunks whose down sweep overlaps the previous chunk's up sweep (LVM_LAP_CHUNKS)
+    std::vector<hipEvent_t> chunk_ev;
     int fuse_down = 2;                    // pyramid levels per pyrDown launch (LVM_FUSE_DOWN=2|3 selects the fused kernels)
     int tailT = 0;                       // first level handled by k_lap_tail (0 = tail disabled)
     TailArgs tail{};
@@ -643,7 +647,11 @@ struct LaplaceState : ModeState {
         std::memcpy(buf, &k, sizeof(k));
         return sizeof(k);
     }
-    ~LaplaceState() override { if (arena) (void)hipFree(arena); if (tarena) (void)hipFree(tarena); }
+    ~LaplaceState() override {
+        if (arena) (void)hipFree(arena);
+        if (tarena) (void)hipFree(tarena);
+        for (hipEvent_t e : chunk_ev) (void)hipEventDestroy(e);
+    }
 };
 
 static void laplace_tail_plan(LaplaceState* st);
@@ -678,8 +686,9 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     laplace_tail_plan(st);
     if (const char* e = std::getenv("LVM_FUSE_DOWN")) st->fuse_down = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_DEPTH")) st->up_depth = std::atoi(e);
+    if (const char* e = std::getenv("LVM_LAP_CHUNKS")) st->chunks = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_ROWS")) st->up_rows = std::atoi(e);
-    if (const char* e = std::getenv("LVM_UP_W4_MIN")) st->up_w4_min = std::atol(e);
+    if (const char* e = std::getenv("LVM_UP_ROWS_MAX_BLOCKS")) st->up_rows_max_blocks = std::atol(e);
     if (const char* e = std::getenv("LVM_ROWS_MIN_ELEMS")) st->rows_min_elems = std::atol(e);
     if (const char* e = std::getenv("LVM_FIN_MIN_TASKS")) st->fin_min_tasks = std::atol(e);
     if (const char* e = std::getenv("LVM_FIN_ROWS")) { const int v = std::atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) st->fin_rows = v; }
@@ -737,7 +746,7 @@ static bool lap_vec4(const FrameIO& io) {   // 4-pixel (12-byte) vector I/O need
 
 // Stage B of a frame: u8 -> Lab -> Gaussian pyramid G_1..G_T (parity buffer `par`) and, when the tail
 // kernel is enabled, everything that happens at the levels >= T (their IIR states, cur_T[par]).
-struct LapBufs { float** G; float** cur; float* curT; int nt; };   // nt frames laid out [frame][stream][channel]
+struct LapBufs { float** G; float** cur; float* curT; int nt; bool no_tail = false; };   // nt frames laid out [frame][stream][channel]
 static LapBufs lap_bufs_frame(LaplaceState* st, int par) { return LapBufs{st->Gp[par], st->cur, st->curT[par], 1}; }
 
 static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, const LapBufs& B, bool first, hipStream_t s) {
@@ -758,7 +767,7 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
                    G[1], g1.w, g1.h, c->lab, c->lab.a255);
     }
-    const bool use_tail = st->tailT && B.nt == 1;                  // batched frames: every level gets many workgroups anyway
+    const bool use_tail = st->tailT && B.nt == 1 && !B.no_tail;    // batched frames: every level gets many workgroups anyway
     const int down_end = use_tail ? st->tailT : levels;            // the tail builds G_{T+1..L} itself
     int l = 1;
     while (l < down_end) {          // G_l -> next levels, three (or two) per launch when possible
@@ -820,7 +829,7 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     laplace_gains(io.w, io.h, levels, p.amplification, p.coWavelength, gains);
     double cLo = p.coLow, cHi = p.coHigh;
     if (cLo == 0) cLo = 0.01;                                            // TemporalFilter.cpp:11-12
-    const bool use_tail = st->tailT && B.nt == 1;
+    const bool use_tail = st->tailT && B.nt == 1 && !B.no_tail;
     const int up_start = use_tail ? st->tailT - 1 : levels - 1;
     for (int l = up_start; l >= 1; --l) {
         UpArgs a;
@@ -832,25 +841,22 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         a.aHi = (float)(1 - cHi); a.bHi = (float)cHi; a.aLo = (float)(1 - cLo); a.bLo = (float)cLo;
         a.gain = gains[l];
         const dim3 grid((a.w + UT_W - 1) / UT_W, (a.h + UT_H - 1) / UT_H, st->planes);
-        // prefetch depth of the frame loop: coarse levels (few workgroups) need several frames in flight
         const long blocks = (long)grid.x * grid.y * grid.z;
-        int depth = (blocks >= 1024) ? 1 : st->up_depth;
-        while (depth > 1 && a.nt % depth != 0) depth >>= 1;           // the ring depth must divide the frame count
-        if (!first && st->up_rows && a.w % 2 == 0) {
-            // barrier-free W x 2 blocks per lane: W = 4 for large levels, W = 2 where the launch is small
-            const long planes = st->planes;
-            const bool w4 = a.w % 4 == 0 && (long)(a.w / 4) * ((a.h + 1) / 2) * planes >= st->up_w4_min;
-            const int W = w4 ? 4 : 2;
-            const int gw = a.w / W;
+        if (!first && st->up_rows && a.w % 2 == 0 && blocks < st->up_rows_max_blocks) {
+            // small launches (coarse levels of few streams): barrier-free 2 x 2 blocks per lane with a
+            // 4-frame load ring; measured 14-25 us per 16 frames against 27-43 us for the tiled kernel.
+            // Large launches keep the LDS-tiled kernel (bandwidth-bound there, and it needs fewer registers).
+            const int gw = a.w / 2;
             const long ngroups = (long)gw * ((a.h + 1) / 2);
-            const dim3 g2((unsigned)((ngroups + 255) / 256), (unsigned)planes);
-            int depth = w4 ? 2 : 4;
+            const dim3 g2((unsigned)((ngroups + 255) / 256), (unsigned)st->planes);
+            int depth = 4;
             while (depth > 1 && a.nt % depth != 0) depth >>= 1;
-            auto kr = w4 ? (depth == 2 ? k_lap_up_rows<4, 2> : k_lap_up_rows<4, 1>)
-                         : (depth == 4 ? k_lap_up_rows<2, 4> : (depth == 2 ? k_lap_up_rows<2, 2> : k_lap_up_rows<2, 1>));
+            auto kr = depth == 4 ? k_lap_up_rows<2, 4> : (depth == 2 ? k_lap_up_rows<2, 2> : k_lap_up_rows<2, 1>);
             LVM_LAUNCH(c, "lap_up", kr, g2, blk, s, a, gw, (int)ngroups);
             continue;
         }
+        int depth = (blocks >= 1024) ? 1 : st->up_depth;              // frame ring of the tiled kernel
+        while (depth > 1 && a.nt % depth != 0) depth >>= 1;           // the ring depth must divide the frame count
         if (first) LVM_LAUNCH(c, "lap_seed", (k_lap_up<true, 1>), grid, blk, s, a);
         else if (depth == 1) LVM_LAUNCH(c, "lap_up", (k_lap_up<false, 1>), grid, blk, s, a);
         else if (depth == 2) LVM_LAUNCH(c, "lap_up", (k_lap_up<false, 2>), grid, blk, s, a);
@@ -919,9 +925,48 @@ int laplace_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int n
         st->tcap = nt;
     }
     if (st->pending.valid) { const int rc = laplace_flush(c, s); if (rc != LVM_OK) return rc; }
-    LapBufs B{st->Gt, st->curt, st->tailT ? st->curt[st->tailT] : nullptr, nt};
-    lap_stage_b(c, st, p, io, B, false, s);
-    lap_stage_a(c, st, p, io, B, false, s);
+    // The batch is cut into chunks of consecutive frames.  The down sweeps (stage B: stateless, bound by the
+    // Lab arithmetic) of all chunks run on the auxiliary stream, the up sweeps (stage A: the IIR kernels
+    // of the coarse levels are a few hundred waves each and leave most of the chip idle) follow chunk by
+    // chunk, in temporal order, on the caller's stream: stage B of chunk k+1 overlaps stage A of chunk k.
+    // Every chunk has its own slice of the batch buffers, so the only dependencies are B(k) -> A(k)
+    // (one event each) and the temporal order of the A stages (stream order).
+    int chunks = st->chunks;
+    if (chunks > nt / 4) chunks = nt / 4;                       // at least 4 frames per chunk
+    if (chunks < 2 || !c->aux_stream || c->profiling) chunks = 1;
+    while ((int)st->chunk_ev.size() < chunks) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { chunks = 1; break; }
+        st->chunk_ev.push_back(e);
+    }
+    const int per = ((nt + chunks - 1) / chunks + 3) & ~3;      // chunk length: a multiple of 4 (ring depth of k_lap_up_rows)
+    if (chunks > 1) {
+        LVM_HIP_TRY(c, hipEventRecord(c->ev_fork, s));
+        LVM_HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+    }
+    struct Chunk { FrameIO io; float* G[kMaxLevels + 1]; float* cur[kMaxLevels + 1]; LapBufs B; };
+    std::vector<Chunk> ch((size_t)chunks);
+    int nch = 0;
+    for (int f0 = 0; f0 < nt; f0 += per, ++nch) {
+        Chunk& k = ch[(size_t)nch];
+        const int n = nt - f0 < per ? nt - f0 : per;
+        k.io = io;
+        k.io.d_in = io.d_in + (size_t)f0 * c->nstreams * io.in_sstride;
+        k.io.d_out = io.d_out + (size_t)f0 * c->nstreams * io.out_sstride;
+        for (int l = 1; l <= levels; ++l) k.G[l] = st->Gt[l] + (size_t)f0 * st->planes * st->g[l].n;
+        for (int l = 1; l < levels; ++l) k.cur[l] = st->curt[l] + (size_t)f0 * st->planes * st->g[l].n;
+        k.B = LapBufs{k.G, k.cur, nullptr, n, true};          // (the tail kernel filters inside stage B: not for overlapped chunks)
+        if (chunks > 1) {
+            lap_stage_b(c, st, p, k.io, k.B, false, c->aux_stream);
+            LVM_HIP_TRY(c, hipEventRecord(st->chunk_ev[(size_t)nch], c->aux_stream));
+        }
+    }
+    for (int q = 0; q < nch; ++q) {
+        Chunk& k = ch[(size_t)q];
+        if (chunks > 1) LVM_HIP_TRY(c, hipStreamWaitEvent(s, st->chunk_ev[(size_t)q], 0));
+        else lap_stage_b(c, st, p, k.io, k.B, false, s);
+        lap_stage_a(c, st, p, k.io, k.B, false, s);
+    }
     LVM_HIP_TRY(c, hipGetLastError());
     return LVM_OK;
 }

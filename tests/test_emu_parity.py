@@ -214,12 +214,10 @@ def test_laplace_emu_temporal_batches(lvm, po, emu, w, h, levels, ns, calls):
     _frames_clip(lvm, po, emu, 0, w, h, levels, ns, calls)
 
 
-@pytest.mark.parametrize("w4min", ["0", "1000000000"])
 @pytest.mark.parametrize("w,h,levels,calls", [(328, 109, 3, (1, 4, 8, 2, 3)), (200, 120, 4, (1, 16, 6))])
-def test_laplace_emu_block_up_kernel_variants(lvm, po, emu, w, h, levels, calls, w4min, monkeypatch):
-    """k_lap_up_rows with 4-pixel-wide blocks forced on (w4min = 0) or off, over batch lengths that select
-    every ring depth (4, 2, 1), on odd heights (half-filled last block row)."""
-    monkeypatch.setenv("LVM_UP_W4_MIN", w4min)
+def test_laplace_emu_block_up_kernel_variants(lvm, po, emu, w, h, levels, calls):
+    """k_lap_up_rows over batch lengths that select every ring depth (4, 2, 1), on odd heights
+    (half-filled last block row)."""
     _frames_clip(lvm, po, emu, 0, w, h, levels, 1, calls)
 
 
