@@ -155,12 +155,19 @@ __global__ __launch_bounds__(256) void k_lap_up(UpArgs a) {
 // pyrUp horizontal pass for 4 consecutive destination columns gx0..gx0+3 (gx0 even) from the source
 // values s[i0-1..i0+2], i0 = gx0/2 (indices outside the plane are never used by the border rules)
 __device__ __forceinline__ float4 pyrup_h4(float sm1, float s0, float s1, float s2, int i0, int sw) {
+    // every border variant is evaluated and the result selected (v_cndmask): divergent branches around
+    // two or three float operations cost far more than the operations
+    const bool f0 = i0 == 0, l0 = i0 == sw - 1, l1 = i0 + 1 == sw - 1;
+    const float p6 = s0 * 6.f, q6 = s1 * 6.f;
+    const float e_gen = sm1 + p6 + s1, e_first = p6 + s1 * 2.f, e_last = sm1 + s0 * 7.f;
+    const float o_gen = (s0 + s1) * 4.f, o_last = s0 * 8.f;
+    const float z_gen = s0 + q6 + s2, z_last = s0 + s1 * 7.f;      // i0 + 1 >= 1 always
+    const float w_gen = (s1 + s2) * 4.f, w_last = s1 * 8.f;
     float4 o;
-    o.x = (i0 == 0) ? s0 * 6.f + s1 * 2.f : ((i0 == sw - 1) ? sm1 + s0 * 7.f : sm1 + s0 * 6.f + s1);
-    o.y = (i0 == sw - 1) ? s0 * 8.f : (s0 + s1) * 4.f;
-    const int i1 = i0 + 1;
-    o.z = (i1 == sw - 1) ? s0 + s1 * 7.f : s0 + s1 * 6.f + s2;     // i1 >= 1 always
-    o.w = (i1 == sw - 1) ? s1 * 8.f : (s1 + s2) * 4.f;
+    o.x = sel(f0, e_first, sel(l0, e_last, e_gen));
+    o.y = sel(l0, o_last, o_gen);
+    o.z = sel(l1, z_last, z_gen);
+    o.w = sel(l1, w_last, w_gen);
     return o;
 }
 
@@ -174,7 +181,7 @@ __device__ __forceinline__ float4 pyrup_h4(float sm1, float s0, float s1, float 
 // the dependent instruction stream per frame, not throughput, sets the time (W = 4 measured slower
 // everywhere: 167 registers at ring depth 2).
 template <int W> struct UpRaw { float g[3][W / 2 + 2]; float c[3][W / 2 + 2]; float gl[2][W]; };
-template <int W, int D>
+template <int W, int D, bool HC>                        // HC: cur_{l+1} exists (every level but the top live one)
 __global__ __launch_bounds__(256) void k_lap_up_rows(UpArgs a, int gw, int ngroups) {
     constexpr int NT = W / 2 + 2;                        // source taps per row: columns i0-1 .. i0+W/2
     const int gi = blockIdx.x * 256 + threadIdx.x;
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(256) void k_lap_up_rows(UpArgs a, int gw, int ngrou
     const int plane = blockIdx.y;
     const int gy = gi / gw, gxg = gi - gy * gw;
     const int gx = gxg * W, y0 = gy * 2;
-    const bool has_cur = a.curn != nullptr;
+    constexpr bool has_cur = HC;
     const bool row1 = y0 + 1 < a.h;                      // the second row of the block exists
     const size_t pn = (size_t)plane * a.wn * a.hn, pl = (size_t)plane * a.w * a.h;
     const int i0 = gx >> 1, j0 = y0 >> 1;
@@ -206,10 +213,13 @@ __global__ __launch_bounds__(256) void k_lap_up_rows(UpArgs a, int gw, int ngrou
             hi_r[1][k] = *reinterpret_cast<const float*>(H + loff1 + 4 * k); lo_r[1][k] = *reinterpret_cast<const float*>(Lo + loff1 + 4 * k);
         }
     }
-    auto load = [&](int t, UpRaw<W>& r) __attribute__((always_inline)) {
-        const char* Gn = reinterpret_cast<const char*>(a.Gn + pn + (size_t)t * a.fsn);
-        const char* Cn = reinterpret_cast<const char*>((has_cur ? a.curn : a.Gn) + pn + (size_t)t * a.fsn);
-        const char* Gl = reinterpret_cast<const char*>(a.Gl + pl + (size_t)t * a.fsl);
+    // frame cursors of the ring refills (uniform pointers, advanced by one frame per refill and parked on
+    // the last frame)
+    const char* Gn = reinterpret_cast<const char*>(a.Gn + pn);
+    const char* Cn = reinterpret_cast<const char*>((has_cur ? a.curn : a.Gn) + pn);
+    const char* Gl = reinterpret_cast<const char*>(a.Gl + pl);
+    int tl = 0;
+    auto load = [&](UpRaw<W>& r) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 3; ++q)
 #pragma unroll
@@ -222,18 +232,25 @@ __global__ __launch_bounds__(256) void k_lap_up_rows(UpArgs a, int gw, int ngrou
             r.gl[0][k] = *reinterpret_cast<const float*>(Gl + loff0 + 4 * k);
             r.gl[1][k] = *reinterpret_cast<const float*>(Gl + loff1 + 4 * k);
         }
+        if (tl + 1 < a.nt) { ++tl; Gn += a.fsn * sizeof(float); Cn += a.fsn * sizeof(float); Gl += a.fsl * sizeof(float); }
     };
-    // horizontal pyrUp pass of one source row for the W destination columns gx .. gx+W-1
+    // horizontal pyrUp pass of one source row for the W destination columns gx .. gx+W-1 (all border
+    // variants evaluated, result selected: no divergent branches)
     auto hpass = [&](const float (&sv)[NT], float (&o)[W]) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < W / 2; ++k) {
             const int i = i0 + k;                        // source column of the destination pair (2i, 2i+1)
+            const bool fi = i == 0, la = i == a.wn - 1;
             const float sm1 = sv[k], s0 = sv[k + 1], s1 = sv[k + 2];
-            o[2 * k] = (i == 0) ? s0 * 6.f + s1 * 2.f : ((i == a.wn - 1) ? sm1 + s0 * 7.f : sm1 + s0 * 6.f + s1);
-            o[2 * k + 1] = (i == a.wn - 1) ? s0 * 8.f : (s0 + s1) * 4.f;
+            const float p6 = s0 * 6.f;
+            const float e_gen = sm1 + p6 + s1, e_first = p6 + s1 * 2.f, e_last = sm1 + s0 * 7.f;
+            const float o_gen = (s0 + s1) * 4.f, o_last = s0 * 8.f;
+            o[2 * k] = sel(fi, e_first, sel(la, e_last, e_gen));
+            o[2 * k + 1] = sel(la, o_last, o_gen);
         }
     };
-    auto filter = [&](int t, const UpRaw<W>& r) __attribute__((always_inline)) {
+    char* cur = reinterpret_cast<char*>(a.cur + pl);
+    auto filter = [&](const UpRaw<W>& r) __attribute__((always_inline)) {
         float hg[3][W], hc[3][W];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -254,24 +271,23 @@ __global__ __launch_bounds__(256) void k_lap_up_rows(UpArgs a, int gw, int ngrou
                 const float up = has_cur ? (y == 0 ? (hc[0][k] + hc[1][k] * 6.f + hc[2][k]) * (1.f / 64.f) : ((hc[1][k] + hc[2][k]) * 4.f) * (1.f / 64.f)) : 0.f;
                 o[y][k] = up + m;                                                // SpatialFilter.cpp:58
             }
-        char* cur = reinterpret_cast<char*>(a.cur + pl + (size_t)t * a.fsl);
 #pragma unroll
         for (int k = 0; k < W; ++k) *reinterpret_cast<float*>(cur + loff0 + 4 * k) = o[0][k];
         if (row1) {
 #pragma unroll
             for (int k = 0; k < W; ++k) *reinterpret_cast<float*>(cur + loff1 + 4 * k) = o[1][k];
         }
+        cur += a.fsl * sizeof(float);
     };
     UpRaw<W> ring[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) load(d < a.nt ? d : a.nt - 1, ring[d]);
+    for (int d = 0; d < D; ++d) load(ring[d]);
     for (int t0 = 0; t0 < a.nt; t0 += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            const int t = t0 + d;
-            const UpRaw<W> cur = ring[d];
-            load(t + D < a.nt ? t + D : a.nt - 1, ring[d]);
-            filter(t, cur);
+            const UpRaw<W> now = ring[d];
+            load(ring[d]);
+            filter(now);
         }
     }
     {
@@ -627,7 +643,7 @@ struct LaplaceState : ModeState {
     long up_rows_max_blocks = 1024;       // launches with fewer tiled workgroups than this use k_lap_up_rows (LVM_UP_ROWS_MAX_BLOCKS)
     int fin_rows = 4;                     // rows per wave strip of k_lap_final_v4 (LVM_FIN_ROWS, power of two)
     int up_depth = 8;                     // frame-loop prefetch depth of k_lap_up at the coarse levels (LVM_UP_DEPTH=1|2|4|8)
-    int chunks = 4;                       // temporal batches: chunks whose down sweep overlaps the previous chunk's up sweep (LVM_LAP_CHUNKS)
+    int chunks = 1;                       // temporal batches: > 1 = chunks whose down sweep overlaps the previous chunk's up sweep on a second stream (LVM_LAP_CHUNKS; measured slower: 27.7k fps at 4 chunks, 30.5k at 2, 34.8k at 1)
     std::vector<hipEvent_t> chunk_ev;
     int fuse_down = 2;                    // pyramid levels per pyrDown launch (LVM_FUSE_DOWN=2|3 selects the fused kernels)
     int tailT = 0;                       // first level handled by k_lap_tail (0 = tail disabled)
@@ -851,7 +867,10 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
             const dim3 g2((unsigned)((ngroups + 255) / 256), (unsigned)st->planes);
             int depth = 4;
             while (depth > 1 && a.nt % depth != 0) depth >>= 1;
-            auto kr = depth == 4 ? k_lap_up_rows<2, 4> : (depth == 2 ? k_lap_up_rows<2, 2> : k_lap_up_rows<2, 1>);
+            const bool hc = a.curn != nullptr;
+            auto kr = depth == 4 ? (hc ? k_lap_up_rows<2, 4, true> : k_lap_up_rows<2, 4, false>)
+                                 : (depth == 2 ? (hc ? k_lap_up_rows<2, 2, true> : k_lap_up_rows<2, 2, false>)
+                                               : (hc ? k_lap_up_rows<2, 1, true> : k_lap_up_rows<2, 1, false>));
             LVM_LAUNCH(c, "lap_up", kr, g2, blk, s, a, gw, (int)ngroups);
             continue;
         }

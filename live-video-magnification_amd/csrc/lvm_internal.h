@@ -27,6 +27,10 @@ __device__ __forceinline__ int reflect101(int p, int len) {
     while (p < 0 || p >= len) p = (p < 0) ? -p : 2 * len - 2 - p;
     return p;
 }
+// value select that stays a v_cndmask (the hint keeps the optimiser from turning it back into a
+// divergent branch around the evaluation of one operand)
+__device__ __forceinline__ float sel(bool c, float a, float b) { return __builtin_unpredictable(c) ? a : b; }
+
 // convertTo(CV_8U): saturate_cast<uchar>(cvRound(v)), cvRound = round-half-even
 __device__ __forceinline__ uint8_t sat_u8(float v) {
     if (!(v == v)) return 0;
@@ -188,14 +192,14 @@ __device__ __forceinline__ void load_invgamma(float* s_igt, const float* g) {
 // pyrUp horizontal pass for destination column gx from source row `s` whose element for
 // source column i sits at s[i - sx0] (OpenCV pyrUp_ border rules, see laplace.hip).
 __device__ __forceinline__ float pyrup_h(const float* s, int gx, int sx0, int sw) {
+    // all border variants are evaluated on clamped indices and the result selected: no divergent branches
     const int i = gx >> 1, li = i - sx0;
-    if ((gx & 1) == 0) {
-        if (i == 0) return s[li] * 6.f + s[li + 1] * 2.f;
-        if (i == sw - 1) return s[li - 1] + s[li] * 7.f;
-        return s[li - 1] + s[li] * 6.f + s[li + 1];
-    }
-    if (i == sw - 1) return s[li] * 8.f;
-    return (s[li] + s[li + 1]) * 4.f;
+    const bool first = i == 0, last = i == sw - 1;
+    const float sm1 = s[first ? li : li - 1], s0 = s[li], s1 = s[last ? li : li + 1];
+    const float p6 = s0 * 6.f;
+    const float even = sel(first, p6 + s1 * 2.f, sel(last, sm1 + s0 * 7.f, sm1 + p6 + s1));
+    const float odd = sel(last, s0 * 8.f, (s0 + s1) * 4.f);
+    return sel((gx & 1) == 0, even, odd);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -125,8 +125,8 @@ __device__ __forceinline__ void pyrup_hpass(float (&hrow)[US_H][UT_W + 1], const
 // vertical pass for destination row gy; lj = local row of source row gy>>1
 __device__ __forceinline__ float pyrup_v(const float (&hrow)[US_H][UT_W + 1], int x, int gy, int sy0) {
     const int lj = (gy >> 1) - sy0;
-    if ((gy & 1) == 0) return (hrow[lj - 1][x] + hrow[lj][x] * 6.f + hrow[lj + 1][x]) * (1.f / 64.f);
-    return ((hrow[lj][x] + hrow[lj + 1][x]) * 4.f) * (1.f / 64.f);
+    const float r0 = hrow[lj - 1][x], r1 = hrow[lj][x], r2 = hrow[lj + 1][x];
+    return sel((gy & 1) == 0, (r0 + r1 * 6.f + r2) * (1.f / 64.f), ((r1 + r2) * 4.f) * (1.f / 64.f));
 }
 
 // ---- vectorised u8 -> planes -> pyrDown (frames whose pixel groups of 4 are dword aligned) ----

@@ -32,6 +32,7 @@ enum { hipStreamNonBlocking = 1 };
 #define __shared__ static thread_local
 #define __launch_bounds__(...)
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
+#define __builtin_unpredictable(x) (x)   // clang-only optimiser hint
 
 namespace hipemu {
 struct State { dim3 tid, bid, bdim, gdim; };
