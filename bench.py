@@ -79,6 +79,8 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, streams, T=0):
         return {
             "col_down0": S * ch * n[0] + 4 * P * n[1],
             "pyr_down": avg([4 * P * (n[l] + n[l + 1]) for l in range(1, levels)]),
+            "pyr_down_rows": avg([4 * P * (n[l] + n[l + 1]) for l in range(1, levels)
+                                  if sizes[l][0] % 4 == 0 and n[l] * P >= (1 << 20)]),
             "col_append": 8 * ch * nL,
             "col_dft": 4 * P * nL * (T + 1),
             "col_norm": 8 * ch * nL,

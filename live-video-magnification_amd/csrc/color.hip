@@ -22,6 +22,7 @@
 //   k_col_out<false>               last pyrUp + bilinear resize + input add -> global min/max
 //   k_col_out<true>                same values again -> u8 with the min/max rescale
 #include <cmath>
+#include <cstdlib>
 
 #include <vector>
 
@@ -171,6 +172,76 @@ __global__ __launch_bounds__(256) void k_col_dft(const float* __restrict__ win, 
             }
         }
         __syncthreads();
+    }
+    block_minmax(vmin, vmax, mm[b].mn1, mm[b].mx1);
+}
+
+// Narrow pass bands (at most kThinBins non-zero spectrum entries -- the usual pulse band is 1-3 bins):
+// one THREAD per window row.  With so few entries the wave-per-row kernel runs its forward sums on 1-3
+// lanes of 64; here every lane runs the (in-order, float64) sums of its own row for all entries while
+// it walks once over the window, then the inverse sums of all n samples.  Entry list built on the host.
+constexpr int kThinBins = 8;
+struct ThinBins { int ne; int bin[kThinBins]; int kind[kThinBins]; float ma[kThinBins], mb[kThinBins]; };
+__global__ __launch_bounds__(256) void k_col_dft_thin(const float* __restrict__ win, int slot0, int n, int cap,
+                                                      int rows_per_stream, int live_per_stream,
+                                                      const double* __restrict__ tw, float* __restrict__ col1, MinMax* mm,
+                                                      ThinBins eb) {
+    const int r = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y, fr = blockIdx.z;
+    slot0 += fr; if (slot0 >= cap) slot0 -= cap;
+    col1 += (size_t)fr * gridDim.y * rows_per_stream;
+    mm += fr * gridDim.y;
+    const bool live = r < live_per_stream;
+    const size_t grow = (size_t)b * rows_per_stream + (live ? r : 0);
+    const double* cs = tw;
+    const double* sn = tw + n;
+    float vmin = INFINITY, vmax = -INFINITY;
+    if (live) {
+        const float* wr = win + grow * cap;
+        double ar[kThinBins], ai[kThinBins];
+        int idx[kThinBins];
+#pragma unroll
+        for (int j = 0; j < kThinBins; ++j) { ar[j] = ai[j] = 0; idx[j] = 0; }
+        int slot = slot0;
+        for (int t = 0; t < n; ++t) {                                                 // dft: sums in sample order
+            const double v = (double)wr[slot];
+            if (++slot >= cap) slot -= cap;
+#pragma unroll
+            for (int j = 0; j < kThinBins; ++j) {
+                if (j >= eb.ne) break;
+                ar[j] += v * cs[idx[j]];
+                ai[j] += -v * sn[idx[j]];
+                idx[j] += eb.bin[j]; if (idx[j] >= n) idx[j] -= n;
+            }
+        }
+        float yre[kThinBins], yim[kThinBins];
+#pragma unroll
+        for (int j = 0; j < kThinBins; ++j) {                                         // mulSpectrums with the packed mask
+            yre[j] = yim[j] = 0.f;
+            if (j >= eb.ne) continue;
+            const float a = (float)(ar[j] / n), bq = (float)(ai[j] / n);
+            if (eb.kind[j] == 0) { yre[j] = a * eb.ma[j] - bq * eb.mb[j]; yim[j] = bq * eb.ma[j] + a * eb.mb[j]; }
+            else yre[j] = a * eb.ma[j];
+            idx[j] = 0;
+        }
+        const bool has_dc = eb.ne > 0 && eb.kind[0] == 1;
+        const bool has_ny = eb.ne > 0 && eb.kind[eb.ne - 1] == 2;
+        float yny = 0.f;
+#pragma unroll
+        for (int j = 0; j < kThinBins; ++j) if (has_ny && j == eb.ne - 1) yny = yre[j];
+        for (int t = 0; t < n; ++t) {                                                 // idft of every sample
+            double acc = has_dc ? yre[0] : 0.f;
+#pragma unroll
+            for (int j = 0; j < kThinBins; ++j) {
+                if (j >= eb.ne) break;
+                if (eb.kind[j] != 0) continue;
+                acc += 2.0 * ((double)yre[j] * cs[idx[j]] - (double)yim[j] * sn[idx[j]]);
+                idx[j] += eb.bin[j]; if (idx[j] >= n) idx[j] -= n;
+            }
+            if (n % 2 == 0) acc += (t % 2 ? -1.0 : 1.0) * (double)yny;
+            const float v = (float)(acc / n);
+            vmin = v < vmin ? v : vmin; vmax = v > vmax ? v : vmax;
+            if (t == 1) col1[grow] = v;                                               // MagnifyCore.hpp:190-192
+        }
     }
     block_minmax(vmin, vmax, mm[b].mn1, mm[b].mx1);
 }
@@ -455,6 +526,8 @@ struct ColorState : ModeState {
     int n = 0, slot0 = 0;            // logical window: n columns starting at ring slot slot0
     int max_images = 0;
     bool co_rows_ok = false;         // the vectorised output kernel's LDS tile covers every output tile
+    bool thin_dft = true;            // thread-per-row DFT for narrow bands (LVM_COL_THIN_DFT=0: wave-per-row kernel)
+    long rows_min_elems = 1 << 20;   // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
     double* tw = nullptr; int tw_n = 0;
     MinMax* mm = nullptr;
     int *xofs = nullptr, *yofs = nullptr; float *xa = nullptr, *ya = nullptr;
@@ -558,7 +631,19 @@ static void col_down(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs& B
     }
     int l = 1;
     while (l < levels) {            // two pyramid levels per launch while possible
-        if (levels - l >= 2) {
+        if (st->g[l].w % 4 == 0 && (long)st->g[l].n * planes >= st->rows_min_elems) {
+            // large planes (temporal batches / many streams): barrier-free wave strips (pyramid.h)
+            const LevelGeom &a = st->g[l], &b = st->g[l + 1];
+            const int sx = (b.w + 127) / 128;
+            int rows = 16;
+            while (rows > 4 && (long)sx * ((b.h + rows - 1) / rows) * planes < 8192) rows >>= 1;
+            const int sy = (b.h + rows - 1) / rows;
+            const long ntasks = (long)sx * sy * planes;
+            const dim3 grid((unsigned)((ntasks + PD_THREADS / 64 - 1) / (PD_THREADS / 64)));
+            LVM_LAUNCH(c, "pyr_down_rows", k_pyr_down_rows<1>, grid, dim3(PD_THREADS), s, (const float*)B.G[l], a.w, a.h, B.G[l + 1], b.w, b.h,
+                       sx, sy, (int)ntasks, rows);
+            l += 1;
+        } else if (levels - l >= 2) {
             const LevelGeom &a = st->g[l], &b1 = st->g[l + 1], &b2 = st->g[l + 2];
             const dim3 grid((b2.w + ML_T - 1) / ML_T, (b2.h + ML_T - 1) / ML_T, planes);
             LVM_LAUNCH(c, "pyr_down2", k_pyr_down_multi<2>, grid, blk, s, (const float*)B.G[l], a.w, a.h, B.G[l + 1], b1.w, b1.h, B.G[l + 2],
@@ -586,7 +671,22 @@ static int col_filter(Ctx* c, ColorState* st, const lvm_params& p, const ColBufs
     if (lo == 0.00) lo += 0.01;                                                       // TemporalFilter.cpp:26-27
     const float width = (float)n;
     const double fl = 2 * lo * width / p.framerate, fh = 2 * hi * width / p.framerate; // :65-66
-    if (n <= kDftMaxN) {
+    // entries of the packed spectrum the 0/1 mask lets through (TemporalFilter.cpp:65-77)
+    ThinBins eb{};
+    int ne = 0;
+    {
+        auto m = [&](int x) { return (x >= fl && x <= fh) ? 1.0f : 0.0f; };
+        const int half = (n - 1) / 2;
+        auto push = [&](int bin, int kind, float ma, float mb) { if (ne < kThinBins) { eb.bin[ne] = bin; eb.kind[ne] = kind; eb.ma[ne] = ma; eb.mb[ne] = mb; } ++ne; };
+        if (m(0) != 0.f) push(0, 1, m(0), 0.f);
+        for (int k = 1; k <= half; ++k) if (m(2 * k - 1) != 0.f || m(2 * k) != 0.f) push(k, 0, m(2 * k - 1), m(2 * k));
+        if (n % 2 == 0 && m(n - 1) != 0.f) push(n / 2, 2, m(n - 1), 0.f);
+        eb.ne = ne;
+    }
+    if (ne <= kThinBins && st->thin_dft) {
+        LVM_LAUNCH(c, "col_dft", k_col_dft_thin, dim3((live + 255) / 256, NS, B.nt), blk, s, (const float*)st->win, slot0, n, st->cap,
+                   st->rows_ps, live, (const double*)st->tw, B.col1, B.mm, eb);
+    } else if (n <= kDftMaxN) {
         int gx = (live + kDftRows - 1) / kDftRows;
         gx = gx < 1024 ? gx : 1024;
         LVM_LAUNCH(c, "col_dft", k_col_dft, dim3(gx, NS, B.nt), blk, s, (const float*)st->win, slot0, n, st->cap, st->rows_ps, live, fl, fh,
@@ -638,6 +738,8 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
     if (!st) {
         st = new ColorState();
         c->state = st;
+        if (const char* e = std::getenv("LVM_COL_THIN_DFT")) st->thin_dft = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_ROWS_MIN_ELEMS")) st->rows_min_elems = std::atol(e);
         const int rc = color_alloc(c, st, io.w, io.h, io.channels, levels);
         if (rc != LVM_OK) return rc;
     }
