@@ -192,8 +192,15 @@ __global__ __launch_bounds__(256) void k_col_dft_thin(const float* __restrict__ 
     mm += fr * gridDim.y;
     const bool live = r < live_per_stream;
     const size_t grow = (size_t)b * rows_per_stream + (live ? r : 0);
-    const double* cs = tw;
-    const double* sn = tw + n;
+    // twiddles in LDS: the table index depends on the running bin phase, so a global (scalar) load per
+    // sample would put its latency on every step of the serial sums
+    __shared__ double s_tw[2 * kDftMaxN];
+    for (int i = threadIdx.x; i < 2 * n; i += 256) s_tw[i] = tw[i];
+    __syncthreads();
+    const double* cs = s_tw;
+    const double* sn = s_tw + n;
+    const bool pow2 = (n & (n - 1)) == 0;            // x / 2^k == x * 2^-k exactly: skip the float64 division
+    const double inv_n = 1.0 / (double)n;
     float vmin = INFINITY, vmax = -INFINITY;
     if (live) {
         const float* wr = win + grow * cap;
@@ -201,16 +208,26 @@ __global__ __launch_bounds__(256) void k_col_dft_thin(const float* __restrict__ 
         int idx[kThinBins];
 #pragma unroll
         for (int j = 0; j < kThinBins; ++j) { ar[j] = ai[j] = 0; idx[j] = 0; }
-        int slot = slot0;
-        for (int t = 0; t < n; ++t) {                                                 // dft: sums in sample order
-            const double v = (double)wr[slot];
-            if (++slot >= cap) slot -= cap;
+        constexpr int U = 8;                         // samples loaded ahead of the sums
+        for (int t0 = 0; t0 < n; t0 += U) {                                           // dft: sums in sample order
+            float v8[U];
 #pragma unroll
-            for (int j = 0; j < kThinBins; ++j) {
-                if (j >= eb.ne) break;
-                ar[j] += v * cs[idx[j]];
-                ai[j] += -v * sn[idx[j]];
-                idx[j] += eb.bin[j]; if (idx[j] >= n) idx[j] -= n;
+            for (int u = 0; u < U; ++u) {
+                int slot = slot0 + (t0 + u < n ? t0 + u : n - 1);
+                if (slot >= cap) slot -= cap;
+                v8[u] = wr[slot];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (t0 + u >= n) break;
+                const double v = (double)v8[u];
+#pragma unroll
+                for (int j = 0; j < kThinBins; ++j) {
+                    if (j >= eb.ne) break;
+                    ar[j] += v * cs[idx[j]];
+                    ai[j] += -v * sn[idx[j]];
+                    idx[j] += eb.bin[j]; if (idx[j] >= n) idx[j] -= n;
+                }
             }
         }
         float yre[kThinBins], yim[kThinBins];
@@ -218,7 +235,7 @@ __global__ __launch_bounds__(256) void k_col_dft_thin(const float* __restrict__ 
         for (int j = 0; j < kThinBins; ++j) {                                         // mulSpectrums with the packed mask
             yre[j] = yim[j] = 0.f;
             if (j >= eb.ne) continue;
-            const float a = (float)(ar[j] / n), bq = (float)(ai[j] / n);
+            const float a = (float)(pow2 ? ar[j] * inv_n : ar[j] / n), bq = (float)(pow2 ? ai[j] * inv_n : ai[j] / n);
             if (eb.kind[j] == 0) { yre[j] = a * eb.ma[j] - bq * eb.mb[j]; yim[j] = bq * eb.ma[j] + a * eb.mb[j]; }
             else yre[j] = a * eb.ma[j];
             idx[j] = 0;
@@ -238,7 +255,7 @@ __global__ __launch_bounds__(256) void k_col_dft_thin(const float* __restrict__ 
                 idx[j] += eb.bin[j]; if (idx[j] >= n) idx[j] -= n;
             }
             if (n % 2 == 0) acc += (t % 2 ? -1.0 : 1.0) * (double)yny;
-            const float v = (float)(acc / n);
+            const float v = (float)(pow2 ? acc * inv_n : acc / n);
             vmin = v < vmin ? v : vmin; vmax = v > vmax ? v : vmax;
             if (t == 1) col1[grow] = v;                                               // MagnifyCore.hpp:190-192
         }
@@ -527,6 +544,7 @@ struct ColorState : ModeState {
     int max_images = 0;
     bool co_rows_ok = false;         // the vectorised output kernel's LDS tile covers every output tile
     bool thin_dft = true;            // thread-per-row DFT for narrow bands (LVM_COL_THIN_DFT=0: wave-per-row kernel)
+    int thin_min_frames = 1;         // ... from this many frames per launch (LVM_COL_THIN_MIN_FRAMES)
     long rows_min_elems = 1 << 20;   // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
     double* tw = nullptr; int tw_n = 0;
     MinMax* mm = nullptr;
@@ -683,7 +701,7 @@ static int col_filter(Ctx* c, ColorState* st, const lvm_params& p, const ColBufs
         if (n % 2 == 0 && m(n - 1) != 0.f) push(n / 2, 2, m(n - 1), 0.f);
         eb.ne = ne;
     }
-    if (ne <= kThinBins && st->thin_dft) {
+    if (ne <= kThinBins && n <= kDftMaxN && st->thin_dft && B.nt >= st->thin_min_frames) {
         LVM_LAUNCH(c, "col_dft", k_col_dft_thin, dim3((live + 255) / 256, NS, B.nt), blk, s, (const float*)st->win, slot0, n, st->cap,
                    st->rows_ps, live, (const double*)st->tw, B.col1, B.mm, eb);
     } else if (n <= kDftMaxN) {
@@ -739,6 +757,7 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         st = new ColorState();
         c->state = st;
         if (const char* e = std::getenv("LVM_COL_THIN_DFT")) st->thin_dft = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_COL_THIN_MIN_FRAMES")) st->thin_min_frames = std::atoi(e);
         if (const char* e = std::getenv("LVM_ROWS_MIN_ELEMS")) st->rows_min_elems = std::atol(e);
         const int rc = color_alloc(c, st, io.w, io.h, io.channels, levels);
         if (rc != LVM_OK) return rc;
