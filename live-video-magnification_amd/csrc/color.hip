@@ -59,6 +59,21 @@ __device__ __forceinline__ void block_minmax(float mn, float mx, int* gmn, int* 
         atomicMin(gmn + cell, fkey(s_mn[0])); atomicMax(gmx + cell, fkey(s_mx[0]));
     }
 }
+// Per-wave variant for kernels whose waves may belong to different frames: every wave folds its 64 values
+// through LDS (one barrier for the workgroup) and its first lane issues the two atomics into the output
+// range cells of frame `z`.
+__device__ __forceinline__ void block_minmax_waves(float mn, float mx, MinMax* mm, int z, bool active) {
+    __shared__ float s_mn[256], s_mx[256];
+    const int t = threadIdx.x;
+    s_mn[t] = mn; s_mx[t] = mx;
+    __syncthreads();
+    if ((t & 63) == 0 && active) {
+        float a = s_mn[t], b = s_mx[t];
+        for (int i = 1; i < 64; ++i) { a = s_mn[t + i] < a ? s_mn[t + i] : a; b = s_mx[t + i] > b ? s_mx[t + i] : b; }
+        const int cell = (int)((blockIdx.x * 4u + (unsigned)(t >> 6)) % kMMCells);
+        atomicMin(mm[z].mn2 + cell, fkey(a)); atomicMax(mm[z].mx2 + cell, fkey(b));
+    }
+}
 
 // img2tempMat (SpatialFilter.cpp:63-84): one window column per frame.  Window layout: win[row][slot]
 // (time-contiguous per row, ring of `cap` slots) so that a wave reads one row's history as one
@@ -245,20 +260,24 @@ __global__ __launch_bounds__(256) void k_col_dft_thin(const float* __restrict__ 
         float yny = 0.f;
 #pragma unroll
         for (int j = 0; j < kThinBins; ++j) if (has_ny && j == eb.ne - 1) yny = yre[j];
-        for (int t = 0; t < n; ++t) {                                                 // idft of every sample
-            double acc = has_dc ? yre[0] : 0.f;
+        auto idft = [&](auto scale) __attribute__((always_inline)) {                  // idft of every sample
+            for (int t = 0; t < n; ++t) {
+                double acc = has_dc ? yre[0] : 0.f;
 #pragma unroll
-            for (int j = 0; j < kThinBins; ++j) {
-                if (j >= eb.ne) break;
-                if (eb.kind[j] != 0) continue;
-                acc += 2.0 * ((double)yre[j] * cs[idx[j]] - (double)yim[j] * sn[idx[j]]);
-                idx[j] += eb.bin[j]; if (idx[j] >= n) idx[j] -= n;
+                for (int j = 0; j < kThinBins; ++j) {
+                    if (j >= eb.ne) break;
+                    if (eb.kind[j] != 0) continue;
+                    acc += 2.0 * ((double)yre[j] * cs[idx[j]] - (double)yim[j] * sn[idx[j]]);
+                    idx[j] += eb.bin[j]; if (idx[j] >= n) idx[j] -= n;
+                }
+                if (n % 2 == 0) acc += (t % 2 ? -1.0 : 1.0) * (double)yny;
+                const float v = (float)scale(acc);
+                vmin = v < vmin ? v : vmin; vmax = v > vmax ? v : vmax;
+                if (t == 1) col1[grow] = v;                                           // MagnifyCore.hpp:190-192
             }
-            if (n % 2 == 0) acc += (t % 2 ? -1.0 : 1.0) * (double)yny;
-            const float v = (float)(pow2 ? acc * inv_n : acc / n);
-            vmin = v < vmin ? v : vmin; vmax = v > vmax ? v : vmax;
-            if (t == 1) col1[grow] = v;                                               // MagnifyCore.hpp:190-192
-        }
+        };
+        if (pow2) idft([&](double x) { return x * inv_n; });                          // (uniform branch: no division in the loop)
+        else idft([&](double x) { return x / n; });
     }
     block_minmax(vmin, vmax, mm[b].mn1, mm[b].mx1);
 }
@@ -528,6 +547,114 @@ __global__ __launch_bounds__(256) void k_col_out_v4(OutArgs a) {
     if (!WRITE) block_minmax(vmin, vmax, a.mm[b].mn2, a.mm[b].mx2);
 }
 
+// Barrier-free strip form of k_col_out_v4 (same preconditions, same arithmetic).  Every wave owns a
+// strip of 256 x `rows` output pixels, one lane per group of 4 pixels.  Output row gy blends the two
+// pyrUp rows sy0 = yofs[gy] and sy0 + 1, and those two rows need exactly three consecutive rows of the
+// horizontal pass of V starting at js = (sy0 - 1) >> 1: the lane computes that horizontal pass straight
+// from global memory and keeps the three rows in registers, advancing the window as js grows (js and
+// the row parity are uniform across the wave: no divergence, no LDS, no barrier until the final
+// min/max reduction of the workgroup).
+struct HRow3 { float4 c[3]; };
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_col_out_rows(OutArgs a, int strips_x, int strips_y, int ntasks, int rows) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + wave;
+    float vmin = INFINITY, vmax = -INFINITY;
+    int b = 0;
+    if (task < ntasks) {
+        b = task / (strips_x * strips_y);
+        const int r = task - b * (strips_x * strips_y);
+        const int ty = r / strips_x, tx = r - ty * strips_x;
+        const int gx = tx * 256 + 4 * lane, y0 = ty * rows;
+        if (gx < a.w) {
+            const int uh = 2 * a.vh;
+            const uint8_t* src = a.in + (size_t)b * a.in_sstride;
+            uint8_t* dst = a.out + (size_t)b * a.out_sstride;
+            const unsigned xoff = (unsigned)gx * 3u;
+            const float* pl = a.V + (size_t)b * 3 * ((size_t)a.vw * a.vh);
+            const size_t pstride = (size_t)a.vw * a.vh;
+            const int i0 = gx >> 1;
+            const unsigned cm1 = 4u * (i0 > 0 ? i0 - 1 : 0), c00 = 4u * i0, cp1 = 4u * (i0 + 1 < a.vw ? i0 + 1 : a.vw - 1),
+                           cp2 = 4u * (i0 + 2 < a.vw ? i0 + 2 : a.vw - 1);
+            auto hrow = [&](int vy) __attribute__((always_inline)) {       // horizontal pyrUp pass of V row vy (border map -1 -> 1, vh -> vh - 1)
+                HRow3 o;
+                vy = vy < 0 ? 1 : (vy >= a.vh ? a.vh - 1 : vy);
+                const char* row = reinterpret_cast<const char*>(pl + (size_t)vy * a.vw);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const char* rc = row + c * pstride * sizeof(float);
+                    const float sm1 = *reinterpret_cast<const float*>(rc + cm1), s0 = *reinterpret_cast<const float*>(rc + c00),
+                                s1 = *reinterpret_cast<const float*>(rc + cp1), s2 = *reinterpret_cast<const float*>(rc + cp2);
+                    const bool f0 = i0 == 0, l0 = i0 == a.vw - 1, l1 = i0 + 1 == a.vw - 1;
+                    o.c[c].x = sel(f0, s0 * 6.f + s1 * 2.f, sel(l0, sm1 + s0 * 7.f, sm1 + s0 * 6.f + s1));
+                    o.c[c].y = sel(l0, s0 * 8.f, (s0 + s1) * 4.f);
+                    o.c[c].z = sel(l1, s0 + s1 * 7.f, s0 + s1 * 6.f + s2);
+                    o.c[c].w = sel(l1, s1 * 8.f, (s1 + s2) * 4.f);
+                }
+                return o;
+            };
+            float osc = 0.f, osh = 0.f;
+            if (WRITE) {   // convertTo(CV_8U, 255/(max-min), -min*255/(max-min)) (MagnifyCore.hpp:202)
+                const double mn = (double)mm_min(a.mm[b].mn2), mx = (double)mm_max(a.mm[b].mx2);
+                osc = (float)(255.0 / (mx - mn)); osh = (float)(-mn * 255.0 / (mx - mn));
+            }
+            const int yend = y0 + rows < a.h ? y0 + rows : a.h;
+            int js = (a.yofs[y0] - 1) >> 1;
+            HRow3 A = hrow(js), B = hrow(js + 1), C = hrow(js + 2);
+            for (int gy = y0; gy < yend; ++gy) {
+                const int sy0 = a.yofs[gy];
+                const float b1 = a.ya[gy], b0 = 1.f - b1;
+                const bool clamp1 = sy0 + 1 > uh - 1;                // sy1 = sy0 (last row)
+                const int jn = (sy0 - 1) >> 1;
+                while (js < jn) { A = B; B = C; C = hrow(js + 3); ++js; }
+                const Px4 pin = *reinterpret_cast<const Px4*>(src + (size_t)gy * a.in_stride + xoff);
+                float val[3][4];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float* pa = &A.c[c].x; const float* pb = &B.c[c].x; const float* pc = &C.c[c].x;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float u0, u1;
+                        if ((sy0 & 1) == 0) {             // rows 2j (window j-1, j, j+1) and 2j+1 (j, j+1)
+                            u0 = (pa[k] + pb[k] * 6.f + pc[k]) * (1.f / 64.f);
+                            u1 = ((pb[k] + pc[k]) * 4.f) * (1.f / 64.f);
+                        } else {                          // rows 2j+1 (window j, j+1) and 2j+2 (j, j+1, j+2)
+                            u0 = ((pa[k] + pb[k]) * 4.f) * (1.f / 64.f);
+                            u1 = (pa[k] + pb[k] * 6.f + pc[k]) * (1.f / 64.f);
+                        }
+                        if (clamp1) u1 = u0;
+                        // resize INTER_LINEAR: horizontal taps are (1, 0) here; vertical D = S0*b0 + S1*b1
+                        val[c][k] = u0 * b0 + u1 * b1;
+                    }
+                }
+                int Bv[4], Gv[4], Rv[4];
+                unpack_px4(pin, Bv, Gv, Rv);
+                float ov[12];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float o0 = (float)Bv[k] * 1.0f + val[0][k], o1 = (float)Gv[k] * 1.0f + val[1][k], o2 = (float)Rv[k] * 1.0f + val[2][k];
+                    if (WRITE) {
+                        ov[3 * k] = o0 * osc + osh; ov[3 * k + 1] = o1 * osc + osh; ov[3 * k + 2] = o2 * osc + osh;
+                        if (a.dbg && b == 0) { float* d = a.dbg + ((size_t)gy * a.w + gx + k) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
+                    } else {
+                        vmin = fminf(vmin, fminf(o0, fminf(o1, o2))); vmax = fmaxf(vmax, fmaxf(o0, fmaxf(o1, o2)));
+                    }
+                }
+                if (WRITE) {
+                    Px4 q;
+                    q.a = pack_u8x4(ov[0], ov[1], ov[2], ov[3]); q.b = pack_u8x4(ov[4], ov[5], ov[6], ov[7]); q.c = pack_u8x4(ov[8], ov[9], ov[10], ov[11]);
+                    *reinterpret_cast<Px4*>(dst + (size_t)gy * a.out_stride + xoff) = q;
+                }
+            }
+        }
+    }
+    if (!WRITE) {
+        // all four waves of a workgroup belong to the same frame when strips_x * strips_y is a multiple of 4 or
+        // the workgroup does not straddle a frame boundary; otherwise reduce per wave into that wave's frame
+        block_minmax_waves(vmin, vmax, a.mm, b, task < ntasks);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -544,7 +671,9 @@ struct ColorState : ModeState {
     int max_images = 0;
     bool co_rows_ok = false;         // the vectorised output kernel's LDS tile covers every output tile
     bool thin_dft = true;            // thread-per-row DFT for narrow bands (LVM_COL_THIN_DFT=0: wave-per-row kernel)
-    int thin_min_frames = 1;         // ... from this many frames per launch (LVM_COL_THIN_MIN_FRAMES)
+    long out_min_tasks = 2048;       // strips are shortened until a launch has this many (LVM_COL_OUT_MIN_TASKS)
+    int out_rows = 8;                // rows per wave strip of k_col_out_rows (LVM_COL_OUT_ROWS; 0 = tiled k_col_out_v4)
+    int thin_min_frames = 4;         // ... from this many frames per launch (LVM_COL_THIN_MIN_FRAMES)
     long rows_min_elems = 1 << 20;   // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
     double* tw = nullptr; int tw_n = 0;
     MinMax* mm = nullptr;
@@ -739,7 +868,16 @@ static void col_up_out(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs&
     const bool vec4 = C == 3 && io.w == 2 * uw && io.w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 &&
                       io.out_stride % 4 == 0 && io.out_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0 && ((uintptr_t)io.d_out % 4) == 0 &&
                       st->co_rows_ok;
-    if (vec4) {
+    if (vec4 && st->out_rows > 0) {
+        const int sx = (io.w + 255) / 256;
+        int rows = st->out_rows;
+        while (rows > 2 && (long)sx * ((io.h + rows - 1) / rows) * NZ < st->out_min_tasks) rows >>= 1;
+        const int sy = (io.h + rows - 1) / rows;
+        const long ntasks = (long)sx * sy * NZ;
+        const dim3 g2((unsigned)((ntasks + 3) / 4));
+        LVM_LAUNCH(c, "col_minmax", k_col_out_rows<false>, g2, blk, s, a, sx, sy, (int)ntasks, rows);
+        LVM_LAUNCH(c, "col_out", k_col_out_rows<true>, g2, blk, s, a, sx, sy, (int)ntasks, rows);
+    } else if (vec4) {
         LVM_LAUNCH(c, "col_minmax", k_col_out_v4<false>, grid, blk, s, a);
         LVM_LAUNCH(c, "col_out", k_col_out_v4<true>, grid, blk, s, a);
     } else {
@@ -757,6 +895,8 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         st = new ColorState();
         c->state = st;
         if (const char* e = std::getenv("LVM_COL_THIN_DFT")) st->thin_dft = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_COL_OUT_ROWS")) st->out_rows = std::atoi(e);
+        if (const char* e = std::getenv("LVM_COL_OUT_MIN_TASKS")) st->out_min_tasks = std::atol(e);
         if (const char* e = std::getenv("LVM_COL_THIN_MIN_FRAMES")) st->thin_min_frames = std::atoi(e);
         if (const char* e = std::getenv("LVM_ROWS_MIN_ELEMS")) st->rows_min_elems = std::atol(e);
         const int rc = color_alloc(c, st, io.w, io.h, io.channels, levels);

@@ -87,6 +87,18 @@ def test_color_emu_bit_exact(lvm, po, emu, w, h, levels, ch, fps):
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 20, 0.0, exact=True)
 
 
+@pytest.mark.parametrize("rows", ["0", "2", "8", "16"])
+@pytest.mark.parametrize("w,h,levels", [(264, 90, 3), (96, 77, 2)])
+def test_color_emu_output_kernel_variants(lvm, po, emu, w, h, levels, rows, monkeypatch):
+    """The vectorised output kernels: tiled (rows = 0) and wave strips of 2 / 8 / 16 rows, on heights the
+    up chain overshoots (the bilinear row map skips source rows) and widths with a partly filled wave."""
+    monkeypatch.setenv("LVM_COL_OUT_ROWS", rows)
+    monkeypatch.setenv("LVM_COL_OUT_MIN_TASKS", "0")
+    ck, pk = lvm.synth.config(3, (w, h, levels))
+    ck["fps"] = 15.0; pk["framerate"] = 15.0
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 6, 0.0, exact=True)
+
+
 def test_color_emu_wide_band_and_fps_change(lvm, po, emu):
     ck, pk = lvm.synth.config(3, (64, 48, 2))
     pk["coLow"] = 0.0; pk["coHigh"] = 40.0                   # every packed element passes (lo == 0 -> 0.01)
