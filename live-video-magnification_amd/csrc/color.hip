@@ -672,7 +672,7 @@ struct ColorState : ModeState {
     bool co_rows_ok = false;         // the vectorised output kernel's LDS tile covers every output tile
     bool thin_dft = true;            // thread-per-row DFT for narrow bands (LVM_COL_THIN_DFT=0: wave-per-row kernel)
     long out_min_tasks = 2048;       // strips are shortened until a launch has this many (LVM_COL_OUT_MIN_TASKS)
-    int out_rows = 8;                // rows per wave strip of k_col_out_rows (LVM_COL_OUT_ROWS; 0 = tiled k_col_out_v4)
+    int out_rows = 16;               // rows per wave strip of k_col_out_rows (LVM_COL_OUT_ROWS; 0 = tiled k_col_out_v4)
     int thin_min_frames = 4;         // ... from this many frames per launch (LVM_COL_THIN_MIN_FRAMES)
     long rows_min_elems = 1 << 20;   // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
     double* tw = nullptr; int tw_n = 0;
