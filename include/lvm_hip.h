@@ -94,6 +94,38 @@ int  lvm_process_device_frames(lvm_ctx* ctx, const lvm_params* p, int n_frames, 
                                ptrdiff_t out_stride, ptrdiff_t out_stream_stride,
                                ptrdiff_t out_frame_stride, int* produced, void* hip_stream);
 
+/* ---- the two uint8 stages in front of the magnifier -------------------------
+ * processing/IProcessor.hpp:26-41 PreprocessParams + ProcessorConfig::grayscale (IProcessor.hpp:45).  */
+typedef struct lvm_preprocess_params {
+    int32_t downscale;      /* 1 / 2 / 4 / 8, clamped to [1, 8] like PreprocessProcessor.cpp:14 */
+    int32_t roi_enabled;
+    float   roiX, roiY, roiW, roiH;   /* fractions of the full frame */
+    int32_t grayscale;      /* ProcessorConfig::grayscale: BGR -> Gray8 after the decimation */
+} lvm_preprocess_params;
+
+/* Geometry of PreprocessProcessor::process + GrayscaleProcessor::process for a w x h x channels frame:
+ * the clamped ROI rectangle (PreprocessProcessor.cpp:19-31) and the size / channel count of the frame
+ * handed to the magnifier (:36-39, GrayscaleProcessor.cpp:8-15).                                      */
+int  lvm_preprocess_geometry(const lvm_preprocess_params* pp, int w, int h, int channels, int* roi_x,
+                             int* roi_y, int* roi_w, int* roi_h, int* out_w, int* out_h, int* out_channels);
+/* PreprocessProcessor::process (processing/PreprocessProcessor.cpp:10-51: crop + cv::resize INTER_AREA)
+ * followed by GrayscaleProcessor::process (processing/GrayscaleProcessor.cpp:7-16) on DEVICE memory, all
+ * n_streams streams, one kernel: the full frame is read once, the small frame written once.  d_out has
+ * the geometry lvm_preprocess_geometry reports.  Enqueued on hip_stream, not synchronised.            */
+int  lvm_preprocess_device(lvm_ctx* ctx, const lvm_preprocess_params* pp, const uint8_t* d_in, int w, int h,
+                           int channels, ptrdiff_t in_stride, ptrdiff_t in_stream_stride, uint8_t* d_out,
+                           ptrdiff_t out_stride, ptrdiff_t out_stream_stride, void* hip_stream);
+/* runChainOnce (processing/ChainBuilder.cpp:19-29) for the three stages Preprocess -> Grayscale ->
+ * Magnification on host memory, n_streams == 1: only the ROI rows cross PCIe, crop / decimation / gray /
+ * magnification run on the device, the (small) result comes back.  `out` must hold out_h rows of
+ * out_w * out_channels bytes (lvm_preprocess_geometry).  It is always written: the magnified frame
+ * when *produced != 0, otherwise the preprocessed frame (the reference's passthrough hands the
+ * magnifier's INPUT on, MagnificationProcessor.cpp:61).  The structural key of the magnifier follows
+ * the PreprocessParams (MagnifyCore.hpp:55-56), p->preprocess_key is ignored here.                  */
+int  lvm_chain_process(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_params* p, const uint8_t* in,
+                       int w, int h, int channels, ptrdiff_t in_stride, uint8_t* out, ptrdiff_t out_stride,
+                       int* produced);
+
 /* Cross-frame software pipeline for lvm_process_device (throughput mode, default depth 0).
  * depth 1 (implemented for the Laplace mode; other modes ignore it): a call enqueues the
  * down-sweep of ITS frame on an internal second stream concurrently with the up-sweep + output of

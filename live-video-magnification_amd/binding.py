@@ -76,6 +76,17 @@ class LvmParams(C.Structure):
                 ("preprocess_key", C.c_uint64)]
 
 
+class LvmPreprocessParams(C.Structure):
+    """lvm_preprocess_params (include/lvm_hip.h): PreprocessParams + ProcessorConfig::grayscale."""
+    _fields_ = [("downscale", C.c_int32), ("roi_enabled", C.c_int32), ("roiX", C.c_float), ("roiY", C.c_float),
+                ("roiW", C.c_float), ("roiH", C.c_float), ("grayscale", C.c_int32)]
+
+
+def to_c_preprocess(pre, grayscale=False):
+    return LvmPreprocessParams(int(pre.downscale), 1 if pre.roiEnabled else 0, pre.roiX, pre.roiY, pre.roiW, pre.roiH,
+                               1 if grayscale else 0)
+
+
 class LvmError(RuntimeError):
     pass
 
@@ -83,7 +94,8 @@ class LvmError(RuntimeError):
 SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process_device", "lvm_process_device_frames", "lvm_set_pipeline", "lvm_flush", "lvm_synchronize",
            "lvm_last_error", "lvm_max_levels", "lvm_optimal_buffer_size", "lvm_butterworth2",
            "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_profile_enable", "lvm_profile_collect",
-           "lvm_profile_entry", "lvm_set_graph", "lvm_algorithmic_bytes"]
+           "lvm_profile_entry", "lvm_set_graph", "lvm_algorithmic_bytes",
+           "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process"]
 
 
 def bind(lib):
@@ -119,6 +131,12 @@ def bind(lib):
     lib.lvm_set_graph.argtypes = [vp, C.c_int]
     lib.lvm_algorithmic_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
     lib.lvm_algorithmic_bytes.restype = C.c_double
+    ip = C.POINTER(C.c_int)
+    lib.lvm_preprocess_geometry.argtypes = [C.POINTER(LvmPreprocessParams), C.c_int, C.c_int, C.c_int, ip, ip, ip, ip, ip, ip, ip]
+    lib.lvm_preprocess_device.argtypes = [vp, C.POINTER(LvmPreprocessParams), vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t,
+                                          C.c_ssize_t, vp, C.c_ssize_t, C.c_ssize_t, vp]
+    lib.lvm_chain_process.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), vp, C.c_int, C.c_int, C.c_int,
+                                      C.c_ssize_t, vp, C.c_ssize_t, ip]
     return lib
 
 
@@ -170,6 +188,31 @@ class Context:
 
     def reset(self):
         self._check(self.lib.lvm_reset(self.h))
+
+    def preprocess_geometry(self, cpre, w, h, ch):
+        """(roi_x, roi_y, roi_w, roi_h, out_w, out_h, out_channels) of the two stages in front of the magnifier."""
+        v = [C.c_int() for _ in range(7)]
+        rc = self.lib.lvm_preprocess_geometry(C.byref(cpre), w, h, ch, *[C.byref(x) for x in v])
+        if rc != 0:
+            raise LvmError("lvm_preprocess_geometry: invalid arguments")
+        return tuple(x.value for x in v)
+
+    def preprocess_device(self, cpre, d_in, w, h, ch, in_stride, in_sstride, d_out, out_stride, out_sstride, stream=None):
+        self._check(self.lib.lvm_preprocess_device(self.h, C.byref(cpre), d_in, w, h, ch, in_stride, in_sstride, d_out, out_stride,
+                                                   out_sstride, stream))
+
+    def chain_process(self, frame, cpre, cparams):
+        """Preprocess -> Grayscale -> Magnification on a host frame (lvm_chain_process).  Returns (out, produced);
+        `out` is the magnified frame, or the preprocessed frame on passthrough."""
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        h, w = frame.shape[:2]
+        ch = 1 if frame.ndim == 2 else frame.shape[2]
+        _, _, _, _, ow, oh, och = self.preprocess_geometry(cpre, w, h, ch)
+        out = np.empty((oh, ow) if och == 1 else (oh, ow, och), dtype=np.uint8)
+        produced = C.c_int(0)
+        self._check(self.lib.lvm_chain_process(self.h, C.byref(cpre), C.byref(cparams), frame.ctypes.data, w, h, ch, w * ch,
+                                               out.ctypes.data, ow * och, C.byref(produced)))
+        return out, bool(produced.value)
 
     def process(self, frame, cparams):
         frame = np.ascontiguousarray(frame, dtype=np.uint8)
@@ -264,6 +307,26 @@ class MagnificationProcessor:
     def process_ex(self, frame, cfg):
         cp = to_c_params(cfg.magnification, cfg.preprocess.key())
         return self.ctx.process(frame, cp)
+
+    def reset(self):
+        self.ctx.reset()
+
+
+class ProcessingChain:
+    """Mirror of runChainOnce (processing/ChainBuilder.cpp:19-29) for the three per-frame stages
+    PreprocessProcessor -> GrayscaleProcessor -> MagnificationProcessor, all on the device: process(frame, cfg)
+    returns what the reference chain hands to the display (the magnified frame, or the preprocessed frame
+    when the magnifier passes its input through)."""
+
+    def __init__(self, device=0, lib=None):
+        self.ctx = Context(device, 1, lib)
+
+    def process(self, frame, cfg):
+        out, _ = self.process_ex(frame, cfg)
+        return out
+
+    def process_ex(self, frame, cfg):
+        return self.ctx.chain_process(frame, to_c_preprocess(cfg.preprocess, cfg.grayscale), to_c_params(cfg.magnification, 0))
 
     def reset(self):
         self.ctx.reset()

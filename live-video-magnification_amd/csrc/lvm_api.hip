@@ -102,6 +102,9 @@ static void tracker_disable(Ctx* c) { c->t_mode = LVM_MODE_NONE; c->t_levels = -
 static int ensure_float(Ctx* c, size_t count) {
     if (count > c->float_cap) {
         if (c->d_float) (void)hipFree(c->d_float);
+    lvm::preprocess_release(c);
+    if (c->d_pre_in) (void)hipFree(c->d_pre_in);
+    if (c->d_pre_out) (void)hipFree(c->d_pre_out);
         c->d_float = nullptr; c->float_cap = 0;
         LVM_HIP_TRY(c, hipMalloc((void**)&c->d_float, count * sizeof(float)));
         c->float_cap = count;
@@ -257,6 +260,96 @@ int lvm_process_device_frames(lvm_ctx* c, const lvm_params* p, int n_frames, con
         if (rc != LVM_OK) return rc;
         ++f;
     }
+    return LVM_OK;
+}
+
+
+int lvm_preprocess_geometry(const lvm_preprocess_params* pp, int w, int h, int channels, int* rx, int* ry, int* rw, int* rh,
+                            int* ow, int* oh, int* och) {
+    if (!pp || w <= 0 || h <= 0 || (channels != 1 && channels != 3)) return LVM_ERR_INVALID;
+    int v[7];
+    lvm::preprocess_geometry(*pp, w, h, channels, &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]);
+    int* dst[7] = {rx, ry, rw, rh, ow, oh, och};
+    for (int i = 0; i < 7; ++i) if (dst[i]) *dst[i] = v[i];
+    return LVM_OK;
+}
+
+int lvm_preprocess_device(lvm_ctx* c, const lvm_preprocess_params* pp, const uint8_t* d_in, int w, int h, int channels,
+                          ptrdiff_t in_stride, ptrdiff_t in_stream_stride, uint8_t* d_out, ptrdiff_t out_stride,
+                          ptrdiff_t out_stream_stride, void* hip_stream) {
+    if (!c || !pp) return LVM_ERR_INVALID;
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return lvm::preprocess_device(c, *pp, d_in, w, h, channels, in_stride, in_stream_stride, d_out, out_stride, out_stream_stride, s);
+}
+
+// FNV-1a over the PreprocessParams fields the reference compares (IProcessor.hpp:36-39)
+static uint64_t preprocess_key_of(const lvm_preprocess_params& pp) {
+    uint64_t k = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { k ^= b[i]; k *= 1099511628211ull; } };
+    const int32_t en = pp.roi_enabled ? 1 : 0;
+    mix(&pp.downscale, 4); mix(&en, 4); mix(&pp.roiX, 4); mix(&pp.roiY, 4); mix(&pp.roiW, 4); mix(&pp.roiH, 4);
+    return k;
+}
+
+int lvm_chain_process(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, const uint8_t* in, int w, int h, int channels,
+                      ptrdiff_t in_stride, uint8_t* out, ptrdiff_t out_stride, int* produced) {
+    if (!c || !pp || !p || !produced) return LVM_ERR_INVALID;
+    *produced = 0;
+    if (c->nstreams != 1) { c->err = "lvm_chain_process needs a 1-stream context"; return LVM_ERR_INVALID; }
+    if (!in || !out || w <= 0 || h <= 0 || (channels != 1 && channels != 3) || in_stride < (ptrdiff_t)w * channels) {
+        c->err = "bad frame arguments"; return LVM_ERR_INVALID;
+    }
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    int rx, ry, rw, rh, ow, oh, och;
+    lvm::preprocess_geometry(*pp, w, h, channels, &rx, &ry, &rw, &rh, &ow, &oh, &och);
+    if (out_stride < (ptrdiff_t)ow * och) { c->err = "output stride too small"; return LVM_ERR_INVALID; }
+    const size_t roi_row = (size_t)rw * channels, roi_bytes = roi_row * rh;
+    const size_t out_row = (size_t)ow * och, out_bytes = out_row * oh;
+    auto reserve = [&](uint8_t*& ptr, size_t& cap, size_t need) -> int {
+        if (need <= cap) return LVM_OK;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; cap = 0;
+        LVM_HIP_TRY(c, hipMalloc((void**)&ptr, need));
+        cap = need;
+        return LVM_OK;
+    };
+    hipStream_t s = c->own_stream;
+    int rc = reserve(c->d_pre_in, c->pre_in_cap, roi_bytes); if (rc != LVM_OK) return rc;
+    rc = reserve(c->d_pre_out, c->pre_out_cap, out_bytes); if (rc != LVM_OK) return rc;
+    if (out_bytes > c->stage_cap) {           // magnifier output staging (shared with lvm_process)
+        LVM_HIP_TRY(c, hipStreamSynchronize(s));
+        if (c->d_in) (void)hipFree(c->d_in);
+        if (c->d_out) (void)hipFree(c->d_out);
+        c->d_in = c->d_out = nullptr; c->stage_cap = 0;
+        LVM_HIP_TRY(c, hipMalloc((void**)&c->d_in, out_bytes));
+        LVM_HIP_TRY(c, hipMalloc((void**)&c->d_out, out_bytes));
+        c->stage_cap = out_bytes;
+    }
+    // only the ROI rows cross PCIe (the crop is the pitch of the 2-D copy)
+    LVM_HIP_TRY(c, hipMemcpy2DAsync(c->d_pre_in, roi_row, in + (size_t)ry * in_stride + (size_t)rx * channels, (size_t)in_stride, roi_row,
+                                    (size_t)rh, hipMemcpyHostToDevice, s));
+    const uint8_t* mag_in = c->d_pre_in;
+    const bool identity = ow == rw && oh == rh && och == channels;      // PreprocessProcessor.cpp:15, GrayscaleProcessor.cpp:8-9
+    if (!identity) {
+        lvm_preprocess_params q = *pp;
+        q.roi_enabled = 0;                                               // already cropped by the copy
+        // (the decimated size must be the one of the clamped ROI: same arithmetic on rw x rh)
+        rc = lvm::preprocess_device(c, q, c->d_pre_in, rw, rh, channels, (ptrdiff_t)roi_row, (ptrdiff_t)roi_bytes, c->d_pre_out,
+                                    (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, s);
+        if (rc != LVM_OK) { (void)hipStreamSynchronize(s); return rc; }
+        mag_in = c->d_pre_out;
+    }
+    lvm_params mp = *p;
+    mp.preprocess_key = preprocess_key_of(*pp);
+    lvm::FrameIO io{mag_in, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, c->d_out, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, ow, oh, och};
+    const int saved_depth = c->pipeline_depth;
+    c->pipeline_depth = 0;
+    rc = lvm::process_device(c, &mp, io, s, produced);
+    c->pipeline_depth = saved_depth;
+    if (rc != LVM_OK) { (void)hipStreamSynchronize(s); return rc; }
+    LVM_HIP_TRY(c, hipMemcpy2DAsync(out, (size_t)out_stride, *produced ? c->d_out : mag_in, out_row, out_row, (size_t)oh, hipMemcpyDeviceToHost, s));
+    LVM_HIP_TRY(c, hipStreamSynchronize(s));
     return LVM_OK;
 }
 

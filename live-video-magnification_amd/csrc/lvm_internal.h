@@ -260,6 +260,9 @@ struct Ctx {
     hipStream_t aux_stream = nullptr; // second stream of the cross-frame pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool exact_lab = false;   // debug: OpenCV-order Lab arithmetic everywhere (bit-faithful to the oracle)
+    // preprocess stage (preprocess.hip): area tables of the current geometry, staging of the host chain
+    void* pre_tables = nullptr;
+    uint8_t *d_pre_in = nullptr, *d_pre_out = nullptr; size_t pre_in_cap = 0, pre_out_cap = 0;
 };
 
 void prof_begin(Ctx* c, const char* name, hipStream_t s);
@@ -284,6 +287,13 @@ void prof_end(Ctx* c, hipStream_t s);
     } while (0)
 
 
+
+// preprocess.hip
+void preprocess_geometry(const lvm_preprocess_params& pp, int w, int h, int channels, int* rx, int* ry, int* rw, int* rh,
+                         int* ow, int* oh, int* och);
+int preprocess_device(Ctx* c, const lvm_preprocess_params& pp, const uint8_t* d_in, int w, int h, int channels, ptrdiff_t in_stride,
+                      ptrdiff_t in_sstride, uint8_t* d_out, ptrdiff_t out_stride, ptrdiff_t out_sstride, hipStream_t s);
+void preprocess_release(Ctx* c);
 
 // mode entry points (laplace.hip / riesz.hip / color.hip).  Return LVM_OK or an error;
 // *produced follows the reference's passthrough rules.

@@ -85,6 +85,22 @@ public:
         return produced != 0;
     }
 
+    // Preprocess -> Grayscale -> Magnification on a host frame (runChainOnce, processing/ChainBuilder.cpp:19-29).
+    // `out` must hold the geometry chain_geometry() reports; it receives the magnified frame, or the
+    // preprocessed frame when the magnifier passes its input through (return value false).
+    bool chain_process(const lvm_preprocess_params& pre, const MagnificationParams& p, const std::uint8_t* in, int w, int h,
+                       int channels, std::ptrdiff_t in_stride, std::uint8_t* out, std::ptrdiff_t out_stride) {
+        const lvm_params c = to_c(p, 0);
+        int produced = 0;
+        check(lvm_chain_process(ctx_, &pre, &c, in, w, h, channels, in_stride, out, out_stride, &produced));
+        return produced != 0;
+    }
+    // size and channel count of the frame the chain emits for a w x h x channels input
+    static void chain_geometry(const lvm_preprocess_params& pre, int w, int h, int channels, int* ow, int* oh, int* och) {
+        if (lvm_preprocess_geometry(&pre, w, h, channels, nullptr, nullptr, nullptr, nullptr, ow, oh, och) != LVM_OK)
+            throw Error(LVM_ERR_INVALID, "lvm_preprocess_geometry: invalid arguments");
+    }
+
     void synchronize() { check(lvm_synchronize(ctx_)); }
     lvm_ctx* handle() const { return ctx_; }
 

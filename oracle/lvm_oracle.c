@@ -1167,3 +1167,137 @@ int lvmo_process(lvmo_ctx* c, const lvmo_params* p, const uint8_t* in, int w, in
     *produced = ok;
     return 0;
 }
+
+/* =====================================================================================================
+ * Preprocess + Grayscale (the stages in front of the magnifier).
+ * PARITY UNPINNED like the rest of the OpenCV boundary: cv::resize(INTER_AREA) and cvtColor(BGR2GRAY) are
+ * restated from OpenCV 4.x (imgproc/src/resize.cpp resizeAreaFast_ / resizeArea_, color_rgb.simd.hpp
+ * RGB2Gray<uchar>); the reference holds no fixture for them.
+ * ===================================================================================================== */
+static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+/* PreprocessProcessor.cpp:13-31 and :36-39; GrayscaleProcessor.cpp:8-9 */
+void lvmo_preprocess_geometry(const lvmo_pre_params* pp, int w, int h, int channels, int* rx, int* ry,
+                              int* rw, int* rh, int* ow, int* oh, int* och) {
+    const int divisor = clampi(pp->downscale, 1, 8);
+    int x = 0, y = 0, cw = w, chh = h;
+    if (pp->roi_enabled) {
+        x = (int)lround((double)pp->roiX * w);
+        y = (int)lround((double)pp->roiY * h);
+        cw = (int)lround((double)pp->roiW * w);
+        chh = (int)lround((double)pp->roiH * h);
+        x = clampi(x, 0, w - 1);
+        y = clampi(y, 0, h - 1);
+        cw = clampi(cw, 1, w - x);
+        chh = clampi(chh, 1, h - y);
+    }
+    *rx = x; *ry = y; *rw = cw; *rh = chh;
+    if (divisor > 1) {
+        *ow = cw / divisor > 1 ? cw / divisor : 1;
+        *oh = chh / divisor > 1 ? chh / divisor : 1;
+    } else { *ow = cw; *oh = chh; }
+    *och = (pp->grayscale && channels != 1) ? 1 : channels;
+}
+
+/* computeResizeAreaTab (resize.cpp): source cells [dx*scale, (dx+1)*scale) with fractional end weights */
+int lvmo_area_table(int ssize, int dsize, double scale, lvmo_area_tab* tab, int cap) {
+    int k = 0;
+    for (int dx = 0; dx < dsize; dx++) {
+        const double fsx1 = dx * scale;
+        const double fsx2 = fsx1 + scale;
+        const double cellWidth = scale < ssize - fsx1 ? scale : ssize - fsx1;
+        int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+        sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+        sx1 = sx1 < sx2 ? sx1 : sx2;
+        if (sx1 - fsx1 > 1e-3) {
+            if (k < cap) { tab[k].di = dx; tab[k].si = sx1 - 1; tab[k].alpha = (float)((sx1 - fsx1) / cellWidth); }
+            k++;
+        }
+        for (int sx = sx1; sx < sx2; sx++) {
+            if (k < cap) { tab[k].di = dx; tab[k].si = sx; tab[k].alpha = (float)(1.0 / cellWidth); }
+            k++;
+        }
+        if (fsx2 - sx2 > 1e-3) {
+            double a = fsx2 - sx2; a = a < 1.0 ? a : 1.0; a = a < cellWidth ? a : cellWidth;
+            if (k < cap) { tab[k].di = dx; tab[k].si = sx2; tab[k].alpha = (float)(a / cellWidth); }
+            k++;
+        }
+    }
+    return k;
+}
+
+static uint8_t sat_u8f(float v) {              /* saturate_cast<uchar>(float) = cvRound, round-half-even */
+    const long r = lrintf(v);
+    return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+}
+
+void lvmo_resize_area_u8(const uint8_t* src, int w, int h, int cn, ptrdiff_t stride, uint8_t* dst, int dw, int dh) {
+    const double scale_x = (double)w / dw, scale_y = (double)h / dh;
+    const int iscale_x = (int)lrint(scale_x), iscale_y = (int)lrint(scale_y);       /* saturate_cast<int>(double) */
+    const int fast = fabs(scale_x - iscale_x) < 2.220446049250313e-16 && fabs(scale_y - iscale_y) < 2.220446049250313e-16;
+    if (fast) {
+        /* resizeAreaFast_: integer sum of the iscale_x x iscale_y block; 2x2 takes the (sum + 2) >> 2 shortcut
+         * of ResizeAreaFastVec, everything else saturate_cast<uchar>(sum * (1.f / area)) */
+        const int area = iscale_x * iscale_y;
+        const float scale = 1.f / area;
+        const int fast2 = iscale_x == 2 && iscale_y == 2;
+        for (int dy = 0; dy < dh; dy++)
+            for (int dx = 0; dx < dw; dx++)
+                for (int c = 0; c < cn; c++) {
+                    int sum = 0;
+                    for (int sy = 0; sy < iscale_y; sy++)
+                        for (int sx = 0; sx < iscale_x; sx++)
+                            sum += src[(size_t)(dy * iscale_y + sy) * stride + (size_t)(dx * iscale_x + sx) * cn + c];
+                    dst[((size_t)dy * dw + dx) * cn + c] = fast2 ? (uint8_t)((sum + 2) >> 2) : sat_u8f((float)sum * scale);
+                }
+        return;
+    }
+    /* resizeArea_<uchar, float>: per source row a horizontal weighted sum (table order), rows accumulated
+     * with their vertical weights; an output row is emitted when the table moves on to the next one */
+    lvmo_area_tab* xtab = (lvmo_area_tab*)malloc(sizeof(lvmo_area_tab) * (size_t)(w * 2 + 2));
+    lvmo_area_tab* ytab = (lvmo_area_tab*)malloc(sizeof(lvmo_area_tab) * (size_t)(h * 2 + 2));
+    const int xn = lvmo_area_table(w, dw, scale_x, xtab, w * 2 + 2);
+    const int yn = lvmo_area_table(h, dh, scale_y, ytab, h * 2 + 2);
+    float* buf = (float*)malloc(sizeof(float) * (size_t)dw * cn);
+    float* sum = (float*)malloc(sizeof(float) * (size_t)dw * cn);
+    int prev_dy = ytab[0].di;
+    for (int i = 0; i < dw * cn; i++) sum[i] = 0.f;
+    for (int j = 0; j < yn; j++) {
+        const float beta = ytab[j].alpha;
+        const int dy = ytab[j].di, sy = ytab[j].si;
+        const uint8_t* S = src + (size_t)sy * stride;
+        for (int i = 0; i < dw * cn; i++) buf[i] = 0.f;
+        for (int k = 0; k < xn; k++) {
+            const float alpha = xtab[k].alpha;
+            for (int c = 0; c < cn; c++) buf[xtab[k].di * cn + c] += S[xtab[k].si * cn + c] * alpha;
+        }
+        if (dy != prev_dy) {
+            for (int i = 0; i < dw * cn; i++) { dst[(size_t)prev_dy * dw * cn + i] = sat_u8f(sum[i]); sum[i] = beta * buf[i]; }
+            prev_dy = dy;
+        } else {
+            for (int i = 0; i < dw * cn; i++) sum[i] += beta * buf[i];
+        }
+    }
+    for (int i = 0; i < dw * cn; i++) dst[(size_t)prev_dy * dw * cn + i] = sat_u8f(sum[i]);
+    free(xtab); free(ytab); free(buf); free(sum);
+}
+
+/* RGB2Gray<uchar> (OpenCV 4.x): 15-bit fixed point, BY15 = 3735, GY15 = 19235, RY15 = 9798 */
+void lvmo_bgr2gray_u8(const uint8_t* src, int npix, uint8_t* dst) {
+    for (int i = 0; i < npix; i++)
+        dst[i] = (uint8_t)((src[3 * i] * 3735 + src[3 * i + 1] * 19235 + src[3 * i + 2] * 9798 + (1 << 14)) >> 15);
+}
+
+void lvmo_preprocess(const lvmo_pre_params* pp, const uint8_t* in, int w, int h, int channels,
+                     ptrdiff_t in_stride, uint8_t* out) {
+    int rx, ry, rw, rh, ow, oh, och;
+    lvmo_preprocess_geometry(pp, w, h, channels, &rx, &ry, &rw, &rh, &ow, &oh, &och);
+    const int divisor = clampi(pp->downscale, 1, 8);
+    const uint8_t* crop = in + (size_t)ry * in_stride + (size_t)rx * channels;
+    uint8_t* tmp = (uint8_t*)malloc((size_t)ow * oh * channels);
+    if (divisor > 1) lvmo_resize_area_u8(crop, rw, rh, channels, in_stride, tmp, ow, oh);          /* PreprocessProcessor.cpp:36-40 */
+    else for (int y = 0; y < oh; y++) memcpy(tmp + (size_t)y * ow * channels, crop + (size_t)y * in_stride, (size_t)ow * channels);   /* :42 */
+    if (och != channels) lvmo_bgr2gray_u8(tmp, ow * oh, out);                                       /* GrayscaleProcessor.cpp:13 */
+    else memcpy(out, tmp, (size_t)ow * oh * channels);
+    free(tmp);
+}

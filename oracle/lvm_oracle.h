@@ -76,6 +76,30 @@ void lvmo_riesz_kernels(float lp[81], float hp[81]);                  /* RieszPy
 float lvmo_cube_root(float v);
 const float* lvmo_gamma_tab(int inverse);  /* 1024*4 spline coefficients */
 
+/* ---- the two stages in front of the magnifier --------------------------------
+ * PreprocessProcessor::process (processing/PreprocessProcessor.cpp:10-51): ROI crop in normalised
+ * coordinates + cv::resize(INTER_AREA) by 1/2/4/8, and GrayscaleProcessor::process
+ * (processing/GrayscaleProcessor.cpp:7-16): cv::cvtColor(BGR2GRAY) on the uint8 frame.            */
+typedef struct lvmo_pre_params {
+    int32_t downscale;      /* clamped to [1, 8] like PreprocessProcessor.cpp:14 */
+    int32_t roi_enabled;
+    float   roiX, roiY, roiW, roiH;
+    int32_t grayscale;      /* ProcessorConfig::grayscale */
+} lvmo_pre_params;
+/* geometry of the stage output: ROI rectangle inside the source and the output size/channels */
+void lvmo_preprocess_geometry(const lvmo_pre_params* pp, int w, int h, int channels, int* rx, int* ry,
+                              int* rw, int* rh, int* ow, int* oh, int* och);
+/* out: ow*oh*och bytes, contiguous rows */
+void lvmo_preprocess(const lvmo_pre_params* pp, const uint8_t* in, int w, int h, int channels,
+                     ptrdiff_t in_stride, uint8_t* out);
+/* cv::resize(INTER_AREA) on uint8, scale >= 1 in both directions (fast integer path or the general
+ * area tables), and the fixed-point BGR2GRAY */
+void lvmo_resize_area_u8(const uint8_t* src, int w, int h, int cn, ptrdiff_t stride, uint8_t* dst, int dw, int dh);
+void lvmo_bgr2gray_u8(const uint8_t* src, int npix, uint8_t* dst);
+/* the decimation table of the general path: returns the number of entries written (<= cap) */
+typedef struct lvmo_area_tab { int si, di; float alpha; } lvmo_area_tab;
+int  lvmo_area_table(int ssize, int dsize, double scale, lvmo_area_tab* tab, int cap);
+
 #ifdef __cplusplus
 }
 #endif

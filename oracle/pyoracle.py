@@ -37,6 +37,12 @@ _u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 
 
+class PreParams(C.Structure):
+    """lvmo_pre_params: PreprocessParams (IProcessor.hpp:26-35) + ProcessorConfig::grayscale."""
+    _fields_ = [("downscale", C.c_int32), ("roi_enabled", C.c_int32), ("roiX", C.c_float), ("roiY", C.c_float),
+                ("roiW", C.c_float), ("roiH", C.c_float), ("grayscale", C.c_int32)]
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -73,6 +79,15 @@ def lib():
         L.lvmo_cube_root.restype = C.c_float
         L.lvmo_gamma_tab.argtypes = [C.c_int]
         L.lvmo_gamma_tab.restype = C.POINTER(C.c_float)
+        ip = C.POINTER(C.c_int)
+        L.lvmo_preprocess_geometry.argtypes = [C.POINTER(PreParams), C.c_int, C.c_int, C.c_int, ip, ip, ip, ip, ip, ip, ip]
+        L.lvmo_preprocess_geometry.restype = None
+        L.lvmo_preprocess.argtypes = [C.POINTER(PreParams), _u8p, C.c_int, C.c_int, C.c_int, C.c_ssize_t, _u8p]
+        L.lvmo_preprocess.restype = None
+        L.lvmo_resize_area_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_ssize_t, _u8p, C.c_int, C.c_int]
+        L.lvmo_resize_area_u8.restype = None
+        L.lvmo_bgr2gray_u8.argtypes = [_u8p, C.c_int, _u8p]
+        L.lvmo_bgr2gray_u8.restype = None
         # a few threads only: on many-core hosts OpenMP fork/join over tiny pyramid levels dominates
         L.lvmo_set_threads(max(1, min(8, os.cpu_count() or 1)))
         _lib = L
@@ -267,3 +282,41 @@ def riesz_kernels():
 def gamma_tab(inverse=False):
     p = lib().lvmo_gamma_tab(int(inverse))
     return np.ctypeslib.as_array(p, shape=(4096,)).copy()
+
+
+def make_pre_params(downscale=1, roiEnabled=False, roiX=0.0, roiY=0.0, roiW=1.0, roiH=1.0, grayscale=False):
+    return PreParams(int(downscale), 1 if roiEnabled else 0, roiX, roiY, roiW, roiH, 1 if grayscale else 0)
+
+
+def preprocess_geometry(pp, w, h, ch):
+    v = [C.c_int() for _ in range(7)]
+    lib().lvmo_preprocess_geometry(C.byref(pp), w, h, ch, *[C.byref(x) for x in v])
+    return tuple(x.value for x in v)
+
+
+def preprocess(frame, pp):
+    """PreprocessProcessor + GrayscaleProcessor of the reference on a uint8 frame."""
+    frame = np.ascontiguousarray(frame, dtype=np.uint8)
+    h, w = frame.shape[:2]
+    ch = 1 if frame.ndim == 2 else frame.shape[2]
+    _, _, _, _, ow, oh, och = preprocess_geometry(pp, w, h, ch)
+    out = np.empty((oh, ow) if och == 1 else (oh, ow, och), dtype=np.uint8)
+    lib().lvmo_preprocess(C.byref(pp), frame, w, h, ch, w * ch, out)
+    return out
+
+
+def resize_area_u8(a, dsize):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    h, w = a.shape[:2]
+    cn = 1 if a.ndim == 2 else a.shape[2]
+    dw, dh = dsize
+    out = np.empty((dh, dw) if cn == 1 else (dh, dw, cn), dtype=np.uint8)
+    lib().lvmo_resize_area_u8(a, w, h, cn, w * cn, out, dw, dh)
+    return out
+
+
+def bgr2gray_u8(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    out = np.empty(a.shape[:2], dtype=np.uint8)
+    lib().lvmo_bgr2gray_u8(a, a.shape[0] * a.shape[1], out)
+    return out

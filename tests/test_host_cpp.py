@@ -20,6 +20,13 @@ int main() {
         bool produced = m.process(p, 0, in.data(), 64, 48, 3, 64 * 3, out.data(), 64 * 3);
         std::printf("produced=%d first=%d\n", (int)produced, (int)out[0]);
         m.reset();
+        // the three-stage chain: 2x decimation + gray in front of the magnifier
+        lvm_preprocess_params pre{}; pre.downscale = 2; pre.roiW = pre.roiH = 1.f; pre.grayscale = 1;
+        int ow = 0, oh = 0, och = 0;
+        lvm::Magnifier::chain_geometry(pre, 64, 48, 3, &ow, &oh, &och);
+        std::vector<unsigned char> small((size_t)ow * oh * och);
+        produced = m.chain_process(pre, p, in.data(), 64, 48, 3, 64 * 3, small.data(), ow * och);
+        std::printf("chain %dx%dx%d produced=%d first=%d\n", ow, oh, och, (int)produced, (int)small[0]);
     } catch (const lvm::Error& e) { std::printf("lvm::Error %d: %s\n", e.status(), e.what()); return 3; }
     return 0;
 }
@@ -36,6 +43,6 @@ def test_cpp_wrapper_compiles_links_and_fails_loudly_without_gpu(tmp_path):
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     import torch
     if torch.cuda.is_available():
-        assert r.returncode == 0 and "produced=1" in r.stdout, r.stdout + r.stderr
+        assert r.returncode == 0 and "produced=1" in r.stdout and "chain 32x24x1 produced=1 first=90" in r.stdout, r.stdout + r.stderr
     else:
         assert r.returncode == 3 and "lvm::Error -3" in r.stdout, r.stdout + r.stderr
