@@ -69,7 +69,10 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, streams, T=0):
             # band 4 + prior(3) R/W 24 + phase(2) R/W 16 + registers(8) R/W 64 + amp,tc,ts 12
             "rz_phase": sum(120 * S * n[l] for l in range(nb)),          # one launch covers every band level
             "rz_seed": sum((4 + 13 * 4) * S * n[l] for l in range(nb)),
-            "rz_blur_amp": sum(28 * S * n[l] for l in range(nb)),
+            # the register-blocked kernel serves the levels with w % 4 == 0, w >= 128, h >= 64 (riesz.hip)
+            "rz_blur_amp": sum(28 * S * n[l] for l in range(nb) if sizes[l][0] % 4 == 0 and sizes[l][0] >= 128 and sizes[l][1] >= 64),
+            "rz_blur_amp_small": sum(28 * S * n[l] for l in range(nb)
+                                     if not (sizes[l][0] % 4 == 0 and sizes[l][0] >= 128 and sizes[l][1] >= 64)),
             "rz_collapse": avg([4 * S * (2 * n[l] + n[l + 1]) for l in range(1, nb)]),
             "rz_final": S * (6 * n[0] + 4 * n[0] + 4 * n[1]),
         }.get(name)

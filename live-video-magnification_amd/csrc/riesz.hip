@@ -156,19 +156,28 @@ __global__ __launch_bounds__(256) void k_rz_split(const float* __restrict__ oct,
             }
         }
     }
-    if (threadIdx.x < 64) {   // 2 x low-pass at even pixels only: 32 x 8 per tile, 4 per thread
-        const int v = threadIdx.x >> 3, q = threadIdx.x & 7;
-        const int y = 2 * v, x = 8 * q;
+    {   // 2 x low-pass at even pixels only: 32 x 8 per tile, ONE per thread so that all four waves share the
+        // work (the 9 floats of a kernel row start at an even column: five aligned 64-bit LDS reads)
+        const int v = threadIdx.x >> 5, q = threadIdx.x & 31;
+        const int y = 2 * v, x = 2 * q;
         const int gx = x0 + x, gy = y0 + y;
         if (gx < w && gy < h) {
-            float o[4];
-            conv9x4s2(s, x, y, kLp9, 2.0f, o);                                        // :232-234
-            float* d = next + ((size_t)blockIdx.z * nh + gy / 2) * nw + gx / 2;
-            if ((nw & 3) == 0 && gx + 6 < w) *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
-            else {
+            float acc = 0.f;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) if (gx + 2 * m < w) d[m] = o[m];
+            for (int i = 0; i < 9; ++i) {
+                const float2 a = *reinterpret_cast<const float2*>(&s[y + i][x]);
+                const float2 b = *reinterpret_cast<const float2*>(&s[y + i][x + 2]);
+                const float2 c = *reinterpret_cast<const float2*>(&s[y + i][x + 4]);
+                const float2 d = *reinterpret_cast<const float2*>(&s[y + i][x + 6]);
+                const float e = s[y + i][x + 8];
+                const float t[9] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y, e};
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const float kv = kLp9[i * 9 + j] * 2.0f;                           // x2 is exact
+                    if (kv != 0.f) acc = __builtin_fmaf(kv, t[j], acc);               // :232-234, row-major like conv9
+                }
             }
+            next[((size_t)blockIdx.z * nh + gy / 2) * nw + gx / 2] = acc;
         }
     }
 }
@@ -320,8 +329,41 @@ struct BlurArgs {                      // all band levels in one launch (indepen
     int nlv;
     float g[13];
     float alpha, thr;
+    int exact;                         // 1: libm-order amplify (cosf/sinf, IEEE divisions); 0: hardware sin/cos and reciprocals
 };
 
+// RieszPyramidLevel::amplify for one pixel (RieszPyramid.cpp:125-143) given the three blurred values.
+// EXACT: the reference's operations (IEEE divisions, sqrtf, cosf/sinf) -- what the oracle computes.
+// Otherwise: reciprocals and the hardware sine/cosine (v_sin_f32 / v_cos_f32 take revolutions; the angle is
+// in [0, pi], absolute error ~1e-6): the phase-shifted band moves by ~1e-6 of its amplitude, and nothing
+// downstream feeds back into the temporal state.  The precise sinf/cosf pair alone is ~200 instructions
+// per pixel, more than the three 13-tap Gaussians together.
+template <bool EXACT>
+__device__ __forceinline__ float rz_amplify(float v0, float v1, float v2, float r1, float r2, float band, float alpha, float thr) {
+    if (EXACT) {
+        const float c = v1 / v0, sn = v2 / v0;                         // :125-126
+        const float magV = sqrtf(c * c + sn * sn);                     // :133-134
+        float magV2 = magV * alpha;                                     // :135
+        magV2 = magV2 > thr ? thr : magV2;                               // :136 THRESH_TRUNC
+        const float cp = cosf(magV2), sp = sinf(magV2);                // :138
+        float pair = (r1 * c + r2 * sn) / magV;                        // :139-140
+        if (pair != pair) pair = 0.f;                                  // :141
+        return band * cp - pair * sp;                                  // :143
+    }
+    const float iv = __builtin_amdgcn_rcpf(v0);
+    const float c = v1 * iv, sn = v2 * iv;
+    const float m2 = c * c + sn * sn;
+    const float magV = __builtin_amdgcn_sqrtf(m2);
+    float magV2 = magV * alpha;
+    magV2 = magV2 > thr ? thr : magV2;
+    const float rev = magV2 * 0.15915494309189535f;
+    const float cp = __builtin_amdgcn_cosf(rev), sp = __builtin_amdgcn_sinf(rev);
+    float pair = (r1 * c + r2 * sn) * __builtin_amdgcn_rcpf(magV);
+    if (pair != pair) pair = 0.f;
+    return band * cp - pair * sp;
+}
+
+template <bool EXACT>
 __global__ __launch_bounds__(256) void k_rz_blur_amp(BlurArgs aa) {
     __shared__ float s[3][BSH][BS + 1];
     __shared__ float hr[3][BSH][BT + 1];
@@ -361,14 +403,104 @@ __global__ __launch_bounds__(256) void k_rz_blur_amp(BlurArgs aa) {
             v[f] = acc;
         }
         const size_t idx = pl + (size_t)gy * a.w + gx;
-        const float c = v[1] / v[0], sn = v[2] / v[0];                 // :125-126
-        const float magV = sqrtf(c * c + sn * sn);                     // :133-134
-        float magV2 = magV * aa.alpha;                                  // :135
-        magV2 = magV2 > aa.thr ? aa.thr : magV2;                         // :136 THRESH_TRUNC
-        const float cp = cosf(magV2), sp = sinf(magV2);                // :138
-        float pair = (a.R1[idx] * c + a.R2[idx] * sn) / magV;          // :139-140
-        if (pair != pair) pair = 0.f;                                  // :141
-        a.bandA[idx] = a.band[idx] * cp - pair * sp;                   // :143
+        a.bandA[idx] = rz_amplify<EXACT>(v[0], v[1], v[2], a.R1[idx], a.R2[idx], a.band[idx], aa.alpha, aa.thr);
+    }
+}
+
+// Register-blocked variant for levels whose width is a multiple of 4 (the large ones).  Tile 64 x 32,
+// staged with an 8-column / 6-row halo so that interior tiles load 128-bit vectors.  Row pass: a work item
+// is four adjacent outputs of one staged row, their 16 source values come from eight 64-bit LDS reads
+// (208 bytes of LDS traffic per four outputs become 64).  Column pass + amplify: a thread owns a 4 x 2
+// pixel block for all three planes, 14 128-bit reads per plane.  Every output keeps its own accumulator
+// and receives its taps in the order of the scalar kernel, so both kernels give identical bits.
+constexpr int B2W = 64, B2H = 32, B2HX = 8, B2HY = 6, B2SW = B2W + 2 * B2HX, B2SH = B2H + 2 * B2HY;
+template <bool EXACT>
+__global__ __launch_bounds__(256) void k_rz_blur_amp4(BlurArgs aa) {
+    __shared__ __attribute__((aligned(16))) float s[3][B2SH][B2SW];
+    __shared__ __attribute__((aligned(16))) float hr[3][B2SH][B2W];
+    int lvl = 0;
+    while (lvl + 1 < aa.nlv && (int)blockIdx.x >= aa.lv[lvl + 1].block0) ++lvl;
+    const BlurLv& a = aa.lv[lvl];
+    const int t = blockIdx.x - a.block0;
+    const int bs = t / (a.tx * a.ty), tr = t - bs * (a.tx * a.ty);
+    const int x0 = (tr % a.tx) * B2W, y0 = (tr / a.tx) * B2H;
+    const size_t pl = (size_t)bs * a.w * a.h;
+    const float* src[3] = {a.amp + pl, a.tc + pl, a.ts + pl};
+    const bool interior = x0 - B2HX >= 0 && x0 + B2W + B2HX <= a.w && y0 - B2HY >= 0 && y0 + B2H + B2HY <= a.h;
+    if (interior) {
+        for (int i = threadIdx.x; i < 3 * B2SH * (B2SW / 4); i += 256) {
+            const int f = i / (B2SH * (B2SW / 4)), r = i - f * (B2SH * (B2SW / 4));
+            const int ly = r / (B2SW / 4), g = r - ly * (B2SW / 4);
+            *reinterpret_cast<float4*>(&s[f][ly][4 * g]) =
+                *reinterpret_cast<const float4*>(src[f] + (size_t)(y0 - B2HY + ly) * a.w + (x0 - B2HX + 4 * g));
+        }
+    } else {
+        for (int i = threadIdx.x; i < B2SH * B2SW; i += 256) {
+            const int ly = i / B2SW, lx = i - ly * B2SW;
+            const size_t si = (size_t)reflect101(y0 - B2HY + ly, a.h) * a.w + reflect101(x0 - B2HX + lx, a.w);
+            s[0][ly][lx] = src[0][si]; s[1][ly][lx] = src[1][si]; s[2][ly][lx] = src[2][si];
+        }
+    }
+    __syncthreads();
+    // RowFilter: acc = k0*S0; acc = fma(kj, Sj, acc), left to right.  Output column x reads staged columns
+    // x + 2 .. x + 14 (the staging halo is 8, the filter radius 6).
+    for (int i = threadIdx.x; i < 3 * B2SH * (B2W / 4); i += 256) {
+        const int f = i / (B2SH * (B2W / 4)), r = i - f * (B2SH * (B2W / 4));
+        const int ly = r / (B2W / 4), g = r - ly * (B2W / 4);
+        const float* row = &s[f][ly][4 * g + 2];
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const float2 p2 = *reinterpret_cast<const float2*>(row + 2 * q); v[2 * q] = p2.x; v[2 * q + 1] = p2.y; }
+        float o[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float acc = aa.g[0] * v[m];
+#pragma unroll
+            for (int j = 1; j < 13; ++j) acc = __builtin_fmaf(aa.g[j], v[m + j], acc);
+            o[m] = acc;
+        }
+        *reinterpret_cast<float4*>(&hr[f][ly][4 * g]) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+    const int gq = threadIdx.x & 15, yq = threadIdx.x >> 4;           // 16 column groups x 16 row pairs
+    const int x = 4 * gq, y = 2 * yq;
+    const int gx = x0 + x, gy = y0 + y;
+    if (gx >= a.w || gy >= a.h) return;
+    float bl[3][2][4];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {   // SymmColumnFilter: centre, then fma(kj, S[+j] + S[-j]); rows y .. y+13 serve both outputs
+        float4 rr[14];
+#pragma unroll
+        for (int q = 0; q < 14; ++q) rr[q] = *reinterpret_cast<const float4*>(&hr[f][y + q][x]);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) {
+            const float* ctr = &rr[d + 6].x;
+            float acc[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[m] = aa.g[6] * ctr[m];
+#pragma unroll
+            for (int j = 1; j <= 6; ++j) {
+                const float* up = &rr[d + 6 + j].x; const float* dn = &rr[d + 6 - j].x;
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[m] = __builtin_fmaf(aa.g[6 + j], up[m] + dn[m], acc[m]);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) bl[f][d][m] = acc[m];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        if (gy + d >= a.h) break;
+        const size_t idx = pl + (size_t)(gy + d) * a.w + gx;
+        const float4 r1 = *reinterpret_cast<const float4*>(a.R1 + idx), r2 = *reinterpret_cast<const float4*>(a.R2 + idx),
+                     bd = *reinterpret_cast<const float4*>(a.band + idx);
+        const float* R1 = &r1.x; const float* R2 = &r2.x; const float* Bd = &bd.x;
+        float o[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            o[m] = rz_amplify<EXACT>(bl[0][d][m], bl[1][d][m], bl[2][d][m], R1[m], R2[m], Bd[m], aa.alpha, aa.thr);
+        }
+        *reinterpret_cast<float4*>(a.bandA + idx) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -539,6 +671,7 @@ struct RieszState : ModeState {
     int tcap = 0; float* tarena = nullptr;
     float* ft[kMaxLevels + 1][F_ALL_N] = {}; float* oct_t[kMaxLevels + 1] = {}; float* res_t[kMaxLevels + 1] = {};   // per band level: band,P,R1p,R2p,phc,phs,lo0c,lo0s,lo1c,lo1s,hi0c,hi0s,hi1c,hi1s,amp,tc,ts,bandA
     bool inited = false;
+    bool blur4 = true;               // register-blocked Gaussian/amplify kernel on the large levels (LVM_RZ_BLUR4=0: scalar kernel everywhere)
     double lo_freq = 0, hi_freq = 0, fps = 0;
     double la[3] = {}, lb[3] = {}, ha[3] = {}, hb[3] = {};
     bool steady(const lvm_params& p) const override {
@@ -630,17 +763,21 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
         for (int i = 0; i < 13; ++i) a.g[i] = (float)(t[i] * sum);
         const double PI_PERCENT = 3.1415926535897932384626433832795 / 100.0;
         a.alpha = (float)p.amplification; a.thr = (float)(p.coWavelength * PI_PERCENT);
-        int blocks = 0;
+        // levels whose width is a multiple of 4 (and not tiny) take the register-blocked kernel, the rest the scalar one
+        BlurArgs a4 = a;
+        int blocks = 0, blocks4 = 0, n1 = 0, n4 = 0;
         for (int l = 0; l < nb; ++l) {
-            BlurLv& v = a.lv[l];
+            const bool big = st->blur4 && st->g[l].w % 4 == 0 && st->g[l].w >= 128 && st->g[l].h >= 64;
+            BlurLv& v = big ? a4.lv[n4++] : a.lv[n1++];
             float** q = B.pf[l];
             v.amp = q[F_AMP]; v.tc = q[F_TC]; v.ts = q[F_TS]; v.band = q[F_BAND]; v.R1 = q[F_R1C]; v.R2 = q[F_R2C]; v.bandA = q[F_BANDA];
             v.w = st->g[l].w; v.h = st->g[l].h;
-            v.tx = (v.w + BT - 1) / BT; v.ty = (v.h + BTH - 1) / BTH;
-            v.block0 = blocks;
-            blocks += v.tx * v.ty * NZ;
+            if (big) { v.tx = (v.w + B2W - 1) / B2W; v.ty = (v.h + B2H - 1) / B2H; v.block0 = blocks4; blocks4 += v.tx * v.ty * NZ; }
+            else { v.tx = (v.w + BT - 1) / BT; v.ty = (v.h + BTH - 1) / BTH; v.block0 = blocks; blocks += v.tx * v.ty * NZ; }
         }
-        LVM_LAUNCH(c, "rz_blur_amp", k_rz_blur_amp, dim3(blocks), blk, s, a);
+        a.nlv = n1; a4.nlv = n4;
+        if (n4) LVM_LAUNCH(c, "rz_blur_amp", c->exact_lab ? k_rz_blur_amp4<true> : k_rz_blur_amp4<false>, dim3(blocks4), blk, s, a4);
+        if (n1) LVM_LAUNCH(c, "rz_blur_amp_small", c->exact_lab ? k_rz_blur_amp<true> : k_rz_blur_amp<false>, dim3(blocks), blk, s, a);
     }
     const float* resn = B.oct[levels - 1];       // res_{L-1} = residual octave
     for (int l = nb - 1; l >= 1; --l) {
@@ -676,6 +813,7 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
     RieszState* st = static_cast<RieszState*>(c->state);
     if (!st) {
         st = new RieszState();
+        if (const char* e = std::getenv("LVM_RZ_BLUR4")) st->blur4 = std::atoi(e) != 0;
         c->state = st;
         const int rc = riesz_alloc(c, st, io.w, io.h, levels);
         if (rc != LVM_OK) return rc;

@@ -67,6 +67,10 @@ static inline unsigned __builtin_amdgcn_cvt_pk_u8_f32(float v, unsigned byte, un
     r = r < 0.f ? 0.f : (r > 255.f ? 255.f : r);
     return (old & ~(0xffu << (8 * byte))) | ((unsigned)r << (8 * byte));
 }
+static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
+static inline float __builtin_amdgcn_sinf(float rev) { return sinf(rev * 6.283185307179586f); }   // v_sin_f32: argument in revolutions
+static inline float __builtin_amdgcn_cosf(float rev) { return cosf(rev * 6.283185307179586f); }
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }   // only ever applied to wave-uniform values
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }

@@ -62,6 +62,15 @@ def test_riesz_emu_bit_exact(lvm, po, emu, w, h, levels):
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 6, 0.0, exact=True)
 
 
+@pytest.mark.parametrize("blur4", ["1", "0"])
+def test_riesz_emu_register_blocked_blur(lvm, po, emu, blur4, monkeypatch):
+    """k_rz_blur_amp4 (64 x 32 tiles, vector staging of interior tiles, 4 x 2 outputs per thread) against the
+    scalar kernel's arithmetic: a frame with interior, edge and partial tiles on two levels."""
+    monkeypatch.setenv("LVM_RZ_BLUR4", blur4)
+    ck, pk = lvm.synth.config(2, (264, 150, 3))
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0, exact=True)
+
+
 def test_riesz_emu_cutoff_change_gray_and_reset(lvm, po, emu):
     ck, pk = lvm.synth.config(2, (96, 64, 3))
 
