@@ -408,16 +408,18 @@ __global__ __launch_bounds__(256) void k_rz_blur_amp(BlurArgs aa) {
 }
 
 // Register-blocked variant for levels whose width is a multiple of 4 (the large ones).  Tile 64 x 32,
-// staged with an 8-column / 6-row halo so that interior tiles load 128-bit vectors.  Row pass: a work item
-// is four adjacent outputs of one staged row, their 16 source values come from eight 64-bit LDS reads
-// (208 bytes of LDS traffic per four outputs become 64).  Column pass + amplify: a thread owns a 4 x 2
-// pixel block for all three planes, 14 128-bit reads per plane.  Every output keeps its own accumulator
+// staged with an 8-column / 6-row halo so that interior tiles load 128-bit vectors.  The three planes
+// (amp, c, s) go through the SAME LDS buffers one after the other (25 KB per workgroup instead of 76 KB:
+// six workgroups per CU hide the staging latency), their column-pass results wait in registers for the
+// amplify step.  Row pass: a work item is four adjacent outputs of one staged row, their source values
+// come from five aligned 128-bit LDS reads (20 bytes per output instead of 52).  Column pass + amplify: a
+// thread owns a 4 x 2 pixel block, 14 128-bit reads per plane.  Every output keeps its own accumulator
 // and receives its taps in the order of the scalar kernel, so both kernels give identical bits.
 constexpr int B2W = 64, B2H = 32, B2HX = 8, B2HY = 6, B2SW = B2W + 2 * B2HX, B2SH = B2H + 2 * B2HY;
 template <bool EXACT>
 __global__ __launch_bounds__(256) void k_rz_blur_amp4(BlurArgs aa) {
-    __shared__ __attribute__((aligned(16))) float s[3][B2SH][B2SW];
-    __shared__ __attribute__((aligned(16))) float hr[3][B2SH][B2W];
+    __shared__ __attribute__((aligned(16))) float s[B2SH][B2SW];
+    __shared__ __attribute__((aligned(16))) float hr[B2SH][B2W];
     int lvl = 0;
     while (lvl + 1 < aa.nlv && (int)blockIdx.x >= aa.lv[lvl + 1].block0) ++lvl;
     const BlurLv& a = aa.lv[lvl];
@@ -425,69 +427,79 @@ __global__ __launch_bounds__(256) void k_rz_blur_amp4(BlurArgs aa) {
     const int bs = t / (a.tx * a.ty), tr = t - bs * (a.tx * a.ty);
     const int x0 = (tr % a.tx) * B2W, y0 = (tr / a.tx) * B2H;
     const size_t pl = (size_t)bs * a.w * a.h;
-    const float* src[3] = {a.amp + pl, a.tc + pl, a.ts + pl};
     const bool interior = x0 - B2HX >= 0 && x0 + B2W + B2HX <= a.w && y0 - B2HY >= 0 && y0 + B2H + B2HY <= a.h;
-    if (interior) {
-        for (int i = threadIdx.x; i < 3 * B2SH * (B2SW / 4); i += 256) {
-            const int f = i / (B2SH * (B2SW / 4)), r = i - f * (B2SH * (B2SW / 4));
-            const int ly = r / (B2SW / 4), g = r - ly * (B2SW / 4);
-            *reinterpret_cast<float4*>(&s[f][ly][4 * g]) =
-                *reinterpret_cast<const float4*>(src[f] + (size_t)(y0 - B2HY + ly) * a.w + (x0 - B2HX + 4 * g));
-        }
-    } else {
-        for (int i = threadIdx.x; i < B2SH * B2SW; i += 256) {
-            const int ly = i / B2SW, lx = i - ly * B2SW;
-            const size_t si = (size_t)reflect101(y0 - B2HY + ly, a.h) * a.w + reflect101(x0 - B2HX + lx, a.w);
-            s[0][ly][lx] = src[0][si]; s[1][ly][lx] = src[1][si]; s[2][ly][lx] = src[2][si];
-        }
-    }
-    __syncthreads();
-    // RowFilter: acc = k0*S0; acc = fma(kj, Sj, acc), left to right.  Output column x reads staged columns
-    // x + 2 .. x + 14 (the staging halo is 8, the filter radius 6).
-    for (int i = threadIdx.x; i < 3 * B2SH * (B2W / 4); i += 256) {
-        const int f = i / (B2SH * (B2W / 4)), r = i - f * (B2SH * (B2W / 4));
-        const int ly = r / (B2W / 4), g = r - ly * (B2W / 4);
-        const float* row = &s[f][ly][4 * g + 2];
-        float v[16];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { const float2 p2 = *reinterpret_cast<const float2*>(row + 2 * q); v[2 * q] = p2.x; v[2 * q + 1] = p2.y; }
-        float o[4];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            float acc = aa.g[0] * v[m];
-#pragma unroll
-            for (int j = 1; j < 13; ++j) acc = __builtin_fmaf(aa.g[j], v[m + j], acc);
-            o[m] = acc;
-        }
-        *reinterpret_cast<float4*>(&hr[f][ly][4 * g]) = make_float4(o[0], o[1], o[2], o[3]);
-    }
-    __syncthreads();
-    const int gq = threadIdx.x & 15, yq = threadIdx.x >> 4;           // 16 column groups x 16 row pairs
+    const int gq = threadIdx.x & 15, yq = threadIdx.x >> 4;           // column pass: 16 column groups x 16 row pairs
     const int x = 4 * gq, y = 2 * yq;
-    const int gx = x0 + x, gy = y0 + y;
-    if (gx >= a.w || gy >= a.h) return;
     float bl[3][2][4];
 #pragma unroll
-    for (int f = 0; f < 3; ++f) {   // SymmColumnFilter: centre, then fma(kj, S[+j] + S[-j]); rows y .. y+13 serve both outputs
-        float4 rr[14];
-#pragma unroll
-        for (int q = 0; q < 14; ++q) rr[q] = *reinterpret_cast<const float4*>(&hr[f][y + q][x]);
-#pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            const float* ctr = &rr[d + 6].x;
-            float acc[4];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[m] = aa.g[6] * ctr[m];
-#pragma unroll
-            for (int j = 1; j <= 6; ++j) {
-                const float* up = &rr[d + 6 + j].x; const float* dn = &rr[d + 6 - j].x;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) acc[m] = __builtin_fmaf(aa.g[6 + j], up[m] + dn[m], acc[m]);
+    for (int f = 0; f < 3; ++f) {
+        const float* src = (f == 0 ? a.amp : (f == 1 ? a.tc : a.ts)) + pl;
+        if (f > 0) __syncthreads();                                   // the row pass of plane f-1 has finished reading s
+        if (interior) {
+#pragma unroll 1
+            for (int i = threadIdx.x; i < B2SH * (B2SW / 4); i += 256) {
+                const int ly = i / (B2SW / 4), g = i - ly * (B2SW / 4);
+                *reinterpret_cast<float4*>(&s[ly][4 * g]) =
+                    *reinterpret_cast<const float4*>(src + (size_t)(y0 - B2HY + ly) * a.w + (x0 - B2HX + 4 * g));
             }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) bl[f][d][m] = acc[m];
+        } else {
+#pragma unroll 1
+            for (int i = threadIdx.x; i < B2SH * B2SW; i += 256) {
+                const int ly = i / B2SW, lx = i - ly * B2SW;
+                s[ly][lx] = src[(size_t)reflect101(y0 - B2HY + ly, a.h) * a.w + reflect101(x0 - B2HX + lx, a.w)];
+            }
         }
+        __syncthreads();                                              // ... and the column pass of plane f-1 reading hr
+        // RowFilter: acc = k0*S0; acc = fma(kj, Sj, acc), left to right.  Output column x reads staged columns
+        // x + 2 .. x + 14 (the staging halo is 8, the filter radius 6): elements 2 .. 17 of five aligned vectors.
+#pragma unroll 1
+        for (int i = threadIdx.x; i < B2SH * (B2W / 4); i += 256) {
+            const int ly = i / (B2W / 4), g = i - ly * (B2W / 4);
+            float v[20];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const float4 p4 = *reinterpret_cast<const float4*>(&s[ly][4 * g + 4 * q]);
+                v[4 * q] = p4.x; v[4 * q + 1] = p4.y; v[4 * q + 2] = p4.z; v[4 * q + 3] = p4.w;
+            }
+            float o[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float acc = aa.g[0] * v[m + 2];
+#pragma unroll
+                for (int j = 1; j < 13; ++j) acc = __builtin_fmaf(aa.g[j], v[m + 2 + j], acc);
+                o[m] = acc;
+            }
+            *reinterpret_cast<float4*>(&hr[ly][4 * g]) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        __syncthreads();
+        // SymmColumnFilter: centre, then fma(kj, S[+j] + S[-j]); hr rows y .. y+13 serve both output rows.
+        // Rows are fetched as the two accumulations reach them (row y+6+j of the first output is row
+        // y+7+(j-1) of the second), so only a few are live at a time.
+        float4 up0 = *reinterpret_cast<const float4*>(&hr[y + 7][x]);   // centre of output row 1, first "up" row of output row 0
+        float4 dn1 = *reinterpret_cast<const float4*>(&hr[y + 6][x]);   // centre of output row 0, first "down" row of output row 1
+        float acc0[4], acc1[4];
+        {
+            const float* c0 = &dn1.x; const float* c1 = &up0.x;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { acc0[m] = aa.g[6] * c0[m]; acc1[m] = aa.g[6] * c1[m]; }
+        }
+#pragma unroll
+        for (int j = 1; j <= 6; ++j) {
+            const float4 dn0 = *reinterpret_cast<const float4*>(&hr[y + 6 - j][x]);
+            const float4 up1 = *reinterpret_cast<const float4*>(&hr[y + 7 + j][x]);
+            const float* u0 = &up0.x; const float* d0 = &dn0.x; const float* u1 = &up1.x; const float* d1 = &dn1.x;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc0[m] = __builtin_fmaf(aa.g[6 + j], u0[m] + d0[m], acc0[m]);
+                acc1[m] = __builtin_fmaf(aa.g[6 + j], u1[m] + d1[m], acc1[m]);
+            }
+            up0 = up1; dn1 = dn0;          // row y+7+j is the next "up" row of output 0, row y+6-j the next "down" row of output 1
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) { bl[f][0][m] = acc0[m]; bl[f][1][m] = acc1[m]; }
     }
+    const int gx = x0 + x, gy = y0 + y;
+    if (gx >= a.w || gy >= a.h) return;
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
         if (gy + d >= a.h) break;
@@ -497,9 +509,8 @@ __global__ __launch_bounds__(256) void k_rz_blur_amp4(BlurArgs aa) {
         const float* R1 = &r1.x; const float* R2 = &r2.x; const float* Bd = &bd.x;
         float o[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < 4; ++m)
             o[m] = rz_amplify<EXACT>(bl[0][d][m], bl[1][d][m], bl[2][d][m], R1[m], R2[m], Bd[m], aa.alpha, aa.thr);
-        }
         *reinterpret_cast<float4*>(a.bandA + idx) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
