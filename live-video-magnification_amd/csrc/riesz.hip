@@ -164,124 +164,49 @@ __device__ __forceinline__ void stage_reflect(float (&s)[CSH][CSW], const float*
     }
 }
 
-// Tile prefetch of the persistent stencil kernels: the source elements of the NEXT tile are loaded into
-// registers before the current tile is filtered and written to the other LDS buffer afterwards, so the
-// global-load latency (longer than the filtering of a tile) is hidden and there is one barrier per tile.
-// Interior tiles of planes whose width is a multiple of 4 take two 128-bit loads per thread, everything
-// else seven scalar loads with REFLECT_101 indices.
-constexpr int kStageScalar = (CSH * CSW + 255) / 256, kStageVec = (CSH * (CSW / 4) + 255) / 256;
-struct TilePrefetch {
-    float v[kStageVec * 4 > kStageScalar ? kStageVec * 4 : kStageScalar];
-    bool vec;
-};
-__device__ __forceinline__ void tile_load(TilePrefetch& r, const float* __restrict__ src, int w, int h, int x0, int y0) {
-    r.vec = (w & 3) == 0 && x0 - SH >= 0 && x0 + CW + SH <= w && y0 - SH >= 0 && y0 + CH + SH <= h;
-    if (r.vec) {
-#pragma unroll
-        for (int k = 0; k < kStageVec; ++k) {
-            const int i = threadIdx.x + k * 256;
-            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < CSH * (CSW / 4)) {
-                const int ly = i / (CSW / 4), g = i - ly * (CSW / 4);
-                q = *reinterpret_cast<const float4*>(src + (size_t)(y0 - SH + ly) * w + (x0 - SH + 4 * g));
-            }
-            r.v[4 * k] = q.x; r.v[4 * k + 1] = q.y; r.v[4 * k + 2] = q.z; r.v[4 * k + 3] = q.w;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < kStageScalar; ++k) {
-            const int i = threadIdx.x + k * 256;
-            r.v[k] = 0.f;
-            if (i < CSH * CSW) {
-                const int ly = i / CSW, lx = i - ly * CSW;
-                r.v[k] = src[(size_t)reflect101(y0 - SH + ly, h) * w + reflect101(x0 - SH + lx, w)];
-            }
-        }
-    }
-}
-__device__ __forceinline__ void tile_store(const TilePrefetch& r, float (&s)[CSH][CSW]) {
-    if (r.vec) {
-#pragma unroll
-        for (int k = 0; k < kStageVec; ++k) {
-            const int i = threadIdx.x + k * 256;
-            if (i < CSH * (CSW / 4)) {
-                const int ly = i / (CSW / 4), g = i - ly * (CSW / 4);
-                *reinterpret_cast<float4*>(&s[ly][4 * g]) = make_float4(r.v[4 * k], r.v[4 * k + 1], r.v[4 * k + 2], r.v[4 * k + 3]);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < kStageScalar; ++k) {
-            const int i = threadIdx.x + k * 256;
-            if (i < CSH * CSW) { const int ly = i / CSW, lx = i - ly * CSW; s[ly][lx] = r.v[k]; }
-        }
-    }
-}
-
-// Persistent workgroups walk over (plane, tile): blockIdx.x, blockIdx.x + gridDim.x, ...
 __global__ __launch_bounds__(256) void k_rz_split(const float* __restrict__ oct, int w, int h,
-                                                     float* __restrict__ band, float* __restrict__ next, int nw, int nh,
-                                                     int tiles_x, int tiles_y, int ntiles) {
-    __shared__ __attribute__((aligned(16))) float sbuf[2][CSH][CSW];
-    const int per = tiles_x * tiles_y;
-    auto origin = [&](int t, int& pl, int& x0, int& y0) __attribute__((always_inline)) {
-        pl = t / per; const int r = t - pl * per; const int ty = r / tiles_x;
-        x0 = (r - ty * tiles_x) * CW; y0 = ty * CH;
-    };
-    int t = blockIdx.x;
-    if (t >= ntiles) return;
-    TilePrefetch pf;
-    {
-        int pl, x0, y0; origin(t, pl, x0, y0);
-        tile_load(pf, oct + (size_t)pl * w * h, w, h, x0, y0);
-        tile_store(pf, sbuf[0]);
-    }
+                                                     float* __restrict__ band, float* __restrict__ next, int nw, int nh) {
+    __shared__ __attribute__((aligned(16))) float s[CSH][CSW];
+    const int x0 = blockIdx.x * CW, y0 = blockIdx.y * CH;
+    stage_reflect(s, oct + (size_t)blockIdx.z * w * h, w, h, x0, y0);
     __syncthreads();
-    for (int buf = 0; t < ntiles; t += gridDim.x, buf ^= 1) {
-        const int tn = t + gridDim.x;
-        if (tn < ntiles) { int pl, x0, y0; origin(tn, pl, x0, y0); tile_load(pf, oct + (size_t)pl * w * h, w, h, x0, y0); }
-        int pl, x0, y0; origin(t, pl, x0, y0);
-        float (&s)[CSH][CSW] = sbuf[buf];
-        {   // high-pass band at every pixel: 4 per thread
-            const int y = threadIdx.x >> 4, x = (threadIdx.x & 15) * 4;
-            const int gx = x0 + x, gy = y0 + y;
-            if (gx < w && gy < h) {
-                float o[4];
-                conv9x4(s, x, y, kHp9, 1.0f, o);                                          // :227
-                float* d = band + ((size_t)pl * h + gy) * w + gx;
-                if ((w & 3) == 0) *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);   // gx % 4 == 0, planes 256-B aligned
-                else {
+    {   // high-pass band at every pixel: 4 per thread
+        const int y = threadIdx.x >> 4, x = (threadIdx.x & 15) * 4;
+        const int gx = x0 + x, gy = y0 + y;
+        if (gx < w && gy < h) {
+            float o[4];
+            conv9x4(s, x, y, kHp9, 1.0f, o);                                          // :227
+            float* d = band + ((size_t)blockIdx.z * h + gy) * w + gx;
+            if ((w & 3) == 0) *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);   // gx % 4 == 0, planes 256-B aligned
+            else {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) if (gx + m < w) d[m] = o[m];
-                }
+                for (int m = 0; m < 4; ++m) if (gx + m < w) d[m] = o[m];
             }
         }
-        {   // 2 x low-pass at even pixels only: 32 x 8 per tile, ONE per thread so that all four waves share the
-            // work (the 9 floats of a kernel row start at an even column: five aligned 64-bit LDS reads)
-            const int v = threadIdx.x >> 5, q = threadIdx.x & 31;
-            const int y = 2 * v, x = 2 * q;
-            const int gx = x0 + x, gy = y0 + y;
-            if (gx < w && gy < h) {
-                float acc = 0.f;
+    }
+    {   // 2 x low-pass at even pixels only: 32 x 8 per tile, ONE per thread so that all four waves share the
+        // work (the 9 floats of a kernel row start at an even column: five aligned 64-bit LDS reads)
+        const int v = threadIdx.x >> 5, q = threadIdx.x & 31;
+        const int y = 2 * v, x = 2 * q;
+        const int gx = x0 + x, gy = y0 + y;
+        if (gx < w && gy < h) {
+            float acc = 0.f;
 #pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    const float2 a = *reinterpret_cast<const float2*>(&s[y + i][x]);
-                    const float2 b = *reinterpret_cast<const float2*>(&s[y + i][x + 2]);
-                    const float2 c = *reinterpret_cast<const float2*>(&s[y + i][x + 4]);
-                    const float2 d = *reinterpret_cast<const float2*>(&s[y + i][x + 6]);
-                    const float e = s[y + i][x + 8];
-                    const float tt[9] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y, e};
+            for (int i = 0; i < 9; ++i) {
+                const float2 a = *reinterpret_cast<const float2*>(&s[y + i][x]);
+                const float2 b = *reinterpret_cast<const float2*>(&s[y + i][x + 2]);
+                const float2 c = *reinterpret_cast<const float2*>(&s[y + i][x + 4]);
+                const float2 d = *reinterpret_cast<const float2*>(&s[y + i][x + 6]);
+                const float e = s[y + i][x + 8];
+                const float t[9] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y, e};
 #pragma unroll
-                    for (int j = 0; j < 9; ++j) {
-                        const float kv = kLp9[i * 9 + j] * 2.0f;                           // x2 is exact
-                        if (kv != 0.f) acc = __builtin_fmaf(kv, tt[j], acc);              // :232-234, row-major like conv9
-                    }
+                for (int j = 0; j < 9; ++j) {
+                    const float kv = kLp9[i * 9 + j] * 2.0f;                           // x2 is exact
+                    if (kv != 0.f) acc = __builtin_fmaf(kv, t[j], acc);               // :232-234, row-major like conv9
                 }
-                next[((size_t)pl * nh + gy / 2) * nw + gx / 2] = acc;
             }
+            next[((size_t)blockIdx.z * nh + gy / 2) * nw + gx / 2] = acc;
         }
-        if (tn < ntiles) tile_store(pf, sbuf[buf ^ 1]);
-        __syncthreads();              // the next tile is staged, and everyone has finished reading this one
     }
 }
 
@@ -785,7 +710,6 @@ struct RieszState : ModeState {
     int tcap = 0; float* tarena = nullptr;
     float* ft[kMaxLevels + 1][F_ALL_N] = {}; float* oct_t[kMaxLevels + 1] = {}; float* res_t[kMaxLevels + 1] = {};   // per band level: band,P,R1p,R2p,phc,phs,lo0c,lo0s,lo1c,lo1s,hi0c,hi0s,hi1c,hi1s,amp,tc,ts,bandA
     bool inited = false;
-    long persist_blocks = 1024;      // workgroups of the persistent stencil kernels (4 per CU; LVM_RZ_PERSIST)
     bool blur4 = true;               // register-blocked Gaussian/amplify kernel on the large levels (LVM_RZ_BLUR4=0: scalar kernel everywhere)
     double lo_freq = 0, hi_freq = 0, fps = 0;
     double la[3] = {}, lb[3] = {}, ha[3] = {}, hb[3] = {};
@@ -841,11 +765,8 @@ static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B,
     }
     for (int l = 0; l < nb; ++l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
-        const int tx = (a.w + CW - 1) / CW, ty = (a.h + CH - 1) / CH;
-        const long ntiles = (long)tx * ty * NZ;
-        const dim3 grid((unsigned)(ntiles < st->persist_blocks ? ntiles : st->persist_blocks));
-        LVM_LAUNCH(c, "rz_split", k_rz_split, grid, blk, s, (const float*)B.oct[l], a.w, a.h, B.pf[l][F_BAND], B.oct[l + 1], b.w, b.h,
-                   tx, ty, (int)ntiles);
+        const dim3 grid((a.w + CW - 1) / CW, (a.h + CH - 1) / CH, NZ);
+        LVM_LAUNCH(c, "rz_split", k_rz_split, grid, blk, s, (const float*)B.oct[l], a.w, a.h, B.pf[l][F_BAND], B.oct[l + 1], b.w, b.h);
     }
 }
 
@@ -938,7 +859,6 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
     if (!st) {
         st = new RieszState();
         if (const char* e = std::getenv("LVM_RZ_BLUR4")) st->blur4 = std::atoi(e) != 0;
-        if (const char* e = std::getenv("LVM_RZ_PERSIST")) st->persist_blocks = std::atol(e) > 0 ? std::atol(e) : 1024;
         c->state = st;
         const int rc = riesz_alloc(c, st, io.w, io.h, levels);
         if (rc != LVM_OK) return rc;

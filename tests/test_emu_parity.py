@@ -71,15 +71,6 @@ def test_riesz_emu_register_blocked_blur(lvm, po, emu, blur4, monkeypatch):
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0, exact=True)
 
 
-@pytest.mark.parametrize("blocks", ["3", "7"])
-def test_riesz_emu_persistent_tile_loop(lvm, po, emu, blocks, monkeypatch):
-    """The persistent stencil kernels with far fewer workgroups than tiles: every workgroup walks over several
-    tiles through the double-buffered LDS stage (interior, border and partial tiles interleaved)."""
-    monkeypatch.setenv("LVM_RZ_PERSIST", blocks)
-    ck, pk = lvm.synth.config(2, (264, 150, 4))
-    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0, exact=True)
-
-
 def test_riesz_emu_cutoff_change_gray_and_reset(lvm, po, emu):
     ck, pk = lvm.synth.config(2, (96, 64, 3))
 
