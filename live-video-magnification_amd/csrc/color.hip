@@ -672,6 +672,8 @@ struct ColorState : ModeState {
     bool co_rows_ok = false;         // the vectorised output kernel's LDS tile covers every output tile
     bool thin_dft = true;            // thread-per-row DFT for narrow bands (LVM_COL_THIN_DFT=0: wave-per-row kernel)
     long out_min_tasks = 2048;       // strips are shortened until a launch has this many (LVM_COL_OUT_MIN_TASKS)
+    bool d0_rows_on = true;          // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
+    long d0_min_tasks = 4096;        // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
     int out_rows = 16;               // rows per wave strip of k_col_out_rows (LVM_COL_OUT_ROWS; 0 = tiled k_col_out_v4)
     int thin_min_frames = 4;         // ... from this many frames per launch (LVM_COL_THIN_MIN_FRAMES)
     long rows_min_elems = 1 << 20;   // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
@@ -769,7 +771,15 @@ static void col_down(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs& B
     const LevelGeom& g1 = st->g[1];
     const dim3 grid0((g1.w + 31) / 32, (g1.h + 15) / 16, NZ);
     const bool vec4 = C == 3 && w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0;
-    if (vec4) {
+    const int d0_sx = (g1.w + D0R_OUT - 1) / D0R_OUT;
+    int d0_rows = 16;
+    while (d0_rows > 8 && (long)d0_sx * ((g1.h + d0_rows - 1) / d0_rows) * NZ < st->d0_min_tasks) d0_rows >>= 1;
+    const long d0_tasks = (long)d0_sx * ((g1.h + d0_rows - 1) / d0_rows) * NZ;
+    if (vec4 && st->d0_rows_on && d0_tasks >= st->d0_min_tasks) {   // wave strips with DPP halo exchange (pyramid.h)
+        const dim3 gridr((unsigned)((d0_tasks + D0R_THREADS / 64 - 1) / (D0R_THREADS / 64)));
+        LVM_LAUNCH(c, "col_down0", (k_down0_rows<false, true>), gridr, dim3(D0R_THREADS), s, io.d_in, (long)io.in_stride, (long)io.in_sstride,
+                   w, h, B.G[1], g1.w, g1.h, c->lab, d0_sx, (g1.h + d0_rows - 1) / d0_rows, (int)d0_tasks, d0_rows);
+    } else if (vec4) {
         auto kv = k_down0_v4<false, true>;
         LVM_LAUNCH(c, "col_down0", kv, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, B.G[1], g1.w, g1.h, c->lab);
     } else {
@@ -895,6 +905,8 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         st = new ColorState();
         c->state = st;
         if (const char* e = std::getenv("LVM_COL_THIN_DFT")) st->thin_dft = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
         if (const char* e = std::getenv("LVM_COL_OUT_ROWS")) st->out_rows = std::atoi(e);
         if (const char* e = std::getenv("LVM_COL_OUT_MIN_TASKS")) st->out_min_tasks = std::atol(e);
         if (const char* e = std::getenv("LVM_COL_THIN_MIN_FRAMES")) st->thin_min_frames = std::atoi(e);

@@ -641,6 +641,8 @@ struct LaplaceState : ModeState {
     long rows_min_elems = 1 << 20;        // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
     int up_rows = 1;                      // barrier-free k_lap_up_rows for the steady state (LVM_UP_ROWS=0: tiled k_lap_up)
     long up_rows_max_blocks = 1024;       // launches with fewer tiled workgroups than this use k_lap_up_rows (LVM_UP_ROWS_MAX_BLOCKS)
+    bool d0_rows_on = true;               // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
+    long d0_min_tasks = 4096;             // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
     int fin_rows = 4;                     // rows per wave strip of k_lap_final_v4 (LVM_FIN_ROWS, power of two)
     int up_depth = 8;                     // frame-loop prefetch depth of k_lap_up at the coarse levels (LVM_UP_DEPTH=1|2|4|8)
     int chunks = 1;                       // temporal batches: > 1 = chunks whose down sweep overlaps the previous chunk's up sweep on a second stream (LVM_LAP_CHUNKS; measured slower: 27.7k fps at 4 chunks, 30.5k at 2, 34.8k at 1)
@@ -702,6 +704,8 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     laplace_tail_plan(st);
     if (const char* e = std::getenv("LVM_FUSE_DOWN")) st->fuse_down = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_DEPTH")) st->up_depth = std::atoi(e);
+    if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
+    if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
     if (const char* e = std::getenv("LVM_LAP_CHUNKS")) st->chunks = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_ROWS")) st->up_rows = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_ROWS_MAX_BLOCKS")) st->up_rows_max_blocks = std::atol(e);
@@ -774,7 +778,17 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     float** G = B.G;
     const LevelGeom& g1 = st->g[1];
     const dim3 grid0((g1.w + DT_W - 1) / DT_W, (g1.h + DT_H - 1) / DT_H, NS);
-    if (lap_vec4(io)) {
+    // wave strips (DPP halo exchange, no LDS tile) when the launch has enough of them, else the LDS-tiled kernel
+    const int d0_sx = (g1.w + D0R_OUT - 1) / D0R_OUT;
+    int d0_rows = 16;
+    while (d0_rows > 8 && (long)d0_sx * ((g1.h + d0_rows - 1) / d0_rows) * NS < st->d0_min_tasks) d0_rows >>= 1;
+    const long d0_tasks = (long)d0_sx * ((g1.h + d0_rows - 1) / d0_rows) * NS;
+    if (lap_vec4(io) && st->d0_rows_on && d0_tasks >= st->d0_min_tasks) {
+        auto kd0 = c->exact_lab ? k_down0_rows<true, true> : k_down0_rows<true, false>;
+        const dim3 gridr((unsigned)((d0_tasks + D0R_THREADS / 64 - 1) / (D0R_THREADS / 64)));
+        LVM_LAUNCH(c, "lap_down0", kd0, gridr, dim3(D0R_THREADS), s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
+                   G[1], g1.w, g1.h, c->lab, d0_sx, (g1.h + d0_rows - 1) / d0_rows, (int)d0_tasks, d0_rows);
+    } else if (lap_vec4(io)) {
         auto kd0 = c->exact_lab ? k_down0_v4<true, true> : k_down0_v4<true, false>;
         LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
                    G[1], g1.w, g1.h, c->lab);

@@ -229,6 +229,79 @@ __global__ __launch_bounds__(256) void k_down0_v4(const uint8_t* __restrict__ in
     }
 }
 
+// ---- u8 BGR -> (Lab) -> pyrDown -> G_1 as wave strips ----------------------------------------------
+// Barrier-free form of k_down0_v4 (same preconditions, same arithmetic).  A wave owns a strip of 124 output
+// columns x `rows` output rows of one frame.  Lane i holds the source pixel group 4g .. 4g+3, g = 62 tx - 1 + i,
+// of the current source row: one 12-byte load, the colour conversion of its 4 pixels, and -- instead of an LDS
+// tile -- two DPP wave shifts per channel hand it the two pixels left of the group and the pixel right of it
+// (wave_shr:1 / wave_shl:1 cross all 64 lanes on gfx950).  Lanes 1 .. 62 then own the two outputs 2g, 2g+1;
+// lanes 0 and 63 only feed their neighbours.  Groups outside the image are the REFLECT_101 mirror of the
+// edge group, obtained by loading that group and swapping its pixels.  The horizontal results slide down
+// the strip in a 5-row register window.  Only the gamma table lives in LDS.
+__device__ __forceinline__ float dpp_shr1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_shl1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }
+constexpr int D0R_THREADS = 256, D0R_OUT = 124;
+template <bool LAB, bool EXACT>
+__global__ __launch_bounds__(D0R_THREADS) void k_down0_rows(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
+                                                            int w, int h, float* __restrict__ G1, int w1, int h1, LabCoef lab,
+                                                            int strips_x, int strips_y, int ntasks, int rows) {
+    __shared__ float s_gam[256];
+    if (LAB) { load_gamma_u8(s_gam, lab.gamma_u8); __syncthreads(); }
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int task = blockIdx.x * (D0R_THREADS / 64) + wave;
+    if (task >= ntasks) return;
+    const int b = task / (strips_x * strips_y);
+    const int r = task - b * (strips_x * strips_y);
+    const int ty = r / strips_x, tx = r - ty * strips_x;
+    const int ngroups = w >> 2;                                    // w % 4 == 0
+    const int g = tx * (D0R_OUT / 2) - 1 + lane;                    // source group of this lane
+    const bool left_mirror = g < 0, right_mirror = g >= ngroups;    // REFLECT_101 mirrors of the edge groups
+    const int gl = left_mirror ? 0 : (right_mirror ? ngroups - 1 : g);
+    const unsigned xoff = 12u * (unsigned)gl;
+    const uint8_t* src = in + (size_t)b * in_sstride;
+    const int ox = 2 * g, oy0 = ty * rows;
+    const bool owner = lane >= 1 && lane <= 62 && g >= 0 && ox < w1;    // (ox even, w1 even: ox + 1 < w1 too)
+    // colour planes of the lane's 4 pixels for source row sy, and the two horizontal pyrDown results per plane
+    auto hrow = [&](int sy, float (&ha)[3], float (&hb)[3]) __attribute__((always_inline)) {
+        const Px4 pv = *reinterpret_cast<const Px4*>(src + (size_t)reflect101(sy, h) * in_stride + xoff);
+        int Bv[4], Gv[4], Rv[4];
+        unpack_px4(pv, Bv, Gv, Rv);
+        float P[3][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (LAB) lin_bgr_to_lab<EXACT>(s_gam[Bv[q]], s_gam[Gv[q]], s_gam[Rv[q]], lab.fwd, P[0][q], P[1][q], P[2][q]);
+            else { P[0][q] = (float)Bv[q] * 1.0f; P[1][q] = (float)Gv[q] * 1.0f; P[2][q] = (float)Rv[q] * 1.0f; }   // colour mode: unscaled planes
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            // what the neighbours see of this lane: (p2, p3) towards the right neighbour, p0 towards the left one.
+            // Mirrored groups: pixels -2, -1 are pixels 2, 1 of group 0; pixel w is pixel w-2 = pixel 2 of the last group.
+            const float give2 = P[c][2], give3 = left_mirror ? P[c][1] : P[c][3], give0 = right_mirror ? P[c][2] : P[c][0];
+            const float L2 = dpp_shr1(give2), L3 = dpp_shr1(give3), R0 = dpp_shl1(give0);
+            ha[c] = P[c][0] * 6.f + (L3 + P[c][1]) * 4.f + L2 + P[c][2];
+            hb[c] = P[c][2] * 6.f + (P[c][1] + P[c][3]) * 4.f + P[c][0] + R0;
+        }
+    };
+    const int yend = oy0 + rows < h1 ? oy0 + rows : h1;
+    float a0[3], a1[3], a2[3], a3[3], a4[3], b0[3], b1[3], b2[3], b3[3], b4[3];
+    hrow(2 * oy0 - 2, a0, b0); hrow(2 * oy0 - 1, a1, b1); hrow(2 * oy0, a2, b2);
+    const size_t plane = (size_t)w1 * h1;
+    float* dst = G1 + (size_t)b * 3 * plane;
+    for (int oy = oy0; oy < yend; ++oy) {
+        hrow(2 * oy + 1, a3, b3); hrow(2 * oy + 2, a4, b4);
+        if (owner) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float va = (a2[c] * 6.f + (a1[c] + a3[c]) * 4.f + a0[c] + a4[c]) * (1.f / 256.f);
+                const float vb = (b2[c] * 6.f + (b1[c] + b3[c]) * 4.f + b0[c] + b4[c]) * (1.f / 256.f);
+                *reinterpret_cast<float2*>(dst + c * plane + (size_t)oy * w1 + ox) = make_float2(va, vb);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a0[c] = a2[c]; a1[c] = a3[c]; a2[c] = a4[c]; b0[c] = b2[c]; b1[c] = b3[c]; b2[c] = b4[c]; }
+    }
+}
+
 // ---- pyrDown of large float planes: wave strips, no LDS ---------------------------------------------
 // Every wave owns a strip of 128 output columns x `rows` output rows of one plane; a lane produces two
 // adjacent outputs per row.  The 7 source values a lane needs from a source row (columns 2x-2 .. 2x+4)

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <ucontext.h>
 
+#include <cstdlib>
 #include <vector>
 
 namespace hipemu {
@@ -20,6 +21,22 @@ void entry() {
 }
 }  // namespace
 void sync() { swapcontext(&cur->ctx, &sched); }
+// Cross-lane shift by one lane over a 64-lane wave.  The fibres of a workgroup run round-robin between
+// yields, so "deposit, yield, read the neighbour, yield" is a correct exchange as long as all lanes of the
+// wave execute the same sequence of yields (wave-uniform control flow, as DPP requires on the hardware).
+int dpp_wave_shift(int old, int src, int ctrl) {
+    static thread_local int slot[1024];
+    const unsigned t = st.tid.x + st.bdim.x * (st.tid.y + st.bdim.y * st.tid.z);
+    slot[t] = src;
+    sync();
+    const unsigned lane = t & 63u;
+    int r = old;
+    if (ctrl == 0x138) { if (lane > 0) r = slot[t - 1]; }
+    else if (ctrl == 0x130) { if (lane < 63) r = slot[t + 1]; }
+    else std::abort();
+    sync();
+    return r;
+}
 void launch(const std::function<void()>& fn, dim3 grid, dim3 block) {
     const unsigned n = block.x * block.y * block.z;
     if (fibers.size() < n) {

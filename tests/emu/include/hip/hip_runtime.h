@@ -39,7 +39,7 @@ struct State { dim3 tid, bid, bdim, gdim; };
 extern thread_local State st;
 void sync();
 void launch(const std::function<void()>& body, dim3 grid, dim3 block);
-float shfl(float v, int src_lane);
+int dpp_wave_shift(int old, int src, int ctrl);
 }  // namespace hipemu
 #define threadIdx (hipemu::st.tid)
 #define blockIdx (hipemu::st.bid)
@@ -71,6 +71,8 @@ static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
 static inline float __builtin_amdgcn_sinf(float rev) { return sinf(rev * 6.283185307179586f); }   // v_sin_f32: argument in revolutions
 static inline float __builtin_amdgcn_cosf(float rev) { return cosf(rev * 6.283185307179586f); }
+// DPP wave_shr:1 (0x138) / wave_shl:1 (0x130): every lane of the wave must execute it (uniform control flow)
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) { return hipemu::dpp_wave_shift(old, src, ctrl); }
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }   // only ever applied to wave-uniform values
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }

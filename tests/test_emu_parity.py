@@ -198,6 +198,18 @@ def test_laplace_emu_wave_strip_pyrdown(lvm, po, emu, w, h, levels, monkeypatch)
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 3, 0.0, exact=True)
 
 
+@pytest.mark.parametrize("idx,w,h,levels", [(0, 328, 109, 3), (0, 1000, 70, 4), (0, 124 * 2 * 2, 40, 2), (3, 264, 90, 3), (3, 96, 77, 2)])
+def test_emu_wave_strip_first_kernel(lvm, po, emu, idx, w, h, levels, monkeypatch):
+    """k_down0_rows (u8 -> Lab / float -> pyrDown with DPP halo exchange between lanes) forced onto small frames:
+    several strips per row (mirrored left / right edge groups, a strip ending exactly at the image edge), partly
+    filled last strips, odd heights; Laplace (Lab) and Color (unscaled planes)."""
+    monkeypatch.setenv("LVM_D0_MIN_TASKS", "0")
+    ck, pk = lvm.synth.config(idx, (w, h, levels))
+    if idx == 3:
+        ck["fps"] = 15.0; pk["framerate"] = 15.0
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0, exact=True)
+
+
 def _frames_clip(lvm, po, lib, idx, w, h, levels, n_streams, calls, over=None, clip_over=None):
     """lvm_process_device_frames: batches of consecutive frames (sizes in `calls`) of n_streams streams
     must give exactly the frames the oracle produces one by one."""
