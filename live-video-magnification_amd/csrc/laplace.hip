@@ -780,9 +780,8 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     const dim3 grid0((g1.w + DT_W - 1) / DT_W, (g1.h + DT_H - 1) / DT_H, NS);
     // wave strips (DPP halo exchange, no LDS tile) when the launch has enough of them, else the LDS-tiled kernel
     const int d0_sx = (g1.w + D0R_OUT - 1) / D0R_OUT;
-    int d0_rows = 16;
-    while (d0_rows > 8 && (long)d0_sx * ((g1.h + d0_rows - 1) / d0_rows) * NS < st->d0_min_tasks) d0_rows >>= 1;
-    const long d0_tasks = (long)d0_sx * ((g1.h + d0_rows - 1) / d0_rows) * NS;
+    long d0_tasks = 0;
+    const int d0_rows = down0_rows_choice(g1.w, g1.h, NS, &d0_tasks);
     if (lap_vec4(io) && st->d0_rows_on && d0_tasks >= st->d0_min_tasks) {
         auto kd0 = c->exact_lab ? k_down0_rows<true, true> : k_down0_rows<true, false>;
         const dim3 gridr((unsigned)((d0_tasks + D0R_THREADS / 64 - 1) / (D0R_THREADS / 64)));
