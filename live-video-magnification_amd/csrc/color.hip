@@ -773,8 +773,8 @@ static void col_down(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs& B
     const bool vec4 = C == 3 && w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0;
     const int d0_sx = (g1.w + D0R_OUT - 1) / D0R_OUT;
     long d0_tasks = 0;
-    const int d0_rows = down0_rows_choice(g1.w, g1.h, NZ, &d0_tasks);
-    if (vec4 && st->d0_rows_on && d0_tasks >= st->d0_min_tasks) {   // wave strips with DPP halo exchange (pyramid.h)
+    const int d0_rows = down0_rows_choice(g1.w, g1.h, NZ, st->d0_min_tasks, &d0_tasks);
+    if (vec4 && st->d0_rows_on && d0_tasks > 0) {   // wave strips with DPP halo exchange (pyramid.h)
         const dim3 gridr((unsigned)((d0_tasks + D0R_THREADS / 64 - 1) / (D0R_THREADS / 64)));
         LVM_LAUNCH(c, "col_down0", (k_down0_rows<false, true>), gridr, dim3(D0R_THREADS), s, io.d_in, (long)io.in_stride, (long)io.in_sstride,
                    w, h, B.G[1], g1.w, g1.h, c->lab, d0_sx, (g1.h + d0_rows - 1) / d0_rows, (int)d0_tasks, d0_rows);

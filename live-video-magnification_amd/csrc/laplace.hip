@@ -781,8 +781,8 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     // wave strips (DPP halo exchange, no LDS tile) when the launch has enough of them, else the LDS-tiled kernel
     const int d0_sx = (g1.w + D0R_OUT - 1) / D0R_OUT;
     long d0_tasks = 0;
-    const int d0_rows = down0_rows_choice(g1.w, g1.h, NS, &d0_tasks);
-    if (lap_vec4(io) && st->d0_rows_on && d0_tasks >= st->d0_min_tasks) {
+    const int d0_rows = down0_rows_choice(g1.w, g1.h, NS, st->d0_min_tasks, &d0_tasks);
+    if (lap_vec4(io) && st->d0_rows_on && d0_tasks > 0) {
         auto kd0 = c->exact_lab ? k_down0_rows<true, true> : k_down0_rows<true, false>;
         const dim3 gridr((unsigned)((d0_tasks + D0R_THREADS / 64 - 1) / (D0R_THREADS / 64)));
         LVM_LAUNCH(c, "lap_down0", kd0, gridr, dim3(D0R_THREADS), s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,

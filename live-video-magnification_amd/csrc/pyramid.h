@@ -243,15 +243,16 @@ __device__ __forceinline__ float dpp_shl1(float v) { return __int_as_float(__bui
 constexpr int D0R_THREADS = 256, D0R_OUT = 124;
 // Strip height for k_down0_rows: a strip of r output rows converts 2r + 3 source rows, and the launch takes as
 // long as the busiest SIMD (1024 of them on MI355X) has strips -- minimise ceil(strips / 1024) * (2r + 3).
-inline int down0_rows_choice(int w1, int h1, long frames, long* tasks_out) {
+inline int down0_rows_choice(int w1, int h1, long frames, long min_tasks, long* tasks_out) {
     const long sx = (w1 + D0R_OUT - 1) / D0R_OUT;
     int best = 8; long best_cost = -1, best_tasks = 0;
     for (int r = 6; r <= 32; ++r) {
         const long tasks = sx * ((h1 + r - 1) / r) * frames;
+        if (tasks < min_tasks) continue;                        // keep at least ~4 waves per SIMD in flight
         const long cost = ((tasks + 1023) / 1024) * (2 * r + 3);
         if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; best_tasks = tasks; }
     }
-    *tasks_out = best_tasks;
+    *tasks_out = best_tasks;                                    // 0: no strip height gives enough strips
     return best;
 }
 template <bool LAB, bool EXACT>
