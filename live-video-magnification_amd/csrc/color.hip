@@ -357,44 +357,6 @@ __global__ __launch_bounds__(256) void k_col_norm(const float* __restrict__ col1
     up0[r] = (col1[r] * fs + fsh) * amp;
 }
 
-// ---- the first pyrUps of the up chain in one launch ---------------------------------------------------
-// buildImgFromGaussPyr (SpatialFilter.cpp:40-46) starts from the smallest level (30 x 17 at 1080p); its first
-// steps are a few thousand pixels each and cost a full launch + dependent latency apiece.  One 1024-thread
-// workgroup per plane runs K consecutive pyrUps with the intermediate levels and the horizontal temporaries
-// in LDS and writes only the last result.  Same arithmetic as k_pyr_up (pyrup_h, the vertical formulas).
-constexpr int kUpTailMaxSteps = 4, kUpTailPool = 36000;       // floats of LDS (144 KB)
-struct UpTailArgs { const float* src; float* dst; int w0, h0, steps; int off[kUpTailMaxSteps + 1]; int offT; };
-__global__ __launch_bounds__(1024) void k_col_up_tail(UpTailArgs a) {
-    __shared__ float pool[kUpTailPool];
-    const int tid = threadIdx.x;
-    const size_t plane = blockIdx.x;
-    int sw = a.w0, sh = a.h0;
-    const float* gsrc = a.src + plane * ((size_t)sw * sh);
-    for (int i = tid; i < sw * sh; i += 1024) pool[a.off[0] + i] = gsrc[i];
-    __syncthreads();
-    for (int k = 0; k < a.steps; ++k) {
-        const int dw = 2 * sw, dh = 2 * sh;
-        const float* __restrict__ S = pool + a.off[k];
-        float* __restrict__ T = pool + a.offT;                     // sh x dw horizontal results
-        for (int i = tid; i < sh * dw; i += 1024) {
-            const int y = i / dw, x = i - y * dw;
-            T[i] = pyrup_h(S + (size_t)y * sw, x, 0, sw);
-        }
-        __syncthreads();
-        const bool last = k + 1 == a.steps;
-        float* __restrict__ D = last ? a.dst + plane * ((size_t)dw * dh) : pool + a.off[k + 1];
-        for (int i = tid; i < dh * dw; i += 1024) {
-            const int y = i / dw, x = i - y * dw;
-            const int j = y >> 1;
-            const int jm = j == 0 ? 1 : j - 1, jp = j == sh - 1 ? sh - 1 : j + 1;
-            D[i] = sel((y & 1) == 0, (T[jm * dw + x] + T[j * dw + x] * 6.f + T[jp * dw + x]) * (1.f / 64.f),
-                       ((T[j * dw + x] + T[jp * dw + x]) * 4.f) * (1.f / 64.f));
-        }
-        __syncthreads();
-        sw = dw; sh = dh;
-    }
-}
-
 // ---- last pyrUp + resize(INTER_LINEAR) + input add (SpatialFilter.cpp:45-48, MagnifyCore.hpp:197-203)
 constexpr int CT_W = 64, CT_H = 16;                 // output tile
 constexpr int CU_W = 100, CU_H = 28;                // max extent of the pyrUp'ed tile (scale < 1.5)
@@ -716,7 +678,6 @@ struct ColorState : ModeState {
     bool co_rows_ok = false;         // the vectorised output kernel's LDS tile covers every output tile
     bool thin_dft = true;            // thread-per-row DFT for narrow bands (LVM_COL_THIN_DFT=0: wave-per-row kernel)
     long out_min_tasks = 2048;       // strips are shortened until a launch has this many (LVM_COL_OUT_MIN_TASKS)
-    bool up_tail = true;             // the first pyrUps of the up chain in one LDS-resident launch (LVM_COL_UP_TAIL=0: one launch per level)
     bool d0_rows_on = true;          // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
     long d0_min_tasks = 4096;        // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
     int out_rows = 16;               // rows per wave strip of k_col_out_rows (LVM_COL_OUT_ROWS; 0 = tiled k_col_out_v4)
@@ -906,27 +867,8 @@ static void col_up_out(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs&
     const int C = io.channels, NZ = c->nstreams * B.nt, planes = st->planes * B.nt, levels = st->levels;
     const dim3 blk(256);
     int uw = st->g[levels].w, uh = st->g[levels].h;
-    int k0 = 0;
-    if (st->up_tail) {
-        // the largest K <= levels - 1 leading pyrUps whose levels 0 .. K-1 plus the horizontal temporary of the last
-        // step (2 n_{K-1} floats) fit in the LDS pool
-        int K = 0;
-        for (int cand = 2; cand <= kUpTailMaxSteps && cand <= levels - 1; ++cand) {
-            long total = 0, n = (long)uw * uh;
-            for (int k = 0; k < cand; ++k) { total += n; if (k == cand - 1) total += 2 * n; n *= 4; }
-            if (total <= kUpTailPool) K = cand;
-        }
-        if (K >= 2) {
-            UpTailArgs t{};
-            t.src = B.up[0]; t.dst = B.up[K]; t.w0 = uw; t.h0 = uh; t.steps = K;
-            int off = 0; long n = (long)uw * uh;
-            for (int k = 0; k < K; ++k) { t.off[k] = off; off += (int)n; n *= 4; }
-            t.offT = off;
-            LVM_LAUNCH(c, "pyr_up_tail", k_col_up_tail, dim3(planes), dim3(1024), s, t);
-            k0 = K; uw <<= K; uh <<= K;
-        }
-    }
-    for (int k = k0; k + 1 < levels; ++k) {      // generic pyrUps, the last one is fused into k_col_out
+    // (a fused LDS-resident launch for the first three pyrUps measured 23.5 us against 3 x 7 us: not kept)
+    for (int k = 0; k + 1 < levels; ++k) {      // L-1 generic pyrUps, the last one is fused into k_col_out
         const dim3 grid((2 * uw + 63) / 64, (2 * uh + 15) / 16, planes);
         LVM_LAUNCH(c, "pyr_up", k_pyr_up<1>, grid, blk, s, (const float*)B.up[k], uw, uh, B.up[k + 1], 2 * uw, 2 * uh);
         uw *= 2; uh *= 2;
@@ -969,7 +911,6 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         st = new ColorState();
         c->state = st;
         if (const char* e = std::getenv("LVM_COL_THIN_DFT")) st->thin_dft = std::atoi(e) != 0;
-        if (const char* e = std::getenv("LVM_COL_UP_TAIL")) st->up_tail = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
         if (const char* e = std::getenv("LVM_COL_OUT_ROWS")) st->out_rows = std::atoi(e);
