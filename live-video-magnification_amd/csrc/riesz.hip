@@ -225,7 +225,6 @@ struct PhaseLv {                       // one band level
                                        // aliases R1p / R2p in per-frame mode
     int w, h, tx, ty, block0;          // geometry, tiles per stream, first workgroup of this level
     long fs;                           // frame stride (floats) of band / amp / tc / ts / R1c / R2c
-    int store_pair;                    // 0: the amplify kernel of this level recomputes the Riesz pair from the band (k_rz_blur_amp4)
 };
 // All band levels in ONE launch: the levels are independent in this stage, and the small ones are
 // pure launch latency on their own.
@@ -338,7 +337,7 @@ __global__ __launch_bounds__(256) void k_rz_phase(PhaseArgs aa) {
         a.amp[fidx] = am;
         a.tc[fidx] = (yhc - ylc) * am;                                     // RieszPyramid.cpp:118-120
         a.ts[fidx] = (yhs - yls) * am;
-        if (a.R1c != a.R1p && a.store_pair) { a.R1c[fidx] = r1; a.R2c[fidx] = r2; }   // batched frames keep their own pair
+        if (a.R1c != a.R1p) { a.R1c[fidx] = r1; a.R2c[fidx] = r2; }        // batched frames keep their own pair
         Pp = p; R1 = r1; R2 = r2;                                          // MagnifyCore.hpp:267
     }
     if (!ok) return;
@@ -527,49 +526,19 @@ __global__ __launch_bounds__(256) void k_rz_blur_amp4(BlurArgs aa) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) { bl[f][0][m] = acc0[m]; bl[f][1][m] = acc1[m]; }
     }
-    // fourth pass through the same LDS buffer: the band tile.  The Riesz pair of the current band
-    // (RieszPyramidLevel::build, RieszPyramid.cpp:66-78: filter2D with [-0.2 -0.48 0 0.48 0.2] and its transpose,
-    // REFLECT_101) is recomputed here with the phase kernel's fma chain instead of being written there and read
-    // back (2 x 4 bytes per band pixel and frame each way).
-    __syncthreads();
-    {
-        const float* src = a.band + pl;
-        if (interior) {
-#pragma unroll 1
-            for (int i = threadIdx.x; i < B2SH * (B2SW / 4); i += 256) {
-                const int ly = i / (B2SW / 4), g = i - ly * (B2SW / 4);
-                *reinterpret_cast<float4*>(&s[ly][4 * g]) =
-                    *reinterpret_cast<const float4*>(src + (size_t)(y0 - B2HY + ly) * a.w + (x0 - B2HX + 4 * g));
-            }
-        } else {
-#pragma unroll 1
-            for (int i = threadIdx.x; i < B2SH * B2SW; i += 256) {
-                const int ly = i / B2SW, lx = i - ly * B2SW;
-                s[ly][lx] = src[(size_t)reflect101(y0 - B2HY + ly, a.h) * a.w + reflect101(x0 - B2HX + lx, a.w)];
-            }
-        }
-    }
-    __syncthreads();
     const int gx = x0 + x, gy = y0 + y;
     if (gx >= a.w || gy >= a.h) return;
 #pragma unroll
     for (int d = 0; d < 2; ++d) {
         if (gy + d >= a.h) break;
         const size_t idx = pl + (size_t)(gy + d) * a.w + gx;
-        const int ly = y + d + B2HY, lx = x + B2HX;
+        const float4 r1 = *reinterpret_cast<const float4*>(a.R1 + idx), r2 = *reinterpret_cast<const float4*>(a.R2 + idx),
+                     bd = *reinterpret_cast<const float4*>(a.band + idx);
+        const float* R1 = &r1.x; const float* R2 = &r2.x; const float* Bd = &bd.x;
         float o[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-            float r1 = __builtin_fmaf(-0.2f, s[ly][lx + m - 2], 0.f);
-            r1 = __builtin_fmaf(-0.48f, s[ly][lx + m - 1], r1);
-            r1 = __builtin_fmaf(0.48f, s[ly][lx + m + 1], r1);
-            r1 = __builtin_fmaf(0.2f, s[ly][lx + m + 2], r1);
-            float r2 = __builtin_fmaf(-0.2f, s[ly - 2][lx + m], 0.f);
-            r2 = __builtin_fmaf(-0.48f, s[ly - 1][lx + m], r2);
-            r2 = __builtin_fmaf(0.48f, s[ly + 1][lx + m], r2);
-            r2 = __builtin_fmaf(0.2f, s[ly + 2][lx + m], r2);
-            o[m] = rz_amplify<EXACT>(bl[0][d][m], bl[1][d][m], bl[2][d][m], r1, r2, s[ly][lx + m], aa.alpha, aa.thr);
-        }
+        for (int m = 0; m < 4; ++m)
+            o[m] = rz_amplify<EXACT>(bl[0][d][m], bl[1][d][m], bl[2][d][m], R1[m], R2[m], Bd[m], aa.alpha, aa.thr);
         *reinterpret_cast<float4*>(a.bandA + idx) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
@@ -801,9 +770,6 @@ static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B,
     }
 }
 
-// levels served by the register-blocked Gaussian/amplify kernel (which recomputes the Riesz pair itself)
-static bool rz_blur4_level(const RieszState* st, int l) { return st->blur4 && st->g[l].w % 4 == 0 && st->g[l].w >= 128 && st->g[l].h >= 64; }
-
 static void rz_phase(Ctx* c, RieszState* st, const RzBufs& B, int mode, hipStream_t s) {
     const int NS = c->nstreams, nb = st->levels - 1;
     if (nb < 1) return;
@@ -824,7 +790,6 @@ static void rz_phase(Ctx* c, RieszState* st, const RzBufs& B, int mode, hipStrea
         v.tx = (v.w + PT_W - 1) / PT_W; v.ty = (v.h + PT_H - 1) / PT_H;
         v.block0 = blocks;
         v.fs = (long)NS * (long)st->g[l].n;
-        v.store_pair = rz_blur4_level(st, l) ? 0 : 1;
         blocks += v.tx * v.ty * NS;
     }
     LVM_LAUNCH(c, mode ? "rz_seed" : "rz_phase", k_rz_phase, dim3(blocks), dim3(256), s, a);
@@ -847,7 +812,7 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
         BlurArgs a4 = a;
         int blocks = 0, blocks4 = 0, n1 = 0, n4 = 0;
         for (int l = 0; l < nb; ++l) {
-            const bool big = rz_blur4_level(st, l);
+            const bool big = st->blur4 && st->g[l].w % 4 == 0 && st->g[l].w >= 128 && st->g[l].h >= 64;
             BlurLv& v = big ? a4.lv[n4++] : a.lv[n1++];
             float** q = B.pf[l];
             v.amp = q[F_AMP]; v.tc = q[F_TC]; v.ts = q[F_TS]; v.band = q[F_BAND]; v.R1 = q[F_R1C]; v.R2 = q[F_R2C]; v.bandA = q[F_BANDA];

@@ -265,8 +265,7 @@ def test_frames_api_other_modes_fall_back_frame_by_frame(lvm, po, emu):
     _frames_clip(lvm, po, emu, 3, 96, 64, 3, 1, (4, 3))
 
 
-@pytest.mark.parametrize("w,h,levels,ns,calls", [(96, 64, 3, 1, (2, 5, 3)), (135, 77, 4, 2, (3, 4)), (160, 90, 5, 1, (6, 2)), (64, 48, 1, 1, (4,)),
-                                                  (264, 150, 3, 2, (3, 3))])   # two streams through the register-blocked blur (pair recomputed there)
+@pytest.mark.parametrize("w,h,levels,ns,calls", [(96, 64, 3, 1, (2, 5, 3)), (135, 77, 4, 2, (3, 4)), (160, 90, 5, 1, (6, 2)), (64, 48, 1, 1, (4,))])
 def test_riesz_emu_temporal_batches(lvm, po, emu, w, h, levels, ns, calls):
     _frames_clip(lvm, po, emu, 2, w, h, levels, ns, calls)
 
