@@ -550,6 +550,27 @@ __global__ __launch_bounds__(256) void k_rz_blur_amp4(BlurArgs aa) {
 __device__ __forceinline__ void collapse_stage(float (&sb)[CSH][CSW], float (&su)[CSH][CSW],
                                                const float* __restrict__ bandA, const float* __restrict__ resn,
                                                int w, int h, int nw, int nh, int x0, int y0) {
+    // Interior tiles of planes whose width is a multiple of 4 need no reflection: the band tile is 432 aligned
+    // 128-bit loads, and the zero-injected tile is its 12 even rows, each 36 consecutive coarse values spread as
+    // (v, 0, v', 0), plus 12 rows of zeros -- about a tenth of the instructions of the per-element path below,
+    // which was ~40 % of this kernel's instruction count.
+    const bool interior = (w & 3) == 0 && x0 - SH >= 0 && x0 + CW + SH <= w && y0 - SH >= 0 && y0 + CH + SH <= h;
+    if (interior) {
+        for (int i = threadIdx.x; i < CSH * (CSW / 4); i += 256) {
+            const int ly = i / (CSW / 4), g = i - ly * (CSW / 4);
+            *reinterpret_cast<float4*>(&sb[ly][4 * g]) =
+                *reinterpret_cast<const float4*>(bandA + (size_t)(y0 - SH + ly) * w + (x0 - SH + 4 * g));
+        }
+        // tile origin (x0 - 4, y0 - 4) is even-even, so local parity = image parity
+        const int cx0 = (x0 - SH) >> 1, cy0 = (y0 - SH) >> 1;
+        for (int i = threadIdx.x; i < (CSH / 2) * (CSW / 4); i += 256) {
+            const int r = i / (CSW / 4), g = i - r * (CSW / 4);
+            const float2 v = *reinterpret_cast<const float2*>(resn + (size_t)(cy0 + r) * nw + (cx0 + 2 * g));   // 8-byte aligned: cx0, nw even
+            *reinterpret_cast<float4*>(&su[2 * r][4 * g]) = make_float4(v.x, 0.f, v.y, 0.f);
+            *reinterpret_cast<float4*>(&su[2 * r + 1][4 * g]) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < CSH * CSW; i += 256) {
         const int ly = i / CSW, lx = i - ly * CSW;
         const int yr = reflect101(y0 - SH + ly, h), xr = reflect101(x0 - SH + lx, w);
