@@ -585,28 +585,34 @@ __device__ __forceinline__ void collapse_stage(float (&sb)[CSH][CSW], float (&su
 }
 // 4 adjacent outputs (lx..lx+3, ly), lx % 4 == 0; gx0 = image column of lx (even, tiles start at
 // multiples of 64), gy = image row.  Polyphase low-pass of the zero-injected image + high-pass.
-__device__ __forceinline__ void collapse_px4(const float (&sb)[CSH][CSW], const float (&su)[CSH][CSW],
-                                             int lx, int ly, int gy, float (&o)[4]) {
-    float lp[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool odd = (gy & 1) != 0;                 // rows i == gy (mod 2)
+// polyphase low-pass of the zero-injected tile for the 4 outputs; ODD = parity of the image row (the kernel rows
+// i == gy (mod 2) are the only ones that meet non-zero samples: 0,2,4,6,8 or 1,3,5,7)
+template <bool ODD>
+__device__ __forceinline__ void collapse_lp4(const float (&su)[CSH][CSW], int lx, int ly, float (&lp)[4]) {
+    lp[0] = lp[1] = lp[2] = lp[3] = 0.f;
 #pragma unroll
-    for (int ii = 0; ii < 5; ++ii) {
-        const int ie = 2 * ii, io = 2 * ii + 1 < 9 ? 2 * ii + 1 : 8;
-        const int i = odd ? io : ie;
-        const bool row_ok = !(odd && ii == 4);      // odd rows: i = 1,3,5,7 only
+    for (int ii = 0; ii < (ODD ? 4 : 5); ++ii) {
+        const int i = ODD ? 2 * ii + 1 : 2 * ii;
         const float4 a = *reinterpret_cast<const float4*>(&su[ly + i][lx]);
         const float4 b = *reinterpret_cast<const float4*>(&su[ly + i][lx + 4]);
         const float4 c = *reinterpret_cast<const float4*>(&su[ly + i][lx + 8]);
         const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
-        if (row_ok) {
 #pragma unroll
-            for (int j = 0; j < 9; ++j) {           // output m (column parity m & 1) uses taps j == m (mod 2)
-                const float kv = (odd ? kLp9[io * 9 + j] : kLp9[ie * 9 + j]) * 2.0f;
-                if ((j & 1) == 0) { lp[0] = __builtin_fmaf(kv, v[j], lp[0]); lp[2] = __builtin_fmaf(kv, v[j + 2], lp[2]); }
-                else { lp[1] = __builtin_fmaf(kv, v[j + 1], lp[1]); lp[3] = __builtin_fmaf(kv, v[j + 3], lp[3]); }
-            }
+        for (int j = 0; j < 9; ++j) {           // output m (column parity m & 1) uses taps j == m (mod 2)
+            const float kv = kLp9[i * 9 + j] * 2.0f;
+            if ((j & 1) == 0) { lp[0] = __builtin_fmaf(kv, v[j], lp[0]); lp[2] = __builtin_fmaf(kv, v[j + 2], lp[2]); }
+            else { lp[1] = __builtin_fmaf(kv, v[j + 1], lp[1]); lp[3] = __builtin_fmaf(kv, v[j + 3], lp[3]); }
         }
     }
+}
+// The row parity is uniform across a wave (collapse_row() below maps waves 0-1 to the even rows of the tile
+// and waves 2-3 to the odd ones), so the parity test is a scalar branch and every tap weight an immediate.
+__device__ __forceinline__ int collapse_row() { return ((threadIdx.x >> 4) & 7) * 2 + (threadIdx.x >> 7); }
+__device__ __forceinline__ void collapse_px4(const float (&sb)[CSH][CSW], const float (&su)[CSH][CSW],
+                                             int lx, int ly, int gy, float (&o)[4]) {
+    float lp[4];
+    if (__builtin_amdgcn_readfirstlane(gy & 1)) collapse_lp4<true>(su, lx, ly, lp);
+    else collapse_lp4<false>(su, lx, ly, lp);
     float hp[4];
     conv9x4(sb, lx, ly, kHp9, 1.0f, hp);
 #pragma unroll
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(256) void k_rz_collapse(const float* __restrict__ b
     const size_t pl = (size_t)blockIdx.z * w * h, pn = (size_t)blockIdx.z * nw * nh;
     collapse_stage(sb, su, bandA + pl, resn + pn, w, h, nw, nh, x0, y0);
     __syncthreads();
-    const int y = threadIdx.x >> 4, x = (threadIdx.x & 15) * 4;
+    const int y = collapse_row(), x = (threadIdx.x & 15) * 4;
     const int gx = x0 + x, gy = y0 + y;
     if (gx < w && gy < h) {
         float o[4];
@@ -652,7 +658,7 @@ __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in
     load_gamma_u8(s_gam, lab.gamma_u8);
     __syncthreads();
     const int ntiles = tiles_x * tiles_y * nstreams;
-    const int y = threadIdx.x >> 4, x = (threadIdx.x & 15) * 4;
+    const int y = collapse_row(), x = (threadIdx.x & 15) * 4;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int b = t / (tiles_x * tiles_y);
         const int r = t - b * (tiles_x * tiles_y);
