@@ -210,6 +210,96 @@ __global__ __launch_bounds__(256) void k_rz_split(const float* __restrict__ oct,
     }
 }
 
+// Variant with twice the tile height (64 x 32) and 4 x 2 outputs per thread: k_rz_split keeps the LDS pipe ~70 %
+// busy (SQ counters, profiles/), this one reads 10 instead of 18 kernel rows per 8 high-pass outputs and 11
+// instead of 18 per 2 low-pass outputs (110 B of LDS traffic per pixel instead of 195).  Same accumulation
+// order per output.  Used for planes whose width is a multiple of 4.
+constexpr int C2H = 32, C2SH = C2H + 2 * SH;
+__global__ __launch_bounds__(256) void k_rz_split2(const float* __restrict__ oct, int w, int h,
+                                                      float* __restrict__ band, float* __restrict__ next, int nw, int nh) {
+    __shared__ __attribute__((aligned(16))) float s[C2SH][CSW];
+    const int x0 = blockIdx.x * CW, y0 = blockIdx.y * C2H;
+    const float* src = oct + (size_t)blockIdx.z * w * h;
+    const bool interior = x0 - SH >= 0 && x0 + CW + SH <= w && y0 - SH >= 0 && y0 + C2H + SH <= h;
+    if (interior) {
+        for (int i = threadIdx.x; i < C2SH * (CSW / 4); i += 256) {
+            const int ly = i / (CSW / 4), g = i - ly * (CSW / 4);
+            *reinterpret_cast<float4*>(&s[ly][4 * g]) = *reinterpret_cast<const float4*>(src + (size_t)(y0 - SH + ly) * w + (x0 - SH + 4 * g));
+        }
+    } else {
+        for (int i = threadIdx.x; i < C2SH * CSW; i += 256) {
+            const int ly = i / CSW, lx = i - ly * CSW;
+            s[ly][lx] = src[(size_t)reflect101(y0 - SH + ly, h) * w + reflect101(x0 - SH + lx, w)];
+        }
+    }
+    __syncthreads();
+    {   // high-pass band: 4 columns x 2 rows per thread, kernel rows 0..9 of the window feed both output rows
+        const int yq = threadIdx.x >> 4, x = (threadIdx.x & 15) * 4, y = 2 * yq;
+        const int gx = x0 + x, gy = y0 + y;
+        float o0[4] = {0.f, 0.f, 0.f, 0.f}, o1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const float4 a = *reinterpret_cast<const float4*>(&s[y + r][x]);
+            const float4 b = *reinterpret_cast<const float4*>(&s[y + r][x + 4]);
+            const float4 c = *reinterpret_cast<const float4*>(&s[y + r][x + 8]);
+            const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+            if (r < 9) {                           // kernel row r of output row 0
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const float kv = kHp9[r * 9 + j];
+                    if (kv != 0.f) {
+                        o0[0] = __builtin_fmaf(kv, v[j], o0[0]); o0[1] = __builtin_fmaf(kv, v[j + 1], o0[1]);
+                        o0[2] = __builtin_fmaf(kv, v[j + 2], o0[2]); o0[3] = __builtin_fmaf(kv, v[j + 3], o0[3]);
+                    }
+                }
+            }
+            if (r >= 1) {                          // kernel row r-1 of output row 1
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const float kv = kHp9[(r - 1) * 9 + j];
+                    if (kv != 0.f) {
+                        o1[0] = __builtin_fmaf(kv, v[j], o1[0]); o1[1] = __builtin_fmaf(kv, v[j + 1], o1[1]);
+                        o1[2] = __builtin_fmaf(kv, v[j + 2], o1[2]); o1[3] = __builtin_fmaf(kv, v[j + 3], o1[3]);
+                    }
+                }
+            }
+        }
+        if (gx < w && gy < h) {                    // w % 4 == 0: whole groups are inside
+            float* d = band + ((size_t)blockIdx.z * h + gy) * w + gx;
+            *reinterpret_cast<float4*>(d) = make_float4(o0[0], o0[1], o0[2], o0[3]);                  // RieszPyramid.cpp:227
+            if (gy + 1 < h) *reinterpret_cast<float4*>(d + w) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+        }
+    }
+    {   // 2 x low-pass at even pixels: 32 x 16 per tile, two vertically adjacent ones (rows y, y + 2) per thread
+        const int v2 = threadIdx.x >> 5, q = threadIdx.x & 31;
+        const int y = 4 * v2, x = 2 * q;
+        const int gx = x0 + x, gy = y0 + y;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 11; ++r) {
+            const float2 a = *reinterpret_cast<const float2*>(&s[y + r][x]);
+            const float2 b = *reinterpret_cast<const float2*>(&s[y + r][x + 2]);
+            const float2 c = *reinterpret_cast<const float2*>(&s[y + r][x + 4]);
+            const float2 d = *reinterpret_cast<const float2*>(&s[y + r][x + 6]);
+            const float e = s[y + r][x + 8];
+            const float tt[9] = {a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y, e};
+            if (r < 9) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) { const float kv = kLp9[r * 9 + j] * 2.0f; if (kv != 0.f) a0 = __builtin_fmaf(kv, tt[j], a0); }   // :232-234
+            }
+            if (r >= 2) {
+#pragma unroll
+                for (int j = 0; j < 9; ++j) { const float kv = kLp9[(r - 2) * 9 + j] * 2.0f; if (kv != 0.f) a1 = __builtin_fmaf(kv, tt[j], a1); }
+            }
+        }
+        if (gx < w && gy < h) {
+            float* d = next + ((size_t)blockIdx.z * nh + gy / 2) * nw + gx / 2;
+            d[0] = a0;
+            if (gy + 2 < h) d[nw] = a1;
+        }
+    }
+}
+
 // ---- phase difference + amplitude + temporal filters -----------------------------------------
 // RieszPyramidLevel::build (:66-78), computePhaseDifferenceAndAmplitude (:81-111),
 // RieszTemporalFilter::IIRTemporalFilter (TemporalFilter.cpp:340-351), *old = *cur (:267).
@@ -737,6 +827,7 @@ struct RieszState : ModeState {
     int tcap = 0; float* tarena = nullptr;
     float* ft[kMaxLevels + 1][F_ALL_N] = {}; float* oct_t[kMaxLevels + 1] = {}; float* res_t[kMaxLevels + 1] = {};   // per band level: band,P,R1p,R2p,phc,phs,lo0c,lo0s,lo1c,lo1s,hi0c,hi0s,hi1c,hi1s,amp,tc,ts,bandA
     bool inited = false;
+    bool split2 = true;              // 64 x 32 tiles with 4 x 2 outputs per thread in the 9x9 split (LVM_RZ_SPLIT2=0: k_rz_split)
     bool blur4 = true;               // register-blocked Gaussian/amplify kernel on the large levels (LVM_RZ_BLUR4=0: scalar kernel everywhere)
     double lo_freq = 0, hi_freq = 0, fps = 0;
     double la[3] = {}, lb[3] = {}, ha[3] = {}, hb[3] = {};
@@ -792,6 +883,11 @@ static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B,
     }
     for (int l = 0; l < nb; ++l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
+        if (st->split2 && a.w % 4 == 0) {
+            const dim3 grid2((a.w + CW - 1) / CW, (a.h + C2H - 1) / C2H, NZ);
+            LVM_LAUNCH(c, "rz_split", k_rz_split2, grid2, blk, s, (const float*)B.oct[l], a.w, a.h, B.pf[l][F_BAND], B.oct[l + 1], b.w, b.h);
+            continue;
+        }
         const dim3 grid((a.w + CW - 1) / CW, (a.h + CH - 1) / CH, NZ);
         LVM_LAUNCH(c, "rz_split", k_rz_split, grid, blk, s, (const float*)B.oct[l], a.w, a.h, B.pf[l][F_BAND], B.oct[l + 1], b.w, b.h);
     }
@@ -886,6 +982,7 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
     if (!st) {
         st = new RieszState();
         if (const char* e = std::getenv("LVM_RZ_BLUR4")) st->blur4 = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_RZ_SPLIT2")) st->split2 = std::atoi(e) != 0;
         c->state = st;
         const int rc = riesz_alloc(c, st, io.w, io.h, levels);
         if (rc != LVM_OK) return rc;
