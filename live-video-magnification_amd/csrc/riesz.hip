@@ -677,8 +677,8 @@ __device__ __forceinline__ void collapse_stage(float (&sb)[CSH][CSW], float (&su
 // multiples of 64), gy = image row.  Polyphase low-pass of the zero-injected image + high-pass.
 // polyphase low-pass of the zero-injected tile for the 4 outputs; ODD = parity of the image row (the kernel rows
 // i == gy (mod 2) are the only ones that meet non-zero samples: 0,2,4,6,8 or 1,3,5,7)
-template <bool ODD, int ROWS>
-__device__ __forceinline__ void collapse_lp4(const float (&su)[ROWS][CSW], int lx, int ly, float (&lp)[4]) {
+template <bool ODD>
+__device__ __forceinline__ void collapse_lp4(const float (&su)[CSH][CSW], int lx, int ly, float (&lp)[4]) {
     lp[0] = lp[1] = lp[2] = lp[3] = 0.f;
 #pragma unroll
     for (int ii = 0; ii < (ODD ? 4 : 5); ++ii) {
@@ -701,103 +701,15 @@ __device__ __forceinline__ int collapse_row() { return ((threadIdx.x >> 4) & 7) 
 __device__ __forceinline__ void collapse_px4(const float (&sb)[CSH][CSW], const float (&su)[CSH][CSW],
                                              int lx, int ly, int gy, float (&o)[4]) {
     float lp[4];
-    if (__builtin_amdgcn_readfirstlane(gy & 1)) collapse_lp4<true, CSH>(su, lx, ly, lp);
-    else collapse_lp4<false, CSH>(su, lx, ly, lp);
+    if (__builtin_amdgcn_readfirstlane(gy & 1)) collapse_lp4<true>(su, lx, ly, lp);
+    else collapse_lp4<false>(su, lx, ly, lp);
     float hp[4];
     conv9x4(sb, lx, ly, kHp9, 1.0f, hp);
 #pragma unroll
     for (int m = 0; m < 4; ++m) o[m] = lp[m] + hp[m];                                 // :322
 }
 
-// 64 x 32 tiles, 4 x 2 outputs per thread (as k_rz_split2): the 10 band rows a thread reads serve both of its
-// output rows, and since it owns one even and one odd row the polyphase low-pass needs no parity branch.
-__device__ __forceinline__ void collapse_stage2(float (&sb)[C2SH][CSW], float (&su)[C2SH][CSW],
-                                                const float* __restrict__ bandA, const float* __restrict__ resn,
-                                                int w, int h, int nw, int nh, int x0, int y0) {
-    const bool interior = (w & 3) == 0 && x0 - SH >= 0 && x0 + CW + SH <= w && y0 - SH >= 0 && y0 + C2H + SH <= h;
-    if (interior) {
-        for (int i = threadIdx.x; i < C2SH * (CSW / 4); i += 256) {
-            const int ly = i / (CSW / 4), g = i - ly * (CSW / 4);
-            *reinterpret_cast<float4*>(&sb[ly][4 * g]) =
-                *reinterpret_cast<const float4*>(bandA + (size_t)(y0 - SH + ly) * w + (x0 - SH + 4 * g));
-        }
-        const int cx0 = (x0 - SH) >> 1, cy0 = (y0 - SH) >> 1;
-        for (int i = threadIdx.x; i < (C2SH / 2) * (CSW / 4); i += 256) {
-            const int r = i / (CSW / 4), g = i - r * (CSW / 4);
-            const float2 v = *reinterpret_cast<const float2*>(resn + (size_t)(cy0 + r) * nw + (cx0 + 2 * g));
-            *reinterpret_cast<float4*>(&su[2 * r][4 * g]) = make_float4(v.x, 0.f, v.y, 0.f);
-            *reinterpret_cast<float4*>(&su[2 * r + 1][4 * g]) = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        return;
-    }
-    for (int i = threadIdx.x; i < C2SH * CSW; i += 256) {
-        const int ly = i / CSW, lx = i - ly * CSW;
-        const int yr = reflect101(y0 - SH + ly, h), xr = reflect101(x0 - SH + lx, w);
-        sb[ly][lx] = bandA[(size_t)yr * w + xr];
-        float u = 0.f;
-        if (((xr | yr) & 1) == 0) {   // injectZerosEven (:280-302) of resize(INTER_NEAREST) (:314)
-            const int sx = xr / 2 < nw ? xr / 2 : nw - 1, sy = yr / 2 < nh ? yr / 2 : nh - 1;
-            u = resn[(size_t)sy * nw + sx];
-        }
-        su[ly][lx] = u;
-    }
-}
-// outputs (lx..lx+3, ly) -> o0 and (lx..lx+3, ly+1) -> o1; ly even (tile rows start at multiples of 32)
-__device__ __forceinline__ void collapse_px4x2(const float (&sb)[C2SH][CSW], const float (&su)[C2SH][CSW], int lx, int ly,
-                                               float (&o0)[4], float (&o1)[4]) {
-    float h0[4] = {0.f, 0.f, 0.f, 0.f}, h1[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const float4 a = *reinterpret_cast<const float4*>(&sb[ly + r][lx]);
-        const float4 b = *reinterpret_cast<const float4*>(&sb[ly + r][lx + 4]);
-        const float4 c = *reinterpret_cast<const float4*>(&sb[ly + r][lx + 8]);
-        const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
-        if (r < 9) {
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const float kv = kHp9[r * 9 + j];
-                if (kv != 0.f) {
-                    h0[0] = __builtin_fmaf(kv, v[j], h0[0]); h0[1] = __builtin_fmaf(kv, v[j + 1], h0[1]);
-                    h0[2] = __builtin_fmaf(kv, v[j + 2], h0[2]); h0[3] = __builtin_fmaf(kv, v[j + 3], h0[3]);
-                }
-            }
-        }
-        if (r >= 1) {
-#pragma unroll
-            for (int j = 0; j < 9; ++j) {
-                const float kv = kHp9[(r - 1) * 9 + j];
-                if (kv != 0.f) {
-                    h1[0] = __builtin_fmaf(kv, v[j], h1[0]); h1[1] = __builtin_fmaf(kv, v[j + 1], h1[1]);
-                    h1[2] = __builtin_fmaf(kv, v[j + 2], h1[2]); h1[3] = __builtin_fmaf(kv, v[j + 3], h1[3]);
-                }
-            }
-        }
-    }
-    float l0[4], l1[4];
-    collapse_lp4<false, C2SH>(su, lx, ly, l0);
-    collapse_lp4<true, C2SH>(su, lx, ly + 1, l1);
-#pragma unroll
-    for (int m = 0; m < 4; ++m) { o0[m] = l0[m] + h0[m]; o1[m] = l1[m] + h1[m]; }         // :322
-}
-__global__ __launch_bounds__(256) void k_rz_collapse2(const float* __restrict__ bandA, const float* __restrict__ resn,
-                                                      float* __restrict__ res, int w, int h, int nw, int nh) {
-    __shared__ __attribute__((aligned(16))) float sb[C2SH][CSW];
-    __shared__ __attribute__((aligned(16))) float su[C2SH][CSW];
-    const int x0 = blockIdx.x * CW, y0 = blockIdx.y * C2H;
-    const size_t pl = (size_t)blockIdx.z * w * h, pn = (size_t)blockIdx.z * nw * nh;
-    collapse_stage2(sb, su, bandA + pl, resn + pn, w, h, nw, nh, x0, y0);
-    __syncthreads();
-    const int y = 2 * (threadIdx.x >> 4), x = (threadIdx.x & 15) * 4;
-    const int gx = x0 + x, gy = y0 + y;
-    if (gx < w && gy < h) {                        // w % 4 == 0: whole groups are inside
-        float o0[4], o1[4];
-        collapse_px4x2(sb, su, x, y, o0, o1);
-        float* d = res + pl + (size_t)gy * w + gx;
-        *reinterpret_cast<float4*>(d) = make_float4(o0[0], o0[1], o0[2], o0[3]);
-        if (gy + 1 < h) *reinterpret_cast<float4*>(d + w) = make_float4(o1[0], o1[1], o1[2], o1[3]);
-    }
-}
-
+// (a 64 x 32 / 4 x 2 variant of this kernel, like k_rz_split2, needs 300 registers and measured 48 us against 29 us)
 __global__ __launch_bounds__(256) void k_rz_collapse(const float* __restrict__ bandA, const float* __restrict__ resn,
                                                      float* __restrict__ res, int w, int h, int nw, int nh) {
     __shared__ __attribute__((aligned(16))) float sb[CSH][CSW];
@@ -1039,13 +951,8 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
     const float* resn = B.oct[levels - 1];       // res_{L-1} = residual octave
     for (int l = nb - 1; l >= 1; --l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
-        if (st->split2 && a.w % 4 == 0) {
-            const dim3 grid2((a.w + CW - 1) / CW, (a.h + C2H - 1) / C2H, NZ);
-            LVM_LAUNCH(c, "rz_collapse", k_rz_collapse2, grid2, blk, s, (const float*)B.pf[l][F_BANDA], resn, B.res[l], a.w, a.h, b.w, b.h);
-        } else {
-            const dim3 grid((a.w + CW - 1) / CW, (a.h + CH - 1) / CH, NZ);
-            LVM_LAUNCH(c, "rz_collapse", k_rz_collapse, grid, blk, s, (const float*)B.pf[l][F_BANDA], resn, B.res[l], a.w, a.h, b.w, b.h);
-        }
+        const dim3 grid((a.w + CW - 1) / CW, (a.h + CH - 1) / CH, NZ);
+        LVM_LAUNCH(c, "rz_collapse", k_rz_collapse, grid, blk, s, (const float*)B.pf[l][F_BANDA], resn, B.res[l], a.w, a.h, b.w, b.h);
         resn = B.res[l];
     }
     const int tx = (w + CW - 1) / CW, ty = (h + CH - 1) / CH;
