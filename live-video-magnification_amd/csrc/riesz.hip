@@ -95,25 +95,12 @@ __global__ __launch_bounds__(256) void k_rz_lab4(const uint8_t* __restrict__ in,
 }
 
 // ---- 9x9 split: band = hp9 * oct, next octave = (2 lp9 * oct) at even pixels ------------------
-// RieszPyramid.cpp:215-238 (buildPyramid) + subsample (:254-278).  Tile 32x16, halo 4.
-constexpr int ST_W = 32, ST_H = 16, SH = 4;
-constexpr int SS_W = ST_W + 2 * SH, SS_H = ST_H + 2 * SH;
-
-__device__ __forceinline__ float conv9(const float (&s)[SS_H][SS_W + 1], int lx, int ly, const float* k, float kscale) {
-    float acc = 0.f;
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const float kv = k[i * 9 + j] * kscale;   // x2 is exact
-            if (kv != 0.f) acc = __builtin_fmaf(kv, s[ly + i][lx + j], acc);
-        }
-    return acc;
-}
+// RieszPyramid.cpp:215-238 (buildPyramid) + subsample (:254-278).
+constexpr int SH = 4;                      // halo of the 9x9 kernels
 
 // Register-blocked variants: tile 64x16 (+ halo 4), row pitch 72 floats so that the 12 (16) floats a
 // thread needs per kernel row are three (four) aligned 128-bit LDS reads.  Each output keeps its own
-// accumulator and receives its 81 taps in row-major order, exactly like conv9.
+// accumulator and receives its 81 taps in row-major order (filter2D's order).
 constexpr int CW = 64, CH = 16, CSW = CW + 2 * SH, CSH = CH + 2 * SH;
 
 // 4 adjacent outputs (lx..lx+3, ly), lx % 4 == 0.  Fully unrolled: the 81 coefficients become
@@ -133,26 +120,6 @@ __device__ __forceinline__ void conv9x4(const float (&s)[CSH][CSW], int lx, int 
             if (kv != 0.f) {
                 o[0] = __builtin_fmaf(kv, v[j], o[0]); o[1] = __builtin_fmaf(kv, v[j + 1], o[1]);
                 o[2] = __builtin_fmaf(kv, v[j + 2], o[2]); o[3] = __builtin_fmaf(kv, v[j + 3], o[3]);
-            }
-        }
-    }
-}
-// 4 outputs at every second column (lx, lx+2, lx+4, lx+6), lx % 8 == 0 (the decimated low-pass)
-__device__ __forceinline__ void conv9x4s2(const float (&s)[CSH][CSW], int lx, int ly, const float* k, float kscale, float (&o)[4]) {
-    o[0] = o[1] = o[2] = o[3] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        const float4 a = *reinterpret_cast<const float4*>(&s[ly + i][lx]);
-        const float4 b = *reinterpret_cast<const float4*>(&s[ly + i][lx + 4]);
-        const float4 c = *reinterpret_cast<const float4*>(&s[ly + i][lx + 8]);
-        const float4 d = *reinterpret_cast<const float4*>(&s[ly + i][lx + 12]);
-        const float v[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-#pragma unroll
-        for (int j = 0; j < 9; ++j) {
-            const float kv = k[i * 9 + j] * kscale;
-            if (kv != 0.f) {
-                o[0] = __builtin_fmaf(kv, v[j], o[0]); o[1] = __builtin_fmaf(kv, v[j + 2], o[1]);
-                o[2] = __builtin_fmaf(kv, v[j + 4], o[2]); o[3] = __builtin_fmaf(kv, v[j + 6], o[3]);
             }
         }
     }
@@ -202,7 +169,7 @@ __global__ __launch_bounds__(256) void k_rz_split(const float* __restrict__ oct,
 #pragma unroll
                 for (int j = 0; j < 9; ++j) {
                     const float kv = kLp9[i * 9 + j] * 2.0f;                           // x2 is exact
-                    if (kv != 0.f) acc = __builtin_fmaf(kv, t[j], acc);               // :232-234, row-major like conv9
+                    if (kv != 0.f) acc = __builtin_fmaf(kv, t[j], acc);               // :232-234, row-major taps
                 }
             }
             next[((size_t)blockIdx.z * nh + gy / 2) * nw + gx / 2] = acc;
