@@ -246,6 +246,14 @@ def main():
             roofline = {"bound": "hbm", "kernel": dom, "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(k["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "avg_us": k["avg_us"], "alg_bytes_per_launch": k["alg_bytes"]}
+            # what actually limits that kernel, from the committed SQ-counter passes (profiles/*_sq_counters.txt)
+            limiter = {"lap_final": "VALU-bound (Lab arithmetic): 77 % VALU issue utilisation, 31 % LDS",
+                       "lap_down0": "VALU-bound (Lab arithmetic): 68 % VALU issue utilisation",
+                       "rz_blur_amp": "39 % VALU, 51 % LDS busy; 3.2 TB/s of compulsory traffic",
+                       "rz_final": "49 % VALU, 57 % LDS busy (9x9 taps + table lookups)",
+                       "rz_phase": "VALU-bound: 79 % VALU issue utilisation (acosf, sqrt/div, float64 filter products)"}.get(dom)
+            if limiter:
+                roofline["limiter"] = limiter
     b_alg = lvm.load().lvm_algorithmic_bytes(pk["mode"], w, h, ch, levels, pk["framerate"])
     frame_frac = b_alg * (fps / world) / (HBM_PEAK_GBS * 1e9)
 
