@@ -104,12 +104,12 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--levels", type=int, default=0)
-    ap.add_argument("--ring", type=int, default=32, help="distinct input frames kept in HBM")
+    ap.add_argument("--ring", type=int, default=64, help="distinct input frames kept in HBM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay steady-state frames from a captured hipGraph")
-    ap.add_argument("--frames-per-call", type=int, default=16, help="consecutive frames of the stream(s) handed to one lvm_process_device_frames call (1 = per-frame calls)")
+    ap.add_argument("--frames-per-call", type=int, default=32, help="consecutive frames of the stream(s) handed to one lvm_process_device_frames call (1 = per-frame calls)")
     ap.add_argument("--pipeline", type=int, default=0, help="cross-frame pipeline depth of lvm_process_device (0 or 1)")
-    ap.add_argument("--profile-steps", type=int, default=60)
+    ap.add_argument("--profile-steps", type=int, default=-1, help="frames of the per-kernel timing pass (default: two calls of T frames; 0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (smoke-testing the N > 1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     args = ap.parse_args()
@@ -216,9 +216,13 @@ def main():
     # ---- per-kernel timing pass (HIP events on the launch stream) -> roofline ----
     roofline = None
     kernels = {}
+    if args.profile_steps < 0:
+        args.profile_steps = 2 * T if T > 1 else 60        # whole calls only: every launch then covers exactly T frames
     if rank == 0 and args.profile_steps > 0:
         ctx.flush(stream)
         ctx.set_pipeline(0)           # per-kernel event timing uses the plain schedule
+        pad = (-n) % ring             # start on a ring boundary so that every call of the pass covers exactly T frames
+        run_frames(n, pad); n += pad
         ctx.profile(True)
         run_frames(n, args.profile_steps); n += args.profile_steps
         torch.cuda.synchronize()
@@ -229,7 +233,9 @@ def main():
         for name, (ms, cnt) in prof.items():
             avg_us = 1e3 * ms / max(cnt, 1)
             # a launch of the temporally batched schedule covers T_frames frames of every stream
-            ab = kernel_alg_bytes(args.mode, name, w, h, ch, levels, B * T, Twin)
+            # frames one launch covers: T, except that the colour mode cuts a call into chunks of <= 16 frames (window ring)
+            T_launch = min(T, 16) if args.mode == "color" else T
+            ab = kernel_alg_bytes(args.mode, name, w, h, ch, levels, B * T_launch, Twin)
             kernels[name] = {"avg_us": round(avg_us, 3), "launches": cnt, "share": round(ms / tot, 4),
                              "alg_bytes": ab, "gbs": (round(ab / (avg_us * 1e-6) / 1e9, 1) if ab else None)}
         dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
