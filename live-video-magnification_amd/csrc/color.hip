@@ -582,9 +582,6 @@ __global__ __launch_bounds__(256) void k_col_out_rows(OutArgs a, int strips_x, i
             const int i0 = gx >> 1;
             const unsigned cm1 = 4u * (i0 > 0 ? i0 - 1 : 0), c00 = 4u * i0, cp1 = 4u * (i0 + 1 < a.vw ? i0 + 1 : a.vw - 1),
                            cp2 = 4u * (i0 + 2 < a.vw ? i0 + 2 : a.vw - 1);
-            const bool hf0 = i0 == 0, hl0 = i0 == a.vw - 1, hl1 = i0 + 1 == a.vw - 1;
-            const float hw_ax = hf0 ? 0.f : 1.f, hw_bx = (!hf0 && hl0) ? 7.f : 6.f, hw_cx = hf0 ? 2.f : (hl0 ? 0.f : 1.f), hw_my = hl0 ? 0.f : 1.f,
-                        hw_ky = hl0 ? 8.f : 4.f, hw_bz = hl1 ? 7.f : 6.f, hw_cz = hl1 ? 0.f : 1.f, hw_mw = hl1 ? 0.f : 1.f, hw_kw = hl1 ? 8.f : 4.f;
             auto hrow = [&](int vy) __attribute__((always_inline)) {       // horizontal pyrUp pass of V row vy (border map -1 -> 1, vh -> vh - 1)
                 HRow3 o;
                 vy = vy < 0 ? 1 : (vy >= a.vh ? a.vh - 1 : vy);
@@ -594,11 +591,11 @@ __global__ __launch_bounds__(256) void k_col_out_rows(OutArgs a, int strips_x, i
                     const char* rc = row + c * pstride * sizeof(float);
                     const float sm1 = *reinterpret_cast<const float*>(rc + cm1), s0 = *reinterpret_cast<const float*>(rc + c00),
                                 s1 = *reinterpret_cast<const float*>(rc + cp1), s2 = *reinterpret_cast<const float*>(rc + cp2);
-                    // border rules folded into per-lane weights (same values as the selected formulas: x*1 and + y*0 are exact)
-                    o.c[c].x = (sm1 * hw_ax + s0 * hw_bx) + s1 * hw_cx;
-                    o.c[c].y = (s0 + s1 * hw_my) * hw_ky;
-                    o.c[c].z = (s0 + s1 * hw_bz) + s2 * hw_cz;
-                    o.c[c].w = (s1 + s2 * hw_mw) * hw_kw;
+                    const bool f0 = i0 == 0, l0 = i0 == a.vw - 1, l1 = i0 + 1 == a.vw - 1;
+                    o.c[c].x = sel(f0, s0 * 6.f + s1 * 2.f, sel(l0, sm1 + s0 * 7.f, sm1 + s0 * 6.f + s1));
+                    o.c[c].y = sel(l0, s0 * 8.f, (s0 + s1) * 4.f);
+                    o.c[c].z = sel(l1, s0 + s1 * 7.f, s0 + s1 * 6.f + s2);
+                    o.c[c].w = sel(l1, s1 * 8.f, (s1 + s2) * 4.f);
                 }
                 return o;
             };

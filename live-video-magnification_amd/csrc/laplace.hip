@@ -154,27 +154,20 @@ __global__ __launch_bounds__(256) void k_lap_up(UpArgs a) {
 
 // pyrUp horizontal pass for 4 consecutive destination columns gx0..gx0+3 (gx0 even) from the source
 // values s[i0-1..i0+2], i0 = gx0/2 (indices outside the plane are never used by the border rules)
-// The border rules only change WEIGHTS, so a lane folds them once into per-lane constants and the pass is a
-// fixed mul/add sequence: general x = (sm1*1 + s0*6) + s1*1, first column (s0*6) + s1*2, last column
-// (sm1 + s0*7) + s1*0; y = (s0 + s1*1)*4 or (s0 + s1*0)*8; z, w likewise one source column further.
-// Multiplying by 1 and adding x*0 are exact for finite x, so the results equal the branchy formulas (up to
-// the sign of a zero).
-struct H4W { float ax, bx, cx, my, ky, bz, cz, mw, kw; };
-__device__ __forceinline__ H4W pyrup_h4_weights(int i0, int sw) {
+__device__ __forceinline__ float4 pyrup_h4(float sm1, float s0, float s1, float s2, int i0, int sw) {
+    // every border variant is evaluated and the result selected (v_cndmask): divergent branches around
+    // two or three float operations cost far more than the operations
     const bool f0 = i0 == 0, l0 = i0 == sw - 1, l1 = i0 + 1 == sw - 1;
-    H4W w;
-    w.ax = f0 ? 0.f : 1.f; w.bx = (!f0 && l0) ? 7.f : 6.f; w.cx = f0 ? 2.f : (l0 ? 0.f : 1.f);
-    w.my = l0 ? 0.f : 1.f; w.ky = l0 ? 8.f : 4.f;
-    w.bz = l1 ? 7.f : 6.f; w.cz = l1 ? 0.f : 1.f;
-    w.mw = l1 ? 0.f : 1.f; w.kw = l1 ? 8.f : 4.f;
-    return w;
-}
-__device__ __forceinline__ float4 pyrup_h4(float sm1, float s0, float s1, float s2, const H4W& w) {
+    const float p6 = s0 * 6.f, q6 = s1 * 6.f;
+    const float e_gen = sm1 + p6 + s1, e_first = p6 + s1 * 2.f, e_last = sm1 + s0 * 7.f;
+    const float o_gen = (s0 + s1) * 4.f, o_last = s0 * 8.f;
+    const float z_gen = s0 + q6 + s2, z_last = s0 + s1 * 7.f;      // i0 + 1 >= 1 always
+    const float w_gen = (s1 + s2) * 4.f, w_last = s1 * 8.f;
     float4 o;
-    o.x = (sm1 * w.ax + s0 * w.bx) + s1 * w.cx;
-    o.y = (s0 + s1 * w.my) * w.ky;
-    o.z = (s0 + s1 * w.bz) + s2 * w.cz;
-    o.w = (s1 + s2 * w.mw) * w.kw;
+    o.x = sel(f0, e_first, sel(l0, e_last, e_gen));
+    o.y = sel(l0, o_last, o_gen);
+    o.z = sel(l1, z_last, z_gen);
+    o.w = sel(l1, w_last, w_gen);
     return o;
 }
 
@@ -241,22 +234,19 @@ __global__ __launch_bounds__(256) void k_lap_up_rows(UpArgs a, int gw, int ngrou
         }
         if (tl + 1 < a.nt) { ++tl; Gn += a.fsn * sizeof(float); Cn += a.fsn * sizeof(float); Gl += a.fsl * sizeof(float); }
     };
-    // horizontal pyrUp pass of one source row for the W destination columns gx .. gx+W-1: the border rules are
-    // folded into per-lane weights once (see pyrup_h4_weights), the pass itself is a fixed mul/add sequence
-    float wa[W / 2], wb[W / 2], wc[W / 2], wm[W / 2], wk[W / 2];
-#pragma unroll
-    for (int k = 0; k < W / 2; ++k) {
-        const int i = i0 + k;                            // source column of the destination pair (2i, 2i+1)
-        const bool fi = i == 0, la = i == a.wn - 1;
-        wa[k] = fi ? 0.f : 1.f; wb[k] = (!fi && la) ? 7.f : 6.f; wc[k] = fi ? 2.f : (la ? 0.f : 1.f);
-        wm[k] = la ? 0.f : 1.f; wk[k] = la ? 8.f : 4.f;
-    }
+    // horizontal pyrUp pass of one source row for the W destination columns gx .. gx+W-1 (all border
+    // variants evaluated, result selected: no divergent branches)
     auto hpass = [&](const float (&sv)[NT], float (&o)[W]) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < W / 2; ++k) {
+            const int i = i0 + k;                        // source column of the destination pair (2i, 2i+1)
+            const bool fi = i == 0, la = i == a.wn - 1;
             const float sm1 = sv[k], s0 = sv[k + 1], s1 = sv[k + 2];
-            o[2 * k] = (sm1 * wa[k] + s0 * wb[k]) + s1 * wc[k];
-            o[2 * k + 1] = (s0 + s1 * wm[k]) * wk[k];
+            const float p6 = s0 * 6.f;
+            const float e_gen = sm1 + p6 + s1, e_first = p6 + s1 * 2.f, e_last = sm1 + s0 * 7.f;
+            const float o_gen = (s0 + s1) * 4.f, o_last = s0 * 8.f;
+            o[2 * k] = sel(fi, e_first, sel(la, e_last, e_gen));
+            o[2 * k + 1] = sel(la, o_last, o_gen);
         }
     };
     char* cur = reinterpret_cast<char*>(a.cur + pl);
@@ -424,7 +414,6 @@ __global__ __launch_bounds__(FIN_THREADS) void k_lap_final_v4(const uint8_t* __r
         const int i0 = gx >> 1;
         const unsigned cm1 = 4u * (i0 > 0 ? i0 - 1 : 0), c00 = 4u * i0, cp1 = 4u * (i0 + 1 < w1 ? i0 + 1 : w1 - 1), cp2 = 4u * (i0 + 2 < w1 ? i0 + 2 : w1 - 1);   // byte offsets
         const size_t pstride = (size_t)w1 * h1;
-        const H4W hw = pyrup_h4_weights(i0, w1);
         // horizontal pass of source row sy (vertical border map: row -1 -> 1, row h1 -> h1 - 1); the row
         // base is uniform, the four column offsets are per-lane byte offsets
         auto hrow = [&](int sy) __attribute__((always_inline)) {
@@ -435,7 +424,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_lap_final_v4(const uint8_t* __r
             for (int c = 0; c < 3; ++c) {
                 const char* rc = row + c * pstride * sizeof(float);
                 o.c[c] = pyrup_h4(*reinterpret_cast<const float*>(rc + cm1), *reinterpret_cast<const float*>(rc + c00),
-                                  *reinterpret_cast<const float*>(rc + cp1), *reinterpret_cast<const float*>(rc + cp2), hw);
+                                  *reinterpret_cast<const float*>(rc + cp1), *reinterpret_cast<const float*>(rc + cp2), i0, w1);
             }
             return o;
         };
