@@ -275,3 +275,35 @@ def test_color_emu_temporal_batches(lvm, po, emu, w, h, levels, ns, calls):
     """fps 7 -> the window caps at 16 columns: once it is full the remaining frames of a call share
     launches (every frame of a batch sees the ring shifted by one column)."""
     _frames_clip(lvm, po, emu, 3, w, h, levels, ns, calls, over={"framerate": 7.0, "coLow": 0.4, "coHigh": 2.0}, clip_over={"fps": 7.0})
+
+
+# ---- ragged rows: strides larger than the row ---------------------------------------------------------
+@pytest.mark.parametrize("idx,pad_in,pad_out", [(0, 4, 8), (0, 1, 3), (2, 4, 4), (2, 7, 1), (3, 8, 4), (3, 5, 5)])
+def test_emu_padded_row_strides(lvm, po, emu, idx, pad_in, pad_out):
+    """lvm_process_device on frames whose rows are padded (a cv::Mat ROI view has step > cols * channels):
+    dword-aligned paddings keep the vectorised kernels, odd ones select the generic byte kernels; the padding
+    bytes of the output must stay untouched."""
+    w, h, levels = 96, 64, 3
+    ck, pk = lvm.synth.config(idx, (w, h, levels))
+    clip = lvm.synth.Clip(**ck)
+    P = po.make_params(**pk)
+    cp = c_params(lvm, pk)
+    ctx = lvm.Context(0, 1, emu)
+    ctx.exact_lab(True)
+    orc = po.Oracle()
+    si, so = w * 3 + pad_in, w * 3 + pad_out
+    try:
+        for t in range(6):
+            f = clip.frame(t)
+            buf_in = np.full((h, si), 0xAB, np.uint8)
+            buf_in[:, :w * 3] = f.reshape(h, w * 3)
+            buf_out = np.full((h, so), 0xCD, np.uint8)
+            ref, pr = orc.process(f, P)
+            pg = ctx.process_device(cp, buf_in.ctypes.data, w, h, 3, si, si * h, buf_out.ctypes.data, so, so * h)
+            ctx.synchronize()
+            assert pr == pg
+            assert (buf_out[:, w * 3:] == 0xCD).all(), "padding bytes of the output were written"
+            if pr:
+                assert np.array_equal(buf_out[:, :w * 3].reshape(h, w, 3), ref), "frame %d" % t
+    finally:
+        ctx.close(); orc.close()

@@ -93,6 +93,41 @@ def test_laplace_batched_streams_device_path(lvm, po, hip):
     ctx.close()
 
 
+@pytest.mark.parametrize("idx,pad_in,pad_out", [(0, 4, 8), (0, 1, 3), (2, 4, 4), (2, 7, 1), (3, 8, 4), (3, 5, 5)])
+def test_padded_row_strides_device_path(lvm, po, hip, idx, pad_in, pad_out):
+    """Ragged rows (stride > width * channels, as a cv::Mat ROI view has): dword-aligned paddings keep the
+    vectorised kernels, odd ones select the byte kernels; the padding bytes of the output stay untouched."""
+    import torch
+    w, h, levels = 320, 180, 4
+    ck, pk = lvm.synth.config(idx, (w, h, levels))
+    clip = lvm.synth.Clip(**ck)
+    P = po.make_params(**pk)
+    cp = c_params(lvm, pk)
+    ctx = lvm.Context(0, 1, hip)
+    orc = po.Oracle()
+    si, so = w * 3 + pad_in, w * 3 + pad_out
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        for t in range(6):
+            f = clip.frame(t)
+            buf_in = np.full((h, si), 0xAB, np.uint8)
+            buf_in[:, :w * 3] = f.reshape(h, w * 3)
+            d_in = torch.from_numpy(buf_in).cuda()
+            d_out = torch.full((h, so), 0xCD, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()
+            ref, pr = orc.process(f, P)
+            pg = ctx.process_device(cp, d_in.data_ptr(), w, h, 3, si, si * h, d_out.data_ptr(), so, so * h, stream)
+            torch.cuda.synchronize()
+            assert pr == pg
+            got = d_out.cpu().numpy()
+            assert (got[:, w * 3:] == 0xCD).all(), "padding bytes of the output were written"
+            if pr:
+                du = np.abs(ref.astype(int) - got[:, :w * 3].reshape(h, w, 3).astype(int))
+                assert du.max() <= 1 and (du == 0).mean() >= 0.999
+    finally:
+        ctx.close(); orc.close()
+
+
 def test_passthrough_and_errors(lvm, po, hip):
     ctx = lvm.Context(0, 1, hip)
     f = np.full((40, 40, 3), 90, np.uint8)
