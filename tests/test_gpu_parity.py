@@ -165,6 +165,38 @@ def test_riesz_1080p_full_size(lvm, po, hip):
     print("riesz 1080p worst", worst)
 
 
+def test_riesz_4k_8_levels_configs4(lvm, po, hip):
+    """BASELINE configs[4]'s per-GPU share at its full size (3840x2160, 8 levels): a few frames against the oracle,
+    per-frame calls and one temporal batch of the same stream."""
+    import torch
+    ck, pk = lvm.synth.config(4)
+    worst = run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 3, FLOAT_TOL)
+    print("riesz 4K worst", worst)
+    clip = lvm.synth.Clip(**ck)
+    w, h = ck["w"], ck["h"]
+    frames = np.stack([clip.frame(t) for t in range(5)])
+    ctx = lvm.Context(0, 1, hip)
+    orc = po.Oracle()
+    P = po.make_params(**pk)
+    cp = c_params(lvm, pk)
+    try:
+        d_in = torch.from_numpy(frames).cuda()
+        d_out = torch.zeros_like(d_in)
+        fb = w * h * 3
+        st = torch.cuda.current_stream().cuda_stream
+        prod = ctx.process_device_frames(cp, 5, d_in.data_ptr(), w, h, 3, w * 3, fb, fb, d_out.data_ptr(), w * 3, fb, fb, st)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        for t in range(5):
+            ref, pr = orc.process(frames[t], P)
+            assert pr == prod[t]
+            if pr:
+                du = np.abs(ref.astype(int) - got[t].astype(int))
+                assert du.max() <= 1 and (du == 0).mean() >= 0.999, (t, du.max(), (du == 0).mean())
+    finally:
+        ctx.close(); orc.close()
+
+
 def test_riesz_cutoff_change(lvm, po, hip):
     ck, pk = lvm.synth.config(2, (320, 180, 4))
 
