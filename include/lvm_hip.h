@@ -126,6 +126,14 @@ int  lvm_chain_process(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_
                        int w, int h, int channels, ptrdiff_t in_stride, uint8_t* out, ptrdiff_t out_stride,
                        int* produced);
 
+/* The same for all n_streams streams of a context at once (one processing thread feeding N
+ * cameras): in[s] / out[s] are the host frames of stream s, all with the same geometry and parameters; one
+ * preprocess launch and one launch per magnifier stage cover every stream.  *produced applies to all streams
+ * (they share mode, geometry and history length).                                                     */
+int  lvm_chain_process_batch(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_params* p,
+                             const uint8_t* const* in, int w, int h, int channels, ptrdiff_t in_stride,
+                             uint8_t* const* out, ptrdiff_t out_stride, int* produced);
+
 /* Cross-frame software pipeline for lvm_process_device (throughput mode, default depth 0).
  * depth 1 (implemented for the Laplace mode; other modes ignore it): a call enqueues the
  * down-sweep of ITS frame on an internal second stream concurrently with the up-sweep + output of

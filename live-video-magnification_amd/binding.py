@@ -95,7 +95,7 @@ SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process
            "lvm_last_error", "lvm_max_levels", "lvm_optimal_buffer_size", "lvm_butterworth2",
            "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_profile_enable", "lvm_profile_collect",
            "lvm_profile_entry", "lvm_set_graph", "lvm_algorithmic_bytes",
-           "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process"]
+           "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process", "lvm_chain_process_batch"]
 
 
 def bind(lib):
@@ -137,6 +137,8 @@ def bind(lib):
                                           C.c_ssize_t, vp, C.c_ssize_t, C.c_ssize_t, vp]
     lib.lvm_chain_process.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), vp, C.c_int, C.c_int, C.c_int,
                                       C.c_ssize_t, vp, C.c_ssize_t, ip]
+    lib.lvm_chain_process_batch.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), C.POINTER(vp), C.c_int, C.c_int,
+                                            C.c_int, C.c_ssize_t, C.POINTER(vp), C.c_ssize_t, ip]
     return lib
 
 
@@ -200,6 +202,22 @@ class Context:
     def preprocess_device(self, cpre, d_in, w, h, ch, in_stride, in_sstride, d_out, out_stride, out_sstride, stream=None):
         self._check(self.lib.lvm_preprocess_device(self.h, C.byref(cpre), d_in, w, h, ch, in_stride, in_sstride, d_out, out_stride,
                                                    out_sstride, stream))
+
+    def chain_process_batch(self, frames, cpre, cparams):
+        """lvm_chain_process_batch: one host frame per stream of this context (same geometry); returns (outs, produced)."""
+        frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+        if len(frames) != self.n_streams:
+            raise LvmError("chain_process_batch needs one frame per stream")
+        h, w = frames[0].shape[:2]
+        ch = 1 if frames[0].ndim == 2 else frames[0].shape[2]
+        _, _, _, _, ow, oh, och = self.preprocess_geometry(cpre, w, h, ch)
+        outs = [np.empty((oh, ow) if och == 1 else (oh, ow, och), dtype=np.uint8) for _ in frames]
+        pin = (C.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
+        pout = (C.c_void_p * len(frames))(*[o.ctypes.data for o in outs])
+        produced = C.c_int(0)
+        self._check(self.lib.lvm_chain_process_batch(self.h, C.byref(cpre), C.byref(cparams), pin, w, h, ch, w * ch, pout, ow * och,
+                                                     C.byref(produced)))
+        return outs, bool(produced.value)
 
     def chain_process(self, frame, cpre, cparams):
         """Preprocess -> Grayscale -> Magnification on a host frame (lvm_chain_process).  Returns (out, produced);

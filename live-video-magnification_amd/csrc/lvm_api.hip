@@ -105,6 +105,7 @@ static int ensure_float(Ctx* c, size_t count) {
     lvm::preprocess_release(c);
     if (c->d_pre_in) (void)hipFree(c->d_pre_in);
     if (c->d_pre_out) (void)hipFree(c->d_pre_out);
+    if (c->d_chain_out) (void)hipFree(c->d_chain_out);
         c->d_float = nullptr; c->float_cap = 0;
         LVM_HIP_TRY(c, hipMalloc((void**)&c->d_float, count * sizeof(float)));
         c->float_cap = count;
@@ -292,14 +293,15 @@ static uint64_t preprocess_key_of(const lvm_preprocess_params& pp) {
     return k;
 }
 
-int lvm_chain_process(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, const uint8_t* in, int w, int h, int channels,
-                      ptrdiff_t in_stride, uint8_t* out, ptrdiff_t out_stride, int* produced) {
-    if (!c || !pp || !p || !produced) return LVM_ERR_INVALID;
+int lvm_chain_process_batch(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, const uint8_t* const* in, int w, int h,
+                            int channels, ptrdiff_t in_stride, uint8_t* const* out, ptrdiff_t out_stride, int* produced) {
+    if (!c || !pp || !p || !produced || !in || !out) return LVM_ERR_INVALID;
     *produced = 0;
-    if (c->nstreams != 1) { c->err = "lvm_chain_process needs a 1-stream context"; return LVM_ERR_INVALID; }
-    if (!in || !out || w <= 0 || h <= 0 || (channels != 1 && channels != 3) || in_stride < (ptrdiff_t)w * channels) {
+    const int NS = c->nstreams;
+    if (w <= 0 || h <= 0 || (channels != 1 && channels != 3) || in_stride < (ptrdiff_t)w * channels) {
         c->err = "bad frame arguments"; return LVM_ERR_INVALID;
     }
+    for (int s = 0; s < NS; ++s) if (!in[s] || !out[s]) { c->err = "null frame pointer"; return LVM_ERR_INVALID; }
     LVM_HIP_TRY(c, hipSetDevice(c->device));
     int rx, ry, rw, rh, ow, oh, och;
     lvm::preprocess_geometry(*pp, w, h, channels, &rx, &ry, &rw, &rh, &ow, &oh, &och);
@@ -315,26 +317,19 @@ int lvm_chain_process(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_par
         return LVM_OK;
     };
     hipStream_t s = c->own_stream;
-    int rc = reserve(c->d_pre_in, c->pre_in_cap, roi_bytes); if (rc != LVM_OK) return rc;
-    rc = reserve(c->d_pre_out, c->pre_out_cap, out_bytes); if (rc != LVM_OK) return rc;
-    if (out_bytes > c->stage_cap) {           // magnifier output staging (shared with lvm_process)
-        LVM_HIP_TRY(c, hipStreamSynchronize(s));
-        if (c->d_in) (void)hipFree(c->d_in);
-        if (c->d_out) (void)hipFree(c->d_out);
-        c->d_in = c->d_out = nullptr; c->stage_cap = 0;
-        LVM_HIP_TRY(c, hipMalloc((void**)&c->d_in, out_bytes));
-        LVM_HIP_TRY(c, hipMalloc((void**)&c->d_out, out_bytes));
-        c->stage_cap = out_bytes;
-    }
+    LVM_HIP_TRY(c, hipStreamSynchronize(s));      // staging buffers may be replaced below
+    int rc = reserve(c->d_pre_in, c->pre_in_cap, roi_bytes * NS); if (rc != LVM_OK) return rc;
+    rc = reserve(c->d_pre_out, c->pre_out_cap, out_bytes * NS); if (rc != LVM_OK) return rc;
+    rc = reserve(c->d_chain_out, c->chain_out_cap, out_bytes * NS); if (rc != LVM_OK) return rc;
     // only the ROI rows cross PCIe (the crop is the pitch of the 2-D copy)
-    LVM_HIP_TRY(c, hipMemcpy2DAsync(c->d_pre_in, roi_row, in + (size_t)ry * in_stride + (size_t)rx * channels, (size_t)in_stride, roi_row,
-                                    (size_t)rh, hipMemcpyHostToDevice, s));
+    for (int k = 0; k < NS; ++k)
+        LVM_HIP_TRY(c, hipMemcpy2DAsync(c->d_pre_in + (size_t)k * roi_bytes, roi_row, in[k] + (size_t)ry * in_stride + (size_t)rx * channels,
+                                        (size_t)in_stride, roi_row, (size_t)rh, hipMemcpyHostToDevice, s));
     const uint8_t* mag_in = c->d_pre_in;
     const bool identity = ow == rw && oh == rh && och == channels;      // PreprocessProcessor.cpp:15, GrayscaleProcessor.cpp:8-9
     if (!identity) {
         lvm_preprocess_params q = *pp;
         q.roi_enabled = 0;                                               // already cropped by the copy
-        // (the decimated size must be the one of the clamped ROI: same arithmetic on rw x rh)
         rc = lvm::preprocess_device(c, q, c->d_pre_in, rw, rh, channels, (ptrdiff_t)roi_row, (ptrdiff_t)roi_bytes, c->d_pre_out,
                                     (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, s);
         if (rc != LVM_OK) { (void)hipStreamSynchronize(s); return rc; }
@@ -342,15 +337,25 @@ int lvm_chain_process(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_par
     }
     lvm_params mp = *p;
     mp.preprocess_key = preprocess_key_of(*pp);
-    lvm::FrameIO io{mag_in, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, c->d_out, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, ow, oh, och};
+    lvm::FrameIO io{mag_in, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, c->d_chain_out, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, ow, oh, och};
     const int saved_depth = c->pipeline_depth;
     c->pipeline_depth = 0;
     rc = lvm::process_device(c, &mp, io, s, produced);
     c->pipeline_depth = saved_depth;
     if (rc != LVM_OK) { (void)hipStreamSynchronize(s); return rc; }
-    LVM_HIP_TRY(c, hipMemcpy2DAsync(out, (size_t)out_stride, *produced ? c->d_out : mag_in, out_row, out_row, (size_t)oh, hipMemcpyDeviceToHost, s));
+    const uint8_t* res = *produced ? c->d_chain_out : mag_in;
+    for (int k = 0; k < NS; ++k)
+        LVM_HIP_TRY(c, hipMemcpy2DAsync(out[k], (size_t)out_stride, res + (size_t)k * out_bytes, out_row, out_row, (size_t)oh, hipMemcpyDeviceToHost, s));
     LVM_HIP_TRY(c, hipStreamSynchronize(s));
     return LVM_OK;
+}
+
+int lvm_chain_process(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, const uint8_t* in, int w, int h, int channels,
+                      ptrdiff_t in_stride, uint8_t* out, ptrdiff_t out_stride, int* produced) {
+    if (!c || !produced) return LVM_ERR_INVALID;
+    *produced = 0;
+    if (c->nstreams != 1) { c->err = "lvm_chain_process needs a 1-stream context"; return LVM_ERR_INVALID; }
+    return lvm_chain_process_batch(c, pp, p, &in, w, h, channels, in_stride, &out, out_stride, produced);
 }
 
 int lvm_process(lvm_ctx* c, const lvm_params* p, const uint8_t* in, int w, int h, int channels, ptrdiff_t in_stride,

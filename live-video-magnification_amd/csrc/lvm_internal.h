@@ -262,7 +262,7 @@ struct Ctx {
     bool exact_lab = false;   // debug: OpenCV-order Lab arithmetic everywhere (bit-faithful to the oracle)
     // preprocess stage (preprocess.hip): area tables of the current geometry, staging of the host chain
     void* pre_tables = nullptr;
-    uint8_t *d_pre_in = nullptr, *d_pre_out = nullptr; size_t pre_in_cap = 0, pre_out_cap = 0;
+    uint8_t *d_pre_in = nullptr, *d_pre_out = nullptr, *d_chain_out = nullptr; size_t pre_in_cap = 0, pre_out_cap = 0, chain_out_cap = 0;
 };
 
 void prof_begin(Ctx* c, const char* name, hipStream_t s);

@@ -136,6 +136,37 @@ def test_chain_emu_preprocess_then_laplace(lvm, po, emu):
     _check_chain(lvm, po, emu, True)
 
 
+def _check_chain_batch(lvm, po, lib, exact):
+    """lvm_chain_process_batch: three independent streams (different clips), one launch per stage for all of them."""
+    ck, pk = lvm.synth.config(0, (96, 64, 3))
+    clips = [lvm.synth.Clip(seed=77 + s, **ck) for s in range(3)]
+    ctx = lvm.Context(0, 3, lib)
+    ctx.exact_lab(exact)
+    orcs = [po.Oracle() for _ in range(3)]
+    P = po.make_params(**pk)
+    cpre, opre = _params(lvm, po, 2, (0.05, 0.1, 0.9, 0.8), True)
+    try:
+        for t in range(6):
+            frames = [c.frame(t) for c in clips]
+            outs, pg = ctx.chain_process_batch(frames, cpre, c_params(lvm, pk))
+            for s in range(3):
+                ref, pr = orcs[s].process(po.preprocess(frames[s], opre), P)
+                assert pr == pg
+                if exact:
+                    assert np.array_equal(outs[s], ref), "frame %d stream %d" % (t, s)
+                else:
+                    d = np.abs(outs[s].astype(np.int32) - ref.astype(np.int32))
+                    assert d.max() <= 1 and (d == 0).mean() >= 0.999
+    finally:
+        ctx.close()
+        for o in orcs:
+            o.close()
+
+
+def test_chain_batch_emu_three_streams(lvm, po, emu):
+    _check_chain_batch(lvm, po, emu, True)
+
+
 def test_chain_rejects_bad_arguments(lvm, po, emu):
     ctx = lvm.Context(0, 2, emu)
     try:
@@ -154,6 +185,12 @@ def test_preprocess_gpu_bit_exact(lvm, po, hip):
 def test_chain_gpu_preprocess_then_laplace(lvm, po, hip):
     _check_chain(lvm, po, hip, False)
     _check_chain(lvm, po, hip, True)
+
+
+@pytest.mark.gpu
+def test_chain_batch_gpu_three_streams(lvm, po, hip):
+    _check_chain_batch(lvm, po, hip, False)
+    _check_chain_batch(lvm, po, hip, True)
 
 
 @pytest.mark.gpu
