@@ -307,3 +307,30 @@ def test_emu_padded_row_strides(lvm, po, emu, idx, pad_in, pad_out):
                 assert np.array_equal(buf_out[:, :w * 3].reshape(h, w, 3), ref), "frame %d" % t
     finally:
         ctx.close(); orc.close()
+
+
+# ---- degenerate content: flat black / white regions and constant frames -----------------------------------
+class _PatchedClip:
+    """The synthetic clip with a flat black block, a flat white block and (from frame `const_from`) a constant frame:
+    0/0 in the Riesz phase and amplitude steps (NaN patches, RieszPyramid.cpp:105-106,141), max == min in the colour
+    normalisations (TemporalFilter.cpp:55, MagnifyCore.hpp:200-203)."""
+
+    def __init__(self, clip, const_from=None):
+        self.clip, self.const_from = clip, const_from
+
+    def frame(self, t):
+        f = self.clip.frame(t).copy()
+        h, w = f.shape[:2]
+        f[h // 8:h // 2, w // 8:w // 3] = 0
+        f[h // 2:h - h // 8, w // 2:w - w // 8] = 255
+        if self.const_from is not None and t >= self.const_from:
+            f[...] = 77
+        return f
+
+
+@pytest.mark.parametrize("idx,const_from", [(0, None), (2, None), (3, None), (0, 5), (2, 5), (3, 5)])
+def test_emu_flat_regions_and_constant_frames(lvm, po, emu, idx, const_from):
+    ck, pk = lvm.synth.config(idx, (96, 64, 3))
+    if idx == 3:
+        ck["fps"] = 15.0; pk["framerate"] = 15.0
+    run_pair(lvm, po, emu, _PatchedClip(lvm.synth.Clip(**ck), const_from), pk, 9, 0.0, exact=True)

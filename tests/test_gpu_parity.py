@@ -128,6 +128,26 @@ def test_padded_row_strides_device_path(lvm, po, hip, idx, pad_in, pad_out):
         ctx.close(); orc.close()
 
 
+@pytest.mark.parametrize("idx,const_from", [(0, None), (2, None), (3, None), (0, 5), (2, 5), (3, 5)])
+def test_flat_regions_and_constant_frames(lvm, po, hip, idx, const_from):
+    """Flat black / white blocks and a switch to constant frames: the 0/0 and max == min corners of the three modes."""
+    ck, pk = lvm.synth.config(idx, (320, 180, 4))
+    if idx == 3:
+        ck["fps"] = 15.0; pk["framerate"] = 15.0
+    base = lvm.synth.Clip(**ck)
+
+    class Patched:
+        def frame(self, t):
+            f = base.frame(t).copy()
+            h, w = f.shape[:2]
+            f[h // 8:h // 2, w // 8:w // 3] = 0
+            f[h // 2:h - h // 8, w // 2:w - w // 8] = 255
+            if const_from is not None and t >= const_from:
+                f[...] = 77
+            return f
+    run_pair(lvm, po, hip, Patched(), pk, 9, FLOAT_TOL)
+
+
 def test_passthrough_and_errors(lvm, po, hip):
     ctx = lvm.Context(0, 1, hip)
     f = np.full((40, 40, 3), 90, np.uint8)
