@@ -429,7 +429,7 @@ __device__ __forceinline__ float rz_amplify(float v0, float v1, float v2, float 
         const float c = v1 / v0, sn = v2 / v0;                         // :125-126
         const float magV = sqrtf(c * c + sn * sn);                     // :133-134
         float magV2 = magV * alpha;                                     // :135
-        magV2 = magV2 > thr ? thr : magV2;                               // :136 THRESH_TRUNC
+        magV2 = magV2 < thr ? magV2 : thr;                               // :136 THRESH_TRUNC = v_min(src, thr): NaN -> thr (minps)
         const float cp = cosf(magV2), sp = sinf(magV2);                // :138
         float pair = (r1 * c + r2 * sn) / magV;                        // :139-140
         if (pair != pair) pair = 0.f;                                  // :141
@@ -440,7 +440,7 @@ __device__ __forceinline__ float rz_amplify(float v0, float v1, float v2, float 
     const float m2 = c * c + sn * sn;
     const float magV = __builtin_amdgcn_sqrtf(m2);
     float magV2 = magV * alpha;
-    magV2 = magV2 > thr ? thr : magV2;
+    magV2 = magV2 < thr ? magV2 : thr;                               // NaN -> thr, like the exact flavour
     const float rev = magV2 * 0.15915494309189535f;
     const float cp = __builtin_amdgcn_cosf(rev), sp = __builtin_amdgcn_sinf(rev);
     float pair = (r1 * c + r2 * sn) * __builtin_amdgcn_rcpf(magV);

@@ -1036,7 +1036,10 @@ static void rlevel_amplify(RieszLevel* L, double alpha, double threshold, const 
         const float c = bc[i] / L->ampBlur[i], s = bs[i] / L->ampBlur[i]; /* :125-126 */
         const float magV = sqrtf(c * c + s * s);                        /* :133-134 */
         float magV2 = magV * fa;                                        /* :135 */
-        magV2 = magV2 > thr ? thr : magV2;                              /* :136 THRESH_TRUNC */
+        /* :136 cv::threshold(THRESH_TRUNC) on CV_32F is v_min(src, thresh) in OpenCV's vector loop (minps: the
+         * SECOND operand when the first is NaN), so a NaN magnitude (0/0 in a flat black region) becomes thr;
+         * only the <= 3-pixel scalar tail of a row would keep the NaN.  The vector semantics are restated. */
+        magV2 = magV2 < thr ? magV2 : thr;
         const float cp = cosf(magV2), sp = sinf(magV2);                 /* :138 cosSin */
         float pair = (L->r1[i] * c + L->r2[i] * s) / magV;              /* :139-140 */
         if (pair != pair) pair = 0.f;                                   /* :141 */

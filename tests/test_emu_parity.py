@@ -328,9 +328,11 @@ class _PatchedClip:
         return f
 
 
-@pytest.mark.parametrize("idx,const_from", [(0, None), (2, None), (3, None), (0, 5), (2, 5), (3, 5)])
-def test_emu_flat_regions_and_constant_frames(lvm, po, emu, idx, const_from):
-    ck, pk = lvm.synth.config(idx, (96, 64, 3))
+@pytest.mark.parametrize("idx,const_from,size", [(0, None, (96, 64, 3)), (2, None, (96, 64, 3)), (3, None, (96, 64, 3)), (0, 5, (96, 64, 3)),
+                                                   (2, 5, (96, 64, 3)), (3, 5, (96, 64, 3)),
+                                                   (2, None, (200, 120, 3))])   # black block wider than the 9x9 + 13x13 supports: exact 0/0
+def test_emu_flat_regions_and_constant_frames(lvm, po, emu, idx, const_from, size):
+    ck, pk = lvm.synth.config(idx, size)
     if idx == 3:
         ck["fps"] = 15.0; pk["framerate"] = 15.0
     run_pair(lvm, po, emu, _PatchedClip(lvm.synth.Clip(**ck), const_from), pk, 9, 0.0, exact=True)
