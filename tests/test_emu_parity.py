@@ -336,3 +336,21 @@ def test_emu_flat_regions_and_constant_frames(lvm, po, emu, idx, const_from, siz
     if idx == 3:
         ck["fps"] = 15.0; pk["framerate"] = 15.0
     run_pair(lvm, po, emu, _PatchedClip(lvm.synth.Clip(**ck), const_from), pk, 9, 0.0, exact=True)
+
+
+class _ConstClip:
+    def __init__(self, h, w, v):
+        self.f = np.full((h, w, 3), v, np.uint8)
+
+    def frame(self, t):
+        return self.f
+
+
+@pytest.mark.parametrize("idx", [0, 2, 3])
+def test_emu_fully_constant_clip(lvm, po, emu, idx):
+    """Every frame the same constant: Color's output range collapses (max == min, 255 / 0 in convertTo:
+    MagnifyCore.hpp:200-203), Riesz sees 0/0 in every phase difference, Laplace must return the Lab round trip."""
+    ck, pk = lvm.synth.config(idx, (96, 64, 3))
+    if idx == 3:
+        pk["framerate"] = 15.0
+    run_pair(lvm, po, emu, _ConstClip(64, 96, 131), pk, 8, 0.0, exact=True)

@@ -148,6 +148,21 @@ def test_flat_regions_and_constant_frames(lvm, po, hip, idx, const_from):
     run_pair(lvm, po, hip, Patched(), pk, 9, FLOAT_TOL)
 
 
+@pytest.mark.parametrize("idx", [0, 2, 3])
+def test_fully_constant_clip(lvm, po, hip, idx):
+    """Every frame the same constant: Color's output range collapses (max == min), Riesz sees 0/0 everywhere."""
+    ck, pk = lvm.synth.config(idx, (320, 180, 4))
+    if idx == 3:
+        pk["framerate"] = 15.0
+
+    class Const:
+        f = np.full((180, 320, 3), 131, np.uint8)
+
+        def frame(self, t):
+            return self.f
+    run_pair(lvm, po, hip, Const(), pk, 8, FLOAT_TOL)
+
+
 def test_passthrough_and_errors(lvm, po, hip):
     ctx = lvm.Context(0, 1, hip)
     f = np.full((40, 40, 3), 90, np.uint8)
