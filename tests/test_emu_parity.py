@@ -354,3 +354,19 @@ def test_emu_fully_constant_clip(lvm, po, emu, idx):
     if idx == 3:
         pk["framerate"] = 15.0
     run_pair(lvm, po, emu, _ConstClip(64, 96, 131), pk, 8, 0.0, exact=True)
+
+
+@pytest.mark.parametrize("idx,over", [(3, dict(coLow=5.0, coHigh=1.0)),                # colour: empty pass band (mask all zero)
+                                       (3, dict(coLow=0.0, coHigh=0.3)),                # colour: lo == 0 -> 0.01, DC excluded, first bins
+                                       (2, dict(coLow=0.5, coHigh=20.0)),               # Riesz: cutoff above Nyquist (Wn > 1)
+                                       (2, dict(coLow=0.5, coHigh=15.0)),               # Riesz: cutoff exactly at Nyquist (Wn == 1)
+                                       (2, dict(coLow=3.0, coHigh=1.0)),                # Riesz: hi < lo
+                                       (0, dict(amplification=1000.0, chromAttenuation=1.0)),   # Laplace: far out of gamut
+                                       (0, dict(amplification=0.0)),
+                                       (2, dict(amplification=0.0, coWavelength=0.0))])  # Riesz: zero gain / zero threshold
+def test_emu_extreme_parameters(lvm, po, emu, idx, over):
+    ck, pk = lvm.synth.config(idx, (96, 64, 3))
+    if idx == 3:
+        ck["fps"] = 15.0; pk["framerate"] = 15.0
+    pk.update(over)
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 8, 0.0, exact=True)

@@ -163,6 +163,19 @@ def test_fully_constant_clip(lvm, po, hip, idx):
     run_pair(lvm, po, hip, Const(), pk, 8, FLOAT_TOL)
 
 
+@pytest.mark.parametrize("idx,over", [(3, dict(coLow=5.0, coHigh=1.0)), (3, dict(coLow=0.0, coHigh=0.3)), (2, dict(coLow=0.5, coHigh=20.0)),
+                                       (2, dict(coLow=0.5, coHigh=15.0)), (2, dict(coLow=3.0, coHigh=1.0)),
+                                       (0, dict(amplification=1000.0, chromAttenuation=1.0)), (0, dict(amplification=0.0)),
+                                       (2, dict(amplification=0.0, coWavelength=0.0))])
+def test_extreme_parameters(lvm, po, hip, idx, over):
+    """Empty / degenerate pass bands, cutoffs at and above Nyquist, zero and huge gains (see the emulation test of the same name)."""
+    ck, pk = lvm.synth.config(idx, (320, 180, 4))
+    if idx == 3:
+        ck["fps"] = 15.0; pk["framerate"] = 15.0
+    pk.update(over)
+    run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 8, FLOAT_TOL)
+
+
 def test_passthrough_and_errors(lvm, po, hip):
     ctx = lvm.Context(0, 1, hip)
     f = np.full((40, 40, 3), 90, np.uint8)
