@@ -370,3 +370,30 @@ def test_emu_extreme_parameters(lvm, po, emu, idx, over):
         ck["fps"] = 15.0; pk["framerate"] = 15.0
     pk.update(over)
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 8, 0.0, exact=True)
+
+
+class _ShapeShifter:
+    """Frames whose size / channel count changes mid-stream (the structural tracker must drop all state:
+    MagnifyCore.hpp:53-65) and changes back."""
+
+    def __init__(self, lvm, ck):
+        self.a = lvm.synth.Clip(**ck)
+        k2 = dict(ck); k2["w"], k2["h"] = 80, 48
+        self.b = lvm.synth.Clip(**k2)
+
+    def frame(self, t):
+        if t < 4:
+            return self.a.frame(t)
+        if t < 7:
+            return self.b.frame(t)                       # smaller frame
+        if t < 10:
+            return np.ascontiguousarray(self.a.frame(t)[:, :, 1])   # gray frame of the first size
+        return self.a.frame(t)
+
+
+@pytest.mark.parametrize("idx", [0, 2, 3])
+def test_emu_size_and_channel_changes(lvm, po, emu, idx):
+    ck, pk = lvm.synth.config(idx, (96, 64, 2))
+    if idx == 3:
+        ck["fps"] = 15.0; pk["framerate"] = 15.0
+    run_pair(lvm, po, emu, _ShapeShifter(lvm, ck), pk, 13, 0.0, exact=True)
