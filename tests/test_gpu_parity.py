@@ -176,6 +176,15 @@ def test_extreme_parameters(lvm, po, hip, idx, over):
     run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 8, FLOAT_TOL)
 
 
+@pytest.mark.parametrize("idx,frames", [(0, 600), (2, 400), (3, 400)])
+def test_long_clip_state_drift(lvm, po, hip, idx, frames):
+    """Hundreds of frames: the IIR / Butterworth / rolling-window states of the default (fast) arithmetic must not drift
+    away from the oracle's (parity metric of SURVEY.md 8c: >= 64 frames, state drift included)."""
+    ck, pk = lvm.synth.config(idx, (160, 90, 3))
+    worst = run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, frames, FLOAT_TOL)
+    print("long clip mode", idx, "frames", frames, "worst rel/u8/frac", worst)
+
+
 def test_passthrough_and_errors(lvm, po, hip):
     ctx = lvm.Context(0, 1, hip)
     f = np.full((40, 40, 3), 90, np.uint8)
