@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void k_lap_final(const uint8_t* __restrict__ i
                     L = L + m0; a = a + m1; bb = bb + m2;                            // :148
                 }
                 float o0, o1, o2;
-                lab_to_bgr<EXACT>(L, a, bb, lab.inv, s_igt, o0, o1, o2);                    // :152
+                lab_to_bgr<EXACT>(L, a, bb, EXACT ? lab.inv : lab.inv1024, s_igt, o0, o1, o2);                    // :152
                 if (dbg && b == 0) {
                     float* d = dbg + ((size_t)gy * w + gx) * 3;
                     d[0] = o0; d[1] = o1; d[2] = o2;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_lap_final_v4(const uint8_t* __r
                     }
                 }
                 float o0, o1, o2;
-                lab_to_bgr<EXACT>(L, a, bb, lab.inv, s_igt, o0, o1, o2);
+                lab_to_bgr<EXACT>(L, a, bb, EXACT ? lab.inv : lab.inv1024, s_igt, o0, o1, o2);
                 if (dbg && b == 0) { float* d = dbg + ((size_t)gy * w + gx + k) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
                 if (EXACT) {
                     ov[3 * k] = o0 * 255.0f + lab.a255; ov[3 * k + 1] = o1 * 255.0f + lab.a255; ov[3 * k + 2] = o2 * 255.0f + lab.a255;

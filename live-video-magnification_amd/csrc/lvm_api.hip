@@ -165,6 +165,7 @@ int lvm_create(int device, int n_streams, lvm_ctx** out) {
     c->nstreams = n_streams;
     float g[256], ig[4096];
     lvm::build_lab_tables(g, ig, c->lab.fwd, c->lab.inv);
+    for (int i = 0; i < 9; ++i) c->lab.inv1024[i] = c->lab.inv[i] * 1024.0f;
     bool ok = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;

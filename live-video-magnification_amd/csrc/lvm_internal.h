@@ -54,6 +54,7 @@ __device__ __forceinline__ uint32_t pack_u8x4(float v0, float v1, float v2, floa
 struct LabCoef {
     float fwd[9];             // BGR(linear) -> XYZ/white, row-major, column 0 multiplies B
     float inv[9];             // XYZ -> BGR(linear), row 0 produces B
+    float inv1024[9];         // inv * 1024 (exact): the fast flavour gets the spline coordinate straight out of the matrix
     const float* gamma_u8;    // [256]  sRGB gamma of u8/255 (device)
     const float* invgamma;    // [1024*4] cubic-spline coefficients of the inverse gamma (device)
     float a255;               // float(1.0/255.0f)
@@ -139,6 +140,7 @@ __device__ __forceinline__ float clip01_fast(float v) { return __builtin_amdgcn_
 // clamp to [0, 1): the largest float below 1 instead of 1 moves the inverse-gamma result by < 1e-7 and
 // lets spline1024 skip the knot clamp
 __device__ __forceinline__ float clip01_open(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 0.99999994f); }
+__device__ __forceinline__ float clip1024_open(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 1023.99994f); }   // = clip01_open(v / 1024) * 1024
 // convertTo(CV_8U) for finite input: round-half-even, clamp, convert (3 instructions)
 __device__ __forceinline__ uint32_t sat_u8_fast(float v) { return (uint32_t)__builtin_amdgcn_fmed3f(rintf(v), 0.f, 255.f); }
 // Lab2RGBfloat::process + inverse gamma; igt = inverse-gamma spline table (LDS).  EXACT keeps
@@ -167,6 +169,7 @@ __device__ __forceinline__ void lab_to_bgr(float li, float ai, float bi, const f
         fx = __builtin_fmaf(ai, 1.0f / 500.0f, fy); fz = __builtin_fmaf(bi, -1.0f / 200.0f, fy);
         fx = (fx <= fThresh) ? (fx - 16.0f / 116.0f) * (1.0f / 7.787f) : fx * fx * fx;
         fz = (fz <= fThresh) ? (fz - 16.0f / 116.0f) * (1.0f / 7.787f) : fz * fz * fz;
+        // iv = inv1024 here: a power-of-two scale commutes with every rounding, so c * 1024 comes out directly
         c0 = __builtin_fmaf(iv[0], fx, __builtin_fmaf(iv[1], y, iv[2] * fz));
         c1 = __builtin_fmaf(iv[3], fx, __builtin_fmaf(iv[4], y, iv[5] * fz));
         c2 = __builtin_fmaf(iv[6], fx, __builtin_fmaf(iv[7], y, iv[8] * fz));
@@ -176,9 +179,9 @@ __device__ __forceinline__ void lab_to_bgr(float li, float ai, float bi, const f
         o1 = spline1024<true>(clip01(c1) * 1024.f, igt);
         o2 = spline1024<true>(clip01(c2) * 1024.f, igt);
     } else {
-        o0 = spline1024<false>(clip01_open(c0) * 1024.f, igt);
-        o1 = spline1024<false>(clip01_open(c1) * 1024.f, igt);
-        o2 = spline1024<false>(clip01_open(c2) * 1024.f, igt);
+        o0 = spline1024<false>(clip1024_open(c0), igt);
+        o1 = spline1024<false>(clip1024_open(c1), igt);
+        o2 = spline1024<false>(clip1024_open(c2), igt);
     }
 }
 // cooperative loads of the two Lab tables into LDS (256 threads)
