@@ -199,7 +199,7 @@ def main():
 
     red_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
     if args.mode == "color":   # the rolling window must be full before the steady state starts
-        args.warmup = max(args.warmup, lvm.load().lvm_optimal_buffer_size(int(pk["framerate"])) + 16)
+        args.warmup = max(args.warmup, lvm.load().lvm_optimal_buffer_size(int(pk["framerate"])) + 32)
     n = 0
     run_frames(0, args.warmup); n += args.warmup
     base = n
@@ -233,8 +233,8 @@ def main():
         for name, (ms, cnt) in prof.items():
             avg_us = 1e3 * ms / max(cnt, 1)
             # a launch of the temporally batched schedule covers T_frames frames of every stream
-            # frames one launch covers: T, except that the colour mode cuts a call into chunks of <= 16 frames (window ring)
-            T_launch = min(T, 16) if args.mode == "color" else T
+            # frames one launch covers: T, except that the colour mode cuts a call into chunks of <= 32 frames (window ring)
+            T_launch = min(T, 32) if args.mode == "color" else T
             ab = kernel_alg_bytes(args.mode, name, w, h, ch, levels, B * T_launch, Twin)
             kernels[name] = {"avg_us": round(avg_us, 3), "launches": cnt, "share": round(ms / tot, 4),
                              "alg_bytes": ab, "gbs": (round(ab / (avg_us * 1e-6) / 1e9, 1) if ab else None)}

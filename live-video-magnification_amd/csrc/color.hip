@@ -926,7 +926,7 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
     const int maxImages = optimal_buffer_size((int)p.framerate);
     st->max_images = maxImages;
     {
-        const int want = maxImages > 0 && maxImages <= 4096 ? maxImages + 17 : 0;      // room for temporal batches
+        const int want = maxImages > 0 && maxImages <= 4096 ? maxImages + kColorBatchMax + 1 : 0;      // room for temporal batches
         const int rc = color_reserve(c, st, st->n + 1 > want ? st->n + 1 : want, s);
         if (rc != LVM_OK) return rc;
     }

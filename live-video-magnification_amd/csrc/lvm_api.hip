@@ -247,8 +247,8 @@ int lvm_process_device_frames(lvm_ctx* c, const lvm_params* p, int n_frames, con
             int rc = 1;
             if (p->mode == LVM_MODE_LAPLACE && lvm::laplace_can_batch(c)) rc = lvm::laplace_process_frames(c, *p, io, left, s);
             else if (p->mode == LVM_MODE_PHASE && channels >= 3 && lvm::riesz_can_batch(c, *p)) rc = lvm::riesz_process_frames(c, *p, io, left, s);
-            else if (p->mode == LVM_MODE_COLOR && lvm::color_can_batch(c, *p, left < 16 ? left : 16)) {
-                const int nb = left < 16 ? left : 16;      // the window ring keeps 16 spare slots
+            else if (p->mode == LVM_MODE_COLOR && lvm::color_can_batch(c, *p, left < lvm::kColorBatchMax ? left : lvm::kColorBatchMax)) {
+                const int nb = left < lvm::kColorBatchMax ? left : lvm::kColorBatchMax;      // the window ring keeps that many spare slots
                 rc = lvm::color_process_frames(c, *p, io, nb, s);
                 if (rc == LVM_OK) { for (int k = f; k < f + nb; ++k) produced[k] = 1; f += nb; continue; }
             }

@@ -298,6 +298,8 @@ int preprocess_device(Ctx* c, const lvm_preprocess_params& pp, const uint8_t* d_
                       ptrdiff_t in_sstride, uint8_t* d_out, ptrdiff_t out_stride, ptrdiff_t out_sstride, hipStream_t s);
 void preprocess_release(Ctx* c);
 
+constexpr int kColorBatchMax = 32;    // frames of one colour-mode temporal batch (spare slots of the window ring)
+
 // mode entry points (laplace.hip / riesz.hip / color.hip).  Return LVM_OK or an error;
 // *produced follows the reference's passthrough rules.
 int laplace_flush(Ctx* c, hipStream_t s);

@@ -270,7 +270,8 @@ def test_riesz_emu_temporal_batches(lvm, po, emu, w, h, levels, ns, calls):
     _frames_clip(lvm, po, emu, 2, w, h, levels, ns, calls)
 
 
-@pytest.mark.parametrize("w,h,levels,ns,calls", [(64, 48, 2, 1, (18, 5, 7, 3)), (40, 30, 1, 2, (20, 6)), (80, 52, 3, 1, (17, 16, 9))])
+@pytest.mark.parametrize("w,h,levels,ns,calls", [(64, 48, 2, 1, (18, 5, 7, 3)), (40, 30, 1, 2, (20, 6)), (80, 52, 3, 1, (17, 16, 9)),
+                                                  (48, 32, 2, 1, (18, 40, 35))])   # calls longer than one batch (32 frames) are cut
 def test_color_emu_temporal_batches(lvm, po, emu, w, h, levels, ns, calls):
     """fps 7 -> the window caps at 16 columns: once it is full the remaining frames of a call share
     launches (every frame of a batch sees the ring shifted by one column)."""
