@@ -260,6 +260,17 @@ def main():
                        "rz_phase": "VALU-bound: 79 % VALU issue utilisation (acosf, sqrt/div, float64 filter products)"}.get(dom)
             if limiter:
                 roofline["limiter"] = limiter
+            # the committed rocprofv3 --stats summary of this command (kernels back to back, no event gaps): its average for
+            # the same kernel.  The VALU-bound kernels run a few % slower there (sustained clocks); see profiles/README.md.
+            try:
+                sym = {"lap_final": "ILb1ELb0EEEvPKhllPhlliiPKfiiNS_7LabCoefEfiiiiPf", "lap_down0": "down0_rowsILb1ELb0", "lap_up": "k_lap_upILb0ELi1"}.get(dom)
+                if sym and args.mode == "laplace" and traffic is not None:
+                    for line in open(os.path.join(ROOT, "profiles", "r01_rocprof_laplace_kernel_stats.txt")):
+                        if sym in line:
+                            roofline["rocprof_avg_us"] = float(line.split()[2])
+                            break
+            except Exception:
+                pass
     b_alg = lvm.load().lvm_algorithmic_bytes(pk["mode"], w, h, ch, levels, pk["framerate"])
     frame_frac = b_alg * (fps / world) / (HBM_PEAK_GBS * 1e9)
 
