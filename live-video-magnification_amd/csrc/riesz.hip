@@ -301,23 +301,12 @@ __device__ __forceinline__ float arc_cos(float x) {
     return acosf(x);
 }
 __device__ __forceinline__ float mul_sd(float x, double s) { return (float)((double)x * s); }
-// float x double-coefficient product without the float64 unit: s = hi + lo (two floats), x*s ~ fma(x, hi, x*lo).
-// Error <= 2^-47 relative before the single rounding to float, i.e. it differs from (float)((double)x*s) only on
-// double-rounding ties; used by the default (non-exact) flavour of the phase kernel, whose 20 such products per
-// pixel and frame are a fifth of its instructions (the kernel is VALU-bound).
-struct SplitD { float hi, lo; };
-__device__ __forceinline__ SplitD split_d(double s) { SplitD r; r.hi = (float)s; r.lo = (float)(s - (double)r.hi); return r; }
-template <bool EXACT>
-__device__ __forceinline__ float mul_sx(float x, double s, SplitD q) { return EXACT ? mul_sd(x, s) : __builtin_fmaf(x, q.hi, x * q.lo); }
 
 // With nt > 1 the workgroup walks over nt consecutive frames: the 13 state values of a pixel (prior
 // band + Riesz pair, accumulated phase, 8 filter registers) stay in registers and move through HBM
 // once per launch instead of once per frame; the band tile of frame t+1 is prefetched while frame t
 // is processed.
-template <bool EXACT>
 __global__ __launch_bounds__(256) void k_rz_phase(PhaseArgs aa) {
-    const SplitD qlb0 = split_d(aa.lb0), qlb1 = split_d(aa.lb1), qlb2 = split_d(aa.lb2), qla1 = split_d(aa.la1), qla2 = split_d(aa.la2),
-                 qhb0 = split_d(aa.hb0), qhb1 = split_d(aa.hb1), qhb2 = split_d(aa.hb2), qha1 = split_d(aa.ha1), qha2 = split_d(aa.ha2);
     __shared__ float s[PT_H + 4][PT_W + 4 + 1];
     int lvl = 0;
     while (lvl + 1 < aa.nlv && (int)blockIdx.x >= aa.lv[lvl + 1].block0) ++lvl;
@@ -390,18 +379,18 @@ __global__ __launch_bounds__(256) void k_rz_phase(PhaseArgs aa) {
         // IIRTemporalFilter for the low and the high cutoff (TemporalFilter.cpp:343-350); both keep
         // their own copy of the accumulated phase in the reference, the copies are always equal.
         phc = phc + dc; phs = phs + ds;
-        const float ylc = mul_sx<EXACT>(phc, aa.lb0, qlb0) + lo0c;
-        const float yls = mul_sx<EXACT>(phs, aa.lb0, qlb0) + lo0s;
-        lo0c = (mul_sx<EXACT>(phc, aa.lb1, qlb1) + lo1c) - mul_sx<EXACT>(ylc, aa.la1, qla1);
-        lo0s = (mul_sx<EXACT>(phs, aa.lb1, qlb1) + lo1s) - mul_sx<EXACT>(yls, aa.la1, qla1);
-        lo1c = mul_sx<EXACT>(phc, aa.lb2, qlb2) - mul_sx<EXACT>(ylc, aa.la2, qla2);
-        lo1s = mul_sx<EXACT>(phs, aa.lb2, qlb2) - mul_sx<EXACT>(yls, aa.la2, qla2);
-        const float yhc = mul_sx<EXACT>(phc, aa.hb0, qhb0) + hi0c;
-        const float yhs = mul_sx<EXACT>(phs, aa.hb0, qhb0) + hi0s;
-        hi0c = (mul_sx<EXACT>(phc, aa.hb1, qhb1) + hi1c) - mul_sx<EXACT>(yhc, aa.ha1, qha1);
-        hi0s = (mul_sx<EXACT>(phs, aa.hb1, qhb1) + hi1s) - mul_sx<EXACT>(yhs, aa.ha1, qha1);
-        hi1c = mul_sx<EXACT>(phc, aa.hb2, qhb2) - mul_sx<EXACT>(yhc, aa.ha2, qha2);
-        hi1s = mul_sx<EXACT>(phs, aa.hb2, qhb2) - mul_sx<EXACT>(yhs, aa.ha2, qha2);
+        const float ylc = mul_sd(phc, aa.lb0) + lo0c;
+        const float yls = mul_sd(phs, aa.lb0) + lo0s;
+        lo0c = (mul_sd(phc, aa.lb1) + lo1c) - mul_sd(ylc, aa.la1);
+        lo0s = (mul_sd(phs, aa.lb1) + lo1s) - mul_sd(yls, aa.la1);
+        lo1c = mul_sd(phc, aa.lb2) - mul_sd(ylc, aa.la2);
+        lo1s = mul_sd(phs, aa.lb2) - mul_sd(yls, aa.la2);
+        const float yhc = mul_sd(phc, aa.hb0) + hi0c;
+        const float yhs = mul_sd(phs, aa.hb0) + hi0s;
+        hi0c = (mul_sd(phc, aa.hb1) + hi1c) - mul_sd(yhc, aa.ha1);
+        hi0s = (mul_sd(phs, aa.hb1) + hi1s) - mul_sd(yhs, aa.ha1);
+        hi1c = mul_sd(phc, aa.hb2) - mul_sd(yhc, aa.ha2);
+        hi1s = mul_sd(phs, aa.hb2) - mul_sd(yhs, aa.ha2);
         a.amp[fidx] = am;
         a.tc[fidx] = (yhc - ylc) * am;                                     // RieszPyramid.cpp:118-120
         a.ts[fidx] = (yhs - yls) * am;
@@ -894,7 +883,7 @@ static void rz_phase(Ctx* c, RieszState* st, const RzBufs& B, int mode, hipStrea
         v.fs = (long)NS * (long)st->g[l].n;
         blocks += v.tx * v.ty * NS;
     }
-    LVM_LAUNCH(c, mode ? "rz_seed" : "rz_phase", c->exact_lab ? k_rz_phase<true> : k_rz_phase<false>, dim3(blocks), dim3(256), s, a);
+    LVM_LAUNCH(c, mode ? "rz_seed" : "rz_phase", k_rz_phase, dim3(blocks), dim3(256), s, a);
 }
 
 // amplify + collapse + output of the nt frames (RieszPyramid.cpp:248-252, 304-325; MagnifyCore.hpp:269-277)
