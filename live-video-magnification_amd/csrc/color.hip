@@ -6,21 +6,21 @@
 // (TemporalFilter.cpp:24-80).
 //
 // HBM layout per context: G_l[plane][h_l][w_l] (l = 1..L, unscaled [0,255] floats), the rolling
-// window win[slot][row] with row = plane * n_L + pixel (one "slot" per frame, ring buffer of
-// capacity >= getOptimalBufferSize(fps); lanes = rows, so every time step is one coalesced
-// load), the packed filtered spectrum Y[element][row], the up-chain images up_k[plane] of size
+// window win[row][slot] with row = plane * n_L + pixel (time-contiguous per row, ring buffer of
+// capacity >= getOptimalBufferSize(fps) + 33 slots: one row's history is one contiguous run and a
+// temporal batch of up to 32 frames appends 32 columns), the up-chain images up_k[plane] of size
 // (w_L 2^k) x (h_L 2^k), two min/max pairs per stream and the bilinear resize tables.
 //
-// Launch sequence per frame:
-//   k_down0 + k_pyr_down x (L-1)   u8 -> float -> Gaussian pyramid (shared with laplace.hip)
-//   k_col_append                   smallest level -> window slot; resets the min/max cells
-//   k_col_dft                      per row: packed real DFT of the needed elements (float64 sums),
-//                                  0/1 mask applied as a packed complex spectrum (mulSpectrums),
-//                                  inverse transform of all T samples -> global min/max, keep column 1
+// Launch sequence (one frame, or a batch of <= 32 frames of every stream):
+//   k_down0_rows | k_down0_v4, k_pyr_down_rows | _multi   u8 -> float -> Gaussian pyramid (pyramid.h)
+//   k_col_append                   smallest level -> window slots; resets the min/max cells
+//   k_col_dft | k_col_dft_thin     per row: packed real DFT of the needed elements (float64 sums), 0/1 mask applied
+//                                  as a packed complex spectrum (mulSpectrums), inverse transform of all T samples
+//                                  -> global min/max, keep column 1   (wave per row | thread per row, narrow bands)
 //   k_col_norm                     min-max normalise column 1, x alpha -> up_0
 //   k_pyr_up x (L-1)               up_k -> up_{k+1}
-//   k_col_out<false>               last pyrUp + bilinear resize + input add -> global min/max
-//   k_col_out<true>                same values again -> u8 with the min/max rescale
+//   k_col_out_rows<false>          last pyrUp + bilinear resize + input add -> global min/max   (wave strips;
+//   k_col_out_rows<true>           same values again -> u8 with the min/max rescale             k_col_out* = tiles)
 #include <cmath>
 #include <cstdlib>
 

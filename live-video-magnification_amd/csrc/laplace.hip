@@ -12,14 +12,16 @@
 // Band 0 and the residual are multiplied by 0 in the reference (MagnifyCore.hpp:129-131), so
 // their bands and IIR states are never computed (dead state).
 //
-// Launch sequence per frame (L levels):
-//   k_lap_down0           u8 BGR -> Lab -> pyrDown           -> G_1
-//   k_pyr_down  x (L-1)   G_l -> G_{l+1}
-//   k_lap_up    x (L-1)   l = L-1..1, fused: band_l = G_l - pyrUp(G_{l+1}); IIR x2 (state R/W);
-//                         x gain_l; cur_l = pyrUp(cur_{l+1}) + motion_l
-//   k_lap_final           out = u8(Lab2BGR(Lab(u8 in) + [1,ca,ca] * pyrUp(cur_1)))
-// All stencils are LDS-staged tiles; pyrDown/pyrUp follow OpenCV's border rules and operation
-// order exactly (see the per-kernel comments) so the result is order-faithful to the oracle.
+// Launch sequence (L levels; a launch covers one frame or, in temporal batches, T frames of every stream):
+//   k_down0_rows | k_down0_v4        u8 BGR -> Lab -> pyrDown -> G_1   (wave strips + DPP halo | LDS tile)
+//   k_pyr_down_rows | _multi | plain G_l -> G_{l+1}                      (wave strips for large planes)
+//   k_lap_up | k_lap_up_rows         l = L-1..1, fused: band_l = G_l - pyrUp(G_{l+1}); IIR x2; x gain_l;
+//                                    cur_l = pyrUp(cur_{l+1}) + motion_l; in a batch the frame loop runs inside
+//                                    the kernel with the IIR states in registers (LDS tiles | 2x2 blocks per lane)
+//   k_lap_tail                       per-frame calls: all levels with <= 8192 pixels in one LDS-resident launch
+//   k_lap_final_v4 | k_lap_final     out = u8(Lab2BGR(Lab(u8 in) + [1,ca,ca] * pyrUp(cur_1)))   (wave strips | tile)
+// pyrDown/pyrUp follow OpenCV's border rules and operation order exactly (see the per-kernel comments) so
+// every variant is order-faithful to the oracle; which variant runs is decided per launch from its size.
 #include <cstdlib>
 #include <cstring>
 #include <vector>
