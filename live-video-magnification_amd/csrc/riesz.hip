@@ -14,14 +14,15 @@
 //   bandA_l  amplified band (collapse input)
 // plus the octaves oct_l (oct_0 = L plane) and the collapse results res_l.
 //
-// Launch sequence per frame:
-//   k_rz_lab               u8 BGR -> L plane
-//   k_rz_split  x (L-1)    9x9 high-pass (band) + 9x9 low-pass at even pixels (next octave), one LDS tile
-//   k_rz_phase  x (L-1)    Riesz pair (5-tap H/V), quaternion phase difference vs prior, amplitude,
-//                          phase accumulation, both IIR filters, prior <- current
-//   k_rz_blur_amp x (L-1)  three separable 13-tap Gaussians (amp, c, s) + phase-shift of the band
-//   k_rz_collapse x (L-2)  res_l = lp(zero-inject(res_{l+1})) (polyphase) + hp(bandA_l)
-//   k_rz_final             level-0 collapse + Lab2BGR(L', a, b) -> u8
+// Launch sequence (one frame, or a temporal batch of T frames of every stream):
+//   k_rz_lab4 | k_rz_lab             u8 BGR -> L plane (exact float64 cube root)
+//   k_rz_split2 | k_rz_split x (L-1) 9x9 high-pass (band) + 9x9 low-pass at even pixels (next octave), one LDS tile
+//   k_rz_phase (one launch, all band levels)   Riesz pair (5-tap H/V), quaternion phase difference vs prior, amplitude,
+//                                    phase accumulation, both IIR filters, prior <- current; in a batch the frame loop
+//                                    runs inside the kernel with the 13 state values in registers
+//   k_rz_blur_amp4 | k_rz_blur_amp   three separable 13-tap Gaussians (amp, c, s) + phase-shift of the band
+//   k_rz_collapse x (L-2)            res_l = lp(zero-inject(res_{l+1})) (polyphase) + hp(bandA_l)
+//   k_rz_final                       level-0 collapse + Lab2BGR(L', a, b) -> u8
 // Summation order of every filter equals the oracle's (row-major non-zero taps, fma chain).
 #include <cmath>
 
