@@ -678,6 +678,7 @@ struct ColorState : ModeState {
     bool co_rows_ok = false;         // the vectorised output kernel's LDS tile covers every output tile
     bool thin_dft = true;            // thread-per-row DFT for narrow bands (LVM_COL_THIN_DFT=0: wave-per-row kernel)
     long out_min_tasks = 2048;       // strips are shortened until a launch has this many (LVM_COL_OUT_MIN_TASKS)
+    bool up_rows = true;             // barrier-free pyrUp of the up chain (LVM_COL_UP_ROWS=0: tiled k_pyr_up)
     bool d0_rows_on = true;          // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
     long d0_min_tasks = 4096;        // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
     int out_rows = 16;               // rows per wave strip of k_col_out_rows (LVM_COL_OUT_ROWS; 0 = tiled k_col_out_v4)
@@ -869,8 +870,14 @@ static void col_up_out(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs&
     int uw = st->g[levels].w, uh = st->g[levels].h;
     // (a fused LDS-resident launch for the first three pyrUps measured 23.5 us against 3 x 7 us: not kept)
     for (int k = 0; k + 1 < levels; ++k) {      // L-1 generic pyrUps, the last one is fused into k_col_out
-        const dim3 grid((2 * uw + 63) / 64, (2 * uh + 15) / 16, planes);
-        LVM_LAUNCH(c, "pyr_up", k_pyr_up<1>, grid, blk, s, (const float*)B.up[k], uw, uh, B.up[k + 1], 2 * uw, 2 * uh);
+        if (st->up_rows && (2 * uw) % 4 == 0) {      // barrier-free blocks of 4 x 2 outputs per lane (pyramid.h)
+            const long ngroups = (long)(2 * uw / 4) * uh;
+            LVM_LAUNCH(c, "pyr_up", k_pyr_up_rows<1>, dim3((unsigned)((ngroups + 255) / 256), planes), blk, s, (const float*)B.up[k], uw, uh,
+                       B.up[k + 1], (int)ngroups);
+        } else {
+            const dim3 grid((2 * uw + 63) / 64, (2 * uh + 15) / 16, planes);
+            LVM_LAUNCH(c, "pyr_up", k_pyr_up<1>, grid, blk, s, (const float*)B.up[k], uw, uh, B.up[k + 1], 2 * uw, 2 * uh);
+        }
         uw *= 2; uh *= 2;
     }
     OutArgs a;
@@ -911,6 +918,7 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         st = new ColorState();
         c->state = st;
         if (const char* e = std::getenv("LVM_COL_THIN_DFT")) st->thin_dft = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_COL_UP_ROWS")) st->up_rows = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
         if (const char* e = std::getenv("LVM_COL_OUT_ROWS")) st->out_rows = std::atoi(e);

@@ -229,6 +229,44 @@ __global__ __launch_bounds__(256) void k_down0_v4(const uint8_t* __restrict__ in
     }
 }
 
+// ---- pyrUp of float planes without LDS (dsize = 2n exactly, dw % 4 == 0) ----------------------------------
+// The tiled k_pyr_up spends ~48 instructions per output pixel (92 % VALU-busy in the colour up chain).  Here a
+// lane owns a block of 4 columns x 2 rows (output rows 2j, 2j+1): three source rows x four dword loads, the
+// horizontal pass with the border variants selected per lane, both vertical formulas, two 16-byte stores.
+template <int TU>
+__global__ __launch_bounds__(256) void k_pyr_up_rows(const float* __restrict__ src, int sw, int sh,
+                                                     float* __restrict__ dst, int ngroups) {
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi >= ngroups) return;
+    const int dw = 2 * sw, gw = dw >> 2;                 // groups of 4 output columns per row
+    const int j = gi / gw, gx = (gi - j * gw) * 4;
+    const float* sp = src + (size_t)blockIdx.y * sw * sh;
+    float* dp = dst + (size_t)blockIdx.y * (size_t)dw * (2 * sh);
+    const int i0 = gx >> 1;
+    const int cm1 = i0 > 0 ? i0 - 1 : 0, cp1 = i0 + 1 < sw ? i0 + 1 : sw - 1, cp2 = i0 + 2 < sw ? i0 + 2 : sw - 1;
+    const bool f0 = i0 == 0, l0 = i0 == sw - 1, l1 = i0 + 1 == sw - 1;
+    float h[3][4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        int sy = j - 1 + q; sy = sy < 0 ? 1 : (sy >= sh ? sh - 1 : sy);       // vertical border map: row -1 -> 1, row sh -> sh - 1
+        const float* r = sp + (size_t)sy * sw;
+        const float sm1 = r[cm1], s0 = r[i0], s1 = r[cp1], s2 = r[cp2];
+        h[q][0] = sel(f0, s0 * 6.f + s1 * 2.f, sel(l0, sm1 + s0 * 7.f, sm1 + s0 * 6.f + s1));
+        h[q][1] = sel(l0, s0 * 8.f, (s0 + s1) * 4.f);
+        h[q][2] = sel(l1, s0 + s1 * 7.f, s0 + s1 * 6.f + s2);
+        h[q][3] = sel(l1, s1 * 8.f, (s1 + s2) * 4.f);
+    }
+    float e[4], o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        e[k] = (h[0][k] + h[1][k] * 6.f + h[2][k]) * (1.f / 64.f);
+        o[k] = ((h[1][k] + h[2][k]) * 4.f) * (1.f / 64.f);
+    }
+    float* d0 = dp + (size_t)(2 * j) * dw + gx;
+    *reinterpret_cast<float4*>(d0) = make_float4(e[0], e[1], e[2], e[3]);
+    *reinterpret_cast<float4*>(d0 + dw) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // ---- u8 BGR -> (Lab) -> pyrDown -> G_1 as wave strips ----------------------------------------------
 // Barrier-free form of k_down0_v4 (same preconditions, same arithmetic).  A wave owns a strip of 124 output
 // columns x `rows` output rows of one frame.  Lane i holds the source pixel group 4g .. 4g+3, g = 62 tx - 1 + i,
