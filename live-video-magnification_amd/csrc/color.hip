@@ -607,8 +607,6 @@ __global__ __launch_bounds__(256) void k_col_out_rows(OutArgs a, int strips_x, i
             const int yend = y0 + rows < a.h ? y0 + rows : a.h;
             int js = (a.yofs[y0] - 1) >> 1;
             HRow3 A = hrow(js), B = hrow(js + 1), C = hrow(js + 2);
-            float u1s[3][4] = {};                               // the second pyrUp row of the previous output row ...
-            int u1_row = -1;                                    // ... and its row index
             for (int gy = y0; gy < yend; ++gy) {
                 const int sy0 = a.yofs[gy];
                 const float b1 = a.ya[gy], b0 = 1.f - b1;
@@ -616,10 +614,7 @@ __global__ __launch_bounds__(256) void k_col_out_rows(OutArgs a, int strips_x, i
                 const int jn = (sy0 - 1) >> 1;
                 while (js < jn) { A = B; B = C; C = hrow(js + 3); ++js; }
                 const Px4 pin = *reinterpret_cast<const Px4*>(src + (size_t)gy * a.in_stride + xoff);
-                // pyrUp rows sy0 and sy0 + 1 of the lane's 4 columns; row sy0 usually IS the previous output row's second
-                // row (the row map advances by one U row per output row except where it skips), then it is reused
                 float val[3][4];
-                const bool reuse = sy0 == u1_row;              // wave-uniform
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float* pa = &A.c[c].x; const float* pb = &B.c[c].x; const float* pc = &C.c[c].x;
@@ -627,19 +622,17 @@ __global__ __launch_bounds__(256) void k_col_out_rows(OutArgs a, int strips_x, i
                     for (int k = 0; k < 4; ++k) {
                         float u0, u1;
                         if ((sy0 & 1) == 0) {             // rows 2j (window j-1, j, j+1) and 2j+1 (j, j+1)
-                            u0 = reuse ? u1s[c][k] : (pa[k] + pb[k] * 6.f + pc[k]) * (1.f / 64.f);
+                            u0 = (pa[k] + pb[k] * 6.f + pc[k]) * (1.f / 64.f);
                             u1 = ((pb[k] + pc[k]) * 4.f) * (1.f / 64.f);
                         } else {                          // rows 2j+1 (window j, j+1) and 2j+2 (j, j+1, j+2)
-                            u0 = reuse ? u1s[c][k] : ((pa[k] + pb[k]) * 4.f) * (1.f / 64.f);
+                            u0 = ((pa[k] + pb[k]) * 4.f) * (1.f / 64.f);
                             u1 = (pa[k] + pb[k] * 6.f + pc[k]) * (1.f / 64.f);
                         }
                         if (clamp1) u1 = u0;
-                        u1s[c][k] = u1;
                         // resize INTER_LINEAR: horizontal taps are (1, 0) here; vertical D = S0*b0 + S1*b1
                         val[c][k] = u0 * b0 + u1 * b1;
                     }
                 }
-                u1_row = clamp1 ? sy0 : sy0 + 1;
                 int Bv[4], Gv[4], Rv[4];
                 unpack_px4(pin, Bv, Gv, Rv);
                 float ov[12];
