@@ -307,6 +307,7 @@ __device__ __forceinline__ float mul_sd(float x, double s) { return (float)((dou
 // band + Riesz pair, accumulated phase, 8 filter registers) stay in registers and move through HBM
 // once per launch instead of once per frame; the band tile of frame t+1 is prefetched while frame t
 // is processed.
+template <bool EXACT>
 __global__ __launch_bounds__(256) void k_rz_phase(PhaseArgs aa) {
     __shared__ float s[PT_H + 4][PT_W + 4 + 1];
     int lvl = 0;
@@ -372,11 +373,19 @@ __global__ __launch_bounds__(256) void k_rz_phase(PhaseArgs aa) {
         const float xy = q1 * q1 + q2 * q2;                                // :89
         const float ampq = sqrtf(q0 * q0 + xy);                            // :91
         const float phi = arc_cos(q0 / ampq);                              // :93-97
-        const float sxy = sqrtf(xy);                                       // :99-100
-        float dc = (q1 / sxy) * phi, ds = (q2 / sxy) * phi;                // :102-104
+        // The acos argument above keeps IEEE sqrt and division in every flavour (it is the ill-conditioned step);
+        // the direction q/|q| and the amplitude are well-conditioned: the default flavour uses v_rsq / v_sqrt there.
+        float dc, ds;
+        if (EXACT) {
+            const float sxy = sqrtf(xy);                                   // :99-100
+            dc = (q1 / sxy) * phi; ds = (q2 / sxy) * phi;                  // :102-104
+        } else {
+            const float rs = __builtin_amdgcn_rsqf(xy);
+            dc = (q1 * rs) * phi; ds = (q2 * rs) * phi;
+        }
         if (dc != dc) dc = 0.f;                                            // :105-106
         if (ds != ds) ds = 0.f;
-        const float am = sqrtf(ampq);                                      // :108
+        const float am = EXACT ? sqrtf(ampq) : __builtin_amdgcn_sqrtf(ampq);   // :108
         // IIRTemporalFilter for the low and the high cutoff (TemporalFilter.cpp:343-350); both keep
         // their own copy of the accumulated phase in the reference, the copies are always equal.
         phc = phc + dc; phs = phs + ds;
@@ -884,7 +893,7 @@ static void rz_phase(Ctx* c, RieszState* st, const RzBufs& B, int mode, hipStrea
         v.fs = (long)NS * (long)st->g[l].n;
         blocks += v.tx * v.ty * NS;
     }
-    LVM_LAUNCH(c, mode ? "rz_seed" : "rz_phase", k_rz_phase, dim3(blocks), dim3(256), s, a);
+    LVM_LAUNCH(c, mode ? "rz_seed" : "rz_phase", c->exact_lab ? k_rz_phase<true> : k_rz_phase<false>, dim3(blocks), dim3(256), s, a);
 }
 
 // amplify + collapse + output of the nt frames (RieszPyramid.cpp:248-252, 304-325; MagnifyCore.hpp:269-277)

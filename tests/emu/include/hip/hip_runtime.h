@@ -69,6 +69,7 @@ static inline unsigned __builtin_amdgcn_cvt_pk_u8_f32(float v, unsigned byte, un
 }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
 static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
+static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / sqrtf(x); }
 static inline float __builtin_amdgcn_sinf(float rev) { return sinf(rev * 6.283185307179586f); }   // v_sin_f32: argument in revolutions
 static inline float __builtin_amdgcn_cosf(float rev) { return cosf(rev * 6.283185307179586f); }
 // DPP wave_shr:1 (0x138) / wave_shl:1 (0x130): every lane of the wave must execute it (uniform control flow)
