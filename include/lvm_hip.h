@@ -94,6 +94,17 @@ int  lvm_process_device_frames(lvm_ctx* ctx, const lvm_params* p, int n_frames, 
                                ptrdiff_t out_stride, ptrdiff_t out_stream_stride,
                                ptrdiff_t out_frame_stride, int* produced, void* hip_stream);
 
+/* Largest n_frames the caller will pass to lvm_process_device_frames: the per-batch pyramids are then
+ * allocated once when a mode's state is created, never inside a steady-state call (an export knows its
+ * batch size up front, export/Exporter.cpp:216-259).  Without the hint the buffers grow on demand.   */
+int  lvm_set_max_frames(lvm_ctx* ctx, int n_frames);
+
+/* Page-locked host memory for frame buffers (what the reference's core/FramePool.cpp:29-36 would allocate
+ * its pooled cv::Mat storage from): frames in such memory cross PCIe by DMA at link speed in lvm_process /
+ * lvm_chain_process.  Pageable frames work too (the HIP runtime pins them on the fly).               */
+int  lvm_host_alloc(size_t bytes, void** out);
+void lvm_host_free(void* p);
+
 /* ---- the two uint8 stages in front of the magnifier -------------------------
  * processing/IProcessor.hpp:26-41 PreprocessParams + ProcessorConfig::grayscale (IProcessor.hpp:45).  */
 typedef struct lvm_preprocess_params {

@@ -95,7 +95,8 @@ SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process
            "lvm_last_error", "lvm_max_levels", "lvm_optimal_buffer_size", "lvm_butterworth2",
            "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_profile_enable", "lvm_profile_collect",
            "lvm_profile_entry", "lvm_set_graph", "lvm_algorithmic_bytes",
-           "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process", "lvm_chain_process_batch"]
+           "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process", "lvm_chain_process_batch",
+           "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free"]
 
 
 def bind(lib):
@@ -139,6 +140,10 @@ def bind(lib):
                                       C.c_ssize_t, vp, C.c_ssize_t, ip]
     lib.lvm_chain_process_batch.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), C.POINTER(vp), C.c_int, C.c_int,
                                             C.c_int, C.c_ssize_t, C.POINTER(vp), C.c_ssize_t, ip]
+    lib.lvm_set_max_frames.argtypes = [vp, C.c_int]
+    lib.lvm_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    lib.lvm_host_free.argtypes = [vp]
+    lib.lvm_host_free.restype = None
     return lib
 
 
@@ -255,6 +260,9 @@ class Context:
         self._check(self.lib.lvm_process_device_frames(self.h, C.byref(cparams), n_frames, d_in, w, h, ch, in_stride, in_sstride,
                                                        in_fstride, d_out, out_stride, out_sstride, out_fstride, produced, stream))
         return [bool(x) for x in produced]
+
+    def set_max_frames(self, n):
+        self._check(self.lib.lvm_set_max_frames(self.h, int(n)))
 
     def set_pipeline(self, depth):
         self._check(self.lib.lvm_set_pipeline(self.h, int(depth)))

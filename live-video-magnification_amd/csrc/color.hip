@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void k_col_regrow(const float* __restrict__ ow
 // broadcasts).  Inverse: lane owns output samples t, t+64, ... and sums the entries in ascending
 // bin order.  Both are the oracle's summation orders, so results are order-faithful.
 constexpr int kDftMaxN = 1024;             // window lengths above this use k_col_dft_serial
+constexpr int kTwAllMax = 512;             // window lengths up to this get their twiddle tables built once for every warm-up length
 constexpr int kDftRows = 4;                // rows (waves) per workgroup
 struct DftEntry { short bin; short kind; };   // kind 0 = complex bin, 1 = DC, 2 = Nyquist
 __global__ __launch_bounds__(256) void k_col_dft(const float* __restrict__ win, int slot0, int n, int cap,
@@ -684,13 +685,15 @@ struct ColorState : ModeState {
     int out_rows = 16;               // rows per wave strip of k_col_out_rows (LVM_COL_OUT_ROWS; 0 = tiled k_col_out_v4)
     int thin_min_frames = 4;         // ... from this many frames per launch (LVM_COL_THIN_MIN_FRAMES)
     long rows_min_elems = 1 << 20;   // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
-    double* tw = nullptr; int tw_n = 0;
+    double* tw = nullptr; int tw_n = 0;          // table of the current window length (points into tw_all or at tw_own)
+    double* tw_all = nullptr; int tw_all_max = 0; std::vector<size_t> tw_off;   // tables of every length 2 .. tw_all_max
+    double* tw_own = nullptr;
     MinMax* mm = nullptr;
     int *xofs = nullptr, *yofs = nullptr; float *xa = nullptr, *ya = nullptr;
     // temporal batching
     int tcap = 0; float* tarena = nullptr; float* Gt[kMaxLevels + 1] = {}; float* upt[kMaxLevels + 1] = {}; float* col1t = nullptr; MinMax* mmt = nullptr;
     ~ColorState() override {
-        void* p[] = {arena, win, Y, tw, mm, xofs, yofs, xa, ya, tarena, mmt};
+        void* p[] = {arena, win, Y, tw_all, tw_own, mm, xofs, yofs, xa, ya, tarena, mmt};
         for (void* q : p) if (q) (void)hipFree(q);
     }
 };
@@ -708,6 +711,7 @@ static void resize_tab(int d, int s, std::vector<int>& ofs, std::vector<float>& 
     }
 }
 
+static int color_reserve_frames(Ctx* c, ColorState* st, int nt, hipStream_t s);
 static int color_alloc(Ctx* c, ColorState* st, int w, int h, int channels, int levels) {
     st->levels = levels; st->channels = channels; st->planes = c->nstreams * channels;
     st->g[0] = {w, h, (size_t)w * h};
@@ -803,19 +807,19 @@ static void col_down(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs& B
             const int sy = (b.h + rows - 1) / rows;
             const long ntasks = (long)sx * sy * planes;
             const dim3 grid((unsigned)((ntasks + PD_THREADS / 64 - 1) / (PD_THREADS / 64)));
-            LVM_LAUNCH(c, "pyr_down_rows", k_pyr_down_rows<1>, grid, dim3(PD_THREADS), s, (const float*)B.G[l], a.w, a.h, B.G[l + 1], b.w, b.h,
+            LVM_LAUNCH(c, LName("pyr_down_rows", l), k_pyr_down_rows<1>, grid, dim3(PD_THREADS), s, (const float*)B.G[l], a.w, a.h, B.G[l + 1], b.w, b.h,
                        sx, sy, (int)ntasks, rows);
             l += 1;
         } else if (levels - l >= 2) {
             const LevelGeom &a = st->g[l], &b1 = st->g[l + 1], &b2 = st->g[l + 2];
             const dim3 grid((b2.w + ML_T - 1) / ML_T, (b2.h + ML_T - 1) / ML_T, planes);
-            LVM_LAUNCH(c, "pyr_down2", k_pyr_down_multi<2>, grid, blk, s, (const float*)B.G[l], a.w, a.h, B.G[l + 1], b1.w, b1.h, B.G[l + 2],
+            LVM_LAUNCH(c, LName("pyr_down2", l), k_pyr_down_multi<2>, grid, blk, s, (const float*)B.G[l], a.w, a.h, B.G[l + 1], b1.w, b1.h, B.G[l + 2],
                        b2.w, b2.h, (float*)nullptr, 0, 0);
             l += 2;
         } else {
             const LevelGeom &a = st->g[l], &b = st->g[l + 1];
             const dim3 grid((b.w + 31) / 32, (b.h + 15) / 16, planes);
-            LVM_LAUNCH(c, "pyr_down", k_pyr_down<1>, grid, blk, s, (const float*)B.G[l], a.w, a.h, B.G[l + 1], b.w, b.h);
+            LVM_LAUNCH(c, LName("pyr_down", l), k_pyr_down<1>, grid, blk, s, (const float*)B.G[l], a.w, a.h, B.G[l + 1], b.w, b.h);
             l += 1;
         }
     }
@@ -872,11 +876,11 @@ static void col_up_out(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs&
     for (int k = 0; k + 1 < levels; ++k) {      // L-1 generic pyrUps, the last one is fused into k_col_out
         if (st->up_rows && (2 * uw) % 4 == 0) {      // barrier-free blocks of 4 x 2 outputs per lane (pyramid.h)
             const long ngroups = (long)(2 * uw / 4) * uh;
-            LVM_LAUNCH(c, "pyr_up", k_pyr_up_rows<1>, dim3((unsigned)((ngroups + 255) / 256), planes), blk, s, (const float*)B.up[k], uw, uh,
+            LVM_LAUNCH(c, LName("pyr_up", k), k_pyr_up_rows<1>, dim3((unsigned)((ngroups + 255) / 256), planes), blk, s, (const float*)B.up[k], uw, uh,
                        B.up[k + 1], (int)ngroups);
         } else {
             const dim3 grid((2 * uw + 63) / 64, (2 * uh + 15) / 16, planes);
-            LVM_LAUNCH(c, "pyr_up", k_pyr_up<1>, grid, blk, s, (const float*)B.up[k], uw, uh, B.up[k + 1], 2 * uw, 2 * uh);
+            LVM_LAUNCH(c, LName("pyr_up", k), k_pyr_up<1>, grid, blk, s, (const float*)B.up[k], uw, uh, B.up[k + 1], 2 * uw, 2 * uh);
         }
         uw *= 2; uh *= 2;
     }
@@ -925,7 +929,8 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         if (const char* e = std::getenv("LVM_COL_OUT_MIN_TASKS")) st->out_min_tasks = std::atol(e);
         if (const char* e = std::getenv("LVM_COL_THIN_MIN_FRAMES")) st->thin_min_frames = std::atoi(e);
         if (const char* e = std::getenv("LVM_ROWS_MIN_ELEMS")) st->rows_min_elems = std::atol(e);
-        const int rc = color_alloc(c, st, io.w, io.h, io.channels, levels);
+        int rc = color_alloc(c, st, io.w, io.h, io.channels, levels);
+        if (rc == LVM_OK && c->max_frames > 1) rc = color_reserve_frames(c, st, c->max_frames, s);
         if (rc != LVM_OK) return rc;
     }
     const ColBufs B{st->G, st->up, st->col1, st->mm, 1};
@@ -942,13 +947,38 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
     int n = st->n + 1, slot0 = st->slot0;
     if (n > maxImages && maxImages > 0) { slot0 = (slot0 + 1) % st->cap; n -= 1; }
     if (n >= 2 && st->tw_n != n) {   // twiddles cos/sin(2 pi k / n), float64, computed on the host like the oracle's
-        std::vector<double> t(2 * (size_t)n);
-        for (int k = 0; k < n; ++k) { t[k] = std::cos(2.0 * 3.1415926535897932384626433832795 * k / n); t[n + k] = std::sin(2.0 * 3.1415926535897932384626433832795 * k / n); }
-        LVM_HIP_TRY(c, hipStreamSynchronize(s));
-        if (st->tw) (void)hipFree(st->tw);
-        st->tw = nullptr;
-        LVM_HIP_TRY(c, hipMalloc((void**)&st->tw, t.size() * sizeof(double)));
-        LVM_HIP_TRY(c, hipMemcpy(st->tw, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+        // The window length grows by one per frame during warm-up (2, 3, .. maxImages): the tables of every length up
+        // to maxImages are built and uploaded ONCE (sum 2n doubles: 132 KB for T = 128), so a warm-up frame costs no
+        // host synchronisation, allocation or copy.  Lengths beyond kTwAllMax (fps > 256) keep the per-length upload.
+        const double two_pi = 2.0 * 3.1415926535897932384626433832795;
+        if (maxImages <= kTwAllMax && n <= maxImages) {
+            if (st->tw_all_max < maxImages) {
+                std::vector<double> t; std::vector<size_t> off((size_t)maxImages + 1, 0);
+                for (int m = 2; m <= maxImages; ++m) {
+                    off[(size_t)m] = t.size();
+                    for (int k = 0; k < m; ++k) t.push_back(std::cos(two_pi * k / m));
+                    for (int k = 0; k < m; ++k) t.push_back(std::sin(two_pi * k / m));
+                }
+                LVM_HIP_TRY(c, hipStreamSynchronize(s));
+                sync_streams(c);
+                if (st->tw_all) (void)hipFree(st->tw_all);
+                st->tw_all = nullptr; st->tw_all_max = 0;
+                LVM_HIP_TRY(c, hipMalloc((void**)&st->tw_all, t.size() * sizeof(double)));
+                LVM_HIP_TRY(c, hipMemcpy(st->tw_all, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+                st->tw_off = off; st->tw_all_max = maxImages;
+            }
+            st->tw = st->tw_all + st->tw_off[(size_t)n];
+        } else {
+            std::vector<double> t(2 * (size_t)n);
+            for (int k = 0; k < n; ++k) { t[k] = std::cos(two_pi * k / n); t[n + k] = std::sin(two_pi * k / n); }
+            LVM_HIP_TRY(c, hipStreamSynchronize(s));
+            sync_streams(c);
+            if (st->tw_own) (void)hipFree(st->tw_own);
+            st->tw_own = nullptr;
+            LVM_HIP_TRY(c, hipMalloc((void**)&st->tw_own, t.size() * sizeof(double)));
+            LVM_HIP_TRY(c, hipMemcpy(st->tw_own, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+            st->tw = st->tw_own;
+        }
         st->tw_n = n;
     }
     const int rc = col_filter(c, st, p, B, slot, slot0, n, s);
@@ -958,6 +988,34 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
     col_up_out(c, st, io, B, s);
     LVM_HIP_TRY(c, hipGetLastError());
     *produced = 1;
+    return LVM_OK;
+}
+
+// Buffers of a temporal batch; sized for max(nt, lvm_set_max_frames hint capped at kColorBatchMax) so steady-state
+// calls never allocate.
+static int color_reserve_frames(Ctx* c, ColorState* st, int nt, hipStream_t s) {
+    const int hint = c->max_frames < kColorBatchMax ? c->max_frames : kColorBatchMax;
+    if (nt < hint) nt = hint;
+    if (nt <= st->tcap) return LVM_OK;
+    const int levels = st->levels, NS = c->nstreams;
+    LVM_HIP_TRY(c, hipStreamSynchronize(s));
+    sync_streams(c);
+    if (st->tarena) (void)hipFree(st->tarena);
+    if (st->mmt) (void)hipFree(st->mmt);
+    st->tarena = nullptr; st->mmt = nullptr; st->tcap = 0;
+    auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
+    const size_t nL = st->g[levels].n;
+    size_t total = 64;
+    for (int l = 1; l <= levels; ++l) total += pad(st->g[l].n * st->planes * nt);
+    for (int k = 0; k < levels; ++k) total += pad((nL << (2 * k)) * st->planes * nt);
+    total += pad((size_t)st->rows * nt);
+    if (hipMalloc((void**)&st->tarena, total * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); st->tarena = nullptr; c->err = "color: hipMalloc (frames) failed"; return LVM_ERR_OOM; }
+    LVM_HIP_TRY(c, hipMalloc((void**)&st->mmt, sizeof(MinMax) * NS * nt));
+    float* q = st->tarena;
+    for (int l = 1; l <= levels; ++l) { st->Gt[l] = q; q += pad(st->g[l].n * st->planes * nt); }
+    for (int k = 0; k < levels; ++k) { st->upt[k] = q; q += pad((nL << (2 * k)) * st->planes * nt); }
+    st->col1t = q;
+    st->tcap = nt;
     return LVM_OK;
 }
 
@@ -973,26 +1031,7 @@ bool color_can_batch(const Ctx* c, const lvm_params& p, int nt) {
 
 int color_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int nt, hipStream_t s) {
     ColorState* st = static_cast<ColorState*>(c->state);
-    const int levels = st->levels, NS = c->nstreams;
-    if (nt > st->tcap) {
-        LVM_HIP_TRY(c, hipStreamSynchronize(s));
-        if (st->tarena) (void)hipFree(st->tarena);
-        if (st->mmt) (void)hipFree(st->mmt);
-        st->tarena = nullptr; st->mmt = nullptr; st->tcap = 0;
-        auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
-        const size_t nL = st->g[levels].n;
-        size_t total = 64;
-        for (int l = 1; l <= levels; ++l) total += pad(st->g[l].n * st->planes * nt);
-        for (int k = 0; k < levels; ++k) total += pad((nL << (2 * k)) * st->planes * nt);
-        total += pad((size_t)st->rows * nt);
-        if (hipMalloc((void**)&st->tarena, total * sizeof(float)) != hipSuccess) { st->tarena = nullptr; c->err = "color: hipMalloc (frames) failed"; return LVM_ERR_OOM; }
-        LVM_HIP_TRY(c, hipMalloc((void**)&st->mmt, sizeof(MinMax) * NS * nt));
-        float* q = st->tarena;
-        for (int l = 1; l <= levels; ++l) { st->Gt[l] = q; q += pad(st->g[l].n * st->planes * nt); }
-        for (int k = 0; k < levels; ++k) { st->upt[k] = q; q += pad((nL << (2 * k)) * st->planes * nt); }
-        st->col1t = q;
-        st->tcap = nt;
-    }
+    if (nt > st->tcap) { const int rc = color_reserve_frames(c, st, nt, s); if (rc != LVM_OK) return rc; }
     const ColBufs B{st->Gt, st->upt, st->col1t, st->mmt, nt};
     col_down(c, st, io, B, s);
     // frame f appends at slot (slot0 + n + f) and, the window being full, sees it start at slot0 + f + 1

@@ -675,6 +675,7 @@ struct LaplaceState : ModeState {
 };
 
 static void laplace_tail_plan(LaplaceState* st);
+static int laplace_reserve_frames(Ctx* c, LaplaceState* st, int nt, hipStream_t s);
 
 static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, int levels) {
     st->levels = levels;
@@ -812,25 +813,25 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
             const int sy = (b.h + rows - 1) / rows;
             const long ntasks = (long)sx * sy * planes;
             const dim3 grid((unsigned)((ntasks + PD_THREADS / 64 - 1) / (PD_THREADS / 64)));
-            LVM_LAUNCH(c, "pyr_down_rows", k_pyr_down_rows<0>, grid, dim3(PD_THREADS), s, (const float*)G[l], a.w, a.h, G[l + 1], b.w, b.h,
+            LVM_LAUNCH(c, LName("pyr_down_rows", l), k_pyr_down_rows<0>, grid, dim3(PD_THREADS), s, (const float*)G[l], a.w, a.h, G[l + 1], b.w, b.h,
                        sx, sy, (int)ntasks, rows);
             l += 1;
         } else if (left >= 3 && st->fuse_down >= 3) {
             const LevelGeom &a = st->g[l], &b1 = st->g[l + 1], &b2 = st->g[l + 2], &b3 = st->g[l + 3];
             const dim3 grid((b3.w + ML_T - 1) / ML_T, (b3.h + ML_T - 1) / ML_T, planes);
-            LVM_LAUNCH(c, "pyr_down3", k_pyr_down_multi<3>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b1.w, b1.h,
+            LVM_LAUNCH(c, LName("pyr_down3", l), k_pyr_down_multi<3>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b1.w, b1.h,
                        G[l + 2], b2.w, b2.h, G[l + 3], b3.w, b3.h);
             l += 3;
         } else if (left >= 2 && st->fuse_down >= 2) {
             const LevelGeom &a = st->g[l], &b1 = st->g[l + 1], &b2 = st->g[l + 2];
             const dim3 grid((b2.w + ML_T - 1) / ML_T, (b2.h + ML_T - 1) / ML_T, planes);
-            LVM_LAUNCH(c, "pyr_down2", k_pyr_down_multi<2>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b1.w, b1.h,
+            LVM_LAUNCH(c, LName("pyr_down2", l), k_pyr_down_multi<2>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b1.w, b1.h,
                        G[l + 2], b2.w, b2.h, (float*)nullptr, 0, 0);
             l += 2;
         } else {
             const LevelGeom &a = st->g[l], &b = st->g[l + 1];
             const dim3 grid((b.w + DT_W - 1) / DT_W, (b.h + DT_H - 1) / DT_H, planes);
-            LVM_LAUNCH(c, "pyr_down", k_pyr_down<0>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b.w, b.h);
+            LVM_LAUNCH(c, LName("pyr_down", l), k_pyr_down<0>, grid, blk, s, (const float*)G[l], a.w, a.h, G[l + 1], b.w, b.h);
             l += 1;
         }
     }
@@ -886,16 +887,16 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
             auto kr = depth == 4 ? (hc ? k_lap_up_rows<2, 4, true> : k_lap_up_rows<2, 4, false>)
                                  : (depth == 2 ? (hc ? k_lap_up_rows<2, 2, true> : k_lap_up_rows<2, 2, false>)
                                                : (hc ? k_lap_up_rows<2, 1, true> : k_lap_up_rows<2, 1, false>));
-            LVM_LAUNCH(c, "lap_up", kr, g2, blk, s, a, gw, (int)ngroups);
+            LVM_LAUNCH(c, LName("lap_up", l), kr, g2, blk, s, a, gw, (int)ngroups);
             continue;
         }
         int depth = (blocks >= 1024) ? 1 : st->up_depth;              // frame ring of the tiled kernel
         while (depth > 1 && a.nt % depth != 0) depth >>= 1;           // the ring depth must divide the frame count
-        if (first) LVM_LAUNCH(c, "lap_seed", (k_lap_up<true, 1>), grid, blk, s, a);
-        else if (depth == 1) LVM_LAUNCH(c, "lap_up", (k_lap_up<false, 1>), grid, blk, s, a);
-        else if (depth == 2) LVM_LAUNCH(c, "lap_up", (k_lap_up<false, 2>), grid, blk, s, a);
-        else if (depth <= 4) LVM_LAUNCH(c, "lap_up", (k_lap_up<false, 4>), grid, blk, s, a);
-        else LVM_LAUNCH(c, "lap_up", (k_lap_up<false, 8>), grid, blk, s, a);
+        if (first) LVM_LAUNCH(c, LName("lap_seed", l), (k_lap_up<true, 1>), grid, blk, s, a);
+        else if (depth == 1) LVM_LAUNCH(c, LName("lap_up", l), (k_lap_up<false, 1>), grid, blk, s, a);
+        else if (depth == 2) LVM_LAUNCH(c, LName("lap_up", l), (k_lap_up<false, 2>), grid, blk, s, a);
+        else if (depth <= 4) LVM_LAUNCH(c, LName("lap_up", l), (k_lap_up<false, 4>), grid, blk, s, a);
+        else LVM_LAUNCH(c, LName("lap_up", l), (k_lap_up<false, 8>), grid, blk, s, a);
     }
     const int tx = (io.w + UT_W - 1) / UT_W, ty = (io.h + UT_H - 1) / UT_H;
     const int ntiles = tx * ty * NS;
@@ -937,6 +938,29 @@ int laplace_flush(Ctx* c, hipStream_t s) {
     return LVM_OK;
 }
 
+// Buffers of a temporal batch (pyramids / collapse accumulators of nt frames).  Sized for the larger of nt and the
+// caller's lvm_set_max_frames hint, so a steady-state call never allocates; called when the state is created
+// (hint given) or when a batch exceeds what is there.
+static int laplace_reserve_frames(Ctx* c, LaplaceState* st, int nt, hipStream_t s) {
+    if (nt < c->max_frames) nt = c->max_frames;
+    if (nt <= st->tcap) return LVM_OK;
+    const int levels = st->levels;
+    LVM_HIP_TRY(c, hipStreamSynchronize(s));
+    sync_streams(c);
+    if (st->tarena) (void)hipFree(st->tarena);
+    st->tarena = nullptr; st->tcap = 0;
+    auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
+    size_t total = 64;
+    for (int l = 1; l <= levels; ++l) total += pad(st->g[l].n * st->planes * nt);
+    for (int l = 1; l < levels; ++l) total += pad(st->g[l].n * st->planes * nt);
+    if (hipMalloc((void**)&st->tarena, total * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); st->tarena = nullptr; c->err = "laplace: hipMalloc (frames) failed"; return LVM_ERR_OOM; }
+    float* q = st->tarena;
+    for (int l = 1; l <= levels; ++l) { st->Gt[l] = q; q += pad(st->g[l].n * st->planes * nt); }
+    for (int l = 1; l < levels; ++l) { st->curt[l] = q; q += pad(st->g[l].n * st->planes * nt); }
+    st->tcap = nt;
+    return LVM_OK;
+}
+
 // Temporal batch: nt consecutive frames of every stream in one pass (the reference's export loop,
 // export/Exporter.cpp:216-259, sees its frames in exactly this order).  Frame f of stream b lives at
 // d_in + (f * n_streams + b) * in_sstride.  Preconditions (checked by the caller): state seeded,
@@ -944,20 +968,7 @@ int laplace_flush(Ctx* c, hipStream_t s) {
 int laplace_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int nt, hipStream_t s) {
     LaplaceState* st = static_cast<LaplaceState*>(c->state);
     const int levels = st->levels;
-    if (nt > st->tcap) {
-        LVM_HIP_TRY(c, hipStreamSynchronize(s));
-        if (st->tarena) (void)hipFree(st->tarena);
-        st->tarena = nullptr; st->tcap = 0;
-        auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
-        size_t total = 64;
-        for (int l = 1; l <= levels; ++l) total += pad(st->g[l].n * st->planes * nt);
-        for (int l = 1; l < levels; ++l) total += pad(st->g[l].n * st->planes * nt);
-        if (hipMalloc((void**)&st->tarena, total * sizeof(float)) != hipSuccess) { st->tarena = nullptr; c->err = "laplace: hipMalloc (frames) failed"; return LVM_ERR_OOM; }
-        float* q = st->tarena;
-        for (int l = 1; l <= levels; ++l) { st->Gt[l] = q; q += pad(st->g[l].n * st->planes * nt); }
-        for (int l = 1; l < levels; ++l) { st->curt[l] = q; q += pad(st->g[l].n * st->planes * nt); }
-        st->tcap = nt;
-    }
+    if (nt > st->tcap) { const int rc = laplace_reserve_frames(c, st, nt, s); if (rc != LVM_OK) return rc; }
     if (st->pending.valid) { const int rc = laplace_flush(c, s); if (rc != LVM_OK) return rc; }
     // The batch is cut into chunks of consecutive frames.  The down sweeps (stage B: stateless, bound by the
     // Lab arithmetic) of all chunks run on the auxiliary stream, the up sweeps (stage A: the IIR kernels
@@ -1015,7 +1026,8 @@ int laplace_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, 
     if (!st) {
         st = new LaplaceState();
         c->state = st;
-        const int rc = laplace_alloc(c, st, io.w, io.h, io.channels, levels);
+        int rc = laplace_alloc(c, st, io.w, io.h, io.channels, levels);
+        if (rc == LVM_OK && c->max_frames > 1) rc = laplace_reserve_frames(c, st, c->max_frames, s);
         if (rc != LVM_OK) return rc;
     }
     const bool first = !st->seeded;

@@ -26,6 +26,21 @@ void prof_begin(Ctx* c, const char* name, hipStream_t s) {
 }
 void prof_end(Ctx* c, hipStream_t s) { (void)hipEventRecord(c->prof_events.back().e1, s); }
 
+// Waits for everything this context has enqueued -- on its own two streams and on caller streams (through the
+// event recorded after every enqueue; an event outlives the stream it was recorded on).  Never a device-wide
+// synchronisation: the reference runs a live chain and an export chain side by side (export/Exporter.cpp:204,231)
+// and one context's reset must not stall the other.
+void sync_streams(Ctx* c) {
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
+    if (c->ev_done && c->ev_done_set) (void)hipEventSynchronize(c->ev_done);
+    (void)hipGetLastError();
+}
+static void mark_enqueued(Ctx* c, hipStream_t s) {
+    if (s == c->own_stream || !c->ev_done) return;       // the own stream is synchronised directly
+    if (hipEventRecord(c->ev_done, s) == hipSuccess) c->ev_done_set = true; else (void)hipGetLastError();
+}
+
 static void drop_graphs(Ctx* c) {
     for (auto& g : c->graphs) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -97,15 +112,22 @@ static int run_mode_graphed(Ctx* c, const lvm_params* p, int levels, const Frame
     *produced = prod;
     return LVM_OK;
 }
+// A failed call (allocation failure, launch error) must not leave a half-built state installed: the next call
+// would launch kernels on null buffers.  Drop it and disarm the tracker so that the next frame starts afresh,
+// which is also what the reference's recovery path does (ProcessingChain.cpp:50-62 resets every stage).
+static void tracker_disable(Ctx* c);
+static void fail_state(Ctx* c, hipStream_t s) {
+    (void)hipStreamSynchronize(s);
+    sync_streams(c);
+    drop_state(c);
+    tracker_disable(c);
+}
 static void tracker_disable(Ctx* c) { c->t_mode = LVM_MODE_NONE; c->t_levels = -1; c->t_channels = -1; c->t_w = c->t_h = 0; }
 
 static int ensure_float(Ctx* c, size_t count) {
     if (count > c->float_cap) {
+        sync_streams(c);            // kernels of earlier calls may still be writing the kept frame
         if (c->d_float) (void)hipFree(c->d_float);
-    lvm::preprocess_release(c);
-    if (c->d_pre_in) (void)hipFree(c->d_pre_in);
-    if (c->d_pre_out) (void)hipFree(c->d_pre_out);
-    if (c->d_chain_out) (void)hipFree(c->d_chain_out);
         c->d_float = nullptr; c->float_cap = 0;
         LVM_HIP_TRY(c, hipMalloc((void**)&c->d_float, count * sizeof(float)));
         c->float_cap = count;
@@ -118,7 +140,13 @@ static int ensure_float(Ctx* c, size_t count) {
 static int process_device(Ctx* c, const lvm_params* p, const FrameIO& io, hipStream_t s, int* produced) {
     *produced = 0;
     if (p->mode == LVM_MODE_NONE || io.d_in == nullptr || io.w <= 0 || io.h <= 0) {      // :21-29
-        if (c->t_mode != LVM_MODE_NONE) { drop_state(c); tracker_disable(c); }
+        if (c->t_mode != LVM_MODE_NONE) {
+            // pipelined mode: the pending frame's output is owed to its caller (same rule as on a structural change)
+            if (c->t_mode == LVM_MODE_LAPLACE) (void)laplace_flush(c, s);
+            LVM_HIP_TRY(c, hipStreamSynchronize(s));
+            sync_streams(c);
+            drop_state(c); tracker_disable(c);
+        }
         return LVM_OK;
     }
     if (p->mode < 0 || p->mode > LVM_MODE_NONE) { c->err = "invalid mode"; return LVM_ERR_INVALID; }
@@ -134,6 +162,7 @@ static int process_device(Ctx* c, const lvm_params* p, const FrameIO& io, hipStr
         // buffers of the old geometry may still be in use by queued kernels
         if (c->t_mode == LVM_MODE_LAPLACE) (void)laplace_flush(c, s);   // pipelined mode: do not lose the pending frame
         LVM_HIP_TRY(c, hipStreamSynchronize(s));
+        sync_streams(c);                                                 // earlier calls may have used other streams
         c->t_mode = p->mode; c->t_levels = levels; c->t_w = io.w; c->t_h = io.h;
         c->t_channels = io.channels; c->t_pre = p->preprocess_key;
         drop_state(c);                                                                  // :39-43
@@ -142,9 +171,12 @@ static int process_device(Ctx* c, const lvm_params* p, const FrameIO& io, hipStr
         const int rc = ensure_float(c, (size_t)io.w * io.h * io.channels);
         if (rc != LVM_OK) return rc;
     }
-    if (c->use_graph && !c->profiling && c->state && c->state->steady(*p))
-        return run_mode_graphed(c, p, levels, io, s, produced);
-    return run_mode(c, p, levels, io, s, produced);
+    int rc;
+    if (c->use_graph && !c->profiling && c->state && c->state->steady(*p)) rc = run_mode_graphed(c, p, levels, io, s, produced);
+    else rc = run_mode(c, p, levels, io, s, produced);
+    mark_enqueued(c, s);
+    if (rc != LVM_OK) fail_state(c, s);
+    return rc;
 }
 
 }  // namespace lvm
@@ -170,6 +202,7 @@ int lvm_create(int device, int n_streams, lvm_ctx** out) {
     ok = ok && hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_gamma_u8, sizeof(g)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_invgamma, sizeof(ig)) == hipSuccess;
     ok = ok && hipMemcpy(c->d_gamma_u8, g, sizeof(g), hipMemcpyHostToDevice) == hipSuccess;
@@ -185,8 +218,7 @@ int lvm_create(int device, int n_streams, lvm_ctx** out) {
 void lvm_destroy(lvm_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    (void)hipDeviceSynchronize();
+    lvm::sync_streams(c);
     lvm::drop_graphs(c);
     delete c->state; c->state = nullptr;
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
@@ -195,6 +227,12 @@ void lvm_destroy(lvm_ctx* c) {
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_float) (void)hipFree(c->d_float);
+    lvm::preprocess_release(c);
+    if (c->d_pre_in) (void)hipFree(c->d_pre_in);
+    if (c->d_pre_out) (void)hipFree(c->d_pre_out);
+    if (c->d_chain_out) (void)hipFree(c->d_chain_out);
+    c->d_pre_in = c->d_pre_out = c->d_chain_out = nullptr; c->pre_in_cap = c->pre_out_cap = c->chain_out_cap = 0;
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -205,8 +243,8 @@ void lvm_destroy(lvm_ctx* c) {
 int lvm_reset(lvm_ctx* c) {                       // MagnificationProcessor.cpp:10-15
     if (!c) return LVM_ERR_INVALID;
     (void)hipSetDevice(c->device);
-    (void)hipDeviceSynchronize();
-    (void)hipGetLastError();
+    // (an owed pipelined frame is discarded: reset() means "forget everything", MagnificationProcessor.cpp:10-15)
+    lvm::sync_streams(c);
     lvm::drop_state(c);
     lvm::tracker_disable(c);
     c->t_pre = 0;
@@ -394,6 +432,23 @@ int lvm_process(lvm_ctx* c, const lvm_params* p, const uint8_t* in, int w, int h
     return LVM_OK;
 }
 
+// Page-locked host frames for the reference's FramePool (core/FramePool.cpp:29-36 allocates the pooled cv::Mat
+// buffers the chain hands to process()): frames living in such memory cross PCIe by DMA at link speed in
+// lvm_process / lvm_chain_process with no staging copy anywhere (hipMemcpy2DAsync sees the registration).
+int lvm_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return LVM_ERR_INVALID;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes, 0) != hipSuccess) { (void)hipGetLastError(); *out = nullptr; return LVM_ERR_OOM; }
+    return LVM_OK;
+}
+void lvm_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
+int lvm_set_max_frames(lvm_ctx* c, int n_frames) {
+    if (!c || n_frames < 1) return LVM_ERR_INVALID;
+    c->max_frames = n_frames;
+    return LVM_OK;
+}
+
 int lvm_synchronize(lvm_ctx* c) {
     if (!c) return LVM_ERR_INVALID;
     LVM_HIP_TRY(c, hipStreamSynchronize(c->own_stream));
@@ -409,7 +464,7 @@ int lvm_debug_exact_lab(lvm_ctx* c, int on) { if (!c) return LVM_ERR_INVALID; c-
 int lvm_debug_read_float(lvm_ctx* c, float* dst, size_t count) {
     if (!c || !dst) return LVM_ERR_INVALID;
     if (!c->d_float || count > c->float_count) { c->err = "no float frame kept"; return LVM_ERR_INVALID; }
-    LVM_HIP_TRY(c, hipDeviceSynchronize());
+    lvm::sync_streams(c);
     LVM_HIP_TRY(c, hipMemcpy(dst, c->d_float, count * sizeof(float), hipMemcpyDeviceToHost));
     return LVM_OK;
 }
@@ -422,8 +477,9 @@ int lvm_profile_enable(lvm_ctx* c, int on) {
 
 int lvm_profile_collect(lvm_ctx* c) {
     if (!c) return LVM_ERR_INVALID;
-    LVM_HIP_TRY(c, hipDeviceSynchronize());
+    lvm::sync_streams(c);
     for (auto& e : c->prof_events) {
+        (void)hipEventSynchronize(e.e1);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) { c->prof_totals[e.name].ms += ms; c->prof_totals[e.name].n += 1; }
         (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1);
@@ -444,9 +500,9 @@ int lvm_profile_entry(lvm_ctx* c, int idx, char* name, size_t cap, double* total
 int lvm_set_pipeline(lvm_ctx* c, int depth) {
     if (!c || depth < 0 || depth > 1) return LVM_ERR_INVALID;
     if (depth != c->pipeline_depth) {
-        LVM_HIP_TRY(c, hipDeviceSynchronize());
+        lvm::sync_streams(c);
         if (c->t_mode == LVM_MODE_LAPLACE) (void)lvm::laplace_flush(c, c->own_stream);
-        LVM_HIP_TRY(c, hipDeviceSynchronize());
+        lvm::sync_streams(c);
         lvm::drop_graphs(c);
         c->pipeline_depth = depth;
     }

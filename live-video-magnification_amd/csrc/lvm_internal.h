@@ -9,6 +9,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -262,12 +263,15 @@ struct Ctx {
     int pipeline_depth = 0;           // 0 = every call completes its own frame; 1 = outputs lag one call (Laplace)
     hipStream_t aux_stream = nullptr; // second stream of the cross-frame pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_done = nullptr; bool ev_done_set = false;   // recorded after every enqueue on a caller stream (sync_streams)
+    int max_frames = 0;               // lvm_set_max_frames: temporal-batch buffers are sized for this many frames up front
     bool exact_lab = false;   // debug: OpenCV-order Lab arithmetic everywhere (bit-faithful to the oracle)
     // preprocess stage (preprocess.hip): area tables of the current geometry, staging of the host chain
     void* pre_tables = nullptr;
     uint8_t *d_pre_in = nullptr, *d_pre_out = nullptr, *d_chain_out = nullptr; size_t pre_in_cap = 0, pre_out_cap = 0, chain_out_cap = 0;
 };
 
+void sync_streams(Ctx* c);
 void prof_begin(Ctx* c, const char* name, hipStream_t s);
 void prof_end(Ctx* c, hipStream_t s);
 
@@ -279,6 +283,14 @@ void prof_end(Ctx* c, hipStream_t s);
             return LVM_ERR_HIP;                                                           \
         }                                                                                 \
     } while (0)
+
+// Report name of a per-level launch ("lap_up_l1"); only built while profiling (the macro below evaluates its
+// name argument inside the profiling branch).
+struct LName {
+    char s[40];
+    LName(const char* base, int level) { std::snprintf(s, sizeof(s), "%s_l%d", base, level); }
+    operator const char*() const { return s; }
+};
 
 // Launch with optional event bracketing.  `nm` is the kernel's report name; template kernels
 // with several arguments are passed through a function-pointer variable.

@@ -380,7 +380,11 @@ __global__ __launch_bounds__(256) void k_rz_phase(PhaseArgs aa) {
             const float sxy = sqrtf(xy);                                   // :99-100
             dc = (q1 / sxy) * phi; ds = (q2 / sxy) * phi;                  // :102-104
         } else {
-            const float rs = __builtin_amdgcn_rsqf(xy);
+            // v_rsq_f32 flushes a denormal argument to 0 (-> +inf) where sqrt + divide stay finite: rescale by 2^64
+            // below 2^-100 (xy == 0 still gives inf -> 0 * inf = NaN -> patched to 0 below, like the reference's 0 / 0)
+            const bool tiny = xy < 0x1p-100f;
+            float rs = __builtin_amdgcn_rsqf(tiny ? xy * 0x1p64f : xy);
+            rs = tiny ? rs * 0x1p32f : rs;
             dc = (q1 * rs) * phi; ds = (q2 * rs) * phi;
         }
         if (dc != dc) dc = 0.f;                                            // :105-106
@@ -817,6 +821,7 @@ struct RieszState : ModeState {
 enum { F_BAND, F_P, F_R1, F_R2, F_PHC, F_PHS, F_LO0C, F_LO0S, F_LO1C, F_LO1S, F_HI0C, F_HI0S, F_HI1C, F_HI1S, F_AMP, F_TC, F_TS, F_BANDA, F_COUNT,
        F_R1C = F_COUNT, F_R2C, F_ALL };   // F_R1C / F_R2C: per-frame Riesz pair (aliases F_R1 / F_R2 in per-frame mode)
 
+static int riesz_reserve_frames(Ctx* c, RieszState* st, int nt, hipStream_t s);
 static int riesz_alloc(Ctx* c, RieszState* st, int w, int h, int levels) {
     st->levels = levels;
     const int NS = c->nstreams;
@@ -863,11 +868,11 @@ static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B,
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
         if (st->split2 && a.w % 4 == 0) {
             const dim3 grid2((a.w + CW - 1) / CW, (a.h + C2H - 1) / C2H, NZ);
-            LVM_LAUNCH(c, "rz_split", k_rz_split2, grid2, blk, s, (const float*)B.oct[l], a.w, a.h, B.pf[l][F_BAND], B.oct[l + 1], b.w, b.h);
+            LVM_LAUNCH(c, LName("rz_split", l), k_rz_split2, grid2, blk, s, (const float*)B.oct[l], a.w, a.h, B.pf[l][F_BAND], B.oct[l + 1], b.w, b.h);
             continue;
         }
         const dim3 grid((a.w + CW - 1) / CW, (a.h + CH - 1) / CH, NZ);
-        LVM_LAUNCH(c, "rz_split", k_rz_split, grid, blk, s, (const float*)B.oct[l], a.w, a.h, B.pf[l][F_BAND], B.oct[l + 1], b.w, b.h);
+        LVM_LAUNCH(c, LName("rz_split", l), k_rz_split, grid, blk, s, (const float*)B.oct[l], a.w, a.h, B.pf[l][F_BAND], B.oct[l + 1], b.w, b.h);
     }
 }
 
@@ -929,7 +934,7 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
     for (int l = nb - 1; l >= 1; --l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
         const dim3 grid((a.w + CW - 1) / CW, (a.h + CH - 1) / CH, NZ);
-        LVM_LAUNCH(c, "rz_collapse", k_rz_collapse, grid, blk, s, (const float*)B.pf[l][F_BANDA], resn, B.res[l], a.w, a.h, b.w, b.h);
+        LVM_LAUNCH(c, LName("rz_collapse", l), k_rz_collapse, grid, blk, s, (const float*)B.pf[l][F_BANDA], resn, B.res[l], a.w, a.h, b.w, b.h);
         resn = B.res[l];
     }
     const int tx = (w + CW - 1) / CW, ty = (h + CH - 1) / CH;
@@ -962,7 +967,8 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         if (const char* e = std::getenv("LVM_RZ_BLUR4")) st->blur4 = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_RZ_SPLIT2")) st->split2 = std::atoi(e) != 0;
         c->state = st;
-        const int rc = riesz_alloc(c, st, io.w, io.h, levels);
+        int rc = riesz_alloc(c, st, io.w, io.h, levels);
+        if (rc == LVM_OK && c->max_frames > 1) rc = riesz_reserve_frames(c, st, c->max_frames, s);
         if (rc != LVM_OK) return rc;
     }
     const RzBufs B{st->oct, st->res, st->f, 1};
@@ -989,28 +995,35 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
     return LVM_OK;
 }
 
+// Buffers of a temporal batch; sized for max(nt, lvm_set_max_frames hint) so steady-state calls never allocate.
+static int riesz_reserve_frames(Ctx* c, RieszState* st, int nt, hipStream_t s) {
+    if (nt < c->max_frames) nt = c->max_frames;
+    if (nt <= st->tcap) return LVM_OK;
+    const int levels = st->levels, NS = c->nstreams;
+    LVM_HIP_TRY(c, hipStreamSynchronize(s));
+    sync_streams(c);
+    if (st->tarena) (void)hipFree(st->tarena);
+    st->tarena = nullptr; st->tcap = 0;
+    auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
+    static const int kPer[] = {F_BAND, F_AMP, F_TC, F_TS, F_BANDA, F_R1C, F_R2C};
+    size_t total = 64;
+    for (int l = 0; l < levels; ++l) total += 2 * pad(st->g[l].n * NS * nt);
+    for (int l = 0; l < levels - 1; ++l) total += 7 * pad(st->g[l].n * NS * nt);
+    if (hipMalloc((void**)&st->tarena, total * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); st->tarena = nullptr; c->err = "riesz: hipMalloc (frames) failed"; return LVM_ERR_OOM; }
+    float* q = st->tarena;
+    for (int l = 0; l < levels; ++l) { st->oct_t[l] = q; q += pad(st->g[l].n * NS * nt); st->res_t[l] = q; q += pad(st->g[l].n * NS * nt); }
+    for (int l = 0; l < levels - 1; ++l) {
+        for (int k = 0; k < F_ALL_N; ++k) st->ft[l][k] = st->f[l][k];          // state planes are shared
+        for (int k : kPer) { st->ft[l][k] = q; q += pad(st->g[l].n * NS * nt); }
+    }
+    st->tcap = nt;
+    return LVM_OK;
+}
+
 // Temporal batch (see laplace_process_frames): nt consecutive frames, steady state only.
 int riesz_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int nt, hipStream_t s) {
     RieszState* st = static_cast<RieszState*>(c->state);
-    const int levels = st->levels, NS = c->nstreams;
-    if (nt > st->tcap) {
-        LVM_HIP_TRY(c, hipStreamSynchronize(s));
-        if (st->tarena) (void)hipFree(st->tarena);
-        st->tarena = nullptr; st->tcap = 0;
-        auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
-        static const int kPer[] = {F_BAND, F_AMP, F_TC, F_TS, F_BANDA, F_R1C, F_R2C};
-        size_t total = 64;
-        for (int l = 0; l < levels; ++l) total += 2 * pad(st->g[l].n * NS * nt);
-        for (int l = 0; l < levels - 1; ++l) total += 7 * pad(st->g[l].n * NS * nt);
-        if (hipMalloc((void**)&st->tarena, total * sizeof(float)) != hipSuccess) { st->tarena = nullptr; c->err = "riesz: hipMalloc (frames) failed"; return LVM_ERR_OOM; }
-        float* q = st->tarena;
-        for (int l = 0; l < levels; ++l) { st->oct_t[l] = q; q += pad(st->g[l].n * NS * nt); st->res_t[l] = q; q += pad(st->g[l].n * NS * nt); }
-        for (int l = 0; l < levels - 1; ++l) {
-            for (int k = 0; k < F_ALL_N; ++k) st->ft[l][k] = st->f[l][k];          // state planes are shared
-            for (int k : kPer) { st->ft[l][k] = q; q += pad(st->g[l].n * NS * nt); }
-        }
-        st->tcap = nt;
-    }
+    if (nt > st->tcap) { const int rc = riesz_reserve_frames(c, st, nt, s); if (rc != LVM_OK) return rc; }
     const RzBufs B{st->oct_t, st->res_t, st->ft, nt};
     rz_build(c, st, io, B, s);
     rz_phase(c, st, B, 0, s);
