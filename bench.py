@@ -2,26 +2,45 @@
 """bench.py -- magnified frames/s of the HIP magnification core on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--mode laplace|riesz|color] [--streams B]
-                    [--frames-per-call T]
+                    [--frames-per-call T] [--no-verify] [--no-subrecords]
 
-A "step" is one frame of the hot path for each of the B streams held by the context, over
-synthetic frames that are already resident in HBM; outputs stay in HBM.  The K steps are issued
-through lvm_process_device_frames in calls of T consecutive frames of the same stream(s) -- the
-reference's export loop (export/Exporter.cpp:216-259) sees its frames in exactly this order; the
-result of every frame is what K per-frame calls give (T = 1 selects those: the live, one-frame
-latency schedule).  Default workload = BASELINE.json configs[1]: Laplace motion, 1920x1080,
-6 levels, IIR 0.4-3 Hz, alpha 20, single stream, one MI355X.  With N > 1 (one rank per GPU, launched by
-torch.distributed.run) every rank runs its own independent stream(s): the path shards by
-stream with no data-path collective (weak scaling); RCCL is only used for the timing barrier
-and the max-over-ranks reduction.
+A "step" is one frame of the hot path for each of the B streams of the context, over synthetic frames that
+are already resident in HBM; outputs stay in HBM.  The K steps are issued through lvm_process_device_frames
+in calls of T consecutive frames of the same stream(s) -- the reference's export loop
+(export/Exporter.cpp:216-259) sees its frames in exactly this order; every frame's result is what K
+per-frame calls give (T = 1 selects those: the live, one-frame-latency schedule).  Headline workload =
+BASELINE.json configs[1]: Laplace motion, 1920x1080, 6 levels, IIR 0.4-3 Hz, alpha 20, one stream per GPU.
 
-Prints ONE JSON line (rank 0) carrying `roofline` (dominant kernel, HIP-event timed on the
-launch stream) and `cpu_baseline` (the CPU oracle timed on this box's host cores, rank 0, N=1).
+Sequence of one run (global frame index i reads input ring slot i % ring and writes output slot i):
+    priming   untimed, the SAME call shape as the timed region (first frame seeds, then whole calls of
+              min(T, K) frames; colour mode: until the rolling window is full) -- every buffer the timed
+              calls need exists afterwards (lvm_set_max_frames sizes the batch arenas when the state is created)
+    warmup    W untimed steps
+    timed     EXACTLY K steps, bracketed by barrier + device synchronisation, MAX over ranks
+    probe     one more call with the float frame kept (parity metric (i) of SURVEY.md 8c)
+    verify    rank 0 (N = 1; every rank with --verify-all-ranks): the CPU oracle replays the same frames from
+              frame 0 and the bench's OWN output frames -- >= 8 spread over the timed calls -- are compared with it
+              (u8 <= 1 LSB and >= 99.9 % identical; float probe <= 1e-4 relative).  The replay doubles as the
+              cpu_baseline sample.
+    profile   per-kernel HIP-event pass (two whole calls) -> roofline of the dominant kernel
+    sub-records (N = 1 unless --subrecords): per-frame schedule (T = 1), host-to-host lvm_process (pageable and
+              pinned frames), B = 4 / 16 streams per launch, and BASELINE configs[4] (Riesz 3840x2160 L8, one
+              stream per GPU; measured at every N)
+
+With --gpus N > 1 and no WORLD_SIZE in the environment the script re-executes itself under
+torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1).  Every rank runs its own independent
+stream(s) (seeds 1234 + global stream id): the path shards by stream with no data-path collective (weak
+scaling); RCCL only carries the timing barrier and the MAX-reduce of the elapsed time.
+
+Prints ONE JSON line (rank 0) carrying `roofline` and `cpu_baseline`.
 """
 import argparse
+import ctypes as C
 import importlib
 import json
+import math
 import os
+import socket
 import sys
 import time
 
@@ -30,6 +49,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MODES = {"laplace": 1, "riesz": 2, "color": 3}  # -> BASELINE.json configs index
+PROFILE_ROUND = "r02"
 
 
 def level_sizes(w, h, levels):
@@ -40,58 +60,216 @@ def level_sizes(w, h, levels):
     return out
 
 
-def kernel_alg_bytes(mode, name, w, h, ch, levels, streams, T=0):
-    """Compulsory bytes one launch of kernel `name` moves (every input read once + every output
-    written once) for the kernel decomposition of DESIGN.md; kernels launched once per level are
-    averaged over their launches (rocprofv3 reports them under one symbol).  None = not tabulated."""
+def kernel_alg_bytes(mode, name, w, h, ch, levels, S, T, Twin=0):
+    """Compulsory bytes ONE launch of the kernel reported as `name` moves when it covers T consecutive frames of S
+    streams: every per-frame input read once and every per-frame output written once (x T), every temporal state
+    word read once and written once PER LAUNCH (the batched kernels keep the state in registers across their T
+    frames).  Per-level launches carry their level in the name ("lap_up_l1").  None = not tabulated."""
     sizes = level_sizes(w, h, levels)
     n = [a * b for a, b in sizes]
-    S = streams
-    P = ch * streams
-    avg = lambda xs: (sum(xs) / len(xs)) if xs else None  # noqa: E731
+    P = ch * S
+    lvl = None
+    base = name
+    if "_l" in name and name.rsplit("_l", 1)[1].isdigit():
+        base, l_s = name.rsplit("_l", 1)
+        lvl = int(l_s)
     if mode == "laplace":
-        return {
-            "lap_down0": S * ch * n[0] + 4 * P * n[1],
-            "lap_final": 2 * S * ch * n[0] + 4 * P * n[1],
-            "pyr_down": avg([4 * P * (n[l] + n[l + 1]) for l in range(1, levels)]),
-            # the wave-strip pyrDown serves the levels with >= 2^20 plane-pixels per launch (laplace.hip)
-            "pyr_down_rows": avg([4 * P * (n[l] + n[l + 1]) for l in range(1, levels)
-                                  if sizes[l][0] % 4 == 0 and n[l] * P >= (1 << 20)]),
-            # G_l + G_{l+1} + cur_{l+1} read, hi/lo read+written, cur_l written
-            "lap_up": avg([4 * P * (n[l] * 6 + 2 * n[l + 1]) for l in range(1, levels)]),
-            "lap_seed": avg([4 * P * (n[l] * 3 + n[l + 1]) for l in range(1, levels)]),
-        }.get(name)
+        if base == "lap_down0":
+            return T * (S * ch * n[0] + 4 * P * n[1])
+        if base in ("lap_final", "lap_final1"):
+            b = T * (2 * S * ch * n[0])
+            if base == "lap_final":
+                return b + T * 4 * P * n[1]                                   # + cur_1 read
+            # fused level-1 step: G_1, G_2, cur_2 read per frame; level-1 IIR states once per launch
+            return b + T * 4 * P * (n[1] + 2 * n[2]) + 16 * P * n[1]
+        if base in ("pyr_down", "pyr_down_rows") and lvl is not None:
+            return T * 4 * P * (n[lvl] + n[lvl + 1])
+        if base == "pyr_down2" and lvl is not None:
+            return T * 4 * P * (n[lvl] + n[lvl + 1] + n[lvl + 2])
+        if base == "pyr_down3" and lvl is not None:
+            return T * 4 * P * (n[lvl] + n[lvl + 1] + n[lvl + 2] + n[lvl + 3])
+        if base == "lap_up" and lvl is not None:
+            per_frame = 4 * P * (n[lvl] + n[lvl + 1] + (n[lvl + 1] if lvl + 1 <= levels - 1 else 0) + n[lvl])
+            return T * per_frame + 16 * P * n[lvl]                            # hi/lo read + written once per launch
+        if base == "lap_coarse":     # levels lvl .. L-1 in one launch: G_lvl.. read, cur_lvl written, states once
+            tot = 0
+            for l in range(lvl, levels):
+                tot += T * 4 * P * n[l] + 16 * P * n[l]
+            return tot + T * 4 * P * (n[levels] + n[lvl])
+        if base == "lap_seed" and lvl is not None:
+            return 4 * P * (n[lvl] * 3 + n[lvl + 1])
+        return None
     if mode == "riesz":
         nb = levels - 1
-        return {
-            "rz_lab": S * (3 * n[0] + 4 * n[0]),
-            "rz_split": avg([4 * S * (2 * n[l] + n[l + 1]) for l in range(nb)]),
-            # band 4 + prior(3) R/W 24 + phase(2) R/W 16 + registers(8) R/W 64 + amp,tc,ts 12
-            "rz_phase": sum(120 * S * n[l] for l in range(nb)),          # one launch covers every band level
-            "rz_seed": sum((4 + 13 * 4) * S * n[l] for l in range(nb)),
-            # the register-blocked kernel serves the levels with w % 4 == 0, w >= 128, h >= 64 (riesz.hip)
-            "rz_blur_amp": sum(28 * S * n[l] for l in range(nb) if sizes[l][0] % 4 == 0 and sizes[l][0] >= 128 and sizes[l][1] >= 64),
-            "rz_blur_amp_small": sum(28 * S * n[l] for l in range(nb)
-                                     if not (sizes[l][0] % 4 == 0 and sizes[l][0] >= 128 and sizes[l][1] >= 64)),
-            "rz_collapse": avg([4 * S * (2 * n[l] + n[l + 1]) for l in range(1, nb)]),
-            "rz_final": S * (6 * n[0] + 4 * n[0] + 4 * n[1]),
-        }.get(name)
+        big = lambda l: sizes[l][0] % 4 == 0 and sizes[l][0] >= 128 and sizes[l][1] >= 64  # noqa: E731
+        if base == "rz_lab":
+            return T * S * (3 * n[0] + 4 * n[0])
+        if base == "rz_split" and lvl is not None:
+            return T * 4 * S * (2 * n[lvl] + n[lvl + 1])
+        if base == "rz_phase":
+            # per frame: band in, amp/tc/ts/R1/R2 out (24 B per band pixel); 13 state floats R + W once per launch
+            return sum((T * 24 + 104) * S * n[l] for l in range(nb))
+        if base == "rz_seed":
+            return sum((4 + 13 * 4) * S * n[l] for l in range(nb))
+        if base == "rz_blur_amp":
+            return T * sum(28 * S * n[l] for l in range(nb) if big(l))
+        if base == "rz_blur_amp_small":
+            return T * sum(28 * S * n[l] for l in range(nb) if not big(l))
+        if base == "rz_collapse" and lvl is not None:
+            return T * 4 * S * (2 * n[lvl] + n[lvl + 1])
+        if base == "rz_final":
+            return T * S * (6 * n[0] + 4 * n[0] + 4 * n[1])
+        return None
     if mode == "color":
         nL = n[levels]
+        if base == "col_down0":
+            return T * (S * ch * n[0] + 4 * P * n[1])
+        if base in ("pyr_down", "pyr_down_rows") and lvl is not None:
+            return T * 4 * P * (n[lvl] + n[lvl + 1])
+        if base == "pyr_down2" and lvl is not None:
+            return T * 4 * P * (n[lvl] + n[lvl + 1] + n[lvl + 2])
+        if base == "col_append":
+            return T * 8 * P * nL
+        if base == "col_dft":
+            return 4 * P * nL * (Twin + T) + T * 4 * P * nL       # the window once per launch + one column out per frame
+        if base == "col_norm":
+            return T * 8 * P * nL
+        if base == "pyr_up" and lvl is not None:
+            return T * 4 * P * nL * (4 ** lvl + 4 ** (lvl + 1))
         nV = nL * 4 ** (levels - 1)
-        return {
-            "col_down0": S * ch * n[0] + 4 * P * n[1],
-            "pyr_down": avg([4 * P * (n[l] + n[l + 1]) for l in range(1, levels)]),
-            "pyr_down_rows": avg([4 * P * (n[l] + n[l + 1]) for l in range(1, levels)
-                                  if sizes[l][0] % 4 == 0 and n[l] * P >= (1 << 20)]),
-            "col_append": 8 * ch * nL,
-            "col_dft": 4 * P * nL * (T + 1),
-            "col_norm": 8 * ch * nL,
-            "pyr_up": avg([4 * P * nL * (4 ** k + 4 ** (k + 1)) for k in range(levels - 1)]),
-            "col_minmax": S * ch * n[0] + 4 * P * nV,
-            "col_out": 2 * S * ch * n[0] + 4 * P * nV,
-        }.get(name)
+        if base == "col_minmax":
+            return T * (S * ch * n[0] + 4 * P * nV)
+        if base == "col_out":
+            return T * (2 * S * ch * n[0] + 4 * P * nV)
+        return None
     return None
+
+
+def batched_frame_bytes(mode, w, h, ch, levels, T, Twin):
+    """Compulsory bytes per frame per stream when T frames share the launches: SURVEY.md 8d's B_alg with the
+    temporal-state term divided by T (the state then crosses HBM once per call, not once per frame)."""
+    sizes = level_sizes(w, h, levels)
+    n = [a * b for a, b in sizes]
+    io = 2.0 * ch * n[0]
+    if mode == "laplace":
+        return io + 16.0 * ch * sum(n[1:levels]) / T
+    if mode == "riesz":
+        return io + 88.0 * sum(n[0:levels - 1]) / T
+    return io + (4.0 * ch * n[levels] * Twin) / min(T, 32) + 4.0 * ch * n[levels]
+
+
+def reexec_under_torchrun(args):
+    """`python bench.py --gpus N` from a plain shell: become N ranks (one per GPU) on this node."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execvpe(cmd[0], cmd, env)
+
+
+def prime_total(lvm, pk, T, K, W):
+    """priming + warm-up frames in front of the timed region: a multiple of T"""
+    need = 1 + min(T, K)
+    if pk["mode"] == lvm.synth.MODE_COLOR:     # the rolling window must be full before the steady state
+        need = max(need, lvm.load().lvm_optimal_buffer_size(int(pk["framerate"])) + 32 + 1)
+    if pk["mode"] == lvm.synth.MODE_PHASE:
+        need += 1                               # the first frame passes through, the second one seeds
+    return ((need + W + T - 1) // T) * T
+
+
+class Runner:
+    """One context + its synthetic clip(s) staged in HBM + the call schedule of the benchmark."""
+
+    def __init__(self, lvm, torch, np, cfg_idx, small, B, ring, T, device, stream_ids, out_frames, time_shift=False):
+        self.lvm, self.torch, self.np = lvm, torch, np
+        ck, pk = lvm.synth.config(cfg_idx, small)
+        self.ck, self.pk = ck, pk
+        self.w, self.h, self.levels, self.ch = ck["w"], ck["h"], pk["levels"], 3
+        self.B, self.ring, self.T = B, ring, T
+        w, h, ch = self.w, self.h, self.ch
+        self.frame_bytes = h * w * ch
+        dev = torch.device("cuda", device)
+        # frames are generated on the GPU in float64 with the generator's own operations (bit-identical to
+        # Clip.frame, checked by tests/test_gpu_parity.py); stream s of this rank uses seed 1234 + global stream id
+        self.d_in = torch.empty((ring, B, h, w, ch), dtype=torch.uint8, device=dev)
+        if time_shift:      # sub-records only: B time-shifted copies of ONE clip (independent states, cheap to stage)
+            clip = lvm.synth.Clip(seed=lvm.sharding.stream_seed(stream_ids[0]), **{k: v for k, v in ck.items() if k != "seed"})
+            base = [clip.frame_torch(t, dev) for t in range(ring)]
+            for t in range(ring):
+                for s in range(B):
+                    self.d_in[t, s] = base[(t + 5 * s) % ring]
+        else:
+            for s, sid in enumerate(stream_ids):
+                clip = lvm.synth.Clip(seed=lvm.sharding.stream_seed(sid), **{k: v for k, v in ck.items() if k != "seed"})
+                for t in range(ring):
+                    self.d_in[t, s] = clip.frame_torch(t, dev)
+        self.oring = max(ring, out_frames)
+        self.oring = ((self.oring + ring - 1) // ring) * ring
+        self.d_out = torch.zeros((self.oring, B, h, w, ch), dtype=torch.uint8, device=dev)
+        self.ctx = lvm.Context(device, B)
+        self.ctx.set_max_frames(T)
+        self.cp = lvm.LvmParams(pk["mode"], pk["levels"], pk["amplification"], pk["coWavelength"], pk["coLow"], pk["coHigh"],
+                                pk["chromAttenuation"], pk["framerate"], 0)
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self.in0 = self.d_in.data_ptr()
+        self.out0 = self.d_out.data_ptr()
+        self.fstride = self.frame_bytes * B
+        self.fast = self.ctx.make_stepper(self.cp, w, h, ch, w * ch, self.frame_bytes, w * ch, self.frame_bytes, self.stream)
+        self.fn_frames = self.ctx.lib.lvm_process_device_frames
+        self.prod = (C.c_int * max(T, 1))()
+        self.p_ref = C.byref(self.cp)
+        self.n = 0                                # frames issued so far
+
+    def run(self, count):
+        """issue the next `count` frames in calls of at most T frames that wrap neither ring"""
+        i, end = self.n, self.n + count
+        w, h, ch, fb, fs = self.w, self.h, self.ch, self.frame_bytes, self.fstride
+        while i < end:
+            t, o = i % self.ring, i % self.oring
+            nf = min(self.T, end - i, self.ring - t, self.oring - o)
+            if nf == 1:
+                rc = self.fast(self.in0 + t * fs, self.out0 + o * fs)
+            else:
+                rc = self.fn_frames(self.ctx.h, self.p_ref, nf, self.in0 + t * fs, w, h, ch, w * ch, fb, fs, self.out0 + o * fs, w * ch,
+                                    fb, fs, self.prod, self.stream)
+            if rc != 0:
+                self.ctx._check(rc)
+            i += nf
+        self.n = end
+
+    def prime(self, K, W):
+        """untimed: the first frame (seeds the state) and whole calls of the timed shape; ends so that the timed
+        region starts on a multiple of T (ring % T == 0: timed calls are never cut by the ring)"""
+        n = prime_total(self.lvm, self.pk, self.T, K, W) - W
+        self.run(n)
+        return n
+
+    def close(self):
+        self.ctx.close()
+
+
+def oracle_replay(po, np, host_frames, pk, ring, n_frames, check, threads, float_at=-1):
+    """The CPU oracle over frames 0 .. n_frames-1 of stream 0 (input slot i % ring); returns the oracle's u8 frames at
+    the indices in `check`, its pre-quantisation float frame at index `float_at`, and the replay's wall time."""
+    o = po.Oracle()
+    P = po.make_params(**pk)
+    po.lib().lvmo_set_threads(threads)
+    keep = {}
+    want = set(check)
+    fl = None
+    t0 = time.perf_counter()
+    for i in range(n_frames):
+        ref, produced = o.process(host_frames[i % ring], P)
+        if i in want:
+            keep[i] = (ref.copy(), bool(produced))
+        if i == float_at:
+            fl = o.last_float().copy()
+    dt = time.perf_counter() - t0
+    o.close()
+    return keep, fl, dt
 
 
 def main():
@@ -104,15 +282,22 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--levels", type=int, default=0)
-    ap.add_argument("--ring", type=int, default=64, help="distinct input frames kept in HBM")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay steady-state frames from a captured hipGraph")
+    ap.add_argument("--ring", type=int, default=64, help="distinct input frames kept in HBM (rounded up to a multiple of T)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle replay (implies --no-verify)")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--verify-all-ranks", action="store_true", help="every rank checks its own stream against the oracle (tests)")
+    ap.add_argument("--subrecords", action="store_true", help="run the sub-records also at N > 1 (default: N = 1 only)")
+    ap.add_argument("--no-subrecords", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay steady-state frames from a captured hipGraph (per-frame calls)")
     ap.add_argument("--frames-per-call", type=int, default=32, help="consecutive frames of the stream(s) handed to one lvm_process_device_frames call (1 = per-frame calls)")
     ap.add_argument("--pipeline", type=int, default=0, help="cross-frame pipeline depth of lvm_process_device (0 or 1)")
     ap.add_argument("--profile-steps", type=int, default=-1, help="frames of the per-kernel timing pass (default: two calls of T frames; 0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (smoke-testing the N > 1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        reexec_under_torchrun(args)
 
     import numpy as np
     import torch
@@ -133,6 +318,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.dist_backend)
+    red_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
 
     lvm = importlib.import_module("live-video-magnification_amd")
     cfg_idx = MODES[args.mode]
@@ -140,180 +326,284 @@ def main():
     ck0, pk0 = lvm.synth.config(cfg_idx)
     if args.width or args.height or args.levels:
         small = (args.width or ck0["w"], args.height or ck0["h"], args.levels or pk0["levels"])
-    ck, pk = lvm.synth.config(cfg_idx, small)
-    w, h, levels, ch = ck["w"], ck["h"], pk["levels"], 3
     B = args.streams
+    K, W = args.steps, args.warmup
+    T = max(1, args.frames_per_call)
+    ring = ((max(args.ring, T) + T - 1) // T) * T
+    T = min(T, ring)
+    verify = not (args.no_verify or args.no_cpu_baseline) and (args.verify_all_ranks or (rank == 0 and world == 1))
+    do_sub = (world == 1 or args.subrecords) and not args.no_subrecords
 
-    # ---- synthetic clip, staged in HBM: ring x B x h x w x 3 (stream s uses seed 1234 + s) ----
-    ring = args.ring
     ids = lvm.sharding.stream_ids(rank, world, B)
-    clips = [lvm.synth.Clip(seed=lvm.sharding.stream_seed(i), **{k: v for k, v in ck.items() if k != "seed"}) for i in ids]
-    host = np.empty((ring, B, h, w, ch), np.uint8)
-    for t in range(ring):
-        for s in range(B):
-            host[t, s] = clips[s].frame(t)
-    d_in = torch.from_numpy(host).cuda()
-    d_out = torch.empty_like(d_in)
-    frame_bytes = h * w * ch
+    # every output frame of the run is kept (HBM is 288 GB: 530 frames of 1080p are 3.3 GB) so that the verification can look
+    # at the timed region's own output; capped, beyond the cap the output ring wraps and only its last frames are checked
+    ck_s, _ = lvm.synth.config(cfg_idx, small)
+    fb = ck_s["w"] * ck_s["h"] * 3 * B
+    expect_frames = prime_total(lvm, lvm.synth.config(cfg_idx, small)[1], T, K, W) + K + T
+    out_frames = expect_frames if verify and expect_frames * fb <= (24 << 30) else ring
+    R = Runner(lvm, torch, np, cfg_idx, small, B, ring, T, local_rank, ids, out_frames)
+    w, h, levels, ch, pk = R.w, R.h, R.levels, R.ch, R.pk
+    R.ctx.set_graph(bool(args.graph))
+    R.ctx.set_pipeline(args.pipeline)
+    stream = R.stream
 
-    ctx = lvm.Context(local_rank, B)
-    ctx.set_graph(bool(args.graph))
-    ctx.set_pipeline(args.pipeline)
-    cp = lvm.LvmParams(pk["mode"], pk["levels"], pk["amplification"], pk["coWavelength"], pk["coLow"], pk["coHigh"],
-                       pk["chromAttenuation"], pk["framerate"], 0)
-    stream = torch.cuda.current_stream().cuda_stream
+    primed = R.prime(K, W)
+    R.run(W)
+    base = R.n
+    dt = lvm.sharding.timed_steps(lambda i: R.run(K), 1, dist, torch.cuda.synchronize, red_dev, finish=lambda: R.ctx.flush(stream))
+    host_enqueue = getattr(lvm.sharding.timed_steps, "host_seconds", 0.0)
+    fps = lvm.sharding.aggregate_fps(world, B, K, dt)
 
-    in_ptrs = [d_in[t].data_ptr() for t in range(ring)]
-    out_ptrs = [d_out[t].data_ptr() for t in range(ring)]
-    fast = ctx.make_stepper(cp, w, h, ch, w * ch, frame_bytes, w * ch, frame_bytes, stream)
+    # ---- float probe: one more call with the pre-quantisation frame kept (stream 0, last frame of the call) ----
+    probe_n = 0
+    float_gpu = None
+    if verify:
+        R.ctx.flush(stream)
+        R.ctx.set_pipeline(0)
+        R.ctx.keep_float(True)
+        probe_n = min(T, ring - R.n % ring)          # ONE call (not cut by the input ring)
+        probe_first = R.n                # the kernels keep the float frame of the FIRST frame of a batch (stream 0)
+        if args.mode == "color":
+            probe_first += 32 * ((probe_n - 1) // 32)      # the colour mode cuts a call into chunks of <= 32 frames
+        R.run(probe_n)
+        torch.cuda.synchronize()
+        float_gpu = R.ctx.read_float((h, w, ch))
+        R.ctx.keep_float(False)
+    n_verify = R.n
 
-    def step(i):
-        t = i % ring
-        rc = fast(in_ptrs[t], out_ptrs[t])
-        if rc != 0:
-            ctx._check(rc)
-
-    # temporal batches: one call = T consecutive ring frames (frame stride = B * frame_bytes)
-    T = max(1, min(args.frames_per_call, ring))
-    fn_frames = ctx.lib.lvm_process_device_frames
-    import ctypes as C
-    prod_arr = (C.c_int * T)()
-    p_ref = C.byref(cp)
-
-    def run_frames(first, count):
-        """process `count` frames starting at global frame index `first`, in calls of at most T frames
-        that never wrap around the ring"""
-        i = first
-        end = first + count
-        while i < end:
-            t = i % ring
-            nf = min(T, end - i, ring - t)
-            if nf == 1:
-                step(i)
-            else:
-                rc = fn_frames(ctx.h, p_ref, nf, in_ptrs[t], w, h, ch, w * ch, frame_bytes, frame_bytes * B, out_ptrs[t], w * ch,
-                               frame_bytes, frame_bytes * B, prod_arr, stream)
-                if rc != 0:
-                    ctx._check(rc)
-            i += nf
-
-    red_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
-    if args.mode == "color":   # the rolling window must be full before the steady state starts
-        args.warmup = max(args.warmup, lvm.load().lvm_optimal_buffer_size(int(pk["framerate"])) + 32)
-    n = 0
-    run_frames(0, args.warmup); n += args.warmup
-    base = n
-    if T > 1:
-        # K steps (frames) issued as ceil(K / T) batched calls; timed_steps sees it as one "step" of K frames
-        dt = lvm.sharding.timed_steps(lambda i: run_frames(base, args.steps), 1, dist, torch.cuda.synchronize,
-                                      red_dev, finish=lambda: ctx.flush(stream))
-    else:
-        dt = lvm.sharding.timed_steps(lambda i: step(base + i), args.steps, dist, torch.cuda.synchronize, torch.device("cuda", local_rank),
-                                      finish=lambda: ctx.flush(stream))
-    n += args.steps
-    fps = lvm.sharding.aggregate_fps(world, B, args.steps, dt)
+    # ---- verification against the CPU oracle (also the cpu_baseline sample) ----
+    cpu = None
+    verified = None
+    vinfo = None
+    if verify:
+        from oracle import pyoracle as po
+        nthreads = max(1, min(16, os.cpu_count() or 1))   # beyond ~16 threads fork/join over small levels dominates
+        host = R.d_in[:, 0].cpu().numpy()                 # stream 0 of this rank
+        lo = max(0, n_verify - R.oring)                   # frames still present in the output ring
+        timed_idx = sorted(set(int(round(x)) for x in np.linspace(base, base + K - 1, 12)))
+        check = [i for i in timed_idx if i >= lo] + [n_verify - 1]
+        if lo == 0:
+            check = [1, primed - 1] + check
+        keep, fl_ref, cdt = oracle_replay(po, np, host, pk, ring, n_verify, check, nthreads, float_at=probe_first)
+        worst_du, worst_frac, ok = 0, 1.0, True
+        n_cmp = 0
+        for i in check:
+            ref, produced = keep[i]
+            if not produced:
+                continue
+            got = R.d_out[i % R.oring, 0].cpu().numpy()
+            du = np.abs(ref.astype(np.int16) - got.astype(np.int16))
+            worst_du = max(worst_du, int(du.max()))
+            worst_frac = min(worst_frac, float((du == 0).mean()))
+            n_cmp += 1
+        rel = float(np.abs(fl_ref - float_gpu).max() / max(float(np.abs(fl_ref).max()), 1e-30))
+        ok = n_cmp >= 8 and worst_du <= 1 and worst_frac >= 0.999 and rel <= 1e-4 and bool(np.isfinite(float_gpu).all())
+        verified = bool(ok)
+        vinfo = {"frames_compared": n_cmp, "timed_frames_compared": len([i for i in check if base <= i < base + K]),
+                 "u8_max_diff": worst_du, "u8_identical_min": round(worst_frac, 6), "float_rel_err_probe": rel,
+                 "bars": "u8 <= 1 LSB, >= 99.9 % identical; float <= 1e-4 of max|ref|", "oracle_frames_replayed": n_verify}
+        cpu = {"value": round(n_verify / cdt, 3), "unit": "frames/s", "cores": nthreads, "kind": "port",
+               "sample": "%d frames of the same %dx%d L%d %s clip (the verification replay), CPU oracle = restatement of the "
+                         "reference, OpenMP over rows" % (n_verify, w, h, levels, args.mode),
+               "reference_probe": probe_reference()}
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as po
+        nthreads = max(1, min(16, os.cpu_count() or 1))
+        host = R.d_in[:, 0].cpu().numpy()
+        _, _, cdt = oracle_replay(po, np, host, pk, ring, 64, [], nthreads)
+        cpu = {"value": round(64 / cdt, 3), "unit": "frames/s", "cores": nthreads, "kind": "port",
+               "sample": "64 frames of the same clip, CPU oracle", "reference_probe": probe_reference()}
 
     # ---- per-kernel timing pass (HIP events on the launch stream) -> roofline ----
     roofline = None
     kernels = {}
+    Twin = lvm.load().lvm_optimal_buffer_size(int(pk["framerate"]))
     if args.profile_steps < 0:
         args.profile_steps = 2 * T if T > 1 else 60        # whole calls only: every launch then covers exactly T frames
     if rank == 0 and args.profile_steps > 0:
-        ctx.flush(stream)
-        ctx.set_pipeline(0)           # per-kernel event timing uses the plain schedule
-        pad = (-n) % ring             # start on a ring boundary so that every call of the pass covers exactly T frames
-        run_frames(n, pad); n += pad
-        ctx.profile(True)
-        run_frames(n, args.profile_steps); n += args.profile_steps
+        R.ctx.flush(stream)
+        R.ctx.set_pipeline(0)           # per-kernel event timing uses the plain schedule
+        R.run((-R.n) % T)               # whole calls
+        R.ctx.profile(True)
+        R.run(args.profile_steps)
         torch.cuda.synchronize()
-        prof = ctx.profile_collect()
-        ctx.profile(False)
+        prof = R.ctx.profile_collect()
+        R.ctx.profile(False)
         tot = sum(v[0] for v in prof.values()) or 1.0
-        Twin = lvm.load().lvm_optimal_buffer_size(int(pk["framerate"]))
+        T_launch = min(T, 32) if args.mode == "color" else T     # the colour mode cuts a call into chunks of <= 32 frames
         for name, (ms, cnt) in prof.items():
             avg_us = 1e3 * ms / max(cnt, 1)
-            # a launch of the temporally batched schedule covers T_frames frames of every stream
-            # frames one launch covers: T, except that the colour mode cuts a call into chunks of <= 32 frames (window ring)
-            T_launch = min(T, 32) if args.mode == "color" else T
-            ab = kernel_alg_bytes(args.mode, name, w, h, ch, levels, B * T_launch, Twin)
+            ab = kernel_alg_bytes(args.mode, name, w, h, ch, levels, B, T_launch, Twin)
             kernels[name] = {"avg_us": round(avg_us, 3), "launches": cnt, "share": round(ms / tot, 4),
                              "alg_bytes": ab, "gbs": (round(ab / (avg_us * 1e-6) / 1e9, 1) if ab else None)}
         dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
         k = kernels[dom]
         # HBM bytes per launch from the PMC counters (separate rocprofv3 passes, committed under profiles/)
         traffic = None
+        rocprof_avg = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_%s.json" % args.mode)))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "%s_pmc_traffic_%s.json" % (PROFILE_ROUND, args.mode))))
             if pm.get("key") == "%s|%dx%d|L%d|B%d|T%d" % (args.mode, w, h, levels, B, T):
                 traffic = pm["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+                rocprof_avg = pm["kernels"].get(dom, {}).get("rocprof_avg_us")
         except Exception:
             traffic = None
         if k["gbs"]:
             roofline = {"bound": "hbm", "kernel": dom, "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(k["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "avg_us": k["avg_us"], "alg_bytes_per_launch": k["alg_bytes"]}
-            # what actually limits that kernel, from the committed SQ-counter passes (profiles/*_sq_counters.txt)
-            limiter = {"lap_final": "VALU-bound (Lab arithmetic): 77 % VALU issue utilisation, 31 % LDS",
-                       "lap_down0": "VALU-bound (Lab arithmetic): 68 % VALU issue utilisation",
-                       "rz_blur_amp": "39 % VALU, 51 % LDS busy; 3.2 TB/s of compulsory traffic",
-                       "rz_final": "49 % VALU, 57 % LDS busy (9x9 taps + table lookups)",
-                       "rz_phase": "VALU-bound: 79 % VALU issue utilisation (acosf, sqrt/div, float64 filter products)"}.get(dom)
-            if limiter:
-                roofline["limiter"] = limiter
-            # the committed rocprofv3 --stats summary of this command (kernels back to back, no event gaps): its average for
-            # the same kernel.  The VALU-bound kernels run a few % slower there (sustained clocks); see profiles/README.md.
-            try:
-                sym = {"lap_final": "ILb1ELb0EEEvPKhllPhlliiPKfiiNS_7LabCoefEfiiiiPf", "lap_down0": "down0_rowsILb1ELb0", "lap_up": "k_lap_upILb0ELi1"}.get(dom)
-                if sym and args.mode == "laplace" and traffic is not None:
-                    for line in open(os.path.join(ROOT, "profiles", "r01_rocprof_laplace_kernel_stats.txt")):
-                        if sym in line:
-                            roofline["rocprof_avg_us"] = float(line.split()[2])
-                            break
-            except Exception:
-                pass
+            if rocprof_avg is not None:
+                roofline["rocprof_avg_us"] = rocprof_avg
     b_alg = lvm.load().lvm_algorithmic_bytes(pk["mode"], w, h, ch, levels, pk["framerate"])
-    frame_frac = b_alg * (fps / world) / (HBM_PEAK_GBS * 1e9)
+    frame_frac = b_alg * (fps / world / B) / (HBM_PEAK_GBS * 1e9)
+    b_bat = batched_frame_bytes(args.mode, w, h, ch, levels, T, Twin)
 
-    # ---- CPU baseline: the oracle (CPU restatement of the reference) on this box's cores ----
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import pyoracle as po
-        o = po.Oracle()
-        P = po.make_params(**pk)
-        nthreads = max(1, min(16, os.cpu_count() or 1))   # beyond ~16 threads fork/join over small levels dominates
-        po.lib().lvmo_set_threads(nthreads)
-        frames = [host[t % ring, 0] for t in range(4)]
-        for f in frames[:2]:
-            o.process(f, P)                       # first frame seeds, second warms caches
-        tc0 = time.perf_counter(); cnt = 0
-        while time.perf_counter() - tc0 < 12.0 and cnt < 400:
-            o.process(host[cnt % ring, 0], P); cnt += 1
-        cdt = time.perf_counter() - tc0
-        cpu = {"value": round(cnt / cdt, 3), "unit": "frames/s", "cores": nthreads, "kind": "port",
-               "sample": "%d frames of the same %dx%d L%d %s clip, CPU oracle (restatement of the reference; "
-                         "OpenCV unavailable), OpenMP over rows" % (cnt, w, h, levels, args.mode)}
+    # ---- gather per-rank facts (tests check value == world * B * K / max dt and every rank's verification) ----
+    rank_facts = [{"rank": rank, "verified": verified, "stream_ids": ids}]
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_facts[0])
+        rank_facts = gathered
+    R.close()
+    del R
+    torch.cuda.empty_cache()
+
+    # ---- sub-records: the other schedules / surfaces SURVEY.md 8d asks for, measured in the same run ----
+    sub = {}
+    if do_sub:
+        sub = sub_records(lvm, torch, np, args, cfg_idx, small, local_rank, rank, world, dist, red_dev)
+    elif world > 1:
+        sub = {"cfg4_riesz_4k": cfg4_record(lvm, torch, np, local_rank, rank, world, dist, red_dev)}
 
     if rank == 0:
         out = {
             "metric": "magnified frames/sec at 1080p, Laplace-motion 6 levels; % HBM roofline" if args.mode == "laplace"
                       else "magnified frames/sec (%s)" % args.mode,
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 5),
-            "host_enqueue_ms_per_step": round(1e3 * getattr(lvm.sharding.timed_steps, "host_seconds", 0.0) / args.steps, 5), "higher_is_better": True, "scaling": "weak",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(1e3 * dt / K, 5),
+            "host_enqueue_ms_per_step": round(1e3 * host_enqueue / K, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d, %d levels, %d stream(s)/GPU, device-resident u8 BGR in/out" %
                                    (args.mode, w, h, levels, B),
                        "baseline_config": cfg_idx, "streams_per_gpu": B, "ring_frames": ring,
-                       "frames_per_call": T, "pipeline_depth": args.pipeline, "hip_graph": bool(args.graph)},
+                       "frames_per_call": T, "priming_frames": primed, "pipeline_depth": args.pipeline, "hip_graph": bool(args.graph)},
+            "verified": verified, "verification": vinfo,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "frame_alg_bytes": b_alg, "frame_roofline_frac": round(frame_frac, 5),
+            "frame_batched_alg_bytes": round(b_bat), "frame_batched_roofline_frac": round(b_bat * (fps / world / B) / (HBM_PEAK_GBS * 1e9), 5),
+            "timed_seconds_max_over_ranks": dt,
+            "ranks": rank_facts,
             "kernels": kernels,
         }
+        out.update(sub)
         print(json.dumps(out))
-    ctx.close()
     if dist:
         dist.destroy_process_group()
+
+
+def probe_reference():
+    """SURVEY.md 8c / BASELINE.md step 1: is a real OpenCV (hence the real reference) available on this box?"""
+    found = {"cv2": False, "opencv_cmake_or_pc": False}
+    try:
+        import cv2  # noqa: F401
+        found["cv2"] = getattr(cv2, "__version__", True)
+    except Exception:
+        pass
+    for d in ("/usr/lib/x86_64-linux-gnu/cmake/opencv4", "/usr/local/lib/cmake/opencv4", "/usr/lib/cmake/opencv4",
+              "/usr/lib/x86_64-linux-gnu/pkgconfig/opencv4.pc", "/usr/local/lib/pkgconfig/opencv4.pc", "/usr/include/opencv4"):
+        if os.path.exists(d):
+            found["opencv_cmake_or_pc"] = d
+    found["oracle_ref_built"] = os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_magnify.so"))
+    return found
+
+
+def timed_run(lvm, torch, R, K, W, dist, red_dev):
+    R.prime(K, W)
+    R.run(W)
+    dt = lvm.sharding.timed_steps(lambda i: R.run(K), 1, dist, torch.cuda.synchronize, red_dev, finish=lambda: R.ctx.flush(R.stream))
+    return dt
+
+
+def cfg4_record(lvm, torch, np, local_rank, rank, world, dist, red_dev, K=64, W=16, T=16):
+    """BASELINE.json configs[4]: Riesz 3840x2160, 8 levels, one stream per GPU (seed 1234 + rank)."""
+    R = Runner(lvm, torch, np, 4, None, 1, 16, T, local_rank, lvm.sharding.stream_ids(rank, world, 1), 16)
+    dt = timed_run(lvm, torch, R, K, W, dist, red_dev)
+    b_alg = lvm.load().lvm_algorithmic_bytes(R.pk["mode"], R.w, R.h, R.ch, R.levels, R.pk["framerate"])
+    R.close()
+    fps = world * K / dt
+    return {"workload": "riesz 3840x2160, 8 levels, 1 stream per GPU, %d frames per call" % T, "value": round(fps, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": K, "ms_per_step": round(1e3 * dt / K, 4), "frame_alg_bytes": b_alg,
+            "frame_roofline_frac": round(b_alg * fps / world / (HBM_PEAK_GBS * 1e9), 5)}
+
+
+def sub_records(lvm, torch, np, args, cfg_idx, small, local_rank, rank, world, dist, red_dev):
+    out = {}
+    ids = lvm.sharding.stream_ids(rank, world, 1)
+    # (1) per-frame schedule: K calls of lvm_process_device, the live one-frame-latency surface
+    R = Runner(lvm, torch, np, cfg_idx, small, 1, 32, 1, local_rank, ids, 32)
+    Kp = 300
+    dt = timed_run(lvm, torch, R, Kp, 32, dist, red_dev)
+    out["per_frame"] = {"schedule": "T = 1: one lvm_process_device call per frame, device-resident", "value": round(world * Kp / dt, 2),
+                        "unit": "frames/s", "steps": Kp, "us_per_frame": round(1e6 * dt / Kp, 2),
+                        "host_enqueue_us_per_frame": round(1e6 * lvm.sharding.timed_steps.host_seconds / Kp, 2)}
+    # (2) host-to-host through lvm_process (the drop-in surface): pageable frames, then page-locked frames
+    w, h, ch, fb = R.w, R.h, R.ch, R.frame_bytes
+    host = R.d_in[:, 0].cpu().numpy()
+    R.ctx.reset()
+    e2e = {}
+    lib = lvm.load()
+    for kind in ("pageable", "pinned"):
+        if kind == "pinned":
+            pin, pout = C.c_void_p(), C.c_void_p()
+            if lib.lvm_host_alloc(fb * 8, C.byref(pin)) != 0 or lib.lvm_host_alloc(fb, C.byref(pout)) != 0:
+                continue
+            src = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(8, h, w, ch))
+            dst = np.ctypeslib.as_array(C.cast(pout, C.POINTER(C.c_uint8)), shape=(h, w, ch))
+            src[:] = host[:8]
+        else:
+            src = host[:8].copy()
+            dst = np.empty((h, w, ch), np.uint8)
+        produced = C.c_int(0)
+        fn = lib.lvm_process
+        ptrs = [src[i].ctypes.data for i in range(8)]
+        po_ = dst.ctypes.data
+        R.ctx.reset()
+        for i in range(20):
+            fn(R.ctx.h, R.p_ref, ptrs[i % 8], w, h, ch, w * ch, po_, w * ch, C.byref(produced))
+        Ke = 150
+        t0 = time.perf_counter()
+        for i in range(Ke):
+            rc = fn(R.ctx.h, R.p_ref, ptrs[i % 8], w, h, ch, w * ch, po_, w * ch, C.byref(produced))
+            if rc != 0:
+                R.ctx._check(rc)
+        de = time.perf_counter() - t0
+        e2e[kind] = {"value": round(Ke / de, 2), "unit": "frames/s", "us_per_frame": round(1e6 * de / Ke, 1),
+                     "pcie_bytes_per_frame": 2 * fb, "pcie_gbs": round(2 * fb * Ke / de / 1e9, 2)}
+        if kind == "pinned":
+            del src, dst
+            lib.lvm_host_free(pin); lib.lvm_host_free(pout)
+    out["e2e_host"] = dict(e2e, surface="lvm_process: host u8 in -> host u8 out, synchronous, one frame in flight "
+                                        "(replaces MagnificationProcessor::process, MagnificationProcessor.cpp:17-67)")
+    R.close()
+    del R
+    torch.cuda.empty_cache()
+    # (3) B streams per launch (time-shifted copies of the clip: independent temporal states)
+    bs = {}
+    for Bn in (4, 16):
+        Tn = 32 if Bn == 4 else 16
+        Rb = Runner(lvm, torch, np, cfg_idx, small, Bn, Tn, Tn, local_rank, ids, Tn, time_shift=True)
+        Kb = 4 * Tn
+        dtb = timed_run(lvm, torch, Rb, Kb, Tn, dist, red_dev)
+        bs["B%d" % Bn] = {"value": round(world * Bn * Kb / dtb, 2), "unit": "frames/s", "streams": Bn, "frames_per_call": Tn,
+                          "us_per_frame": round(1e6 * dtb / (Kb * Bn), 3)}
+        Rb.close()
+        del Rb
+        torch.cuda.empty_cache()
+    out["batched_streams"] = bs
+    # (4) BASELINE configs[4]
+    out["cfg4_riesz_4k"] = cfg4_record(lvm, torch, np, local_rank, rank, world, dist, red_dev)
+    return out
 
 
 if __name__ == "__main__":

@@ -36,7 +36,7 @@ void sync_streams(Ctx* c) {
     if (c->ev_done && c->ev_done_set) (void)hipEventSynchronize(c->ev_done);
     (void)hipGetLastError();
 }
-static void mark_enqueued(Ctx* c, hipStream_t s) {
+void mark_enqueued(Ctx* c, hipStream_t s) {
     if (s == c->own_stream || !c->ev_done) return;       // the own stream is synchronised directly
     if (hipEventRecord(c->ev_done, s) == hipSuccess) c->ev_done_set = true; else (void)hipGetLastError();
 }
@@ -116,7 +116,7 @@ static int run_mode_graphed(Ctx* c, const lvm_params* p, int levels, const Frame
 // would launch kernels on null buffers.  Drop it and disarm the tracker so that the next frame starts afresh,
 // which is also what the reference's recovery path does (ProcessingChain.cpp:50-62 resets every stage).
 static void tracker_disable(Ctx* c);
-static void fail_state(Ctx* c, hipStream_t s) {
+void fail_state(Ctx* c, hipStream_t s) {
     (void)hipStreamSynchronize(s);
     sync_streams(c);
     drop_state(c);
@@ -124,7 +124,7 @@ static void fail_state(Ctx* c, hipStream_t s) {
 }
 static void tracker_disable(Ctx* c) { c->t_mode = LVM_MODE_NONE; c->t_levels = -1; c->t_channels = -1; c->t_w = c->t_h = 0; }
 
-static int ensure_float(Ctx* c, size_t count) {
+int ensure_float(Ctx* c, size_t count) {
     if (count > c->float_cap) {
         sync_streams(c);            // kernels of earlier calls may still be writing the kept frame
         if (c->d_float) (void)hipFree(c->d_float);
@@ -269,6 +269,10 @@ int lvm_process_device_frames(lvm_ctx* c, const lvm_params* p, int n_frames, con
     if (!c || !p || !produced || n_frames < 1) return LVM_ERR_INVALID;
     LVM_HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    if (c->keep_float && w > 0 && h > 0 && (channels == 1 || channels == 3)) {   // the batched schedules keep the first frame of a batch
+        const int rc = lvm::ensure_float(c, (size_t)w * h * channels);
+        if (rc != LVM_OK) return rc;
+    }
     int f = 0;
     while (f < n_frames) {
         lvm::FrameIO io{d_in ? d_in + (size_t)f * in_frame_stride : nullptr, in_stride, in_stream_stride,
@@ -288,10 +292,11 @@ int lvm_process_device_frames(lvm_ctx* c, const lvm_params* p, int n_frames, con
             else if (p->mode == LVM_MODE_COLOR && lvm::color_can_batch(c, *p, left < lvm::kColorBatchMax ? left : lvm::kColorBatchMax)) {
                 const int nb = left < lvm::kColorBatchMax ? left : lvm::kColorBatchMax;      // the window ring keeps that many spare slots
                 rc = lvm::color_process_frames(c, *p, io, nb, s);
-                if (rc == LVM_OK) { for (int k = f; k < f + nb; ++k) produced[k] = 1; f += nb; continue; }
+                if (rc == LVM_OK) { lvm::mark_enqueued(c, s); for (int k = f; k < f + nb; ++k) produced[k] = 1; f += nb; continue; }
             }
             if (rc <= 0) {
-                if (rc != LVM_OK) return rc;
+                lvm::mark_enqueued(c, s);
+                if (rc != LVM_OK) { lvm::fail_state(c, s); return rc; }
                 for (int k = f; k < n_frames; ++k) produced[k] = 1;
                 return LVM_OK;
             }

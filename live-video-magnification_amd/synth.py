@@ -57,6 +57,25 @@ class Clip:
             return np.ascontiguousarray(img[:, :, 1])
         return np.ascontiguousarray(img)
 
+    def frame_torch(self, t, device):
+        """frame(t) computed on `device` with the same float64 operations in the same order (IEEE: bit-identical to
+        frame(t)); staging a 4K clip through numpy costs seconds per frame on the host."""
+        import torch
+        if getattr(self, "_tex_dev", None) is None or self._tex_dev.device != torch.device(device):
+            self._tex_dev = torch.from_numpy(self.tex).to(device)
+        d = self.amp_px * math.sin(2 * math.pi * self.f_motion * t / self.fps)
+        i0 = math.floor(d)
+        fr = d - i0
+        a = self._tex_dev[:, self.pad + i0: self.pad + i0 + self.w]
+        b = self._tex_dev[:, self.pad + i0 + 1: self.pad + i0 + 1 + self.w]
+        img = (1.0 - fr) * a + fr * b
+        if self.amp_color:
+            img = img + self.amp_color * math.sin(2 * math.pi * self.f_color * t / self.fps)
+        img = torch.clip(torch.round(img), 0, 255).to(torch.uint8)
+        if self.channels == 1:
+            return img[:, :, 1].contiguous()
+        return img.contiguous()
+
     def frames(self, n, start=0):
         return np.stack([self.frame(t) for t in range(start, start + n)])
 

@@ -1,0 +1,210 @@
+"""GPU tests of the schedules bench.py times and of the boundary's concurrency rules:
+  * 1920x1080 temporal batches of 32 frames over a 64-frame ring (the benchmarked schedule) for the three modes,
+    every output frame against the CPU oracle + the pre-quantisation float frame of a batch,
+  * a 64-frame 1080p Laplace clip through the host surface (state drift at full size),
+  * bench.py itself: self-verification, the byte model (no kernel above the HBM peak) and the N = 2 launch path
+    (two ranks sharing the GPU over gloo),
+  * two contexts driven from two host threads (the reference's live + export chains, export/Exporter.cpp:204,231),
+    keep_float across a size change after lvm_chain_process, create/destroy in a loop.
+Tolerances as in test_gpu_parity.py."""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import c_params, run_pair
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_synth_frames_on_device_are_bit_identical(lvm):
+    """bench.py stages its clips with Clip.frame_torch on the GPU: same float64 operations, same bytes."""
+    for idx, small in ((1, (640, 360, 4)), (3, (320, 180, 4)), (2, (323, 211, 4))):
+        ck, _ = lvm.synth.config(idx, small)
+        clip = lvm.synth.Clip(**ck)
+        for t in (0, 1, 7, 19, 33):
+            assert np.array_equal(clip.frame(t), clip.frame_torch(t, "cuda").cpu().numpy()), (idx, t)
+
+
+@pytest.mark.parametrize("idx,ncalls", [(1, 3), (2, 3), (3, 6)])
+def test_1080p_batches_of_32_over_a_ring(lvm, po, hip, idx, ncalls):
+    """The benchmarked schedule at its full size: calls of T = 32 consecutive frames through
+    lvm_process_device_frames over a 64-frame input ring, lvm_set_max_frames(32) given up front.  Every produced
+    frame is compared with the oracle (u8), and the float frame of the first frame of the last call too."""
+    import torch
+    T, ring = 32, 64
+    ck, pk = lvm.synth.config(idx)
+    w, h = ck["w"], ck["h"]
+    clip = lvm.synth.Clip(**ck)
+    d_in = torch.stack([clip.frame_torch(t, "cuda") for t in range(ring)])
+    host = d_in.cpu().numpy()
+    n = T * ncalls
+    d_out = torch.zeros((n, h, w, 3), dtype=torch.uint8, device="cuda")
+    fb = w * h * 3
+    ctx = lvm.Context(0, 1, hip)
+    ctx.set_max_frames(T)
+    cp = c_params(lvm, pk)
+    st = torch.cuda.current_stream().cuda_stream
+    produced = []
+    for call in range(ncalls):
+        if call == ncalls - 1:
+            ctx.keep_float(True)
+        t = (call * T) % ring
+        produced += ctx.process_device_frames(cp, T, d_in[t].data_ptr(), w, h, 3, w * 3, fb, fb, d_out[call * T].data_ptr(), w * 3, fb, fb, st)
+    torch.cuda.synchronize()
+    fl_gpu = ctx.read_float((h, w, 3))
+    ctx.close()
+    orc = po.Oracle()
+    P = po.make_params(**pk)
+    worst = [0, 1.0]
+    compared = 0
+    fl_ref = None
+    for i in range(n):
+        ref, pr = orc.process(host[i % ring], P)
+        assert pr == produced[i], (i, pr, produced[i])
+        if i == (ncalls - 1) * T:
+            fl_ref = orc.last_float().copy()
+        if not pr:
+            continue
+        if i % 3 and i < n - 4 and i not in (T, T + 1):      # D2H of every frame would dominate the test: two thirds are skipped
+            continue
+        got = d_out[i].cpu().numpy()
+        du = np.abs(ref.astype(np.int16) - got.astype(np.int16))
+        worst = [max(worst[0], int(du.max())), min(worst[1], float((du == 0).mean()))]
+        assert du.max() <= 1 and (du == 0).mean() >= 0.999, (i, int(du.max()), float((du == 0).mean()))
+        compared += 1
+    orc.close()
+    rel = float(np.abs(fl_ref - fl_gpu).max() / np.abs(fl_ref).max())
+    print("mode cfg", idx, "frames compared", compared, "worst u8 / identical", worst, "float rel", rel)
+    assert compared >= 20
+    assert np.isfinite(fl_gpu).all() and rel <= 1e-4, rel
+
+
+def test_laplace_1080p_64_frames_state_drift(lvm, po, hip):
+    """BASELINE.json configs[1] at full size for 64 frames (float + u8 bars on every frame)."""
+    ck, pk = lvm.synth.config(1)
+    worst = run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 64, 1e-4)
+    print("laplace 1080p 64 frames worst rel/u8/frac", worst)
+
+
+def _bench(args, timeout=900):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_verifies_itself_and_prices_kernels_below_peak():
+    """bench.py at a reduced size: the timed region's own output matches the oracle, the JSON carries the contract's
+    fields, and no per-kernel GB/s exceeds the HBM peak (a figure above peak means the byte model is wrong)."""
+    out = _bench(["--width", "640", "--height", "360", "--levels", "4", "--steps", "64", "--warmup", "8", "--no-subrecords"])
+    assert out["verified"] is True, out["verification"]
+    assert out["verification"]["timed_frames_compared"] >= 8
+    assert out["n_gpus"] == 1 and out["steps"] == 64 and out["warmup"] == 8
+    assert out["roofline"] and out["cpu_baseline"] and out["cpu_baseline"]["kind"] == "port"
+    for name, k in out["kernels"].items():
+        assert k["alg_bytes"] is not None, name
+        assert k["gbs"] <= 8000.0, (name, k)
+    assert abs(out["value"] - out["steps"] / out["timed_seconds_max_over_ranks"]) <= 1e-6 * out["value"] + 0.01
+
+
+@pytest.mark.parametrize("mode", ["riesz", "color"])
+def test_bench_other_modes_verify(mode):
+    out = _bench(["--mode", mode, "--width", "640", "--height", "360", "--levels", "4", "--steps", "32", "--warmup", "8", "--no-subrecords"])
+    assert out["verified"] is True, out["verification"]
+    for name, k in out["kernels"].items():
+        assert k["gbs"] is None or k["gbs"] <= 8000.0, (name, k)
+
+
+def test_bench_two_ranks_from_a_plain_shell():
+    """`python bench.py --gpus 2` with no WORLD_SIZE re-executes under torch.distributed.run: two ranks (sharing the
+    one GPU of this box, gloo for the barrier / MAX-reduce), each with its own stream (seed 1234 + rank), each
+    verified against the oracle for ITS seed; value = 2 ranks x streams x steps / max-over-ranks seconds."""
+    out = _bench(["--gpus", "2", "--share-gpu", "--dist-backend", "gloo", "--steps", "8", "--warmup", "4", "--width", "320", "--height", "180",
+                  "--levels", "4", "--verify-all-ranks", "--no-subrecords", "--frames-per-call", "4", "--ring", "8"])
+    assert out["n_gpus"] == 2
+    ranks = sorted(out["ranks"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == [0, 1]
+    assert [r["stream_ids"] for r in ranks] == [[0], [1]]
+    assert all(r["verified"] is True for r in ranks), ranks
+    expect = 2 * 1 * 8 / out["timed_seconds_max_over_ranks"]
+    assert abs(out["value"] - expect) <= 1e-6 * expect + 0.01
+    assert out["cfg4_riesz_4k"]["n_gpus"] == 2
+
+
+def test_two_contexts_on_two_threads(lvm, po, hip):
+    """Live chain + export chain (export/Exporter.cpp:204,231): two contexts, each driven by its own host thread,
+    different modes and sizes, interleaved resets; both must match their oracle frame by frame."""
+    errors = []
+
+    def worker(idx, small, nframes, reset_at):
+        try:
+            ck, pk = lvm.synth.config(idx, small)
+            clip = lvm.synth.Clip(**ck)
+            P = po.make_params(**pk)
+            cp = c_params(lvm, pk)
+            ctx = lvm.Context(0, 1, hip)
+            orc = po.Oracle()
+            for t in range(nframes):
+                if t == reset_at:
+                    ctx.reset(); orc.reset()
+                f = clip.frame(t)
+                ref, pr = orc.process(f, P)
+                out, pg = ctx.process(f, cp)
+                assert pr == pg, (idx, t)
+                if pr:
+                    du = np.abs(ref.astype(int) - out.astype(int))
+                    assert du.max() <= 1 and (du == 0).mean() >= 0.999, (idx, t, du.max())
+            ctx.close(); orc.close()
+        except BaseException as e:  # noqa: BLE001
+            errors.append((idx, repr(e)))
+
+    th = [threading.Thread(target=worker, args=(0, (640, 360, 4), 40, 17)),
+          threading.Thread(target=worker, args=(2, (320, 180, 4), 30, 11))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+
+
+def test_keep_float_across_size_change_after_chain(lvm, po, hip):
+    """Round-1 defect: growing the kept float frame freed the chain's staging buffers.  chain_process, then keep_float
+    with a LARGER frame through chain_process and lvm_process, then back; plus create/destroy in a loop."""
+    ctx = lvm.Context(0, 1, hip)
+    pre = lvm.to_c_preprocess(lvm.PreprocessParams(downscale=2), False)
+    for (w, h) in ((320, 180), (640, 360), (320, 180), (800, 450)):
+        ck, pk = lvm.synth.config(0, (w, h, 3))
+        clip = lvm.synth.Clip(**ck)
+        cp = c_params(lvm, pk)
+        orc = po.Oracle()
+        P = po.make_params(**pk)
+        ctx.keep_float(True)
+        for t in range(4):
+            f = clip.frame(t)
+            small = po.preprocess(f, po.make_pre_params(downscale=2))
+            out, produced = ctx.chain_process(f, pre, cp)
+            assert produced and out.shape == (h // 2, w // 2, 3)
+            ref, _ = orc.process(small, P)
+            du = np.abs(ref.astype(int) - out.astype(int))
+            assert du.max() <= 1, (w, h, t, du.max())
+            fl = ctx.read_float((h // 2, w // 2, 3))
+            assert np.isfinite(fl).all()
+        ctx.keep_float(False)
+        out2, produced = ctx.process(clip.frame(0), cp)      # host surface on the same context (structural change)
+        assert produced
+        orc.close()
+    ctx.close()
+    for _ in range(20):                                      # every context that used the chain API must free it
+        c2 = lvm.Context(0, 1, hip)
+        ck, pk = lvm.synth.config(0, (320, 180, 3))
+        c2.chain_process(lvm.synth.Clip(**ck).frame(0), pre, c_params(lvm, pk))
+        c2.close()

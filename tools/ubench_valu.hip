@@ -75,7 +75,6 @@ KERNEL64(k_pk_mov, "v_pk_mov_b32 %0, %0, %1")
 KERNEL64(k_fma64, "v_fma_f64 %0, %0, %1, %2")
 KERNEL64(k_mul64, "v_mul_f64 %0, %0, %1")
 KERNEL64(k_add64, "v_add_f64 %0, %0, %1")
-KERNEL64(k_cvt_f64_f32, "v_cvt_f32_f64 %0, %0")
 
 // LDS table lookups with a per-lane random index: ds_read_b32 from a 256-entry table (the u8 gamma LUT) and
 // ds_read_b128 from a 1024 x float4 table (the inverse-gamma spline), plus a bank-private layout of the former
@@ -118,7 +117,7 @@ int main() {
         {"v_mov_b32 dpp wave_shr", k_dpp_shr}, {"v_mov_b32 dpp row_shr", k_dpp_rowshr}, {"v_add_f32 dpp row_shr", k_add_dpp},
         {"v_lshl_add_u32", k_lshl_add}, {"v_and_or_b32", k_and_or}, {"v_perm_b32", k_perm}, {"v_rndne_f32", k_rndne}, {"v_ldexp_f32", k_ldexp},
         {"v_max_f32", k_max}, {"v_mad_u32_u24", k_mad_u32_u24}, {"v_nop", k_swmmac_nop},
-        {"v_fma_f64", k_fma64}, {"v_mul_f64", k_mul64}, {"v_add_f64", k_add64}, {"v_cvt_f32_f64", k_cvt_f64_f32},
+        {"v_fma_f64", k_fma64}, {"v_mul_f64", k_mul64}, {"v_add_f64", k_add64},
     };
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     double base = 0;
