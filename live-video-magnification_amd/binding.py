@@ -22,7 +22,7 @@ import struct
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblvm_hip.so")
+LIB_PATH = os.environ.get("LVM_HIP_LIB") or os.path.join(_HERE, "liblvm_hip.so")   # (override: A/B builds of the same sources)
 
 
 class MagnificationMode(enum.IntEnum):

@@ -414,7 +414,11 @@ __global__ __launch_bounds__(FIN_THREADS) void k_lap_final_v4(const uint8_t* __r
         const unsigned xoff = (unsigned)gx * 3u;
         const float* pl = cur1 + (size_t)b * 3 * ((size_t)w1 * h1);
         const int i0 = gx >> 1;
-        const unsigned cm1 = 4u * (i0 > 0 ? i0 - 1 : 0), c00 = 4u * i0, cp1 = 4u * (i0 + 1 < w1 ? i0 + 1 : w1 - 1), cp2 = 4u * (i0 + 2 < w1 ? i0 + 2 : w1 - 1);   // byte offsets
+        // byte offsets of the four taps.  Default flavour: the border rule is applied by the LOADS (column -1 reads column 1,
+        // column w1 reads column w1 - 1) and every lane runs the interior formulas -- s1 + 6 s0 + s1 = 6 s0 + 2 s1,
+        // s0 + 6 s1 + s1 = s0 + 7 s1, (s1 + s1) 4 = 8 s1: equal up to the rounding of one addition at the two border
+        // columns, 16 selects / border variants less per lane and source row.
+        const unsigned cm1 = 4u * (i0 > 0 ? i0 - 1 : (EXACT ? 0 : 1)), c00 = 4u * i0, cp1 = 4u * (i0 + 1 < w1 ? i0 + 1 : w1 - 1), cp2 = 4u * (i0 + 2 < w1 ? i0 + 2 : w1 - 1);
         const size_t pstride = (size_t)w1 * h1;
         // horizontal pass of source row sy (vertical border map: row -1 -> 1, row h1 -> h1 - 1); the row
         // base is uniform, the four column offsets are per-lane byte offsets
@@ -425,8 +429,10 @@ __global__ __launch_bounds__(FIN_THREADS) void k_lap_final_v4(const uint8_t* __r
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const char* rc = row + c * pstride * sizeof(float);
-                o.c[c] = pyrup_h4(*reinterpret_cast<const float*>(rc + cm1), *reinterpret_cast<const float*>(rc + c00),
-                                  *reinterpret_cast<const float*>(rc + cp1), *reinterpret_cast<const float*>(rc + cp2), i0, w1);
+                const float sm1 = *reinterpret_cast<const float*>(rc + cm1), s0 = *reinterpret_cast<const float*>(rc + c00),
+                            s1 = *reinterpret_cast<const float*>(rc + cp1), s2 = *reinterpret_cast<const float*>(rc + cp2);
+                if (EXACT) o.c[c] = pyrup_h4(sm1, s0, s1, s2, i0, w1);
+                else { o.c[c].x = sm1 + s0 * 6.f + s1; o.c[c].y = (s0 + s1) * 4.f; o.c[c].z = s0 + s1 * 6.f + s2; o.c[c].w = (s1 + s2) * 4.f; }
             }
             return o;
         };

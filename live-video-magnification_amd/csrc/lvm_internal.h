@@ -114,7 +114,9 @@ __device__ __forceinline__ void lin_bgr_to_lab(float B, float G, float R, const 
         FX = X > 0.008856f ? cx : __builtin_fmaf(7.787f, X, _a);
         FY = Y > 0.008856f ? cy : __builtin_fmaf(7.787f, Y, _a);
         FZ = Z > 0.008856f ? cz : __builtin_fmaf(7.787f, Z, _a);
-        L = Y > 0.008856f ? __builtin_fmaf(116.f, FY, -16.f) : (903.3f * Y);
+        // L = 116 f(Y) - 16 on both sides of the threshold: below it 116 (7.787 Y + 16/116) - 16 = 903.292 Y against the
+        // reference's 903.3 Y, < 7e-5 of the 0..100 range (one select and one multiply less per pixel)
+        L = __builtin_fmaf(116.f, FY, -16.f);
     }
     a = 500.f * (FX - FY);
     b = 200.f * (FY - FZ);
@@ -184,6 +186,13 @@ __device__ __forceinline__ void lab_to_bgr(float li, float ai, float bi, const f
         o1 = spline1024<false>(clip1024_open(c1), igt);
         o2 = spline1024<false>(clip1024_open(c2), igt);
     }
+}
+// 4-pixel form of the forward conversion (the strip kernels convert pixel groups)
+template <bool EXACT>
+__device__ __forceinline__ void lab_fwd4(const float (&Bl)[4], const float (&Gl)[4], const float (&Rl)[4], const float* fw,
+                                         float (&L)[4], float (&a)[4], float (&b)[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) lin_bgr_to_lab<EXACT>(Bl[k], Gl[k], Rl[k], fw, L[k], a[k], b[k]);
 }
 // cooperative loads of the two Lab tables into LDS (256 threads)
 __device__ __forceinline__ void load_gamma_u8(float* s_gam, const float* g) { s_gam[threadIdx.x] = g[threadIdx.x]; }

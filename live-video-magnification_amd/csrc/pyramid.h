@@ -278,6 +278,9 @@ __global__ __launch_bounds__(256) void k_pyr_up_rows(const float* __restrict__ s
 // the strip in a 5-row register window.  Only the gamma table lives in LDS.
 __device__ __forceinline__ float dpp_shr1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }
 __device__ __forceinline__ float dpp_shl1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }
+// the same with a fallback for the lane that has no source lane (lane 0 / lane 63 keep `old`)
+__device__ __forceinline__ float dpp_shr1_old(float old, float v) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x138, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_shl1_old(float old, float v) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x130, 0xf, 0xf, false)); }
 constexpr int D0R_THREADS = 256, D0R_OUT = 124;
 // Strip height for k_down0_rows: a strip of r output rows converts 2r + 3 source rows, and the launch takes as
 // long as the busiest SIMD (1024 of them on MI355X) has strips -- minimise ceil(strips / 1024) * (2r + 3).
@@ -319,10 +322,14 @@ __global__ __launch_bounds__(D0R_THREADS) void k_down0_rows(const uint8_t* __res
         int Bv[4], Gv[4], Rv[4];
         unpack_px4(pv, Bv, Gv, Rv);
         float P[3][4];
+        if (LAB) {
+            float Bl[4], Gl[4], Rl[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (LAB) lin_bgr_to_lab<EXACT>(s_gam[Bv[q]], s_gam[Gv[q]], s_gam[Rv[q]], lab.fwd, P[0][q], P[1][q], P[2][q]);
-            else { P[0][q] = (float)Bv[q] * 1.0f; P[1][q] = (float)Gv[q] * 1.0f; P[2][q] = (float)Rv[q] * 1.0f; }   // colour mode: unscaled planes
+            for (int q = 0; q < 4; ++q) { Bl[q] = s_gam[Bv[q]]; Gl[q] = s_gam[Gv[q]]; Rl[q] = s_gam[Rv[q]]; }
+            lab_fwd4<EXACT>(Bl, Gl, Rl, lab.fwd, P[0], P[1], P[2]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { P[0][q] = (float)Bv[q] * 1.0f; P[1][q] = (float)Gv[q] * 1.0f; P[2][q] = (float)Rv[q] * 1.0f; }   // colour mode: unscaled planes
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {

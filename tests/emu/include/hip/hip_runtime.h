@@ -74,7 +74,9 @@ static inline float __builtin_amdgcn_sinf(float rev) { return sinf(rev * 6.28318
 static inline float __builtin_amdgcn_cosf(float rev) { return cosf(rev * 6.283185307179586f); }
 // DPP wave_shr:1 (0x138) / wave_shl:1 (0x130): every lane of the wave must execute it (uniform control flow)
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) { return hipemu::dpp_wave_shift(old, src, ctrl); }
-static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }   // only ever applied to wave-uniform values
+static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
+// wave-uniform shortcuts compute what the general path selects, so a per-lane answer is equivalent here
+static inline unsigned long long __builtin_amdgcn_ballot_w64(bool c) { return c ? 1ull : 0ull; }   // only ever applied to wave-uniform values
 static inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
 static inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 static inline unsigned __float_as_uint(float f) { unsigned i; std::memcpy(&i, &f, 4); return i; }

@@ -398,3 +398,24 @@ def test_emu_size_and_channel_changes(lvm, po, emu, idx):
     if idx == 3:
         ck["fps"] = 15.0; pk["framerate"] = 15.0
     run_pair(lvm, po, emu, _ShapeShifter(lvm, ck), pk, 13, 0.0, exact=True)
+
+
+@pytest.mark.parametrize("w,h,levels", [(520, 40, 3), (260, 36, 2), (256, 34, 2), (772, 22, 2)])
+def test_fast_final_kernel_strips_and_shortcut_paths(lvm, po, emu, w, h, levels):
+    """Default-flavour last Laplace kernel (k_lap_final_fast): several wave strips per row, a last strip with a
+    single lane / a half wave, DPP halo exchange with the halo loads of the first and last lane; a clip with very
+    dark and saturated patches so that the general (select / spline) paths and the wave-uniform shortcuts both run,
+    strong amplification so that outputs clamp at 0 and 255."""
+    ck, pk = lvm.synth.config(0, (w, h, levels))
+    pk["amplification"] = 60.0
+    base = lvm.synth.Clip(**ck)
+
+    class Patched:
+        def frame(self, t):
+            f = base.frame(t).copy()
+            f[2:h // 2, 8:w // 4] = (f[2:h // 2, 8:w // 4] // 12)           # values 0..20: below the CIE threshold
+            f[h // 2:h - 1, w // 2:w - 5] = 255 - (255 - f[h // 2:h - 1, w // 2:w - 5]) // 16
+            f[:, w - 4:] = f[:, w - 4:] // 3
+            return f
+    worst = run_pair(lvm, po, emu, Patched(), pk, 7, 1e-4, exact=False, exact_lab=False, u8_frac=0.998)
+    print("fast final kernel", (w, h, levels), worst)

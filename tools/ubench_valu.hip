@@ -68,6 +68,15 @@ KERNEL32(k_ldexp, "v_ldexp_f32 %0, %0, %1")
 KERNEL32(k_max, "v_max_f32 %0, %0, %1")
 KERNEL32(k_mad_u32_u24, "v_mad_u32_u24 %0, %0, %1, %2")
 KERNEL32(k_swmmac_nop, "v_nop")
+KERNEL32(k_cndmask_e64, "v_cndmask_b32_e64 %0, %0, %1, s[10:11]")
+KERNEL32(k_cndmask_fma, "v_cndmask_b32 %0, %0, %1, vcc\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2")
+KERNEL32(k_fma4, "v_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2\n\tv_fma_f32 %0, %0, %1, %2")
+KERNEL32(k_cmp_cnd, "v_cmp_gt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc")
+KERNEL32(k_mov, "v_mov_b32 %0, %1")
+KERNEL32(k_xor, "v_xor_b32 %0, %0, %1")
+KERNEL32(k_min3, "v_min3_f32 %0, %0, %1, %2")
+KERNEL32(k_snop, "s_nop 0")
+KERNEL32(k_sdwa, "v_lshlrev_b32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1")
 KERNEL64(k_pk_fma, "v_pk_fma_f32 %0, %0, %1, %2")
 KERNEL64(k_pk_mul, "v_pk_mul_f32 %0, %0, %1")
 KERNEL64(k_pk_add, "v_pk_add_f32 %0, %0, %1")
@@ -117,6 +126,8 @@ int main() {
         {"v_mov_b32 dpp wave_shr", k_dpp_shr}, {"v_mov_b32 dpp row_shr", k_dpp_rowshr}, {"v_add_f32 dpp row_shr", k_add_dpp},
         {"v_lshl_add_u32", k_lshl_add}, {"v_and_or_b32", k_and_or}, {"v_perm_b32", k_perm}, {"v_rndne_f32", k_rndne}, {"v_ldexp_f32", k_ldexp},
         {"v_max_f32", k_max}, {"v_mad_u32_u24", k_mad_u32_u24}, {"v_nop", k_swmmac_nop},
+        {"v_cndmask_b32_e64 sgpr", k_cndmask_e64}, {"cndmask + 3 fma (per 4)", k_cndmask_fma}, {"4 fma (per 4)", k_fma4}, {"cmp + cndmask (per 2)", k_cmp_cnd},
+        {"v_mov_b32", k_mov}, {"v_xor_b32", k_xor}, {"v_min3_f32", k_min3}, {"s_nop 0", k_snop}, {"v_lshlrev_b32_sdwa", k_sdwa},
         {"v_fma_f64", k_fma64}, {"v_mul_f64", k_mul64}, {"v_add_f64", k_add64},
     };
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
