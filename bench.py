@@ -91,11 +91,10 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, S, T, Twin=0):
         if base == "lap_up" and lvl is not None:
             per_frame = 4 * P * (n[lvl] + n[lvl + 1] + (n[lvl + 1] if lvl + 1 <= levels - 1 else 0) + n[lvl])
             return T * per_frame + 16 * P * n[lvl]                            # hi/lo read + written once per launch
-        if base == "lap_coarse":     # levels lvl .. L-1 in one launch: G_lvl.. read, cur_lvl written, states once
-            tot = 0
-            for l in range(lvl, levels):
-                tot += T * 4 * P * n[l] + 16 * P * n[l]
-            return tot + T * 4 * P * (n[levels] + n[lvl])
+        if base == "lap_iir":        # levels 2 .. L-1 in one launch: G_l, G_{l+1} read, m_l written per frame; states once
+            return sum(T * 4 * P * (2 * n[l] + n[l + 1]) + 16 * P * n[l] for l in range(2, levels))
+        if base == "lap_collapse":   # m_2 .. m_{L-1} read, cur_2 written
+            return T * 4 * P * (sum(n[l] for l in range(2, levels)) + n[2])
         if base == "lap_seed" and lvl is not None:
             return 4 * P * (n[lvl] * 3 + n[lvl + 1])
         return None

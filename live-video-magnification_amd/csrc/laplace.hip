@@ -303,6 +303,231 @@ __global__ __launch_bounds__(256) void k_lap_up_rows(UpArgs a, int gw, int ngrou
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Temporal batches, levels 2 .. L-1: the level-by-level chain of fused launches (each a few hundred waves walking
+// over the frames of the batch, i.e. the length of the dependent instruction stream times the number of levels) is
+// cut in two:
+//   k_lap_iir_levels   ONE launch for all those levels.  m_l(t) = gain_l * (hi_l(t) - lo_l(t)) depends on G_l and
+//                      G_{l+1} only, not on the other levels' results, so every level runs side by side: a lane owns
+//                      a 2 x 2 block of one (level, plane) for all frames, states in registers, raw loads of the next
+//                      D frames in flight (as k_lap_up_rows).  m_l is stored where cur_l will be.
+//   k_lap_collapse     cur_l = pyrUp(cur_{l+1}) + m_l for l = L-2 .. 2 is stateless: ONE launch, a workgroup per
+//                      (frame, plane, 64 x 32 tile of level 2), the few coarse pixels a tile depends on recomputed in
+//                      LDS (34 x 18, 19 x 11, 12 x 8 .. per level).
+// Same arithmetic and operation order as k_lap_up / k_lap_tail, hence the same frames.
+// ------------------------------------------------------------------------------------------
+constexpr int kIirLevels = 10;
+struct IirLevel {
+    const float* Gl; const float* Gn; float* hi; float* lo; float* out;
+    int w, h, wn, hn; float gain; long fsl, fsn; int block0, gw, ngroups, top;
+};
+struct IirArgs { IirLevel lv[kIirLevels]; int nlv, nt; float aHi, bHi, aLo, bLo; };
+
+template <int D>
+__global__ __launch_bounds__(256) void k_lap_iir_levels(IirArgs aa) {
+    int k = 0;
+    while (k + 1 < aa.nlv && (int)blockIdx.x >= aa.lv[k + 1].block0) ++k;
+    const IirLevel& a = aa.lv[k];
+    const int gi = ((int)blockIdx.x - a.block0) * 256 + threadIdx.x;
+    if (gi >= a.ngroups) return;
+    const int plane = blockIdx.y;
+    const int gy = gi / a.gw, gxg = gi - gy * a.gw;
+    const int gx = gxg * 2, y0 = gy * 2;
+    const bool row1 = y0 + 1 < a.h;
+    const size_t pn = (size_t)plane * a.wn * a.hn, pl = (size_t)plane * a.w * a.h;
+    const int i0 = gx >> 1, j0 = y0 >> 1;
+    unsigned soff[3][3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        int sy = j0 - 1 + q; sy = sy < 0 ? 1 : (sy >= a.hn ? a.hn - 1 : sy);       // vertical border map
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            int sx = i0 - 1 + c; sx = sx < 0 ? 0 : (sx >= a.wn ? a.wn - 1 : sx);
+            soff[q][c] = 4u * (unsigned)(sy * a.wn + sx);
+        }
+    }
+    const unsigned loff0 = 4u * (unsigned)(y0 * a.w + gx), loff1 = row1 ? loff0 + 4u * (unsigned)a.w : loff0;
+    float hi_r[2][2], lo_r[2][2];
+    {
+        const char* H = reinterpret_cast<const char*>(a.hi + pl); const char* Lo = reinterpret_cast<const char*>(a.lo + pl);
+        const float2 h0 = *reinterpret_cast<const float2*>(H + loff0), h1 = *reinterpret_cast<const float2*>(H + loff1);
+        const float2 l0 = *reinterpret_cast<const float2*>(Lo + loff0), l1 = *reinterpret_cast<const float2*>(Lo + loff1);
+        hi_r[0][0] = h0.x; hi_r[0][1] = h0.y; hi_r[1][0] = h1.x; hi_r[1][1] = h1.y;
+        lo_r[0][0] = l0.x; lo_r[0][1] = l0.y; lo_r[1][0] = l1.x; lo_r[1][1] = l1.y;
+    }
+    struct Raw { float g[3][3]; float2 gl[2]; };
+    const char* Gn = reinterpret_cast<const char*>(a.Gn + pn);
+    const char* Gl = reinterpret_cast<const char*>(a.Gl + pl);
+    int tl = 0;
+    auto load = [&](Raw& r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) r.g[q][c] = *reinterpret_cast<const float*>(Gn + soff[q][c]);
+        r.gl[0] = *reinterpret_cast<const float2*>(Gl + loff0);
+        r.gl[1] = *reinterpret_cast<const float2*>(Gl + loff1);
+        if (tl + 1 < aa.nt) { ++tl; Gn += a.fsn * sizeof(float); Gl += a.fsl * sizeof(float); }
+    };
+    const bool fi = i0 == 0, la = i0 == a.wn - 1;
+    char* out = reinterpret_cast<char*>(a.out + pl);
+    auto filter = [&](const Raw& r) __attribute__((always_inline)) {
+        float hg[3][2];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float sm1 = r.g[q][0], s0 = r.g[q][1], s1 = r.g[q][2];
+            const float p6 = s0 * 6.f;
+            hg[q][0] = sel(fi, p6 + s1 * 2.f, sel(la, sm1 + s0 * 7.f, sm1 + p6 + s1));
+            hg[q][1] = sel(la, s0 * 8.f, (s0 + s1) * 4.f);
+        }
+        float o[2][2];
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float upg = y == 0 ? (hg[0][c] + hg[1][c] * 6.f + hg[2][c]) * (1.f / 64.f) : ((hg[1][c] + hg[2][c]) * 4.f) * (1.f / 64.f);
+                const float glv = y == 0 ? (c == 0 ? r.gl[0].x : r.gl[0].y) : (c == 0 ? r.gl[1].x : r.gl[1].y);
+                const float band = glv - upg;                                    // SpatialFilter.cpp:33
+                const float t1 = hi_r[y][c] * aa.aHi + band * aa.bHi;            // TemporalFilter.cpp:16
+                const float t2 = lo_r[y][c] * aa.aLo + band * aa.bLo;            // :17
+                hi_r[y][c] = t1; lo_r[y][c] = t2;
+                const float m = (t1 - t2) * a.gain;                              // :21, MagnifyCore.hpp:129-132
+                o[y][c] = a.top ? 0.f + m : m;                                   // top live level: pyrUp of the zeroed residual + m
+            }
+        *reinterpret_cast<float2*>(out + loff0) = make_float2(o[0][0], o[0][1]);
+        if (row1) *reinterpret_cast<float2*>(out + loff1) = make_float2(o[1][0], o[1][1]);
+        out += a.fsl * sizeof(float);
+    };
+    Raw ring[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) load(ring[d]);
+    for (int t0 = 0; t0 < aa.nt; t0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const Raw now = ring[d];
+            load(ring[d]);
+            filter(now);
+        }
+    }
+    {
+        char* H = reinterpret_cast<char*>(a.hi + pl); char* Lo = reinterpret_cast<char*>(a.lo + pl);
+        *reinterpret_cast<float2*>(H + loff0) = make_float2(hi_r[0][0], hi_r[0][1]);
+        *reinterpret_cast<float2*>(Lo + loff0) = make_float2(lo_r[0][0], lo_r[0][1]);
+        if (row1) {
+            *reinterpret_cast<float2*>(H + loff1) = make_float2(hi_r[1][0], hi_r[1][1]);
+            *reinterpret_cast<float2*>(Lo + loff1) = make_float2(lo_r[1][0], lo_r[1][1]);
+        }
+    }
+}
+
+constexpr int CT_W = 64, CT_H = 32, kCollapsePool = 3072;
+struct CollapseArgs { float* cur[kIirLevels]; int w[kIirLevels], h[kIirLevels]; int nlv; };   // index 0 = level 2, nlv - 1 = top live level
+template <int NLV>                                      // number of levels (compile time: the per-level region scalars stay in SGPRs)
+__global__ __launch_bounds__(256) void k_lap_collapse(CollapseArgs a) {
+    __shared__ float pool[kCollapsePool];
+    const int tid = threadIdx.x;
+    const size_t z = blockIdx.z;                         // frame * planes + plane
+    // regions of the levels a tile of level 2 depends on: columns / rows [x0/2 - 1, x1/2 + 1] of the level above, clipped
+    // (uniform values: scalar registers)
+    int rx0[NLV], ry0[NLV], rw[NLV], rh[NLV], roff[NLV];
+    int toff;
+    {
+        int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H;
+        int x1 = x0 + CT_W - 1 < a.w[0] - 1 ? x0 + CT_W - 1 : a.w[0] - 1, y1 = y0 + CT_H - 1 < a.h[0] - 1 ? y0 + CT_H - 1 : a.h[0] - 1;
+        rx0[0] = x0; ry0[0] = y0; rw[0] = x1 - x0 + 1; rh[0] = y1 - y0 + 1; roff[0] = 0;
+        int off = 0;
+#pragma unroll
+        for (int k = 1; k < NLV; ++k) {
+            {
+                int nx0 = x0 / 2 - 1, nx1 = x1 / 2 + 1, ny0 = y0 / 2 - 1, ny1 = y1 / 2 + 1;
+                nx0 = nx0 < 0 ? 0 : nx0; ny0 = ny0 < 0 ? 0 : ny0;
+                nx1 = nx1 > a.w[k] - 1 ? a.w[k] - 1 : nx1; ny1 = ny1 > a.h[k] - 1 ? a.h[k] - 1 : ny1;
+                rx0[k] = nx0; ry0[k] = ny0; rw[k] = nx1 - nx0 + 1; rh[k] = ny1 - ny0 + 1; roff[k] = off;
+                off += rw[k] * rh[k];
+                x0 = nx0; x1 = nx1; y0 = ny0; y1 = ny1;
+            }
+        }
+        toff = off;                                      // temporaries (horizontal passes) start here
+    }
+    // ONE round of global loads: the m regions of every coarser level into LDS, the tile's own m_2 into registers.
+    // Thread (tx, ty) = (tid & 63, tid >> 6) owns column tx of every region and the rows ty, ty + 4, ..: no index
+    // division anywhere, the column's border case and (rows advancing by 4) the row parity are fixed per thread.
+    const int tx = tid & 63, ty = tid >> 6;
+    constexpr int NP = CT_H / 4;
+    float m2[NP];
+    float* g2 = a.cur[0] + z * ((size_t)a.w[0] * a.h[0]);
+    const bool in0 = tx < rw[0];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {                       // level 2: this thread's rows are the NP consecutive ones ty * NP ..
+        const int y = ty * NP + q;
+        m2[q] = (in0 && y < rh[0]) ? g2[(size_t)(ry0[0] + y) * a.w[0] + rx0[0] + tx] : 0.f;
+    }
+#pragma unroll
+    for (int k = 1; k < NLV; ++k) {
+        const float* src = a.cur[k] + z * ((size_t)a.w[k] * a.h[k]) + (size_t)ry0[k] * a.w[k] + rx0[k];
+        float* dst = pool + roff[k];
+        if (tx < rw[k])
+            for (int y = ty; y < rh[k]; y += 4) dst[y * rw[k] + tx] = src[(size_t)y * a.w[k] + tx];
+    }
+    __syncthreads();
+    float* tmp = pool + toff;
+#pragma unroll
+    for (int k = NLV - 2; k >= 0; --k) {
+        const int sw = a.w[k + 1], sh = a.h[k + 1];
+        const float* srcn = pool + roff[k + 1];
+        const int nw = rw[k + 1], nh = rh[k + 1], nx0 = rx0[k + 1], ny0 = ry0[k + 1];
+        const int cw = rw[k], chh = rh[k], cx0 = rx0[k], cy0 = ry0[k];
+        const bool inx = tx < cw;
+        {   // horizontal pass of the region rows of level k+1 for this thread's column (pyrup_h with the column's case hoisted)
+            const int gx = cx0 + tx, i = gx >> 1, li = i - nx0;
+            const bool fi = i == 0, la = i == sw - 1, even = (gx & 1) == 0;
+            const int lm = fi ? li : li - 1, lp = la ? li : li + 1;
+            if (inx)
+                for (int r = ty; r < nh; r += 4) {
+                    const float* sr = srcn + r * nw;
+                    const float sm1 = sr[lm], s0 = sr[li], s1 = sr[lp];
+                    const float p6 = s0 * 6.f;
+                    const float ev = sel(fi, p6 + s1 * 2.f, sel(la, sm1 + s0 * 7.f, sm1 + p6 + s1));
+                    const float od = sel(la, s0 * 8.f, (s0 + s1) * 4.f);
+                    tmp[r * cw + tx] = sel(even, ev, od);
+                }
+        }
+        __syncthreads();
+        // vertical pass + add: rows ty, ty + 4, .. of the region (cy0 is even or the region starts at an odd row: parity per row)
+        if (k > 0) {
+            float* dst = pool + roff[k];                 // holds m_k, becomes cur_k
+            if (inx)
+                for (int y = ty; y < chh; y += 4) {
+                    const int gy = cy0 + y, j = gy >> 1;
+                    const int jm = (j == 0 ? 1 : j - 1) - ny0, jj = j - ny0, jp = (j == sh - 1 ? sh - 1 : j + 1) - ny0;
+                    const float up = ((gy & 1) == 0) ? (tmp[jm * cw + tx] + tmp[jj * cw + tx] * 6.f + tmp[jp * cw + tx]) * (1.f / 64.f)
+                                                     : ((tmp[jj * cw + tx] + tmp[jp * cw + tx]) * 4.f) * (1.f / 64.f);
+                    dst[y * cw + tx] = up + dst[y * cw + tx];                    // SpatialFilter.cpp:58
+                }
+            __syncthreads();
+        } else {
+            // NP consecutive rows per thread (the tile starts on an even row): the NP / 2 + 2 source rows they need are
+            // read once; a row index beyond the last source row is that row (pyrUp's bottom rule), row -1 is row 1
+            if (inx) {
+                const int jb = (cy0 >> 1) + ty * (NP / 2);
+                float R[NP / 2 + 2];
+                R[0] = tmp[((jb == 0 ? 1 : jb - 1) - ny0) * cw + tx];
+#pragma unroll
+                for (int i = 0; i <= NP / 2; ++i) {
+                    const int jr = jb + i < sh - 1 ? jb + i : sh - 1;
+                    R[i + 1] = tmp[(jr - ny0) * cw + tx];
+                }
+                float* gp = g2 + (size_t)(cy0 + ty * NP) * a.w[0] + cx0 + tx;
+#pragma unroll
+                for (int q = 0; q < NP; ++q) {
+                    const int i = q >> 1;                // source row jb + i is R[i + 1]
+                    const float up = (q & 1) == 0 ? (R[i] + R[i + 1] * 6.f + R[i + 2]) * (1.f / 64.f) : ((R[i + 1] + R[i + 2]) * 4.f) * (1.f / 64.f);
+                    if (ty * NP + q < chh) gp[(size_t)q * a.w[0]] = up + m2[q];
+                }
+            }
+        }
+    }
+}
+
 // Final level: out = u8(Lab2BGR(Lab(in) + [1, ca, ca] * pyrUp(cur_1))).  MOTION = false is
 // the first frame / L == 1 case (motion image is identically zero).  Persistent workgroups
 // walk over (stream, tile); the inverse-gamma spline table lives in LDS.
@@ -647,11 +872,13 @@ struct LaplaceState : ModeState {
     float* Gt[kMaxLevels + 1] = {}; float* curt[kMaxLevels + 1] = {};
     long fin_min_tasks = 2048;            // strips are shortened until a launch has this many of them (LVM_FIN_MIN_TASKS)
     long rows_min_elems = 1 << 20;        // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
+    int split_levels = 1;                 // temporal batches: levels >= 2 as one IIR launch + one collapse launch (LVM_LAP_SPLIT=0: level-by-level chain)
+    int up_rows4 = 0;                     // large launches: k_lap_up_rows<4, D> instead of the tiled kernel (LVM_UP_ROWS4=1|2 = ring depth)
     int up_rows = 1;                      // barrier-free k_lap_up_rows for the steady state (LVM_UP_ROWS=0: tiled k_lap_up)
     long up_rows_max_blocks = 1024;       // launches with fewer tiled workgroups than this use k_lap_up_rows (LVM_UP_ROWS_MAX_BLOCKS)
     bool d0_rows_on = true;               // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
     long d0_min_tasks = 4096;             // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
-    int fin_rows = 4;                     // rows per wave strip of k_lap_final_v4 (LVM_FIN_ROWS, power of two)
+    int fin_rows = 8;                     // rows per wave strip of k_lap_final_v4 (LVM_FIN_ROWS, power of two)
     int up_depth = 8;                     // frame-loop prefetch depth of k_lap_up at the coarse levels (LVM_UP_DEPTH=1|2|4|8)
     int chunks = 1;                       // temporal batches: > 1 = chunks whose down sweep overlaps the previous chunk's up sweep on a second stream (LVM_LAP_CHUNKS; measured slower: 27.7k fps at 4 chunks, 30.5k at 2, 34.8k at 1)
     std::vector<hipEvent_t> chunk_ev;
@@ -716,6 +943,8 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
     if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
     if (const char* e = std::getenv("LVM_LAP_CHUNKS")) st->chunks = std::atoi(e);
+    if (const char* e = std::getenv("LVM_LAP_SPLIT")) st->split_levels = std::atoi(e);
+    if (const char* e = std::getenv("LVM_UP_ROWS4")) st->up_rows4 = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_ROWS")) st->up_rows = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_ROWS_MAX_BLOCKS")) st->up_rows_max_blocks = std::atol(e);
     if (const char* e = std::getenv("LVM_ROWS_MIN_ELEMS")) st->rows_min_elems = std::atol(e);
@@ -868,7 +1097,42 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     double cLo = p.coLow, cHi = p.coHigh;
     if (cLo == 0) cLo = 0.01;                                            // TemporalFilter.cpp:11-12
     const bool use_tail = st->tailT && B.nt == 1 && !B.no_tail;
-    const int up_start = use_tail ? st->tailT - 1 : levels - 1;
+    int up_start = use_tail ? st->tailT - 1 : levels - 1;
+    // temporal batches: levels 2 .. L-1 decoupled (one IIR launch for all of them + one stateless collapse launch)
+    bool split = !first && st->split_levels && B.nt >= 4 && levels >= 3 && levels - 2 <= kIirLevels;
+    for (int l = 2; l <= levels - 1 && split; ++l) split = st->g[l].w % 2 == 0;
+    if (split) {
+        IirArgs ia;
+        ia.nlv = levels - 2; ia.nt = B.nt;
+        ia.aHi = (float)(1 - cHi); ia.bHi = (float)cHi; ia.aLo = (float)(1 - cLo); ia.bLo = (float)cLo;
+        int blocks = 0;
+        for (int l = 2; l <= levels - 1; ++l) {          // finest level first: its blocks are the long ones
+            IirLevel& v = ia.lv[l - 2];
+            v.Gl = G[l]; v.Gn = G[l + 1]; v.hi = st->hi[l]; v.lo = st->lo[l]; v.out = B.cur[l];
+            v.w = st->g[l].w; v.h = st->g[l].h; v.wn = st->g[l + 1].w; v.hn = st->g[l + 1].h;
+            v.gain = gains[l]; v.fsl = (long)st->planes * (long)st->g[l].n; v.fsn = (long)st->planes * (long)st->g[l + 1].n;
+            v.gw = v.w / 2; v.ngroups = v.gw * ((v.h + 1) / 2); v.block0 = blocks; v.top = l == levels - 1;
+            blocks += (v.ngroups + 255) / 256;
+        }
+        int depth = 8;
+        while (depth > 1 && B.nt % depth != 0) depth >>= 1;
+        auto ki = depth == 8 ? k_lap_iir_levels<8> : (depth == 4 ? k_lap_iir_levels<4> : (depth == 2 ? k_lap_iir_levels<2> : k_lap_iir_levels<1>));
+        LVM_LAUNCH(c, "lap_iir", ki, dim3((unsigned)blocks, (unsigned)st->planes), blk, s, ia);
+        if (levels >= 4) {
+            CollapseArgs ca;
+            ca.nlv = levels - 2;
+            for (int l = 2; l <= levels - 1; ++l) { ca.cur[l - 2] = B.cur[l]; ca.w[l - 2] = st->g[l].w; ca.h[l - 2] = st->g[l].h; }
+            const dim3 gridc((st->g[2].w + CT_W - 1) / CT_W, (st->g[2].h + CT_H - 1) / CT_H, (unsigned)(st->planes * B.nt));
+            void (*kc)(CollapseArgs) = nullptr;
+            switch (ca.nlv) {
+            case 2: kc = k_lap_collapse<2>; break; case 3: kc = k_lap_collapse<3>; break; case 4: kc = k_lap_collapse<4>; break;
+            case 5: kc = k_lap_collapse<5>; break; case 6: kc = k_lap_collapse<6>; break; case 7: kc = k_lap_collapse<7>; break;
+            case 8: kc = k_lap_collapse<8>; break; case 9: kc = k_lap_collapse<9>; break; default: kc = k_lap_collapse<10>; break;
+            }
+            LVM_LAUNCH(c, "lap_collapse", kc, gridc, blk, s, ca);
+        }
+        up_start = 1;
+    }
     for (int l = up_start; l >= 1; --l) {
         UpArgs a;
         a.Gl = G[l]; a.Gn = G[l + 1];
@@ -894,6 +1158,15 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
                                  : (depth == 2 ? (hc ? k_lap_up_rows<2, 2, true> : k_lap_up_rows<2, 2, false>)
                                                : (hc ? k_lap_up_rows<2, 1, true> : k_lap_up_rows<2, 1, false>));
             LVM_LAUNCH(c, LName("lap_up", l), kr, g2, blk, s, a, gw, (int)ngroups);
+            continue;
+        }
+        if (!first && st->up_rows4 && a.w % 4 == 0 && a.curn != nullptr) {
+            // large launches (level 1): 4 x 2 pixels per lane, 16-byte accesses of level l, no LDS
+            const int gw = a.w / 4;
+            const long ngroups = (long)gw * ((a.h + 1) / 2);
+            const dim3 g2((unsigned)((ngroups + 255) / 256), (unsigned)st->planes);
+            if (st->up_rows4 == 2 && a.nt % 2 == 0) LVM_LAUNCH(c, LName("lap_up", l), (k_lap_up_rows<4, 2, true>), g2, blk, s, a, gw, (int)ngroups);
+            else LVM_LAUNCH(c, LName("lap_up", l), (k_lap_up_rows<4, 1, true>), g2, blk, s, a, gw, (int)ngroups);
             continue;
         }
         int depth = (blocks >= 1024) ? 1 : st->up_depth;              // frame ring of the tiled kernel

@@ -247,6 +247,20 @@ def test_laplace_emu_temporal_batches(lvm, po, emu, w, h, levels, ns, calls):
     _frames_clip(lvm, po, emu, 0, w, h, levels, ns, calls)
 
 
+@pytest.mark.parametrize("w,h,levels,ns,calls", [(640, 360, 5, 1, (1, 8, 4)), (256, 256, 6, 1, (1, 4, 6)), (320, 182, 5, 2, (1, 5, 16)),
+                                                  (576, 72, 4, 1, (1, 4, 4))])
+def test_laplace_emu_split_levels_iir_and_collapse(lvm, po, emu, w, h, levels, ns, calls):
+    """Temporal batches of >= 4 frames: levels 2 .. L-1 as ONE k_lap_iir_levels launch + ONE k_lap_collapse launch
+    (several 64 x 32 tiles of level 2, odd level heights, levels of a few pixels, two streams, every ring depth)."""
+    _frames_clip(lvm, po, emu, 0, w, h, levels, ns, calls)
+
+
+def test_laplace_emu_level_chain_still_matches(lvm, po, emu, monkeypatch):
+    """LVM_LAP_SPLIT=0 keeps the level-by-level chain of fused launches in temporal batches."""
+    monkeypatch.setenv("LVM_LAP_SPLIT", "0")
+    _frames_clip(lvm, po, emu, 0, 320, 180, 4, 1, (1, 8, 4))
+
+
 @pytest.mark.parametrize("w,h,levels,calls", [(328, 109, 3, (1, 4, 8, 2, 3)), (200, 120, 4, (1, 16, 6))])
 def test_laplace_emu_block_up_kernel_variants(lvm, po, emu, w, h, levels, calls):
     """k_lap_up_rows over batch lengths that select every ring depth (4, 2, 1), on odd heights
