@@ -145,6 +145,23 @@ int  lvm_chain_process_batch(lvm_ctx* ctx, const lvm_preprocess_params* pp, cons
                              const uint8_t* const* in, int w, int h, int channels, ptrdiff_t in_stride,
                              uint8_t* const* out, ptrdiff_t out_stride, int* produced);
 
+/* ---- export hand-off on the device ---------------------------------------------------
+ * export/ExportTypes.hpp:11 -- numeric order of `enum class SplitMode`                                        */
+enum lvm_split { LVM_SPLIT_NONE = 0, LVM_SPLIT_LEFT_RIGHT = 1, LVM_SPLIT_TOP_BOTTOM = 2 };
+/* Pane and canvas size of Exporter::compose (export/Exporter.cpp:53-88) for an original of ow x oh and a processed
+ * frame of pw x ph: panes are cropped to the common EVEN size (:63-64; split None: the processed frame's own even
+ * size, :56).  Returns LVM_OK; all four outputs are 0 when the reference returns an empty Mat (:57, :65).     */
+int  lvm_compose_geometry(int split, int ow, int oh, int pw, int ph, int* pane_w, int* pane_h, int* canvas_w,
+                          int* canvas_h);
+/* Exporter::compose on DEVICE memory for all n_streams streams: toBgr (gray -> b = g = r, Exporter.cpp:22-34), crop,
+ * and the side-by-side / stacked / single-pane BGR canvas (3 bytes per pixel, canvas_stride >= 3 * canvas_w).  d_orig
+ * may be NULL (the reference falls back to the processed frame, :62).  Enqueued on hip_stream, not synchronised.  The
+ * text overlay (:36-50, cv::putText) is not part of this entry point: labels are drawn on the downloaded canvas. */
+int  lvm_compose_device(lvm_ctx* ctx, int split, const uint8_t* d_orig, int ow, int oh, int och,
+                        ptrdiff_t orig_stride, ptrdiff_t orig_stream_stride, const uint8_t* d_proc, int pw, int ph,
+                        int pch, ptrdiff_t proc_stride, ptrdiff_t proc_stream_stride, uint8_t* d_canvas,
+                        ptrdiff_t canvas_stride, ptrdiff_t canvas_stream_stride, void* hip_stream);
+
 /* Cross-frame software pipeline for lvm_process_device (throughput mode, default depth 0).
  * depth 1 (implemented for the Laplace mode; other modes ignore it): a call enqueues the
  * down-sweep of ITS frame on an internal second stream concurrently with the up-sweep + output of

@@ -96,7 +96,7 @@ SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process
            "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_profile_enable", "lvm_profile_collect",
            "lvm_profile_entry", "lvm_set_graph", "lvm_algorithmic_bytes",
            "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process", "lvm_chain_process_batch",
-           "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free"]
+           "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free", "lvm_compose_geometry", "lvm_compose_device"]
 
 
 def bind(lib):
@@ -140,6 +140,9 @@ def bind(lib):
                                       C.c_ssize_t, vp, C.c_ssize_t, ip]
     lib.lvm_chain_process_batch.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), C.POINTER(vp), C.c_int, C.c_int,
                                             C.c_int, C.c_ssize_t, C.POINTER(vp), C.c_ssize_t, ip]
+    lib.lvm_compose_geometry.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip]
+    lib.lvm_compose_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, C.c_int, C.c_int, C.c_int,
+                                       C.c_ssize_t, C.c_ssize_t, vp, C.c_ssize_t, C.c_ssize_t, vp]
     lib.lvm_set_max_frames.argtypes = [vp, C.c_int]
     lib.lvm_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     lib.lvm_host_free.argtypes = [vp]
@@ -260,6 +263,18 @@ class Context:
         self._check(self.lib.lvm_process_device_frames(self.h, C.byref(cparams), n_frames, d_in, w, h, ch, in_stride, in_sstride,
                                                        in_fstride, d_out, out_stride, out_sstride, out_fstride, produced, stream))
         return [bool(x) for x in produced]
+
+    def compose_geometry(self, split, ow, oh, pw, ph):
+        """(pane_w, pane_h, canvas_w, canvas_h) of Exporter::compose; zeros = the reference's empty Mat."""
+        v = [C.c_int() for _ in range(4)]
+        if self.lib.lvm_compose_geometry(int(split), ow, oh, pw, ph, *[C.byref(x) for x in v]) != 0:
+            raise LvmError("lvm_compose_geometry: invalid split mode")
+        return tuple(x.value for x in v)
+
+    def compose_device(self, split, d_orig, ow, oh, och, ostride, osstride, d_proc, pw, ph, pch, pstride, psstride, d_canvas, cstride,
+                       csstride, stream=None):
+        self._check(self.lib.lvm_compose_device(self.h, int(split), d_orig, ow, oh, och, ostride, osstride, d_proc, pw, ph, pch, pstride,
+                                                psstride, d_canvas, cstride, csstride, stream))
 
     def set_max_frames(self, n):
         self._check(self.lib.lvm_set_max_frames(self.h, int(n)))

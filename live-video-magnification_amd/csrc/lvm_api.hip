@@ -328,6 +328,28 @@ int lvm_preprocess_device(lvm_ctx* c, const lvm_preprocess_params* pp, const uin
     return lvm::preprocess_device(c, *pp, d_in, w, h, channels, in_stride, in_stream_stride, d_out, out_stride, out_stream_stride, s);
 }
 
+int lvm_compose_geometry(int split, int ow, int oh, int pw, int ph, int* pane_w, int* pane_h, int* canvas_w, int* canvas_h) {
+    if (split < LVM_SPLIT_NONE || split > LVM_SPLIT_TOP_BOTTOM) return LVM_ERR_INVALID;
+    int v[4];
+    (void)lvm::compose_geometry(split, ow, oh, pw, ph, &v[0], &v[1], &v[2], &v[3]);
+    int* dst[4] = {pane_w, pane_h, canvas_w, canvas_h};
+    for (int i = 0; i < 4; ++i) if (dst[i]) *dst[i] = v[i];
+    return LVM_OK;
+}
+
+int lvm_compose_device(lvm_ctx* c, int split, const uint8_t* d_orig, int ow, int oh, int och, ptrdiff_t orig_stride,
+                       ptrdiff_t orig_stream_stride, const uint8_t* d_proc, int pw, int ph, int pch, ptrdiff_t proc_stride,
+                       ptrdiff_t proc_stream_stride, uint8_t* d_canvas, ptrdiff_t canvas_stride, ptrdiff_t canvas_stream_stride,
+                       void* hip_stream) {
+    if (!c) return LVM_ERR_INVALID;
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    const int rc = lvm::compose_device(c, split, d_orig, ow, oh, och, orig_stride, orig_stream_stride, d_proc, pw, ph, pch, proc_stride,
+                                       proc_stream_stride, d_canvas, canvas_stride, canvas_stream_stride, s);
+    lvm::mark_enqueued(c, s);
+    return rc;
+}
+
 // FNV-1a over the PreprocessParams fields the reference compares (IProcessor.hpp:36-39)
 static uint64_t preprocess_key_of(const lvm_preprocess_params& pp) {
     uint64_t k = 1469598103934665603ull;

@@ -281,6 +281,9 @@ struct Ctx {
 };
 
 void sync_streams(Ctx* c);
+void mark_enqueued(Ctx* c, hipStream_t s);
+void fail_state(Ctx* c, hipStream_t s);
+int ensure_float(Ctx* c, size_t count);
 void prof_begin(Ctx* c, const char* name, hipStream_t s);
 void prof_end(Ctx* c, hipStream_t s);
 
@@ -318,6 +321,12 @@ void preprocess_geometry(const lvm_preprocess_params& pp, int w, int h, int chan
 int preprocess_device(Ctx* c, const lvm_preprocess_params& pp, const uint8_t* d_in, int w, int h, int channels, ptrdiff_t in_stride,
                       ptrdiff_t in_sstride, uint8_t* d_out, ptrdiff_t out_stride, ptrdiff_t out_sstride, hipStream_t s);
 void preprocess_release(Ctx* c);
+
+// compose.hip
+int compose_geometry(int split, int ow, int oh, int pw, int ph, int* pane_w, int* pane_h, int* canvas_w, int* canvas_h);
+int compose_device(Ctx* c, int split, const uint8_t* d_orig, int ow, int oh, int och, ptrdiff_t ostride, ptrdiff_t osstride,
+                   const uint8_t* d_proc, int pw, int ph, int pch, ptrdiff_t pstride, ptrdiff_t psstride, uint8_t* d_canvas,
+                   ptrdiff_t cstride, ptrdiff_t csstride, hipStream_t s);
 
 constexpr int kColorBatchMax = 32;    // frames of one colour-mode temporal batch (spare slots of the window ring)
 

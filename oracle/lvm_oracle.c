@@ -1304,3 +1304,34 @@ void lvmo_preprocess(const lvmo_pre_params* pp, const uint8_t* in, int w, int h,
     else memcpy(out, tmp, (size_t)ow * oh * channels);
     free(tmp);
 }
+
+/* ---- export pane composition: Exporter::compose (export/Exporter.cpp:53-88) with toBgr (:22-34) -------------------
+ * split: 0 None, 1 LeftRight, 2 TopBottom (export/ExportTypes.hpp:11).  The text overlay (:36-50) is not restated.
+ * Returns 0 and leaves the canvas untouched when the reference returns an empty Mat (:57, :65).                     */
+int lvmo_compose_geometry(int split, int ow, int oh, int pw, int ph, int* cw, int* ch) {
+    int w, h;
+    if (split == 0) { w = pw & ~1; h = ph & ~1; }                                      /* :56 */
+    else { w = (ow < pw ? ow : pw) & ~1; h = (oh < ph ? oh : ph) & ~1; }               /* :63-64 */
+    if (w <= 0 || h <= 0) { *cw = 0; *ch = 0; return 0; }
+    *cw = split == 1 ? 2 * w : w;                                                      /* :71 */
+    *ch = split == 2 ? 2 * h : h;                                                      /* :79 */
+    return 1;
+}
+static void compose_pane(const uint8_t* src, int cn, ptrdiff_t stride, int w, int h, uint8_t* dst, ptrdiff_t dstride) {
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < 3; c++)
+                dst[(size_t)y * dstride + 3 * x + c] = cn == 3 ? src[(size_t)y * stride + 3 * x + c] : src[(size_t)y * stride + x];   /* GRAY2BGR: b = g = r */
+}
+int lvmo_compose(int split, const uint8_t* orig, int ow, int oh, int och, ptrdiff_t ostride, const uint8_t* proc, int pw, int ph,
+                 int pch, ptrdiff_t pstride, uint8_t* canvas, ptrdiff_t cstride) {
+    if (!orig) { orig = proc; ow = pw; oh = ph; och = pch; ostride = pstride; }         /* :62 */
+    int cw, ch;
+    if (!lvmo_compose_geometry(split, ow, oh, pw, ph, &cw, &ch)) return 0;
+    if (split == 0) { compose_pane(proc, pch, pstride, cw, ch, canvas, cstride); return 1; }   /* :58 */
+    const int w = split == 1 ? cw / 2 : cw, h = split == 2 ? ch / 2 : ch;
+    compose_pane(orig, och, ostride, w, h, canvas, cstride);                            /* :73, :81 */
+    if (split == 1) compose_pane(proc, pch, pstride, w, h, canvas + 3 * w, cstride);    /* :74 */
+    else compose_pane(proc, pch, pstride, w, h, canvas + (size_t)h * cstride, cstride); /* :82 */
+    return 1;
+}

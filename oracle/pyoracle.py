@@ -88,6 +88,9 @@ def lib():
         L.lvmo_resize_area_u8.restype = None
         L.lvmo_bgr2gray_u8.argtypes = [_u8p, C.c_int, _u8p]
         L.lvmo_bgr2gray_u8.restype = None
+        L.lvmo_compose_geometry.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip]
+        L.lvmo_compose.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                   C.c_ssize_t, C.c_void_p, C.c_ssize_t]
         # a few threads only: on many-core hosts OpenMP fork/join over tiny pyramid levels dominates
         L.lvmo_set_threads(max(1, min(8, os.cpu_count() or 1)))
         _lib = L
@@ -320,3 +323,23 @@ def bgr2gray_u8(a):
     out = np.empty(a.shape[:2], dtype=np.uint8)
     lib().lvmo_bgr2gray_u8(a, a.shape[0] * a.shape[1], out)
     return out
+
+
+def compose(split, orig, proc):
+    """Exporter::compose (export/Exporter.cpp:53-88, no text overlay): returns the BGR canvas or None (empty Mat)."""
+    proc = np.ascontiguousarray(proc, dtype=np.uint8)
+    ph, pw = proc.shape[:2]
+    pch = 1 if proc.ndim == 2 else proc.shape[2]
+    if orig is not None:
+        orig = np.ascontiguousarray(orig, dtype=np.uint8)
+        oh, ow = orig.shape[:2]
+        och = 1 if orig.ndim == 2 else orig.shape[2]
+    else:
+        oh, ow, och = ph, pw, pch
+    cw, ch = C.c_int(), C.c_int()
+    if not lib().lvmo_compose_geometry(split, ow, oh, pw, ph, C.byref(cw), C.byref(ch)):
+        return None
+    canvas = np.zeros((ch.value, cw.value, 3), np.uint8)
+    lib().lvmo_compose(split, orig.ctypes.data if orig is not None else None, ow, oh, och, ow * och, proc.ctypes.data, pw, ph, pch, pw * pch,
+                       canvas.ctypes.data, cw.value * 3)
+    return canvas
