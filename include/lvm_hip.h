@@ -145,6 +145,14 @@ int  lvm_chain_process_batch(lvm_ctx* ctx, const lvm_preprocess_params* pp, cons
                              const uint8_t* const* in, int w, int h, int channels, ptrdiff_t in_stride,
                              uint8_t* const* out, ptrdiff_t out_stride, int* produced);
 
+/* The same plus the frames the magnifier SAW (runChainOnce's `original`, processing/ChainBuilder.cpp:19-29: what the
+ * display shows in its left pane, core/LatestFrameMailbox.hpp:13-16): pre_out[s] (may be NULL, entries may be NULL)
+ * receives the preprocessed frame of stream s, same geometry as out[s].                                        */
+int  lvm_chain_process_batch_ex(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_params* p,
+                                const uint8_t* const* in, int w, int h, int channels, ptrdiff_t in_stride,
+                                uint8_t* const* out, ptrdiff_t out_stride, uint8_t* const* pre_out,
+                                ptrdiff_t pre_stride, int* produced);
+
 /* ---- export hand-off on the device ---------------------------------------------------
  * export/ExportTypes.hpp:11 -- numeric order of `enum class SplitMode`                                        */
 enum lvm_split { LVM_SPLIT_NONE = 0, LVM_SPLIT_LEFT_RIGHT = 1, LVM_SPLIT_TOP_BOTTOM = 2 };

@@ -96,7 +96,7 @@ SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process
            "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_profile_enable", "lvm_profile_collect",
            "lvm_profile_entry", "lvm_set_graph", "lvm_algorithmic_bytes",
            "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process", "lvm_chain_process_batch",
-           "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free", "lvm_compose_geometry", "lvm_compose_device"]
+           "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free", "lvm_compose_geometry", "lvm_compose_device", "lvm_chain_process_batch_ex"]
 
 
 def bind(lib):
@@ -140,6 +140,8 @@ def bind(lib):
                                       C.c_ssize_t, vp, C.c_ssize_t, ip]
     lib.lvm_chain_process_batch.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), C.POINTER(vp), C.c_int, C.c_int,
                                             C.c_int, C.c_ssize_t, C.POINTER(vp), C.c_ssize_t, ip]
+    lib.lvm_chain_process_batch_ex.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), C.POINTER(vp), C.c_int, C.c_int,
+                                               C.c_int, C.c_ssize_t, C.POINTER(vp), C.c_ssize_t, C.POINTER(vp), C.c_ssize_t, ip]
     lib.lvm_compose_geometry.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip]
     lib.lvm_compose_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, C.c_int, C.c_int, C.c_int,
                                        C.c_ssize_t, C.c_ssize_t, vp, C.c_ssize_t, C.c_ssize_t, vp]

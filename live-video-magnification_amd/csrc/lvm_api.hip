@@ -361,6 +361,12 @@ static uint64_t preprocess_key_of(const lvm_preprocess_params& pp) {
 
 int lvm_chain_process_batch(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, const uint8_t* const* in, int w, int h,
                             int channels, ptrdiff_t in_stride, uint8_t* const* out, ptrdiff_t out_stride, int* produced) {
+    return lvm_chain_process_batch_ex(c, pp, p, in, w, h, channels, in_stride, out, out_stride, nullptr, 0, produced);
+}
+
+int lvm_chain_process_batch_ex(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, const uint8_t* const* in, int w, int h,
+                               int channels, ptrdiff_t in_stride, uint8_t* const* out, ptrdiff_t out_stride, uint8_t* const* pre_out,
+                               ptrdiff_t pre_stride, int* produced) {
     if (!c || !pp || !p || !produced || !in || !out) return LVM_ERR_INVALID;
     *produced = 0;
     const int NS = c->nstreams;
@@ -412,6 +418,12 @@ int lvm_chain_process_batch(lvm_ctx* c, const lvm_preprocess_params* pp, const l
     const uint8_t* res = *produced ? c->d_chain_out : mag_in;
     for (int k = 0; k < NS; ++k)
         LVM_HIP_TRY(c, hipMemcpy2DAsync(out[k], (size_t)out_stride, res + (size_t)k * out_bytes, out_row, out_row, (size_t)oh, hipMemcpyDeviceToHost, s));
+    if (pre_out) {     // the pre-magnification frames (runChainOnce's `original`, ChainBuilder.cpp:19-29): the display's left pane
+        if (pre_stride < (ptrdiff_t)out_row) { c->err = "pre_out stride too small"; (void)hipStreamSynchronize(s); return LVM_ERR_INVALID; }
+        for (int k = 0; k < NS; ++k)
+            if (pre_out[k])
+                LVM_HIP_TRY(c, hipMemcpy2DAsync(pre_out[k], (size_t)pre_stride, mag_in + (size_t)k * out_bytes, out_row, out_row, (size_t)oh, hipMemcpyDeviceToHost, s));
+    }
     LVM_HIP_TRY(c, hipStreamSynchronize(s));
     return LVM_OK;
 }

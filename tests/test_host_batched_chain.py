@@ -1,0 +1,134 @@
+"""The reference-side half of the batched chain: host/HipBatchedProcessingChain.hpp is the
+N-source generalisation of ProcessingChain::run (processing/ProcessingChain.cpp:34-71).  Its template core compiles
+without OpenCV / Qt: this test drives it with mock queues / mailboxes / frames -- three sources, one processing thread,
+one lvm_chain_process_batch_ex call per tick -- and checks, on a GPU, every published frame against a per-source
+single-stream Magnifier (same library, so byte-equal), the `original` pane, the passthrough rule and the
+catch-reset-publish-input path (:50-58).  Without a GPU the constructor must fail loudly (no CPU fallback)."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "live-video-magnification_amd")
+
+SRC = r'''
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <vector>
+#include "HipBatchedProcessingChain.hpp"
+
+struct MFrame { std::vector<unsigned char> px; int w, h, ch; long seq; };
+struct MockTraits {
+    using FrameRef = std::shared_ptr<const MFrame>;
+    struct View { const std::uint8_t* data; int w, h, channels; std::ptrdiff_t stride; };
+    static View view(const FrameRef& f) { return View{f->px.data(), f->w, f->h, f->ch, (std::ptrdiff_t)f->w * f->ch}; }
+    static FrameRef make_like(const FrameRef& in, int w, int h, int ch, std::uint8_t** data, std::ptrdiff_t* stride) {
+        auto o = std::make_shared<MFrame>();
+        o->px.assign((size_t)w * h * ch, 0); o->w = w; o->h = h; o->ch = ch; o->seq = in->seq;
+        *data = o->px.data(); *stride = (std::ptrdiff_t)w * ch;
+        return o;
+    }
+    struct Queue {                       // the part of core/BoundedQueue.hpp the chain uses: blocking pop + stop
+        std::mutex m; std::condition_variable cv; std::deque<FrameRef> q; bool stopped = false;
+        void push(FrameRef f) { { std::lock_guard<std::mutex> l(m); q.push_back(std::move(f)); } cv.notify_one(); }
+    };
+    static bool pop(Queue& q, FrameRef& f) {
+        std::unique_lock<std::mutex> l(q.m);
+        q.cv.wait(l, [&] { return q.stopped || !q.q.empty(); });
+        if (q.q.empty()) return false;
+        f = q.q.front(); q.q.pop_front(); return true;
+    }
+    static void stop(Queue& q) { { std::lock_guard<std::mutex> l(q.m); q.stopped = true; } q.cv.notify_all(); }
+    struct Mailbox { std::mutex m; std::vector<std::pair<FrameRef, FrameRef>> all; };   // keeps every publish (the real one keeps the latest)
+    static void publish(Mailbox& b, FrameRef p, FrameRef o) { std::lock_guard<std::mutex> l(b.m); b.all.emplace_back(std::move(p), std::move(o)); }
+    struct Snapshot { lvm_preprocess_params pre; lvm::MagnificationParams mag; };
+    struct Config { Snapshot s; };
+    static Snapshot read(Config& c) { return c.s; }
+    struct Instr { int errors = 0, processed = 0; };
+    static void on_error(Instr* i) { if (i) ++i->errors; }
+    static void on_processed(Instr* i, const FrameRef&) { if (i) ++i->processed; }
+};
+
+static std::shared_ptr<const MFrame> frame(int w, int h, int ch, int src, long t) {
+    auto f = std::make_shared<MFrame>();
+    f->w = w; f->h = h; f->ch = ch; f->seq = t; f->px.resize((size_t)w * h * ch);
+    for (size_t i = 0; i < f->px.size(); ++i) f->px[i] = (unsigned char)(40 + ((i * 7 + src * 31 + (size_t)t * 13 + (i / 97)) % 150));
+    return f;
+}
+
+int main() {
+    const int N = 3, W = 96, H = 64, T = 6;
+    try {
+        std::vector<MockTraits::Queue> q(N); std::vector<MockTraits::Mailbox> mb(N);
+        std::vector<MockTraits::Queue*> qp; std::vector<MockTraits::Mailbox*> mp;
+        for (int s = 0; s < N; ++s) { qp.push_back(&q[s]); mp.push_back(&mb[s]); }
+        MockTraits::Instr instr; MockTraits::Config cfg{};
+        cfg.s.pre.downscale = 2; cfg.s.pre.roiW = cfg.s.pre.roiH = 1.f;
+        cfg.s.mag.mode = lvm::MagnificationMode::Laplace; cfg.s.mag.levels = 3; cfg.s.mag.amplification = 15; cfg.s.mag.coWavelength = 100;
+        cfg.s.mag.coLow = 0.1; cfg.s.mag.coHigh = 0.4; cfg.s.mag.chromAttenuation = 0.2;
+        lvm::BatchedChain<MockTraits> chain(qp, mp, &instr, &cfg, 0);
+        for (long t = 0; t < T; ++t) for (int s = 0; s < N; ++s) q[s].push(frame(W, H, 3, s, t));
+        chain.start();
+        while (chain.ticks() < (unsigned)T) std::this_thread::yield();
+        // a tick whose sources disagree on the geometry: counted, context reset, inputs published (ProcessingChain.cpp:50-58)
+        q[0].push(frame(W, H, 3, 0, T)); q[1].push(frame(W / 2, H, 3, 1, T)); q[2].push(frame(W, H, 3, 2, T));
+        while (chain.ticks() < (unsigned)T + 1) std::this_thread::yield();
+        // and the chain keeps working afterwards (first frame after the reset = Lab round trip of the input)
+        for (int s = 0; s < N; ++s) q[s].push(frame(W, H, 3, s, T + 1));
+        while (chain.ticks() < (unsigned)T + 2) std::this_thread::yield();
+        chain.stop();
+        int bad = 0;
+        for (int s = 0; s < N; ++s) {
+            lvm::Magnifier single(0, 1);                         // the reference arrangement: one chain per source
+            if ((int)mb[s].all.size() != T + 2) { std::printf("source %d: %zu publishes\n", s, mb[s].all.size()); ++bad; continue; }
+            for (long t = 0; t < T; ++t) {
+                auto in = frame(W, H, 3, s, t);
+                std::vector<unsigned char> ref((size_t)(W / 2) * (H / 2) * 3);
+                const bool produced = single.chain_process(cfg.s.pre, cfg.s.mag, in->px.data(), W, H, 3, W * 3, ref.data(), (W / 2) * 3);
+                const auto& pr = mb[s].all[(size_t)t];
+                if (!produced || pr.first->w != W / 2 || pr.first->seq != t || pr.first->px != ref) { std::printf("source %d frame %ld differs\n", s, t); ++bad; }
+                if (pr.second->w != W / 2 || pr.second->px.size() != ref.size() || pr.second->seq != t) { std::printf("source %d frame %ld: bad original pane\n", s, t); ++bad; }
+            }
+            const auto& er = mb[s].all[(size_t)T];
+            if (er.first != er.second || er.first->seq != T) { std::printf("source %d: error tick did not publish the input\n", s); ++bad; }
+            const auto& af = mb[s].all[(size_t)T + 1];
+            if (af.first->w != W / 2 || af.first->seq != T + 1) { std::printf("source %d: no recovery\n", s); ++bad; }
+        }
+        std::printf("ticks=%llu errors=%llu instr_errors=%d processed=%d bad=%d\n", (unsigned long long)chain.ticks(),
+                    (unsigned long long)chain.errors(), instr.errors, instr.processed, bad);
+        return bad ? 4 : 0;
+    } catch (const lvm::Error& e) { std::printf("lvm::Error %d: %s\n", e.status(), e.what()); return 3; }
+}
+'''
+
+
+def _run(tmp_path):
+    src = tmp_path / "t.cpp"
+    src.write_text(SRC)
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-pthread", str(src), "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(PKG, "host"), "-L", PKG, "-llvm_hip", "-Wl,-rpath," + PKG,
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.is_available():
+        assert r.returncode == 0 and "ticks=8 errors=1 instr_errors=1 processed=24 bad=0" in r.stdout, r.stdout + r.stderr
+    else:
+        assert r.returncode == 3 and "lvm::Error -3" in r.stdout, r.stdout + r.stderr
+
+
+def test_batched_chain_compiles_and_runs_three_sources(tmp_path):
+    _run(tmp_path)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_batched_chain_compiles_and_runs_three_sources_on_the_gpu(tmp_path):
+    """the same program where a device exists: the results branch of the assertions runs"""
+    import torch
+    assert torch.cuda.is_available()
+    _run(tmp_path)

@@ -33,7 +33,7 @@ int main() {
 '''
 
 
-def test_cpp_wrapper_compiles_links_and_fails_loudly_without_gpu(tmp_path):
+def _run(tmp_path):
     src = tmp_path / "t.cpp"
     src.write_text(SRC)
     exe = tmp_path / "t"
@@ -46,3 +46,18 @@ def test_cpp_wrapper_compiles_links_and_fails_loudly_without_gpu(tmp_path):
         assert r.returncode == 0 and "produced=1" in r.stdout and "chain 32x24x1 produced=1 first=90" in r.stdout, r.stdout + r.stderr
     else:
         assert r.returncode == 3 and "lvm::Error -3" in r.stdout, r.stdout + r.stderr
+
+
+def test_cpp_wrapper_compiles_links_and_fails_loudly_without_gpu(tmp_path):
+    _run(tmp_path)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_cpp_wrapper_compiles_links_on_the_gpu(tmp_path):
+    """the same program where a device exists: the results branch of the assertions runs"""
+    import torch
+    assert torch.cuda.is_available()
+    _run(tmp_path)
