@@ -358,8 +358,77 @@ static inline void bgr2lab_px(float s0, float s1, float s2, float* o) {
     o[1] = 500.f * (FX - FY);
     o[2] = 200.f * (FY - FZ);
 }
+/* ---- OpenCV 4's DEFAULT forward float path: the trilinear-interpolated 33^3 int16 LUT ---------------------------
+ * [cv] color_lab.cpp: RGB2Labfloat with useInterpolation (= sRGB + default coefficients + default white point, the
+ * case cv::cvtColor(COLOR_BGR2Lab) on CV_32F is), initLabTabs (LAB_LUT_DIM = 33, lab_base_shift = 14, trilinear_shift
+ * = 4), trilinearInterpolate.  UNPINNED like the rest of the OpenCV boundary (restated from the published source, no
+ * OpenCV here to check against) and OFF by default: the library implements the analytic form; this option exists to
+ * QUANTIFY how far a real OpenCV 4 build would sit from it (tests/test_oracle_modes.py).
+ * The table is built in float64 (OpenCV: softfloat / softdouble); entries are rounded to 1/16384 of the range, so the
+ * two agree except for an occasional last int16 unit.                                                              */
+enum { LAB_LUT_DIM = 33, LAB_BASE_SHIFT = 14, LAB_BASE = 1 << LAB_BASE_SHIFT, LAB_LUT_SHIFT = 5, TRI_SHIFT = 4 };
+static int16_t* g_lab_lut = NULL;               /* [r][g][b][3] at the 33^3 grid (OpenCV stores 8 replicated corners per cell) */
+static int g_lab_use_lut = 0;
+void lvmo_set_lab_lut(int on) { g_lab_use_lut = on != 0; }
+static void lab_lut_init(void) {
+    if (g_lab_lut) return;
+    static const double M[9] = { 0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227 };
+    static const double D65[3] = { 0.950456, 1.0, 1.088754 };
+    int16_t* t = (int16_t*)malloc(sizeof(int16_t) * 3 * LAB_LUT_DIM * LAB_LUT_DIM * LAB_LUT_DIM);
+    for (int p = 0; p < LAB_LUT_DIM; ++p)
+        for (int q = 0; q < LAB_LUT_DIM; ++q)
+            for (int r = 0; r < LAB_LUT_DIM; ++r) {
+                double rgb[3] = { (double)p / (LAB_LUT_DIM - 1), (double)q / (LAB_LUT_DIM - 1), (double)r / (LAB_LUT_DIM - 1) };
+                for (int k = 0; k < 3; ++k) rgb[k] = rgb[k] <= 0.04045 ? rgb[k] / 12.92 : pow((rgb[k] + 0.055) / 1.055, 2.4);   /* applyGamma */
+                double xyz[3];
+                for (int k = 0; k < 3; ++k) xyz[k] = (M[k * 3] * rgb[0] + M[k * 3 + 1] * rgb[1] + M[k * 3 + 2] * rgb[2]) / D65[k];
+                double f[3];
+                for (int k = 0; k < 3; ++k) f[k] = xyz[k] > 216.0 / 24389.0 ? cbrt(xyz[k]) : (24389.0 / 27.0 * xyz[k] + 16.0) / 116.0;
+                const double L = xyz[1] > 216.0 / 24389.0 ? 116.0 * f[1] - 16.0 : 24389.0 / 27.0 * xyz[1];
+                const double a = 500.0 * (f[0] - f[1]), b = 200.0 * (f[1] - f[2]);
+                int16_t* e = t + 3 * ((p * LAB_LUT_DIM + q) * LAB_LUT_DIM + r);
+                e[0] = (int16_t)lrint(LAB_BASE * L / 100.0);
+                e[1] = (int16_t)lrint(LAB_BASE * (a + 128.0) / 256.0);
+                e[2] = (int16_t)lrint(LAB_BASE * (b + 128.0) / 256.0);
+            }
+    g_lab_lut = t;
+}
+/* [cv] RGB2Labfloat::operator(), useInterpolation branch (scalar form; the SIMD form computes the same integers) */
+static inline void bgr2lab_lut_px(float s0, float s1, float s2, float* o) {
+    const int c[3] = { (int)lrintf(clip01(s2) * (float)LAB_BASE), (int)lrintf(clip01(s1) * (float)LAB_BASE), (int)lrintf(clip01(s0) * (float)LAB_BASE) };   /* R, G, B */
+    int t[3], w1[3];
+    for (int k = 0; k < 3; ++k) {
+        t[k] = c[k] >> (LAB_BASE_SHIFT - LAB_LUT_SHIFT);                              /* cell origin */
+        w1[k] = (c[k] >> (LAB_BASE_SHIFT - 8 - 1)) & ((1 << TRI_SHIFT) - 1);          /* weight of the upper neighbour, 0..15 */
+    }
+    int acc[3] = { 0, 0, 0 };
+    for (int corner = 0; corner < 8; ++corner) {
+        int idx[3], wgt = 1;
+        for (int k = 0; k < 3; ++k) {
+            const int up = (corner >> k) & 1;
+            idx[k] = t[k] + up; if (idx[k] > LAB_LUT_DIM - 1) idx[k] = LAB_LUT_DIM - 1;
+            wgt *= up ? w1[k] : (1 << TRI_SHIFT) - w1[k];
+        }
+        const int16_t* e = g_lab_lut + 3 * ((idx[0] * LAB_LUT_DIM + idx[1]) * LAB_LUT_DIM + idx[2]);
+        acc[0] += e[0] * wgt; acc[1] += e[1] * wgt; acc[2] += e[2] * wgt;
+    }
+    for (int k = 0; k < 3; ++k) acc[k] = (acc[k] + (1 << (3 * TRI_SHIFT - 1))) >> (3 * TRI_SHIFT);      /* CV_DESCALE */
+    o[0] = (float)acc[0] * (1.0f / LAB_BASE) * 100.0f;
+    o[1] = (float)acc[1] * (1.0f / LAB_BASE) * 256.0f - 128.0f;
+    o[2] = (float)acc[2] * (1.0f / LAB_BASE) * 256.0f - 128.0f;
+}
 void lvmo_bgr2lab(const float* src, int npix, float* dst) {
     lab_init();
+    if (g_lab_use_lut) {
+        lab_lut_init();
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < npix; ++i) {
+            float o[3];
+            bgr2lab_lut_px(src[i * 3], src[i * 3 + 1], src[i * 3 + 2], o);
+            dst[i * 3] = o[0]; dst[i * 3 + 1] = o[1]; dst[i * 3 + 2] = o[2];
+        }
+        return;
+    }
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < npix; ++i) {
         float o[3];

@@ -100,6 +100,10 @@ void lvmo_bgr2gray_u8(const uint8_t* src, int npix, uint8_t* dst);
 typedef struct lvmo_area_tab { int si, di; float alpha; } lvmo_area_tab;
 int  lvmo_area_table(int ssize, int dsize, double scale, lvmo_area_tab* tab, int cap);
 
+/* Forward Lab flavour of the oracle: 0 (default) analytic float path, 1 OpenCV 4's default trilinear-LUT path
+ * (RGB2Labfloat::useInterpolation) -- quantification only, see lvm_oracle.c */
+void lvmo_set_lab_lut(int on);
+
 /* Exporter::compose (export/Exporter.cpp:53-88) without the text overlay */
 int lvmo_compose_geometry(int split, int ow, int oh, int pw, int ph, int* cw, int* ch);
 int lvmo_compose(int split, const uint8_t* orig, int ow, int oh, int och, ptrdiff_t ostride, const uint8_t* proc, int pw, int ph,

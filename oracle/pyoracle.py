@@ -88,6 +88,8 @@ def lib():
         L.lvmo_resize_area_u8.restype = None
         L.lvmo_bgr2gray_u8.argtypes = [_u8p, C.c_int, _u8p]
         L.lvmo_bgr2gray_u8.restype = None
+        L.lvmo_set_lab_lut.argtypes = [C.c_int]
+        L.lvmo_set_lab_lut.restype = None
         L.lvmo_compose_geometry.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip]
         L.lvmo_compose.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                    C.c_ssize_t, C.c_void_p, C.c_ssize_t]
