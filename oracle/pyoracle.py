@@ -345,3 +345,53 @@ def compose(split, orig, proc):
     lib().lvmo_compose(split, orig.ctypes.data if orig is not None else None, ow, oh, och, ow * och, proc.ctypes.data, pw, ph, pch, pw * pch,
                        canvas.ctypes.data, cw.value * 3)
     return canvas
+
+
+class RefOracle:
+    """The REAL reference stage (oracle/_ref/libref_magnify.so: the reference's own sources + oracle/ref_driver.cpp),
+    same interface as Oracle.  Only exists where OpenCV 4 was found at build time; available() says so."""
+
+    _lib = None
+
+    @classmethod
+    def available(cls):
+        if cls._lib is None:
+            so = os.path.join(_HERE, "_ref", "libref_magnify.so")
+            if not os.path.exists(so):
+                return False
+            try:
+                R = C.CDLL(so)
+            except OSError:
+                return False
+            R.ref_create.restype = C.c_void_p
+            R.ref_destroy.argtypes = [C.c_void_p]
+            R.ref_reset.argtypes = [C.c_void_p]
+            R.ref_process.argtypes = [C.c_void_p, C.POINTER(Params), _u8p, C.c_int, C.c_int, C.c_int, C.c_ssize_t, _u8p, C.c_ssize_t,
+                                      C.POINTER(C.c_int)]
+            cls._lib = R
+        return True
+
+    def __init__(self):
+        if not self.available():
+            raise RuntimeError("oracle/_ref/libref_magnify.so is not built (no OpenCV 4 on the build host)")
+        self._c = self._lib.ref_create()
+
+    def close(self):
+        if getattr(self, "_c", None):
+            self._lib.ref_destroy(self._c)
+            self._c = None
+
+    __del__ = close
+
+    def reset(self):
+        self._lib.ref_reset(self._c)
+
+    def process(self, frame, params):
+        frame = np.ascontiguousarray(frame)
+        h, w = frame.shape[:2]
+        ch = 1 if frame.ndim == 2 else frame.shape[2]
+        out = np.empty_like(frame)
+        produced = C.c_int(0)
+        if self._lib.ref_process(self._c, C.byref(params), frame.reshape(-1), w, h, ch, w * ch, out.reshape(-1), w * ch, C.byref(produced)) != 0:
+            raise RuntimeError("the reference stage threw")
+        return (out, True) if produced.value else (frame, False)
