@@ -50,6 +50,11 @@ __device__ __forceinline__ uint32_t pack_u8x4(float v0, float v1, float v2, floa
     return __builtin_amdgcn_cvt_pk_u8_f32(v3, 3, r);
 }
 
+// Whole-wave shifts by one lane (DPP wave_shr:1 / wave_shl:1 cross all 64 lanes on gfx950, tools/probe_isa.hip):
+// lane i receives lane i - 1's (shr) / lane i + 1's (shl) value; lane 0 / lane 63 receive 0.
+__device__ __forceinline__ float dpp_shr1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }
+__device__ __forceinline__ float dpp_shl1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }
+
 // Lab conversion tables/coefficients (reference: MagnifyCore.hpp:90,152,219,275 call
 // cv::cvtColor COLOR_BGR2Lab / COLOR_Lab2BGR on float [0,1]; OpenCV 4 color_lab.cpp float path).
 struct LabCoef {

@@ -276,11 +276,6 @@ __global__ __launch_bounds__(256) void k_pyr_up_rows(const float* __restrict__ s
 // lanes 0 and 63 only feed their neighbours.  Groups outside the image are the REFLECT_101 mirror of the
 // edge group, obtained by loading that group and swapping its pixels.  The horizontal results slide down
 // the strip in a 5-row register window.  Only the gamma table lives in LDS.
-__device__ __forceinline__ float dpp_shr1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }
-__device__ __forceinline__ float dpp_shl1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }
-// the same with a fallback for the lane that has no source lane (lane 0 / lane 63 keep `old`)
-__device__ __forceinline__ float dpp_shr1_old(float old, float v) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x138, 0xf, 0xf, false)); }
-__device__ __forceinline__ float dpp_shl1_old(float old, float v) { return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), 0x130, 0xf, 0xf, false)); }
 constexpr int D0R_THREADS = 256, D0R_OUT = 124;
 // Strip height for k_down0_rows: a strip of r output rows converts 2r + 3 source rows, and the launch takes as
 // long as the busiest SIMD (1024 of them on MI355X) has strips -- minimise ceil(strips / 1024) * (2r + 3).

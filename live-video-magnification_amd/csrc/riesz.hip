@@ -103,11 +103,20 @@ constexpr int SH = 4;                      // halo of the 9x9 kernels
 // thread needs per kernel row are three (four) aligned 128-bit LDS reads.  Each output keeps its own
 // accumulator and receives its 81 taps in row-major order (filter2D's order).
 constexpr int CW = 64, CH = 16, CSW = CW + 2 * SH, CSH = CH + 2 * SH;
+// Row pitch of the staged tiles.  A wave's 128-bit reads come from lanes 0-15 in one tile row and lanes 16-31, 32-47,
+// 48-63 two rows further down each; ds_read_b128 serves 16 lanes at a time drawn from two such 16-lane rows
+// (MI355X_MICROARCH.md, LDS), so it is conflict-free iff rows two apart start on the same bank: 2 * pitch = 0 (mod 64
+// dwords).  72 (= tile + halo) put 55-66 % of the LDS cycles of these kernels into bank conflicts (profiles/).
+#ifndef LVM_RZ_PITCH
+#define LVM_RZ_PITCH 96
+#endif
+constexpr int CSP = LVM_RZ_PITCH;
+static_assert(CSP >= CSW && CSP % 4 == 0, "pitch");
 
 // 4 adjacent outputs (lx..lx+3, ly), lx % 4 == 0.  Fully unrolled: the 81 coefficients become
 // immediates and zero taps vanish (measured faster than a rolled row loop with scalar coefficient
 // loads, despite the higher register count).
-__device__ __forceinline__ void conv9x4(const float (&s)[CSH][CSW], int lx, int ly, const float* k, float kscale, float (&o)[4]) {
+__device__ __forceinline__ void conv9x4(const float (&s)[CSH][CSP], int lx, int ly, const float* k, float kscale, float (&o)[4]) {
     o[0] = o[1] = o[2] = o[3] = 0.f;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
@@ -125,7 +134,7 @@ __device__ __forceinline__ void conv9x4(const float (&s)[CSH][CSW], int lx, int 
         }
     }
 }
-__device__ __forceinline__ void stage_reflect(float (&s)[CSH][CSW], const float* __restrict__ src, int w, int h, int x0, int y0) {
+__device__ __forceinline__ void stage_reflect(float (&s)[CSH][CSP], const float* __restrict__ src, int w, int h, int x0, int y0) {
     for (int i = threadIdx.x; i < CSH * CSW; i += 256) {
         const int ly = i / CSW, lx = i - ly * CSW;
         s[ly][lx] = src[(size_t)reflect101(y0 - SH + ly, h) * w + reflect101(x0 - SH + lx, w)];
@@ -134,7 +143,7 @@ __device__ __forceinline__ void stage_reflect(float (&s)[CSH][CSW], const float*
 
 __global__ __launch_bounds__(256) void k_rz_split(const float* __restrict__ oct, int w, int h,
                                                      float* __restrict__ band, float* __restrict__ next, int nw, int nh) {
-    __shared__ __attribute__((aligned(16))) float s[CSH][CSW];
+    __shared__ __attribute__((aligned(16))) float s[CSH][CSP];
     const int x0 = blockIdx.x * CW, y0 = blockIdx.y * CH;
     stage_reflect(s, oct + (size_t)blockIdx.z * w * h, w, h, x0, y0);
     __syncthreads();
@@ -185,7 +194,7 @@ __global__ __launch_bounds__(256) void k_rz_split(const float* __restrict__ oct,
 constexpr int C2H = 32, C2SH = C2H + 2 * SH;
 __global__ __launch_bounds__(256) void k_rz_split2(const float* __restrict__ oct, int w, int h,
                                                       float* __restrict__ band, float* __restrict__ next, int nw, int nh) {
-    __shared__ __attribute__((aligned(16))) float s[C2SH][CSW];
+    __shared__ __attribute__((aligned(16))) float s[C2SH][CSP];
     const int x0 = blockIdx.x * CW, y0 = blockIdx.y * C2H;
     const float* src = oct + (size_t)blockIdx.z * w * h;
     const bool interior = x0 - SH >= 0 && x0 + CW + SH <= w && y0 - SH >= 0 && y0 + C2H + SH <= h;
@@ -266,6 +275,119 @@ __global__ __launch_bounds__(256) void k_rz_split2(const float* __restrict__ oct
             if (gy + 2 < h) d[nw] = a1;
         }
     }
+}
+
+// ---- the same split as WAVE STRIPS: no LDS, no barrier ------------------------------------------------------------
+// The tiled kernels above keep the LDS pipe 50-70 % busy (every fma operand is an LDS read) at 30-45 % VALU and two to
+// four waves per SIMD: neither pipe saturates.  Here a wave owns a strip of 248 columns x `rows` output rows of one
+// plane and walks down the INPUT rows: lane i holds the four columns 4g .. 4g+3 (g = 62 tx - 1 + i) of the current
+// input row -- one 16-byte load -- and gets the four columns left and right of them from its neighbours (eight DPP
+// wave shifts; lanes 0 and 63 only feed).  An input row y contributes kernel row i to output row y + 4 - i, so nine
+// partial output rows live in registers (9 x 4 accumulators for the high-pass, 9 x 2 for the low-pass at even
+// pixels); the row that just received kernel row 8 is complete, is stored and its slot cleared for the row nine
+// further down.  Every output still receives its 81 taps in row-major order (kernel rows arrive top to bottom, taps
+// left to right within a row): the same fma chain as conv9x4, bit for bit.  The loop is unrolled over the nine slot
+// phases so that every accumulator index is a compile-time constant.
+// REFLECT_101: rows by reflecting the row index of the load; columns at the image edge from the lane's own and its
+// inner neighbour's values (columns -4..-1 are columns 4, 3, 2, 1; columns w..w+3 are w-2, w-3, w-4, w-5).
+constexpr int SR_THREADS = 256, SR_OWN = 62;
+template <int PHASE>
+__device__ __forceinline__ void split_row_taps(const float (&v)[12], float (&hp)[9][4], float (&lp)[9][2], bool even_row) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int slot = (PHASE + 9 - i) % 9;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const float kv = kHp9[i * 9 + j];
+            if (kv != 0.f) {
+                hp[slot][0] = __builtin_fmaf(kv, v[j], hp[slot][0]); hp[slot][1] = __builtin_fmaf(kv, v[j + 1], hp[slot][1]);
+                hp[slot][2] = __builtin_fmaf(kv, v[j + 2], hp[slot][2]); hp[slot][3] = __builtin_fmaf(kv, v[j + 3], hp[slot][3]);
+            }
+        }
+    }
+    // low-pass only at even output rows: kernel rows of this input row's parity
+    if (even_row) {
+#pragma unroll
+        for (int i = 0; i < 9; i += 2) {
+            const int slot = (PHASE + 9 - i) % 9;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const float kv = kLp9[i * 9 + j] * 2.0f;
+                if (kv != 0.f) { lp[slot][0] = __builtin_fmaf(kv, v[j], lp[slot][0]); lp[slot][1] = __builtin_fmaf(kv, v[j + 2], lp[slot][1]); }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 1; i < 9; i += 2) {
+            const int slot = (PHASE + 9 - i) % 9;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                const float kv = kLp9[i * 9 + j] * 2.0f;
+                if (kv != 0.f) { lp[slot][0] = __builtin_fmaf(kv, v[j], lp[slot][0]); lp[slot][1] = __builtin_fmaf(kv, v[j + 2], lp[slot][1]); }
+            }
+        }
+    }
+}
+// columns c-4 .. c+7 of one row from the lane's own four and its neighbours' (first / last: the lane owns the image's
+// first / last column group)
+__device__ __forceinline__ void row12(const float4 v, bool first, bool last, float (&o)[12]) {
+    float4 L, R;
+    L.x = dpp_shr1(v.x); L.y = dpp_shr1(v.y); L.z = dpp_shr1(v.z); L.w = dpp_shr1(v.w);
+    R.x = dpp_shl1(v.x); R.y = dpp_shl1(v.y); R.z = dpp_shl1(v.z); R.w = dpp_shl1(v.w);
+    const float4 Lf = make_float4(R.x, v.w, v.z, v.y), Rl = make_float4(v.z, v.y, v.x, L.w);
+    L.x = sel(first, Lf.x, L.x); L.y = sel(first, Lf.y, L.y); L.z = sel(first, Lf.z, L.z); L.w = sel(first, Lf.w, L.w);
+    R.x = sel(last, Rl.x, R.x); R.y = sel(last, Rl.y, R.y); R.z = sel(last, Rl.z, R.z); R.w = sel(last, Rl.w, R.w);
+    o[0] = L.x; o[1] = L.y; o[2] = L.z; o[3] = L.w; o[4] = v.x; o[5] = v.y; o[6] = v.z; o[7] = v.w;
+    o[8] = R.x; o[9] = R.y; o[10] = R.z; o[11] = R.w;
+}
+__global__ __launch_bounds__(SR_THREADS) void k_rz_split_rows(const float* __restrict__ oct, int w, int h, float* __restrict__ band,
+                                                                  float* __restrict__ next, int nw, int nh, int strips_x, int strips_y,
+                                                                  int ntasks, int rows) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int task = blockIdx.x * (SR_THREADS / 64) + wave;
+    if (task >= ntasks) return;
+    const int z = task / (strips_x * strips_y);
+    const int r = task - z * (strips_x * strips_y);
+    const int ty = r / strips_x, tx = r - ty * strips_x;
+    const int G = w >> 2;                                           // w % 4 == 0, G >= 2
+    const int g = tx * SR_OWN - 1 + lane;
+    const int gl = g < 0 ? 0 : (g > G - 1 ? G - 1 : g);
+    const bool owner = lane >= 1 && lane <= SR_OWN && g >= 0 && g < G;
+    const bool first = g == 0, last = g == G - 1;
+    const float* src = oct + (size_t)z * w * h + 4 * gl;
+    float* bp = band + (size_t)z * w * h + 4 * gl;
+    float* np = next + (size_t)z * nw * nh + 2 * gl;
+    const int y0 = ty * rows;                                       // rows is even: the strip starts on an even row
+    const int yend = y0 + rows < h ? y0 + rows : h;
+    const int nq = yend - y0 + 8;                                   // input rows y0 - 4 .. yend + 3
+    float hp[9][4], lp[9][2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { hp[k][0] = hp[k][1] = hp[k][2] = hp[k][3] = 0.f; lp[k][0] = lp[k][1] = 0.f; }
+    float4 nxt = *reinterpret_cast<const float4*>(src + (size_t)reflect101(y0 - 4, h) * w);
+    int q = 0;
+#define LVM_SPLIT_STEP(P)                                                                                          \
+    if (q < nq) {                                                                                                   \
+        const float4 cur = nxt;                                                                                     \
+        if (q + 1 < nq) nxt = *reinterpret_cast<const float4*>(src + (size_t)reflect101(y0 - 3 + q, h) * w);       \
+        float v[12];                                                                                                \
+        row12(cur, first, last, v);                                                                                 \
+        split_row_taps<P>(v, hp, lp, (q & 1) == 0);                 /* input row y0 - 4 + q, y0 even */             \
+        constexpr int E = (P + 1) % 9;                              /* output row y0 - 8 + q is complete */         \
+        if (q >= 8) {                                               /* (rows above the strip: cleared, not stored) */ \
+            const int o = y0 - 8 + q;                                                                               \
+            if (owner) {                                                                                            \
+                *reinterpret_cast<float4*>(bp + (size_t)o * w) = make_float4(hp[E][0], hp[E][1], hp[E][2], hp[E][3]);   /* RieszPyramid.cpp:227 */ \
+                if ((o & 1) == 0) *reinterpret_cast<float2*>(np + (size_t)(o >> 1) * nw) = make_float2(lp[E][0], lp[E][1]);   /* :232-234, subsample :254-278 */ \
+            }                                                                                                       \
+        }                                                                                                           \
+        hp[E][0] = hp[E][1] = hp[E][2] = hp[E][3] = 0.f; lp[E][0] = lp[E][1] = 0.f;                                 \
+        ++q;                                                                                                        \
+    }
+    while (q < nq) {
+        LVM_SPLIT_STEP(0) LVM_SPLIT_STEP(1) LVM_SPLIT_STEP(2) LVM_SPLIT_STEP(3) LVM_SPLIT_STEP(4)
+        LVM_SPLIT_STEP(5) LVM_SPLIT_STEP(6) LVM_SPLIT_STEP(7) LVM_SPLIT_STEP(8)
+    }
+#undef LVM_SPLIT_STEP
 }
 
 // ---- phase difference + amplitude + temporal filters -----------------------------------------
@@ -618,7 +740,7 @@ __global__ __launch_bounds__(256) void k_rz_blur_amp4(BlurArgs aa) {
 // res_l = filter2D(zero-injected nearest-upsample of res_{l+1}, 2 lp9) + filter2D(bandA_l, hp9).
 // The zero-injected image is non-zero only at even (x,y) (REFLECT_101 keeps parity), so only taps
 // with j == x and i == y (mod 2) are visited -- in the same row-major order as the full sum.
-__device__ __forceinline__ void collapse_stage(float (&sb)[CSH][CSW], float (&su)[CSH][CSW],
+__device__ __forceinline__ void collapse_stage(float (&sb)[CSH][CSP], float (&su)[CSH][CSP],
                                                const float* __restrict__ bandA, const float* __restrict__ resn,
                                                int w, int h, int nw, int nh, int x0, int y0) {
     // Interior tiles of planes whose width is a multiple of 4 need no reflection: the band tile is 432 aligned
@@ -659,7 +781,7 @@ __device__ __forceinline__ void collapse_stage(float (&sb)[CSH][CSW], float (&su
 // polyphase low-pass of the zero-injected tile for the 4 outputs; ODD = parity of the image row (the kernel rows
 // i == gy (mod 2) are the only ones that meet non-zero samples: 0,2,4,6,8 or 1,3,5,7)
 template <bool ODD>
-__device__ __forceinline__ void collapse_lp4(const float (&su)[CSH][CSW], int lx, int ly, float (&lp)[4]) {
+__device__ __forceinline__ void collapse_lp4(const float (&su)[CSH][CSP], int lx, int ly, float (&lp)[4]) {
     lp[0] = lp[1] = lp[2] = lp[3] = 0.f;
 #pragma unroll
     for (int ii = 0; ii < (ODD ? 4 : 5); ++ii) {
@@ -679,7 +801,7 @@ __device__ __forceinline__ void collapse_lp4(const float (&su)[CSH][CSW], int lx
 // The row parity is uniform across a wave (collapse_row() below maps waves 0-1 to the even rows of the tile
 // and waves 2-3 to the odd ones), so the parity test is a scalar branch and every tap weight an immediate.
 __device__ __forceinline__ int collapse_row() { return ((threadIdx.x >> 4) & 7) * 2 + (threadIdx.x >> 7); }
-__device__ __forceinline__ void collapse_px4(const float (&sb)[CSH][CSW], const float (&su)[CSH][CSW],
+__device__ __forceinline__ void collapse_px4(const float (&sb)[CSH][CSP], const float (&su)[CSH][CSP],
                                              int lx, int ly, int gy, float (&o)[4]) {
     float lp[4];
     if (__builtin_amdgcn_readfirstlane(gy & 1)) collapse_lp4<true>(su, lx, ly, lp);
@@ -693,8 +815,8 @@ __device__ __forceinline__ void collapse_px4(const float (&sb)[CSH][CSW], const 
 // (a 64 x 32 / 4 x 2 variant of this kernel, like k_rz_split2, needs 300 registers and measured 48 us against 29 us)
 __global__ __launch_bounds__(256) void k_rz_collapse(const float* __restrict__ bandA, const float* __restrict__ resn,
                                                      float* __restrict__ res, int w, int h, int nw, int nh) {
-    __shared__ __attribute__((aligned(16))) float sb[CSH][CSW];
-    __shared__ __attribute__((aligned(16))) float su[CSH][CSW];
+    __shared__ __attribute__((aligned(16))) float sb[CSH][CSP];
+    __shared__ __attribute__((aligned(16))) float su[CSH][CSP];
     const int x0 = blockIdx.x * CW, y0 = blockIdx.y * CH;
     const size_t pl = (size_t)blockIdx.z * w * h, pn = (size_t)blockIdx.z * nw * nh;
     collapse_stage(sb, su, bandA + pl, resn + pn, w, h, nw, nh, x0, y0);
@@ -724,8 +846,8 @@ __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in
                                                   float* __restrict__ dbg) {
     __shared__ __attribute__((aligned(16))) float s_igt[4096];
     __shared__ float s_gam[256];
-    __shared__ __attribute__((aligned(16))) float sb[CSH][CSW];
-    __shared__ __attribute__((aligned(16))) float su[CSH][CSW];
+    __shared__ __attribute__((aligned(16))) float sb[CSH][CSP];
+    __shared__ __attribute__((aligned(16))) float su[CSH][CSP];
     load_invgamma(s_igt, lab.invgamma);
     load_gamma_u8(s_gam, lab.gamma_u8);
     __syncthreads();
@@ -809,6 +931,8 @@ struct RieszState : ModeState {
     int tcap = 0; float* tarena = nullptr;
     float* ft[kMaxLevels + 1][F_ALL_N] = {}; float* oct_t[kMaxLevels + 1] = {}; float* res_t[kMaxLevels + 1] = {};   // per band level: band,P,R1p,R2p,phc,phs,lo0c,lo0s,lo1c,lo1s,hi0c,hi0s,hi1c,hi1s,amp,tc,ts,bandA
     bool inited = false;
+    bool split_rows = true;          // LDS-free wave-strip split (LVM_RZ_SPLIT_ROWS=0: the tiled kernels) ...
+    long split_rows_min = 0;         // ... for launches of at least this many plane-pixels (LVM_RZ_SPLIT_ROWS_MIN)
     bool split2 = true;              // 64 x 32 tiles with 4 x 2 outputs per thread in the 9x9 split (LVM_RZ_SPLIT2=0: k_rz_split)
     bool blur4 = true;               // register-blocked Gaussian/amplify kernel on the large levels (LVM_RZ_BLUR4=0: scalar kernel everywhere)
     double lo_freq = 0, hi_freq = 0, fps = 0;
@@ -866,6 +990,17 @@ static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B,
     }
     for (int l = 0; l < nb; ++l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
+        if (st->split_rows && a.w % 4 == 0 && a.w >= 8 && (long)a.n * NZ >= st->split_rows_min) {
+            // wave strips (no LDS); strips of 64 output rows while the launch still has >= 4096 of them
+            const int sx = (a.w / 4 + SR_OWN - 1) / SR_OWN;
+            int rows = 64;
+            while (rows > 8 && (long)sx * ((a.h + rows - 1) / rows) * NZ < 4096) rows >>= 1;
+            const int sy = (a.h + rows - 1) / rows;
+            const long ntasks = (long)sx * sy * NZ;
+            LVM_LAUNCH(c, LName("rz_split", l), k_rz_split_rows, dim3((unsigned)((ntasks + SR_THREADS / 64 - 1) / (SR_THREADS / 64))), dim3(SR_THREADS), s,
+                       (const float*)B.oct[l], a.w, a.h, B.pf[l][F_BAND], B.oct[l + 1], b.w, b.h, sx, sy, (int)ntasks, rows);
+            continue;
+        }
         if (st->split2 && a.w % 4 == 0) {
             const dim3 grid2((a.w + CW - 1) / CW, (a.h + C2H - 1) / C2H, NZ);
             LVM_LAUNCH(c, LName("rz_split", l), k_rz_split2, grid2, blk, s, (const float*)B.oct[l], a.w, a.h, B.pf[l][F_BAND], B.oct[l + 1], b.w, b.h);
@@ -966,6 +1101,8 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         st = new RieszState();
         if (const char* e = std::getenv("LVM_RZ_BLUR4")) st->blur4 = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_RZ_SPLIT2")) st->split2 = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_RZ_SPLIT_ROWS")) st->split_rows = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_RZ_SPLIT_ROWS_MIN")) st->split_rows_min = std::atol(e);
         c->state = st;
         int rc = riesz_alloc(c, st, io.w, io.h, levels);
         if (rc == LVM_OK && c->max_frames > 1) rc = riesz_reserve_frames(c, st, c->max_frames, s);

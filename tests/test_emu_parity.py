@@ -433,3 +433,11 @@ def test_fast_final_kernel_strips_and_shortcut_paths(lvm, po, emu, w, h, levels)
             return f
     worst = run_pair(lvm, po, emu, Patched(), pk, 7, 1e-4, exact=False, exact_lab=False, u8_frac=0.998)
     print("fast final kernel", (w, h, levels), worst)
+
+
+@pytest.mark.parametrize("w,h,levels", [(520, 70, 3), (256, 41, 2), (1000, 24, 2)])
+def test_riesz_emu_wave_strip_stencils(lvm, po, emu, w, h, levels):
+    """The LDS-free 9x9 strip kernels: several 248-column strips per row (a full one, a partial one, a strip whose last
+    lane owns the image's last column group), strips cut by the image height, odd heights, bit-exact against the oracle."""
+    ck, pk = lvm.synth.config(2, (w, h, levels))
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0, exact=True)
