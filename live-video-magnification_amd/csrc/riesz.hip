@@ -408,10 +408,12 @@ struct PhaseLv {                       // one band level
 };
 // All band levels in ONE launch: the levels are independent in this stage, and the small ones are
 // pure launch latency on their own.
+struct SdF { float hi, lo; };           // a float64 coefficient as the sum of two floats
 struct PhaseArgs {
     PhaseLv lv[kMaxBands];
     int nlv;
     double la1, la2, lb0, lb1, lb2, ha1, ha2, hb0, hb1, hb2;
+    SdF fla1, fla2, flb0, flb1, flb2, fha1, fha2, fhb0, fhb1, fhb2;      // the same coefficients as float pairs (default flavour)
     int mode;                          // 0 = normal, 1 = seed with zero Riesz pair (init), 2 = seed with actual pair
     int nt;                            // frames handled by this launch, in temporal order
 };
@@ -424,6 +426,10 @@ __device__ __forceinline__ float arc_cos(float x) {
     return acosf(x);
 }
 __device__ __forceinline__ float mul_sd(float x, double s) { return (float)((double)x * s); }
+// The same product for the default flavour without the float64 unit: s = hi + lo (two floats, exact to 2^-48), x * hi is
+// exact inside the fma, so fma(x, hi, x * lo) is the float nearest to x * s except in double-rounding ties (~2^-24 of
+// the cases, one ulp).  Three conversions / f64 operations become two f32 ones, 20 times per pixel and frame.
+__device__ __forceinline__ float mul_sd(float x, SdF s) { return __builtin_fmaf(x, s.hi, x * s.lo); }
 
 // With nt > 1 the workgroup walks over nt consecutive frames: the 13 state values of a pixel (prior
 // band + Riesz pair, accumulated phase, 8 filter registers) stay in registers and move through HBM
@@ -515,18 +521,20 @@ __global__ __launch_bounds__(256) void k_rz_phase(PhaseArgs aa) {
         // IIRTemporalFilter for the low and the high cutoff (TemporalFilter.cpp:343-350); both keep
         // their own copy of the accumulated phase in the reference, the copies are always equal.
         phc = phc + dc; phs = phs + ds;
-        const float ylc = mul_sd(phc, aa.lb0) + lo0c;
-        const float yls = mul_sd(phs, aa.lb0) + lo0s;
-        lo0c = (mul_sd(phc, aa.lb1) + lo1c) - mul_sd(ylc, aa.la1);
-        lo0s = (mul_sd(phs, aa.lb1) + lo1s) - mul_sd(yls, aa.la1);
-        lo1c = mul_sd(phc, aa.lb2) - mul_sd(ylc, aa.la2);
-        lo1s = mul_sd(phs, aa.lb2) - mul_sd(yls, aa.la2);
-        const float yhc = mul_sd(phc, aa.hb0) + hi0c;
-        const float yhs = mul_sd(phs, aa.hb0) + hi0s;
-        hi0c = (mul_sd(phc, aa.hb1) + hi1c) - mul_sd(yhc, aa.ha1);
-        hi0s = (mul_sd(phs, aa.hb1) + hi1s) - mul_sd(yhs, aa.ha1);
-        hi1c = mul_sd(phc, aa.hb2) - mul_sd(yhc, aa.ha2);
-        hi1s = mul_sd(phs, aa.hb2) - mul_sd(yhs, aa.ha2);
+#define MSD(x, c) (EXACT ? mul_sd((x), aa.c) : mul_sd((x), aa.f##c))
+        const float ylc = MSD(phc, lb0) + lo0c;
+        const float yls = MSD(phs, lb0) + lo0s;
+        lo0c = (MSD(phc, lb1) + lo1c) - MSD(ylc, la1);
+        lo0s = (MSD(phs, lb1) + lo1s) - MSD(yls, la1);
+        lo1c = MSD(phc, lb2) - MSD(ylc, la2);
+        lo1s = MSD(phs, lb2) - MSD(yls, la2);
+        const float yhc = MSD(phc, hb0) + hi0c;
+        const float yhs = MSD(phs, hb0) + hi0s;
+        hi0c = (MSD(phc, hb1) + hi1c) - MSD(yhc, ha1);
+        hi0s = (MSD(phs, hb1) + hi1s) - MSD(yhs, ha1);
+        hi1c = MSD(phc, hb2) - MSD(yhc, ha2);
+        hi1s = MSD(phs, hb2) - MSD(yhs, ha2);
+#undef MSD
         a.amp[fidx] = am;
         a.tc[fidx] = (yhc - ylc) * am;                                     // RieszPyramid.cpp:118-120
         a.ts[fidx] = (yhs - yls) * am;
@@ -932,7 +940,7 @@ struct RieszState : ModeState {
     float* ft[kMaxLevels + 1][F_ALL_N] = {}; float* oct_t[kMaxLevels + 1] = {}; float* res_t[kMaxLevels + 1] = {};   // per band level: band,P,R1p,R2p,phc,phs,lo0c,lo0s,lo1c,lo1s,hi0c,hi0s,hi1c,hi1s,amp,tc,ts,bandA
     bool inited = false;
     bool split_rows = true;          // LDS-free wave-strip split (LVM_RZ_SPLIT_ROWS=0: the tiled kernels) ...
-    long split_rows_min = 0;         // ... for launches of at least this many plane-pixels (LVM_RZ_SPLIT_ROWS_MIN)
+    long split_rows_min = 1L << 25;  // ... for launches of at least this many plane-pixels (LVM_RZ_SPLIT_ROWS_MIN); below, the tiled kernels measure equal or faster
     bool split2 = true;              // 64 x 32 tiles with 4 x 2 outputs per thread in the 9x9 split (LVM_RZ_SPLIT2=0: k_rz_split)
     bool blur4 = true;               // register-blocked Gaussian/amplify kernel on the large levels (LVM_RZ_BLUR4=0: scalar kernel everywhere)
     double lo_freq = 0, hi_freq = 0, fps = 0;
@@ -1018,6 +1026,9 @@ static void rz_phase(Ctx* c, RieszState* st, const RzBufs& B, int mode, hipStrea
     a.nlv = nb; a.mode = mode; a.nt = B.nt;
     a.la1 = st->la[1]; a.la2 = st->la[2]; a.lb0 = st->lb[0]; a.lb1 = st->lb[1]; a.lb2 = st->lb[2];
     a.ha1 = st->ha[1]; a.ha2 = st->ha[2]; a.hb0 = st->hb[0]; a.hb1 = st->hb[1]; a.hb2 = st->hb[2];
+    auto split = [](double v) { SdF r; r.hi = (float)v; r.lo = (float)(v - (double)r.hi); return r; };
+    a.fla1 = split(a.la1); a.fla2 = split(a.la2); a.flb0 = split(a.lb0); a.flb1 = split(a.lb1); a.flb2 = split(a.lb2);
+    a.fha1 = split(a.ha1); a.fha2 = split(a.ha2); a.fhb0 = split(a.hb0); a.fhb1 = split(a.hb1); a.fhb2 = split(a.hb2);
     int blocks = 0;
     for (int l = 0; l < nb; ++l) {
         PhaseLv& v = a.lv[l];
