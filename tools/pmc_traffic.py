@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch from the FETCH_SIZE / WRITE_SIZE passes of tools/pmc.sh -> profiles/rNN_pmc_traffic_<mode>.json
+(the file bench.py reads for `roofline.traffic`).  Usage: pmc_traffic.py MODE KEY DIR_P0 DIR_FETCH DIR_WRITE > out.json
+Counter values are KB summed over the TCC instances; per-launch averages over the launches of the steady-state grid
+(the largest launches of each symbol)."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+NAMES = {  # kernel symbol prefix -> bench.py report name
+    "k_lap_final_v4<true, false>": "lap_final", "k_down0_rows<true, false>": "lap_down0", "k_down0_rows<false, false>": "col_down0",
+    "k_lap_up<false, 1>": "lap_up_l1", "k_lap_iir_levels": "lap_iir", "k_lap_collapse": "lap_collapse",
+    "k_rz_final<true, false, true>": "rz_final", "k_rz_blur_amp4<false>": "rz_blur_amp", "k_rz_phase<false>": "rz_phase",
+    "k_rz_lab4": "rz_lab", "k_rz_split_rows": "rz_split_l0", "k_col_out_rows<true>": "col_out", "k_col_out_rows<false>": "col_minmax",
+}
+
+
+def short(name):
+    name = name.split("(")[0]
+    for pre in ("void lvm::", "lvm::"):
+        if name.startswith(pre):
+            name = name[len(pre):]
+    return name
+
+
+def read(d, counter):
+    per = defaultdict(float)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                per[(r["Dispatch_Id"], short(r["Kernel_Name"]))] += float(r["Counter_Value"])
+    out = defaultdict(list)
+    for (_, k), v in per.items():
+        out[k].append(v)
+    return out
+
+
+def main():
+    mode, key, p0, pf, pw = sys.argv[1:6]
+    dur = defaultdict(list)
+    for f in glob.glob(os.path.join(p0, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    fetch, write = read(pf, "FETCH_SIZE"), read(pw, "WRITE_SIZE")
+    kernels = {}
+    for sym in sorted(dur, key=lambda k: -sum(dur[k])):
+        name = next((v for k, v in NAMES.items() if sym.startswith(k)), None)
+        if name is None or name in kernels:      # (symbols are visited by total time: the steady-state variant comes first)
+            continue
+        big = lambda xs: [x for x in xs if x >= 0.5 * max(xs)] if xs else []   # noqa: E731  (steady-state launches only)
+        d, fe, wr = big(dur[sym]), big(fetch.get(sym, [])), big(write.get(sym, []))
+        if not d:
+            continue
+        fk, wk = (sum(fe) / len(fe) if fe else 0.0), (sum(wr) / len(wr) if wr else 0.0)
+        kernels[name] = {"symbol": sym, "launches": len(d), "rocprof_avg_us": round(sum(d) / len(d), 2), "FETCH_SIZE_KB": round(fk, 1),
+                         "WRITE_SIZE_KB": round(wk, 1), "hbm_bytes_per_launch": int((fk + wk) * 1024)}
+    print(json.dumps({"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no other trace domain) of "
+                              "bench.py on MI355X; KB summed over the TCC instances, averaged over the steady-state launches.  No x2 "
+                              "correction: round 1 calibrated WRITE_SIZE * 1024 against a known byte count (exact) and FETCH_SIZE "
+                              "against the 12-byte-per-lane input reads (within 7 %); the guide's x2 applies to 16 B/lane streaming loads.",
+                      "key": key, "mode": mode, "kernels": kernels}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

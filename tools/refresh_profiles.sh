@@ -1,23 +1,22 @@
 #!/bin/bash
-# Reproduces the files under profiles/ on a GPU box (run from the repo root, e.g. `gpurun -- 'bash tools/refresh_profiles.sh'`):
-# the bench lines of every mode, the rocprofv3 kernel trace of the default (Laplace) bench and the two PMC passes for the
-# HBM traffic (FETCH_SIZE and WRITE_SIZE in separate runs, no other trace domains).  Outputs land in gpurun_out/profiles/;
-# tools/rocpd_stats.py folds the rocpd databases into the text summaries that are committed.
+# Reproduces the round-2 files under profiles/ on a GPU box (`gpurun -- 'bash tools/refresh_profiles.sh'`): the bench
+# lines of every mode (driver-shaped and default), the rocprofv3 kernel-trace summaries and the PMC passes (FETCH_SIZE,
+# WRITE_SIZE, SQ counters: each in its own run, never combined with other trace domains).  Outputs land in
+# gpurun_out/profiles_r02/; copy what is to be judged into profiles/.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$ROOT/gpurun_out/profiles
-mkdir -p $OUT
-cd $ROOT
-timeout 600 python bench.py > $OUT/bench_laplace.json 2> $OUT/bench_laplace.err
-timeout 300 python bench.py --mode riesz > $OUT/bench_riesz.json 2>/dev/null
-timeout 300 python bench.py --mode color > $OUT/bench_color.json 2>/dev/null
-timeout 300 python bench.py --no-cpu-baseline --frames-per-call 1 > $OUT/bench_laplace_perframe.json 2>/dev/null
-timeout 300 python bench.py --no-cpu-baseline --streams 8 > $OUT/bench_laplace_8streams.json 2>/dev/null
-timeout 400 python bench.py --no-cpu-baseline --mode riesz --width 3840 --height 2160 --levels 8 --steps 96 --warmup 32 > $OUT/bench_riesz_4k.json 2>/dev/null
-cd /tmp && export TMPDIR=/tmp
-B="python $ROOT/bench.py --no-cpu-baseline --profile-steps 0 --steps 128 --warmup 64"
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof -o lap -- $B > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/prof -o lap_fetch -- $B > /dev/null 2>&1
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/prof -o lap_write -- $B > /dev/null 2>&1
-cd $ROOT
-python tools/rocpd_stats.py $OUT/prof/lap_results.db | head -20
+O=$ROOT/gpurun_out/profiles_r02; mkdir -p $O; cd $ROOT
+timeout 400 python bench.py --steps 20 --warmup 5 > $O/r02_bench_laplace_driver_shape.json 2> $O/err.txt
+timeout 600 python bench.py > $O/r02_bench_laplace.json 2>> $O/err.txt
+timeout 400 python bench.py --mode riesz --no-subrecords > $O/r02_bench_riesz.json 2>> $O/err.txt
+timeout 400 python bench.py --mode color --no-subrecords > $O/r02_bench_color.json 2>> $O/err.txt
+SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
+SQ2="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
+for m in laplace riesz color; do
+  bash tools/pmc.sh profiles_r02/pmc_$m "--mode $m --steps 128 --warmup 32" "$SQ1" "$SQ2" "FETCH_SIZE" "WRITE_SIZE" > /dev/null 2>&1
+  cp $O/pmc_$m/summary.txt $O/r02_rocprof_${m}_kernels_and_sq_counters.txt
+  cp $O/pmc_$m/p0/t_kernel_stats.csv $O/r02_rocprof_${m}_kernel_stats.csv
+  w=1920; h=1080
+  python tools/pmc_traffic.py $m "$m|${w}x${h}|L6|B1|T32" $O/pmc_$m/p0 $O/pmc_$m/p3 $O/pmc_$m/p4 > $O/r02_pmc_traffic_$m.json
+done
+ls -la $O | head -30
