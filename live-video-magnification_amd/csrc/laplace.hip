@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void k_lap_iir_levels(IirArgs aa) {
     }
 }
 
-constexpr int CT_W = 64, CT_H = 32, kCollapsePool = 3072;
+constexpr int CT_W = 64, CT_H = 32, CP_R = 36, kCollapsePool = 4096;      // CP_R: row pitch of the coarser levels' regions (<= 34 columns)
 struct CollapseArgs { float* cur[kIirLevels]; int w[kIirLevels], h[kIirLevels]; int nlv; };   // index 0 = level 2, nlv - 1 = top live level
 template <int NLV>                                      // number of levels (compile time: the per-level region scalars stay in SGPRs)
 __global__ __launch_bounds__(256) void k_lap_collapse(CollapseArgs a) {
@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void k_lap_collapse(CollapseArgs a) {
                 nx0 = nx0 < 0 ? 0 : nx0; ny0 = ny0 < 0 ? 0 : ny0;
                 nx1 = nx1 > a.w[k] - 1 ? a.w[k] - 1 : nx1; ny1 = ny1 > a.h[k] - 1 ? a.h[k] - 1 : ny1;
                 rx0[k] = nx0; ry0[k] = ny0; rw[k] = nx1 - nx0 + 1; rh[k] = ny1 - ny0 + 1; roff[k] = off;
-                off += rw[k] * rh[k];
+                off += CP_R * rh[k];
                 x0 = nx0; x1 = nx1; y0 = ny0; y1 = ny1;
             }
         }
@@ -451,22 +451,26 @@ __global__ __launch_bounds__(256) void k_lap_collapse(CollapseArgs a) {
     // ONE round of global loads: the m regions of every coarser level into LDS, the tile's own m_2 into registers.
     // Thread (tx, ty) = (tid & 63, tid >> 6) owns column tx of every region and the rows ty, ty + 4, ..: no index
     // division anywhere, the column's border case and (rows advancing by 4) the row parity are fixed per thread.
+    // LDS rows have constant pitches (CP_R for the regions, CT_W for the horizontal-pass rows) and the global
+    // accesses walk row pointers: no per-element integer multiply.
     const int tx = tid & 63, ty = tid >> 6;
     constexpr int NP = CT_H / 4;
     float m2[NP];
     float* g2 = a.cur[0] + z * ((size_t)a.w[0] * a.h[0]);
     const bool in0 = tx < rw[0];
+    const int w0 = a.w[0];
+    float* gp = g2 + ((ry0[0] + ty * NP) * w0 + rx0[0] + tx);          // this thread's first level-2 pixel
 #pragma unroll
     for (int q = 0; q < NP; ++q) {                       // level 2: this thread's rows are the NP consecutive ones ty * NP ..
-        const int y = ty * NP + q;
-        m2[q] = (in0 && y < rh[0]) ? g2[(size_t)(ry0[0] + y) * a.w[0] + rx0[0] + tx] : 0.f;
+        m2[q] = (in0 && ty * NP + q < rh[0]) ? gp[q * w0] : 0.f;
     }
 #pragma unroll
     for (int k = 1; k < NLV; ++k) {
-        const float* src = a.cur[k] + z * ((size_t)a.w[k] * a.h[k]) + (size_t)ry0[k] * a.w[k] + rx0[k];
-        float* dst = pool + roff[k];
+        const int wk = a.w[k];
+        const float* src = a.cur[k] + z * ((size_t)wk * a.h[k]) + ((ry0[k] + ty) * wk + rx0[k] + tx);
+        float* dst = pool + roff[k] + ty * CP_R + tx;
         if (tx < rw[k])
-            for (int y = ty; y < rh[k]; y += 4) dst[y * rw[k] + tx] = src[(size_t)y * a.w[k] + tx];
+            for (int y = ty; y < rh[k]; y += 4) { *dst = *src; dst += 4 * CP_R; src += 4 * wk; }
     }
     __syncthreads();
     float* tmp = pool + toff;
@@ -474,22 +478,25 @@ __global__ __launch_bounds__(256) void k_lap_collapse(CollapseArgs a) {
     for (int k = NLV - 2; k >= 0; --k) {
         const int sw = a.w[k + 1], sh = a.h[k + 1];
         const float* srcn = pool + roff[k + 1];
-        const int nw = rw[k + 1], nh = rh[k + 1], nx0 = rx0[k + 1], ny0 = ry0[k + 1];
+        const int nh = rh[k + 1], nx0 = rx0[k + 1], ny0 = ry0[k + 1];
         const int cw = rw[k], chh = rh[k], cx0 = rx0[k], cy0 = ry0[k];
         const bool inx = tx < cw;
         {   // horizontal pass of the region rows of level k+1 for this thread's column (pyrup_h with the column's case hoisted)
             const int gx = cx0 + tx, i = gx >> 1, li = i - nx0;
             const bool fi = i == 0, la = i == sw - 1, even = (gx & 1) == 0;
             const int lm = fi ? li : li - 1, lp = la ? li : li + 1;
-            if (inx)
+            if (inx) {
+                const float* sr = srcn + ty * CP_R;
+                float* tr = tmp + ty * CT_W + tx;
                 for (int r = ty; r < nh; r += 4) {
-                    const float* sr = srcn + r * nw;
                     const float sm1 = sr[lm], s0 = sr[li], s1 = sr[lp];
                     const float p6 = s0 * 6.f;
                     const float ev = sel(fi, p6 + s1 * 2.f, sel(la, sm1 + s0 * 7.f, sm1 + p6 + s1));
                     const float od = sel(la, s0 * 8.f, (s0 + s1) * 4.f);
-                    tmp[r * cw + tx] = sel(even, ev, od);
+                    *tr = sel(even, ev, od);
+                    sr += 4 * CP_R; tr += 4 * CT_W;
                 }
+            }
         }
         __syncthreads();
         // vertical pass + add: rows ty, ty + 4, .. of the region (cy0 is even or the region starts at an odd row: parity per row)
@@ -499,9 +506,9 @@ __global__ __launch_bounds__(256) void k_lap_collapse(CollapseArgs a) {
                 for (int y = ty; y < chh; y += 4) {
                     const int gy = cy0 + y, j = gy >> 1;
                     const int jm = (j == 0 ? 1 : j - 1) - ny0, jj = j - ny0, jp = (j == sh - 1 ? sh - 1 : j + 1) - ny0;
-                    const float up = ((gy & 1) == 0) ? (tmp[jm * cw + tx] + tmp[jj * cw + tx] * 6.f + tmp[jp * cw + tx]) * (1.f / 64.f)
-                                                     : ((tmp[jj * cw + tx] + tmp[jp * cw + tx]) * 4.f) * (1.f / 64.f);
-                    dst[y * cw + tx] = up + dst[y * cw + tx];                    // SpatialFilter.cpp:58
+                    const float up = ((gy & 1) == 0) ? (tmp[jm * CT_W + tx] + tmp[jj * CT_W + tx] * 6.f + tmp[jp * CT_W + tx]) * (1.f / 64.f)
+                                                     : ((tmp[jj * CT_W + tx] + tmp[jp * CT_W + tx]) * 4.f) * (1.f / 64.f);
+                    dst[y * CP_R + tx] = up + dst[y * CP_R + tx];                // SpatialFilter.cpp:58
                 }
             __syncthreads();
         } else {
@@ -510,18 +517,17 @@ __global__ __launch_bounds__(256) void k_lap_collapse(CollapseArgs a) {
             if (inx) {
                 const int jb = (cy0 >> 1) + ty * (NP / 2);
                 float R[NP / 2 + 2];
-                R[0] = tmp[((jb == 0 ? 1 : jb - 1) - ny0) * cw + tx];
+                R[0] = tmp[((jb == 0 ? 1 : jb - 1) - ny0) * CT_W + tx];
 #pragma unroll
                 for (int i = 0; i <= NP / 2; ++i) {
                     const int jr = jb + i < sh - 1 ? jb + i : sh - 1;
-                    R[i + 1] = tmp[(jr - ny0) * cw + tx];
+                    R[i + 1] = tmp[(jr - ny0) * CT_W + tx];
                 }
-                float* gp = g2 + (size_t)(cy0 + ty * NP) * a.w[0] + cx0 + tx;
 #pragma unroll
                 for (int q = 0; q < NP; ++q) {
                     const int i = q >> 1;                // source row jb + i is R[i + 1]
                     const float up = (q & 1) == 0 ? (R[i] + R[i + 1] * 6.f + R[i + 2]) * (1.f / 64.f) : ((R[i + 1] + R[i + 2]) * 4.f) * (1.f / 64.f);
-                    if (ty * NP + q < chh) gp[(size_t)q * a.w[0]] = up + m2[q];
+                    if (ty * NP + q < chh) gp[q * w0] = up + m2[q];
                 }
             }
         }
