@@ -74,3 +74,76 @@ def test_stream_ids_cover_all_streams():
     for world in (1, 2, 4, 8):
         allids = sum((lvm.sharding.stream_ids(r, world, 2) for r in range(world)), [])
         assert allids == list(range(2 * world))
+
+
+def _worker_product(rank, world, port, q, emu_so):
+    """One rank of the N > 1 path with the PRODUCT in the loop: the library's sources compiled against the HIP emulation
+    (the CPU box has no GPU; the gfx950 build runs the same rank code in tests/test_gpu_schedules.py).  Each rank owns the
+    streams bench.py would give it, runs them through the C ABI in temporal batches, checks them against the oracle
+    for ITS seeds and takes part in the barrier + MAX-reduce timing."""
+    import ctypes
+    import importlib
+    import sys
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    lvm = importlib.import_module("live-video-magnification_amd")
+    from oracle import pyoracle as po
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = lvm.bind(ctypes.CDLL(emu_so))
+    B, T, K = 2, 4, 8
+    ck, pk = lvm.synth.config(0, (64, 48, 3))
+    ids = lvm.sharding.stream_ids(rank, world, B)
+    clips = [lvm.synth.Clip(seed=lvm.sharding.stream_seed(i), **ck) for i in ids]
+    w, h = ck["w"], ck["h"]
+    fb = w * h * 3
+    nfr = 1 + K
+    fin = np.stack([np.stack([c.frame(t) for c in clips]) for t in range(nfr)])          # [frame][stream]
+    fout = np.zeros_like(fin)
+    ctx = lvm.Context(0, B, lib)
+    ctx.exact_lab(True)
+    cp = lvm.LvmParams(pk["mode"], pk["levels"], pk["amplification"], pk["coWavelength"], pk["coLow"], pk["coHigh"],
+                       pk["chromAttenuation"], pk["framerate"], 0)
+
+    def call(first, n):
+        ctx.process_device_frames(cp, n, fin[first].ctypes.data, w, h, 3, w * 3, fb, fb * B, fout[first].ctypes.data, w * 3, fb, fb * B)
+    call(0, 1)                                                                             # seed (untimed)
+    dt = lvm.sharding.timed_steps(lambda i: call(1 + i * T, T), K // T, dist)
+    fps = lvm.sharding.aggregate_fps(world, B, K, dt)
+    ok = True
+    P = po.make_params(**pk)
+    for s_ in range(B):
+        orc = po.Oracle()
+        for t in range(nfr):
+            ref, _ = orc.process(fin[t, s_], P)
+            ok = ok and bool(np.array_equal(ref, fout[t, s_]))
+        orc.close()
+    ctx.close()
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (rank, ids, ok, int(fout.sum())))
+    q.put((rank, dt, fps, gathered))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_run_the_product_on_their_own_streams(emu):
+    """world_size 2 over gloo, the library's kernels (emulation build) in the loop on every rank."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    emu_so = os.path.join(root, "tests", "emu", "_build", "liblvm_emu.so")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_product, args=(r, world, port, q, emu_so)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, dt0, fps0, g0), (_, dt1, fps1, _) = res
+    assert dt0 == dt1 and fps0 == fps1 == pytest.approx(2 * 2 * 8 / dt0)
+    assert [g[1] for g in g0] == [[0, 1], [2, 3]]                    # rank r owns streams 2r, 2r + 1
+    assert all(g[2] for g in g0)                                      # every rank's frames equal the oracle's for its seeds
+    assert g0[0][3] != g0[1][3]                                       # different streams, different frames
