@@ -24,8 +24,8 @@ Sequence of one run (global frame index i reads input ring slot i % ring and wri
               cpu_baseline sample.
     profile   per-kernel HIP-event pass (two whole calls) -> roofline of the dominant kernel
     sub-records (N = 1 unless --subrecords): per-frame schedule (T = 1), host-to-host lvm_process (pageable and
-              pinned frames), B = 4 / 16 streams per launch, and BASELINE configs[4] (Riesz 3840x2160 L8, one
-              stream per GPU; measured at every N)
+              pinned frames), B = 4 / 16 streams per launch, BASELINE configs[4] (Riesz 3840x2160 L8, one stream per
+              GPU; measured at every N), and configs[2] / configs[3] (Riesz / Color 1080p, verified against the oracle)
 
 With --gpus N > 1 and no WORLD_SIZE in the environment the script re-executes itself under
 torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1).  Every rank runs its own independent
@@ -554,6 +554,42 @@ def cfg4_record(lvm, torch, np, local_rank, rank, world, dist, red_dev, K=64, W=
             "frame_roofline_frac": round(b_alg * fps / world / (HBM_PEAK_GBS * 1e9), 5)}
 
 
+def other_mode_record(lvm, torch, np, cfg_idx, local_rank, rank, world, dist, red_dev, K=64, W=32, T=32):
+    """BASELINE configs[2] / configs[3] (Riesz / Color at 1920x1080, 6 levels) in the same run as the headline, so that the
+    driver's record carries them: K timed frames in calls of T, and -- on rank 0 -- the timed region's own output
+    against the CPU oracle (8 frames, u8 bars)."""
+    ids = lvm.sharding.stream_ids(rank, world, 1)
+    pk = lvm.synth.config(cfg_idx)[1]
+    total = prime_total(lvm, pk, T, K, W) + K
+    R = Runner(lvm, torch, np, cfg_idx, None, 1, 64, T, local_rank, ids, total if rank == 0 else 64)
+    R.prime(K, W)
+    R.run(W)
+    base = R.n
+    dt = lvm.sharding.timed_steps(lambda i: R.run(K), 1, dist, torch.cuda.synchronize, red_dev, finish=lambda: R.ctx.flush(R.stream))
+    fps = world * K / dt
+    b_alg = lvm.load().lvm_algorithmic_bytes(R.pk["mode"], R.w, R.h, R.ch, R.levels, R.pk["framerate"])
+    rec = {"workload": "%s 1920x1080, 6 levels, 1 stream per GPU, %d frames per call" % ({2: "riesz", 3: "color"}[cfg_idx], T),
+           "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "us_per_frame": round(1e6 * dt / K, 2),
+           "frame_alg_bytes": b_alg, "frame_roofline_frac": round(b_alg * fps / world / (HBM_PEAK_GBS * 1e9), 5)}
+    if rank == 0 and R.oring >= R.n:
+        from oracle import pyoracle as po
+        host = R.d_in[:, 0].cpu().numpy()
+        check = sorted(set(int(round(x)) for x in np.linspace(base, base + K - 1, 8)))
+        keep, _, _ = oracle_replay(po, np, host, R.pk, R.ring, R.n, check, max(1, min(16, os.cpu_count() or 1)))
+        dmax, fmin, ncmp = 0, 1.0, 0
+        for i in check:
+            ref, produced = keep[i]
+            if produced:
+                du = np.abs(ref.astype(np.int16) - R.d_out[i % R.oring, 0].cpu().numpy().astype(np.int16))
+                dmax, fmin, ncmp = max(dmax, int(du.max())), min(fmin, float((du == 0).mean())), ncmp + 1
+        rec["verified"] = bool(ncmp >= 8 and dmax <= 1 and fmin >= 0.999)
+        rec["verification"] = {"timed_frames_compared": ncmp, "u8_max_diff": dmax, "u8_identical_min": round(fmin, 6)}
+    R.close()
+    del R
+    torch.cuda.empty_cache()
+    return rec
+
+
 def sub_records(lvm, torch, np, args, cfg_idx, small, local_rank, rank, world, dist, red_dev):
     out = {}
     ids = lvm.sharding.stream_ids(rank, world, 1)
@@ -620,6 +656,10 @@ def sub_records(lvm, torch, np, args, cfg_idx, small, local_rank, rank, world, d
     out["batched_streams"] = bs
     # (4) BASELINE configs[4]
     out["cfg4_riesz_4k"] = cfg4_record(lvm, torch, np, local_rank, rank, world, dist, red_dev)
+    # (5) BASELINE configs[2] and configs[3] (the headline run only: `--mode riesz|color` runs them as the main line)
+    if cfg_idx == 1 and not small:
+        out["cfg2_riesz_1080p"] = other_mode_record(lvm, torch, np, 2, local_rank, rank, world, dist, red_dev)
+        out["cfg3_color_1080p"] = other_mode_record(lvm, torch, np, 3, local_rank, rank, world, dist, red_dev)
     return out
 
 
