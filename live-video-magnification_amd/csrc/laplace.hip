@@ -615,6 +615,9 @@ __global__ __launch_bounds__(256) void k_lap_final(const uint8_t* __restrict__ i
 // sits in L2) and slides a three-row register window down the strip for the vertical pass; the row
 // parity is uniform across the wave, so only the formula of that parity is executed.
 constexpr int FIN_THREADS = 512;
+#ifndef LVM_FIN_PAIRS
+#define LVM_FIN_PAIRS 0          // default flavour of the last kernel: colour arithmetic on explicit pixel pairs (0: per pixel)
+#endif
 struct Row3 { float4 c[3]; };            // horizontal-pass results of one source row, 3 channels x 4 columns
 template <bool MOTION, bool EXACT>
 __global__ __launch_bounds__(FIN_THREADS) void k_lap_final_v4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
@@ -676,6 +679,31 @@ __global__ __launch_bounds__(FIN_THREADS) void k_lap_final_v4(const uint8_t* __r
             int Bv[4], Gv[4], Rv[4];
             unpack_px4(pin, Bv, Gv, Rv);
             float ov[12];
+            if (!EXACT && LVM_FIN_PAIRS) {
+                // default flavour: the colour arithmetic on pixel pairs (lvm_internal.h), same values
+                float Bl[4], Gl[4], Rl[4], L4[4], a4[4], b4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { Bl[k] = s_gam[Bv[k]]; Gl[k] = s_gam[Gv[k]]; Rl[k] = s_gam[Rv[k]]; }
+                lab_fwd4<false>(Bl, Gl, Rl, lab.fwd, L4, a4, b4);
+#pragma unroll
+                for (int k = 0; k < 4; k += 2) {
+                    f32x2 Lp, Ap, Bq, o0, o1, o2;
+                    Lp.x = L4[k]; Lp.y = L4[k + 1]; Ap.x = a4[k]; Ap.y = a4[k + 1]; Bq.x = b4[k]; Bq.y = b4[k + 1];
+                    if (MOTION) {
+                        f32x2 m0, m1, m2;
+                        m0.x = m[0][k]; m0.y = m[0][k + 1]; m1.x = m[1][k]; m1.y = m[1][k + 1]; m2.x = m[2][k]; m2.y = m[2][k + 1];
+                        Lp = pk_fma(m0, pk_splat(msc), Lp); Ap = pk_fma(m1, pk_splat(msc * ca), Ap); Bq = pk_fma(m2, pk_splat(msc * ca), Bq);
+                    }
+                    lab_inv_pair(Lp, Ap, Bq, lab.inv1024, s_igt, o0, o1, o2);
+                    if (dbg && b == 0) {
+                        float* d = dbg + ((size_t)gy * w + gx + k) * 3;
+                        d[0] = o0.x; d[1] = o1.x; d[2] = o2.x; d[3] = o0.y; d[4] = o1.y; d[5] = o2.y;
+                    }
+                    const f32x2 s255 = pk_splat(255.0f), a255 = pk_splat(lab.a255);
+                    o0 = pk_fma(o0, s255, a255); o1 = pk_fma(o1, s255, a255); o2 = pk_fma(o2, s255, a255);
+                    ov[3 * k] = o0.x; ov[3 * k + 1] = o1.x; ov[3 * k + 2] = o2.x; ov[3 * k + 3] = o0.y; ov[3 * k + 4] = o1.y; ov[3 * k + 5] = o2.y;
+                }
+            } else
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float L, a, bb;

@@ -192,12 +192,88 @@ __device__ __forceinline__ void lab_to_bgr(float li, float ai, float bi, const f
         o2 = spline1024<false>(clip1024_open(c2), igt);
     }
 }
+// ---- pixel-pair forms of the default flavour (round 2) -----------------------------------------------------------
+// The same operations as lin_bgr_to_lab<false> / lab_to_bgr<false>, two pixels at a time on <2 x float> values: every
+// fma-class operation is a v_pk_fma / v_pk_mul / v_pk_add_f32, which issues at 0.8 of the cost of two scalar ones
+// (profiles/r02_ubench_valu_issue_rates.txt); selects, table look-ups and transcendentals stay per element.  Written
+// out by hand because the SLP vectoriser's own packing of the scalar code costs more register moves than it saves.
+// Results are bit-identical to the scalar default flavour (same operations, same order, per element).
+#ifdef LVM_EMU_F32X2          // tests/emu (g++ has no ext_vector_type): a two-float struct with the same operators
+typedef LVM_EMU_F32X2 f32x2;
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { f32x2 r; r.x = __builtin_fmaf(a.x, b.x, c.x); r.y = __builtin_fmaf(a.y, b.y, c.y); return r; }
+#else
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+__device__ __forceinline__ f32x2 pk_splat(float x) { f32x2 r; r.x = x; r.y = x; return r; }
+__device__ __forceinline__ f32x2 pk_cbrt(f32x2 x) {
+    f32x2 l; l.x = __builtin_amdgcn_logf(x.x); l.y = __builtin_amdgcn_logf(x.y);
+    l = l * pk_splat(0.33333334f);
+    f32x2 r; r.x = __builtin_amdgcn_exp2f(l.x); r.y = __builtin_amdgcn_exp2f(l.y);
+    return r;
+}
+__device__ __forceinline__ void lab_fwd_pair(f32x2 B, f32x2 G, f32x2 R, const float* fw, f32x2& L, f32x2& a, f32x2& b) {
+    const f32x2 X = pk_fma(B, pk_splat(fw[0]), pk_fma(G, pk_splat(fw[1]), R * pk_splat(fw[2])));
+    const f32x2 Y = pk_fma(B, pk_splat(fw[3]), pk_fma(G, pk_splat(fw[4]), R * pk_splat(fw[5])));
+    const f32x2 Z = pk_fma(B, pk_splat(fw[6]), pk_fma(G, pk_splat(fw[7]), R * pk_splat(fw[8])));
+    const f32x2 k = pk_splat(7.787f), c = pk_splat(16.0f / 116.0f);
+    const f32x2 cx = pk_cbrt(X), cy = pk_cbrt(Y), cz = pk_cbrt(Z);
+    const f32x2 lx = pk_fma(k, X, c), ly = pk_fma(k, Y, c), lz = pk_fma(k, Z, c);
+    f32x2 FX, FY, FZ;
+    FX.x = X.x > 0.008856f ? cx.x : lx.x; FX.y = X.y > 0.008856f ? cx.y : lx.y;
+    FY.x = Y.x > 0.008856f ? cy.x : ly.x; FY.y = Y.y > 0.008856f ? cy.y : ly.y;
+    FZ.x = Z.x > 0.008856f ? cz.x : lz.x; FZ.y = Z.y > 0.008856f ? cz.y : lz.y;
+    L = pk_fma(pk_splat(116.f), FY, pk_splat(-16.f));
+    a = pk_splat(500.f) * (FX - FY);
+    b = pk_splat(200.f) * (FY - FZ);
+}
+__device__ __forceinline__ f32x2 pk_spline1024(f32x2 x, const float* tab) {       // x clamped to [0, 1024) by the caller
+    const int i0 = (int)x.x, i1 = (int)x.y;
+    f32x2 fr; fr.x = __builtin_amdgcn_fractf(x.x); fr.y = __builtin_amdgcn_fractf(x.y);
+    const float4 t0 = *reinterpret_cast<const float4*>(tab + i0 * 4), t1 = *reinterpret_cast<const float4*>(tab + i1 * 4);
+    f32x2 c3, c2, c1, c0;
+    c3.x = t0.w; c3.y = t1.w; c2.x = t0.z; c2.y = t1.z; c1.x = t0.y; c1.y = t1.y; c0.x = t0.x; c0.y = t1.x;
+    return pk_fma(pk_fma(pk_fma(c3, fr, c2), fr, c1), fr, c0);
+}
+__device__ __forceinline__ void lab_inv_pair(f32x2 L, f32x2 a, f32x2 b, const float* iv, const float* igt, f32x2& o0, f32x2& o1, f32x2& o2) {
+    const float lThresh = 0.008856f * 903.3f, fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
+    const f32x2 ylin = L * pk_splat(1.0f / 903.3f), fyc = (L + pk_splat(16.0f)) * pk_splat(1.0f / 116.0f);
+    const f32x2 fyl = pk_fma(pk_splat(7.787f), ylin, pk_splat(16.0f / 116.0f));
+    const f32x2 y3 = fyc * fyc * fyc;
+    f32x2 fy, y;
+    fy.x = L.x <= lThresh ? fyl.x : fyc.x; fy.y = L.y <= lThresh ? fyl.y : fyc.y;
+    y.x = L.x <= lThresh ? ylin.x : y3.x; y.y = L.y <= lThresh ? ylin.y : y3.y;
+    f32x2 fx = pk_fma(a, pk_splat(1.0f / 500.0f), fy), fz = pk_fma(b, pk_splat(-1.0f / 200.0f), fy);
+    const f32x2 fxl = (fx - pk_splat(16.0f / 116.0f)) * pk_splat(1.0f / 7.787f), fzl = (fz - pk_splat(16.0f / 116.0f)) * pk_splat(1.0f / 7.787f);
+    const f32x2 fx3 = fx * fx * fx, fz3 = fz * fz * fz;
+    fx.x = fx.x <= fThresh ? fxl.x : fx3.x; fx.y = fx.y <= fThresh ? fxl.y : fx3.y;
+    fz.x = fz.x <= fThresh ? fzl.x : fz3.x; fz.y = fz.y <= fThresh ? fzl.y : fz3.y;
+    f32x2 c0 = pk_fma(pk_splat(iv[0]), fx, pk_fma(pk_splat(iv[1]), y, pk_splat(iv[2]) * fz));
+    f32x2 c1 = pk_fma(pk_splat(iv[3]), fx, pk_fma(pk_splat(iv[4]), y, pk_splat(iv[5]) * fz));
+    f32x2 c2 = pk_fma(pk_splat(iv[6]), fx, pk_fma(pk_splat(iv[7]), y, pk_splat(iv[8]) * fz));
+    c0.x = clip1024_open(c0.x); c0.y = clip1024_open(c0.y); c1.x = clip1024_open(c1.x); c1.y = clip1024_open(c1.y);
+    c2.x = clip1024_open(c2.x); c2.y = clip1024_open(c2.y);
+    o0 = pk_spline1024(c0, igt); o1 = pk_spline1024(c1, igt); o2 = pk_spline1024(c2, igt);
+}
+#ifndef LVM_FWD_PAIRS
+#define LVM_FWD_PAIRS 0
+#endif
 // 4-pixel form of the forward conversion (the strip kernels convert pixel groups)
 template <bool EXACT>
 __device__ __forceinline__ void lab_fwd4(const float (&Bl)[4], const float (&Gl)[4], const float (&Rl)[4], const float* fw,
                                          float (&L)[4], float (&a)[4], float (&b)[4]) {
+    if (EXACT || !LVM_FWD_PAIRS) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) lin_bgr_to_lab<EXACT>(Bl[k], Gl[k], Rl[k], fw, L[k], a[k], b[k]);
+        for (int k = 0; k < 4; ++k) lin_bgr_to_lab<EXACT>(Bl[k], Gl[k], Rl[k], fw, L[k], a[k], b[k]);
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k += 2) {
+        f32x2 Bp, Gp, Rp, Lp, Ap, Bq;
+        Bp.x = Bl[k]; Bp.y = Bl[k + 1]; Gp.x = Gl[k]; Gp.y = Gl[k + 1]; Rp.x = Rl[k]; Rp.y = Rl[k + 1];
+        lab_fwd_pair(Bp, Gp, Rp, fw, Lp, Ap, Bq);
+        L[k] = Lp.x; L[k + 1] = Lp.y; a[k] = Ap.x; a[k + 1] = Ap.y; b[k] = Bq.x; b[k + 1] = Bq.y;
+    }
 }
 // cooperative loads of the two Lab tables into LDS (256 threads)
 __device__ __forceinline__ void load_gamma_u8(float* s_gam, const float* g) { s_gam[threadIdx.x] = g[threadIdx.x]; }

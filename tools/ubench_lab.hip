@@ -74,6 +74,55 @@ __device__ __forceinline__ void lab_inv4_shortcut(const float (&L)[4], const flo
     }
 }
 
+// ---- explicit pixel-pair arithmetic: every fma-class operation on a <2 x float> (v_pk_fma/mul/add_f32) ----------
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float x) { f2 r; r.x = x; r.y = x; return r; }
+__device__ __forceinline__ f2 cbrt2(f2 x) {
+    f2 l; l.x = __builtin_amdgcn_logf(x.x); l.y = __builtin_amdgcn_logf(x.y);
+    l = l * splat(0.33333334f);
+    f2 r; r.x = __builtin_amdgcn_exp2f(l.x); r.y = __builtin_amdgcn_exp2f(l.y);
+    return r;
+}
+__device__ __forceinline__ f2 sel2(f2 x, float thr, f2 a, f2 b) { f2 r; r.x = x.x > thr ? a.x : b.x; r.y = x.y > thr ? a.y : b.y; return r; }
+__device__ __forceinline__ void lab_fwd_pair(f2 B, f2 G, f2 R, const float* fw, f2& L, f2& a, f2& b) {
+    const f2 X = fma2(B, splat(fw[0]), fma2(G, splat(fw[1]), R * splat(fw[2])));
+    const f2 Y = fma2(B, splat(fw[3]), fma2(G, splat(fw[4]), R * splat(fw[5])));
+    const f2 Z = fma2(B, splat(fw[6]), fma2(G, splat(fw[7]), R * splat(fw[8])));
+    const f2 k = splat(7.787f), c = splat(16.0f / 116.0f);
+    const f2 FX = sel2(X, 0.008856f, cbrt2(X), fma2(k, X, c));
+    const f2 FY = sel2(Y, 0.008856f, cbrt2(Y), fma2(k, Y, c));
+    const f2 FZ = sel2(Z, 0.008856f, cbrt2(Z), fma2(k, Z, c));
+    L = fma2(splat(116.f), FY, splat(-16.f));
+    a = splat(500.f) * (FX - FY);
+    b = splat(200.f) * (FY - FZ);
+}
+__device__ __forceinline__ f2 spline2(f2 x, const float* tab) {
+    const int i0 = (int)x.x, i1 = (int)x.y;
+    f2 fr; fr.x = __builtin_amdgcn_fractf(x.x); fr.y = __builtin_amdgcn_fractf(x.y);
+    const float4 t0 = *reinterpret_cast<const float4*>(tab + i0 * 4), t1 = *reinterpret_cast<const float4*>(tab + i1 * 4);
+    f2 w; w.x = t0.w; w.y = t1.w; f2 z; z.x = t0.z; z.y = t1.z; f2 y; y.x = t0.y; y.y = t1.y; f2 xx; xx.x = t0.x; xx.y = t1.x;
+    return fma2(fma2(fma2(w, fr, z), fr, y), fr, xx);
+}
+__device__ __forceinline__ f2 clip2(f2 v) { f2 r; r.x = clip1024_open(v.x); r.y = clip1024_open(v.y); return r; }
+__device__ __forceinline__ void lab_inv_pair(f2 L, f2 a, f2 b, const float* iv, const float* igt, f2& o0, f2& o1, f2& o2) {
+    const float lThresh = 0.008856f * 903.3f, fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
+    const f2 ylin = L * splat(1.0f / 903.3f), fyc = (L + splat(16.0f)) * splat(1.0f / 116.0f);
+    const f2 fyl = fma2(splat(7.787f), ylin, splat(16.0f / 116.0f));
+    f2 fy, y; const f2 y3 = fyc * fyc * fyc;
+    fy.x = L.x <= lThresh ? fyl.x : fyc.x; fy.y = L.y <= lThresh ? fyl.y : fyc.y;
+    y.x = L.x <= lThresh ? ylin.x : y3.x; y.y = L.y <= lThresh ? ylin.y : y3.y;
+    f2 fx = fma2(a, splat(1.0f / 500.0f), fy), fz = fma2(b, splat(-1.0f / 200.0f), fy);
+    const f2 fxl = (fx - splat(16.0f / 116.0f)) * splat(1.0f / 7.787f), fzl = (fz - splat(16.0f / 116.0f)) * splat(1.0f / 7.787f);
+    const f2 fx3 = fx * fx * fx, fz3 = fz * fz * fz;
+    fx.x = fx.x <= fThresh ? fxl.x : fx3.x; fx.y = fx.y <= fThresh ? fxl.y : fx3.y;
+    fz.x = fz.x <= fThresh ? fzl.x : fz3.x; fz.y = fz.y <= fThresh ? fzl.y : fz3.y;
+    const f2 c0 = fma2(splat(iv[0]), fx, fma2(splat(iv[1]), y, splat(iv[2]) * fz));
+    const f2 c1 = fma2(splat(iv[3]), fx, fma2(splat(iv[4]), y, splat(iv[5]) * fz));
+    const f2 c2 = fma2(splat(iv[6]), fx, fma2(splat(iv[7]), y, splat(iv[8]) * fz));
+    o0 = spline2(clip2(c0), igt); o1 = spline2(clip2(c1), igt); o2 = spline2(clip2(c2), igt);
+}
+
 #define ITERS 512
 // VARIANT 0: round-1 per-pixel functions (selects everywhere); 1: 4-pixel functions with the wave-uniform shortcut
 // WHAT 0: forward + motion add + inverse + pack (last kernel); 1: forward only (first kernel)
@@ -99,6 +148,14 @@ __global__ __launch_bounds__(512) void k_lab(unsigned* out, LabCoef lab, unsigne
         if (VARIANT == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) lin_bgr_to_lab<false>(s_gam[Bv[k]], s_gam[Gv[k]], s_gam[Rv[k]], lab.fwd, L[k], A[k], Bb[k]);
+        } else if (VARIANT == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {
+                f2 Bp, Gp, Rp, Lp, Ap, Bq;
+                Bp.x = s_gam[Bv[k]]; Bp.y = s_gam[Bv[k + 1]]; Gp.x = s_gam[Gv[k]]; Gp.y = s_gam[Gv[k + 1]]; Rp.x = s_gam[Rv[k]]; Rp.y = s_gam[Rv[k + 1]];
+                lab_fwd_pair(Bp, Gp, Rp, lab.fwd, Lp, Ap, Bq);
+                L[k] = Lp.x; L[k + 1] = Lp.y; A[k] = Ap.x; A[k + 1] = Ap.y; Bb[k] = Bq.x; Bb[k + 1] = Bq.y;
+            }
         } else {
             float Bl[4], Gl[4], Rl[4];
 #pragma unroll
@@ -118,6 +175,14 @@ __global__ __launch_bounds__(512) void k_lab(unsigned* out, LabCoef lab, unsigne
         if (VARIANT == 0) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) lab_to_bgr<false>(L[k], A[k], Bb[k], lab.inv1024, s_igt, ov[3 * k], ov[3 * k + 1], ov[3 * k + 2]);
+        } else if (VARIANT == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; k += 2) {
+                f2 Lp, Ap, Bq, o0, o1, o2;
+                Lp.x = L[k]; Lp.y = L[k + 1]; Ap.x = A[k]; Ap.y = A[k + 1]; Bq.x = Bb[k]; Bq.y = Bb[k + 1];
+                lab_inv_pair(Lp, Ap, Bq, lab.inv1024, s_igt, o0, o1, o2);
+                ov[3 * k] = o0.x; ov[3 * k + 1] = o1.x; ov[3 * k + 2] = o2.x; ov[3 * k + 3] = o0.y; ov[3 * k + 4] = o1.y; ov[3 * k + 5] = o2.y;
+            }
         } else {
             lab_inv4_shortcut(L, A, Bb, lab.inv1024, s_igt, ov);
         }
@@ -143,7 +208,8 @@ int main() {
     const int blocks = 256 * 2;                       // 2 x 512 threads per CU = 4 waves per SIMD
     struct { const char* name; void (*k)(unsigned*, LabCoef, unsigned, float); } ks[] = {
         {"last kernel colour math, round-1 functions", k_lab<0, 0>}, {"last kernel colour math, uniform shortcut", k_lab<1, 0>},
-        {"first kernel colour math, round-1 functions", k_lab<0, 1>}, {"first kernel colour math, uniform shortcut", k_lab<1, 1>}};
+        {"first kernel colour math, round-1 functions", k_lab<0, 1>}, {"first kernel colour math, uniform shortcut", k_lab<1, 1>},
+        {"last kernel colour math, explicit pixel pairs", k_lab<2, 0>}, {"first kernel colour math, explicit pixel pairs", k_lab<2, 1>}};
     for (auto& e : ks) {
         float best = 1e30f;
         for (int rep = 0; rep < 4; ++rep) {
