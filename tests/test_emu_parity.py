@@ -248,7 +248,7 @@ def test_laplace_emu_temporal_batches(lvm, po, emu, w, h, levels, ns, calls):
 
 
 @pytest.mark.parametrize("w,h,levels,ns,calls", [(640, 360, 5, 1, (1, 8, 4)), (256, 256, 6, 1, (1, 4, 6)), (320, 182, 5, 2, (1, 5, 16)),
-                                                  (576, 72, 4, 1, (1, 4, 4))])
+                                                  (576, 72, 4, 1, (1, 4, 4)), (512, 384, 7, 1, (1, 4))])   # 7 levels: five decoupled levels, the top one 8 x 6
 def test_laplace_emu_split_levels_iir_and_collapse(lvm, po, emu, w, h, levels, ns, calls):
     """Temporal batches of >= 4 frames: levels 2 .. L-1 as ONE k_lap_iir_levels launch + ONE k_lap_collapse launch
     (several 64 x 32 tiles of level 2, odd level heights, levels of a few pixels, two streams, every ring depth)."""

@@ -208,3 +208,35 @@ def test_keep_float_across_size_change_after_chain(lvm, po, hip):
         ck, pk = lvm.synth.config(0, (320, 180, 3))
         c2.chain_process(lvm.synth.Clip(**ck).frame(0), pre, c_params(lvm, pk))
         c2.close()
+
+
+def test_laplace_4k_8_levels_temporal_batches(lvm, po, hip):
+    """Laplace at 3840x2160 with 8 levels in temporal batches: six decoupled levels in k_lap_iir_levels / k_lap_collapse
+    (the deepest pyramid the configs use), every frame against the oracle."""
+    import torch
+    ck, pk = lvm.synth.config(0, (3840, 2160, 8))
+    w, h = ck["w"], ck["h"]
+    clip = lvm.synth.Clip(**ck)
+    nf, ncalls = 5, 2
+    d_in = torch.stack([clip.frame_torch(t, "cuda") for t in range(1 + nf * ncalls)])
+    host = d_in.cpu().numpy()
+    d_out = torch.zeros_like(d_in)
+    fb = w * h * 3
+    ctx = lvm.Context(0, 1, hip)
+    cp = c_params(lvm, pk)
+    st = torch.cuda.current_stream().cuda_stream
+    produced = ctx.process_device_frames(cp, 1, d_in[0].data_ptr(), w, h, 3, w * 3, fb, fb, d_out[0].data_ptr(), w * 3, fb, fb, st)
+    for c in range(ncalls):
+        f0 = 1 + c * nf
+        produced += ctx.process_device_frames(cp, nf, d_in[f0].data_ptr(), w, h, 3, w * 3, fb, fb, d_out[f0].data_ptr(), w * 3, fb, fb, st)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    ctx.close()
+    orc = po.Oracle()
+    P = po.make_params(**pk)
+    for t in range(host.shape[0]):
+        ref, pr = orc.process(host[t], P)
+        assert pr == produced[t]
+        du = np.abs(ref.astype(np.int16) - got[t].astype(np.int16))
+        assert du.max() <= 1 and (du == 0).mean() >= 0.999, (t, int(du.max()), float((du == 0).mean()))
+    orc.close()
