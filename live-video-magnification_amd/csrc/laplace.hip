@@ -913,9 +913,11 @@ struct LaplaceState : ModeState {
     bool d0_rows_on = true;               // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
     long d0_min_tasks = 4096;             // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
     int fin_rows = 8;                     // rows per wave strip of k_lap_final_v4 (LVM_FIN_ROWS, power of two)
+    int up_depth_big = 1;                 // ... at the levels with >= 1024 workgroups (LVM_UP_DEPTH_BIG)
     int up_depth = 8;                     // frame-loop prefetch depth of k_lap_up at the coarse levels (LVM_UP_DEPTH=1|2|4|8)
     int chunks = 1;                       // temporal batches: > 1 = chunks whose down sweep overlaps the previous chunk's up sweep on a second stream (LVM_LAP_CHUNKS; measured slower: 27.7k fps at 4 chunks, 30.5k at 2, 34.8k at 1)
     std::vector<hipEvent_t> chunk_ev;
+    int pd_rows = 16;                     // output rows per wave strip of k_pyr_down_rows (LVM_PD_ROWS)
     int fuse_down = 2;                    // pyramid levels per pyrDown launch (LVM_FUSE_DOWN=2|3 selects the fused kernels)
     int tailT = 0;                       // first level handled by k_lap_tail (0 = tail disabled)
     TailArgs tail{};
@@ -974,6 +976,8 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     laplace_tail_plan(st);
     if (const char* e = std::getenv("LVM_FUSE_DOWN")) st->fuse_down = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_DEPTH")) st->up_depth = std::atoi(e);
+    if (const char* e = std::getenv("LVM_UP_DEPTH_BIG")) st->up_depth_big = std::atoi(e);
+    if (const char* e = std::getenv("LVM_PD_ROWS")) st->pd_rows = std::atoi(e);
     if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
     if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
     if (const char* e = std::getenv("LVM_LAP_CHUNKS")) st->chunks = std::atoi(e);
@@ -1077,7 +1081,7 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
             // large planes (temporal batches / many streams): barrier-free wave strips, one level per launch
             const LevelGeom &a = st->g[l], &b = st->g[l + 1];
             const int sx = (b.w + 127) / 128;
-            int rows = 16;
+            int rows = st->pd_rows;
             while (rows > 4 && (long)sx * ((b.h + rows - 1) / rows) * planes < 8192) rows >>= 1;
             const int sy = (b.h + rows - 1) / rows;
             const long ntasks = (long)sx * sy * planes;
@@ -1203,7 +1207,7 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
             else LVM_LAUNCH(c, LName("lap_up", l), (k_lap_up_rows<4, 1, true>), g2, blk, s, a, gw, (int)ngroups);
             continue;
         }
-        int depth = (blocks >= 1024) ? 1 : st->up_depth;              // frame ring of the tiled kernel
+        int depth = (blocks >= 1024) ? st->up_depth_big : st->up_depth;   // frame ring of the tiled kernel
         while (depth > 1 && a.nt % depth != 0) depth >>= 1;           // the ring depth must divide the frame count
         if (first) LVM_LAUNCH(c, LName("lap_seed", l), (k_lap_up<true, 1>), grid, blk, s, a);
         else if (depth == 1) LVM_LAUNCH(c, LName("lap_up", l), (k_lap_up<false, 1>), grid, blk, s, a);
