@@ -619,8 +619,16 @@ constexpr int FIN_THREADS = 512;
 #define LVM_FIN_PAIRS 0          // default flavour of the last kernel: colour arithmetic on explicit pixel pairs (0: per pixel)
 #endif
 struct Row3 { float4 c[3]; };            // horizontal-pass results of one source row, 3 channels x 4 columns
+#ifndef LVM_FIN_WAVES
+#define LVM_FIN_WAVES 0          // minimum waves per SIMD asked of the register allocator (0: none; 121 VGPRs = 4 waves)
+#endif
+#if LVM_FIN_WAVES
+#define LVM_FIN_BOUNDS __launch_bounds__(FIN_THREADS, LVM_FIN_WAVES)
+#else
+#define LVM_FIN_BOUNDS __launch_bounds__(FIN_THREADS)
+#endif
 template <bool MOTION, bool EXACT>
-__global__ __launch_bounds__(FIN_THREADS) void k_lap_final_v4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
+__global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                        uint8_t* __restrict__ out, long out_stride, long out_sstride,
                                                        int w, int h, const float* __restrict__ cur1, int w1, int h1,
                                                        LabCoef lab, float ca, int strips_x, int strips_y, int nstreams,

@@ -748,7 +748,14 @@ __global__ __launch_bounds__(256) void k_rz_blur_amp4(BlurArgs aa) {
 // res_l = filter2D(zero-injected nearest-upsample of res_{l+1}, 2 lp9) + filter2D(bandA_l, hp9).
 // The zero-injected image is non-zero only at even (x,y) (REFLECT_101 keeps parity), so only taps
 // with j == x and i == y (mod 2) are visited -- in the same row-major order as the full sum.
-__device__ __forceinline__ void collapse_stage(float (&sb)[CSH][CSP], float (&su)[CSH][CSP],
+// COMPACT (planes with even width and height: REFLECT_101 keeps the parity of every coordinate there, so the odd rows and
+// columns of the zero-injected tile are all zeros): the tile holds only its even rows / columns, i.e. 12 x 36 coarse values
+// instead of 24 x 72 with three quarters of them zero -- half the LDS bytes read by the polyphase low-pass (three 64-bit
+// reads per kernel row instead of three 128-bit ones), a fifth of the staging stores, 7 KB less LDS per workgroup.
+constexpr int CCH = CSH / 2, CCP = 40;                    // compact tile: rows, columns, row pitch (floats)
+template <bool COMPACT> struct CollapseTile { float v[COMPACT ? CCH : CSH][COMPACT ? CCP : CSP]; };
+template <bool COMPACT>
+__device__ __forceinline__ void collapse_stage(float (&sb)[CSH][CSP], CollapseTile<COMPACT>& su,
                                                const float* __restrict__ bandA, const float* __restrict__ resn,
                                                int w, int h, int nw, int nh, int x0, int y0) {
     // Interior tiles of planes whose width is a multiple of 4 need no reflection: the band tile is 432 aligned
@@ -767,8 +774,11 @@ __device__ __forceinline__ void collapse_stage(float (&sb)[CSH][CSP], float (&su
         for (int i = threadIdx.x; i < (CSH / 2) * (CSW / 4); i += 256) {
             const int r = i / (CSW / 4), g = i - r * (CSW / 4);
             const float2 v = *reinterpret_cast<const float2*>(resn + (size_t)(cy0 + r) * nw + (cx0 + 2 * g));   // 8-byte aligned: cx0, nw even
-            *reinterpret_cast<float4*>(&su[2 * r][4 * g]) = make_float4(v.x, 0.f, v.y, 0.f);
-            *reinterpret_cast<float4*>(&su[2 * r + 1][4 * g]) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (COMPACT) *reinterpret_cast<float2*>(&su.v[r][2 * g]) = v;
+            else {
+                *reinterpret_cast<float4*>(&su.v[2 * r][4 * g]) = make_float4(v.x, 0.f, v.y, 0.f);
+                *reinterpret_cast<float4*>(&su.v[2 * r + 1][4 * g]) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         return;
     }
@@ -777,27 +787,39 @@ __device__ __forceinline__ void collapse_stage(float (&sb)[CSH][CSP], float (&su
         const int yr = reflect101(y0 - SH + ly, h), xr = reflect101(x0 - SH + lx, w);
         sb[ly][lx] = bandA[(size_t)yr * w + xr];
         float u = 0.f;
-        if (((xr | yr) & 1) == 0) {   // injectZerosEven (:280-302) of resize(INTER_NEAREST) (:314)
+        const bool even = ((xr | yr) & 1) == 0;
+        if (even) {   // injectZerosEven (:280-302) of resize(INTER_NEAREST) (:314)
             const int sx = xr / 2 < nw ? xr / 2 : nw - 1, sy = yr / 2 < nh ? yr / 2 : nh - 1;
             u = resn[(size_t)sy * nw + sx];
         }
-        su[ly][lx] = u;
+        if (!COMPACT) su.v[ly][lx] = u;
+        else if (((lx | ly) & 1) == 0) su.v[ly >> 1][lx >> 1] = u;   // (even plane sizes: local parity = image parity, `even` holds)
     }
 }
 // 4 adjacent outputs (lx..lx+3, ly), lx % 4 == 0; gx0 = image column of lx (even, tiles start at
 // multiples of 64), gy = image row.  Polyphase low-pass of the zero-injected image + high-pass.
 // polyphase low-pass of the zero-injected tile for the 4 outputs; ODD = parity of the image row (the kernel rows
 // i == gy (mod 2) are the only ones that meet non-zero samples: 0,2,4,6,8 or 1,3,5,7)
-template <bool ODD>
-__device__ __forceinline__ void collapse_lp4(const float (&su)[CSH][CSP], int lx, int ly, float (&lp)[4]) {
+template <bool ODD, bool COMPACT>
+__device__ __forceinline__ void collapse_lp4(const CollapseTile<COMPACT>& su, int lx, int ly, float (&lp)[4]) {
     lp[0] = lp[1] = lp[2] = lp[3] = 0.f;
 #pragma unroll
     for (int ii = 0; ii < (ODD ? 4 : 5); ++ii) {
         const int i = ODD ? 2 * ii + 1 : 2 * ii;
-        const float4 a = *reinterpret_cast<const float4*>(&su[ly + i][lx]);
-        const float4 b = *reinterpret_cast<const float4*>(&su[ly + i][lx + 4]);
-        const float4 c = *reinterpret_cast<const float4*>(&su[ly + i][lx + 8]);
-        const float v[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+        float v[12];
+        if (COMPACT) {               // ly + i is even (kernel rows of the output row's parity), lx a multiple of 4
+            const float2 a = *reinterpret_cast<const float2*>(&su.v[(ly + i) >> 1][lx >> 1]);
+            const float2 b = *reinterpret_cast<const float2*>(&su.v[(ly + i) >> 1][(lx >> 1) + 2]);
+            const float2 c = *reinterpret_cast<const float2*>(&su.v[(ly + i) >> 1][(lx >> 1) + 4]);
+            v[0] = a.x; v[2] = a.y; v[4] = b.x; v[6] = b.y; v[8] = c.x; v[10] = c.y;
+            v[1] = v[3] = v[5] = v[7] = v[9] = v[11] = 0.f;   // never read below
+        } else {
+            const float4 a = *reinterpret_cast<const float4*>(&su.v[ly + i][lx]);
+            const float4 b = *reinterpret_cast<const float4*>(&su.v[ly + i][lx + 4]);
+            const float4 c = *reinterpret_cast<const float4*>(&su.v[ly + i][lx + 8]);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+        }
 #pragma unroll
         for (int j = 0; j < 9; ++j) {           // output m (column parity m & 1) uses taps j == m (mod 2)
             const float kv = kLp9[i * 9 + j] * 2.0f;
@@ -809,11 +831,12 @@ __device__ __forceinline__ void collapse_lp4(const float (&su)[CSH][CSP], int lx
 // The row parity is uniform across a wave (collapse_row() below maps waves 0-1 to the even rows of the tile
 // and waves 2-3 to the odd ones), so the parity test is a scalar branch and every tap weight an immediate.
 __device__ __forceinline__ int collapse_row() { return ((threadIdx.x >> 4) & 7) * 2 + (threadIdx.x >> 7); }
-__device__ __forceinline__ void collapse_px4(const float (&sb)[CSH][CSP], const float (&su)[CSH][CSP],
+template <bool COMPACT>
+__device__ __forceinline__ void collapse_px4(const float (&sb)[CSH][CSP], const CollapseTile<COMPACT>& su,
                                              int lx, int ly, int gy, float (&o)[4]) {
     float lp[4];
-    if (__builtin_amdgcn_readfirstlane(gy & 1)) collapse_lp4<true>(su, lx, ly, lp);
-    else collapse_lp4<false>(su, lx, ly, lp);
+    if (__builtin_amdgcn_readfirstlane(gy & 1)) collapse_lp4<true, COMPACT>(su, lx, ly, lp);
+    else collapse_lp4<false, COMPACT>(su, lx, ly, lp);
     float hp[4];
     conv9x4(sb, lx, ly, kHp9, 1.0f, hp);
 #pragma unroll
@@ -821,10 +844,11 @@ __device__ __forceinline__ void collapse_px4(const float (&sb)[CSH][CSP], const 
 }
 
 // (a 64 x 32 / 4 x 2 variant of this kernel, like k_rz_split2, needs 300 registers and measured 48 us against 29 us)
+template <bool COMPACT>
 __global__ __launch_bounds__(256) void k_rz_collapse(const float* __restrict__ bandA, const float* __restrict__ resn,
                                                      float* __restrict__ res, int w, int h, int nw, int nh) {
     __shared__ __attribute__((aligned(16))) float sb[CSH][CSP];
-    __shared__ __attribute__((aligned(16))) float su[CSH][CSP];
+    __shared__ __attribute__((aligned(16))) CollapseTile<COMPACT> su;
     const int x0 = blockIdx.x * CW, y0 = blockIdx.y * CH;
     const size_t pl = (size_t)blockIdx.z * w * h, pn = (size_t)blockIdx.z * nw * nh;
     collapse_stage(sb, su, bandA + pl, resn + pn, w, h, nw, nh, x0, y0);
@@ -846,7 +870,7 @@ __global__ __launch_bounds__(256) void k_rz_collapse(const float* __restrict__ b
 // level-0 collapse (or plain L plane when there are no bands) + Lab2BGR + u8 (MagnifyCore.hpp:272-277).
 // 4 pixels per thread; VEC = the frame's 4-pixel groups are dword aligned (12-byte loads/stores).
 struct __attribute__((packed, aligned(4))) RzPx4 { uint32_t a, b, c; };
-template <bool BANDS, bool EXACT, bool VEC>
+template <bool BANDS, bool EXACT, bool VEC, bool COMPACT>
 __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                   uint8_t* __restrict__ out, long out_stride, long out_sstride, int w, int h,
                                                   const float* __restrict__ bandA, const float* __restrict__ resn, int nw,
@@ -855,7 +879,7 @@ __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in
     __shared__ __attribute__((aligned(16))) float s_igt[4096];
     __shared__ float s_gam[256];
     __shared__ __attribute__((aligned(16))) float sb[CSH][CSP];
-    __shared__ __attribute__((aligned(16))) float su[CSH][CSP];
+    __shared__ __attribute__((aligned(16))) CollapseTile<COMPACT> su;
     load_invgamma(s_igt, lab.invgamma);
     load_gamma_u8(s_gam, lab.gamma_u8);
     __syncthreads();
@@ -941,6 +965,7 @@ struct RieszState : ModeState {
     bool inited = false;
     bool split_rows = true;          // LDS-free wave-strip split (LVM_RZ_SPLIT_ROWS=0: the tiled kernels) ...
     long split_rows_min = 1L << 25;  // ... for launches of at least this many plane-pixels (LVM_RZ_SPLIT_ROWS_MIN); below, the tiled kernels measure equal or faster
+    bool compact = true;             // compact zero-injected tile in the collapse kernels (LVM_RZ_COMPACT=0: the full 24 x 72 tile)
     bool split2 = true;              // 64 x 32 tiles with 4 x 2 outputs per thread in the 9x9 split (LVM_RZ_SPLIT2=0: k_rz_split)
     bool blur4 = true;               // register-blocked Gaussian/amplify kernel on the large levels (LVM_RZ_BLUR4=0: scalar kernel everywhere)
     double lo_freq = 0, hi_freq = 0, fps = 0;
@@ -1080,7 +1105,9 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
     for (int l = nb - 1; l >= 1; --l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
         const dim3 grid((a.w + CW - 1) / CW, (a.h + CH - 1) / CH, NZ);
-        LVM_LAUNCH(c, LName("rz_collapse", l), k_rz_collapse, grid, blk, s, (const float*)B.pf[l][F_BANDA], resn, B.res[l], a.w, a.h, b.w, b.h);
+        const bool compact = st->compact && a.w % 2 == 0 && a.h % 2 == 0;
+        LVM_LAUNCH(c, LName("rz_collapse", l), compact ? k_rz_collapse<true> : k_rz_collapse<false>, grid, blk, s, (const float*)B.pf[l][F_BANDA], resn,
+                   B.res[l], a.w, a.h, b.w, b.h);
         resn = B.res[l];
     }
     const int tx = (w + CW - 1) / CW, ty = (h + CH - 1) / CH;
@@ -1090,10 +1117,13 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
     const bool vec = w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && io.out_stride % 4 == 0 &&
                      io.out_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0 && ((uintptr_t)io.d_out % 4) == 0;
     const bool ex = c->exact_lab;
-    auto kfb = vec ? (ex ? k_rz_final<true, true, true> : k_rz_final<true, false, true>)
-                   : (ex ? k_rz_final<true, true, false> : k_rz_final<true, false, false>);
-    auto kfn = vec ? (ex ? k_rz_final<false, true, true> : k_rz_final<false, false, true>)
-                   : (ex ? k_rz_final<false, true, false> : k_rz_final<false, false, false>);
+    const bool compact = st->compact && w % 2 == 0 && h % 2 == 0;
+    auto kfb = compact ? (vec ? (ex ? k_rz_final<true, true, true, true> : k_rz_final<true, false, true, true>)
+                              : (ex ? k_rz_final<true, true, false, true> : k_rz_final<true, false, false, true>))
+                       : (vec ? (ex ? k_rz_final<true, true, true, false> : k_rz_final<true, false, true, false>)
+                              : (ex ? k_rz_final<true, true, false, false> : k_rz_final<true, false, false, false>));
+    auto kfn = vec ? (ex ? k_rz_final<false, true, true, true> : k_rz_final<false, false, true, true>)
+                   : (ex ? k_rz_final<false, true, false, true> : k_rz_final<false, false, false, true>);
     if (nb >= 1)
         LVM_LAUNCH(c, "rz_final", kfb, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
                    (long)io.out_stride, (long)io.out_sstride, w, h, (const float*)B.pf[0][F_BANDA], resn, st->g[1].w, st->g[1].h,
@@ -1112,6 +1142,7 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         st = new RieszState();
         if (const char* e = std::getenv("LVM_RZ_BLUR4")) st->blur4 = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_RZ_SPLIT2")) st->split2 = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_RZ_COMPACT")) st->compact = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_RZ_SPLIT_ROWS")) st->split_rows = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_RZ_SPLIT_ROWS_MIN")) st->split_rows_min = std::atol(e);
         c->state = st;

@@ -56,7 +56,7 @@ def test_laplace_emu_two_streams_are_independent(lvm, po, emu):
 
 
 # ---- Riesz (phase) ---------------------------------------------------------------------------------
-@pytest.mark.parametrize("w,h,levels", [(96, 64, 3), (135, 77, 4), (64, 48, 1), (67, 131, 2), (160, 90, 5)])
+@pytest.mark.parametrize("w,h,levels", [(96, 64, 3), (135, 77, 4), (64, 48, 1), (67, 131, 2), (160, 90, 5), (134, 78, 2)])
 def test_riesz_emu_bit_exact(lvm, po, emu, w, h, levels):
     ck, pk = lvm.synth.config(2, (w, h, levels))
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 6, 0.0, exact=True)
@@ -69,6 +69,15 @@ def test_riesz_emu_register_blocked_blur(lvm, po, emu, blur4, monkeypatch):
     monkeypatch.setenv("LVM_RZ_BLUR4", blur4)
     ck, pk = lvm.synth.config(2, (264, 150, 3))
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0, exact=True)
+
+
+@pytest.mark.parametrize("compact", ["1", "0"])
+def test_riesz_emu_collapse_tile_variants(lvm, po, emu, compact, monkeypatch):
+    """The collapse kernels' zero-injected tile, compact (even rows / columns only; planes with even width and height) and
+    full: interior (vector-staged) and border tiles on level 0, a plane with an odd height on level 1."""
+    monkeypatch.setenv("LVM_RZ_COMPACT", compact)
+    ck, pk = lvm.synth.config(2, (264, 150, 3))
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 3, 0.0, exact=True)
 
 
 def test_riesz_emu_cutoff_change_gray_and_reset(lvm, po, emu):

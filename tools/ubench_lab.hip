@@ -85,7 +85,7 @@ __device__ __forceinline__ f2 cbrt2(f2 x) {
     return r;
 }
 __device__ __forceinline__ f2 sel2(f2 x, float thr, f2 a, f2 b) { f2 r; r.x = x.x > thr ? a.x : b.x; r.y = x.y > thr ? a.y : b.y; return r; }
-__device__ __forceinline__ void lab_fwd_pair(f2 B, f2 G, f2 R, const float* fw, f2& L, f2& a, f2& b) {
+__device__ __forceinline__ void ub_fwd_pair(f2 B, f2 G, f2 R, const float* fw, f2& L, f2& a, f2& b) {
     const f2 X = fma2(B, splat(fw[0]), fma2(G, splat(fw[1]), R * splat(fw[2])));
     const f2 Y = fma2(B, splat(fw[3]), fma2(G, splat(fw[4]), R * splat(fw[5])));
     const f2 Z = fma2(B, splat(fw[6]), fma2(G, splat(fw[7]), R * splat(fw[8])));
@@ -105,7 +105,7 @@ __device__ __forceinline__ f2 spline2(f2 x, const float* tab) {
     return fma2(fma2(fma2(w, fr, z), fr, y), fr, xx);
 }
 __device__ __forceinline__ f2 clip2(f2 v) { f2 r; r.x = clip1024_open(v.x); r.y = clip1024_open(v.y); return r; }
-__device__ __forceinline__ void lab_inv_pair(f2 L, f2 a, f2 b, const float* iv, const float* igt, f2& o0, f2& o1, f2& o2) {
+__device__ __forceinline__ void ub_inv_pair(f2 L, f2 a, f2 b, const float* iv, const float* igt, f2& o0, f2& o1, f2& o2) {
     const float lThresh = 0.008856f * 903.3f, fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
     const f2 ylin = L * splat(1.0f / 903.3f), fyc = (L + splat(16.0f)) * splat(1.0f / 116.0f);
     const f2 fyl = fma2(splat(7.787f), ylin, splat(16.0f / 116.0f));
@@ -130,10 +130,10 @@ template <int VARIANT, int WHAT>
 __global__ __launch_bounds__(512) void k_lab(unsigned* out, LabCoef lab, unsigned seed, float mscale) {
     __shared__ __attribute__((aligned(16))) float s_igt[4096];
     __shared__ float s_gam[256];
-    for (int i = threadIdx.x; i < 1024; i += 512) reinterpret_cast<float4*>(s_igt)[i] = reinterpret_cast<const float4*>(lab.invgamma)[i];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) reinterpret_cast<float4*>(s_igt)[i] = reinterpret_cast<const float4*>(lab.invgamma)[i];
     if (threadIdx.x < 256) s_gam[threadIdx.x] = lab.gamma_u8[threadIdx.x];
     __syncthreads();
-    unsigned st = seed ^ (blockIdx.x * 512u + threadIdx.x) * 2654435761u;
+    unsigned st = seed ^ (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u;
     unsigned acc = 0;
     for (int it = 0; it < ITERS; ++it) {
         Px4 pin;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(512) void k_lab(unsigned* out, LabCoef lab, unsigne
             for (int k = 0; k < 4; k += 2) {
                 f2 Bp, Gp, Rp, Lp, Ap, Bq;
                 Bp.x = s_gam[Bv[k]]; Bp.y = s_gam[Bv[k + 1]]; Gp.x = s_gam[Gv[k]]; Gp.y = s_gam[Gv[k + 1]]; Rp.x = s_gam[Rv[k]]; Rp.y = s_gam[Rv[k + 1]];
-                lab_fwd_pair(Bp, Gp, Rp, lab.fwd, Lp, Ap, Bq);
+                ub_fwd_pair(Bp, Gp, Rp, lab.fwd, Lp, Ap, Bq);
                 L[k] = Lp.x; L[k + 1] = Lp.y; A[k] = Ap.x; A[k + 1] = Ap.y; Bb[k] = Bq.x; Bb[k + 1] = Bq.y;
             }
         } else {
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512) void k_lab(unsigned* out, LabCoef lab, unsigne
             for (int k = 0; k < 4; k += 2) {
                 f2 Lp, Ap, Bq, o0, o1, o2;
                 Lp.x = L[k]; Lp.y = L[k + 1]; Ap.x = A[k]; Ap.y = A[k + 1]; Bq.x = Bb[k]; Bq.y = Bb[k + 1];
-                lab_inv_pair(Lp, Ap, Bq, lab.inv1024, s_igt, o0, o1, o2);
+                ub_inv_pair(Lp, Ap, Bq, lab.inv1024, s_igt, o0, o1, o2);
                 ov[3 * k] = o0.x; ov[3 * k + 1] = o1.x; ov[3 * k + 2] = o2.x; ov[3 * k + 3] = o0.y; ov[3 * k + 4] = o1.y; ov[3 * k + 5] = o2.y;
             }
         } else {
@@ -224,6 +224,25 @@ int main() {
         const double ns_px = (double)best * 1e6 / (4.0 * ITERS * 4);
         printf("%-48s %8.3f ms  %7.3f ns per wave-pixel per SIMD (%.1f cycles at 2.4 GHz) -> a 1080p frame: %.2f us\n", e.name, best, ns_px,
                ns_px * 2.4, ns_px * 1920.0 * 1080.0 / 64.0 / 1024.0 * 1e-3);
+    }
+    // occupancy sweep (round 2, late): the same arithmetic with W = 1, 2, 4, 8 waves per SIMD (W workgroups of 256 threads per CU).
+    // What a kernel that owns its pixels for a whole temporal batch (IIR state in registers) would get from a single stream.
+    for (int W : {1, 2, 4, 8}) {
+        for (int which = 0; which < 2; ++which) {
+            auto k = which ? k_lab<0, 1> : k_lab<0, 0>;
+            float best = 1e30f;
+            for (int rep = 0; rep < 4; ++rep) {
+                (void)hipEventRecord(e0, 0);
+                hipLaunchKernelGGL(k, dim3(256 * W), dim3(256), 0, 0, dout, lab, 12345u, 0.01f);
+                (void)hipEventRecord(e1, 0);
+                (void)hipEventSynchronize(e1);
+                float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+                if (rep && ms < best) best = ms;
+            }
+            const double ns_px = (double)best * 1e6 / ((double)W * ITERS * 4);
+            printf("W = %d waves per SIMD, %s kernel colour math: %8.3f ms  %7.3f ns per wave-pixel per SIMD -> a 1080p frame: %.2f us\n", W,
+                   which ? "first" : "last", best, ns_px, ns_px * 1920.0 * 1080.0 / 64.0 / 1024.0 * 1e-3);
+        }
     }
     return 0;
 }

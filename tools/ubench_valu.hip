@@ -108,6 +108,24 @@ __global__ __launch_bounds__(256) void k_lds(float* out, const unsigned* idx, in
     if (s == 12345.678f) out[0] = s;
 }
 
+// occupancy x ILP sweep: C independent v_fma_f32 chains per lane, launched with W waves per SIMD
+template <int C>
+__global__ __launch_bounds__(256) void k_fma_ilp(float* out, float a, float b) {
+    float r[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) r[k] = a * (threadIdx.x + k) + b;
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 16 / C; ++rep)
+#pragma unroll
+            for (int k = 0; k < C; ++k) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[k]) : "v"(a), "v"(b));
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < C; ++k) s += r[k];
+    if (s == 12345.678f) out[0] = s;
+}
+
 typedef void (*kern_t)(float*, float, float);
 struct Entry { const char* name; kern_t k; };
 
@@ -148,6 +166,25 @@ int main() {
         const double per = (double)best * 1e6 / (8.0 * ITERS * CHAINS);     // ns per wave-instruction per SIMD
         if (base == 0) base = per;
         printf("%-26s %8.3f ms  %6.3f ns/wave-instr/SIMD  x%.2f of v_fma_f32  (%.2f cycles at 2.4 GHz)\n", e.name, best, per, per / base, per * 2.4);
+    }
+    // occupancy x ILP: ns per wave-instruction per SIMD when a SIMD holds W waves of C independent chains each
+    {
+        kern_t ks[5] = {k_fma_ilp<1>, k_fma_ilp<2>, k_fma_ilp<4>, k_fma_ilp<8>, k_fma_ilp<16>};
+        const int cs[5] = {1, 2, 4, 8, 16};
+        for (int W : {1, 2, 4, 8}) {
+            for (int ci = 0; ci < 5; ++ci) {
+                float best = 1e30f;
+                for (int rep = 0; rep < 3; ++rep) {
+                    hipEventRecord(e0, 0);
+                    hipLaunchKernelGGL(ks[ci], dim3(cus * W), dim3(256), 0, 0, d_out, 1.0001f, 0.5f);
+                    hipEventRecord(e1, 0);
+                    hipEventSynchronize(e1);
+                    float ms; hipEventElapsedTime(&ms, e0, e1);
+                    if (rep && ms < best) best = ms;
+                }
+                printf("v_fma_f32  W = %d waves/SIMD, %2d chains: %7.3f ns per wave-instr per SIMD\n", W, cs[ci], (double)best * 1e6 / ((double)W * ITERS * 16));
+            }
+        }
     }
     // LDS lookups
     std::vector<unsigned> h(1 << 16);
