@@ -619,6 +619,9 @@ constexpr int FIN_THREADS = 512;
 #define LVM_FIN_PAIRS 0          // default flavour of the last kernel: colour arithmetic on explicit pixel pairs (0: per pixel)
 #endif
 struct Row3 { float4 c[3]; };            // horizontal-pass results of one source row, 3 channels x 4 columns
+#ifndef LVM_FIN_FSPACE
+#define LVM_FIN_FSPACE 1         // default flavour: add the motion image in (fX, fY, fZ) instead of Lab (lvm_internal.h)
+#endif
 #ifndef LVM_FIN_WAVES
 #define LVM_FIN_WAVES 0          // minimum waves per SIMD asked of the register allocator (0: none; 121 VGPRs = 4 waves)
 #endif
@@ -674,7 +677,9 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, lo
                 const float sm1 = *reinterpret_cast<const float*>(rc + cm1), s0 = *reinterpret_cast<const float*>(rc + c00),
                             s1 = *reinterpret_cast<const float*>(rc + cp1), s2 = *reinterpret_cast<const float*>(rc + cp2);
                 if (EXACT) o.c[c] = pyrup_h4(sm1, s0, s1, s2, i0, w1);
-                else { o.c[c].x = sm1 + s0 * 6.f + s1; o.c[c].y = (s0 + s1) * 4.f; o.c[c].z = s0 + s1 * 6.f + s2; o.c[c].w = (s1 + s2) * 4.f; }
+                else if (LVM_FAST_FMA) {   // one rounding less per even column (fma), a few 1e-8 of the motion image
+                    o.c[c].x = __builtin_fmaf(s0, 6.f, sm1 + s1); o.c[c].y = (s0 + s1) * 4.f; o.c[c].z = __builtin_fmaf(s1, 6.f, s0 + s2); o.c[c].w = (s1 + s2) * 4.f;
+                } else { o.c[c].x = sm1 + s0 * 6.f + s1; o.c[c].y = (s0 + s1) * 4.f; o.c[c].z = s0 + s1 * 6.f + s2; o.c[c].w = (s1 + s2) * 4.f; }
             }
             return o;
         };
@@ -714,6 +719,19 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, lo
             } else
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+                float o0, o1, o2;
+                if (!EXACT && LVM_FIN_FSPACE) {
+                    // default flavour: the motion image is added in (fX, fY, fZ), see lvm_internal.h
+                    float fx, fy, fz;
+                    lin_bgr_to_fxyz(s_gam[Bv[k]], s_gam[Gv[k]], s_gam[Rv[k]], lab.fwd, fx, fy, fz);
+                    if (MOTION) {
+                        const float k0 = msc * (1.0f / 116.0f), k1 = msc * ca * (1.0f / 500.0f), k2 = -(msc * ca * (1.0f / 200.0f));
+                        fx = __builtin_fmaf(m[1][k], k1, __builtin_fmaf(m[0][k], k0, fx));
+                        fz = __builtin_fmaf(m[2][k], k2, __builtin_fmaf(m[0][k], k0, fz));
+                        fy = __builtin_fmaf(m[0][k], k0, fy);
+                    }
+                    fxyz_to_bgr(fx, fy, fz, lab.inv1024, s_igt, o0, o1, o2);
+                } else {
                 float L, a, bb;
                 lin_bgr_to_lab<EXACT>(s_gam[Bv[k]], s_gam[Gv[k]], s_gam[Rv[k]], lab.fwd, L, a, bb);
                 if (MOTION) {
@@ -723,8 +741,8 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, lo
                         a = __builtin_fmaf(m[1][k], msc * ca, a); bb = __builtin_fmaf(m[2][k], msc * ca, bb);
                     }
                 }
-                float o0, o1, o2;
                 lab_to_bgr<EXACT>(L, a, bb, EXACT ? lab.inv : lab.inv1024, s_igt, o0, o1, o2);
+                }
                 if (dbg && b == 0) { float* d = dbg + ((size_t)gy * w + gx + k) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
                 if (EXACT) {
                     ov[3 * k] = o0 * 255.0f + lab.a255; ov[3 * k + 1] = o1 * 255.0f + lab.a255; ov[3 * k + 2] = o2 * 255.0f + lab.a255;
@@ -751,6 +769,11 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, lo
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float sc = EXACT ? (1.f / 64.f) : 1.f;           // (x * 1.f folds away)
+                    if (!EXACT && LVM_FAST_FMA) {
+                        m[c][0] = __builtin_fmaf(B.c[c].x, 6.f, A.c[c].x + C.c[c].x); m[c][1] = __builtin_fmaf(B.c[c].y, 6.f, A.c[c].y + C.c[c].y);
+                        m[c][2] = __builtin_fmaf(B.c[c].z, 6.f, A.c[c].z + C.c[c].z); m[c][3] = __builtin_fmaf(B.c[c].w, 6.f, A.c[c].w + C.c[c].w);
+                        continue;
+                    }
                     m[c][0] = (A.c[c].x + B.c[c].x * 6.f + C.c[c].x) * sc; m[c][1] = (A.c[c].y + B.c[c].y * 6.f + C.c[c].y) * sc;
                     m[c][2] = (A.c[c].z + B.c[c].z * 6.f + C.c[c].z) * sc; m[c][3] = (A.c[c].w + B.c[c].w * 6.f + C.c[c].w) * sc;
                 }

@@ -57,6 +57,9 @@ __device__ __forceinline__ float dpp_shl1(float v) { return __int_as_float(__bui
 
 // Lab conversion tables/coefficients (reference: MagnifyCore.hpp:90,152,219,275 call
 // cv::cvtColor COLOR_BGR2Lab / COLOR_Lab2BGR on float [0,1]; OpenCV 4 color_lab.cpp float path).
+#ifndef LVM_FAST_FMA
+#define LVM_FAST_FMA 1      // default (non-exact) flavour: pyramid tap sums of the first / last kernels as fma chains
+#endif
 struct LabCoef {
     float fwd[9];             // BGR(linear) -> XYZ/white, row-major, column 0 multiplies B
     float inv[9];             // XYZ -> BGR(linear), row 0 produces B
@@ -191,6 +194,39 @@ __device__ __forceinline__ void lab_to_bgr(float li, float ai, float bi, const f
         o1 = spline1024<false>(clip1024_open(c1), igt);
         o2 = spline1024<false>(clip1024_open(c2), igt);
     }
+}
+// ---- the default flavour's last-kernel arithmetic without the detour through (L, a, b) ---------------------------------
+// Lab is affine in (f(X), f(Y), f(Z)): L = 116 fY - 16, a = 500 (fX - fY), b = 200 (fY - fZ), and Lab2RGB starts by undoing
+// exactly that: fy = (L + 16) / 116, fx = a / 500 + fy, fz = fy - b / 200.  Adding a motion image (mL, ma, mb) in Lab and
+// converting back is therefore the same as adding (mL / 116 + ma / 500, mL / 116, mL / 116 - mb / 200) to (fX, fY, fZ):
+// 20 operations per pixel between the forward cube roots and the inverse matrix instead of 31 (no L / a / b, no second
+// affine map, one fma for the linear branch of f^-1).  Below the CIE threshold the reference's y = L / 903.3 becomes
+// (fy - 16/116) / 7.787 = L / 903.292: 9e-6 of a linear-light value < 0.009.  Results move by a few 1e-7 relative (fma
+// roundings); the exact flavour keeps the Lab form.
+__device__ __forceinline__ void lin_bgr_to_fxyz(float B, float G, float R, const float* fw, float& FX, float& FY, float& FZ) {
+    const float _a = 16.0f / 116.0f;
+    const float X = __builtin_fmaf(B, fw[0], __builtin_fmaf(G, fw[1], R * fw[2]));
+    const float Y = __builtin_fmaf(B, fw[3], __builtin_fmaf(G, fw[4], R * fw[5]));
+    const float Z = __builtin_fmaf(B, fw[6], __builtin_fmaf(G, fw[7], R * fw[8]));
+    const float cx = lab_cbrt<false>(X), cy = lab_cbrt<false>(Y), cz = lab_cbrt<false>(Z);
+    FX = X > 0.008856f ? cx : __builtin_fmaf(7.787f, X, _a);
+    FY = Y > 0.008856f ? cy : __builtin_fmaf(7.787f, Y, _a);
+    FZ = Z > 0.008856f ? cz : __builtin_fmaf(7.787f, Z, _a);
+}
+__device__ __forceinline__ float lab_finv(float f) {
+    const float fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
+    const float lin = __builtin_fmaf(f, 1.0f / 7.787f, -(16.0f / 116.0f) / 7.787f), cube = f * f * f;
+    return f <= fThresh ? lin : cube;
+}
+// (fx, fy, fz) -> BGR through the inverse matrix (iv = inv1024) and the inverse-gamma spline
+__device__ __forceinline__ void fxyz_to_bgr(float fx, float fy, float fz, const float* iv, const float* igt, float& o0, float& o1, float& o2) {
+    const float x = lab_finv(fx), y = lab_finv(fy), z = lab_finv(fz);
+    const float c0 = __builtin_fmaf(iv[0], x, __builtin_fmaf(iv[1], y, iv[2] * z));
+    const float c1 = __builtin_fmaf(iv[3], x, __builtin_fmaf(iv[4], y, iv[5] * z));
+    const float c2 = __builtin_fmaf(iv[6], x, __builtin_fmaf(iv[7], y, iv[8] * z));
+    o0 = spline1024<false>(clip1024_open(c0), igt);
+    o1 = spline1024<false>(clip1024_open(c1), igt);
+    o2 = spline1024<false>(clip1024_open(c2), igt);
 }
 // ---- pixel-pair forms of the default flavour (round 2) -----------------------------------------------------------
 // The same operations as lin_bgr_to_lab<false> / lab_to_bgr<false>, two pixels at a time on <2 x float> values: every

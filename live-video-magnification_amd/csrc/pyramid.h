@@ -332,8 +332,13 @@ __global__ __launch_bounds__(D0R_THREADS) void k_down0_rows(const uint8_t* __res
             // Mirrored groups: pixels -2, -1 are pixels 2, 1 of group 0; pixel w is pixel w-2 = pixel 2 of the last group.
             const float give2 = P[c][2], give3 = left_mirror ? P[c][1] : P[c][3], give0 = right_mirror ? P[c][2] : P[c][0];
             const float L2 = dpp_shr1(give2), L3 = dpp_shr1(give3), R0 = dpp_shl1(give0);
-            ha[c] = P[c][0] * 6.f + (L3 + P[c][1]) * 4.f + L2 + P[c][2];
-            hb[c] = P[c][2] * 6.f + (P[c][1] + P[c][3]) * 4.f + P[c][0] + R0;
+            if (!EXACT && LVM_FAST_FMA) {   // default flavour: the same sum as two fmas (two roundings less)
+                ha[c] = __builtin_fmaf(P[c][0], 6.f, __builtin_fmaf(L3 + P[c][1], 4.f, L2 + P[c][2]));
+                hb[c] = __builtin_fmaf(P[c][2], 6.f, __builtin_fmaf(P[c][1] + P[c][3], 4.f, P[c][0] + R0));
+            } else {
+                ha[c] = P[c][0] * 6.f + (L3 + P[c][1]) * 4.f + L2 + P[c][2];
+                hb[c] = P[c][2] * 6.f + (P[c][1] + P[c][3]) * 4.f + P[c][0] + R0;
+            }
         }
     };
     const int yend = oy0 + rows < h1 ? oy0 + rows : h1;
@@ -346,8 +351,14 @@ __global__ __launch_bounds__(D0R_THREADS) void k_down0_rows(const uint8_t* __res
         if (owner) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float va = (a2[c] * 6.f + (a1[c] + a3[c]) * 4.f + a0[c] + a4[c]) * (1.f / 256.f);
-                const float vb = (b2[c] * 6.f + (b1[c] + b3[c]) * 4.f + b0[c] + b4[c]) * (1.f / 256.f);
+                float va, vb;
+                if (!EXACT && LVM_FAST_FMA) {
+                    va = __builtin_fmaf(a2[c], 6.f, __builtin_fmaf(a1[c] + a3[c], 4.f, a0[c] + a4[c])) * (1.f / 256.f);
+                    vb = __builtin_fmaf(b2[c], 6.f, __builtin_fmaf(b1[c] + b3[c], 4.f, b0[c] + b4[c])) * (1.f / 256.f);
+                } else {
+                    va = (a2[c] * 6.f + (a1[c] + a3[c]) * 4.f + a0[c] + a4[c]) * (1.f / 256.f);
+                    vb = (b2[c] * 6.f + (b1[c] + b3[c]) * 4.f + b0[c] + b4[c]) * (1.f / 256.f);
+                }
                 *reinterpret_cast<float2*>(dst + c * plane + (size_t)oy * w1 + ox) = make_float2(va, vb);
             }
         }

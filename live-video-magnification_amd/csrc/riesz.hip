@@ -926,6 +926,8 @@ __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in
                 lin_bgr_to_lab<EXACT || !BANDS>(s_gam[pb[3 * m]], s_gam[pb[3 * m + 1]], s_gam[pb[3 * m + 2]], lab.fwd, L, a, bb);
                 if (BANDS) L = Lc[m];
                 float o0, o1, o2;
+                // (skipping the detour through (a, b) as the last Laplace kernel does -- fx = fX + (fy - fY), fz = fZ + (fy - fY),
+                //  lvm_internal.h -- was measured here too: 480 us either way, this kernel is bound by its 9x9 stencils)
                 lab_to_bgr<EXACT>(L, a, bb, EXACT ? lab.inv : lab.inv1024, s_igt, o0, o1, o2);
                 if (dbg && b == 0 && gx + m < w) { float* d = dbg + ((size_t)gy * w + gx + m) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
                 ob[3 * m] = sat_u8(o0 * 255.0f + lab.a255);
