@@ -630,7 +630,7 @@ struct Row3 { float4 c[3]; };            // horizontal-pass results of one sourc
 #else
 #define LVM_FIN_BOUNDS __launch_bounds__(FIN_THREADS)
 #endif
-template <bool MOTION, bool EXACT>
+template <bool MOTION, bool EXACT, bool DBG>     // DBG: also store the float frame (lvm_debug_keep_float); a per-pixel branch
 __global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                        uint8_t* __restrict__ out, long out_stride, long out_sstride,
                                                        int w, int h, const float* __restrict__ cur1, int w1, int h1,
@@ -708,7 +708,7 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, lo
                         Lp = pk_fma(m0, pk_splat(msc), Lp); Ap = pk_fma(m1, pk_splat(msc * ca), Ap); Bq = pk_fma(m2, pk_splat(msc * ca), Bq);
                     }
                     lab_inv_pair(Lp, Ap, Bq, lab.inv1024, s_igt, o0, o1, o2);
-                    if (dbg && b == 0) {
+                    if (DBG && dbg && b == 0) {
                         float* d = dbg + ((size_t)gy * w + gx + k) * 3;
                         d[0] = o0.x; d[1] = o1.x; d[2] = o2.x; d[3] = o0.y; d[4] = o1.y; d[5] = o2.y;
                     }
@@ -743,7 +743,7 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, lo
                 }
                 lab_to_bgr<EXACT>(L, a, bb, EXACT ? lab.inv : lab.inv1024, s_igt, o0, o1, o2);
                 }
-                if (dbg && b == 0) { float* d = dbg + ((size_t)gy * w + gx + k) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
+                if (DBG && dbg && b == 0) { float* d = dbg + ((size_t)gy * w + gx + k) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
                 if (EXACT) {
                     ov[3 * k] = o0 * 255.0f + lab.a255; ov[3 * k + 1] = o1 * 255.0f + lab.a255; ov[3 * k + 2] = o2 * 255.0f + lab.a255;
                 } else {   // fma(o, 255, 1/255) differs from mul + add only far below the rounding step
@@ -1254,8 +1254,10 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     const float* cur1 = motion ? ((use_tail && st->tailT == 1) ? B.curT : B.cur[1]) : nullptr;
     const int w1 = st->g[1].w, h1 = st->g[1].h;
     float* dbg = c->keep_float ? c->d_float : nullptr;
-    auto kf4 = motion ? (c->exact_lab ? k_lap_final_v4<true, true> : k_lap_final_v4<true, false>)
-                      : (c->exact_lab ? k_lap_final_v4<false, true> : k_lap_final_v4<false, false>);
+    auto kf4 = dbg ? (motion ? (c->exact_lab ? k_lap_final_v4<true, true, true> : k_lap_final_v4<true, false, true>)
+                             : (c->exact_lab ? k_lap_final_v4<false, true, true> : k_lap_final_v4<false, false, true>))
+                   : (motion ? (c->exact_lab ? k_lap_final_v4<true, true, false> : k_lap_final_v4<true, false, false>)
+                             : (c->exact_lab ? k_lap_final_v4<false, true, false> : k_lap_final_v4<false, false, false>));
     auto kf = (C == 3) ? (motion ? (c->exact_lab ? k_lap_final<3, true, true> : k_lap_final<3, true, false>)
                                  : (c->exact_lab ? k_lap_final<3, false, true> : k_lap_final<3, false, false>))
                        : (motion ? k_lap_final<1, true, true> : k_lap_final<1, false, true>);

@@ -25,6 +25,7 @@
 //   k_rz_final                       level-0 collapse + Lab2BGR(L', a, b) -> u8
 // Summation order of every filter equals the oracle's (row-major non-zero taps, fma chain).
 #include <cmath>
+#include <type_traits>
 
 #include "lvm_internal.h"
 
@@ -870,7 +871,7 @@ __global__ __launch_bounds__(256) void k_rz_collapse(const float* __restrict__ b
 // level-0 collapse (or plain L plane when there are no bands) + Lab2BGR + u8 (MagnifyCore.hpp:272-277).
 // 4 pixels per thread; VEC = the frame's 4-pixel groups are dword aligned (12-byte loads/stores).
 struct __attribute__((packed, aligned(4))) RzPx4 { uint32_t a, b, c; };
-template <bool BANDS, bool EXACT, bool VEC, bool COMPACT>
+template <bool BANDS, bool EXACT, bool VEC, bool COMPACT, bool DBG>   // DBG: also store the float frame (compile time: no per-pixel branch otherwise)
 __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                   uint8_t* __restrict__ out, long out_stride, long out_sstride, int w, int h,
                                                   const float* __restrict__ bandA, const float* __restrict__ resn, int nw,
@@ -929,7 +930,7 @@ __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in
                 // (skipping the detour through (a, b) as the last Laplace kernel does -- fx = fX + (fy - fY), fz = fZ + (fy - fY),
                 //  lvm_internal.h -- was measured here too: 480 us either way, this kernel is bound by its 9x9 stencils)
                 lab_to_bgr<EXACT>(L, a, bb, EXACT ? lab.inv : lab.inv1024, s_igt, o0, o1, o2);
-                if (dbg && b == 0 && gx + m < w) { float* d = dbg + ((size_t)gy * w + gx + m) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
+                if (DBG && dbg && b == 0 && gx + m < w) { float* d = dbg + ((size_t)gy * w + gx + m) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
                 ob[3 * m] = sat_u8(o0 * 255.0f + lab.a255);
                 ob[3 * m + 1] = sat_u8(o1 * 255.0f + lab.a255);
                 ob[3 * m + 2] = sat_u8(o2 * 255.0f + lab.a255);
@@ -1120,12 +1121,19 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
                      io.out_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0 && ((uintptr_t)io.d_out % 4) == 0;
     const bool ex = c->exact_lab;
     const bool compact = st->compact && w % 2 == 0 && h % 2 == 0;
-    auto kfb = compact ? (vec ? (ex ? k_rz_final<true, true, true, true> : k_rz_final<true, false, true, true>)
-                              : (ex ? k_rz_final<true, true, false, true> : k_rz_final<true, false, false, true>))
-                       : (vec ? (ex ? k_rz_final<true, true, true, false> : k_rz_final<true, false, true, false>)
-                              : (ex ? k_rz_final<true, true, false, false> : k_rz_final<true, false, false, false>));
-    auto kfn = vec ? (ex ? k_rz_final<false, true, true, true> : k_rz_final<false, false, true, true>)
-                   : (ex ? k_rz_final<false, true, false, true> : k_rz_final<false, false, false, true>);
+    // (BANDS, EXACT, VEC, COMPACT, DBG) -> instantiation
+    auto pick = [&](auto bands) {
+        constexpr bool BN = decltype(bands)::value;
+        auto p3 = [&](auto e, auto v, auto cp) {
+            constexpr bool E = decltype(e)::value, V = decltype(v)::value, CP = decltype(cp)::value;
+            return dbg ? k_rz_final<BN, E, V, CP, true> : k_rz_final<BN, E, V, CP, false>;
+        };
+        auto p2 = [&](auto e, auto v) { return (compact && BN) ? p3(e, v, std::true_type{}) : p3(e, v, std::false_type{}); };
+        auto p1 = [&](auto e) { return vec ? p2(e, std::true_type{}) : p2(e, std::false_type{}); };
+        return ex ? p1(std::true_type{}) : p1(std::false_type{});
+    };
+    auto kfb = pick(std::true_type{});
+    auto kfn = pick(std::false_type{});
     if (nb >= 1)
         LVM_LAUNCH(c, "rz_final", kfb, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
                    (long)io.out_stride, (long)io.out_sstride, w, h, (const float*)B.pf[0][F_BANDA], resn, st->g[1].w, st->g[1].h,
