@@ -439,6 +439,7 @@ def main():
         R.ctx.flush(stream)
         R.ctx.set_pipeline(0)           # per-kernel event timing uses the plain schedule
         R.run((-R.n) % T)               # whole calls
+        R.run(2 * T if T > 1 else 60)   # un-timed: the oracle replay above left the GPU idle for seconds, let the clocks settle
         R.ctx.profile(True)
         R.run(args.profile_steps)
         torch.cuda.synchronize()
@@ -453,6 +454,21 @@ def main():
                              "alg_bytes": ab, "gbs": (round(ab / (avg_us * 1e-6) / 1e9, 1) if ab else None)}
         dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
         k = kernels[dom]
+        # the dominant kernel once more with ONLY its launches bracketed: its neighbours then run back to back as in the
+        # timed region (and under rocprofv3); with an event gap on both sides the VALU-bound kernels run ~10 % faster
+        # (the clock recovers in the gaps), which is not the duration the frame pays for
+        R.ctx.profile_only(dom)
+        R.ctx.profile(True)
+        R.run(args.profile_steps)
+        torch.cuda.synchronize()
+        solo = R.ctx.profile_collect().get(dom)
+        R.ctx.profile(False)
+        R.ctx.profile_only(None)
+        k = dict(k)
+        k["avg_us_all_bracketed"] = k["avg_us"]
+        if solo and solo[1]:
+            k["avg_us"] = round(1e3 * solo[0] / solo[1], 3)
+            k["gbs"] = round(k["alg_bytes"] / (k["avg_us"] * 1e-6) / 1e9, 1) if k["alg_bytes"] else None
         # HBM bytes per launch from the PMC counters (separate rocprofv3 passes, committed under profiles/)
         traffic = None
         rocprof_avg = None
@@ -466,7 +482,9 @@ def main():
         if k["gbs"]:
             roofline = {"bound": "hbm", "kernel": dom, "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(k["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "avg_us": k["avg_us"], "alg_bytes_per_launch": k["alg_bytes"]}
+                        "avg_us": k["avg_us"], "avg_us_all_kernels_bracketed": k["avg_us_all_bracketed"],
+                        "timing": "HIP events on the launch stream around this kernel only (neighbours back to back)",
+                        "alg_bytes_per_launch": k["alg_bytes"]}
             if rocprof_avg is not None:
                 roofline["rocprof_avg_us"] = rocprof_avg
     b_alg = lvm.load().lvm_algorithmic_bytes(pk["mode"], w, h, ch, levels, pk["framerate"])

@@ -208,6 +208,11 @@ int  lvm_debug_exact_lab(lvm_ctx* ctx, int on);
  * into per-kernel totals, readable with lvm_profile_entry (idx = 0..n-1).                   */
 int  lvm_profile_enable(lvm_ctx* ctx, int on);
 int  lvm_profile_collect(lvm_ctx* ctx);
+/* Clears the totals and restricts the bracketing to launches with this report name (NULL or "": all launches).  With
+ * one kernel bracketed its neighbours run back to back, as they do outside the profiling pass: the VALU-bound kernels
+ * take ~10 % longer that way than with an event gap on both sides (the clock recovers in the gaps), and that is the
+ * duration rocprofv3 reports for them.                                                                              */
+int  lvm_profile_only(lvm_ctx* ctx, const char* name);
 int  lvm_profile_entry(lvm_ctx* ctx, int idx, char* name, size_t name_cap, double* total_ms,
                        long long* launches);
 /* Capture the steady-state launch sequence in a hipGraph and replay it (default off: on MI355X /

@@ -93,7 +93,7 @@ class LvmError(RuntimeError):
 
 SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process_device", "lvm_process_device_frames", "lvm_set_pipeline", "lvm_flush", "lvm_synchronize",
            "lvm_last_error", "lvm_max_levels", "lvm_optimal_buffer_size", "lvm_butterworth2",
-           "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_profile_enable", "lvm_profile_collect",
+           "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_profile_enable", "lvm_profile_collect", "lvm_profile_only",
            "lvm_profile_entry", "lvm_set_graph", "lvm_algorithmic_bytes",
            "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process", "lvm_chain_process_batch",
            "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free", "lvm_compose_geometry", "lvm_compose_device", "lvm_chain_process_batch_ex"]
@@ -127,6 +127,7 @@ def bind(lib):
     lib.lvm_debug_exact_lab.argtypes = [vp, C.c_int]
     lib.lvm_profile_enable.argtypes = [vp, C.c_int]
     lib.lvm_profile_collect.argtypes = [vp]
+    lib.lvm_profile_only.argtypes = [vp, C.c_char_p]
     lib.lvm_profile_entry.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double),
                                       C.POINTER(C.c_longlong)]
     lib.lvm_set_graph.argtypes = [vp, C.c_int]
@@ -318,6 +319,10 @@ class Context:
 
     def profile(self, on=True):
         self._check(self.lib.lvm_profile_enable(self.h, int(on)))
+
+    def profile_only(self, name=None):
+        """Clear the totals and bracket only launches with this report name (None: all)."""
+        self._check(self.lib.lvm_profile_only(self.h, name.encode() if name else None))
 
     def profile_collect(self):
         n = self.lib.lvm_profile_collect(self.h)

@@ -15,6 +15,8 @@ struct lvm_ctx : lvm::Ctx {};
 namespace lvm {
 
 void prof_begin(Ctx* c, const char* name, hipStream_t s) {
+    c->prof_skip = !c->prof_only.empty() && c->prof_only != name;     // lvm_profile_only: every other launch runs unbracketed
+    if (c->prof_skip) return;
     int id = -1;
     for (size_t i = 0; i < c->prof_totals.size(); ++i)
         if (c->prof_totals[i].name == name) { id = (int)i; break; }
@@ -24,7 +26,7 @@ void prof_begin(Ctx* c, const char* name, hipStream_t s) {
     (void)hipEventRecord(e.e0, s);
     c->prof_events.push_back(e);
 }
-void prof_end(Ctx* c, hipStream_t s) { (void)hipEventRecord(c->prof_events.back().e1, s); }
+void prof_end(Ctx* c, hipStream_t s) { if (!c->prof_skip) (void)hipEventRecord(c->prof_events.back().e1, s); }
 
 // Waits for everything this context has enqueued -- on its own two streams and on caller streams (through the
 // event recorded after every enqueue; an event outlives the stream it was recorded on).  Never a device-wide
@@ -511,6 +513,14 @@ int lvm_debug_read_float(lvm_ctx* c, float* dst, size_t count) {
 int lvm_profile_enable(lvm_ctx* c, int on) {
     if (!c) return LVM_ERR_INVALID;
     c->profiling = on != 0;
+    return LVM_OK;
+}
+
+int lvm_profile_only(lvm_ctx* c, const char* name) {
+    if (!c) return LVM_ERR_INVALID;
+    (void)lvm_profile_collect(c);
+    c->prof_totals.clear();
+    c->prof_only = name ? name : "";
     return LVM_OK;
 }
 

@@ -382,6 +382,7 @@ struct Ctx {
     bool keep_float = false;
     float* d_float = nullptr; size_t float_cap = 0; size_t float_count = 0;
     bool profiling = false;
+    std::string prof_only; bool prof_skip = false;   // lvm_profile_only: bracket launches of this report name only
     std::vector<ProfEvent> prof_events;
     std::vector<ProfTotal> prof_totals;
     bool use_graph = false;           // measured on MI355X/ROCm 7.2: plain launches are GPU-bound already and graph replay adds ~5 us/frame

@@ -646,8 +646,16 @@ __global__ __launch_bounds__(256) void k_rz_blur_amp(BlurArgs aa) {
 // thread owns a 4 x 2 pixel block, 14 128-bit reads per plane.  Every output keeps its own accumulator
 // and receives its taps in the order of the scalar kernel, so both kernels give identical bits.
 constexpr int B2W = 64, B2H = 32, B2HX = 8, B2HY = 6, B2SW = B2W + 2 * B2HX, B2SH = B2H + 2 * B2HY;
+#ifndef LVM_BLUR_WAVES
+#define LVM_BLUR_WAVES 0           // minimum waves per SIMD asked of the register allocator (0: none; 86 VGPRs = 5 waves)
+#endif
+#if LVM_BLUR_WAVES
+#define LVM_BLUR_BOUNDS __launch_bounds__(256, LVM_BLUR_WAVES)
+#else
+#define LVM_BLUR_BOUNDS __launch_bounds__(256)
+#endif
 template <bool EXACT>
-__global__ __launch_bounds__(256) void k_rz_blur_amp4(BlurArgs aa) {
+__global__ LVM_BLUR_BOUNDS void k_rz_blur_amp4(BlurArgs aa) {
     __shared__ __attribute__((aligned(16))) float s[B2SH][B2SW];
     __shared__ __attribute__((aligned(16))) float hr[B2SH][B2W];
     int lvl = 0;
