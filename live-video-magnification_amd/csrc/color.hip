@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void k_col_out_v4(OutArgs a) {
 // the row parity are uniform across the wave: no divergence, no LDS, no barrier until the final
 // min/max reduction of the workgroup).
 struct HRow3 { float4 c[3]; };
-template <bool WRITE>
+template <bool WRITE, bool DBG>     // DBG: also store the float frame (compile time: no per-pixel branch in the production kernel)
 __global__ __launch_bounds__(256) void k_col_out_rows(OutArgs a, int strips_x, int strips_y, int ntasks, int rows) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int task = blockIdx.x * 4 + wave;
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(256) void k_col_out_rows(OutArgs a, int strips_x, i
                     const float o0 = (float)Bv[k] * 1.0f + val[0][k], o1 = (float)Gv[k] * 1.0f + val[1][k], o2 = (float)Rv[k] * 1.0f + val[2][k];
                     if (WRITE) {
                         ov[3 * k] = o0 * osc + osh; ov[3 * k + 1] = o1 * osc + osh; ov[3 * k + 2] = o2 * osc + osh;
-                        if (a.dbg && b == 0) { float* d = a.dbg + ((size_t)gy * a.w + gx + k) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
+                        if (DBG && a.dbg && b == 0) { float* d = a.dbg + ((size_t)gy * a.w + gx + k) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
                     } else {
                         vmin = fminf(vmin, fminf(o0, fminf(o1, o2))); vmax = fmaxf(vmax, fmaxf(o0, fmaxf(o1, o2)));
                     }
@@ -902,8 +902,9 @@ static void col_up_out(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs&
         const int sy = (io.h + rows - 1) / rows;
         const long ntasks = (long)sx * sy * NZ;
         const dim3 g2((unsigned)((ntasks + 3) / 4));
-        LVM_LAUNCH(c, "col_minmax", k_col_out_rows<false>, g2, blk, s, a, sx, sy, (int)ntasks, rows);
-        LVM_LAUNCH(c, "col_out", k_col_out_rows<true>, g2, blk, s, a, sx, sy, (int)ntasks, rows);
+        LVM_LAUNCH(c, "col_minmax", (k_col_out_rows<false, false>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
+        if (a.dbg) LVM_LAUNCH(c, "col_out", (k_col_out_rows<true, true>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
+        else LVM_LAUNCH(c, "col_out", (k_col_out_rows<true, false>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
     } else if (vec4) {
         LVM_LAUNCH(c, "col_minmax", k_col_out_v4<false>, grid, blk, s, a);
         LVM_LAUNCH(c, "col_out", k_col_out_v4<true>, grid, blk, s, a);

@@ -614,7 +614,10 @@ __global__ __launch_bounds__(256) void k_lap_final(const uint8_t* __restrict__ i
 // pass of the cur_1 rows it needs straight from global memory (cur_1 was just written by k_lap_up and
 // sits in L2) and slides a three-row register window down the strip for the vertical pass; the row
 // parity is uniform across the wave, so only the formula of that parity is executed.
-constexpr int FIN_THREADS = 512;
+#ifndef LVM_FIN_THREADS
+#define LVM_FIN_THREADS 512
+#endif
+constexpr int FIN_THREADS = LVM_FIN_THREADS;
 #ifndef LVM_FIN_PAIRS
 #define LVM_FIN_PAIRS 0          // default flavour of the last kernel: colour arithmetic on explicit pixel pairs (0: per pixel)
 #endif
@@ -943,6 +946,7 @@ struct LaplaceState : ModeState {
     long up_rows_max_blocks = 1024;       // launches with fewer tiled workgroups than this use k_lap_up_rows (LVM_UP_ROWS_MAX_BLOCKS)
     bool d0_rows_on = true;               // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
     long d0_min_tasks = 4096;             // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
+    long fin_groups = 0;                  // workgroups of the persistent last kernel (LVM_FIN_GROUPS; 0 = 1024)
     int fin_rows = 8;                     // rows per wave strip of k_lap_final_v4 (LVM_FIN_ROWS, power of two)
     int up_depth_big = 1;                 // ... at the levels with >= 1024 workgroups (LVM_UP_DEPTH_BIG)
     int up_depth = 8;                     // frame-loop prefetch depth of k_lap_up at the coarse levels (LVM_UP_DEPTH=1|2|4|8)
@@ -1018,6 +1022,7 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     if (const char* e = std::getenv("LVM_UP_ROWS_MAX_BLOCKS")) st->up_rows_max_blocks = std::atol(e);
     if (const char* e = std::getenv("LVM_ROWS_MIN_ELEMS")) st->rows_min_elems = std::atol(e);
     if (const char* e = std::getenv("LVM_FIN_MIN_TASKS")) st->fin_min_tasks = std::atol(e);
+    if (const char* e = std::getenv("LVM_FIN_GROUPS")) st->fin_groups = std::atol(e);
     if (const char* e = std::getenv("LVM_FIN_ROWS")) { const int v = std::atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) st->fin_rows = v; }
     if (st->tailT) {
         st->curT[0] = p; p += pad(st->g[st->tailT].n * st->planes);
@@ -1269,7 +1274,8 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         const int sy = (io.h + rows - 1) / rows;
         const int waves = FIN_THREADS / 64;
         const long groups = ((long)sx * sy * NS + waves - 1) / waves;
-        const dim3 grid4((unsigned)(groups < 1024 ? groups : 1024)), blk4(FIN_THREADS);
+        const long cap = st->fin_groups > 0 ? st->fin_groups : 1024;
+        const dim3 grid4((unsigned)(groups < cap ? groups : cap)), blk4(FIN_THREADS);
         LVM_LAUNCH(c, "lap_final", kf4, grid4, blk4, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
                    (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, sx, sy, NS, rows, dbg);
     } else {
