@@ -32,6 +32,9 @@ def emu(lvm):
     import ctypes
     import subprocess
     here = os.path.join(ROOT, "tests", "emu")
+    alt = os.environ.get("LVM_EMU_LIB")          # e.g. the AddressSanitizer build of tools/emu_asan.sh
+    if alt:
+        return lvm.bind(ctypes.CDLL(alt))
     subprocess.check_call([os.path.join(here, "build_emu.sh")])
     return lvm.bind(ctypes.CDLL(os.path.join(here, "_build", "liblvm_emu.so")))
 
