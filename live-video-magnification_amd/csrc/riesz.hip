@@ -975,7 +975,9 @@ struct RieszState : ModeState {
     float* ft[kMaxLevels + 1][F_ALL_N] = {}; float* oct_t[kMaxLevels + 1] = {}; float* res_t[kMaxLevels + 1] = {};   // per band level: band,P,R1p,R2p,phc,phs,lo0c,lo0s,lo1c,lo1s,hi0c,hi0s,hi1c,hi1s,amp,tc,ts,bandA
     bool inited = false;
     bool split_rows = true;          // LDS-free wave-strip split (LVM_RZ_SPLIT_ROWS=0: the tiled kernels) ...
-    long split_rows_min = 1L << 25;  // ... for launches of at least this many plane-pixels (LVM_RZ_SPLIT_ROWS_MIN); below, the tiled kernels measure equal or faster
+    long split_rows_min = 10000000;  // ... for launches of at least this many plane-pixels (LVM_RZ_SPLIT_ROWS_MIN); below, the tiled kernels measure equal or faster
+    int fin_groups = 0;              // workgroups of the persistent last kernel (LVM_RZ_FIN_GROUPS; 0 = a sixth of the tiles, at least 2048)
+    int split_strip = 0;             // rows per strip of k_rz_split_rows (LVM_RZ_SPLIT_STRIP; 0 = chosen per launch)
     bool compact = true;             // compact zero-injected tile in the collapse kernels (LVM_RZ_COMPACT=0: the full 24 x 72 tile)
     bool split2 = true;              // 64 x 32 tiles with 4 x 2 outputs per thread in the 9x9 split (LVM_RZ_SPLIT2=0: k_rz_split)
     bool blur4 = true;               // register-blocked Gaussian/amplify kernel on the large levels (LVM_RZ_BLUR4=0: scalar kernel everywhere)
@@ -1035,10 +1037,20 @@ static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B,
     for (int l = 0; l < nb; ++l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
         if (st->split_rows && a.w % 4 == 0 && a.w >= 8 && (long)a.n * NZ >= st->split_rows_min) {
-            // wave strips (no LDS); strips of 64 output rows while the launch still has >= 4096 of them
+            // wave strips (no LDS).  A strip of r output rows walks r + 8 input rows and every strip costs the same, so the
+            // launch takes ceil(strips / resident waves) rounds of r + 8 rows: 1080p with 64-row strips is 4352 strips for
+            // 4096 resident waves (126 VGPRs: 4 waves on each of the 1024 SIMDs) -- two rounds, the second one 6 % full;
+            // 68-row strips are exactly one round.  LVM_RZ_SPLIT_STRIP overrides the choice.
             const int sx = (a.w / 4 + SR_OWN - 1) / SR_OWN;
-            int rows = 64;
-            while (rows > 8 && (long)sx * ((a.h + rows - 1) / rows) * NZ < 4096) rows >>= 1;
+            int rows = st->split_strip;
+            if (rows <= 0) {
+                long best_cost = -1;
+                for (int r = 8; r <= 256; r += 2) {
+                    const long tasks = (long)sx * ((a.h + r - 1) / r) * NZ;
+                    const long cost = ((tasks + 4095) / 4096) * (r + 8);
+                    if (best_cost < 0 || cost < best_cost) { best_cost = cost; rows = r; }
+                }
+            }
             const int sy = (a.h + rows - 1) / rows;
             const long ntasks = (long)sx * sy * NZ;
             LVM_LAUNCH(c, LName("rz_split", l), k_rz_split_rows, dim3((unsigned)((ntasks + SR_THREADS / 64 - 1) / (SR_THREADS / 64))), dim3(SR_THREADS), s,
@@ -1123,7 +1135,11 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
     }
     const int tx = (w + CW - 1) / CW, ty = (h + CH - 1) / CH;
     const int ntiles = tx * ty * NZ;
-    const dim3 grid(ntiles < 2048 ? ntiles : 2048);
+    // persistent workgroups (the two Lab tables, 17 KB, are loaded once per workgroup), but many more of them than fit on the
+    // chip at once: the hardware dispatcher then balances the tail.  1080p, 32 frames (65280 tiles): 2048 workgroups 463-474 us,
+    // 5120: 441-446, 10240: 427-433, 20480: 441, one tile per workgroup 487.
+    const int gcap = st->fin_groups > 0 ? st->fin_groups : (ntiles / 6 > 2048 ? ntiles / 6 : 2048);
+    const dim3 grid(ntiles < gcap ? ntiles : gcap);
     float* dbg = c->keep_float ? c->d_float : nullptr;
     const bool vec = w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && io.out_stride % 4 == 0 &&
                      io.out_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0 && ((uintptr_t)io.d_out % 4) == 0;
@@ -1161,6 +1177,8 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         if (const char* e = std::getenv("LVM_RZ_BLUR4")) st->blur4 = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_RZ_SPLIT2")) st->split2 = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_RZ_COMPACT")) st->compact = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_RZ_FIN_GROUPS")) st->fin_groups = std::atoi(e);
+        if (const char* e = std::getenv("LVM_RZ_SPLIT_STRIP")) { const int v = std::atoi(e); if (v >= 2 && v % 2 == 0) st->split_strip = v; }
         if (const char* e = std::getenv("LVM_RZ_SPLIT_ROWS")) st->split_rows = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_RZ_SPLIT_ROWS_MIN")) st->split_rows_min = std::atol(e);
         c->state = st;

@@ -444,9 +444,14 @@ def test_fast_final_kernel_strips_and_shortcut_paths(lvm, po, emu, w, h, levels)
     print("fast final kernel", (w, h, levels), worst)
 
 
+@pytest.mark.parametrize("strip", ["0", "10", "68"])
 @pytest.mark.parametrize("w,h,levels", [(520, 70, 3), (256, 41, 2), (1000, 24, 2)])
-def test_riesz_emu_wave_strip_stencils(lvm, po, emu, w, h, levels):
-    """The LDS-free 9x9 strip kernels: several 248-column strips per row (a full one, a partial one, a strip whose last
-    lane owns the image's last column group), strips cut by the image height, odd heights, bit-exact against the oracle."""
+def test_riesz_emu_wave_strip_stencils(lvm, po, emu, w, h, levels, strip, monkeypatch):
+    """The LDS-free 9x9 strip kernels (forced onto these small planes): several 248-column strips per row (a full one, a
+    partial one, a strip whose last lane owns the image's last column group), strips cut by the image height, odd heights,
+    the strip height chosen by the launch code (0) or forced (10 rows: several strips per column; 68: the 1080p choice),
+    bit-exact against the oracle."""
+    monkeypatch.setenv("LVM_RZ_SPLIT_ROWS_MIN", "1")
+    monkeypatch.setenv("LVM_RZ_SPLIT_STRIP", strip)
     ck, pk = lvm.synth.config(2, (w, h, levels))
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0, exact=True)
