@@ -624,14 +624,17 @@ def sub_records(lvm, torch, np, args, cfg_idx, small, local_rank, rank, world, d
     R.ctx.reset()
     e2e = {}
     lib = lvm.load()
-    for kind in ("pageable", "pinned"):
-        if kind == "pinned":
+    for kind in ("pageable", "pinned", "pageable_staged_through_pinned"):
+        staged = kind == "pageable_staged_through_pinned"   # what a pinned staging buffer INSIDE lvm_process would cost: two memcpys
+        if kind != "pageable":
             pin, pout = C.c_void_p(), C.c_void_p()
             if lib.lvm_host_alloc(fb * 8, C.byref(pin)) != 0 or lib.lvm_host_alloc(fb, C.byref(pout)) != 0:
                 continue
             src = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(8, h, w, ch))
             dst = np.ctypeslib.as_array(C.cast(pout, C.POINTER(C.c_uint8)), shape=(h, w, ch))
             src[:] = host[:8]
+            if staged:
+                pg_src, pg_dst = host[:8].copy(), np.empty((h, w, ch), np.uint8)
         else:
             src = host[:8].copy()
             dst = np.empty((h, w, ch), np.uint8)
@@ -645,13 +648,17 @@ def sub_records(lvm, torch, np, args, cfg_idx, small, local_rank, rank, world, d
         Ke = 150
         t0 = time.perf_counter()
         for i in range(Ke):
+            if staged:
+                np.copyto(src[i % 8], pg_src[i % 8])
             rc = fn(R.ctx.h, R.p_ref, ptrs[i % 8], w, h, ch, w * ch, po_, w * ch, C.byref(produced))
             if rc != 0:
                 R.ctx._check(rc)
+            if staged:
+                np.copyto(pg_dst, dst)
         de = time.perf_counter() - t0
         e2e[kind] = {"value": round(Ke / de, 2), "unit": "frames/s", "us_per_frame": round(1e6 * de / Ke, 1),
                      "pcie_bytes_per_frame": 2 * fb, "pcie_gbs": round(2 * fb * Ke / de / 1e9, 2)}
-        if kind == "pinned":
+        if kind != "pageable":
             del src, dst
             lib.lvm_host_free(pin); lib.lvm_host_free(pout)
     out["e2e_host"] = dict(e2e, surface="lvm_process: host u8 in -> host u8 out, synchronous, one frame in flight "
