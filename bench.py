@@ -105,11 +105,12 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, S, T, Twin=0):
             return T * S * (3 * n[0] + 4 * n[0])
         if base == "rz_split" and lvl is not None:
             return T * 4 * S * (2 * n[lvl] + n[lvl + 1])
-        if base == "rz_phase":
+        vec4 = lambda l: sizes[l][0] % 4 == 0 and sizes[l][0] >= 8  # noqa: E731  (levels of the 4-pixels-per-thread phase kernel)
+        if base in ("rz_phase", "rz_phase_small"):
             # per frame: band in, amp/tc/ts/R1/R2 out (24 B per band pixel); 13 state floats R + W once per launch
-            return sum((T * 24 + 104) * S * n[l] for l in range(nb))
-        if base == "rz_seed":
-            return sum((4 + 13 * 4) * S * n[l] for l in range(nb))
+            return sum((T * 24 + 104) * S * n[l] for l in range(nb) if vec4(l) == (base == "rz_phase"))
+        if base in ("rz_seed", "rz_seed_small"):
+            return sum((4 + 13 * 4) * S * n[l] for l in range(nb) if vec4(l) == (base == "rz_seed"))
         if base == "rz_blur_amp":
             return T * sum(28 * S * n[l] for l in range(nb) if big(l))
         if base == "rz_blur_amp_small":
