@@ -792,14 +792,17 @@ __global__ __launch_bounds__(256) void k_rz_blur_amp(BlurArgs aa) {
 // come from five aligned 128-bit LDS reads (20 bytes per output instead of 52).  Column pass + amplify: a
 // thread owns a 4 x 2 pixel block, 14 128-bit reads per plane.  Every output keeps its own accumulator
 // and receives its taps in the order of the scalar kernel, so both kernels give identical bits.
-constexpr int B2W = 64, B2H = 32, B2HX = 8, B2HY = 6, B2SW = B2W + 2 * B2HX, B2SH = B2H + 2 * B2HY;
+#ifndef LVM_BLUR_H
+#define LVM_BLUR_H 32              // tile height of k_rz_blur_amp4 (32: 256 threads; 64: 512 threads, 19 % instead of 37 % halo rows)
+#endif
+constexpr int B2W = 64, B2H = LVM_BLUR_H, B2T = 8 * B2H, B2HX = 8, B2HY = 6, B2SW = B2W + 2 * B2HX, B2SH = B2H + 2 * B2HY;
 #ifndef LVM_BLUR_WAVES
 #define LVM_BLUR_WAVES 0           // minimum waves per SIMD asked of the register allocator (0: none; 86 VGPRs = 5 waves)
 #endif
 #if LVM_BLUR_WAVES
-#define LVM_BLUR_BOUNDS __launch_bounds__(256, LVM_BLUR_WAVES)
+#define LVM_BLUR_BOUNDS __launch_bounds__(B2T, LVM_BLUR_WAVES)
 #else
-#define LVM_BLUR_BOUNDS __launch_bounds__(256)
+#define LVM_BLUR_BOUNDS __launch_bounds__(B2T)
 #endif
 template <bool EXACT>
 __global__ LVM_BLUR_BOUNDS void k_rz_blur_amp4(BlurArgs aa) {
@@ -822,14 +825,14 @@ __global__ LVM_BLUR_BOUNDS void k_rz_blur_amp4(BlurArgs aa) {
         if (f > 0) __syncthreads();                                   // the row pass of plane f-1 has finished reading s
         if (interior) {
 #pragma unroll 1
-            for (int i = threadIdx.x; i < B2SH * (B2SW / 4); i += 256) {
+            for (int i = threadIdx.x; i < B2SH * (B2SW / 4); i += B2T) {
                 const int ly = i / (B2SW / 4), g = i - ly * (B2SW / 4);
                 *reinterpret_cast<float4*>(&s[ly][4 * g]) =
                     *reinterpret_cast<const float4*>(src + (size_t)(y0 - B2HY + ly) * a.w + (x0 - B2HX + 4 * g));
             }
         } else {
 #pragma unroll 1
-            for (int i = threadIdx.x; i < B2SH * B2SW; i += 256) {
+            for (int i = threadIdx.x; i < B2SH * B2SW; i += B2T) {
                 const int ly = i / B2SW, lx = i - ly * B2SW;
                 s[ly][lx] = src[(size_t)reflect101(y0 - B2HY + ly, a.h) * a.w + reflect101(x0 - B2HX + lx, a.w)];
             }
@@ -838,7 +841,7 @@ __global__ LVM_BLUR_BOUNDS void k_rz_blur_amp4(BlurArgs aa) {
         // RowFilter: acc = k0*S0; acc = fma(kj, Sj, acc), left to right.  Output column x reads staged columns
         // x + 2 .. x + 14 (the staging halo is 8, the filter radius 6): elements 2 .. 17 of five aligned vectors.
 #pragma unroll 1
-        for (int i = threadIdx.x; i < B2SH * (B2W / 4); i += 256) {
+        for (int i = threadIdx.x; i < B2SH * (B2W / 4); i += B2T) {
             const int ly = i / (B2W / 4), g = i - ly * (B2W / 4);
             float v[20];
 #pragma unroll
@@ -1275,7 +1278,7 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
             else { v.tx = (v.w + BT - 1) / BT; v.ty = (v.h + BTH - 1) / BTH; v.block0 = blocks; blocks += v.tx * v.ty * NZ; }
         }
         a.nlv = n1; a4.nlv = n4;
-        if (n4) LVM_LAUNCH(c, "rz_blur_amp", c->exact_lab ? k_rz_blur_amp4<true> : k_rz_blur_amp4<false>, dim3(blocks4), blk, s, a4);
+        if (n4) LVM_LAUNCH(c, "rz_blur_amp", c->exact_lab ? k_rz_blur_amp4<true> : k_rz_blur_amp4<false>, dim3(blocks4), dim3(B2T), s, a4);
         if (n1) LVM_LAUNCH(c, "rz_blur_amp_small", c->exact_lab ? k_rz_blur_amp<true> : k_rz_blur_amp<false>, dim3(blocks), blk, s, a);
     }
     const float* resn = B.oct[levels - 1];       // res_{L-1} = residual octave
