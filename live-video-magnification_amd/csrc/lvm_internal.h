@@ -70,6 +70,7 @@ struct LabCoef {
 };
 
 // cv::cubeRoot (core/mathfuncs.cpp): exponent split + quartic rational polynomial in float64
+template <bool IEEE_DIV = true>
 __device__ __forceinline__ float cv_cube_root(float value) {
     int vi = __float_as_int(value);
     int ix = vi & 0x7fffffff;
@@ -79,11 +80,20 @@ __device__ __forceinline__ float cv_cube_root(float value) {
     shx -= shx >= 0 ? 3 : 0;
     ex = (ex - shx) / 3;
     double fr = (double)__int_as_float((ix & ((1 << 23) - 1)) | ((shx + 127) << 23));
-    fr = (((((45.2548339756803022511987494 * fr + 192.2798368355061050458134625) * fr +
-             119.1654824285581628956914143) * fr + 13.43250139086239872172837314) * fr +
-           0.1636161226585754240958355063) /
-          ((((14.80884093219134573786480845 * fr + 151.9714051044435648658557668) * fr +
-             168.5254414101568283957668343) * fr + 33.9905941350215598754191872) * fr + 1.0));
+    const double num = ((((45.2548339756803022511987494 * fr + 192.2798368355061050458134625) * fr +
+                          119.1654824285581628956914143) * fr + 13.43250139086239872172837314) * fr +
+                        0.1636161226585754240958355063);
+    const double den = ((((14.80884093219134573786480845 * fr + 151.9714051044435648658557668) * fr +
+                          168.5254414101568283957668343) * fr + 33.9905941350215598754191872) * fr + 1.0);
+    if (IEEE_DIV) fr = num / den;
+    else {
+        // den is in [1, 400]: reciprocal estimate + two Newton steps (relative error ~1e-16 instead of the correctly rounded
+        // quotient); the float64 result is rounded to float next, so the two forms differ for ~1e-9 of the arguments (one ulp)
+        double r = __builtin_amdgcn_rcp(den);
+        r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+        r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+        fr = num * r;
+    }
     unsigned r = (unsigned)__float_as_int((float)fr);
     r = (r + ((unsigned)ex << 23) + s) & ((((unsigned)vi * 2u) != 0u) ? 0xffffffffu : 0u);
     return __int_as_float((int)r);
@@ -95,7 +105,7 @@ __device__ __forceinline__ float cv_cube_root(float value) {
 // its 0..100 range, at 3 instructions instead of ~60.
 template <bool EXACT>
 __device__ __forceinline__ float lab_cbrt(float x) {
-    if (EXACT) return cv_cube_root(x);
+    if (EXACT) return cv_cube_root<true>(x);
     return __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(x) * 0.33333334f);
 }
 // RGB2Lab_f scalar path on gamma-expanded B,G,R.  The non-EXACT flavour contracts the matrix rows

@@ -54,6 +54,18 @@ __device__ const float kHp9[81] = {
     0.0000f, 0.0003f, 0.0011f, 0.0022f, 0.0027f, 0.0022f, 0.0011f, 0.0003f, 0.0000f};
 
 // ---- u8 BGR -> L plane (MagnifyCore.hpp:218-222) ---------------------------------------------
+// L of one pixel: the Y row of the matrix and cv::cubeRoot, always the float64 rational polynomial (L feeds the
+// ill-conditioned acos(q0 / |q|) step, DESIGN.md "Numerics": the hardware exp2 / log2 cube root fails the parity bar here).
+// EXACT: exactly lin_bgr_to_lab<true>'s L.  Otherwise the same polynomial with its float64 division done as reciprocal +
+// two Newton steps (12 -> 6 float64 operations; one ulp of L for ~1e-9 of the pixels).
+template <bool EXACT>
+__device__ __forceinline__ float rz_lum(float B, float G, float R, const float* fw) {
+    const float Y = B * fw[3] + G * fw[4] + R * fw[5];
+    const bool hi = Y > 0.008856f;
+    const float FY = hi ? cv_cube_root<EXACT>(Y) : (7.787f * Y + 16.0f / 116.0f);
+    return hi ? (116.f * FY - 16.f) : (903.3f * Y);
+}
+template <bool EXACT>
 __global__ __launch_bounds__(256) void k_rz_lab(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                 int w, int h, float* __restrict__ Lp, LabCoef lab) {
     __shared__ float s_gam[256];
@@ -62,16 +74,14 @@ __global__ __launch_bounds__(256) void k_rz_lab(const uint8_t* __restrict__ in, 
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
     if (x >= w) return;
     const uint8_t* p = in + (size_t)b * in_sstride + (size_t)y * in_stride + (size_t)x * 3;
-    float L, a, bb;
-    // always the exact cube root: L feeds the ill-conditioned acos(q0/|q|) step (DESIGN.md "Numerics")
-    lin_bgr_to_lab<true>(s_gam[p[0]], s_gam[p[1]], s_gam[p[2]], lab.fwd, L, a, bb);
-    Lp[((size_t)b * h + y) * w + x] = L;
+    Lp[((size_t)b * h + y) * w + x] = rz_lum<EXACT>(s_gam[p[0]], s_gam[p[1]], s_gam[p[2]], lab.fwd);
 }
 // Vectorised variant (4-pixel groups dword aligned): one 12-byte load and one 16-byte store per lane, and
 // a workgroup walks over kLabIters x 1024 pixels so the gamma table is loaded once per 4096 pixels instead
 // of once per 256.  Same arithmetic.
 constexpr int kLabIters = 4;
 struct __attribute__((packed, aligned(4))) RzIn4 { uint32_t a, b, c; };
+template <bool EXACT>
 __global__ __launch_bounds__(256) void k_rz_lab4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                  int w, int h, float* __restrict__ Lp, LabCoef lab) {
     __shared__ float s_gam[256];
@@ -88,10 +98,7 @@ __global__ __launch_bounds__(256) void k_rz_lab4(const uint8_t* __restrict__ in,
                                  (v.b >> 16) & 255, v.b >> 24, v.c & 255, (v.c >> 8) & 255, (v.c >> 16) & 255, v.c >> 24};
         float L[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float a, bb;
-            lin_bgr_to_lab<true>(s_gam[pb[3 * k]], s_gam[pb[3 * k + 1]], s_gam[pb[3 * k + 2]], lab.fwd, L[k], a, bb);
-        }
+        for (int k = 0; k < 4; ++k) L[k] = rz_lum<EXACT>(s_gam[pb[3 * k]], s_gam[pb[3 * k + 1]], s_gam[pb[3 * k + 2]], lab.fwd);
         *reinterpret_cast<float4*>(Lp + ((size_t)b * h + y) * w + x) = make_float4(L[0], L[1], L[2], L[3]);
     }
 }
@@ -1180,10 +1187,10 @@ static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B,
     const dim3 blk(256);
     if (w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0) {
         const long groups = (long)(w / 4) * h;
-        LVM_LAUNCH(c, "rz_lab", k_rz_lab4, dim3((unsigned)((groups + 256 * kLabIters - 1) / (256 * kLabIters)), NZ), blk, s, io.d_in,
+        LVM_LAUNCH(c, "rz_lab", c->exact_lab ? k_rz_lab4<true> : k_rz_lab4<false>, dim3((unsigned)((groups + 256 * kLabIters - 1) / (256 * kLabIters)), NZ), blk, s, io.d_in,
                    (long)io.in_stride, (long)io.in_sstride, w, h, B.oct[0], c->lab);
     } else {
-        LVM_LAUNCH(c, "rz_lab", k_rz_lab, dim3((w + 255) / 256, h, NZ), blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, B.oct[0], c->lab);
+        LVM_LAUNCH(c, "rz_lab", c->exact_lab ? k_rz_lab<true> : k_rz_lab<false>, dim3((w + 255) / 256, h, NZ), blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, B.oct[0], c->lab);
     }
     for (int l = 0; l < nb; ++l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];

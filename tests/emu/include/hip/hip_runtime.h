@@ -68,6 +68,7 @@ static inline unsigned __builtin_amdgcn_cvt_pk_u8_f32(float v, unsigned byte, un
     return (old & ~(0xffu << (8 * byte))) | ((unsigned)r << (8 * byte));
 }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+static inline double __builtin_amdgcn_rcp(double x) { return 1.0 / x; }
 static inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
 static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / sqrtf(x); }
 static inline float __builtin_amdgcn_sinf(float rev) { return sinf(rev * 6.283185307179586f); }   // v_sin_f32: argument in revolutions
