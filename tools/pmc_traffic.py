@@ -13,8 +13,8 @@ from collections import defaultdict
 NAMES = {  # kernel symbol prefix -> bench.py report name
     "k_lap_final_v4<true, false, false>": "lap_final", "k_down0_rows<true, false>": "lap_down0", "k_down0_rows<false, false>": "col_down0",
     "k_lap_up<false, 1>": "lap_up_l1", "k_lap_iir_levels": "lap_iir", "k_lap_collapse": "lap_collapse",
-    "k_rz_final<true, false, true, true, false>": "rz_final", "k_rz_blur_amp4<false>": "rz_blur_amp", "k_rz_phase<false>": "rz_phase",
-    "k_rz_lab4": "rz_lab", "k_rz_split_rows": "rz_split_l0", "k_col_out_rows<true>": "col_out", "k_col_out_rows<false>": "col_minmax",
+    "k_rz_final<true, false, true, true, false>": "rz_final", "k_rz_blur_amp4<false>": "rz_blur_amp", "k_rz_phase4<false>": "rz_phase", "k_rz_phase<false>": "rz_phase_small",
+    "k_rz_lab4": "rz_lab", "k_rz_split_rows": "rz_split_l0", "k_col_out_rows<true, false>": "col_out", "k_col_out_rows<false, false>": "col_minmax",
 }
 
 
