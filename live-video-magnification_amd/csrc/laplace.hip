@@ -938,7 +938,8 @@ struct LaplaceState : ModeState {
     // temporal batching (lvm_process_device_frames): pyramids / accumulators of up to tcap frames
     int tcap = 0; float* tarena = nullptr;
     float* Gt[kMaxLevels + 1] = {}; float* curt[kMaxLevels + 1] = {};
-    long fin_min_tasks = 2048;            // strips are shortened until a launch has this many of them (LVM_FIN_MIN_TASKS)
+    int split_min_nt = 1;                 // frames per launch from which levels >= 2 run as IIR + collapse launches (LVM_LAP_SPLIT_MIN_NT)
+    long fin_min_tasks = 4096;            // strips are shortened until a launch has this many of them (LVM_FIN_MIN_TASKS)
     long rows_min_elems = 1 << 20;        // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
     int split_levels = 1;                 // temporal batches: levels >= 2 as one IIR launch + one collapse launch (LVM_LAP_SPLIT=0: level-by-level chain)
     int up_rows4 = 0;                     // large launches: k_lap_up_rows<4, D> instead of the tiled kernel (LVM_UP_ROWS4=1|2 = ring depth)
@@ -1017,6 +1018,7 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
     if (const char* e = std::getenv("LVM_LAP_CHUNKS")) st->chunks = std::atoi(e);
     if (const char* e = std::getenv("LVM_LAP_SPLIT")) st->split_levels = std::atoi(e);
+    if (const char* e = std::getenv("LVM_LAP_SPLIT_MIN_NT")) st->split_min_nt = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_ROWS4")) st->up_rows4 = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_ROWS")) st->up_rows = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_ROWS_MAX_BLOCKS")) st->up_rows_max_blocks = std::atol(e);
@@ -1081,6 +1083,17 @@ static bool lap_vec4(const FrameIO& io) {   // 4-pixel (12-byte) vector I/O need
 struct LapBufs { float** G; float** cur; float* curT; int nt; bool no_tail = false; };   // nt frames laid out [frame][stream][channel]
 static LapBufs lap_bufs_frame(LaplaceState* st, int par) { return LapBufs{st->Gp[par], st->cur, st->curT[par], 1}; }
 
+// Levels 2 .. L-1 decoupled into one IIR launch + one stateless collapse launch (k_lap_iir_levels / k_lap_collapse) instead
+// of the level-by-level chain / the LDS-resident tail kernel?  Temporal batches of >= 4 frames always; single frames too
+// (LVM_LAP_SPLIT_MIN_NT, default 1): per-frame calls at 1080p L6 then run pyrDown 4->5->6, the IIR launch and the collapse
+// launch (6 + 7 + 8 us) in place of the tail kernel and two level launches (21 + 7 + 7 us), 13.2 k -> see profiles/README.md.
+static bool lap_split_now(const LaplaceState* st, const LapBufs& B, bool first) {
+    const int levels = st->levels;
+    bool split = !first && st->split_levels && B.nt >= st->split_min_nt && levels >= 3 && levels - 2 <= kIirLevels;
+    for (int l = 2; l <= levels - 1 && split; ++l) split = st->g[l].w % 2 == 0;
+    return split;
+}
+
 static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, const LapBufs& B, bool first, hipStream_t s) {
     const int C = io.channels, levels = st->levels;
     const int NS = c->nstreams * B.nt;        // stateless kernels: a frame of the batch is just one more stream
@@ -1108,7 +1121,7 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
                    G[1], g1.w, g1.h, c->lab, c->lab.a255);
     }
-    const bool use_tail = st->tailT && B.nt == 1 && !B.no_tail;    // batched frames: every level gets many workgroups anyway
+    const bool use_tail = st->tailT && B.nt == 1 && !B.no_tail && !lap_split_now(st, B, first);   // batched frames: every level gets many workgroups anyway
     const int down_end = use_tail ? st->tailT : levels;            // the tail builds G_{T+1..L} itself
     int l = 1;
     while (l < down_end) {          // G_l -> next levels, three (or two) per launch when possible
@@ -1170,11 +1183,10 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     laplace_gains(io.w, io.h, levels, p.amplification, p.coWavelength, gains);
     double cLo = p.coLow, cHi = p.coHigh;
     if (cLo == 0) cLo = 0.01;                                            // TemporalFilter.cpp:11-12
-    const bool use_tail = st->tailT && B.nt == 1 && !B.no_tail;
+    const bool split = lap_split_now(st, B, first);
+    const bool use_tail = st->tailT && B.nt == 1 && !B.no_tail && !split;
     int up_start = use_tail ? st->tailT - 1 : levels - 1;
-    // temporal batches: levels 2 .. L-1 decoupled (one IIR launch for all of them + one stateless collapse launch)
-    bool split = !first && st->split_levels && B.nt >= 4 && levels >= 3 && levels - 2 <= kIirLevels;
-    for (int l = 2; l <= levels - 1 && split; ++l) split = st->g[l].w % 2 == 0;
+    // levels 2 .. L-1 decoupled (one IIR launch for all of them + one stateless collapse launch)
     if (split) {
         IirArgs ia;
         ia.nlv = levels - 2; ia.nt = B.nt;
