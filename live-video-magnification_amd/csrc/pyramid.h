@@ -97,7 +97,12 @@ __global__ __launch_bounds__(256) void k_pyr_down(const float* __restrict__ src,
 // dst[2j] = (r0 + r1*6 + r2)/64, dst[2j+1] = ((r1 + r2)*4)/64.  dsize is 2n or 2n-1.
 // Output tile UT_W x UT_H, source tile (UT_W/2+2) x (UT_H/2+2).
 // ------------------------------------------------------------------------------------------
-constexpr int UT_W = 64, UT_H = 16;
+#ifndef LVM_UT_W
+#define LVM_UT_W 64
+#define LVM_UT_H 16
+#endif
+constexpr int UT_W = LVM_UT_W, UT_H = LVM_UT_H;     // (128 x 8 measured too: see profiles/README.md)
+static_assert(UT_W * UT_H == 1024 && UT_W % 2 == 0 && UT_H % 2 == 0, "four pixels per thread of a 256-thread workgroup");
 constexpr int US_W = UT_W / 2 + 2, US_H = UT_H / 2 + 2;
 
 // stage the source tile of one plane: rows sy0..sy0+US_H-1 (vertical border map), columns
