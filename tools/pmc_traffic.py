@@ -50,7 +50,16 @@ def main():
         name = next((v for k, v in NAMES.items() if sym.startswith(k)), None)
         if name is None or name in kernels:      # (symbols are visited by total time: the steady-state variant comes first)
             continue
-        big = lambda xs: [x for x in xs if x >= 0.5 * max(xs)] if xs else []   # noqa: E731  (steady-state launches only)
+        def big(xs):      # steady-state launches only: the large grid, without isolated cold-start spikes
+            if not xs:
+                return []
+            srt = sorted(xs, reverse=True)
+            ref = srt[0]
+            for v in srt:     # the largest value that at least three launches come close to (an isolated spike is not the reference)
+                if sum(1 for x in srt if x >= 0.8 * v) >= min(3, len(srt)):
+                    ref = v
+                    break
+            return [x for x in xs if 0.5 * ref <= x <= 1.3 * ref]
         d, fe, wr = big(dur[sym]), big(fetch.get(sym, [])), big(write.get(sym, []))
         if not d:
             continue
