@@ -198,11 +198,22 @@ void lvm_butterworth2(double Wn, double a[3], double b[3]);
  * lvm_debug_read_float copies w*h*channels floats (interleaved like the u8 output).        */
 int  lvm_debug_keep_float(lvm_ctx* ctx, int on);
 int  lvm_debug_read_float(lvm_ctx* ctx, float* dst, size_t count);
-/* Lab colour arithmetic flavour.  Default (0): float32 cube root (exp2/log2 + one Newton step) and
- * reciprocal multiplies wherever the value only feeds well-conditioned math.  1: OpenCV's exact
- * operation order everywhere (cv::cubeRoot in float64, true divisions) -- bit-faithful to the CPU
- * oracle, used by the kernel-logic tests.  The Riesz L plane always uses the exact form.          */
+/* Colour arithmetic.  The forward conversion is what cv::cvtColor(COLOR_BGR2Lab) on CV_32F computes in OpenCV 4
+ * (MagnifyCore.hpp:90,219): RGB2Labfloat's trilinear interpolation in a 33 x 33 x 33 int16 table -- integer work, bit-exact.
+ * lvm_debug_exact_lab(1): every float operation around it (inverse conversion, pyramid taps, Riesz amplify) in OpenCV's
+ * operation order with true divisions -- bit-faithful to the CPU oracle on the emulation build, used by the kernel-logic
+ * tests; 0 (default): reciprocal multiplies / fma chains / hardware transcendentals where the value feeds
+ * well-conditioned math.  lvm_debug_lab_analytic(1): the cube-root form RGB2Lab_f computes when OpenCV's interpolation is
+ * switched off (implies the exact operation order).                                                                    */
 int  lvm_debug_exact_lab(lvm_ctx* ctx, int on);
+int  lvm_debug_lab_analytic(lvm_ctx* ctx, int on);
+/* The forward table: LVM_LAB_LUT_ENTRIES int16 values in OpenCV's RGB2Labprev order, index 3 (p + 33 q + 1089 r) + channel
+ * with p, q, r the R, G, B grid indices and entries L / 100 * 16384, (a + 128) / 256 * 16384, (b + 128) / 256 * 16384.
+ * lvm_create builds it by restating initLabTabs (color_lab.cpp); lvm_set_lab_lut installs another one, e.g. the table of
+ * a real OpenCV build recovered by converting the 33^3 node colours (oracle/ref_driver.cpp) -- the context must be idle. */
+#define LVM_LAB_LUT_ENTRIES (33 * 33 * 33 * 3)
+int  lvm_get_lab_lut(lvm_ctx* ctx, int16_t* dst);
+int  lvm_set_lab_lut(lvm_ctx* ctx, const int16_t* src);
 /* Per-kernel timing with HIP events recorded on the launch stream.  While enabled every
  * kernel launch is bracketed by two events; lvm_profile_collect synchronises and folds them
  * into per-kernel totals, readable with lvm_profile_entry (idx = 0..n-1).                   */

@@ -69,6 +69,9 @@ class ProcessorConfig:
     magnification: MagnificationParams = dataclasses.field(default_factory=MagnificationParams)
 
 
+LAB_LUT_ENTRIES = 33 * 33 * 33 * 3
+
+
 class LvmParams(C.Structure):
     _fields_ = [("mode", C.c_int32), ("levels", C.c_int32), ("amplification", C.c_double),
                 ("coWavelength", C.c_double), ("coLow", C.c_double), ("coHigh", C.c_double),
@@ -93,7 +96,7 @@ class LvmError(RuntimeError):
 
 SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process_device", "lvm_process_device_frames", "lvm_set_pipeline", "lvm_flush", "lvm_synchronize",
            "lvm_last_error", "lvm_max_levels", "lvm_optimal_buffer_size", "lvm_butterworth2",
-           "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_profile_enable", "lvm_profile_collect", "lvm_profile_only",
+           "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_debug_lab_analytic", "lvm_get_lab_lut", "lvm_set_lab_lut", "lvm_profile_enable", "lvm_profile_collect", "lvm_profile_only",
            "lvm_profile_entry", "lvm_set_graph", "lvm_algorithmic_bytes",
            "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process", "lvm_chain_process_batch",
            "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free", "lvm_compose_geometry", "lvm_compose_device", "lvm_chain_process_batch_ex"]
@@ -125,6 +128,9 @@ def bind(lib):
     lib.lvm_debug_keep_float.argtypes = [vp, C.c_int]
     lib.lvm_debug_read_float.argtypes = [vp, vp, C.c_size_t]
     lib.lvm_debug_exact_lab.argtypes = [vp, C.c_int]
+    lib.lvm_debug_lab_analytic.argtypes = [vp, C.c_int]
+    lib.lvm_get_lab_lut.argtypes = [vp, vp]
+    lib.lvm_set_lab_lut.argtypes = [vp, vp]
     lib.lvm_profile_enable.argtypes = [vp, C.c_int]
     lib.lvm_profile_collect.argtypes = [vp]
     lib.lvm_profile_only.argtypes = [vp, C.c_char_p]
@@ -316,6 +322,21 @@ class Context:
 
     def exact_lab(self, on=True):
         self._check(self.lib.lvm_debug_exact_lab(self.h, int(on)))
+
+    def lab_analytic(self, on=True):
+        """Analytic forward Lab (OpenCV with its interpolation switched off) instead of the 33^3 table."""
+        self._check(self.lib.lvm_debug_lab_analytic(self.h, int(on)))
+
+    def lab_lut(self):
+        """The forward table in use: int16 [33*33*33*3], index 3 (p + 33 q + 1089 r) + channel."""
+        a = np.empty(LAB_LUT_ENTRIES, np.int16)
+        self._check(self.lib.lvm_get_lab_lut(self.h, a.ctypes.data))
+        return a
+
+    def set_lab_lut(self, table):
+        a = np.ascontiguousarray(table, np.int16).reshape(-1)
+        assert a.size == LAB_LUT_ENTRIES
+        self._check(self.lib.lvm_set_lab_lut(self.h, a.ctypes.data))
 
     def profile(self, on=True):
         self._check(self.lib.lvm_profile_enable(self.h, int(on)))

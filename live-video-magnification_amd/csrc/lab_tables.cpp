@@ -10,7 +10,9 @@
 //   calculateMaxLevels (SpatialFilter.cpp:5-11), getOptimalBufferSize (TemporalFilter.cpp:82-94),
 //   butterworth(2, Wn) (TemporalFilter.cpp:280-297).
 #include <cmath>
+#include <cstdint>
 #include <cstring>
+#include <vector>
 
 #include "lvm_hip.h"
 
@@ -81,6 +83,114 @@ void build_lab_tables(float gamma_u8[256], float invgamma[4096], float fwd[9], f
         inv[i + 3] = (float)Mi[i + 3] * wp;
         inv[i + 0] = (float)Mi[i + 6] * wp;
     }
+}
+
+// ---- OpenCV 4's RGB2Lab interpolation table (color_lab.cpp initLabTabs, the enableRGB2LabInterpolation block) ----------
+// OpenCV builds the 33^3 table with its softfloat type, i.e. IEEE binary32 operations rounded one by one; the same
+// sequence is restated here on native floats (this translation unit is built with -ffp-contract=off):
+//   R, G, B = applyGamma(p / 32): x <= 809/20000 ? x / (323/25) : pow((x + 11/200) / (1 + 11/200), 12/5), where softfloat's
+//   pow is exp(y * log(x)) with log, the product and exp each rounded to binary32 (log / exp are evaluated in binary64
+//   inside and rounded once: restated with the C library's double log / exp);
+//   X, Y, Z = R C0 + G C1 + B C2 (coefficients = double(sRGB2XYZ_D65 * 1 / D65) rounded to binary32);
+//   f(t) = t > 216/24389 ? cbrt(t) : fma(t, 841/108, 16/116)   (softfloat cbrt = the cv::cubeRoot polynomial);
+//   L = Y > 216/24389 ? 116 fY - 16 : Y * (24389/27);  a = 500 (fX - fY);  b = 200 (fY - fZ);
+//   entries cvRound(16384 L / 100), cvRound(16384 (a + 128) / 256), cvRound(16384 (b + 128) / 256).
+// UNPINNED: no OpenCV exists in this image to compare the table with; a real build's table can be
+// recovered by converting the 33^3 node colours (oracle/ref_driver.cpp does that where OpenCV exists) and handed to
+// lvm_set_lab_lut().  The oracle (oracle/lvm_oracle.c lab_lut_init) restates the same sequence independently;
+// tests/test_lab_lut.py compares the two tables entry by entry.
+namespace {
+float cube_root_f32(float value) {              // cv::cubeRoot / softfloat f32_cbrt
+    uint32_t vi; std::memcpy(&vi, &value, 4);
+    const uint32_t ix = vi & 0x7fffffffu, s = vi & 0x80000000u;
+    int ex = (int)(ix >> 23) - 127;
+    int shx = ex % 3;
+    shx -= shx >= 0 ? 3 : 0;
+    ex = (ex - shx) / 3;
+    const uint32_t fb = (ix & ((1u << 23) - 1)) | ((uint32_t)(shx + 127) << 23);
+    float ff; std::memcpy(&ff, &fb, 4);
+    double fr = (double)ff;
+    fr = ((((45.2548339756803022511987494 * fr + 192.2798368355061050458134625) * fr + 119.1654824285581628956914143) * fr +
+           13.43250139086239872172837314) * fr + 0.1636161226585754240958355063) /
+         ((((14.80884093219134573786480845 * fr + 151.9714051044435648658557668) * fr + 168.5254414101568283957668343) * fr +
+           33.9905941350215598754191872) * fr + 1.0);
+    const float rf = (float)fr;
+    uint32_t r; std::memcpy(&r, &rf, 4);
+    r = (r + ((uint32_t)ex << 23) + s) & ((vi * 2u) != 0u ? 0xffffffffu : 0u);
+    float out; std::memcpy(&out, &r, 4);
+    return out;
+}
+float sf_gamma(float x) {
+    const float thr = 809.f / 20000.f, low = 323.f / 25.f, shift = 11.f / 200.f, power = 12.f / 5.f;
+    if (x <= thr) return x / low;
+    const float base = (x + shift) / (1.f + shift);
+    const float lg = (float)std::log((double)base);
+    const float pr = power * lg;
+    return (float)std::exp((double)pr);
+}
+}  // namespace
+
+// compact[((r * 33 + q) * 33 + p) * 3 + ch], p = R index (fastest), q = G, r = B
+void build_lab_lut_compact(std::vector<int16_t>& compact) {
+    static const double M[9] = {0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227};
+    static const double D65[3] = {0.950456, 1.0, 1.088754};
+    float C[9];
+    for (int i = 0; i < 3; ++i) {
+        const double sw = i == 1 ? 1.0 : 1.0 / D65[i];
+        for (int j = 0; j < 3; ++j) C[i * 3 + j] = (float)(M[i * 3 + j] * sw);
+    }
+    const float lthresh = 216.f / 24389.f, lscale = 841.f / 108.f, lbias = 16.f / 116.f, l9033 = 24389.f / 27.f;
+    float gam[33];
+    for (int p = 0; p < 33; ++p) gam[p] = sf_gamma((float)p / 32.f);
+    compact.assign((size_t)33 * 33 * 33 * 3, 0);
+    for (int r = 0; r < 33; ++r)
+        for (int q = 0; q < 33; ++q)
+            for (int p = 0; p < 33; ++p) {
+                const float R = gam[p], G = gam[q], B = gam[r];
+                const float X = R * C[0] + G * C[1] + B * C[2];
+                const float Y = R * C[3] + G * C[4] + B * C[5];
+                const float Z = R * C[6] + G * C[7] + B * C[8];
+                const float FX = X > lthresh ? cube_root_f32(X) : std::fmaf(X, lscale, lbias);
+                const float FY = Y > lthresh ? cube_root_f32(Y) : std::fmaf(Y, lscale, lbias);
+                const float FZ = Z > lthresh ? cube_root_f32(Z) : std::fmaf(Z, lscale, lbias);
+                const float L = Y > lthresh ? (116.f * FY - 16.f) : (Y * l9033);
+                const float a = 500.f * (FX - FY), b = 200.f * (FY - FZ);
+                int16_t* e = &compact[(((size_t)r * 33 + q) * 33 + p) * 3];
+                e[0] = (int16_t)std::lrintf(16384.f * L / 100.f);
+                e[1] = (int16_t)std::lrintf(16384.f * (a + 128.f) / 256.f);
+                e[2] = (int16_t)std::lrintf(16384.f * (b + 128.f) / 256.f);
+            }
+}
+
+// device layout (lab_lut.h): node (p, q, r) = { L[r], L[r+1], a[r], a[r+1], b[r], b[r+1], 0, 0 }, r + 1 clamped to 32,
+// node index p + 33 q + 1089 r, padded by 35 zero nodes
+void lab_lut_nodes_from_compact(const int16_t* compact, std::vector<uint16_t>& nodes) {
+    nodes.assign((size_t)(33 * 33 * 33 + 35) * 8, 0);
+    for (int r = 0; r < 33; ++r)
+        for (int q = 0; q < 33; ++q)
+            for (int p = 0; p < 33; ++p) {
+                const int r1 = r < 32 ? r + 1 : 32;
+                const int16_t* e0 = compact + (((size_t)r * 33 + q) * 33 + p) * 3;
+                const int16_t* e1 = compact + (((size_t)r1 * 33 + q) * 33 + p) * 3;
+                uint16_t* n = &nodes[((size_t)p + 33 * q + 1089 * r) * 8];
+                for (int ch = 0; ch < 3; ++ch) { n[2 * ch] = (uint16_t)e0[ch]; n[2 * ch + 1] = (uint16_t)e1[ch]; }
+            }
+}
+// lab_lut.h takes cell and weight of a u8 channel value from (514 u + 4) >> 8 instead of rounding float(u) * a255 * 16384:
+// the identity is checked for all 256 values whenever a context is created
+bool lab_lut_fine_index_ok() {
+    const float a255 = (float)(1.0 / 255.0f);
+    for (int u = 0; u < 256; ++u) {
+        float v = (float)u * a255;
+        v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+        const long c = std::lrintf(v * 16384.f);
+        if ((c >> 5) != (long)((u * 514 + 4) >> 8)) return false;
+    }
+    return true;
+}
+void build_lab_lut_nodes(std::vector<int16_t>& compact, std::vector<uint16_t>& nodes) {
+    build_lab_lut_compact(compact);
+    lab_lut_nodes_from_compact(compact.data(), nodes);
 }
 
 int max_levels(int w, int h) {

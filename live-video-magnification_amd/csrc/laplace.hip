@@ -537,17 +537,18 @@ __global__ __launch_bounds__(256) void k_lap_collapse(CollapseArgs a) {
 // Final level: out = u8(Lab2BGR(Lab(in) + [1, ca, ca] * pyrUp(cur_1))).  MOTION = false is
 // the first frame / L == 1 case (motion image is identically zero).  Persistent workgroups
 // walk over (stream, tile); the inverse-gamma spline table lives in LDS.
-template <int C, bool MOTION, bool EXACT>
+template <int C, bool MOTION, int FL>
 __global__ __launch_bounds__(256) void k_lap_final(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                    uint8_t* __restrict__ out, long out_stride, long out_sstride,
                                                    int w, int h, const float* __restrict__ cur1, int w1, int h1,
                                                    LabCoef lab, float ca, int tiles_x, int tiles_y, int nstreams,
                                                    float* __restrict__ dbg) {
+    constexpr bool EXACT = fl_exact(FL);
     __shared__ __attribute__((aligned(16))) float s_igt[C == 3 ? 4096 : 4];
-    __shared__ float s_gam[C == 3 ? 256 : 1];
+    __shared__ float s_gam[C == 3 && !fl_lut(FL) ? 256 : 1];
     __shared__ float s_c[C][US_H][US_W + 1];
     __shared__ float h_c[C][US_H][UT_W + 1];
-    if (C == 3) { load_invgamma(s_igt, lab.invgamma); load_gamma_u8(s_gam, lab.gamma_u8); }
+    if (C == 3) { load_invgamma(s_igt, lab.invgamma); if (!fl_lut(FL)) load_gamma_u8(s_gam, lab.gamma_u8); }
     __syncthreads();
     const int ntiles = tiles_x * tiles_y * nstreams;
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(256) void k_lap_final(const uint8_t* __restrict__ i
             uint8_t* q = dst + (size_t)gy * out_stride + (size_t)gx * C;
             if (C == 3) {
                 float L, a, bb;
-                lin_bgr_to_lab<EXACT>(s_gam[p[0]], s_gam[C == 3 ? p[1] : 0], s_gam[C == 3 ? p[2] : 0], lab.fwd, L, a, bb);
+                bgr_u8_to_lab<FL>(p[0], p[C == 3 ? 1 : 0], p[C == 3 ? 2 : 0], s_gam, lab, L, a, bb);
                 if (MOTION) {
                     const float m0 = pyrup_v(h_c[0], x, gy, sy0);
                     const float m1 = pyrup_v(h_c[C > 1 ? 1 : 0], x, gy, sy0) * ca;   // MagnifyCore.hpp:143-144
@@ -618,13 +619,7 @@ __global__ __launch_bounds__(256) void k_lap_final(const uint8_t* __restrict__ i
 #define LVM_FIN_THREADS 512
 #endif
 constexpr int FIN_THREADS = LVM_FIN_THREADS;
-#ifndef LVM_FIN_PAIRS
-#define LVM_FIN_PAIRS 0          // default flavour of the last kernel: colour arithmetic on explicit pixel pairs (0: per pixel)
-#endif
 struct Row3 { float4 c[3]; };            // horizontal-pass results of one source row, 3 channels x 4 columns
-#ifndef LVM_FIN_FSPACE
-#define LVM_FIN_FSPACE 1         // default flavour: add the motion image in (fX, fY, fZ) instead of Lab (lvm_internal.h)
-#endif
 #ifndef LVM_FIN_WAVES
 #define LVM_FIN_WAVES 0          // minimum waves per SIMD asked of the register allocator (0: none; 121 VGPRs = 4 waves)
 #endif
@@ -633,18 +628,19 @@ struct Row3 { float4 c[3]; };            // horizontal-pass results of one sourc
 #else
 #define LVM_FIN_BOUNDS __launch_bounds__(FIN_THREADS)
 #endif
-template <bool MOTION, bool EXACT, bool DBG>     // DBG: also store the float frame (lvm_debug_keep_float); a per-pixel branch
+template <bool MOTION, bool DBG, int FL>     // DBG: also store the float frame (lvm_debug_keep_float); a per-pixel branch
 __global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                        uint8_t* __restrict__ out, long out_stride, long out_sstride,
                                                        int w, int h, const float* __restrict__ cur1, int w1, int h1,
                                                        LabCoef lab, float ca, int strips_x, int strips_y, int nstreams,
                                                        int rows, float* __restrict__ dbg) {
+    constexpr bool EXACT = fl_exact(FL);
     __shared__ __attribute__((aligned(16))) float s_igt[4096];
-    __shared__ float s_gam[256];
+    __shared__ float s_gam[fl_lut(FL) ? 1 : 256];
     {
         const float4* src = reinterpret_cast<const float4*>(lab.invgamma);
         for (int i = threadIdx.x; i < 1024; i += FIN_THREADS) reinterpret_cast<float4*>(s_igt)[i] = src[i];
-        if (threadIdx.x < 256) s_gam[threadIdx.x] = lab.gamma_u8[threadIdx.x];
+        if (!fl_lut(FL) && threadIdx.x < 256) s_gam[threadIdx.x] = lab.gamma_u8[threadIdx.x];
     }
     __syncthreads();
     constexpr int WAVES = FIN_THREADS / 64;
@@ -695,48 +691,11 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, lo
             int Bv[4], Gv[4], Rv[4];
             unpack_px4(pin, Bv, Gv, Rv);
             float ov[12];
-            if (!EXACT && LVM_FIN_PAIRS) {
-                // default flavour: the colour arithmetic on pixel pairs (lvm_internal.h), same values
-                float Bl[4], Gl[4], Rl[4], L4[4], a4[4], b4[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) { Bl[k] = s_gam[Bv[k]]; Gl[k] = s_gam[Gv[k]]; Rl[k] = s_gam[Rv[k]]; }
-                lab_fwd4<false>(Bl, Gl, Rl, lab.fwd, L4, a4, b4);
-#pragma unroll
-                for (int k = 0; k < 4; k += 2) {
-                    f32x2 Lp, Ap, Bq, o0, o1, o2;
-                    Lp.x = L4[k]; Lp.y = L4[k + 1]; Ap.x = a4[k]; Ap.y = a4[k + 1]; Bq.x = b4[k]; Bq.y = b4[k + 1];
-                    if (MOTION) {
-                        f32x2 m0, m1, m2;
-                        m0.x = m[0][k]; m0.y = m[0][k + 1]; m1.x = m[1][k]; m1.y = m[1][k + 1]; m2.x = m[2][k]; m2.y = m[2][k + 1];
-                        Lp = pk_fma(m0, pk_splat(msc), Lp); Ap = pk_fma(m1, pk_splat(msc * ca), Ap); Bq = pk_fma(m2, pk_splat(msc * ca), Bq);
-                    }
-                    lab_inv_pair(Lp, Ap, Bq, lab.inv1024, s_igt, o0, o1, o2);
-                    if (DBG && dbg && b == 0) {
-                        float* d = dbg + ((size_t)gy * w + gx + k) * 3;
-                        d[0] = o0.x; d[1] = o1.x; d[2] = o2.x; d[3] = o0.y; d[4] = o1.y; d[5] = o2.y;
-                    }
-                    const f32x2 s255 = pk_splat(255.0f), a255 = pk_splat(lab.a255);
-                    o0 = pk_fma(o0, s255, a255); o1 = pk_fma(o1, s255, a255); o2 = pk_fma(o2, s255, a255);
-                    ov[3 * k] = o0.x; ov[3 * k + 1] = o1.x; ov[3 * k + 2] = o2.x; ov[3 * k + 3] = o0.y; ov[3 * k + 4] = o1.y; ov[3 * k + 5] = o2.y;
-                }
-            } else
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float o0, o1, o2;
-                if (!EXACT && LVM_FIN_FSPACE) {
-                    // default flavour: the motion image is added in (fX, fY, fZ), see lvm_internal.h
-                    float fx, fy, fz;
-                    lin_bgr_to_fxyz(s_gam[Bv[k]], s_gam[Gv[k]], s_gam[Rv[k]], lab.fwd, fx, fy, fz);
-                    if (MOTION) {
-                        const float k0 = msc * (1.0f / 116.0f), k1 = msc * ca * (1.0f / 500.0f), k2 = -(msc * ca * (1.0f / 200.0f));
-                        fx = __builtin_fmaf(m[1][k], k1, __builtin_fmaf(m[0][k], k0, fx));
-                        fz = __builtin_fmaf(m[2][k], k2, __builtin_fmaf(m[0][k], k0, fz));
-                        fy = __builtin_fmaf(m[0][k], k0, fy);
-                    }
-                    fxyz_to_bgr(fx, fy, fz, lab.inv1024, s_igt, o0, o1, o2);
-                } else {
                 float L, a, bb;
-                lin_bgr_to_lab<EXACT>(s_gam[Bv[k]], s_gam[Gv[k]], s_gam[Rv[k]], lab.fwd, L, a, bb);
+                bgr_u8_to_lab<FL>(Bv[k], Gv[k], Rv[k], s_gam, lab, L, a, bb);
                 if (MOTION) {
                     if (EXACT) { L = L + m[0][k]; a = a + m[1][k] * ca; bb = bb + m[2][k] * ca; }
                     else {
@@ -745,7 +704,6 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, lo
                     }
                 }
                 lab_to_bgr<EXACT>(L, a, bb, EXACT ? lab.inv : lab.inv1024, s_igt, o0, o1, o2);
-                }
                 if (DBG && dbg && b == 0) { float* d = dbg + ((size_t)gy * w + gx + k) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
                 if (EXACT) {
                     ov[3 * k] = o0 * 255.0f + lab.a255; ov[3 * k + 1] = o1 * 255.0f + lab.a255; ov[3 * k + 2] = o2 * 255.0f + lab.a255;
@@ -1107,17 +1065,18 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     const int d0_sx = (g1.w + D0R_OUT - 1) / D0R_OUT;
     long d0_tasks = 0;
     const int d0_rows = down0_rows_choice(g1.w, g1.h, NS, st->d0_min_tasks, &d0_tasks);
+    const int fl = lab_flavour(c);
     if (lap_vec4(io) && st->d0_rows_on && d0_tasks > 0) {
-        auto kd0 = c->exact_lab ? k_down0_rows<true, true> : k_down0_rows<true, false>;
+        auto kd0 = LVM_FL_PICK(fl, k_down0_rows, true);
         const dim3 gridr((unsigned)((d0_tasks + D0R_THREADS / 64 - 1) / (D0R_THREADS / 64)));
         LVM_LAUNCH(c, "lap_down0", kd0, gridr, dim3(D0R_THREADS), s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
                    G[1], g1.w, g1.h, c->lab, d0_sx, (g1.h + d0_rows - 1) / d0_rows, (int)d0_tasks, d0_rows);
     } else if (lap_vec4(io)) {
-        auto kd0 = c->exact_lab ? k_down0_v4<true, true> : k_down0_v4<true, false>;
+        auto kd0 = LVM_FL_PICK(fl, k_down0_v4, true);
         LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
                    G[1], g1.w, g1.h, c->lab);
     } else {
-        auto kd0 = (C == 3) ? (c->exact_lab ? k_down0<3, true, true> : k_down0<3, true, false>) : k_down0<1, false, true>;
+        auto kd0 = (C == 3) ? LVM_FL_PICK(fl, k_down0, 3, true) : k_down0<1, false, FL_LUT_EXACT>;
         LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
                    G[1], g1.w, g1.h, c->lab, c->lab.a255);
     }
@@ -1271,13 +1230,11 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     const float* cur1 = motion ? ((use_tail && st->tailT == 1) ? B.curT : B.cur[1]) : nullptr;
     const int w1 = st->g[1].w, h1 = st->g[1].h;
     float* dbg = c->keep_float ? c->d_float : nullptr;
-    auto kf4 = dbg ? (motion ? (c->exact_lab ? k_lap_final_v4<true, true, true> : k_lap_final_v4<true, false, true>)
-                             : (c->exact_lab ? k_lap_final_v4<false, true, true> : k_lap_final_v4<false, false, true>))
-                   : (motion ? (c->exact_lab ? k_lap_final_v4<true, true, false> : k_lap_final_v4<true, false, false>)
-                             : (c->exact_lab ? k_lap_final_v4<false, true, false> : k_lap_final_v4<false, false, false>));
-    auto kf = (C == 3) ? (motion ? (c->exact_lab ? k_lap_final<3, true, true> : k_lap_final<3, true, false>)
-                                 : (c->exact_lab ? k_lap_final<3, false, true> : k_lap_final<3, false, false>))
-                       : (motion ? k_lap_final<1, true, true> : k_lap_final<1, false, true>);
+    const int fl = lab_flavour(c);
+    auto kf4 = dbg ? (motion ? LVM_FL_PICK(fl, k_lap_final_v4, true, true) : LVM_FL_PICK(fl, k_lap_final_v4, false, true))
+                   : (motion ? LVM_FL_PICK(fl, k_lap_final_v4, true, false) : LVM_FL_PICK(fl, k_lap_final_v4, false, false));
+    auto kf = (C == 3) ? (motion ? LVM_FL_PICK(fl, k_lap_final, 3, true) : LVM_FL_PICK(fl, k_lap_final, 3, false))
+                       : (motion ? k_lap_final<1, true, FL_LUT_EXACT> : k_lap_final<1, false, FL_LUT_EXACT>);
     if (lap_vec4(io)) {
         // wave strips of 256 x rows pixels; shorter strips when there are few of them (per-frame calls)
         const int sx = (io.w + 255) / 256;

@@ -52,6 +52,16 @@ static void drop_graphs(Ctx* c) {
 }
 static void drop_state(Ctx* c) { drop_graphs(c); delete c->state; c->state = nullptr; }
 
+// (re)build the device nodes of the forward Lab table from c->lab_lut_compact
+int upload_lab_lut(Ctx* c) {
+    std::vector<uint16_t> nodes;
+    lab_lut_nodes_from_compact(c->lab_lut_compact.data(), nodes);
+    if (!c->d_lab_lut && hipMalloc((void**)&c->d_lab_lut, nodes.size() * sizeof(uint16_t)) != hipSuccess) { c->d_lab_lut = nullptr; c->err = "hipMalloc (Lab table) failed"; return LVM_ERR_OOM; }
+    LVM_HIP_TRY(c, hipMemcpy(c->d_lab_lut, nodes.data(), nodes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    c->lab.lut = c->d_lab_lut;
+    return LVM_OK;
+}
+
 static int run_mode(Ctx* c, const lvm_params* p, int levels, const FrameIO& io, hipStream_t s, int* produced) {
     switch (p->mode) {                                                                  // MagnificationProcessor.cpp:48-60
     case LVM_MODE_LAPLACE: return laplace_process(c, *p, levels, io, s, produced);
@@ -69,7 +79,7 @@ static int run_mode(Ctx* c, const lvm_params* p, int levels, const FrameIO& io, 
 static int run_mode_graphed(Ctx* c, const lvm_params* p, int levels, const FrameIO& io, hipStream_t s, int* produced) {
     struct Key { FrameIO io; lvm_params p; int levels; int exact; float* dbg; size_t nx; uint8_t extra[256]; } k;
     std::memset(&k, 0, sizeof(k));
-    k.io = io; k.p = *p; k.levels = levels; k.exact = c->exact_lab ? 1 : 0; k.dbg = c->keep_float ? c->d_float : nullptr;
+    k.io = io; k.p = *p; k.levels = levels; k.exact = lvm::lab_flavour(c); k.dbg = c->keep_float ? c->d_float : nullptr;
     k.nx = c->state->key_extra(k.extra, sizeof(k.extra));
     const uint8_t* kb = reinterpret_cast<const uint8_t*>(&k);
     GraphEntry* e = nullptr;
@@ -209,6 +219,12 @@ int lvm_create(int device, int n_streams, lvm_ctx** out) {
     ok = ok && hipMalloc((void**)&c->d_invgamma, sizeof(ig)) == hipSuccess;
     ok = ok && hipMemcpy(c->d_gamma_u8, g, sizeof(g), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(c->d_invgamma, ig, sizeof(ig), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        // OpenCV's forward Lab table (lab_tables.cpp) and the closed form of its cell index (lab_lut.h)
+        if (!lvm::lab_lut_fine_index_ok()) { lvm_destroy(c); return LVM_ERR_INVALID; }
+        lvm::build_lab_lut_compact(c->lab_lut_compact);
+        ok = lvm::upload_lab_lut(c) == LVM_OK;
+    }
     if (!ok) { lvm_destroy(c); return LVM_ERR_HIP; }
     c->lab.gamma_u8 = c->d_gamma_u8;
     c->lab.invgamma = c->d_invgamma;
@@ -226,6 +242,7 @@ void lvm_destroy(lvm_ctx* c) {
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
     if (c->d_gamma_u8) (void)hipFree(c->d_gamma_u8);
     if (c->d_invgamma) (void)hipFree(c->d_invgamma);
+    if (c->d_lab_lut) (void)hipFree(c->d_lab_lut);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_float) (void)hipFree(c->d_float);
@@ -501,6 +518,25 @@ const char* lvm_last_error(lvm_ctx* c) { return c ? c->err.c_str() : "null conte
 int lvm_debug_keep_float(lvm_ctx* c, int on) { if (!c) return LVM_ERR_INVALID; c->keep_float = on != 0; return LVM_OK; }
 
 int lvm_debug_exact_lab(lvm_ctx* c, int on) { if (!c) return LVM_ERR_INVALID; c->exact_lab = on != 0; return LVM_OK; }
+
+int lvm_debug_lab_analytic(lvm_ctx* c, int on) { if (!c) return LVM_ERR_INVALID; c->lab_analytic = on != 0; return LVM_OK; }
+
+int lvm_get_lab_lut(lvm_ctx* c, int16_t* dst) {
+    if (!c || !dst) return LVM_ERR_INVALID;
+    std::memcpy(dst, c->lab_lut_compact.data(), c->lab_lut_compact.size() * sizeof(int16_t));
+    return LVM_OK;
+}
+
+int lvm_set_lab_lut(lvm_ctx* c, const int16_t* src) {
+    if (!c || !src) return LVM_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    for (size_t i = 0; i < (size_t)LVM_LAB_LUT_ENTRIES; ++i)
+        if (src[i] < 0 || src[i] > 16384) { c->err = "lvm_set_lab_lut: entry outside [0, 16384]"; return LVM_ERR_INVALID; }
+    lvm::sync_streams(c);                        // kernels in flight read the old table
+    LVM_HIP_TRY(c, hipDeviceSynchronize());
+    c->lab_lut_compact.assign(src, src + LVM_LAB_LUT_ENTRIES);
+    return lvm::upload_lab_lut(c);
+}
 
 int lvm_debug_read_float(lvm_ctx* c, float* dst, size_t count) {
     if (!c || !dst) return LVM_ERR_INVALID;

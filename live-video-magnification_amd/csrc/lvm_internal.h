@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "lvm_hip.h"
+#include "lab_lut.h"
 
 namespace lvm {
 
@@ -67,6 +68,7 @@ struct LabCoef {
     const float* gamma_u8;    // [256]  sRGB gamma of u8/255 (device)
     const float* invgamma;    // [1024*4] cubic-spline coefficients of the inverse gamma (device)
     float a255;               // float(1.0/255.0f)
+    const uint4* lut;         // OpenCV's 33^3 forward table as 16-byte nodes (lab_lut.h, device)
 };
 
 // cv::cubeRoot (core/mathfuncs.cpp): exponent split + quartic rational polynomial in float64
@@ -205,121 +207,21 @@ __device__ __forceinline__ void lab_to_bgr(float li, float ai, float bi, const f
         o2 = spline1024<false>(clip1024_open(c2), igt);
     }
 }
-// ---- the default flavour's last-kernel arithmetic without the detour through (L, a, b) ---------------------------------
-// Lab is affine in (f(X), f(Y), f(Z)): L = 116 fY - 16, a = 500 (fX - fY), b = 200 (fY - fZ), and Lab2RGB starts by undoing
-// exactly that: fy = (L + 16) / 116, fx = a / 500 + fy, fz = fy - b / 200.  Adding a motion image (mL, ma, mb) in Lab and
-// converting back is therefore the same as adding (mL / 116 + ma / 500, mL / 116, mL / 116 - mb / 200) to (fX, fY, fZ):
-// 20 operations per pixel between the forward cube roots and the inverse matrix instead of 31 (no L / a / b, no second
-// affine map, one fma for the linear branch of f^-1).  Below the CIE threshold the reference's y = L / 903.3 becomes
-// (fy - 16/116) / 7.787 = L / 903.292: 9e-6 of a linear-light value < 0.009.  Results move by a few 1e-7 relative (fma
-// roundings); the exact flavour keeps the Lab form.
-__device__ __forceinline__ void lin_bgr_to_fxyz(float B, float G, float R, const float* fw, float& FX, float& FY, float& FZ) {
-    const float _a = 16.0f / 116.0f;
-    const float X = __builtin_fmaf(B, fw[0], __builtin_fmaf(G, fw[1], R * fw[2]));
-    const float Y = __builtin_fmaf(B, fw[3], __builtin_fmaf(G, fw[4], R * fw[5]));
-    const float Z = __builtin_fmaf(B, fw[6], __builtin_fmaf(G, fw[7], R * fw[8]));
-    const float cx = lab_cbrt<false>(X), cy = lab_cbrt<false>(Y), cz = lab_cbrt<false>(Z);
-    FX = X > 0.008856f ? cx : __builtin_fmaf(7.787f, X, _a);
-    FY = Y > 0.008856f ? cy : __builtin_fmaf(7.787f, Y, _a);
-    FZ = Z > 0.008856f ? cz : __builtin_fmaf(7.787f, Z, _a);
-}
-__device__ __forceinline__ float lab_finv(float f) {
-    const float fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
-    const float lin = __builtin_fmaf(f, 1.0f / 7.787f, -(16.0f / 116.0f) / 7.787f), cube = f * f * f;
-    return f <= fThresh ? lin : cube;
-}
-// (fx, fy, fz) -> BGR through the inverse matrix (iv = inv1024) and the inverse-gamma spline
-__device__ __forceinline__ void fxyz_to_bgr(float fx, float fy, float fz, const float* iv, const float* igt, float& o0, float& o1, float& o2) {
-    const float x = lab_finv(fx), y = lab_finv(fy), z = lab_finv(fz);
-    const float c0 = __builtin_fmaf(iv[0], x, __builtin_fmaf(iv[1], y, iv[2] * z));
-    const float c1 = __builtin_fmaf(iv[3], x, __builtin_fmaf(iv[4], y, iv[5] * z));
-    const float c2 = __builtin_fmaf(iv[6], x, __builtin_fmaf(iv[7], y, iv[8] * z));
-    o0 = spline1024<false>(clip1024_open(c0), igt);
-    o1 = spline1024<false>(clip1024_open(c1), igt);
-    o2 = spline1024<false>(clip1024_open(c2), igt);
-}
-// ---- pixel-pair forms of the default flavour (round 2) -----------------------------------------------------------
-// The same operations as lin_bgr_to_lab<false> / lab_to_bgr<false>, two pixels at a time on <2 x float> values: every
-// fma-class operation is a v_pk_fma / v_pk_mul / v_pk_add_f32, which issues at 0.8 of the cost of two scalar ones
-// (profiles/r02_ubench_valu_issue_rates.txt); selects, table look-ups and transcendentals stay per element.  Written
-// out by hand because the SLP vectoriser's own packing of the scalar code costs more register moves than it saves.
-// Results are bit-identical to the scalar default flavour (same operations, same order, per element).
-#ifdef LVM_EMU_F32X2          // tests/emu (g++ has no ext_vector_type): a two-float struct with the same operators
-typedef LVM_EMU_F32X2 f32x2;
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { f32x2 r; r.x = __builtin_fmaf(a.x, b.x, c.x); r.y = __builtin_fmaf(a.y, b.y, c.y); return r; }
-#else
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-#endif
-__device__ __forceinline__ f32x2 pk_splat(float x) { f32x2 r; r.x = x; r.y = x; return r; }
-__device__ __forceinline__ f32x2 pk_cbrt(f32x2 x) {
-    f32x2 l; l.x = __builtin_amdgcn_logf(x.x); l.y = __builtin_amdgcn_logf(x.y);
-    l = l * pk_splat(0.33333334f);
-    f32x2 r; r.x = __builtin_amdgcn_exp2f(l.x); r.y = __builtin_amdgcn_exp2f(l.y);
-    return r;
-}
-__device__ __forceinline__ void lab_fwd_pair(f32x2 B, f32x2 G, f32x2 R, const float* fw, f32x2& L, f32x2& a, f32x2& b) {
-    const f32x2 X = pk_fma(B, pk_splat(fw[0]), pk_fma(G, pk_splat(fw[1]), R * pk_splat(fw[2])));
-    const f32x2 Y = pk_fma(B, pk_splat(fw[3]), pk_fma(G, pk_splat(fw[4]), R * pk_splat(fw[5])));
-    const f32x2 Z = pk_fma(B, pk_splat(fw[6]), pk_fma(G, pk_splat(fw[7]), R * pk_splat(fw[8])));
-    const f32x2 k = pk_splat(7.787f), c = pk_splat(16.0f / 116.0f);
-    const f32x2 cx = pk_cbrt(X), cy = pk_cbrt(Y), cz = pk_cbrt(Z);
-    const f32x2 lx = pk_fma(k, X, c), ly = pk_fma(k, Y, c), lz = pk_fma(k, Z, c);
-    f32x2 FX, FY, FZ;
-    FX.x = X.x > 0.008856f ? cx.x : lx.x; FX.y = X.y > 0.008856f ? cx.y : lx.y;
-    FY.x = Y.x > 0.008856f ? cy.x : ly.x; FY.y = Y.y > 0.008856f ? cy.y : ly.y;
-    FZ.x = Z.x > 0.008856f ? cz.x : lz.x; FZ.y = Z.y > 0.008856f ? cz.y : lz.y;
-    L = pk_fma(pk_splat(116.f), FY, pk_splat(-16.f));
-    a = pk_splat(500.f) * (FX - FY);
-    b = pk_splat(200.f) * (FY - FZ);
-}
-__device__ __forceinline__ f32x2 pk_spline1024(f32x2 x, const float* tab) {       // x clamped to [0, 1024) by the caller
-    const int i0 = (int)x.x, i1 = (int)x.y;
-    f32x2 fr; fr.x = __builtin_amdgcn_fractf(x.x); fr.y = __builtin_amdgcn_fractf(x.y);
-    const float4 t0 = *reinterpret_cast<const float4*>(tab + i0 * 4), t1 = *reinterpret_cast<const float4*>(tab + i1 * 4);
-    f32x2 c3, c2, c1, c0;
-    c3.x = t0.w; c3.y = t1.w; c2.x = t0.z; c2.y = t1.z; c1.x = t0.y; c1.y = t1.y; c0.x = t0.x; c0.y = t1.x;
-    return pk_fma(pk_fma(pk_fma(c3, fr, c2), fr, c1), fr, c0);
-}
-__device__ __forceinline__ void lab_inv_pair(f32x2 L, f32x2 a, f32x2 b, const float* iv, const float* igt, f32x2& o0, f32x2& o1, f32x2& o2) {
-    const float lThresh = 0.008856f * 903.3f, fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
-    const f32x2 ylin = L * pk_splat(1.0f / 903.3f), fyc = (L + pk_splat(16.0f)) * pk_splat(1.0f / 116.0f);
-    const f32x2 fyl = pk_fma(pk_splat(7.787f), ylin, pk_splat(16.0f / 116.0f));
-    const f32x2 y3 = fyc * fyc * fyc;
-    f32x2 fy, y;
-    fy.x = L.x <= lThresh ? fyl.x : fyc.x; fy.y = L.y <= lThresh ? fyl.y : fyc.y;
-    y.x = L.x <= lThresh ? ylin.x : y3.x; y.y = L.y <= lThresh ? ylin.y : y3.y;
-    f32x2 fx = pk_fma(a, pk_splat(1.0f / 500.0f), fy), fz = pk_fma(b, pk_splat(-1.0f / 200.0f), fy);
-    const f32x2 fxl = (fx - pk_splat(16.0f / 116.0f)) * pk_splat(1.0f / 7.787f), fzl = (fz - pk_splat(16.0f / 116.0f)) * pk_splat(1.0f / 7.787f);
-    const f32x2 fx3 = fx * fx * fx, fz3 = fz * fz * fz;
-    fx.x = fx.x <= fThresh ? fxl.x : fx3.x; fx.y = fx.y <= fThresh ? fxl.y : fx3.y;
-    fz.x = fz.x <= fThresh ? fzl.x : fz3.x; fz.y = fz.y <= fThresh ? fzl.y : fz3.y;
-    f32x2 c0 = pk_fma(pk_splat(iv[0]), fx, pk_fma(pk_splat(iv[1]), y, pk_splat(iv[2]) * fz));
-    f32x2 c1 = pk_fma(pk_splat(iv[3]), fx, pk_fma(pk_splat(iv[4]), y, pk_splat(iv[5]) * fz));
-    f32x2 c2 = pk_fma(pk_splat(iv[6]), fx, pk_fma(pk_splat(iv[7]), y, pk_splat(iv[8]) * fz));
-    c0.x = clip1024_open(c0.x); c0.y = clip1024_open(c0.y); c1.x = clip1024_open(c1.x); c1.y = clip1024_open(c1.y);
-    c2.x = clip1024_open(c2.x); c2.y = clip1024_open(c2.y);
-    o0 = pk_spline1024(c0, igt); o1 = pk_spline1024(c1, igt); o2 = pk_spline1024(c2, igt);
-}
-#ifndef LVM_FWD_PAIRS
-#define LVM_FWD_PAIRS 0
-#endif
-// 4-pixel form of the forward conversion (the strip kernels convert pixel groups)
-template <bool EXACT>
-__device__ __forceinline__ void lab_fwd4(const float (&Bl)[4], const float (&Gl)[4], const float (&Rl)[4], const float* fw,
-                                         float (&L)[4], float (&a)[4], float (&b)[4]) {
-    if (EXACT || !LVM_FWD_PAIRS) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) lin_bgr_to_lab<EXACT>(Bl[k], Gl[k], Rl[k], fw, L[k], a[k], b[k]);
-        return;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k += 2) {
-        f32x2 Bp, Gp, Rp, Lp, Ap, Bq;
-        Bp.x = Bl[k]; Bp.y = Bl[k + 1]; Gp.x = Gl[k]; Gp.y = Gl[k + 1]; Rp.x = Rl[k]; Rp.y = Rl[k + 1];
-        lab_fwd_pair(Bp, Gp, Rp, fw, Lp, Ap, Bq);
-        L[k] = Lp.x; L[k + 1] = Lp.y; a[k] = Ap.x; a[k + 1] = Ap.y; b[k] = Bq.x; b[k + 1] = Bq.y;
-    }
+// ---- flavours of the colour arithmetic (template parameter FL of every kernel that converts) ------------------------
+// FL_LUT_FAST  (default): forward = OpenCV 4's interpolated 33^3 table (integer, bit-exact against the oracle), inverse and
+//              pyramid taps with reciprocal multiplies / fma chains / selects;
+// FL_LUT_EXACT (lvm_debug_exact_lab): the same forward table, every float operation in OpenCV's order (bit-identical to the
+//              oracle on the CPU emulation build);
+// FL_ANALYTIC  (lvm_debug_lab_analytic): the cube-root form RGB2Lab_f computes when its interpolation is switched off,
+//              OpenCV's operation order (the oracle with lvmo_set_lab_lut(0)).
+enum { FL_LUT_FAST = 0, FL_LUT_EXACT = 1, FL_ANALYTIC = 2 };
+constexpr bool fl_exact(int FL) { return FL != FL_LUT_FAST; }
+constexpr bool fl_lut(int FL) { return FL != FL_ANALYTIC; }
+// forward conversion of one u8 pixel; s_gam = the 256-entry gamma table in LDS (analytic flavour only)
+template <int FL>
+__device__ __forceinline__ void bgr_u8_to_lab(int B, int G, int R, const float* s_gam, const LabCoef& lab, float& L, float& a, float& b) {
+    if (fl_lut(FL)) lut_lab((uint32_t)B, (uint32_t)G, (uint32_t)R, lab.lut, L, a, b);
+    else lin_bgr_to_lab<true>(s_gam[B], s_gam[G], s_gam[R], lab.fwd, L, a, b);
 }
 // cooperative loads of the two Lab tables into LDS (256 threads)
 __device__ __forceinline__ void load_gamma_u8(float* s_gam, const float* g) { s_gam[threadIdx.x] = g[threadIdx.x]; }
@@ -351,6 +253,7 @@ struct ProfTotal { std::string name; double ms = 0; long long n = 0; };
 struct LevelGeom { int w, h; size_t n; };   // n = w*h
 
 struct Ctx;
+int lab_flavour(const Ctx* c);
 struct FrameIO {
     const uint8_t* d_in; ptrdiff_t in_stride, in_sstride;
     uint8_t* d_out; ptrdiff_t out_stride, out_sstride;
@@ -402,11 +305,19 @@ struct Ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_done = nullptr; bool ev_done_set = false;   // recorded after every enqueue on a caller stream (sync_streams)
     int max_frames = 0;               // lvm_set_max_frames: temporal-batch buffers are sized for this many frames up front
-    bool exact_lab = false;   // debug: OpenCV-order Lab arithmetic everywhere (bit-faithful to the oracle)
+    bool exact_lab = false;   // debug: OpenCV-order float arithmetic everywhere (bit-faithful to the oracle)
+    bool lab_analytic = false;   // debug: analytic forward Lab (OpenCV with its interpolation switched off) instead of the 33^3 table
+    uint4* d_lab_lut = nullptr;  // the forward table as 16-byte nodes (lab_lut.h)
+    std::vector<int16_t> lab_lut_compact;   // the same table, [r][q][p][3] (lvm_get_lab_lut)
     // preprocess stage (preprocess.hip): area tables of the current geometry, staging of the host chain
     void* pre_tables = nullptr;
     uint8_t *d_pre_in = nullptr, *d_pre_out = nullptr, *d_chain_out = nullptr; size_t pre_in_cap = 0, pre_out_cap = 0, chain_out_cap = 0;
 };
+
+inline int lab_flavour(const Ctx* c) { return c->lab_analytic ? FL_ANALYTIC : (c->exact_lab ? FL_LUT_EXACT : FL_LUT_FAST); }
+// kernel instantiation of the context's flavour: LVM_FL_PICK(fl, k_name, other template arguments...)
+#define LVM_FL_PICK(fl, K, ...) ((fl) == FL_ANALYTIC ? K<__VA_ARGS__, FL_ANALYTIC> : ((fl) == FL_LUT_EXACT ? K<__VA_ARGS__, FL_LUT_EXACT> : K<__VA_ARGS__, FL_LUT_FAST>))
+#define LVM_FL_PICK0(fl, K) ((fl) == FL_ANALYTIC ? K<FL_ANALYTIC> : ((fl) == FL_LUT_EXACT ? K<FL_LUT_EXACT> : K<FL_LUT_FAST>))
 
 void sync_streams(Ctx* c);
 void mark_enqueued(Ctx* c, hipStream_t s);
@@ -473,6 +384,10 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
 
 // host tables (lab_tables.cpp)
 void build_lab_tables(float gamma_u8[256], float invgamma[4096], float fwd[9], float inv[9]);
+void build_lab_lut_compact(std::vector<int16_t>& compact);
+void lab_lut_nodes_from_compact(const int16_t* compact, std::vector<uint16_t>& nodes);
+bool lab_lut_fine_index_ok();
+int upload_lab_lut(Ctx* c);
 void butterworth2(double Wn, double a[3], double b[3]);
 int max_levels(int w, int h);
 int optimal_buffer_size(int fps);

@@ -42,16 +42,16 @@ __device__ __forceinline__ void pyrdown_tile(float (&s_src)[C][DS_H][DS_W], floa
 
 // u8 frame -> float (Lab for C == 3, x/255 for C == 1; SCALE255 = false keeps [0,255] for the
 // colour mode, MagnifyCore.hpp:169) -> pyrDown -> level-1 planes.
-template <int C, bool LAB, bool EXACT>
+template <int C, bool LAB, int FL>
 __global__ __launch_bounds__(256) void k_down0(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                int w, int h, float* __restrict__ G1, int w1, int h1,
                                                LabCoef lab, float scale) {
     __shared__ float s_src[C][DS_H][DS_W];
     __shared__ float s_row[C][DS_H][DT_W];
-    __shared__ float s_gam[LAB ? 256 : 1];
+    __shared__ float s_gam[LAB && !fl_lut(FL) ? 256 : 1];
     const int tid = threadIdx.x;
     const int b = blockIdx.z;
-    if (LAB) { load_gamma_u8(s_gam, lab.gamma_u8); __syncthreads(); }
+    if (LAB && !fl_lut(FL)) { load_gamma_u8(s_gam, lab.gamma_u8); __syncthreads(); }
     const int ox0 = blockIdx.x * DT_W, oy0 = blockIdx.y * DT_H;
     const uint8_t* src = in + (size_t)b * in_sstride;
     for (int i = tid; i < DS_H * DS_W; i += 256) {
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_down0(const uint8_t* __restrict__ in, l
         const uint8_t* p = src + (size_t)gy * in_stride + (size_t)gx * C;
         if (LAB) {
             float L, a, bb;
-            lin_bgr_to_lab<EXACT>(s_gam[p[0]], s_gam[LAB ? p[1] : 0], s_gam[LAB ? p[2] : 0], lab.fwd, L, a, bb);
+            bgr_u8_to_lab<FL>(p[0], p[LAB ? 1 : 0], p[LAB ? 2 : 0], s_gam, lab, L, a, bb);
             s_src[0][ly][lx] = L; s_src[C > 1 ? 1 : 0][ly][lx] = a; s_src[C > 2 ? 2 : 0][ly][lx] = bb;
         } else {
 #pragma unroll
@@ -149,13 +149,12 @@ __device__ __forceinline__ void unpack_px4(const Px4 v, int (&B)[4], int (&G)[4]
 // 8 floats a pair of adjacent outputs needs are two aligned 128-bit reads; the vertical pass
 // slides a 5-row register window (no intermediate LDS image).
 constexpr int D0_ROWS = 2 * DT_H + 3, D0_GROUPS = 18, D0_PITCH = 76;
-template <bool LAB, bool EXACT>
+template <bool LAB, int FL>
 __global__ __launch_bounds__(256) void k_down0_v4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                   int w, int h, float* __restrict__ G1, int w1, int h1, LabCoef lab) {
     __shared__ __attribute__((aligned(16))) float s_src[3][D0_ROWS][D0_PITCH];
-    __shared__ float s_gam[256];
-    load_gamma_u8(s_gam, lab.gamma_u8);
-    __syncthreads();
+    __shared__ float s_gam[LAB && !fl_lut(FL) ? 256 : 1];
+    if (LAB && !fl_lut(FL)) { load_gamma_u8(s_gam, lab.gamma_u8); __syncthreads(); }
     const int b = blockIdx.z;
     const int ox0 = blockIdx.x * DT_W, oy0 = blockIdx.y * DT_H;
     const int sx0 = 2 * ox0 - 4, sy0 = 2 * oy0 - 2;
@@ -192,7 +191,7 @@ __global__ __launch_bounds__(256) void k_down0_v4(const uint8_t* __restrict__ in
         float L[4], A[4], Bb[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            if (LAB) lin_bgr_to_lab<EXACT>(s_gam[Bv[q]], s_gam[Gv[q]], s_gam[Rv[q]], lab.fwd, L[q], A[q], Bb[q]);
+            if (LAB) bgr_u8_to_lab<FL>(Bv[q], Gv[q], Rv[q], s_gam, lab, L[q], A[q], Bb[q]);
             else { L[q] = (float)Bv[q] * 1.0f; A[q] = (float)Gv[q] * 1.0f; Bb[q] = (float)Rv[q] * 1.0f; }   // colour mode: unscaled planes
         }
         float* d0 = &s_src[0][r][4 * g + 2];
@@ -297,12 +296,13 @@ inline int down0_rows_choice(int w1, int h1, long frames, long min_tasks, long* 
     *tasks_out = best_tasks;                                    // 0: no strip height gives enough strips
     return best;
 }
-template <bool LAB, bool EXACT>
+template <bool LAB, int FL>
 __global__ __launch_bounds__(D0R_THREADS) void k_down0_rows(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                             int w, int h, float* __restrict__ G1, int w1, int h1, LabCoef lab,
                                                             int strips_x, int strips_y, int ntasks, int rows) {
-    __shared__ float s_gam[256];
-    if (LAB) { load_gamma_u8(s_gam, lab.gamma_u8); __syncthreads(); }
+    constexpr bool EXACT = fl_exact(FL);
+    __shared__ float s_gam[LAB && !fl_lut(FL) ? 256 : 1];
+    if (LAB && !fl_lut(FL)) { load_gamma_u8(s_gam, lab.gamma_u8); __syncthreads(); }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int task = blockIdx.x * (D0R_THREADS / 64) + wave;
     if (task >= ntasks) return;
@@ -326,10 +326,8 @@ __global__ __launch_bounds__(D0R_THREADS) void k_down0_rows(const uint8_t* __res
         unpack_px4(pv, Bv, Gv, Rv);
         float P[3][4];
         if (LAB) {
-            float Bl[4], Gl[4], Rl[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { Bl[q] = s_gam[Bv[q]]; Gl[q] = s_gam[Gv[q]]; Rl[q] = s_gam[Rv[q]]; }
-            lab_fwd4<EXACT>(Bl, Gl, Rl, lab.fwd, P[0], P[1], P[2]);
+            for (int q = 0; q < 4; ++q) bgr_u8_to_lab<FL>(Bv[q], Gv[q], Rv[q], s_gam, lab, P[0][q], P[1][q], P[2][q]);
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) { P[0][q] = (float)Bv[q] * 1.0f; P[1][q] = (float)Gv[q] * 1.0f; P[2][q] = (float)Rv[q] * 1.0f; }   // colour mode: unscaled planes

@@ -54,10 +54,10 @@ __device__ const float kHp9[81] = {
     0.0000f, 0.0003f, 0.0011f, 0.0022f, 0.0027f, 0.0022f, 0.0011f, 0.0003f, 0.0000f};
 
 // ---- u8 BGR -> L plane (MagnifyCore.hpp:218-222) ---------------------------------------------
-// L of one pixel: the Y row of the matrix and cv::cubeRoot, always the float64 rational polynomial (L feeds the
-// ill-conditioned acos(q0 / |q|) step, DESIGN.md "Numerics": the hardware exp2 / log2 cube root fails the parity bar here).
-// EXACT: exactly lin_bgr_to_lab<true>'s L.  Otherwise the same polynomial with its float64 division done as reciprocal +
-// two Newton steps (12 -> 6 float64 operations; one ulp of L for ~1e-9 of the pixels).
+// L of one pixel.  Default (and what OpenCV 4 computes): the L channel of the interpolated 33^3 table (lut_lab_L, integer
+// arithmetic, bit-exact).  Analytic flavour: the Y row of the matrix and cv::cubeRoot's float64 rational polynomial (L feeds
+// the ill-conditioned acos(q0 / |q|) step, DESIGN.md "Numerics").  EXACT = false of rz_lum (division as reciprocal + two
+// Newton steps) is kept for tools/ only.
 template <bool EXACT>
 __device__ __forceinline__ float rz_lum(float B, float G, float R, const float* fw) {
     const float Y = B * fw[3] + G * fw[4] + R * fw[5];
@@ -65,28 +65,26 @@ __device__ __forceinline__ float rz_lum(float B, float G, float R, const float* 
     const float FY = hi ? cv_cube_root<EXACT>(Y) : (7.787f * Y + 16.0f / 116.0f);
     return hi ? (116.f * FY - 16.f) : (903.3f * Y);
 }
-template <bool EXACT>
+template <int FL>
 __global__ __launch_bounds__(256) void k_rz_lab(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                 int w, int h, float* __restrict__ Lp, LabCoef lab) {
-    __shared__ float s_gam[256];
-    load_gamma_u8(s_gam, lab.gamma_u8);
-    __syncthreads();
+    __shared__ float s_gam[fl_lut(FL) ? 1 : 256];
+    if (!fl_lut(FL)) { load_gamma_u8(s_gam, lab.gamma_u8); __syncthreads(); }
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
     if (x >= w) return;
     const uint8_t* p = in + (size_t)b * in_sstride + (size_t)y * in_stride + (size_t)x * 3;
-    Lp[((size_t)b * h + y) * w + x] = rz_lum<EXACT>(s_gam[p[0]], s_gam[p[1]], s_gam[p[2]], lab.fwd);
+    Lp[((size_t)b * h + y) * w + x] = fl_lut(FL) ? lut_lab_L(p[0], p[1], p[2], lab.lut) : rz_lum<true>(s_gam[p[0]], s_gam[p[1]], s_gam[p[2]], lab.fwd);
 }
 // Vectorised variant (4-pixel groups dword aligned): one 12-byte load and one 16-byte store per lane, and
 // a workgroup walks over kLabIters x 1024 pixels so the gamma table is loaded once per 4096 pixels instead
 // of once per 256.  Same arithmetic.
 constexpr int kLabIters = 4;
 struct __attribute__((packed, aligned(4))) RzIn4 { uint32_t a, b, c; };
-template <bool EXACT>
+template <int FL>
 __global__ __launch_bounds__(256) void k_rz_lab4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                  int w, int h, float* __restrict__ Lp, LabCoef lab) {
-    __shared__ float s_gam[256];
-    load_gamma_u8(s_gam, lab.gamma_u8);
-    __syncthreads();
+    __shared__ float s_gam[fl_lut(FL) ? 1 : 256];
+    if (!fl_lut(FL)) { load_gamma_u8(s_gam, lab.gamma_u8); __syncthreads(); }
     const int gpr = w >> 2, ngroups = gpr * h, b = blockIdx.y;
 #pragma unroll 1
     for (int it = 0; it < kLabIters; ++it) {
@@ -98,7 +96,9 @@ __global__ __launch_bounds__(256) void k_rz_lab4(const uint8_t* __restrict__ in,
                                  (v.b >> 16) & 255, v.b >> 24, v.c & 255, (v.c >> 8) & 255, (v.c >> 16) & 255, v.c >> 24};
         float L[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) L[k] = rz_lum<EXACT>(s_gam[pb[3 * k]], s_gam[pb[3 * k + 1]], s_gam[pb[3 * k + 2]], lab.fwd);
+        for (int k = 0; k < 4; ++k)
+            L[k] = fl_lut(FL) ? lut_lab_L(pb[3 * k], pb[3 * k + 1], pb[3 * k + 2], lab.lut)
+                              : rz_lum<true>(s_gam[pb[3 * k]], s_gam[pb[3 * k + 1]], s_gam[pb[3 * k + 2]], lab.fwd);
         *reinterpret_cast<float4*>(Lp + ((size_t)b * h + y) * w + x) = make_float4(L[0], L[1], L[2], L[3]);
     }
 }
@@ -1036,18 +1036,19 @@ __global__ __launch_bounds__(256) void k_rz_collapse(const float* __restrict__ b
 // level-0 collapse (or plain L plane when there are no bands) + Lab2BGR + u8 (MagnifyCore.hpp:272-277).
 // 4 pixels per thread; VEC = the frame's 4-pixel groups are dword aligned (12-byte loads/stores).
 struct __attribute__((packed, aligned(4))) RzPx4 { uint32_t a, b, c; };
-template <bool BANDS, bool EXACT, bool VEC, bool COMPACT, bool DBG>   // DBG: also store the float frame (compile time: no per-pixel branch otherwise)
+template <bool BANDS, int FL, bool VEC, bool COMPACT, bool DBG>   // DBG: also store the float frame (compile time: no per-pixel branch otherwise)
 __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                   uint8_t* __restrict__ out, long out_stride, long out_sstride, int w, int h,
                                                   const float* __restrict__ bandA, const float* __restrict__ resn, int nw,
                                                   int nh, LabCoef lab, int tiles_x, int tiles_y, int nstreams,
                                                   float* __restrict__ dbg) {
+    constexpr bool EXACT = fl_exact(FL);
     __shared__ __attribute__((aligned(16))) float s_igt[4096];
-    __shared__ float s_gam[256];
+    __shared__ float s_gam[fl_lut(FL) ? 1 : 256];
     __shared__ __attribute__((aligned(16))) float sb[CSH][CSP];
     __shared__ __attribute__((aligned(16))) CollapseTile<COMPACT> su;
     load_invgamma(s_igt, lab.invgamma);
-    load_gamma_u8(s_gam, lab.gamma_u8);
+    if (!fl_lut(FL)) load_gamma_u8(s_gam, lab.gamma_u8);
     __syncthreads();
     const int ntiles = tiles_x * tiles_y * nstreams;
     const int y = collapse_row(), x = (threadIdx.x & 15) * 4;
@@ -1088,12 +1089,9 @@ __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 float L, a, bb;
-                // without bands L itself is the output luminance: keep it exact then
-                lin_bgr_to_lab<EXACT || !BANDS>(s_gam[pb[3 * m]], s_gam[pb[3 * m + 1]], s_gam[pb[3 * m + 2]], lab.fwd, L, a, bb);
+                bgr_u8_to_lab<FL>(pb[3 * m], pb[3 * m + 1], pb[3 * m + 2], s_gam, lab, L, a, bb);
                 if (BANDS) L = Lc[m];
                 float o0, o1, o2;
-                // (skipping the detour through (a, b) as the last Laplace kernel does -- fx = fX + (fy - fY), fz = fZ + (fy - fY),
-                //  lvm_internal.h -- was measured here too: 480 us either way, this kernel is bound by its 9x9 stencils)
                 lab_to_bgr<EXACT>(L, a, bb, EXACT ? lab.inv : lab.inv1024, s_igt, o0, o1, o2);
                 if (DBG && dbg && b == 0 && gx + m < w) { float* d = dbg + ((size_t)gy * w + gx + m) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
                 ob[3 * m] = sat_u8(o0 * 255.0f + lab.a255);
@@ -1187,10 +1185,10 @@ static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B,
     const dim3 blk(256);
     if (w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0) {
         const long groups = (long)(w / 4) * h;
-        LVM_LAUNCH(c, "rz_lab", c->exact_lab ? k_rz_lab4<true> : k_rz_lab4<false>, dim3((unsigned)((groups + 256 * kLabIters - 1) / (256 * kLabIters)), NZ), blk, s, io.d_in,
+        LVM_LAUNCH(c, "rz_lab", LVM_FL_PICK0(lab_flavour(c), k_rz_lab4), dim3((unsigned)((groups + 256 * kLabIters - 1) / (256 * kLabIters)), NZ), blk, s, io.d_in,
                    (long)io.in_stride, (long)io.in_sstride, w, h, B.oct[0], c->lab);
     } else {
-        LVM_LAUNCH(c, "rz_lab", c->exact_lab ? k_rz_lab<true> : k_rz_lab<false>, dim3((w + 255) / 256, h, NZ), blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, B.oct[0], c->lab);
+        LVM_LAUNCH(c, "rz_lab", LVM_FL_PICK0(lab_flavour(c), k_rz_lab), dim3((w + 255) / 256, h, NZ), blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, B.oct[0], c->lab);
     }
     for (int l = 0; l < nb; ++l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
@@ -1255,8 +1253,8 @@ static void rz_phase(Ctx* c, RieszState* st, const RzBufs& B, int mode, hipStrea
         (vec ? blocks4 : blocks) += v.tx * v.ty * NS;
     }
     a.nlv = n1; a4.nlv = n4;
-    if (n4) LVM_LAUNCH(c, mode ? "rz_seed" : "rz_phase", c->exact_lab ? k_rz_phase4<true> : k_rz_phase4<false>, dim3(blocks4), dim3(256), s, a4);
-    if (n1) LVM_LAUNCH(c, mode ? "rz_seed_small" : "rz_phase_small", c->exact_lab ? k_rz_phase<true> : k_rz_phase<false>, dim3(blocks), dim3(256), s, a);
+    if (n4) LVM_LAUNCH(c, mode ? "rz_seed" : "rz_phase", (lab_flavour(c) != FL_LUT_FAST) ? k_rz_phase4<true> : k_rz_phase4<false>, dim3(blocks4), dim3(256), s, a4);
+    if (n1) LVM_LAUNCH(c, mode ? "rz_seed_small" : "rz_phase_small", (lab_flavour(c) != FL_LUT_FAST) ? k_rz_phase<true> : k_rz_phase<false>, dim3(blocks), dim3(256), s, a);
 }
 
 // amplify + collapse + output of the nt frames (RieszPyramid.cpp:248-252, 304-325; MagnifyCore.hpp:269-277)
@@ -1285,8 +1283,8 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
             else { v.tx = (v.w + BT - 1) / BT; v.ty = (v.h + BTH - 1) / BTH; v.block0 = blocks; blocks += v.tx * v.ty * NZ; }
         }
         a.nlv = n1; a4.nlv = n4;
-        if (n4) LVM_LAUNCH(c, "rz_blur_amp", c->exact_lab ? k_rz_blur_amp4<true> : k_rz_blur_amp4<false>, dim3(blocks4), dim3(B2T), s, a4);
-        if (n1) LVM_LAUNCH(c, "rz_blur_amp_small", c->exact_lab ? k_rz_blur_amp<true> : k_rz_blur_amp<false>, dim3(blocks), blk, s, a);
+        if (n4) LVM_LAUNCH(c, "rz_blur_amp", (lab_flavour(c) != FL_LUT_FAST) ? k_rz_blur_amp4<true> : k_rz_blur_amp4<false>, dim3(blocks4), dim3(B2T), s, a4);
+        if (n1) LVM_LAUNCH(c, "rz_blur_amp_small", (lab_flavour(c) != FL_LUT_FAST) ? k_rz_blur_amp<true> : k_rz_blur_amp<false>, dim3(blocks), blk, s, a);
     }
     const float* resn = B.oct[levels - 1];       // res_{L-1} = residual octave
     for (int l = nb - 1; l >= 1; --l) {
@@ -1307,18 +1305,19 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
     float* dbg = c->keep_float ? c->d_float : nullptr;
     const bool vec = w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && io.out_stride % 4 == 0 &&
                      io.out_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0 && ((uintptr_t)io.d_out % 4) == 0;
-    const bool ex = c->exact_lab;
+    const int fl = lab_flavour(c);
     const bool compact = st->compact && w % 2 == 0 && h % 2 == 0;
-    // (BANDS, EXACT, VEC, COMPACT, DBG) -> instantiation
+    // (BANDS, FL, VEC, COMPACT, DBG) -> instantiation
     auto pick = [&](auto bands) {
         constexpr bool BN = decltype(bands)::value;
         auto p3 = [&](auto e, auto v, auto cp) {
-            constexpr bool E = decltype(e)::value, V = decltype(v)::value, CP = decltype(cp)::value;
+            constexpr int E = decltype(e)::value; constexpr bool V = decltype(v)::value, CP = decltype(cp)::value;
             return dbg ? k_rz_final<BN, E, V, CP, true> : k_rz_final<BN, E, V, CP, false>;
         };
         auto p2 = [&](auto e, auto v) { return (compact && BN) ? p3(e, v, std::true_type{}) : p3(e, v, std::false_type{}); };
         auto p1 = [&](auto e) { return vec ? p2(e, std::true_type{}) : p2(e, std::false_type{}); };
-        return ex ? p1(std::true_type{}) : p1(std::false_type{});
+        return fl == FL_ANALYTIC ? p1(std::integral_constant<int, FL_ANALYTIC>{})
+                                 : (fl == FL_LUT_EXACT ? p1(std::integral_constant<int, FL_LUT_EXACT>{}) : p1(std::integral_constant<int, FL_LUT_FAST>{}));
     };
     auto kfb = pick(std::true_type{});
     auto kfn = pick(std::false_type{});

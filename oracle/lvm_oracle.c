@@ -360,38 +360,63 @@ static inline void bgr2lab_px(float s0, float s1, float s2, float* o) {
 }
 /* ---- OpenCV 4's DEFAULT forward float path: the trilinear-interpolated 33^3 int16 LUT ---------------------------
  * [cv] color_lab.cpp: RGB2Labfloat with useInterpolation (= sRGB + default coefficients + default white point, the
- * case cv::cvtColor(COLOR_BGR2Lab) on CV_32F is), initLabTabs (LAB_LUT_DIM = 33, lab_base_shift = 14, trilinear_shift
- * = 4), trilinearInterpolate.  UNPINNED like the rest of the OpenCV boundary (restated from the published source, no
- * OpenCV here to check against) and OFF by default: the library implements the analytic form; this option exists to
- * QUANTIFY how far a real OpenCV 4 build would sit from it (tests/test_oracle_modes.py).
- * The table is built in float64 (OpenCV: softfloat / softdouble); entries are rounded to 1/16384 of the range, so the
- * two agree except for an occasional last int16 unit.                                                              */
+ * case cv::cvtColor(COLOR_BGR2Lab) on CV_32F is -- MagnifyCore.hpp:90,219), initLabTabs (LAB_LUT_DIM = 33,
+ * lab_base_shift = 14, trilinear_shift = 4), trilinearInterpolate.  This IS what the reference computes, so it is the
+ * oracle's default since round 3; lvmo_set_lab_lut(0) selects the analytic form (OpenCV with interpolation disabled).
+ * UNPINNED like the rest of the OpenCV boundary (restated from the published source, no OpenCV here to check against).
+ * Table build: OpenCV uses its softfloat type, i.e. IEEE binary32 operations rounded one by one; restated on native floats
+ * (-ffp-contract=off).  softfloat's pow(x, y) = exp(y * log(x)) with log, product and exp each rounded to binary32 (its
+ * log / exp work in binary64 inside and round once: the C library's double log / exp stand in for them), its cbrt is the
+ * cv::cubeRoot polynomial, mulAdd is a fused multiply-add.  A real build's table can be installed with
+ * lvmo_lab_lut_override (oracle/ref_driver.cpp recovers it from cvtColor on the 33^3 node colours).                  */
 enum { LAB_LUT_DIM = 33, LAB_BASE_SHIFT = 14, LAB_BASE = 1 << LAB_BASE_SHIFT, LAB_LUT_SHIFT = 5, TRI_SHIFT = 4 };
-static int16_t* g_lab_lut = NULL;               /* [r][g][b][3] at the 33^3 grid (OpenCV stores 8 replicated corners per cell) */
-static int g_lab_use_lut = 0;
+enum { LAB_LUT_ENTRIES = 3 * LAB_LUT_DIM * LAB_LUT_DIM * LAB_LUT_DIM };
+static int16_t* g_lab_lut = NULL;               /* RGB2Labprev order: [3 (p + 33 q + 1089 r) + ch], p / q / r = R / G / B grid index
+                                                   (OpenCV then replicates the 8 corners of every cell: same values) */
+static int g_lab_use_lut = 1;
 void lvmo_set_lab_lut(int on) { g_lab_use_lut = on != 0; }
+static float lut_apply_gamma(float x) {         /* applyGamma(softfloat) */
+    const float thr = 809.f / 20000.f, low = 323.f / 25.f, shift = 11.f / 200.f, power = 12.f / 5.f;
+    if (x <= thr) return x / low;
+    const float base = (x + shift) / (1.f + shift);
+    const float lg = (float)log((double)base);
+    const float pr = power * lg;
+    return (float)exp((double)pr);
+}
 static void lab_lut_init(void) {
     if (g_lab_lut) return;
     static const double M[9] = { 0.412453, 0.357580, 0.180423, 0.212671, 0.715160, 0.072169, 0.019334, 0.119193, 0.950227 };
     static const double D65[3] = { 0.950456, 1.0, 1.088754 };
-    int16_t* t = (int16_t*)malloc(sizeof(int16_t) * 3 * LAB_LUT_DIM * LAB_LUT_DIM * LAB_LUT_DIM);
-    for (int p = 0; p < LAB_LUT_DIM; ++p)
+    float C[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) C[i * 3 + j] = (float)(M[i * 3 + j] * (i == 1 ? 1.0 : 1.0 / D65[i]));
+    const float lthresh = 216.f / 24389.f, lscale = 841.f / 108.f, lbias = 16.f / 116.f, f9033 = 24389.f / 27.f;
+    int16_t* t = (int16_t*)malloc(sizeof(int16_t) * LAB_LUT_ENTRIES);
+    for (int r = 0; r < LAB_LUT_DIM; ++r)
         for (int q = 0; q < LAB_LUT_DIM; ++q)
-            for (int r = 0; r < LAB_LUT_DIM; ++r) {
-                double rgb[3] = { (double)p / (LAB_LUT_DIM - 1), (double)q / (LAB_LUT_DIM - 1), (double)r / (LAB_LUT_DIM - 1) };
-                for (int k = 0; k < 3; ++k) rgb[k] = rgb[k] <= 0.04045 ? rgb[k] / 12.92 : pow((rgb[k] + 0.055) / 1.055, 2.4);   /* applyGamma */
-                double xyz[3];
-                for (int k = 0; k < 3; ++k) xyz[k] = (M[k * 3] * rgb[0] + M[k * 3 + 1] * rgb[1] + M[k * 3 + 2] * rgb[2]) / D65[k];
-                double f[3];
-                for (int k = 0; k < 3; ++k) f[k] = xyz[k] > 216.0 / 24389.0 ? cbrt(xyz[k]) : (24389.0 / 27.0 * xyz[k] + 16.0) / 116.0;
-                const double L = xyz[1] > 216.0 / 24389.0 ? 116.0 * f[1] - 16.0 : 24389.0 / 27.0 * xyz[1];
-                const double a = 500.0 * (f[0] - f[1]), b = 200.0 * (f[1] - f[2]);
-                int16_t* e = t + 3 * ((p * LAB_LUT_DIM + q) * LAB_LUT_DIM + r);
-                e[0] = (int16_t)lrint(LAB_BASE * L / 100.0);
-                e[1] = (int16_t)lrint(LAB_BASE * (a + 128.0) / 256.0);
-                e[2] = (int16_t)lrint(LAB_BASE * (b + 128.0) / 256.0);
+            for (int p = 0; p < LAB_LUT_DIM; ++p) {
+                const float R = lut_apply_gamma((float)p / 32.f), G = lut_apply_gamma((float)q / 32.f), B = lut_apply_gamma((float)r / 32.f);
+                const float X = R * C[0] + G * C[1] + B * C[2];
+                const float Y = R * C[3] + G * C[4] + B * C[5];
+                const float Z = R * C[6] + G * C[7] + B * C[8];
+                const float FX = X > lthresh ? lvmo_cube_root(X) : fmaf(X, lscale, lbias);
+                const float FY = Y > lthresh ? lvmo_cube_root(Y) : fmaf(Y, lscale, lbias);
+                const float FZ = Z > lthresh ? lvmo_cube_root(Z) : fmaf(Z, lscale, lbias);
+                const float L = Y > lthresh ? (116.f * FY - 16.f) : (Y * f9033);
+                const float a = 500.f * (FX - FY), b = 200.f * (FY - FZ);
+                int16_t* e = t + 3 * (p + LAB_LUT_DIM * (q + LAB_LUT_DIM * r));
+                e[0] = (int16_t)lrintf((float)LAB_BASE * L / 100.f);
+                e[1] = (int16_t)lrintf((float)LAB_BASE * (a + 128.f) / 256.f);
+                e[2] = (int16_t)lrintf((float)LAB_BASE * (b + 128.f) / 256.f);
             }
     g_lab_lut = t;
+}
+void lvmo_lab_lut_table(int16_t* out) { lab_lut_init(); memcpy(out, g_lab_lut, sizeof(int16_t) * LAB_LUT_ENTRIES); }
+void lvmo_lab_lut_override(const int16_t* tab) {     /* NULL: back to the restated table */
+    if (g_lab_lut) { free(g_lab_lut); g_lab_lut = NULL; }
+    if (!tab) return;
+    g_lab_lut = (int16_t*)malloc(sizeof(int16_t) * LAB_LUT_ENTRIES);
+    memcpy(g_lab_lut, tab, sizeof(int16_t) * LAB_LUT_ENTRIES);
 }
 /* [cv] RGB2Labfloat::operator(), useInterpolation branch (scalar form; the SIMD form computes the same integers) */
 static inline void bgr2lab_lut_px(float s0, float s1, float s2, float* o) {
@@ -409,7 +434,7 @@ static inline void bgr2lab_lut_px(float s0, float s1, float s2, float* o) {
             idx[k] = t[k] + up; if (idx[k] > LAB_LUT_DIM - 1) idx[k] = LAB_LUT_DIM - 1;
             wgt *= up ? w1[k] : (1 << TRI_SHIFT) - w1[k];
         }
-        const int16_t* e = g_lab_lut + 3 * ((idx[0] * LAB_LUT_DIM + idx[1]) * LAB_LUT_DIM + idx[2]);
+        const int16_t* e = g_lab_lut + 3 * (idx[0] + LAB_LUT_DIM * (idx[1] + LAB_LUT_DIM * idx[2]));
         acc[0] += e[0] * wgt; acc[1] += e[1] * wgt; acc[2] += e[2] * wgt;
     }
     for (int k = 0; k < 3; ++k) acc[k] = (acc[k] + (1 << (3 * TRI_SHIFT - 1))) >> (3 * TRI_SHIFT);      /* CV_DESCALE */

@@ -100,9 +100,12 @@ void lvmo_bgr2gray_u8(const uint8_t* src, int npix, uint8_t* dst);
 typedef struct lvmo_area_tab { int si, di; float alpha; } lvmo_area_tab;
 int  lvmo_area_table(int ssize, int dsize, double scale, lvmo_area_tab* tab, int cap);
 
-/* Forward Lab flavour of the oracle: 0 (default) analytic float path, 1 OpenCV 4's default trilinear-LUT path
- * (RGB2Labfloat::useInterpolation) -- quantification only, see lvm_oracle.c */
+/* Forward Lab flavour of the oracle: 1 (default) OpenCV 4's default trilinear-LUT path (RGB2Labfloat::useInterpolation,
+ * what cv::cvtColor(COLOR_BGR2Lab) on CV_32F runs), 0 the analytic float path (OpenCV with interpolation disabled) */
 void lvmo_set_lab_lut(int on);
+/* the 33^3 x 3 int16 table in RGB2Labprev order (3 (p + 33 q + 1089 r) + channel); override with a real build's table */
+void lvmo_lab_lut_table(int16_t* out);
+void lvmo_lab_lut_override(const int16_t* tab);
 
 /* Exporter::compose (export/Exporter.cpp:53-88) without the text overlay */
 int lvmo_compose_geometry(int split, int ow, int oh, int pw, int ph, int* cw, int* ch);

@@ -90,6 +90,10 @@ def lib():
         L.lvmo_bgr2gray_u8.restype = None
         L.lvmo_set_lab_lut.argtypes = [C.c_int]
         L.lvmo_set_lab_lut.restype = None
+        L.lvmo_lab_lut_table.argtypes = [C.c_void_p]
+        L.lvmo_lab_lut_table.restype = None
+        L.lvmo_lab_lut_override.argtypes = [C.c_void_p]
+        L.lvmo_lab_lut_override.restype = None
         L.lvmo_compose_geometry.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip]
         L.lvmo_compose.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                    C.c_ssize_t, C.c_void_p, C.c_ssize_t]

@@ -35,7 +35,11 @@ def emu(lvm):
     alt = os.environ.get("LVM_EMU_LIB")          # e.g. the AddressSanitizer build of tools/emu_asan.sh
     if alt:
         return lvm.bind(ctypes.CDLL(alt))
-    subprocess.check_call([os.path.join(here, "build_emu.sh")])
+    import fcntl
+    os.makedirs(os.path.join(here, "_build"), exist_ok=True)
+    with open(os.path.join(here, "_build", ".lock"), "w") as lk:       # pytest-xdist workers build one at a time
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        subprocess.check_call([os.path.join(here, "build_emu.sh")])
     return lvm.bind(ctypes.CDLL(os.path.join(here, "_build", "liblvm_emu.so")))
 
 

@@ -52,6 +52,8 @@ static inline void hipLaunchKernelGGL(K kern, dim3 grid, dim3 block, size_t, hip
     hipemu::launch([=]() { kern(args...); }, grid, block);
 }
 
+struct uint4 { unsigned x, y, z, w; };
+#define LVM_EMU_NO_DOT2 1      // lab_lut.h: v_dot2_i32_i16 spelled out
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }

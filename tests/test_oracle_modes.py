@@ -130,11 +130,11 @@ def test_color_window_cap(lvm, po):
 
 
 def test_opencv_lut_forward_lab_gap_is_quantified(lvm, po):
-    """OpenCV 4's default float BGR2Lab is a trilinear-interpolated 33^3 int16 LUT (RGB2Labfloat::useInterpolation), the
-    oracle's default -- and the library -- the analytic path.  This test runs the oracle with both flavours on the
-    reference's own configs (reduced size) and records how far the magnified frames move: the number DESIGN.md section 5
-    quotes for 'what a real OpenCV 4 build would add on top of the parity margins'.  Bounds are loose on purpose: the
-    point is that the gap is far above 1e-4 (Laplace ~5e-3; Riesz, whose phase step is ill-conditioned, ~0.3) and that it is known."""
+    """OpenCV 4's default float BGR2Lab is a trilinear-interpolated 33^3 int16 LUT (RGB2Labfloat::useInterpolation): the
+    oracle's and the library's default since round 3 (rounds 1-2 implemented the analytic path).  This test runs the oracle
+    with both flavours on the reference's own configs (reduced size) and records how far the magnified frames move -- why an
+    analytic implementation cannot meet the 1e-4 bar against a real OpenCV 4 build.  Bounds are loose
+    on purpose: the gap is far above 1e-4 (Laplace ~5e-3; Riesz, whose phase step is ill-conditioned, ~0.3)."""
     res = {}
     for name, idx, nfr in (("laplace", 0, 12), ("riesz", 2, 8)):
         ck, pk = lvm.synth.config(idx, (320, 180, 4))
@@ -152,7 +152,7 @@ def test_opencv_lut_forward_lab_gap_is_quantified(lvm, po):
                         fl.append(o.last_float().copy()); u8.append(out.copy())
                 o.close()
             finally:
-                po.lib().lvmo_set_lab_lut(0)
+                po.lib().lvmo_set_lab_lut(1)
             outs[lut] = (np.stack(fl), np.stack(u8))
         rel = float(np.abs(outs[0][0] - outs[1][0]).max() / np.abs(outs[0][0]).max())
         du = np.abs(outs[0][1].astype(int) - outs[1][1].astype(int))

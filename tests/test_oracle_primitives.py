@@ -143,7 +143,15 @@ def srgb_to_lab_f64(bgr):
     return np.stack([L, 500 * (f(X) - f(Y)), 200 * (f(Y) - f(Z))], -1)
 
 
-def test_bgr2lab_matches_analytic_definition(po):
+@pytest.fixture
+def analytic_lab(po):
+    """The oracle's analytic forward Lab (OpenCV with its interpolation switched off) for one test."""
+    po.lib().lvmo_set_lab_lut(0)
+    yield
+    po.lib().lvmo_set_lab_lut(1)
+
+
+def test_bgr2lab_matches_analytic_definition(po, analytic_lab):
     a = rng_img(40, 50, 3, seed=3)
     lab = po.bgr2lab(a)
     np.testing.assert_allclose(lab, srgb_to_lab_f64(a), rtol=0, atol=2e-4)
@@ -153,10 +161,30 @@ def test_bgr2lab_matches_analytic_definition(po):
     np.testing.assert_allclose(black, 0, atol=1e-6)
 
 
-def test_lab_round_trip(po):
+def test_bgr2lab_lut_interpolates_the_definition(po):
+    """OpenCV 4's default (the oracle's default): the 33^3 table, trilinear 4-bit weights.  Within the table's
+    interpolation error of the CIE definition (L 0.3 of 100, a / b 0.7), exact at white and black."""
+    a = rng_img(40, 50, 3, seed=3)
+    d = np.abs(po.bgr2lab(a) - srgb_to_lab_f64(a)).reshape(-1, 3).max(axis=0)
+    assert d[0] < 0.3 and d[1] < 0.7 and d[2] < 0.7, d
+    white = po.bgr2lab(np.ones((1, 1, 3), np.float32))
+    assert abs(white[0, 0, 0] - 100.0) < 0.01 and abs(white[0, 0, 1]) < 0.02 and abs(white[0, 0, 2]) < 0.02
+    np.testing.assert_allclose(po.bgr2lab(np.zeros((1, 1, 3), np.float32)), 0, atol=1e-6)
+
+
+def test_lab_round_trip(po, analytic_lab):
     u8 = np.random.default_rng(5).integers(0, 256, (64, 64, 3)).astype(np.float32) * np.float32(1.0 / 255.0)
     back = po.lab2bgr(po.bgr2lab(u8))
     np.testing.assert_allclose(back, u8, rtol=0, atol=2e-4)  # << 1/255: the 8-bit round trip is exact
+
+
+def test_lab_round_trip_through_the_lut(po):
+    """forward LUT + analytic inverse (what a first frame of the reference is): within the table's interpolation error,
+    i.e. the 8-bit round trip is exact for most but not all colours."""
+    u = np.random.default_rng(5).integers(0, 256, (64, 64, 3))
+    back = po.lab2bgr(po.bgr2lab(u.astype(np.float32) * np.float32(1.0 / 255.0)))
+    q = np.rint(back * 255.0).astype(np.int64)
+    assert np.abs(q - u).max() <= 2 and (q == u).mean() > 0.8
 
 
 def test_cube_root(po):

@@ -1,0 +1,329 @@
+// Cost of OpenCV's LUT forward Lab on MI355X for candidate table layouts, next to the analytic default flavour, on the
+// bench clip's statistics (synth.texture: two sinusoids + uniform noise of +-12 per channel) and on a smooth frame.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -Iinclude \
+//         -Ilive-video-magnification_amd/csrc tools/ubench_lut.hip live-video-magnification_amd/csrc/lab_tables.cpp -o /tmp/ubench_lut
+// Every kernel: one lane = one 4-pixel group (12-byte load), converts, stores one float4 of sums (16 bytes per 4 pixels).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "pyramid.h"
+#include "lab_lut.h"
+using namespace lvm;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+// ---- analytic default flavour ----
+__global__ __launch_bounds__(256) void k_analytic(const uint8_t* in, float4* out, int ngroups, LabCoef lab) {
+    __shared__ float s_gam[256];
+    load_gamma_u8(s_gam, lab.gamma_u8);
+    __syncthreads();
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi >= ngroups) return;
+    const Px4 pv = *reinterpret_cast<const Px4*>(in + (size_t)gi * 12);
+    int Bv[4], Gv[4], Rv[4];
+    unpack_px4(pv, Bv, Gv, Rv);
+    float Bl[4], Gl[4], Rl[4], L[4], a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { Bl[q] = s_gam[Bv[q]]; Gl[q] = s_gam[Gv[q]]; Rl[q] = s_gam[Rv[q]]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lin_bgr_to_lab<false>(Bl[q], Gl[q], Rl[q], lab.fwd, L[q], a[q], b[q]);
+    out[gi] = make_float4(L[0] + L[1] + L[2] + L[3], a[0] + a[1] + a[2] + a[3], b[0] + b[1] + b[2] + b[3], 0.f);
+}
+// ---- layout D: 16-byte nodes (lab_lut.h) ----
+__global__ __launch_bounds__(256) void k_lut_nodes(const uint8_t* in, float4* out, int ngroups, const uint4* nodes) {
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi >= ngroups) return;
+    const Px4 pv = *reinterpret_cast<const Px4*>(in + (size_t)gi * 12);
+    int Bv[4], Gv[4], Rv[4];
+    unpack_px4(pv, Bv, Gv, Rv);
+    float L[4], a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lut_lab(Bv[q], Gv[q], Rv[q], nodes, L[q], a[q], b[q]);
+    out[gi] = make_float4(L[0] + L[1] + L[2] + L[3], a[0] + a[1] + a[2] + a[3], b[0] + b[1] + b[2] + b[3], 0.f);
+}
+// ---- layout A: OpenCV's replicated cells (24 int16 per cell: 8 corners x {L, a, b}, corner index 4 dp + 2 dq + dr) ----
+__device__ __forceinline__ void lut_lab_cells(uint32_t B, uint32_t G, uint32_t R, const uint4* __restrict__ cells, float& L, float& a, float& b) {
+    const uint32_t fr = lut_fine(R), fg = lut_fine(G), fb = lut_fine(B);
+    const uint32_t x = fr & 15u, y = fg & 15u, z = fb & 15u;
+    const uint32_t n = 3u * ((fr >> 4) + 33u * (fg >> 4) + 1089u * (fb >> 4));
+    const uint4 cL = cells[n], ca = cells[n + 1], cb = cells[n + 2];
+    const uint32_t wz = (16u - z) | (z << 16), x0 = 16u - x, y0 = 16u - y;
+    const uint32_t w00 = (x0 * y0) * wz, w01 = (x0 * y) * wz, w10 = (x * y0) * wz, w11 = (x * y) * wz;   // (dp, dq)
+    const int rnd = 1 << 11;
+    const int iL = lut_dot2(cL.w, w11, lut_dot2(cL.z, w10, lut_dot2(cL.y, w01, lut_dot2(cL.x, w00, rnd)))) >> 12;
+    const int ia = lut_dot2(ca.w, w11, lut_dot2(ca.z, w10, lut_dot2(ca.y, w01, lut_dot2(ca.x, w00, rnd)))) >> 12;
+    const int ib = lut_dot2(cb.w, w11, lut_dot2(cb.z, w10, lut_dot2(cb.y, w01, lut_dot2(cb.x, w00, rnd)))) >> 12;
+    L = lut_L(iL); a = lut_ab(ia); b = lut_ab(ib);
+}
+__global__ __launch_bounds__(256) void k_lut_cells(const uint8_t* in, float4* out, int ngroups, const uint4* cells) {
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi >= ngroups) return;
+    const Px4 pv = *reinterpret_cast<const Px4*>(in + (size_t)gi * 12);
+    int Bv[4], Gv[4], Rv[4];
+    unpack_px4(pv, Bv, Gv, Rv);
+    float L[4], a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lut_lab_cells(Bv[q], Gv[q], Rv[q], cells, L[q], a[q], b[q]);
+    out[gi] = make_float4(L[0] + L[1] + L[2] + L[3], a[0] + a[1] + a[2] + a[3], b[0] + b[1] + b[2] + b[3], 0.f);
+}
+// ---- layout E: the L channel alone, compact int16 [r][q][p] padded to dwords, resident in LDS (72 KB): what the
+// Riesz L plane needs.  A B-direction pair would be unaligned for odd r, so the table is stored with p fastest and the
+// R-direction pair (p, p + 1) is read as the two aligned dwords around it (ds_read2_b32) + one v_alignbit.
+constexpr int kLdsLWords = (kLabLutNodes + 1089 + 33 + 2) / 2 + 1;
+__global__ __launch_bounds__(1024) void k_lut_lds_L(const uint8_t* in, float4* out, int ngroups, const uint32_t* Lwords, int per_block) {
+    extern __shared__ uint32_t s_L[];
+    for (int i = threadIdx.x; i < kLdsLWords; i += 1024) s_L[i] = Lwords[i];
+    __syncthreads();
+    const int g0 = blockIdx.x * per_block;
+    for (int k = threadIdx.x; k < per_block; k += 1024) {
+        const int gi = g0 + k;
+        if (gi >= ngroups) break;
+        const Px4 pv = *reinterpret_cast<const Px4*>(in + (size_t)gi * 12);
+        int Bv[4], Gv[4], Rv[4];
+        unpack_px4(pv, Bv, Gv, Rv);
+        float L[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t fr = lut_fine(Rv[q]), fg = lut_fine(Gv[q]), fb = lut_fine(Bv[q]);
+            const uint32_t x = fr & 15u, y = fg & 15u, z = fb & 15u;
+            const uint32_t n = (fr >> 4) + 33u * (fg >> 4) + 1089u * (fb >> 4);
+            const uint32_t sh = (n & 1u) * 16u;
+            auto pair = [&](uint32_t m) __attribute__((always_inline)) {       // (T[m], T[m + 1]), m has n's parity iff the offset is even
+                const uint32_t wd = m >> 1;
+                return __builtin_amdgcn_alignbit(s_L[wd + 1], s_L[wd], (m & 1u) * 16u);
+            };
+            (void)sh;
+            const uint32_t wx = (16u - x) | (x << 16), y0 = 16u - y, z0 = 16u - z;
+            const uint32_t w00 = (y0 * z0) * wx, w10 = (y * z0) * wx, w01 = (y0 * z) * wx, w11 = (y * z) * wx;   // (dq, dr)
+            const int iL = lut_dot2(pair(n + 33 + 1089), w11, lut_dot2(pair(n + 1089), w01, lut_dot2(pair(n + 33), w10, lut_dot2(pair(n), w00, 1 << 11)))) >> 12;
+            L[q] = lut_L(iL);
+        }
+        out[gi] = make_float4(L[0] + L[1] + L[2] + L[3], 0.f, 0.f, 0.f);
+    }
+}
+
+// ---- layout F (hybrid): (a, b) packed per NODE in LDS (a in the low, b in the high half of a dword; 144 KB, one 1024-thread
+// workgroup per CU), L from an L2-resident table of CELLS (8 corners x int16 = one 16-byte gather per pixel, 575 KB).
+// v_perm_b32 turns two B-neighbour node dwords into the (a[r], a[r+1]) / (b[r], b[r+1]) pairs v_dot2_i32_i16 wants.
+constexpr int kAbWords = kLabLutNodes + 34;
+template <bool NT>
+__global__ __launch_bounds__(1024) void k_lut_hybrid(const uint8_t* in, float4* out, int ngroups, const uint32_t* abwords, const uint4* Lcells, int per_block) {
+    __shared__ uint32_t s_ab[kAbWords];
+    for (int i = threadIdx.x; i < kAbWords; i += 1024) s_ab[i] = abwords[i];
+    __syncthreads();
+    const int g0 = blockIdx.x * per_block;
+    for (int k = threadIdx.x; k < per_block; k += 1024) {
+        const int gi = g0 + k;
+        if (gi >= ngroups) break;
+        Px4 pv;
+        if (NT) {
+            const uint32_t* pi = reinterpret_cast<const uint32_t*>(in + (size_t)gi * 12);
+            pv.a = __builtin_nontemporal_load(pi); pv.b = __builtin_nontemporal_load(pi + 1); pv.c = __builtin_nontemporal_load(pi + 2);
+        } else pv = *reinterpret_cast<const Px4*>(in + (size_t)gi * 12);
+        int Bv[4], Gv[4], Rv[4];
+        unpack_px4(pv, Bv, Gv, Rv);
+        float L[4], a[4], b[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t fr = lut_fine(Rv[q]), fg = lut_fine(Gv[q]), fb = lut_fine(Bv[q]);
+            const uint32_t x = fr & 15u, y = fg & 15u, z = fb & 15u;
+            const uint32_t tb = fb >> 4;
+            const uint32_t n = (fr >> 4) + 33u * (fg >> 4) + 1089u * tb;
+            const uint32_t n1 = n + (tb < 32u ? 1089u : 0u);
+            const uint4 cL = Lcells[n];
+            const uint32_t d00 = s_ab[n], d10 = s_ab[n + 1], d01 = s_ab[n + 33], d11 = s_ab[n + 34];
+            const uint32_t e00 = s_ab[n1], e10 = s_ab[n1 + 1], e01 = s_ab[n1 + 33], e11 = s_ab[n1 + 34];
+            const uint32_t wz = (16u - z) | (z << 16), x0 = 16u - x, y0 = 16u - y;
+            const uint32_t w00 = (x0 * y0) * wz, w10 = (x * y0) * wz, w01 = (x0 * y) * wz, w11 = (x * y) * wz;
+            const int rnd = 1 << 11;
+            // L cell: corner index 4 dp + 2 dq + dr -> dwords (dp, dq) = x: (0,0) y: (0,1) z: (1,0) w: (1,1)
+            const int iL = lut_dot2(cL.w, w11, lut_dot2(cL.z, w10, lut_dot2(cL.y, w01, lut_dot2(cL.x, w00, rnd)))) >> 12;
+            // pairs along B: low halves = a, high halves = b
+            #define LO(d, e) __builtin_amdgcn_perm((e), (d), 0x05040100u)
+            #define HI(d, e) __builtin_amdgcn_perm((e), (d), 0x07060302u)
+            const int ia = lut_dot2(LO(d11, e11), w11, lut_dot2(LO(d01, e01), w01, lut_dot2(LO(d10, e10), w10, lut_dot2(LO(d00, e00), w00, rnd)))) >> 12;
+            const int ib = lut_dot2(HI(d11, e11), w11, lut_dot2(HI(d01, e01), w01, lut_dot2(HI(d10, e10), w10, lut_dot2(HI(d00, e00), w00, rnd)))) >> 12;
+            L[q] = lut_L(iL); a[q] = lut_ab(ia); b[q] = lut_ab(ib);
+        }
+        if (NT) {
+            float* po = reinterpret_cast<float*>(out + gi);
+            __builtin_nontemporal_store(L[0] + L[1] + L[2] + L[3], po); __builtin_nontemporal_store(a[0] + a[1] + a[2] + a[3], po + 1);
+            __builtin_nontemporal_store(b[0] + b[1] + b[2] + b[3], po + 2); __builtin_nontemporal_store(0.f, po + 3);
+        } else out[gi] = make_float4(L[0] + L[1] + L[2] + L[3], a[0] + a[1] + a[2] + a[3], b[0] + b[1] + b[2] + b[3], 0.f);
+    }
+}
+
+// hybrid, scheduled by hand: the next group's input is fetched one iteration ahead, the four L-cell gathers of a group are
+// issued first, the (a, b) work runs on the LDS data while they are in flight, L is folded last
+template <int ABL>
+__global__ __launch_bounds__(1024) void k_lut_hybrid_sched(const uint8_t* in, float4* out, int ngroups, const uint32_t* abwords, const uint4* Lcells, int per_block) {
+    __shared__ uint32_t s_ab[kAbWords];
+    for (int i = threadIdx.x; i < kAbWords; i += 1024) s_ab[i] = abwords[i];
+    __syncthreads();
+    const int g0 = blockIdx.x * per_block;
+    const int gend = g0 + per_block < ngroups ? g0 + per_block : ngroups;
+    auto fetch = [&](int gi) __attribute__((always_inline)) {
+        Px4 pv;
+        const uint32_t* pi = reinterpret_cast<const uint32_t*>(in + (size_t)gi * 12);
+        pv.a = __builtin_nontemporal_load(pi); pv.b = __builtin_nontemporal_load(pi + 1); pv.c = __builtin_nontemporal_load(pi + 2);
+        return pv;
+    };
+    int gi = g0 + threadIdx.x;
+    Px4 nxt{};
+    if (gi < gend) nxt = fetch(gi);
+    for (; gi < gend; gi += 1024) {
+        const Px4 pv = nxt;
+        if (gi + 1024 < gend) nxt = fetch(gi + 1024);
+        int Bv[4], Gv[4], Rv[4];
+        unpack_px4(pv, Bv, Gv, Rv);
+        uint32_t n[4], n1[4], w00[4], w10[4], w01[4], w11[4];
+        uint4 cL[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t fr = lut_fine(Rv[q]), fg = lut_fine(Gv[q]), fb = lut_fine(Bv[q]);
+            const uint32_t x = fr & 15u, y = fg & 15u, z = fb & 15u, tb = fb >> 4;
+            n[q] = (fr >> 4) + 33u * (fg >> 4) + 1089u * tb;
+            n1[q] = n[q] + (tb < 32u ? 1089u : 0u);
+            if (ABL == 3) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(cL[q]) : "v"(Lcells + n[q]) : "memory");
+            else if (ABL == 4) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(cL[q]) : "v"(Lcells + n[q]) : "memory");
+            else if (ABL == 5) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(cL[q]) : "v"(Lcells + n[q]) : "memory");
+            else if (ABL == 6) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(cL[q]) : "v"(Lcells + n[q]) : "memory");
+            else if (ABL != 1) cL[q] = Lcells[n[q]]; else cL[q] = make_uint4(n[q], n1[q], fr, fg);
+            const uint32_t wz = (16u - z) | (z << 16), x0 = 16u - x, y0 = 16u - y;
+            w00[q] = (x0 * y0) * wz; w10[q] = (x * y0) * wz; w01[q] = (x0 * y) * wz; w11[q] = (x * y) * wz;
+        }
+        float L[4], a[4], b[4];
+        const int rnd = 1 << 11;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t d00, d10, d01, d11, e00, e10, e01, e11;
+            if (ABL != 2) { d00 = s_ab[n[q]]; d10 = s_ab[n[q] + 1]; d01 = s_ab[n[q] + 33]; d11 = s_ab[n[q] + 34];
+                            e00 = s_ab[n1[q]]; e10 = s_ab[n1[q] + 1]; e01 = s_ab[n1[q] + 33]; e11 = s_ab[n1[q] + 34]; }
+            else { d00 = n[q]; d10 = n[q] + 1; d01 = n[q] * 3; d11 = n[q] ^ 77; e00 = n1[q]; e10 = n1[q] + 1; e01 = n1[q] * 3; e11 = n1[q] ^ 77; }
+            const int ia = lut_dot2(LO(d11, e11), w11[q], lut_dot2(LO(d01, e01), w01[q], lut_dot2(LO(d10, e10), w10[q], lut_dot2(LO(d00, e00), w00[q], rnd)))) >> 12;
+            const int ib = lut_dot2(HI(d11, e11), w11[q], lut_dot2(HI(d01, e01), w01[q], lut_dot2(HI(d10, e10), w10[q], lut_dot2(HI(d00, e00), w00[q], rnd)))) >> 12;
+            a[q] = lut_ab(ia); b[q] = lut_ab(ib);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL >= 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int iL = lut_dot2(cL[q].w, w11[q], lut_dot2(cL[q].z, w10[q], lut_dot2(cL[q].y, w01[q], lut_dot2(cL[q].x, w00[q], rnd)))) >> 12;
+            L[q] = lut_L(iL);
+        }
+        float* po = reinterpret_cast<float*>(out + gi);
+        __builtin_nontemporal_store(L[0] + L[1] + L[2] + L[3], po); __builtin_nontemporal_store(a[0] + a[1] + a[2] + a[3], po + 1);
+        __builtin_nontemporal_store(b[0] + b[1] + b[2] + b[3], po + 2); __builtin_nontemporal_store(0.f, po + 3);
+    }
+}
+
+namespace lvm { void build_lab_lut_nodes(std::vector<int16_t>& compact, std::vector<uint16_t>& nodes); }
+
+static void make_frames(std::vector<uint8_t>& f, int w, int h, int nf, bool noisy) {
+    f.resize((size_t)nf * w * h * 3);
+    uint64_t s = 88172645463325252ull;
+    for (int t = 0; t < nf; ++t)
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                const double base = 96.0 + 48.0 * sin(2 * M_PI * ((x + 0.3 * t) / 37.0 + y / 53.0)) + 32.0 * sin(2 * M_PI * (x / 11.0 - y / 7.0));
+                for (int c = 0; c < 3; ++c) {
+                    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+                    const double n = noisy ? ((double)(s >> 11) / 9007199254740992.0 * 24.0 - 12.0) : (c * 7.0);
+                    double v = base + n; v = v < 4 ? 4 : (v > 251 ? 251 : v);
+                    f[(((size_t)t * h + y) * w + x) * 3 + c] = (uint8_t)lrint(v);
+                }
+            }
+}
+
+int main() {
+    const int w = 1920, h = 1080, nf = 32;
+    const int ngroups = w * h * nf / 4;
+    float gam[256], inv[4096], fwd[9], invm[9];
+    build_lab_tables(gam, inv, fwd, invm);
+    float* d_gam; CK(hipMalloc(&d_gam, sizeof(gam))); CK(hipMemcpy(d_gam, gam, sizeof(gam), hipMemcpyHostToDevice));
+    LabCoef lab{}; memcpy(lab.fwd, fwd, sizeof(fwd)); lab.gamma_u8 = d_gam;
+    std::vector<int16_t> compact; std::vector<uint16_t> nodes;
+    build_lab_lut_nodes(compact, nodes);
+    // compact[(r*33+q)*33+p][3]; OpenCV cells
+    std::vector<int16_t> cells((size_t)kLabLutNodes * 24 + 64, 0);
+    auto C = [&](int p, int q, int r, int ch) { p = p > 32 ? 32 : p; q = q > 32 ? 32 : q; r = r > 32 ? 32 : r; return compact[(((size_t)r * 33 + q) * 33 + p) * 3 + ch]; };
+    for (int r = 0; r < 33; ++r) for (int q = 0; q < 33; ++q) for (int p = 0; p < 33; ++p)
+        for (int ch = 0; ch < 3; ++ch) for (int dp = 0; dp < 2; ++dp) for (int dq = 0; dq < 2; ++dq) for (int dr = 0; dr < 2; ++dr)
+            cells[((size_t)p + 33 * q + 1089 * r) * 24 + ch * 8 + 4 * dp + 2 * dq + dr] = C(p + dp, q + dq, r + dr, ch);
+    std::vector<uint32_t> lw(kLdsLWords + 1, 0);
+    { std::vector<int16_t> t16((size_t)kLdsLWords * 2 + 2, 0);
+      for (int i = 0; i < kLabLutNodes; ++i) t16[i] = compact[(size_t)i * 3];
+      memcpy(lw.data(), t16.data(), (size_t)kLdsLWords * 4); }
+    std::vector<uint32_t> abw(kAbWords, 0);
+    std::vector<int16_t> lcells((size_t)(kLabLutNodes + 2) * 8, 0);
+    for (int r = 0; r < 33; ++r) for (int q = 0; q < 33; ++q) for (int p = 0; p < 33; ++p) {
+        const size_t n = (size_t)p + 33 * q + 1089 * r;
+        abw[n] = (uint32_t)(uint16_t)C(p, q, r, 1) | ((uint32_t)(uint16_t)C(p, q, r, 2) << 16);
+        for (int dp = 0; dp < 2; ++dp) for (int dq = 0; dq < 2; ++dq) for (int dr = 0; dr < 2; ++dr) lcells[n * 8 + 4 * dp + 2 * dq + dr] = C(p + dp, q + dq, r + dr, 0);
+    }
+    uint32_t* d_abw; uint4* d_lcells;
+    CK(hipMalloc(&d_abw, abw.size() * 4)); CK(hipMemcpy(d_abw, abw.data(), abw.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_lcells, lcells.size() * 2)); CK(hipMemcpy(d_lcells, lcells.data(), lcells.size() * 2, hipMemcpyHostToDevice));
+    uint4 *d_nodes, *d_cells; uint32_t* d_lw;
+    CK(hipMalloc(&d_nodes, nodes.size() * 2)); CK(hipMemcpy(d_nodes, nodes.data(), nodes.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_cells, cells.size() * 2)); CK(hipMemcpy(d_cells, cells.data(), cells.size() * 2, hipMemcpyHostToDevice));
+    CK(hipMalloc(&d_lw, lw.size() * 4)); CK(hipMemcpy(d_lw, lw.data(), lw.size() * 4, hipMemcpyHostToDevice));
+    CK(hipFuncSetAttribute((const void*)k_lut_lds_L, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLWords * 4));
+    uint8_t* d_in; float4 *d_o0, *d_o1, *d_o2, *d_o3, *d_o4;
+    CK(hipMalloc(&d_in, (size_t)ngroups * 12));
+    for (float4** p : { &d_o0, &d_o1, &d_o2, &d_o3, &d_o4 }) CK(hipMalloc(p, (size_t)ngroups * 16));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int noisy = 1; noisy >= 0; --noisy) {
+        std::vector<uint8_t> fr; make_frames(fr, w, h, nf, noisy != 0);
+        CK(hipMemcpy(d_in, fr.data(), fr.size(), hipMemcpyHostToDevice));
+        const int nb = (ngroups + 255) / 256;
+        const int lds_blocks = 256 * 2, per_block = (ngroups + lds_blocks - 1) / lds_blocks;
+        const int hyb_blocks = 256 * 8, hyb_per_block = (ngroups + hyb_blocks - 1) / hyb_blocks;
+        auto run = [&](int which) {
+            switch (which) {
+                case 0: hipLaunchKernelGGL(k_analytic, dim3(nb), dim3(256), 0, 0, d_in, d_o0, ngroups, lab); break;
+                case 1: hipLaunchKernelGGL(k_lut_nodes, dim3(nb), dim3(256), 0, 0, d_in, d_o1, ngroups, d_nodes); break;
+                case 2: hipLaunchKernelGGL(k_lut_cells, dim3(nb), dim3(256), 0, 0, d_in, d_o2, ngroups, d_cells); break;
+                case 3: hipLaunchKernelGGL(k_lut_lds_L, dim3(lds_blocks), dim3(1024), kLdsLWords * 4, 0, d_in, d_o3, ngroups, d_lw, per_block); break;
+                case 4: hipLaunchKernelGGL(k_lut_hybrid<false>, dim3(hyb_blocks), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, hyb_per_block); break;
+                case 5: hipLaunchKernelGGL(k_lut_hybrid<false>, dim3(256), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
+                case 6: hipLaunchKernelGGL(k_lut_hybrid<true>, dim3(256), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
+                case 8: hipLaunchKernelGGL(k_lut_hybrid_sched<0>, dim3(256), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
+                case 9: hipLaunchKernelGGL(k_lut_hybrid_sched<1>, dim3(256), dim3(1024), 0, 0, d_in, d_o3, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
+                case 11: hipLaunchKernelGGL(k_lut_hybrid_sched<3>, dim3(256), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
+                case 12: hipLaunchKernelGGL(k_lut_hybrid_sched<4>, dim3(256), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
+                case 13: hipLaunchKernelGGL(k_lut_hybrid_sched<5>, dim3(256), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
+                case 14: hipLaunchKernelGGL(k_lut_hybrid_sched<6>, dim3(256), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
+                case 10: hipLaunchKernelGGL(k_lut_hybrid_sched<2>, dim3(256), dim3(1024), 0, 0, d_in, d_o3, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
+                case 7: hipLaunchKernelGGL(k_lut_hybrid<true>, dim3(hyb_blocks), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, hyb_per_block); break;
+            }
+        };
+        const char* names[15] = { "analytic (default flavour)", "LUT 16-byte nodes (575 KB, 4 loads)", "LUT OpenCV cells (1.7 MB, 3 loads)", "LUT L only, LDS 72 KB", "LUT hybrid: (a,b) LDS 144 KB + L cells", "hybrid, 256 persistent workgroups", "hybrid, 256 workgroups, nontemporal in/out", "hybrid, 2048 workgroups, nontemporal", "hybrid, 256 workgroups, hand-scheduled", "   ablation: no L gather (LDS + VALU)", "   ablation: no LDS reads (gather + VALU)", "hand-scheduled, L gather sc1", "hand-scheduled, L gather nt", "hand-scheduled, L gather sc0 sc1", "hand-scheduled, L gather sc0" };
+        for (int rep = 0; rep < 2; ++rep)
+            for (int k = 0; k < 15; ++k) {
+                if (k == 3 || k == 1 || k == 7) continue;
+                for (int i = 0; i < 5; ++i) run(k);
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < 20; ++i) run(k);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep) printf("%-6s %-40s %8.1f us per %d frames  (%.2f us per 1080p frame)\n", noisy ? "noisy" : "smooth", names[k], ms * 1000 / 20, nf, ms * 1000 / 20 / nf);
+            }
+        // correctness: nodes == cells bit for bit; L of the LDS kernel == L of the nodes kernel; distance from analytic
+        std::vector<float4> o0(ngroups), o1(ngroups), o2(ngroups), o3(ngroups), o4(ngroups);
+        CK(hipMemcpy(o4.data(), d_o4, (size_t)ngroups * 16, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(o0.data(), d_o0, (size_t)ngroups * 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(o1.data(), d_o1, (size_t)ngroups * 16, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(o2.data(), d_o2, (size_t)ngroups * 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(o3.data(), d_o3, (size_t)ngroups * 16, hipMemcpyDeviceToHost));
+        long bad12 = 0, bad13 = 0, bad14 = 0; double dmax = 0;
+        for (int i = 0; i < ngroups; ++i) {
+            if (memcmp(&o1[i], &o2[i], 12)) ++bad12;
+            if (o1[i].x != o3[i].x) ++bad13;
+            if (memcmp(&o1[i], &o4[i], 12)) ++bad14;
+            dmax = fmax(dmax, fabs(o1[i].x - o0[i].x) / 4);
+        }
+        printf("       nodes vs cells mismatches %ld, nodes vs LDS-L mismatches %ld, nodes vs hybrid mismatches %ld, mean-of-4 |L_lut - L_analytic| max %.4f\n", bad12, bad13, bad14, dmax);
+    }
+    return 0;
+}
