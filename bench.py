@@ -73,11 +73,16 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, S, T, Twin=0):
     if "_l" in name and name.rsplit("_l", 1)[1].isdigit():
         base, l_s = name.rsplit("_l", 1)
         lvl = int(l_s)
+    # Round 3: 3-channel frames pass through OpenCV's forward Lab table ONCE (labconv.hip) and the kernels that need
+    # Lab(in) read integer planes back: 2 bytes (iL) + 4 bytes (ia | ib << 16) per pixel instead of 3 bytes of BGR.
+    lab_in = 6 if ch == 3 else ch
+    if base == "lab_lut":
+        return T * S * n[0] * (3 + (6 if mode == "laplace" else 8))              # Riesz: L as float plane
     if mode == "laplace":
         if base == "lap_down0":
-            return T * (S * ch * n[0] + 4 * P * n[1])
+            return T * (S * lab_in * n[0] + 4 * P * n[1])
         if base in ("lap_final", "lap_final1"):
-            b = T * (2 * S * ch * n[0])
+            b = T * (S * (lab_in + ch) * n[0])
             if base == "lap_final":
                 return b + T * 4 * P * n[1]                                   # + cur_1 read
             # fused level-1 step: G_1, G_2, cur_2 read per frame; level-1 IIR states once per launch
@@ -118,7 +123,7 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, S, T, Twin=0):
         if base == "rz_collapse" and lvl is not None:
             return T * 4 * S * (2 * n[lvl] + n[lvl + 1])
         if base == "rz_final":
-            return T * S * (6 * n[0] + 4 * n[0] + 4 * n[1])
+            return T * S * ((4 + 3) * n[0] + 4 * n[0] + 4 * n[1])               # (ia, ib) plane in, BGR out, band + coarser result in
         return None
     if mode == "color":
         nL = n[levels]

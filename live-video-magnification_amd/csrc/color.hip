@@ -788,13 +788,13 @@ static void col_down(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs& B
     if (vec4 && st->d0_rows_on && d0_tasks > 0) {   // wave strips with DPP halo exchange (pyramid.h)
         const dim3 gridr((unsigned)((d0_tasks + D0R_THREADS / 64 - 1) / (D0R_THREADS / 64)));
         LVM_LAUNCH(c, "col_down0", (k_down0_rows<false, FL_LUT_EXACT>), gridr, dim3(D0R_THREADS), s, io.d_in, (long)io.in_stride, (long)io.in_sstride,
-                   w, h, B.G[1], g1.w, g1.h, c->lab, d0_sx, (g1.h + d0_rows - 1) / d0_rows, (int)d0_tasks, d0_rows);
+                   w, h, B.G[1], g1.w, g1.h, c->lab, d0_sx, (g1.h + d0_rows - 1) / d0_rows, (int)d0_tasks, d0_rows, LabPlanes{nullptr, nullptr});
     } else if (vec4) {
         auto kv = k_down0_v4<false, FL_LUT_EXACT>;
-        LVM_LAUNCH(c, "col_down0", kv, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, B.G[1], g1.w, g1.h, c->lab);
+        LVM_LAUNCH(c, "col_down0", kv, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, B.G[1], g1.w, g1.h, c->lab, LabPlanes{nullptr, nullptr});
     } else {
         auto kd0 = (C == 3) ? k_down0<3, false, FL_LUT_EXACT> : k_down0<1, false, FL_LUT_EXACT>;
-        LVM_LAUNCH(c, "col_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, B.G[1], g1.w, g1.h, c->lab, 1.0f);
+        LVM_LAUNCH(c, "col_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, B.G[1], g1.w, g1.h, c->lab, 1.0f, LabPlanes{nullptr, nullptr});
     }
     int l = 1;
     while (l < levels) {            // two pyramid levels per launch while possible

@@ -9,16 +9,19 @@
 //
 // This stage feeds u8 frames scaled by float(1/255) (convertTo, MagnifyCore.hpp:89,218), so a channel takes 256 values and
 // its rounded 14-bit value c = cvRound(float(u) * a255 * 16384) satisfies  c >> 5 == (514 u + 4) >> 8  for every u
-// (checked exhaustively by tests/test_lab_lut.py and by lab_tables.cpp at start-up): cell index and weight are two bit
-// fields of one v_mad_u32_u24, no table look-up and no float operation.  Everything after that is integer arithmetic,
-// so the result is BIT-EXACT against the oracle's restatement (oracle/lvm_oracle.c bgr2lab_lut_px).
+// (checked exhaustively by tests/test_lab_lut.py and by lab_tables.cpp whenever a context is created): cell index and
+// weight are two bit fields of one v_mad_u32_u24, no table look-up and no float operation.  Everything after that is
+// integer arithmetic, so the result is BIT-EXACT against the oracle's restatement (oracle/lvm_oracle.c bgr2lab_lut_px).
 //
-// Table layout in HBM / L2 (built by lab_tables.cpp, 575 KB, resident in every XCD's 4 MB L2): one 16-byte NODE per grid
-// point (p = R index fastest, q = G, r = B slowest) holding the B-direction pairs of the three channels,
-//     { L[r], L[r+1], a[r], a[r+1], b[r], b[r+1], 0, 0 }   (int16 each; r + 1 clamped to 32),
-// so that one v_dot2_i32_i16 with the packed weights (w * (16 - z), w * z) folds a pair.  A pixel reads the 4 nodes
-// (p + dx, q + dy, r): two 32-byte runs.  OpenCV's own layout (8 replicated corners per CELL, 3 x 16 bytes per pixel,
-// 1.7 MB) was measured too (tools/ubench_lut.hip, profiles/README.md).
+// Where the table lives on MI355X (measured: tools/ubench_lut.hip, tools/probe_gather.hip, profiles/README.md round 3).
+// A pixel needs 8 corners x 3 channels = 48 bytes of table.  Gathered from L2 (OpenCV's own layout: 8 replicated corners per
+// cell, 1.7 MB) the conversion costs 10 us per 1080p frame -- a random L2-resident gather is ~140 cycles per wave
+// instruction on a CU, whatever its width -- against 3 us for the analytic form.  The 160 KB LDS cannot hold three
+// channels (215 KB as int16) but it does hold TWO as one dword per grid node, (a | b << 16), 144 KB, one 1024-thread
+// workgroup per CU: 8 random ds_read_b32 per pixel; L comes from an L2-resident table of CELLS (8 corners x int16 = ONE
+// 16-byte gather per pixel, 575 KB).  LDS pipe, texture-address pipe and VALU then carry about a third of the work each:
+// 5.5 us per 1080p frame.  v_perm_b32 turns two B-neighbour node dwords into the (a[r], a[r+1]) / (b[r], b[r+1]) pairs that
+// v_dot2_i32_i16 folds with the packed weights (w (16 - z), w z).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
@@ -27,57 +30,65 @@ namespace lvm {
 
 constexpr int kLabLutDim = 33;
 constexpr int kLabLutNodes = kLabLutDim * kLabLutDim * kLabLutDim;
-// nodes p + 1 / q + 1 of an edge cell (weight 0) index past the cube: the allocation is padded by 35 nodes
-constexpr int kLabLutNodesPadded = kLabLutNodes + 35;
+// node index n = p + 33 q + 1089 r (p, q, r = R, G, B grid index).  Neighbours n + 1, n + 33, n + 34 of an edge cell carry
+// weight 0 and may index past the cube: the node table is padded by 34 entries (the B neighbour is clamped instead).
+constexpr int kLabAbWords = kLabLutNodes + 34;
+constexpr int kLabLCells = kLabLutNodes;
 
 #ifndef LVM_EMU_NO_DOT2
 typedef short lut_s2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int lut_dot2(uint32_t pair, uint32_t wts, int acc) {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(lut_s2, pair), __builtin_bit_cast(lut_s2, wts), acc, false);
 }
-#else           // tests/emu (g++): the same sum spelled out
+// (lo16(d), lo16(e)) and (hi16(d), hi16(e)) of two dwords
+__device__ __forceinline__ uint32_t lut_lo2(uint32_t d, uint32_t e) { return __builtin_amdgcn_perm(e, d, 0x05040100u); }
+__device__ __forceinline__ uint32_t lut_hi2(uint32_t d, uint32_t e) { return __builtin_amdgcn_perm(e, d, 0x07060302u); }
+#else           // tests/emu (g++): the same values spelled out
 __device__ __forceinline__ int lut_dot2(uint32_t pair, uint32_t wts, int acc) {
     return acc + (int)(int16_t)(pair & 0xffff) * (int)(int16_t)(wts & 0xffff) + (int)(int16_t)(pair >> 16) * (int)(int16_t)(wts >> 16);
 }
+__device__ __forceinline__ uint32_t lut_lo2(uint32_t d, uint32_t e) { return (d & 0xffffu) | (e << 16); }
+__device__ __forceinline__ uint32_t lut_hi2(uint32_t d, uint32_t e) { return (d >> 16) | (e & 0xffff0000u); }
 #endif
 
 // fine grid coordinate of a u8 channel value: bits 4.. = cell, bits 0..3 = weight of the upper neighbour
 __device__ __forceinline__ uint32_t lut_fine(uint32_t u) { return (u * 514u + 4u) >> 8; }
 
-// integer Lab of one pixel: iL in [0, 16384], ia, ib = (a + 128) / 256 * 16384
-__device__ __forceinline__ void lut_lab_int(uint32_t B, uint32_t G, uint32_t R, const uint4* __restrict__ nodes, int& iL, int& ia, int& ib) {
+// device tables of a context (lab_tables.cpp builds them from the compact table)
+struct LabLut {
+    const uint32_t* ab;       // [kLabAbWords]  a | b << 16 per node (copied into LDS by the conversion kernel)
+    const uint4* Lcells;      // [kLabLCells]   the 8 L corners of cell n, int16 index 4 dp + 2 dq + dr
+};
+
+// integer Lab of one pixel: iL in [0, 16384], ia, ib = (a + 128) / 256 * 16384.  s_ab = the node table in LDS.
+__device__ __forceinline__ void lut_lab_int(uint32_t B, uint32_t G, uint32_t R, const uint32_t* s_ab, const uint4* __restrict__ Lcells,
+                                            int& iL, int& ia, int& ib) {
     const uint32_t fr = lut_fine(R), fg = lut_fine(G), fb = lut_fine(B);
-    const uint32_t x = fr & 15u, y = fg & 15u, z = fb & 15u;
-    const uint32_t n = (fr >> 4) + 33u * (fg >> 4) + 1089u * (fb >> 4);
-    const uint4 n00 = nodes[n], n10 = nodes[n + 1], n01 = nodes[n + 33], n11 = nodes[n + 34];
+    const uint32_t x = fr & 15u, y = fg & 15u, z = fb & 15u, tb = fb >> 4;
+    const uint32_t n = (fr >> 4) + 33u * (fg >> 4) + 1089u * tb;
+    const uint32_t n1 = n + (tb < 32u ? 1089u : 0u);            // B neighbour (tb == 32 only for u = 255, where z == 0)
+    // the L cell: one 16-byte gather at a 32-bit byte offset from the uniform base
+    const uint4 cL = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Lcells) + (n << 4));
+    const uint32_t d00 = s_ab[n], d10 = s_ab[n + 1], d01 = s_ab[n + 33], d11 = s_ab[n + 34];
+    const uint32_t e00 = s_ab[n1], e10 = s_ab[n1 + 1], e01 = s_ab[n1 + 33], e11 = s_ab[n1 + 34];
     const uint32_t wz = (16u - z) | (z << 16);                 // (16 - z, z) as an int16 pair
     const uint32_t x0 = 16u - x, y0 = 16u - y;
-    // w(dx, dy) * (16 - z | z): each half <= 4096, no carry between the halves
+    // w(dp, dq) * (16 - z | z): each half <= 4096, no carry between the halves
     const uint32_t w00 = (x0 * y0) * wz, w10 = (x * y0) * wz, w01 = (x0 * y) * wz, w11 = (x * y) * wz;
     const int rnd = 1 << 11;                                  // CV_DESCALE(v, 12) = (v + 2048) >> 12
-    iL = lut_dot2(n11.x, w11, lut_dot2(n01.x, w01, lut_dot2(n10.x, w10, lut_dot2(n00.x, w00, rnd)))) >> 12;
-    ia = lut_dot2(n11.y, w11, lut_dot2(n01.y, w01, lut_dot2(n10.y, w10, lut_dot2(n00.y, w00, rnd)))) >> 12;
-    ib = lut_dot2(n11.z, w11, lut_dot2(n01.z, w01, lut_dot2(n10.z, w10, lut_dot2(n00.z, w00, rnd)))) >> 12;
+    ia = lut_dot2(lut_lo2(d11, e11), w11, lut_dot2(lut_lo2(d01, e01), w01, lut_dot2(lut_lo2(d10, e10), w10, lut_dot2(lut_lo2(d00, e00), w00, rnd)))) >> 12;
+    ib = lut_dot2(lut_hi2(d11, e11), w11, lut_dot2(lut_hi2(d01, e01), w01, lut_dot2(lut_hi2(d10, e10), w10, lut_dot2(lut_hi2(d00, e00), w00, rnd)))) >> 12;
+    // cell dwords: x = (dp 0, dq 0), y = (0, 1), z = (1, 0), w = (1, 1), each the (dr 0, dr 1) pair
+    iL = lut_dot2(cL.w, w11, lut_dot2(cL.y, w01, lut_dot2(cL.z, w10, lut_dot2(cL.x, w00, rnd)))) >> 12;
 }
 // the float values RGB2Labfloat stores (each product is exact in float32: a power-of-two scale, 25 * iL < 2^24)
 __device__ __forceinline__ float lut_L(int iL) { return (float)iL * (100.0f / 16384.0f); }
 __device__ __forceinline__ float lut_ab(int i) { return (float)i * (1.0f / 64.0f) - 128.0f; }
 
-// the L channel alone (Riesz L plane): the first dword of each node
-__device__ __forceinline__ float lut_lab_L(uint32_t B, uint32_t G, uint32_t R, const uint4* __restrict__ nodes) {
-    const uint32_t fr = lut_fine(R), fg = lut_fine(G), fb = lut_fine(B);
-    const uint32_t x = fr & 15u, y = fg & 15u, z = fb & 15u;
-    const uint32_t n = (fr >> 4) + 33u * (fg >> 4) + 1089u * (fb >> 4);
-    const uint32_t l00 = nodes[n].x, l10 = nodes[n + 1].x, l01 = nodes[n + 33].x, l11 = nodes[n + 34].x;
-    const uint32_t wz = (16u - z) | (z << 16), x0 = 16u - x, y0 = 16u - y;
-    const int iL = lut_dot2(l11, (x * y) * wz, lut_dot2(l01, (x0 * y) * wz, lut_dot2(l10, (x * y0) * wz, lut_dot2(l00, (x0 * y0) * wz, 1 << 11)))) >> 12;
-    return lut_L(iL);
-}
-
-__device__ __forceinline__ void lut_lab(uint32_t B, uint32_t G, uint32_t R, const uint4* __restrict__ nodes, float& L, float& a, float& b) {
-    int iL, ia, ib;
-    lut_lab_int(B, G, R, nodes, iL, ia, ib);
-    L = lut_L(iL); a = lut_ab(ia); b = lut_ab(ib);
+// ---- integer Lab planes: what the conversion kernel (labconv.hip) hands to the kernels that used to convert ------------
+// iL: uint16 per pixel; iab: ia | ib << 16 per pixel; one plane pair per frame, frame stride = w * h elements.
+__device__ __forceinline__ void lab_from_planes(uint32_t iL, uint32_t iab, float& L, float& a, float& b) {
+    L = lut_L((int)iL); a = lut_ab((int)(iab & 0xffffu)); b = lut_ab((int)(iab >> 16));
 }
 
 }  // namespace lvm

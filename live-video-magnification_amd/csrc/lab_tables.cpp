@@ -162,18 +162,23 @@ void build_lab_lut_compact(std::vector<int16_t>& compact) {
             }
 }
 
-// device layout (lab_lut.h): node (p, q, r) = { L[r], L[r+1], a[r], a[r+1], b[r], b[r+1], 0, 0 }, r + 1 clamped to 32,
-// node index p + 33 q + 1089 r, padded by 35 zero nodes
-void lab_lut_nodes_from_compact(const int16_t* compact, std::vector<uint16_t>& nodes) {
-    nodes.assign((size_t)(33 * 33 * 33 + 35) * 8, 0);
+// device layouts (lab_lut.h): ab[n] = a | b << 16 of node n = p + 33 q + 1089 r (padded by 34 zero entries);
+// lcells[8 n + 4 dp + 2 dq + dr] = L of node (p + dp, q + dq, r + dr), indices clamped to 32
+void lab_lut_device_tables(const int16_t* compact, std::vector<uint32_t>& ab, std::vector<int16_t>& lcells) {
+    ab.assign((size_t)33 * 33 * 33 + 34, 0u);
+    lcells.assign((size_t)33 * 33 * 33 * 8, 0);
+    auto at = [&](int p, int q, int r, int ch) {
+        p = p > 32 ? 32 : p; q = q > 32 ? 32 : q; r = r > 32 ? 32 : r;
+        return compact[(((size_t)r * 33 + q) * 33 + p) * 3 + ch];
+    };
     for (int r = 0; r < 33; ++r)
         for (int q = 0; q < 33; ++q)
             for (int p = 0; p < 33; ++p) {
-                const int r1 = r < 32 ? r + 1 : 32;
-                const int16_t* e0 = compact + (((size_t)r * 33 + q) * 33 + p) * 3;
-                const int16_t* e1 = compact + (((size_t)r1 * 33 + q) * 33 + p) * 3;
-                uint16_t* n = &nodes[((size_t)p + 33 * q + 1089 * r) * 8];
-                for (int ch = 0; ch < 3; ++ch) { n[2 * ch] = (uint16_t)e0[ch]; n[2 * ch + 1] = (uint16_t)e1[ch]; }
+                const size_t n = (size_t)p + 33 * q + 1089 * r;
+                ab[n] = (uint32_t)(uint16_t)at(p, q, r, 1) | ((uint32_t)(uint16_t)at(p, q, r, 2) << 16);
+                for (int dp = 0; dp < 2; ++dp)
+                    for (int dq = 0; dq < 2; ++dq)
+                        for (int dr = 0; dr < 2; ++dr) lcells[n * 8 + 4 * dp + 2 * dq + dr] = at(p + dp, q + dq, r + dr, 0);
             }
 }
 // lab_lut.h takes cell and weight of a u8 channel value from (514 u + 4) >> 8 instead of rounding float(u) * a255 * 16384:
@@ -188,11 +193,6 @@ bool lab_lut_fine_index_ok() {
     }
     return true;
 }
-void build_lab_lut_nodes(std::vector<int16_t>& compact, std::vector<uint16_t>& nodes) {
-    build_lab_lut_compact(compact);
-    lab_lut_nodes_from_compact(compact.data(), nodes);
-}
-
 int max_levels(int w, int h) {
     int n = 0;
     while (w > 5 && h > 5) { w = (1 + w) / 2; h = (1 + h) / 2; ++n; }

@@ -1,0 +1,94 @@
+// labconv.hip -- u8 BGR frames -> integer Lab planes through OpenCV 4's interpolated 33^3 table (lab_lut.h).
+//
+// Replaces, for the default flavour, the float conversion the reference does once per frame
+// (convertTo + cv::cvtColor(COLOR_BGR2Lab), MagnifyCore.hpp:89-90 and :218-219).  The table look-up is the expensive
+// part of a frame (lab_lut.h), so every frame is converted exactly ONCE, here, and the kernels that need Lab(in) -- the
+// first pyramid kernel and the output kernel of the Laplace path, the L plane and the output kernel of the Riesz path --
+// read the integers back: iL as uint16 (Laplace) or already as the float L plane (Riesz), (ia, ib) as one dword.
+// 6 bytes per pixel written + read instead of a second conversion.
+//
+// One persistent 1024-thread workgroup per CU holds the (a, b) node table in LDS (144 KB); a lane converts 4 adjacent
+// pixels per step (12-byte load, 8 + 16-byte stores) or single pixels for frames whose rows are not dword-aligned.
+#include "lvm_internal.h"
+
+namespace lvm {
+
+constexpr int LC_THREADS = 1024;
+
+struct __attribute__((packed, aligned(4))) LcPx4 { uint32_t a, b, c; };
+
+// VEC: w % 4 == 0 and rows / frames dword aligned.  LFLOAT: L is stored as float (the Riesz L plane) instead of uint16.
+template <bool VEC, bool LFLOAT>
+__global__ __launch_bounds__(LC_THREADS) void k_lab_planes(const uint8_t* __restrict__ in, long in_stride, long in_sstride, int w, int h,
+                                                           int nframes, LabLut lut, uint16_t* __restrict__ iLp, float* __restrict__ Lfp,
+                                                           uint32_t* __restrict__ iabp, int per_block) {
+    __shared__ uint32_t s_ab[kLabAbWords];
+    for (int i = threadIdx.x; i < kLabAbWords; i += LC_THREADS) s_ab[i] = lut.ab[i];
+    __syncthreads();
+    const int upr = VEC ? (w >> 2) : w;                   // work units (4-pixel groups / pixels) per row
+    const long total = (long)upr * h * nframes;
+    const long u0 = (long)blockIdx.x * per_block;
+    const long uend = u0 + per_block < total ? u0 + per_block : total;
+    const int upf = upr * h;                              // units per frame
+    // (frame, row, unit in row) of this lane's first unit by division, of the following ones by stepping: a lane moves
+    // LC_THREADS units per step
+    long u = u0 + threadIdx.x;
+    int f = (int)(u / upf);
+    int y, xu;
+    { const int r = (int)(u - (long)f * upf); y = r / upr; xu = r - y * upr; }
+    const int step_y = LC_THREADS / upr, step_x = LC_THREADS - step_y * upr;
+    for (; u < uend; u += LC_THREADS, xu += step_x, y += step_y) {
+        if (xu >= upr) { xu -= upr; ++y; }
+        while (y >= h) { y -= h; ++f; }
+        const uint8_t* p = in + (size_t)f * in_sstride + (size_t)y * in_stride;
+        const size_t o = ((size_t)f * h + y) * w;
+        if (VEC) {
+            // streaming data bypasses the caches' retention (nontemporal): the L cells a CU keeps re-reading stay in its L1
+            LcPx4 v;
+            { const uint32_t* pi = reinterpret_cast<const uint32_t*>(p + (size_t)xu * 12);
+              v.a = __builtin_nontemporal_load(pi); v.b = __builtin_nontemporal_load(pi + 1); v.c = __builtin_nontemporal_load(pi + 2); }
+            const uint32_t pb[12] = {v.a & 255, (v.a >> 8) & 255, (v.a >> 16) & 255, v.a >> 24, v.b & 255, (v.b >> 8) & 255,
+                                     (v.b >> 16) & 255, v.b >> 24, v.c & 255, (v.c >> 8) & 255, (v.c >> 16) & 255, v.c >> 24};
+            int iL[4], ia[4], ib[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lut_lab_int(pb[3 * k], pb[3 * k + 1], pb[3 * k + 2], s_ab, lut.Lcells, iL[k], ia[k], ib[k]);
+            const size_t q = o + (size_t)xu * 4;
+            if (LFLOAT) {
+                float* d = Lfp + q;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(lut_L(iL[k]), d + k);
+            } else {
+                uint32_t* d = reinterpret_cast<uint32_t*>(iLp + q);
+                __builtin_nontemporal_store((uint32_t)iL[0] | ((uint32_t)iL[1] << 16), d);
+                __builtin_nontemporal_store((uint32_t)iL[2] | ((uint32_t)iL[3] << 16), d + 1);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) __builtin_nontemporal_store((uint32_t)ia[k] | ((uint32_t)ib[k] << 16), iabp + q + k);
+        } else {
+            const uint8_t* px = p + (size_t)xu * 3;
+            int iL, ia, ib;
+            lut_lab_int(px[0], px[1], px[2], s_ab, lut.Lcells, iL, ia, ib);
+            if (LFLOAT) Lfp[o + xu] = lut_L(iL); else iLp[o + xu] = (uint16_t)iL;
+            iabp[o + xu] = (uint32_t)ia | ((uint32_t)ib << 16);
+        }
+    }
+}
+
+// nframes frames (batch frames x streams) of w x h BGR pixels at in_sstride.  Exactly one of iL / Lf is non-null.
+void lab_lut_planes(Ctx* c, const uint8_t* d_in, long in_stride, long in_sstride, int w, int h, int nframes, uint16_t* iL, float* Lf,
+                    uint32_t* iab, hipStream_t s) {
+    const bool vec = w % 4 == 0 && in_stride % 4 == 0 && in_sstride % 4 == 0 && ((uintptr_t)d_in % 4) == 0;
+    const long units = (long)(vec ? w / 4 : w) * h * nframes;
+    // one workgroup per CU (the table takes 144 KB of the CU's 160 KB); few units: fewer workgroups, >= 1024 units each
+    long blocks = (units + LC_THREADS - 1) / LC_THREADS;
+    if (blocks > c->num_cus) blocks = c->num_cus;
+    if (blocks < 1) blocks = 1;
+    long per = (units + blocks - 1) / blocks;
+    per = (per + LC_THREADS - 1) / LC_THREADS * LC_THREADS;       // whole steps of the workgroup: neighbouring lanes stay neighbours
+    blocks = (units + per - 1) / per;
+    if (blocks < 1) blocks = 1;
+    auto k = vec ? (Lf ? k_lab_planes<true, true> : k_lab_planes<true, false>) : (Lf ? k_lab_planes<false, true> : k_lab_planes<false, false>);
+    LVM_LAUNCH(c, "lab_lut", k, dim3((unsigned)blocks), dim3(LC_THREADS), s, d_in, in_stride, in_sstride, w, h, nframes, c->lab_lut, iL, Lf, iab, (int)per);
+}
+
+}  // namespace lvm

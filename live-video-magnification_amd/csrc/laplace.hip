@@ -542,7 +542,7 @@ __global__ __launch_bounds__(256) void k_lap_final(const uint8_t* __restrict__ i
                                                    uint8_t* __restrict__ out, long out_stride, long out_sstride,
                                                    int w, int h, const float* __restrict__ cur1, int w1, int h1,
                                                    LabCoef lab, float ca, int tiles_x, int tiles_y, int nstreams,
-                                                   float* __restrict__ dbg) {
+                                                   float* __restrict__ dbg, LabPlanes lp) {
     constexpr bool EXACT = fl_exact(FL);
     __shared__ __attribute__((aligned(16))) float s_igt[C == 3 ? 4096 : 4];
     __shared__ float s_gam[C == 3 && !fl_lut(FL) ? 256 : 1];
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void k_lap_final(const uint8_t* __restrict__ i
             uint8_t* q = dst + (size_t)gy * out_stride + (size_t)gx * C;
             if (C == 3) {
                 float L, a, bb;
-                bgr_u8_to_lab<FL>(p[0], p[C == 3 ? 1 : 0], p[C == 3 ? 2 : 0], s_gam, lab, L, a, bb);
+                fetch_lab_px<FL>(src, in_stride, lp, (size_t)b * w * h, w, gy, gx, s_gam, lab, L, a, bb);
                 if (MOTION) {
                     const float m0 = pyrup_v(h_c[0], x, gy, sy0);
                     const float m1 = pyrup_v(h_c[C > 1 ? 1 : 0], x, gy, sy0) * ca;   // MagnifyCore.hpp:143-144
@@ -633,8 +633,9 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, lo
                                                        uint8_t* __restrict__ out, long out_stride, long out_sstride,
                                                        int w, int h, const float* __restrict__ cur1, int w1, int h1,
                                                        LabCoef lab, float ca, int strips_x, int strips_y, int nstreams,
-                                                       int rows, float* __restrict__ dbg) {
+                                                       int rows, float* __restrict__ dbg, LabPlanes lp) {
     constexpr bool EXACT = fl_exact(FL);
+    constexpr bool PLANES = fl_lut(FL);
     __shared__ __attribute__((aligned(16))) float s_igt[4096];
     __shared__ float s_gam[fl_lut(FL) ? 1 : 256];
     {
@@ -654,6 +655,7 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, lo
         if (gx >= w) continue;
         // uniform (scalar) bases + 32-bit lane offsets
         const uint8_t* src = in + (size_t)b * in_sstride;
+        const size_t poff = (size_t)b * w * h;
         uint8_t* dst = out + (size_t)b * out_sstride;
         const unsigned xoff = (unsigned)gx * 3u;
         const float* pl = cur1 + (size_t)b * 3 * ((size_t)w1 * h1);
@@ -687,15 +689,14 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, lo
         // one output row: colour math of 4 pixels; m = the motion image of the row (EXACT: scaled by 1/64 as
         // pyrUp does; otherwise the unscaled vertical sum, whose power-of-two scale `msc` is folded into the
         // add -- fma(m, 2^-k, L) rounds exactly like L + m * 2^-k)
-        auto emit = [&](const Px4 pin, const float (&m)[3][4], const float msc) __attribute__((always_inline)) {
-            int Bv[4], Gv[4], Rv[4];
-            unpack_px4(pin, Bv, Gv, Rv);
+        auto emit = [&](const Raw4 pin, const float (&m)[3][4], const float msc) __attribute__((always_inline)) {
+            float L4[4], a4[4], b4[4];
+            raw4_to_lab<FL>(pin, s_gam, lab, L4, a4, b4);
             float ov[12];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float o0, o1, o2;
-                float L, a, bb;
-                bgr_u8_to_lab<FL>(Bv[k], Gv[k], Rv[k], s_gam, lab, L, a, bb);
+                float L = L4[k], a = a4[k], bb = b4[k];
                 if (MOTION) {
                     if (EXACT) { L = L + m[0][k]; a = a + m[1][k] * ca; bb = bb + m[2][k] * ca; }
                     else {
@@ -721,10 +722,10 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, lo
         // two output rows (2j, 2j+1) from the window rows A = j-1, B = j, C = j+1; afterwards A holds row
         // j+2, i.e. the window has rotated to (B, C, A).  Returns false when the strip is finished.
         auto step = [&](Row3& A, const Row3& B, const Row3& C) __attribute__((always_inline)) {
-            const Px4 pe = *reinterpret_cast<const Px4*>(src + (size_t)gy * in_stride + xoff);
+            const Raw4 pe = load_raw4<PLANES>(src, in_stride, lp, poff, w, gy, (unsigned)gx);
             const bool has_odd = gy + 1 < yend;
-            Px4 po = pe;
-            if (has_odd) po = *reinterpret_cast<const Px4*>(src + (size_t)(gy + 1) * in_stride + xoff);
+            Raw4 po = pe;
+            if (has_odd) po = load_raw4<PLANES>(src, in_stride, lp, poff, w, gy + 1, (unsigned)gx);
             float m[3][4] = {};
             if (MOTION) {
 #pragma unroll
@@ -896,6 +897,9 @@ struct LaplaceState : ModeState {
     // temporal batching (lvm_process_device_frames): pyramids / accumulators of up to tcap frames
     int tcap = 0; float* tarena = nullptr;
     float* Gt[kMaxLevels + 1] = {}; float* curt[kMaxLevels + 1] = {};
+    // integer Lab planes of the input frames (labconv.hip; 3-channel frames): per frame parity and for temporal batches
+    uint16_t* iLp[2] = {}; uint32_t* iabp[2] = {};
+    uint16_t* iLt = nullptr; uint32_t* iabt = nullptr;
     int split_min_nt = 1;                 // frames per launch from which levels >= 2 run as IIR + collapse launches (LVM_LAP_SPLIT_MIN_NT)
     long fin_min_tasks = 4096;            // strips are shortened until a launch has this many of them (LVM_FIN_MIN_TASKS)
     long rows_min_elems = 1 << 20;        // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
@@ -904,6 +908,8 @@ struct LaplaceState : ModeState {
     int up_rows = 1;                      // barrier-free k_lap_up_rows for the steady state (LVM_UP_ROWS=0: tiled k_lap_up)
     long up_rows_max_blocks = 1024;       // launches with fewer tiled workgroups than this use k_lap_up_rows (LVM_UP_ROWS_MAX_BLOCKS)
     bool d0_rows_on = true;               // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
+    bool d0_fused = true;                 // table conversion fused into the first kernel on large launches (LVM_D0_FUSED=0: separate kernels)
+    long d0_fused_waves = 0;              // ... = launches with at least this many strips (LVM_D0_FUSED_WAVES; 0 = one per resident wave)
     long d0_min_tasks = 4096;             // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
     long fin_groups = 0;                  // workgroups of the persistent last kernel (LVM_FIN_GROUPS; 0 = 1024)
     int fin_rows = 8;                     // rows per wave strip of k_lap_final_v4 (LVM_FIN_ROWS, power of two)
@@ -952,6 +958,8 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
     for (int l = 1; l <= levels; ++l) total += 2 * pad(st->g[l].n * st->planes);
     for (int l = 1; l < levels; ++l) total += 5 * pad(st->g[l].n * st->planes);
+    const size_t npx = st->g[0].n * c->nstreams;                 // pixels of one frame set
+    if (channels == 3) total += 2 * (pad(npx) + pad((npx + 1) / 2));
     if (total == 0) total = 64;
     if (hipMalloc((void**)&st->arena, total * sizeof(float)) != hipSuccess) {
         c->err = "laplace: hipMalloc failed";
@@ -962,6 +970,11 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     for (int q = 0; q < 2; ++q)
         for (int l = 1; l <= levels; ++l) { st->Gp[q][l] = p; p += pad(st->g[l].n * st->planes); }
     for (int l = 1; l <= levels; ++l) st->G[l] = st->Gp[0][l];
+    if (channels == 3)
+        for (int q = 0; q < 2; ++q) {
+            st->iabp[q] = reinterpret_cast<uint32_t*>(p); p += pad(npx);
+            st->iLp[q] = reinterpret_cast<uint16_t*>(p); p += pad((npx + 1) / 2);
+        }
     for (int l = 1; l < levels; ++l) {
         st->hi[l] = p; p += pad(st->g[l].n * st->planes);
         st->lo[l] = p; p += pad(st->g[l].n * st->planes);
@@ -973,6 +986,8 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     if (const char* e = std::getenv("LVM_UP_DEPTH_BIG")) st->up_depth_big = std::atoi(e);
     if (const char* e = std::getenv("LVM_PD_ROWS")) st->pd_rows = std::atoi(e);
     if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
+    if (const char* e = std::getenv("LVM_D0_FUSED")) st->d0_fused = std::atoi(e) != 0;
+    if (const char* e = std::getenv("LVM_D0_FUSED_WAVES")) st->d0_fused_waves = std::atol(e);
     if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
     if (const char* e = std::getenv("LVM_LAP_CHUNKS")) st->chunks = std::atoi(e);
     if (const char* e = std::getenv("LVM_LAP_SPLIT")) st->split_levels = std::atoi(e);
@@ -1038,8 +1053,12 @@ static bool lap_vec4(const FrameIO& io) {   // 4-pixel (12-byte) vector I/O need
 
 // Stage B of a frame: u8 -> Lab -> Gaussian pyramid G_1..G_T (parity buffer `par`) and, when the tail
 // kernel is enabled, everything that happens at the levels >= T (their IIR states, cur_T[par]).
-struct LapBufs { float** G; float** cur; float* curT; int nt; bool no_tail = false; };   // nt frames laid out [frame][stream][channel]
-static LapBufs lap_bufs_frame(LaplaceState* st, int par) { return LapBufs{st->Gp[par], st->cur, st->curT[par], 1}; }
+struct LapBufs { float** G; float** cur; float* curT; int nt; bool no_tail = false; uint16_t* iL = nullptr; uint32_t* iab = nullptr; };   // nt frames laid out [frame][stream][channel]
+static LapBufs lap_bufs_frame(LaplaceState* st, int par) { return LapBufs{st->Gp[par], st->cur, st->curT[par], 1, false, st->iLp[par], st->iabp[par]}; }
+// planes the kernels of a launch read (null: analytic flavour / gray frames)
+static LabPlanes lap_planes(const Ctx* c, const FrameIO& io, const LapBufs& B) {
+    return (io.channels == 3 && fl_lut(lab_flavour(c))) ? LabPlanes{B.iL, B.iab} : LabPlanes{nullptr, nullptr};
+}
 
 // Levels 2 .. L-1 decoupled into one IIR launch + one stateless collapse launch (k_lap_iir_levels / k_lap_collapse) instead
 // of the level-by-level chain / the LDS-resident tail kernel?  Temporal batches of >= 4 frames always; single frames too
@@ -1052,11 +1071,23 @@ static bool lap_split_now(const LaplaceState* st, const LapBufs& B, bool first) 
     return split;
 }
 
-static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, const LapBufs& B, bool first, hipStream_t s) {
+// part: 0 = the whole stage; 1 = only the table conversion + first pyramid kernel (-> G_1 and the integer planes: bound by
+// the table look-ups, hardly touches HBM); 2 = only the rest (the pyrDown chain: bound by HBM).  Chunked batches run part 1
+// of the next chunk on the auxiliary stream under parts 2 + stage A of the current one.
+static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, const LapBufs& B, bool first, hipStream_t s, int part = 0) {
     const int C = io.channels, levels = st->levels;
     const int NS = c->nstreams * B.nt;        // stateless kernels: a frame of the batch is just one more stream
     const int planes = st->planes * B.nt;
     const dim3 blk(256);
+    // every frame goes through OpenCV's forward table exactly once: here (this stage comes first for every frame)
+    const LabPlanes lp = lap_planes(c, io, B);
+    // large launches: conversion and first pyramid kernel in one pass (k_down0_lut_rows); LVM_D0_FUSED=0 keeps them apart
+    long dl_tasks = 0;
+    const long dl_waves = st->d0_fused_waves > 0 ? st->d0_fused_waves : (long)c->num_cus * (D0L_THREADS / 64);
+    const int dl_rows = (lp.iab && levels >= 2 && st->d0_fused && lap_vec4(io) && st->g[1].w % 2 == 0)
+                            ? down0_lut_rows_choice(st->g[1].w, st->g[1].h, NS, dl_waves, &dl_tasks) : 0;
+    const bool fused = dl_tasks > 0;
+    if (part != 2 && lp.iab && !fused) lab_lut_planes(c, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h, NS, B.iL, nullptr, B.iab, s);
     if (levels < 2) return;
     float** G = B.G;
     const LevelGeom& g1 = st->g[1];
@@ -1066,20 +1097,27 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     long d0_tasks = 0;
     const int d0_rows = down0_rows_choice(g1.w, g1.h, NS, st->d0_min_tasks, &d0_tasks);
     const int fl = lab_flavour(c);
-    if (lap_vec4(io) && st->d0_rows_on && d0_tasks > 0) {
+    if (part == 2) {
+    } else if (fused) {
+        const int sx = (g1.w + D0R_OUT - 1) / D0R_OUT, sy = (g1.h + dl_rows - 1) / dl_rows;
+        auto kdl = fl == FL_LUT_EXACT ? k_down0_lut_rows<FL_LUT_EXACT> : k_down0_lut_rows<FL_LUT_FAST>;
+        LVM_LAUNCH(c, "lap_down0", kdl, dim3((unsigned)c->num_cus), dim3(D0L_THREADS), s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
+                   G[1], g1.w, g1.h, c->lab_lut, sx, sy, (int)dl_tasks, dl_rows, B.iL, B.iab);
+    } else if (lap_vec4(io) && st->d0_rows_on && d0_tasks > 0) {
         auto kd0 = LVM_FL_PICK(fl, k_down0_rows, true);
         const dim3 gridr((unsigned)((d0_tasks + D0R_THREADS / 64 - 1) / (D0R_THREADS / 64)));
         LVM_LAUNCH(c, "lap_down0", kd0, gridr, dim3(D0R_THREADS), s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
-                   G[1], g1.w, g1.h, c->lab, d0_sx, (g1.h + d0_rows - 1) / d0_rows, (int)d0_tasks, d0_rows);
+                   G[1], g1.w, g1.h, c->lab, d0_sx, (g1.h + d0_rows - 1) / d0_rows, (int)d0_tasks, d0_rows, lp);
     } else if (lap_vec4(io)) {
         auto kd0 = LVM_FL_PICK(fl, k_down0_v4, true);
         LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
-                   G[1], g1.w, g1.h, c->lab);
+                   G[1], g1.w, g1.h, c->lab, lp);
     } else {
         auto kd0 = (C == 3) ? LVM_FL_PICK(fl, k_down0, 3, true) : k_down0<1, false, FL_LUT_EXACT>;
         LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
-                   G[1], g1.w, g1.h, c->lab, c->lab.a255);
+                   G[1], g1.w, g1.h, c->lab, c->lab.a255, lp);
     }
+    if (part == 1) return;
     const bool use_tail = st->tailT && B.nt == 1 && !B.no_tail && !lap_split_now(st, B, first);   // batched frames: every level gets many workgroups anyway
     const int down_end = use_tail ? st->tailT : levels;            // the tail builds G_{T+1..L} itself
     int l = 1;
@@ -1137,6 +1175,7 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     const int C = io.channels, levels = st->levels;
     const int NS = c->nstreams * B.nt;
     const dim3 blk(256);
+    const LabPlanes lp = lap_planes(c, io, B);
     float** G = B.G;
     float gains[kMaxLevels + 2];
     laplace_gains(io.w, io.h, levels, p.amplification, p.coWavelength, gains);
@@ -1246,10 +1285,10 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         const long cap = st->fin_groups > 0 ? st->fin_groups : 1024;
         const dim3 grid4((unsigned)(groups < cap ? groups : cap)), blk4(FIN_THREADS);
         LVM_LAUNCH(c, "lap_final", kf4, grid4, blk4, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
-                   (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, sx, sy, NS, rows, dbg);
+                   (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, sx, sy, NS, rows, dbg, lp);
     } else {
         LVM_LAUNCH(c, "lap_final", kf, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
-                   (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, tx, ty, NS, dbg);
+                   (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, tx, ty, NS, dbg, lp);
     }
 }
 
@@ -1278,10 +1317,14 @@ static int laplace_reserve_frames(Ctx* c, LaplaceState* st, int nt, hipStream_t 
     size_t total = 64;
     for (int l = 1; l <= levels; ++l) total += pad(st->g[l].n * st->planes * nt);
     for (int l = 1; l < levels; ++l) total += pad(st->g[l].n * st->planes * nt);
+    const size_t npx = st->g[0].n * c->nstreams * nt;
+    const bool lab = st->planes == 3 * c->nstreams;
+    if (lab) total += pad(npx) + pad((npx + 1) / 2);
     if (hipMalloc((void**)&st->tarena, total * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); st->tarena = nullptr; c->err = "laplace: hipMalloc (frames) failed"; return LVM_ERR_OOM; }
     float* q = st->tarena;
     for (int l = 1; l <= levels; ++l) { st->Gt[l] = q; q += pad(st->g[l].n * st->planes * nt); }
     for (int l = 1; l < levels; ++l) { st->curt[l] = q; q += pad(st->g[l].n * st->planes * nt); }
+    if (lab) { st->iabt = reinterpret_cast<uint32_t*>(q); q += pad(npx); st->iLt = reinterpret_cast<uint16_t*>(q); q += pad((npx + 1) / 2); }
     st->tcap = nt;
     return LVM_OK;
 }
@@ -1326,14 +1369,15 @@ int laplace_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int n
         for (int l = 1; l <= levels; ++l) k.G[l] = st->Gt[l] + (size_t)f0 * st->planes * st->g[l].n;
         for (int l = 1; l < levels; ++l) k.cur[l] = st->curt[l] + (size_t)f0 * st->planes * st->g[l].n;
         k.B = LapBufs{k.G, k.cur, nullptr, n, true};          // (the tail kernel filters inside stage B: not for overlapped chunks)
+        if (st->iabt) { k.B.iL = st->iLt + (size_t)f0 * c->nstreams * st->g[0].n; k.B.iab = st->iabt + (size_t)f0 * c->nstreams * st->g[0].n; }
         if (chunks > 1) {
-            lap_stage_b(c, st, p, k.io, k.B, false, c->aux_stream);
+            lap_stage_b(c, st, p, k.io, k.B, false, c->aux_stream, 1);
             LVM_HIP_TRY(c, hipEventRecord(st->chunk_ev[(size_t)nch], c->aux_stream));
         }
     }
     for (int q = 0; q < nch; ++q) {
         Chunk& k = ch[(size_t)q];
-        if (chunks > 1) LVM_HIP_TRY(c, hipStreamWaitEvent(s, st->chunk_ev[(size_t)q], 0));
+        if (chunks > 1) { LVM_HIP_TRY(c, hipStreamWaitEvent(s, st->chunk_ev[(size_t)q], 0)); lap_stage_b(c, st, p, k.io, k.B, false, s, 2); }
         else lap_stage_b(c, st, p, k.io, k.B, false, s);
         lap_stage_a(c, st, p, k.io, k.B, false, s);
     }

@@ -52,13 +52,15 @@ static void drop_graphs(Ctx* c) {
 }
 static void drop_state(Ctx* c) { drop_graphs(c); delete c->state; c->state = nullptr; }
 
-// (re)build the device nodes of the forward Lab table from c->lab_lut_compact
+// (re)build the device layouts of the forward Lab table from c->lab_lut_compact
 int upload_lab_lut(Ctx* c) {
-    std::vector<uint16_t> nodes;
-    lab_lut_nodes_from_compact(c->lab_lut_compact.data(), nodes);
-    if (!c->d_lab_lut && hipMalloc((void**)&c->d_lab_lut, nodes.size() * sizeof(uint16_t)) != hipSuccess) { c->d_lab_lut = nullptr; c->err = "hipMalloc (Lab table) failed"; return LVM_ERR_OOM; }
-    LVM_HIP_TRY(c, hipMemcpy(c->d_lab_lut, nodes.data(), nodes.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    c->lab.lut = c->d_lab_lut;
+    std::vector<uint32_t> ab; std::vector<int16_t> lcells;
+    lab_lut_device_tables(c->lab_lut_compact.data(), ab, lcells);
+    if (!c->d_lab_ab && hipMalloc((void**)&c->d_lab_ab, ab.size() * sizeof(uint32_t)) != hipSuccess) { c->d_lab_ab = nullptr; c->err = "hipMalloc (Lab table) failed"; return LVM_ERR_OOM; }
+    if (!c->d_lab_Lcells && hipMalloc((void**)&c->d_lab_Lcells, lcells.size() * sizeof(int16_t)) != hipSuccess) { c->d_lab_Lcells = nullptr; c->err = "hipMalloc (Lab table) failed"; return LVM_ERR_OOM; }
+    LVM_HIP_TRY(c, hipMemcpy(c->d_lab_ab, ab.data(), ab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    LVM_HIP_TRY(c, hipMemcpy(c->d_lab_Lcells, lcells.data(), lcells.size() * sizeof(int16_t), hipMemcpyHostToDevice));
+    c->lab_lut.ab = c->d_lab_ab; c->lab_lut.Lcells = c->d_lab_Lcells;
     return LVM_OK;
 }
 
@@ -207,6 +209,7 @@ int lvm_create(int device, int n_streams, lvm_ctx** out) {
     if (!c) return LVM_ERR_OOM;
     c->device = device;
     c->nstreams = n_streams;
+    { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) c->num_cus = n; }
     float g[256], ig[4096];
     lvm::build_lab_tables(g, ig, c->lab.fwd, c->lab.inv);
     for (int i = 0; i < 9; ++i) c->lab.inv1024[i] = c->lab.inv[i] * 1024.0f;
@@ -242,7 +245,8 @@ void lvm_destroy(lvm_ctx* c) {
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
     if (c->d_gamma_u8) (void)hipFree(c->d_gamma_u8);
     if (c->d_invgamma) (void)hipFree(c->d_invgamma);
-    if (c->d_lab_lut) (void)hipFree(c->d_lab_lut);
+    if (c->d_lab_ab) (void)hipFree(c->d_lab_ab);
+    if (c->d_lab_Lcells) (void)hipFree(c->d_lab_Lcells);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_float) (void)hipFree(c->d_float);

@@ -68,8 +68,10 @@ struct LabCoef {
     const float* gamma_u8;    // [256]  sRGB gamma of u8/255 (device)
     const float* invgamma;    // [1024*4] cubic-spline coefficients of the inverse gamma (device)
     float a255;               // float(1.0/255.0f)
-    const uint4* lut;         // OpenCV's 33^3 forward table as 16-byte nodes (lab_lut.h, device)
 };
+// Integer Lab planes of the frames of a launch (labconv.hip): frame b's pixel (y, x) at (b * h + y) * w + x.  Null in the
+// analytic flavour and for non-Lab input (gray frames, the colour mode).
+struct LabPlanes { const uint16_t* iL; const uint32_t* iab; };
 
 // cv::cubeRoot (core/mathfuncs.cpp): exponent split + quartic rational polynomial in float64
 template <bool IEEE_DIV = true>
@@ -217,11 +219,56 @@ __device__ __forceinline__ void lab_to_bgr(float li, float ai, float bi, const f
 enum { FL_LUT_FAST = 0, FL_LUT_EXACT = 1, FL_ANALYTIC = 2 };
 constexpr bool fl_exact(int FL) { return FL != FL_LUT_FAST; }
 constexpr bool fl_lut(int FL) { return FL != FL_ANALYTIC; }
-// forward conversion of one u8 pixel; s_gam = the 256-entry gamma table in LDS (analytic flavour only)
+// Lab of pixel (gy, gx) of frame b.  LUT flavours: the integer planes written by labconv.hip (every frame is converted
+// once); analytic flavour: the u8 frame + the 256-entry gamma table in LDS (s_gam).
 template <int FL>
-__device__ __forceinline__ void bgr_u8_to_lab(int B, int G, int R, const float* s_gam, const LabCoef& lab, float& L, float& a, float& b) {
-    if (fl_lut(FL)) lut_lab((uint32_t)B, (uint32_t)G, (uint32_t)R, lab.lut, L, a, b);
-    else lin_bgr_to_lab<true>(s_gam[B], s_gam[G], s_gam[R], lab.fwd, L, a, b);
+__device__ __forceinline__ void fetch_lab_px(const uint8_t* __restrict__ frame, long in_stride, const LabPlanes& lp, size_t plane_off, int w,
+                                             int gy, int gx, const float* s_gam, const LabCoef& lab, float& L, float& a, float& b) {
+    if (fl_lut(FL)) {
+        const size_t i = plane_off + (size_t)gy * w + gx;
+        lab_from_planes(lp.iL[i], lp.iab[i], L, a, b);
+    } else {
+        const uint8_t* p = frame + (size_t)gy * in_stride + (size_t)gx * 3;
+        lin_bgr_to_lab<true>(s_gam[p[0]], s_gam[p[1]], s_gam[p[2]], lab.fwd, L, a, b);
+    }
+}
+// A group of 4 adjacent pixels as loaded: u8 flavour d[0..2] = 12 bytes of BGR; plane flavour d[0..1] = 4 x iL,
+// d[2..5] = 4 x (ia | ib << 16).  (gx % 4 == 0, rows dword aligned.)
+struct Raw4 { uint32_t d[6]; };
+template <bool PLANES>
+__device__ __forceinline__ Raw4 load_raw4(const uint8_t* __restrict__ frame, long in_stride, const LabPlanes& lp, size_t plane_off, int w, int gy, unsigned gx) {
+    Raw4 r{};
+    if (PLANES) {
+        const size_t i = plane_off + (size_t)gy * w + gx;
+        const uint2 l = *reinterpret_cast<const uint2*>(lp.iL + i);
+        const uint4 ab = *reinterpret_cast<const uint4*>(lp.iab + i);
+        r.d[0] = l.x; r.d[1] = l.y; r.d[2] = ab.x; r.d[3] = ab.y; r.d[4] = ab.z; r.d[5] = ab.w;
+    } else {
+        struct __attribute__((packed, aligned(4))) P3 { uint32_t a, b, c; };
+        const P3 v = *reinterpret_cast<const P3*>(frame + (size_t)gy * in_stride + gx * 3u);
+        r.d[0] = v.a; r.d[1] = v.b; r.d[2] = v.c;
+    }
+    return r;
+}
+// pixel k of a group as B, G, R bytes (u8 flavour)
+__device__ __forceinline__ void raw4_bgr(const Raw4& r, int (&B)[4], int (&G)[4], int (&R)[4]) {
+    B[0] = r.d[0] & 255; G[0] = (r.d[0] >> 8) & 255; R[0] = (r.d[0] >> 16) & 255;
+    B[1] = r.d[0] >> 24; G[1] = r.d[1] & 255; R[1] = (r.d[1] >> 8) & 255;
+    B[2] = (r.d[1] >> 16) & 255; G[2] = r.d[1] >> 24; R[2] = r.d[2] & 255;
+    B[3] = (r.d[2] >> 8) & 255; G[3] = (r.d[2] >> 16) & 255; R[3] = r.d[2] >> 24;
+}
+// the 4 pixels of a group as Lab
+template <int FL>
+__device__ __forceinline__ void raw4_to_lab(const Raw4& r, const float* s_gam, const LabCoef& lab, float (&L)[4], float (&a)[4], float (&b)[4]) {
+    if (fl_lut(FL)) {
+        lab_from_planes(r.d[0] & 0xffffu, r.d[2], L[0], a[0], b[0]); lab_from_planes(r.d[0] >> 16, r.d[3], L[1], a[1], b[1]);
+        lab_from_planes(r.d[1] & 0xffffu, r.d[4], L[2], a[2], b[2]); lab_from_planes(r.d[1] >> 16, r.d[5], L[3], a[3], b[3]);
+    } else {
+        int B[4], G[4], R[4];
+        raw4_bgr(r, B, G, R);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lin_bgr_to_lab<true>(s_gam[B[k]], s_gam[G[k]], s_gam[R[k]], lab.fwd, L[k], a[k], b[k]);
+    }
 }
 // cooperative loads of the two Lab tables into LDS (256 threads)
 __device__ __forceinline__ void load_gamma_u8(float* s_gam, const float* g) { s_gam[threadIdx.x] = g[threadIdx.x]; }
@@ -307,7 +354,9 @@ struct Ctx {
     int max_frames = 0;               // lvm_set_max_frames: temporal-batch buffers are sized for this many frames up front
     bool exact_lab = false;   // debug: OpenCV-order float arithmetic everywhere (bit-faithful to the oracle)
     bool lab_analytic = false;   // debug: analytic forward Lab (OpenCV with its interpolation switched off) instead of the 33^3 table
-    uint4* d_lab_lut = nullptr;  // the forward table as 16-byte nodes (lab_lut.h)
+    uint32_t* d_lab_ab = nullptr; uint4* d_lab_Lcells = nullptr;   // the forward table in its device layouts (lab_lut.h)
+    LabLut lab_lut{};
+    int num_cus = 256;
     std::vector<int16_t> lab_lut_compact;   // the same table, [r][q][p][3] (lvm_get_lab_lut)
     // preprocess stage (preprocess.hip): area tables of the current geometry, staging of the host chain
     void* pre_tables = nullptr;
@@ -354,6 +403,10 @@ struct LName {
 
 
 
+// labconv.hip: u8 BGR frames -> integer Lab planes (exactly one of iL / Lf is non-null)
+void lab_lut_planes(Ctx* c, const uint8_t* d_in, long in_stride, long in_sstride, int w, int h, int nframes, uint16_t* iL, float* Lf,
+                    uint32_t* iab, hipStream_t s);
+
 // preprocess.hip
 void preprocess_geometry(const lvm_preprocess_params& pp, int w, int h, int channels, int* rx, int* ry, int* rw, int* rh,
                          int* ow, int* oh, int* och);
@@ -385,7 +438,7 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
 // host tables (lab_tables.cpp)
 void build_lab_tables(float gamma_u8[256], float invgamma[4096], float fwd[9], float inv[9]);
 void build_lab_lut_compact(std::vector<int16_t>& compact);
-void lab_lut_nodes_from_compact(const int16_t* compact, std::vector<uint16_t>& nodes);
+void lab_lut_device_tables(const int16_t* compact, std::vector<uint32_t>& ab, std::vector<int16_t>& lcells);
 bool lab_lut_fine_index_ok();
 int upload_lab_lut(Ctx* c);
 void butterworth2(double Wn, double a[3], double b[3]);

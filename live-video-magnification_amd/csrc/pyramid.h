@@ -45,7 +45,7 @@ __device__ __forceinline__ void pyrdown_tile(float (&s_src)[C][DS_H][DS_W], floa
 template <int C, bool LAB, int FL>
 __global__ __launch_bounds__(256) void k_down0(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                int w, int h, float* __restrict__ G1, int w1, int h1,
-                                               LabCoef lab, float scale) {
+                                               LabCoef lab, float scale, LabPlanes lp) {
     __shared__ float s_src[C][DS_H][DS_W];
     __shared__ float s_row[C][DS_H][DT_W];
     __shared__ float s_gam[LAB && !fl_lut(FL) ? 256 : 1];
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_down0(const uint8_t* __restrict__ in, l
         const uint8_t* p = src + (size_t)gy * in_stride + (size_t)gx * C;
         if (LAB) {
             float L, a, bb;
-            bgr_u8_to_lab<FL>(p[0], p[LAB ? 1 : 0], p[LAB ? 2 : 0], s_gam, lab, L, a, bb);
+            fetch_lab_px<FL>(src, in_stride, lp, (size_t)b * w * h, w, gy, gx, s_gam, lab, L, a, bb);
             s_src[0][ly][lx] = L; s_src[C > 1 ? 1 : 0][ly][lx] = a; s_src[C > 2 ? 2 : 0][ly][lx] = bb;
         } else {
 #pragma unroll
@@ -151,7 +151,8 @@ __device__ __forceinline__ void unpack_px4(const Px4 v, int (&B)[4], int (&G)[4]
 constexpr int D0_ROWS = 2 * DT_H + 3, D0_GROUPS = 18, D0_PITCH = 76;
 template <bool LAB, int FL>
 __global__ __launch_bounds__(256) void k_down0_v4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
-                                                  int w, int h, float* __restrict__ G1, int w1, int h1, LabCoef lab) {
+                                                  int w, int h, float* __restrict__ G1, int w1, int h1, LabCoef lab, LabPlanes lp) {
+    constexpr bool PLANES = LAB && fl_lut(FL);
     __shared__ __attribute__((aligned(16))) float s_src[3][D0_ROWS][D0_PITCH];
     __shared__ float s_gam[LAB && !fl_lut(FL) ? 256 : 1];
     if (LAB && !fl_lut(FL)) { load_gamma_u8(s_gam, lab.gamma_u8); __syncthreads(); }
@@ -161,8 +162,9 @@ __global__ __launch_bounds__(256) void k_down0_v4(const uint8_t* __restrict__ in
     const uint8_t* src = in + (size_t)b * in_sstride;
     // all global loads of this thread are issued before the first use (3 pixel groups per thread)
     constexpr int NG = (D0_ROWS * D0_GROUPS + 255) / 256;
-    Px4 pv[NG];
+    Raw4 pv[NG];
     int prow[NG], pgy[NG], pgx[NG];
+    const size_t poff = (size_t)b * w * h;
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
         const int i = threadIdx.x + k * 256;
@@ -170,29 +172,32 @@ __global__ __launch_bounds__(256) void k_down0_v4(const uint8_t* __restrict__ in
         prow[k] = i < D0_ROWS * D0_GROUPS ? r : -1;
         pgy[k] = reflect101(sy0 + (r < D0_ROWS ? r : 0), h);
         pgx[k] = sx0 + 4 * g;
-        pv[k].a = pv[k].b = pv[k].c = 0;
-        if (prow[k] >= 0 && pgx[k] >= 0 && pgx[k] + 3 < w)
-            pv[k] = *reinterpret_cast<const Px4*>(src + (size_t)pgy[k] * in_stride + (size_t)pgx[k] * 3);
+        pv[k] = Raw4{};
+        if (prow[k] >= 0 && pgx[k] >= 0 && pgx[k] + 3 < w) pv[k] = load_raw4<PLANES>(src, in_stride, lp, poff, w, pgy[k], (unsigned)pgx[k]);
     }
 #pragma unroll
     for (int k = 0; k < NG; ++k) {
         if (prow[k] < 0) continue;
         const int r = prow[k], gy = pgy[k], gx0 = pgx[k], g = (gx0 - sx0) >> 2;
-        int Bv[4], Gv[4], Rv[4];
+        float L[4], A[4], Bb[4];
         if (gx0 >= 0 && gx0 + 3 < w) {
-            unpack_px4(pv[k], Bv, Gv, Rv);
+            if (LAB) raw4_to_lab<FL>(pv[k], s_gam, lab, L, A, Bb);
+            else {
+                int Bv[4], Gv[4], Rv[4];
+                raw4_bgr(pv[k], Bv, Gv, Rv);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { L[q] = (float)Bv[q] * 1.0f; A[q] = (float)Gv[q] * 1.0f; Bb[q] = (float)Rv[q] * 1.0f; }   // colour mode: unscaled planes
+            }
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const uint8_t* p = src + (size_t)gy * in_stride + (size_t)reflect101(gx0 + q, w) * 3;
-                Bv[q] = p[0]; Gv[q] = p[1]; Rv[q] = p[2];
+                const int rx = reflect101(gx0 + q, w);
+                if (LAB) fetch_lab_px<FL>(src, in_stride, lp, poff, w, gy, rx, s_gam, lab, L[q], A[q], Bb[q]);
+                else {
+                    const uint8_t* p = src + (size_t)gy * in_stride + (size_t)rx * 3;
+                    L[q] = (float)p[0] * 1.0f; A[q] = (float)p[1] * 1.0f; Bb[q] = (float)p[2] * 1.0f;
+                }
             }
-        }
-        float L[4], A[4], Bb[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (LAB) bgr_u8_to_lab<FL>(Bv[q], Gv[q], Rv[q], s_gam, lab, L[q], A[q], Bb[q]);
-            else { L[q] = (float)Bv[q] * 1.0f; A[q] = (float)Gv[q] * 1.0f; Bb[q] = (float)Rv[q] * 1.0f; }   // colour mode: unscaled planes
         }
         float* d0 = &s_src[0][r][4 * g + 2];
         float* d1 = &s_src[1][r][4 * g + 2];
@@ -299,8 +304,9 @@ inline int down0_rows_choice(int w1, int h1, long frames, long min_tasks, long* 
 template <bool LAB, int FL>
 __global__ __launch_bounds__(D0R_THREADS) void k_down0_rows(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                             int w, int h, float* __restrict__ G1, int w1, int h1, LabCoef lab,
-                                                            int strips_x, int strips_y, int ntasks, int rows) {
+                                                            int strips_x, int strips_y, int ntasks, int rows, LabPlanes lp) {
     constexpr bool EXACT = fl_exact(FL);
+    constexpr bool PLANES = LAB && fl_lut(FL);
     __shared__ float s_gam[LAB && !fl_lut(FL) ? 256 : 1];
     if (LAB && !fl_lut(FL)) { load_gamma_u8(s_gam, lab.gamma_u8); __syncthreads(); }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -313,22 +319,20 @@ __global__ __launch_bounds__(D0R_THREADS) void k_down0_rows(const uint8_t* __res
     const int g = tx * (D0R_OUT / 2) - 1 + lane;                    // source group of this lane
     const bool left_mirror = g < 0, right_mirror = g >= ngroups;    // REFLECT_101 mirrors of the edge groups
     const int gl = left_mirror ? 0 : (right_mirror ? ngroups - 1 : g);
-    const unsigned xoff = 12u * (unsigned)gl;
     const uint8_t* src = in + (size_t)b * in_sstride;
+    const size_t poff = (size_t)b * w * h;
     const int ox = 2 * g, oy0 = ty * rows;
     const bool owner = lane >= 1 && lane <= 62 && g >= 0 && ox < w1;    // (ox even, w1 even: ox + 1 < w1 too)
     // colour planes of the lane's 4 pixels for source row sy, and the two horizontal pyrDown results per plane
     auto fetch = [&](int sy) __attribute__((always_inline)) {
-        return *reinterpret_cast<const Px4*>(src + (size_t)reflect101(sy, h) * in_stride + xoff);
+        return load_raw4<PLANES>(src, in_stride, lp, poff, w, reflect101(sy, h), 4u * (unsigned)gl);
     };
-    auto hrow = [&](const Px4 pv, float (&ha)[3], float (&hb)[3]) __attribute__((always_inline)) {
-        int Bv[4], Gv[4], Rv[4];
-        unpack_px4(pv, Bv, Gv, Rv);
+    auto hrow = [&](const Raw4 pv, float (&ha)[3], float (&hb)[3]) __attribute__((always_inline)) {
         float P[3][4];
-        if (LAB) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) bgr_u8_to_lab<FL>(Bv[q], Gv[q], Rv[q], s_gam, lab, P[0][q], P[1][q], P[2][q]);
-        } else {
+        if (LAB) raw4_to_lab<FL>(pv, s_gam, lab, P[0], P[1], P[2]);
+        else {
+            int Bv[4], Gv[4], Rv[4];
+            raw4_bgr(pv, Bv, Gv, Rv);
 #pragma unroll
             for (int q = 0; q < 4; ++q) { P[0][q] = (float)Bv[q] * 1.0f; P[1][q] = (float)Gv[q] * 1.0f; P[2][q] = (float)Rv[q] * 1.0f; }   // colour mode: unscaled planes
         }
@@ -354,9 +358,9 @@ __global__ __launch_bounds__(D0R_THREADS) void k_down0_rows(const uint8_t* __res
     float* dst = G1 + (size_t)b * 3 * plane;
     // the two source rows of the NEXT output row are fetched before the current ones are converted: a wave otherwise waits
     // for its 12-byte loads once per output row with nothing of its own to do: 159-164 -> 147-151 us per 32 frames
-    Px4 n3 = fetch(2 * oy0 + 1), n4 = fetch(2 * oy0 + 2);
+    Raw4 n3 = fetch(2 * oy0 + 1), n4 = fetch(2 * oy0 + 2);
     for (int oy = oy0; oy < yend; ++oy) {
-        const Px4 c3 = n3, c4 = n4;
+        const Raw4 c3 = n3, c4 = n4;
         if (oy + 1 < yend) { n3 = fetch(2 * oy + 3); n4 = fetch(2 * oy + 4); }
         hrow(c3, a3, b3); hrow(c4, a4, b4);
         if (owner) {
@@ -375,6 +379,118 @@ __global__ __launch_bounds__(D0R_THREADS) void k_down0_rows(const uint8_t* __res
         }
 #pragma unroll
         for (int c = 0; c < 3; ++c) { a0[c] = a2[c]; a1[c] = a3[c]; a2[c] = a4[c]; b0[c] = b2[c]; b1[c] = b3[c]; b2[c] = b4[c]; }
+    }
+}
+
+// ---- u8 BGR -> OpenCV's forward Lab table -> pyrDown -> G_1, AND the integer Lab planes, in one pass ----------------
+// The conversion kernel (labconv.hip) and k_down0_rows fused for large launches (temporal batches / many streams): the
+// strip walk, DPP halo exchange and 5-row window of k_down0_rows, with every lane converting its 4-pixel group through
+// the table (lut_lab_int: (a, b) nodes in LDS, L cells from L2) instead of reading planes back, and storing the integer
+// planes the output kernel needs for the pixels it OWNS (lanes 1 .. 62, source rows 2 oy0 .. 2 yend - 1: every pixel of
+// the frame exactly once).  Saves the 6 bytes per pixel k_down0_rows would read and one launch; the table keeps one
+// persistent 1024-thread workgroup per CU, whose 16 waves take strips round-robin.
+constexpr int D0L_THREADS = 1024;
+// strip height for `waves` resident waves (k_down0_rows: one wave per SIMD slot of its 256-thread workgroups)
+inline int down0_lut_rows_choice(int w1, int h1, long frames, long waves, long* tasks_out) {
+    const long sx = (w1 + D0R_OUT - 1) / D0R_OUT;
+    int best = 8; long best_cost = -1, best_tasks = 0;
+    for (int r = 6; r <= 32; ++r) {
+        const long tasks = sx * ((h1 + r - 1) / r) * frames;
+        if (tasks * 5 < waves * 3) continue;                    // at least 60 % of the resident waves get a strip
+        const long cost = ((tasks + waves - 1) / waves) * (2 * r + 3);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; best_tasks = tasks; }
+    }
+    *tasks_out = best_tasks;
+    return best;
+}
+template <int FL>
+__global__ __launch_bounds__(D0L_THREADS) void k_down0_lut_rows(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
+                                                                int w, int h, float* __restrict__ G1, int w1, int h1, LabLut lut,
+                                                                int strips_x, int strips_y, int ntasks, int rows,
+                                                                uint16_t* __restrict__ iLp, uint32_t* __restrict__ iabp) {
+    constexpr bool EXACT = fl_exact(FL);
+    __shared__ uint32_t s_ab[kLabAbWords];
+    for (int i = threadIdx.x; i < kLabAbWords; i += D0L_THREADS) s_ab[i] = lut.ab[i];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int ngroups = w >> 2;                                    // w % 4 == 0
+    const size_t plane = (size_t)w1 * h1;
+    for (int task = blockIdx.x * (D0L_THREADS / 64) + wave; task < ntasks; task += gridDim.x * (D0L_THREADS / 64)) {
+        const int b = task / (strips_x * strips_y);
+        const int r = task - b * (strips_x * strips_y);
+        const int ty = r / strips_x, tx = r - ty * strips_x;
+        const int g = tx * (D0R_OUT / 2) - 1 + lane;                    // source group of this lane
+        const bool left_mirror = g < 0, right_mirror = g >= ngroups;    // REFLECT_101 mirrors of the edge groups
+        const int gl = left_mirror ? 0 : (right_mirror ? ngroups - 1 : g);
+        const uint8_t* src = in + (size_t)b * in_sstride;
+        const int ox = 2 * g, oy0 = ty * rows;
+        const bool owner = lane >= 1 && lane <= 62 && g >= 0 && ox < w1;
+        const int yend = oy0 + rows < h1 ? oy0 + rows : h1;
+        const int own_lo = 2 * oy0, own_hi = 2 * yend < h ? 2 * yend : h;    // source rows whose planes this strip stores
+        uint16_t* pL = iLp + (size_t)b * w * h + 4u * (unsigned)gl;
+        uint32_t* pab = iabp + (size_t)b * w * h + 4u * (unsigned)gl;
+        struct __attribute__((packed, aligned(4))) P3 { uint32_t a, b, c; };
+        auto fetch = [&](int sy) __attribute__((always_inline)) {
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(src + (size_t)reflect101(sy, h) * in_stride + 12u * (unsigned)gl);
+            P3 v; v.a = __builtin_nontemporal_load(q); v.b = __builtin_nontemporal_load(q + 1); v.c = __builtin_nontemporal_load(q + 2);
+            return v;
+        };
+        // source row sy: conversion of the lane's 4 pixels, plane stores, the two horizontal pyrDown results per channel
+        auto hrow = [&](const P3 v, int sy, float (&ha)[3], float (&hb)[3]) __attribute__((always_inline)) {
+            const uint32_t pb[12] = {v.a & 255, (v.a >> 8) & 255, (v.a >> 16) & 255, v.a >> 24, v.b & 255, (v.b >> 8) & 255,
+                                     (v.b >> 16) & 255, v.b >> 24, v.c & 255, (v.c >> 8) & 255, (v.c >> 16) & 255, v.c >> 24};
+            int iL[4], ia[4], ib[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lut_lab_int(pb[3 * k], pb[3 * k + 1], pb[3 * k + 2], s_ab, lut.Lcells, iL[k], ia[k], ib[k]);
+            if (owner && sy >= own_lo && sy < own_hi) {
+                const size_t o = (size_t)sy * w;
+                uint32_t* dL = reinterpret_cast<uint32_t*>(pL + o);
+                __builtin_nontemporal_store((uint32_t)iL[0] | ((uint32_t)iL[1] << 16), dL);
+                __builtin_nontemporal_store((uint32_t)iL[2] | ((uint32_t)iL[3] << 16), dL + 1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) __builtin_nontemporal_store((uint32_t)ia[k] | ((uint32_t)ib[k] << 16), pab + o + k);
+            }
+            float P[3][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { P[0][k] = lut_L(iL[k]); P[1][k] = lut_ab(ia[k]); P[2][k] = lut_ab(ib[k]); }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float give2 = P[c][2], give3 = left_mirror ? P[c][1] : P[c][3], give0 = right_mirror ? P[c][2] : P[c][0];
+                const float L2 = dpp_shr1(give2), L3 = dpp_shr1(give3), R0 = dpp_shl1(give0);
+                if (!EXACT && LVM_FAST_FMA) {
+                    ha[c] = __builtin_fmaf(P[c][0], 6.f, __builtin_fmaf(L3 + P[c][1], 4.f, L2 + P[c][2]));
+                    hb[c] = __builtin_fmaf(P[c][2], 6.f, __builtin_fmaf(P[c][1] + P[c][3], 4.f, P[c][0] + R0));
+                } else {
+                    ha[c] = P[c][0] * 6.f + (L3 + P[c][1]) * 4.f + L2 + P[c][2];
+                    hb[c] = P[c][2] * 6.f + (P[c][1] + P[c][3]) * 4.f + P[c][0] + R0;
+                }
+            }
+        };
+        float a0[3], a1[3], a2[3], a3[3], a4[3], b0[3], b1[3], b2[3], b3[3], b4[3];
+        hrow(fetch(2 * oy0 - 2), 2 * oy0 - 2, a0, b0); hrow(fetch(2 * oy0 - 1), 2 * oy0 - 1, a1, b1); hrow(fetch(2 * oy0), 2 * oy0, a2, b2);
+        float* dst = G1 + (size_t)b * 3 * plane;
+        P3 n3 = fetch(2 * oy0 + 1), n4 = fetch(2 * oy0 + 2);
+        for (int oy = oy0; oy < yend; ++oy) {
+            const P3 c3 = n3, c4 = n4;
+            if (oy + 1 < yend) { n3 = fetch(2 * oy + 3); n4 = fetch(2 * oy + 4); }
+            hrow(c3, 2 * oy + 1, a3, b3); hrow(c4, 2 * oy + 2, a4, b4);
+            if (owner) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    float va, vb;
+                    if (!EXACT && LVM_FAST_FMA) {
+                        va = __builtin_fmaf(a2[c], 6.f, __builtin_fmaf(a1[c] + a3[c], 4.f, a0[c] + a4[c])) * (1.f / 256.f);
+                        vb = __builtin_fmaf(b2[c], 6.f, __builtin_fmaf(b1[c] + b3[c], 4.f, b0[c] + b4[c])) * (1.f / 256.f);
+                    } else {
+                        va = (a2[c] * 6.f + (a1[c] + a3[c]) * 4.f + a0[c] + a4[c]) * (1.f / 256.f);
+                        vb = (b2[c] * 6.f + (b1[c] + b3[c]) * 4.f + b0[c] + b4[c]) * (1.f / 256.f);
+                    }
+                    *reinterpret_cast<float2*>(dst + c * plane + (size_t)oy * w1 + ox) = make_float2(va, vb);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { a0[c] = a2[c]; a1[c] = a3[c]; a2[c] = a4[c]; b0[c] = b2[c]; b1[c] = b3[c]; b2[c] = b4[c]; }
+        }
     }
 }
 

@@ -54,10 +54,8 @@ __device__ const float kHp9[81] = {
     0.0000f, 0.0003f, 0.0011f, 0.0022f, 0.0027f, 0.0022f, 0.0011f, 0.0003f, 0.0000f};
 
 // ---- u8 BGR -> L plane (MagnifyCore.hpp:218-222) ---------------------------------------------
-// L of one pixel.  Default (and what OpenCV 4 computes): the L channel of the interpolated 33^3 table (lut_lab_L, integer
-// arithmetic, bit-exact).  Analytic flavour: the Y row of the matrix and cv::cubeRoot's float64 rational polynomial (L feeds
-// the ill-conditioned acos(q0 / |q|) step, DESIGN.md "Numerics").  EXACT = false of rz_lum (division as reciprocal + two
-// Newton steps) is kept for tools/ only.
+// L of one pixel, ANALYTIC flavour only (lvm_debug_lab_analytic): the Y row of the matrix and cv::cubeRoot's float64
+// rational polynomial.  The default flavour takes L from OpenCV's interpolated table (labconv.hip writes the L plane).
 template <bool EXACT>
 __device__ __forceinline__ float rz_lum(float B, float G, float R, const float* fw) {
     const float Y = B * fw[3] + G * fw[4] + R * fw[5];
@@ -65,26 +63,26 @@ __device__ __forceinline__ float rz_lum(float B, float G, float R, const float* 
     const float FY = hi ? cv_cube_root<EXACT>(Y) : (7.787f * Y + 16.0f / 116.0f);
     return hi ? (116.f * FY - 16.f) : (903.3f * Y);
 }
-template <int FL>
 __global__ __launch_bounds__(256) void k_rz_lab(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                 int w, int h, float* __restrict__ Lp, LabCoef lab) {
-    __shared__ float s_gam[fl_lut(FL) ? 1 : 256];
-    if (!fl_lut(FL)) { load_gamma_u8(s_gam, lab.gamma_u8); __syncthreads(); }
+    __shared__ float s_gam[256];
+    load_gamma_u8(s_gam, lab.gamma_u8);
+    __syncthreads();
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;
     if (x >= w) return;
     const uint8_t* p = in + (size_t)b * in_sstride + (size_t)y * in_stride + (size_t)x * 3;
-    Lp[((size_t)b * h + y) * w + x] = fl_lut(FL) ? lut_lab_L(p[0], p[1], p[2], lab.lut) : rz_lum<true>(s_gam[p[0]], s_gam[p[1]], s_gam[p[2]], lab.fwd);
+    Lp[((size_t)b * h + y) * w + x] = rz_lum<true>(s_gam[p[0]], s_gam[p[1]], s_gam[p[2]], lab.fwd);
 }
 // Vectorised variant (4-pixel groups dword aligned): one 12-byte load and one 16-byte store per lane, and
 // a workgroup walks over kLabIters x 1024 pixels so the gamma table is loaded once per 4096 pixels instead
 // of once per 256.  Same arithmetic.
 constexpr int kLabIters = 4;
 struct __attribute__((packed, aligned(4))) RzIn4 { uint32_t a, b, c; };
-template <int FL>
 __global__ __launch_bounds__(256) void k_rz_lab4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
                                                  int w, int h, float* __restrict__ Lp, LabCoef lab) {
-    __shared__ float s_gam[fl_lut(FL) ? 1 : 256];
-    if (!fl_lut(FL)) { load_gamma_u8(s_gam, lab.gamma_u8); __syncthreads(); }
+    __shared__ float s_gam[256];
+    load_gamma_u8(s_gam, lab.gamma_u8);
+    __syncthreads();
     const int gpr = w >> 2, ngroups = gpr * h, b = blockIdx.y;
 #pragma unroll 1
     for (int it = 0; it < kLabIters; ++it) {
@@ -96,9 +94,7 @@ __global__ __launch_bounds__(256) void k_rz_lab4(const uint8_t* __restrict__ in,
                                  (v.b >> 16) & 255, v.b >> 24, v.c & 255, (v.c >> 8) & 255, (v.c >> 16) & 255, v.c >> 24};
         float L[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            L[k] = fl_lut(FL) ? lut_lab_L(pb[3 * k], pb[3 * k + 1], pb[3 * k + 2], lab.lut)
-                              : rz_lum<true>(s_gam[pb[3 * k]], s_gam[pb[3 * k + 1]], s_gam[pb[3 * k + 2]], lab.fwd);
+        for (int k = 0; k < 4; ++k) L[k] = rz_lum<true>(s_gam[pb[3 * k]], s_gam[pb[3 * k + 1]], s_gam[pb[3 * k + 2]], lab.fwd);
         *reinterpret_cast<float4*>(Lp + ((size_t)b * h + y) * w + x) = make_float4(L[0], L[1], L[2], L[3]);
     }
 }
@@ -1041,7 +1037,7 @@ __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in
                                                   uint8_t* __restrict__ out, long out_stride, long out_sstride, int w, int h,
                                                   const float* __restrict__ bandA, const float* __restrict__ resn, int nw,
                                                   int nh, LabCoef lab, int tiles_x, int tiles_y, int nstreams,
-                                                  float* __restrict__ dbg) {
+                                                  float* __restrict__ dbg, const float* __restrict__ Lplane, const uint32_t* __restrict__ iab) {
     constexpr bool EXACT = fl_exact(FL);
     __shared__ __attribute__((aligned(16))) float s_igt[4096];
     __shared__ float s_gam[fl_lut(FL) ? 1 : 256];
@@ -1071,16 +1067,35 @@ __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in
             __builtin_amdgcn_sched_barrier(0);
         }
         if (ok) {
-            const uint8_t* p = in + (size_t)b * in_sstride + (size_t)gy * in_stride + (size_t)gx * 3;
-            uint32_t pb[12];
-            if (VEC) {
-                const RzPx4 v = *reinterpret_cast<const RzPx4*>(p);
-                pb[0] = v.a & 255; pb[1] = (v.a >> 8) & 255; pb[2] = (v.a >> 16) & 255; pb[3] = v.a >> 24;
-                pb[4] = v.b & 255; pb[5] = (v.b >> 8) & 255; pb[6] = (v.b >> 16) & 255; pb[7] = v.b >> 24;
-                pb[8] = v.c & 255; pb[9] = (v.c >> 8) & 255; pb[10] = (v.c >> 16) & 255; pb[11] = v.c >> 24;
-            } else {
+            // Lab(in): analytic flavour from the u8 frame; LUT flavours from the planes the conversion kernel wrote
+            float Lin[4] = {0.f, 0.f, 0.f, 0.f}, ain[4], bin[4];
+            if (fl_lut(FL)) {
+                const size_t i = ((size_t)b * h + gy) * w + gx;
+                uint32_t q[4];
+                if (VEC) { const uint4 v = *reinterpret_cast<const uint4*>(iab + i); q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w; }
+                else {
 #pragma unroll
-                for (int m = 0; m < 12; ++m) pb[m] = (gx + m / 3 < w) ? p[m] : 0;
+                    for (int m = 0; m < 4; ++m) q[m] = (gx + m < w) ? iab[i + m] : 0u;
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    ain[m] = lut_ab((int)(q[m] & 0xffffu)); bin[m] = lut_ab((int)(q[m] >> 16));
+                    if (!BANDS) Lin[m] = (gx + m < w) ? Lplane[i + m] : 0.f;
+                }
+            } else {
+                const uint8_t* p = in + (size_t)b * in_sstride + (size_t)gy * in_stride + (size_t)gx * 3;
+                uint32_t pb[12];
+                if (VEC) {
+                    const RzPx4 v = *reinterpret_cast<const RzPx4*>(p);
+                    pb[0] = v.a & 255; pb[1] = (v.a >> 8) & 255; pb[2] = (v.a >> 16) & 255; pb[3] = v.a >> 24;
+                    pb[4] = v.b & 255; pb[5] = (v.b >> 8) & 255; pb[6] = (v.b >> 16) & 255; pb[7] = v.b >> 24;
+                    pb[8] = v.c & 255; pb[9] = (v.c >> 8) & 255; pb[10] = (v.c >> 16) & 255; pb[11] = v.c >> 24;
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 12; ++m) pb[m] = (gx + m / 3 < w) ? p[m] : 0;
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m) lin_bgr_to_lab<true>(s_gam[pb[3 * m]], s_gam[pb[3 * m + 1]], s_gam[pb[3 * m + 2]], lab.fwd, Lin[m], ain[m], bin[m]);
             }
             float4 Lq = make_float4(0.f, 0.f, 0.f, 0.f);
             if (BANDS) Lq = *reinterpret_cast<const float4*>(&sb[y][x]);   // written by this very thread
@@ -1088,9 +1103,7 @@ __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in
             uint32_t ob[12];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                float L, a, bb;
-                bgr_u8_to_lab<FL>(pb[3 * m], pb[3 * m + 1], pb[3 * m + 2], s_gam, lab, L, a, bb);
-                if (BANDS) L = Lc[m];
+                const float L = BANDS ? Lc[m] : Lin[m], a = ain[m], bb = bin[m];
                 float o0, o1, o2;
                 lab_to_bgr<EXACT>(L, a, bb, EXACT ? lab.inv : lab.inv1024, s_igt, o0, o1, o2);
                 if (DBG && dbg && b == 0 && gx + m < w) { float* d = dbg + ((size_t)gy * w + gx + m) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
@@ -1126,6 +1139,7 @@ struct RieszState : ModeState {
     float* res[kMaxLevels + 1] = {};
     float* f[kMaxLevels + 1][F_ALL_N] = {};
     // temporal batching: per-frame fields (band, amp, tc, ts, bandA, R1c, R2c), octaves and collapse results of tcap frames
+    uint32_t* iab = nullptr; uint32_t* iab_t = nullptr;      // (ia | ib << 16) planes of the input frames (labconv.hip)
     int tcap = 0; float* tarena = nullptr;
     float* ft[kMaxLevels + 1][F_ALL_N] = {}; float* oct_t[kMaxLevels + 1] = {}; float* res_t[kMaxLevels + 1] = {};   // per band level: band,P,R1p,R2p,phc,phs,lo0c,lo0s,lo1c,lo1s,hi0c,hi0s,hi1c,hi1s,amp,tc,ts,bandA
     bool inited = false;
@@ -1160,6 +1174,7 @@ static int riesz_alloc(Ctx* c, RieszState* st, int w, int h, int levels) {
     size_t total = 0;
     for (int l = 0; l < levels; ++l) total += 2 * pad(st->g[l].n * NS);                 // oct, res
     for (int l = 0; l < levels - 1; ++l) total += (size_t)F_COUNT * pad(st->g[l].n * NS);
+    total += pad(st->g[0].n * NS);                                                      // iab
     if (hipMalloc((void**)&st->arena, (total ? total : 64) * sizeof(float)) != hipSuccess) {
         st->arena = nullptr; c->err = "riesz: hipMalloc failed"; return LVM_ERR_OOM;
     }
@@ -1168,6 +1183,7 @@ static int riesz_alloc(Ctx* c, RieszState* st, int w, int h, int levels) {
     for (int l = 0; l < levels - 1; ++l)
         for (int k = 0; k < F_COUNT; ++k) { st->f[l][k] = p; p += pad(st->g[l].n * NS); }
     for (int l = 0; l < levels - 1; ++l) { st->f[l][F_R1C] = st->f[l][F_R1]; st->f[l][F_R2C] = st->f[l][F_R2]; }
+    st->iab = reinterpret_cast<uint32_t*>(p); p += pad(st->g[0].n * NS);
     return LVM_OK;
 }
 
@@ -1177,18 +1193,21 @@ static void riesz_coeffs(double frq, double fps, double a[3], double b[3]) {   /
 }
 
 // One buffer set = where the per-frame arrays of nt frames live ([frame][stream] planes).
-struct RzBufs { float** oct; float** res; float* (*pf)[F_ALL_N]; int nt; };
+struct RzBufs { float** oct; float** res; float* (*pf)[F_ALL_N]; int nt; uint32_t* iab; };
 
 // pyramid of the nt frames: L plane + 9x9 split chain
 static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B, hipStream_t s) {
     const int NZ = c->nstreams * B.nt, w = io.w, h = io.h, nb = st->levels - 1;
     const dim3 blk(256);
-    if (w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0) {
+    if (fl_lut(lab_flavour(c))) {
+        // OpenCV's forward table, once per frame: the float L plane for the pyramid and (ia, ib) for the output kernel
+        lab_lut_planes(c, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, NZ, nullptr, B.oct[0], B.iab, s);
+    } else if (w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0) {
         const long groups = (long)(w / 4) * h;
-        LVM_LAUNCH(c, "rz_lab", LVM_FL_PICK0(lab_flavour(c), k_rz_lab4), dim3((unsigned)((groups + 256 * kLabIters - 1) / (256 * kLabIters)), NZ), blk, s, io.d_in,
+        LVM_LAUNCH(c, "rz_lab", k_rz_lab4, dim3((unsigned)((groups + 256 * kLabIters - 1) / (256 * kLabIters)), NZ), blk, s, io.d_in,
                    (long)io.in_stride, (long)io.in_sstride, w, h, B.oct[0], c->lab);
     } else {
-        LVM_LAUNCH(c, "rz_lab", LVM_FL_PICK0(lab_flavour(c), k_rz_lab), dim3((w + 255) / 256, h, NZ), blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, B.oct[0], c->lab);
+        LVM_LAUNCH(c, "rz_lab", k_rz_lab, dim3((w + 255) / 256, h, NZ), blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, B.oct[0], c->lab);
     }
     for (int l = 0; l < nb; ++l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
@@ -1324,11 +1343,11 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
     if (nb >= 1)
         LVM_LAUNCH(c, "rz_final", kfb, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
                    (long)io.out_stride, (long)io.out_sstride, w, h, (const float*)B.pf[0][F_BANDA], resn, st->g[1].w, st->g[1].h,
-                   c->lab, tx, ty, NZ, dbg);
+                   c->lab, tx, ty, NZ, dbg, (const float*)B.oct[0], (const uint32_t*)B.iab);
     else
         LVM_LAUNCH(c, "rz_final", kfn, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
                    (long)io.out_stride, (long)io.out_sstride, w, h, (const float*)nullptr, (const float*)nullptr, 0, 0,
-                   c->lab, tx, ty, NZ, dbg);
+                   c->lab, tx, ty, NZ, dbg, (const float*)B.oct[0], (const uint32_t*)B.iab);
 }
 
 int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hipStream_t s, int* produced) {
@@ -1350,7 +1369,7 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         if (rc == LVM_OK && c->max_frames > 1) rc = riesz_reserve_frames(c, st, c->max_frames, s);
         if (rc != LVM_OK) return rc;
     }
-    const RzBufs B{st->oct, st->res, st->f, 1};
+    const RzBufs B{st->oct, st->res, st->f, 1, st->iab};
     rz_build(c, st, io, B, s);               // L plane + pyramid of the current frame (needed by every path below)
     // first frame ever, or degenerate coefficients: init and pass the frame through (:226-240)
     if (!st->inited || std::isnan(st->la[0]) || std::isnan(st->ha[0])) {
@@ -1388,6 +1407,7 @@ static int riesz_reserve_frames(Ctx* c, RieszState* st, int nt, hipStream_t s) {
     size_t total = 64;
     for (int l = 0; l < levels; ++l) total += 2 * pad(st->g[l].n * NS * nt);
     for (int l = 0; l < levels - 1; ++l) total += 7 * pad(st->g[l].n * NS * nt);
+    total += pad(st->g[0].n * NS * nt);
     if (hipMalloc((void**)&st->tarena, total * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); st->tarena = nullptr; c->err = "riesz: hipMalloc (frames) failed"; return LVM_ERR_OOM; }
     float* q = st->tarena;
     for (int l = 0; l < levels; ++l) { st->oct_t[l] = q; q += pad(st->g[l].n * NS * nt); st->res_t[l] = q; q += pad(st->g[l].n * NS * nt); }
@@ -1395,6 +1415,7 @@ static int riesz_reserve_frames(Ctx* c, RieszState* st, int nt, hipStream_t s) {
         for (int k = 0; k < F_ALL_N; ++k) st->ft[l][k] = st->f[l][k];          // state planes are shared
         for (int k : kPer) { st->ft[l][k] = q; q += pad(st->g[l].n * NS * nt); }
     }
+    st->iab_t = reinterpret_cast<uint32_t*>(q); q += pad(st->g[0].n * NS * nt);
     st->tcap = nt;
     return LVM_OK;
 }
@@ -1403,7 +1424,7 @@ static int riesz_reserve_frames(Ctx* c, RieszState* st, int nt, hipStream_t s) {
 int riesz_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int nt, hipStream_t s) {
     RieszState* st = static_cast<RieszState*>(c->state);
     if (nt > st->tcap) { const int rc = riesz_reserve_frames(c, st, nt, s); if (rc != LVM_OK) return rc; }
-    const RzBufs B{st->oct_t, st->res_t, st->ft, nt};
+    const RzBufs B{st->oct_t, st->res_t, st->ft, nt, st->iab_t};
     rz_build(c, st, io, B, s);
     rz_phase(c, st, B, 0, s);
     rz_finish(c, st, p, io, B, s);

@@ -52,12 +52,17 @@ static inline void hipLaunchKernelGGL(K kern, dim3 grid, dim3 block, size_t, hip
     hipemu::launch([=]() { kern(args...); }, grid, block);
 }
 
+struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
+static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 #define LVM_EMU_NO_DOT2 1      // lab_lut.h: v_dot2_i32_i16 spelled out
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+template <class T> static inline T __builtin_nontemporal_load(const T* p) { return *p; }
+template <class T, class U> static inline void __builtin_nontemporal_store(U v, T* p) { *p = (T)v; }
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
@@ -87,6 +92,8 @@ static inline float __uint_as_float(unsigned i) { float f; std::memcpy(&f, &i, 4
 
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 3; return hipSuccess; }   // three "CUs": the persistent kernels loop
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "hip-emu error"; }

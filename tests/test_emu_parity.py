@@ -219,6 +219,38 @@ def test_emu_wave_strip_first_kernel(lvm, po, emu, idx, w, h, levels, monkeypatc
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0, exact=True)
 
 
+@pytest.mark.parametrize("w,h,levels,exact", [(328, 109, 3, True), (1000, 70, 4, True), (124 * 2 * 2, 40, 2, True), (264, 90, 3, False)])
+def test_emu_fused_table_conversion_and_first_kernel(lvm, po, emu, w, h, levels, exact, monkeypatch):
+    """k_down0_lut_rows (OpenCV's forward Lab table + pyrDown + the integer planes of the owned pixels in one pass)
+    forced onto small frames: mirrored edge groups, a strip ending at the image edge, partly filled last strips, odd
+    heights (the last source row owned by the last strip); per-frame calls, so the output kernel of every frame reads the
+    planes this kernel stored.  exact=False: the default flavour's fma tap sums against the 1e-4 bar."""
+    monkeypatch.setenv("LVM_D0_FUSED_WAVES", "1")
+    ck, pk = lvm.synth.config(0, (w, h, levels))
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0 if exact else 1e-4, exact=exact)
+
+
+def test_emu_unfused_conversion_in_batches(lvm, po, emu, monkeypatch):
+    """LVM_D0_FUSED=0: labconv.hip's conversion kernel + the plane-reading first kernels in temporal batches."""
+    monkeypatch.setenv("LVM_D0_FUSED", "0")
+    _frames_clip(lvm, po, emu, 0, 320, 180, 4, 1, (1, 6, 5))
+
+
+@pytest.mark.parametrize("chunks,fused", [("2", "1"), ("3", "0")])
+def test_emu_chunked_batches(lvm, po, emu, chunks, fused, monkeypatch):
+    """LVM_LAP_CHUNKS: a temporal batch cut into chunks whose table conversion + first kernel are issued on the auxiliary
+    stream ahead of the rest (per-chunk slices of the batch buffers and of the integer planes)."""
+    monkeypatch.setenv("LVM_LAP_CHUNKS", chunks)
+    monkeypatch.setenv("LVM_D0_FUSED_WAVES", "1")
+    monkeypatch.setenv("LVM_D0_FUSED", fused)
+    _frames_clip(lvm, po, emu, 0, 264, 90, 3, 1, (1, 12, 9))
+
+
+def test_emu_fused_conversion_in_batches_two_streams(lvm, po, emu, monkeypatch):
+    monkeypatch.setenv("LVM_D0_FUSED_WAVES", "1")
+    _frames_clip(lvm, po, emu, 0, 264, 90, 3, 2, (1, 5, 4))
+
+
 def _frames_clip(lvm, po, lib, idx, w, h, levels, n_streams, calls, over=None, clip_over=None):
     """lvm_process_device_frames: batches of consecutive frames (sizes in `calls`) of n_streams streams
     must give exactly the frames the oracle produces one by one."""
