@@ -909,6 +909,7 @@ struct LaplaceState : ModeState {
     long up_rows_max_blocks = 1024;       // launches with fewer tiled workgroups than this use k_lap_up_rows (LVM_UP_ROWS_MAX_BLOCKS)
     bool d0_rows_on = true;               // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
     bool d0_fused = true;                 // table conversion fused into the first kernel on large launches (LVM_D0_FUSED=0: separate kernels)
+    int d0_fused_grid = 0;                // persistent workgroups of the fused kernel (LVM_D0_FUSED_GRID; 0 = one per CU).  Fewer leave CUs to a second stream
     long d0_fused_waves = 0;              // ... = launches with at least this many strips (LVM_D0_FUSED_WAVES; 0 = one per resident wave)
     long d0_min_tasks = 4096;             // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
     long fin_groups = 0;                  // workgroups of the persistent last kernel (LVM_FIN_GROUPS; 0 = 1024)
@@ -988,6 +989,7 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
     if (const char* e = std::getenv("LVM_D0_FUSED")) st->d0_fused = std::atoi(e) != 0;
     if (const char* e = std::getenv("LVM_D0_FUSED_WAVES")) st->d0_fused_waves = std::atol(e);
+    if (const char* e = std::getenv("LVM_D0_FUSED_GRID")) st->d0_fused_grid = std::atoi(e);
     if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
     if (const char* e = std::getenv("LVM_LAP_CHUNKS")) st->chunks = std::atoi(e);
     if (const char* e = std::getenv("LVM_LAP_SPLIT")) st->split_levels = std::atoi(e);
@@ -1053,7 +1055,7 @@ static bool lap_vec4(const FrameIO& io) {   // 4-pixel (12-byte) vector I/O need
 
 // Stage B of a frame: u8 -> Lab -> Gaussian pyramid G_1..G_T (parity buffer `par`) and, when the tail
 // kernel is enabled, everything that happens at the levels >= T (their IIR states, cur_T[par]).
-struct LapBufs { float** G; float** cur; float* curT; int nt; bool no_tail = false; uint16_t* iL = nullptr; uint32_t* iab = nullptr; };   // nt frames laid out [frame][stream][channel]
+struct LapBufs { float** G; float** cur; float* curT; int nt; bool no_tail = false; uint16_t* iL = nullptr; uint32_t* iab = nullptr; bool dbg_frame = true; };   // nt frames laid out [frame][stream][channel]
 static LapBufs lap_bufs_frame(LaplaceState* st, int par) { return LapBufs{st->Gp[par], st->cur, st->curT[par], 1, false, st->iLp[par], st->iabp[par]}; }
 // planes the kernels of a launch read (null: analytic flavour / gray frames)
 static LabPlanes lap_planes(const Ctx* c, const FrameIO& io, const LapBufs& B) {
@@ -1101,7 +1103,8 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     } else if (fused) {
         const int sx = (g1.w + D0R_OUT - 1) / D0R_OUT, sy = (g1.h + dl_rows - 1) / dl_rows;
         auto kdl = fl == FL_LUT_EXACT ? k_down0_lut_rows<FL_LUT_EXACT> : k_down0_lut_rows<FL_LUT_FAST>;
-        LVM_LAUNCH(c, "lap_down0", kdl, dim3((unsigned)c->num_cus), dim3(D0L_THREADS), s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
+        const int dl_grid = (st->d0_fused_grid > 0 && st->d0_fused_grid < c->num_cus) ? st->d0_fused_grid : c->num_cus;
+        LVM_LAUNCH(c, "lap_down0", kdl, dim3((unsigned)dl_grid), dim3(D0L_THREADS), s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
                    G[1], g1.w, g1.h, c->lab_lut, sx, sy, (int)dl_tasks, dl_rows, B.iL, B.iab);
     } else if (lap_vec4(io) && st->d0_rows_on && d0_tasks > 0) {
         auto kd0 = LVM_FL_PICK(fl, k_down0_rows, true);
@@ -1268,7 +1271,7 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     const float ca = (float)p.chromAttenuation;
     const float* cur1 = motion ? ((use_tail && st->tailT == 1) ? B.curT : B.cur[1]) : nullptr;
     const int w1 = st->g[1].w, h1 = st->g[1].h;
-    float* dbg = c->keep_float ? c->d_float : nullptr;
+    float* dbg = (c->keep_float && B.dbg_frame) ? c->d_float : nullptr;   // (the float frame kept is the first one of the batch)
     const int fl = lab_flavour(c);
     auto kf4 = dbg ? (motion ? LVM_FL_PICK(fl, k_lap_final_v4, true, true) : LVM_FL_PICK(fl, k_lap_final_v4, false, true))
                    : (motion ? LVM_FL_PICK(fl, k_lap_final_v4, true, false) : LVM_FL_PICK(fl, k_lap_final_v4, false, false));
@@ -1369,6 +1372,7 @@ int laplace_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int n
         for (int l = 1; l <= levels; ++l) k.G[l] = st->Gt[l] + (size_t)f0 * st->planes * st->g[l].n;
         for (int l = 1; l < levels; ++l) k.cur[l] = st->curt[l] + (size_t)f0 * st->planes * st->g[l].n;
         k.B = LapBufs{k.G, k.cur, nullptr, n, true};          // (the tail kernel filters inside stage B: not for overlapped chunks)
+        k.B.dbg_frame = f0 == 0;
         if (st->iabt) { k.B.iL = st->iLt + (size_t)f0 * c->nstreams * st->g[0].n; k.B.iab = st->iabt + (size_t)f0 * c->nstreams * st->g[0].n; }
         if (chunks > 1) {
             lap_stage_b(c, st, p, k.io, k.B, false, c->aux_stream, 1);
