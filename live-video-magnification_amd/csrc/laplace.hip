@@ -1104,7 +1104,7 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         const int sx = (g1.w + D0R_OUT - 1) / D0R_OUT, sy = (g1.h + dl_rows - 1) / dl_rows;
         auto kdl = fl == FL_LUT_EXACT ? k_down0_lut_rows<FL_LUT_EXACT> : k_down0_lut_rows<FL_LUT_FAST>;
         const int dl_grid = (st->d0_fused_grid > 0 && st->d0_fused_grid < c->num_cus) ? st->d0_fused_grid : c->num_cus;
-        LVM_LAUNCH(c, "lap_down0", kdl, dim3((unsigned)dl_grid), dim3(D0L_THREADS), s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
+        LVM_LAUNCH(c, "lap_down0_lut", kdl, dim3((unsigned)dl_grid), dim3(D0L_THREADS), s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
                    G[1], g1.w, g1.h, c->lab_lut, sx, sy, (int)dl_tasks, dl_rows, B.iL, B.iab);
     } else if (lap_vec4(io) && st->d0_rows_on && d0_tasks > 0) {
         auto kd0 = LVM_FL_PICK(fl, k_down0_rows, true);

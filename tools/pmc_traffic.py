@@ -10,12 +10,22 @@ import os
 import sys
 from collections import defaultdict
 
-NAMES = {  # kernel symbol prefix -> bench.py report name
-    "k_lap_final_v4<true, false, false>": "lap_final", "k_down0_rows<true, false>": "lap_down0", "k_down0_rows<false, false>": "col_down0",
-    "k_lap_up<false, 1>": "lap_up_l1", "k_lap_iir_levels": "lap_iir", "k_lap_collapse": "lap_collapse",
-    "k_rz_final<true, false, true, true, false>": "rz_final", "k_rz_blur_amp4<false>": "rz_blur_amp", "k_rz_phase4<false>": "rz_phase", "k_rz_phase<false>": "rz_phase_small",
-    "k_rz_lab4": "rz_lab", "k_rz_split_rows": "rz_split_l0", "k_col_out_rows<true, false>": "col_out", "k_col_out_rows<false, false>": "col_minmax",
+NAMES = {  # kernel symbol prefix -> bench.py report name (default flavour: FL_LUT_FAST = 0)
+    "k_lap_final_v4<true, false, 0>": "lap_final", "k_down0_lut_rows<0>": "lap_down0_lut", "k_down0_rows<true, 0>": "lap_down0", "k_down0_rows<false, 1>": "col_down0",
+    "k_lab_planes": "lab_lut", "k_lap_up<false, 1>": "lap_up_l1", "k_lap_iir_levels": "lap_iir", "k_lap_collapse": "lap_collapse", "k_pyr_down_rows": "pyr_down_rows_l1",
+    "k_rz_final<true, 0, true, true, false>": "rz_final", "k_rz_blur_amp4<false>": "rz_blur_amp", "k_rz_blur_strips": "rz_blur_amp", "k_rz_phase4<false>": "rz_phase", "k_rz_phase<false>": "rz_phase_small",
+    "k_rz_split_rows": "rz_split_l0", "k_col_out_rows<true, false>": "col_out", "k_col_out_rows<false, false>": "col_minmax",
 }
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def calibration():
+    """true bytes / counter bytes, measured by tools/hbm_counter_calib (tools/calib.sh) on known byte counts"""
+    try:
+        f = json.load(open(os.path.join(HERE, "..", "profiles", "r03_hbm_counter_calibration.json")))["factors"]
+        return float(f["fetch_8B_and_wider"]), float(f["write"])
+    except Exception:
+        return 2.0, 1.0
 
 
 def short(name):
@@ -45,6 +55,7 @@ def main():
         for r in csv.DictReader(open(f)):
             dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     fetch, write = read(pf, "FETCH_SIZE"), read(pw, "WRITE_SIZE")
+    ff, wf = calibration()
     kernels = {}
     for sym in sorted(dur, key=lambda k: -sum(dur[k])):
         name = next((v for k, v in NAMES.items() if sym.startswith(k)), None)
@@ -65,11 +76,14 @@ def main():
             continue
         fk, wk = (sum(fe) / len(fe) if fe else 0.0), (sum(wr) / len(wr) if wr else 0.0)
         kernels[name] = {"symbol": sym, "launches": len(d), "rocprof_avg_us": round(sum(d) / len(d), 2), "FETCH_SIZE_KB": round(fk, 1),
-                         "WRITE_SIZE_KB": round(wk, 1), "hbm_bytes_per_launch": int((fk + wk) * 1024)}
+                         "WRITE_SIZE_KB": round(wk, 1), "hbm_bytes_per_launch": int((ff * fk + wf * wk) * 1024)}
     print(json.dumps({"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, no other trace domain) of "
-                              "bench.py on MI355X; KB summed over the TCC instances, averaged over the steady-state launches.  No x2 "
-                              "correction: round 1 calibrated WRITE_SIZE * 1024 against a known byte count (exact) and FETCH_SIZE "
-                              "against the 12-byte-per-lane input reads (within 7 %); the guide's x2 applies to 16 B/lane streaming loads.",
+                              "bench.py on MI355X; KB summed over the TCC instances, averaged over the steady-state launches.  "
+                              "hbm_bytes_per_launch = (%.3f x FETCH_SIZE + %.3f x WRITE_SIZE) x 1024: the factors are true bytes / counter bytes "
+                              "measured on known byte counts at 4, 8, 12, 16 and 8 + 16 bytes per lane, 1 GiB and 64 MiB footprints "
+                              "(profiles/r03_hbm_counter_calibration.json): FETCH_SIZE reports exactly half of what is read at every width, "
+                              "Infinity-Cache hits included; WRITE_SIZE is exact.  (The round-2 files applied no factor: their read "
+                              "halves are 2 x too small.)" % (ff, wf),
                       "key": key, "mode": mode, "kernels": kernels}, indent=1))
 
 
