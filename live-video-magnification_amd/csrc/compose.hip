@@ -69,6 +69,10 @@ int compose_device(Ctx* c, int split, const uint8_t* d_orig, int ow, int oh, int
     int w, h, cw, chh;
     if (!compose_geometry(split, ow, oh, pw, ph, &w, &h, &cw, &chh)) return LVM_OK;    // empty canvas: nothing to write
     if (cstride < (ptrdiff_t)cw * 3) { c->err = "canvas stride too small"; return LVM_ERR_INVALID; }
+    // the kernel indexes the frames with the caller's strides: rows must hold their pixels, streams must not overlap
+    if (pstride < (ptrdiff_t)pw * pch || (split != LVM_SPLIT_NONE && ostride < (ptrdiff_t)ow * och)) { c->err = "frame stride too small"; return LVM_ERR_INVALID; }
+    if (c->nstreams > 1 && (csstride < (ptrdiff_t)chh * cstride || psstride < (ptrdiff_t)ph * pstride ||
+                            (split != LVM_SPLIT_NONE && osstride < (ptrdiff_t)oh * ostride))) { c->err = "stream stride too small"; return LVM_ERR_INVALID; }
     ComposeArgs a;
     a.src[0] = d_orig; a.stride[0] = ostride; a.sstride[0] = osstride; a.cn[0] = och;
     a.src[1] = d_proc; a.stride[1] = pstride; a.sstride[1] = psstride; a.cn[1] = pch;

@@ -421,6 +421,16 @@ __global__ __launch_bounds__(256) void k_lap_iir_levels(IirArgs aa) {
 
 constexpr int CT_W = 64, CT_H = 32, CP_R = 36, kCollapsePool = 4096;      // CP_R: row pitch of the coarser levels' regions (<= 34 columns)
 struct CollapseArgs { float* cur[kIirLevels]; int w[kIirLevels], h[kIirLevels]; int nlv; };   // index 0 = level 2, nlv - 1 = top live level
+// Worst-case LDS footprint of k_lap_collapse<NLV>: a region of r rows depends on at most r / 2 + 3 rows of the level above
+// (rows [y0 / 2 - 1, y1 / 2 + 1], one more when y0 is odd); the regions of levels 1 .. NLV - 1 at pitch CP_R, then the
+// horizontal-pass rows of the largest source region at pitch CT_W.
+constexpr int collapse_pool_floats(int nlv) {
+    int r = CT_H, total = 0, first = 0;
+    for (int k = 1; k < nlv; ++k) { r = r / 2 + 3; total += CP_R * r; if (k == 1) first = r; }
+    return total + first * CT_W;
+}
+static_assert(collapse_pool_floats(kIirLevels) <= kCollapsePool, "k_lap_collapse: LDS pool too small for CT_W / CT_H / CP_R / kIirLevels");
+static_assert(CT_W / 2 + 2 <= CP_R, "k_lap_collapse: a region row of the level above does not fit the row pitch");
 template <int NLV>                                      // number of levels (compile time: the per-level region scalars stay in SGPRs)
 __global__ __launch_bounds__(256) void k_lap_collapse(CollapseArgs a) {
     __shared__ float pool[kCollapsePool];

@@ -28,19 +28,29 @@ void prof_begin(Ctx* c, const char* name, hipStream_t s) {
 }
 void prof_end(Ctx* c, hipStream_t s) { if (!c->prof_skip) (void)hipEventRecord(c->prof_events.back().e1, s); }
 
-// Waits for everything this context has enqueued -- on its own two streams and on caller streams (through the
-// event recorded after every enqueue; an event outlives the stream it was recorded on).  Never a device-wide
-// synchronisation: the reference runs a live chain and an export chain side by side (export/Exporter.cpp:204,231)
-// and one context's reset must not stall the other.
+// Waits for everything this context has enqueued -- on its own two streams and on caller streams: one event PER DISTINCT
+// caller stream, re-recorded after every enqueue on it (an event outlives the stream it was recorded on).  Not a
+// device-wide synchronisation: the reference runs a live chain and an export chain side by side
+// (export/Exporter.cpp:204,231) and one context's reset must not stall the other.  A caller that cycles through more
+// than kMaxCallerStreams streams gets hipDeviceSynchronize instead (correct, just wider).
+constexpr size_t kMaxCallerStreams = 8;
 void sync_streams(Ctx* c) {
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
-    if (c->ev_done && c->ev_done_set) (void)hipEventSynchronize(c->ev_done);
+    for (auto& e : c->caller_events) (void)hipEventSynchronize(e.second);
+    if (c->caller_overflow) (void)hipDeviceSynchronize();
     (void)hipGetLastError();
 }
 void mark_enqueued(Ctx* c, hipStream_t s) {
-    if (s == c->own_stream || !c->ev_done) return;       // the own stream is synchronised directly
-    if (hipEventRecord(c->ev_done, s) == hipSuccess) c->ev_done_set = true; else (void)hipGetLastError();
+    if (s == c->own_stream) return;                       // the own stream is synchronised directly
+    for (auto& e : c->caller_events)
+        if (e.first == s) { if (hipEventRecord(e.second, s) != hipSuccess) { (void)hipGetLastError(); c->caller_overflow = true; } return; }
+    hipEvent_t ev = nullptr;
+    if (c->caller_events.size() >= kMaxCallerStreams || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError(); c->caller_overflow = true; return;
+    }
+    if (hipEventRecord(ev, s) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(ev); c->caller_overflow = true; return; }
+    c->caller_events.emplace_back(s, ev);
 }
 
 static void drop_graphs(Ctx* c) {
@@ -217,7 +227,6 @@ int lvm_create(int device, int n_streams, lvm_ctx** out) {
     ok = ok && hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_gamma_u8, sizeof(g)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->d_invgamma, sizeof(ig)) == hipSuccess;
     ok = ok && hipMemcpy(c->d_gamma_u8, g, sizeof(g), hipMemcpyHostToDevice) == hipSuccess;
@@ -255,7 +264,7 @@ void lvm_destroy(lvm_ctx* c) {
     if (c->d_pre_out) (void)hipFree(c->d_pre_out);
     if (c->d_chain_out) (void)hipFree(c->d_chain_out);
     c->d_pre_in = c->d_pre_out = c->d_chain_out = nullptr; c->pre_in_cap = c->pre_out_cap = c->chain_out_cap = 0;
-    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    for (auto& e : c->caller_events) (void)hipEventDestroy(e.second);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -348,7 +357,9 @@ int lvm_preprocess_device(lvm_ctx* c, const lvm_preprocess_params* pp, const uin
     if (!c || !pp) return LVM_ERR_INVALID;
     LVM_HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
-    return lvm::preprocess_device(c, *pp, d_in, w, h, channels, in_stride, in_stream_stride, d_out, out_stride, out_stream_stride, s);
+    const int rc = lvm::preprocess_device(c, *pp, d_in, w, h, channels, in_stride, in_stream_stride, d_out, out_stride, out_stream_stride, s);
+    lvm::mark_enqueued(c, s);
+    return rc;
 }
 
 int lvm_compose_geometry(int split, int ow, int oh, int pw, int ph, int* pane_w, int* pane_h, int* canvas_w, int* canvas_h) {

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "lvm_hip.h"
@@ -350,7 +351,8 @@ struct Ctx {
     int pipeline_depth = 0;           // 0 = every call completes its own frame; 1 = outputs lag one call (Laplace)
     hipStream_t aux_stream = nullptr; // second stream of the cross-frame pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t ev_done = nullptr; bool ev_done_set = false;   // recorded after every enqueue on a caller stream (sync_streams)
+    std::vector<std::pair<hipStream_t, hipEvent_t>> caller_events;   // one event per distinct caller stream, re-recorded after every enqueue (sync_streams)
+    bool caller_overflow = false;     // more caller streams than events: sync_streams synchronises the device
     int max_frames = 0;               // lvm_set_max_frames: temporal-batch buffers are sized for this many frames up front
     bool exact_lab = false;   // debug: OpenCV-order float arithmetic everywhere (bit-faithful to the oracle)
     bool lab_analytic = false;   // debug: analytic forward Lab (OpenCV with its interpolation switched off) instead of the 33^3 table

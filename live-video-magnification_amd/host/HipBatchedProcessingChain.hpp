@@ -117,6 +117,11 @@ public:
             T::on_error(instr_);
             (void)lvm_reset(mag_.handle());
             for (std::size_t s = 0; s < n; ++s) T::publish(*out_[s], frames[s], frames[s]);
+        } catch (...) {
+            // anything else: count it, reset, publish nothing (ProcessingChain.cpp:59-62)
+            errors_.fetch_add(1, std::memory_order_acq_rel);
+            T::on_error(instr_);
+            (void)lvm_reset(mag_.handle());
         }
         for (std::size_t s = 0; s < n; ++s) T::on_processed(instr_, frames[s]);   // :64-69
         ticks_.fetch_add(1, std::memory_order_acq_rel);

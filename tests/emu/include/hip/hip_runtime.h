@@ -133,11 +133,3 @@ static inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess
 enum { hipEventDisableTiming = 2 };
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-
-// <2 x float> stand-in for the pixel-pair arithmetic (clang's ext_vector_type in the product build): element-wise, each
-// operation rounded on its own (the translation units are built with -ffp-contract=off)
-struct hipemu_f32x2 { float x, y; };
-static inline hipemu_f32x2 operator*(hipemu_f32x2 a, hipemu_f32x2 b) { hipemu_f32x2 r; r.x = a.x * b.x; r.y = a.y * b.y; return r; }
-static inline hipemu_f32x2 operator+(hipemu_f32x2 a, hipemu_f32x2 b) { hipemu_f32x2 r; r.x = a.x + b.x; r.y = a.y + b.y; return r; }
-static inline hipemu_f32x2 operator-(hipemu_f32x2 a, hipemu_f32x2 b) { hipemu_f32x2 r; r.x = a.x - b.x; r.y = a.y - b.y; return r; }
-#define LVM_EMU_F32X2 hipemu_f32x2

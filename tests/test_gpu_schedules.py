@@ -140,6 +140,23 @@ def test_bench_two_ranks_from_a_plain_shell():
     assert out["cfg4_riesz_4k"]["n_gpus"] == 2
 
 
+def test_bench_eight_ranks_dry_run():
+    """The rank count the driver's scaling run ends with: `python bench.py --gpus 8` (eight ranks sharing this box's one
+    GPU, gloo for the barrier / MAX-reduce) -- launcher path, rendezvous on 127.0.0.1, one stream per rank (seeds 1234 +
+    rank), every rank verified for ITS seed, the cfg4 (Riesz 4K) sub-record produced at N = 8.  No scaling claim: the
+    ranks share one GPU."""
+    out = _bench(["--gpus", "8", "--share-gpu", "--dist-backend", "gloo", "--steps", "8", "--warmup", "4", "--width", "320", "--height", "180",
+                  "--levels", "4", "--verify-all-ranks", "--no-subrecords", "--frames-per-call", "4", "--ring", "8"])
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak"
+    ranks = sorted(out["ranks"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == list(range(8))
+    assert [r["stream_ids"] for r in ranks] == [[i] for i in range(8)]
+    assert all(r["verified"] is True for r in ranks), ranks
+    expect = 8 * 1 * 8 / out["timed_seconds_max_over_ranks"]
+    assert abs(out["value"] - expect) <= 1e-6 * expect + 0.01
+    assert out["cfg4_riesz_4k"]["n_gpus"] == 8
+
+
 def test_two_contexts_on_two_threads(lvm, po, hip):
     """Live chain + export chain (export/Exporter.cpp:204,231): two contexts, each driven by its own host thread,
     different modes and sizes, interleaved resets; both must match their oracle frame by frame."""
