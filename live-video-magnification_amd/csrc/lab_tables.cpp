@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "lvm_hip.h"
+#include "lab_lut.h"
 
 namespace lvm {
 
@@ -164,9 +165,13 @@ void build_lab_lut_compact(std::vector<int16_t>& compact) {
 
 // device layouts (lab_lut.h): ab[n] = a | b << 16 of node n = p + 33 q + 1089 r (padded by 34 zero entries);
 // lcells[8 n + 4 dp + 2 dq + dr] = L of node (p + dp, q + dq, r + dr), indices clamped to 32
+// position of cell (p, q, r) in the L table: 2 x 2 x 2 blocks of cells, one 128-byte line per block (lab_lut.h)
+static size_t lcell_index(int p, int q, int r) {
+    return (((size_t)(p >> 1) + 17 * (q >> 1) + 289 * (r >> 1)) << 3) | (p & 1) | ((q & 1) << 1) | ((r & 1) << 2);
+}
 void lab_lut_device_tables(const int16_t* compact, std::vector<uint32_t>& ab, std::vector<int16_t>& lcells) {
     ab.assign((size_t)33 * 33 * 33 + 34, 0u);
-    lcells.assign((size_t)33 * 33 * 33 * 8, 0);
+    lcells.assign((size_t)kLabLCells * 8, 0);
     auto at = [&](int p, int q, int r, int ch) {
         p = p > 32 ? 32 : p; q = q > 32 ? 32 : q; r = r > 32 ? 32 : r;
         return compact[(((size_t)r * 33 + q) * 33 + p) * 3 + ch];
@@ -178,7 +183,7 @@ void lab_lut_device_tables(const int16_t* compact, std::vector<uint32_t>& ab, st
                 ab[n] = (uint32_t)(uint16_t)at(p, q, r, 1) | ((uint32_t)(uint16_t)at(p, q, r, 2) << 16);
                 for (int dp = 0; dp < 2; ++dp)
                     for (int dq = 0; dq < 2; ++dq)
-                        for (int dr = 0; dr < 2; ++dr) lcells[n * 8 + 4 * dp + 2 * dq + dr] = at(p + dp, q + dq, r + dr, 0);
+                        for (int dr = 0; dr < 2; ++dr) lcells[lcell_index(p, q, r) * 8 + 4 * dp + 2 * dq + dr] = at(p + dp, q + dq, r + dr, 0);
             }
 }
 // lab_lut.h takes cell and weight of a u8 channel value from (514 u + 4) >> 8 instead of rounding float(u) * a255 * 16384:

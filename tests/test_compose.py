@@ -121,3 +121,22 @@ def test_compose_gpu_1080p_two_streams_after_the_magnifier(lvm, po, hip):
                 assert du.max() <= 1 and (du == 0).mean() >= 0.999
     finally:
         ctx.close()
+
+
+def test_compose_rejects_bad_strides(lvm, emu):
+    """The kernel indexes with the caller's strides: rows that cannot hold their pixels and overlapping streams are refused."""
+    import ctypes
+    w, h = 32, 16
+    o, p = _img(w, h, 3, 1), _img(w, h, 3, 2)
+    canvas = np.zeros((2, h, 2 * w, 3), np.uint8)
+    oo, pp = np.stack([o, o]), np.stack([p, p])
+    LR = 1
+    for ns, kw in ((1, dict(pstride=w * 3 - 1)), (1, dict(ostride=w * 3 - 3)), (1, dict(ostride=-w * 3)), (2, dict(csstride=h * 2 * w * 3 - 4)),
+                   (2, dict(psstride=w * 3))):
+        ctx = lvm.Context(0, ns, emu)
+        a = dict(ostride=w * 3, osstride=w * h * 3, pstride=w * 3, psstride=w * h * 3, cstride=2 * w * 3, csstride=h * 2 * w * 3)
+        a.update(kw)
+        with pytest.raises(lvm.LvmError):
+            ctx.compose_device(LR, ctypes.c_void_p(oo.ctypes.data), w, h, 3, a["ostride"], a["osstride"], ctypes.c_void_p(pp.ctypes.data), w, h, 3,
+                               a["pstride"], a["psstride"], ctypes.c_void_p(canvas.ctypes.data), a["cstride"], a["csstride"])
+        ctx.close()
