@@ -51,9 +51,10 @@ template <bool SEED, int D>
 __global__ __launch_bounds__(256) void k_lap_up(UpArgs a) {
     __shared__ float s_g[US_H][US_W + 1], s_c[US_H][US_W + 1];
     __shared__ float h_g[US_H][UT_W + 1], h_c[US_H][UT_W + 1];
-    const int x0 = blockIdx.x * UT_W, y0 = blockIdx.y * UT_H;
+    const Bid3 bq = xcd_swizzle3();
+    const int x0 = bq.x * UT_W, y0 = bq.y * UT_H;
     const int sx0 = x0 / 2 - 1, sy0 = y0 / 2 - 1;
-    const size_t pn = (size_t)blockIdx.z * a.wn * a.hn, pl = (size_t)blockIdx.z * a.w * a.h;
+    const size_t pn = (size_t)bq.z * a.wn * a.hn, pl = (size_t)bq.z * a.w * a.h;
     const bool has_cur = !SEED && a.curn != nullptr;
     constexpr int NP = UT_H * UT_W / 256;                 // pixels per thread
     constexpr int NS = (US_H * US_W + 255) / 256;         // staged source elements per thread

@@ -57,6 +57,41 @@ __device__ __forceinline__ uint32_t pack_u8x4(float v0, float v1, float v2, floa
 __device__ __forceinline__ float dpp_shr1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }
 __device__ __forceinline__ float dpp_shl1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }
 
+// ---- XCD-aware workgroup order ---------------------------------------------------------------------------------------
+// MI355X has 8 XCDs with private 4 MB L2s and places workgroup b of a launch on XCD b % 8 (observed, not contractual --
+// MI355X_MICROARCH.md; used for speed only, results never depend on it).  With tiles handed out in launch order,
+// neighbouring tiles -- which share halo rows / columns -- land on different L2s and every shared line is fetched again
+// through the fabric.  The remap gives every XCD a CONTIGUOUS range of the linear tile order instead (bijective for any
+// workgroup count), so halo re-reads hit the XCD's own L2.  LVM_XCD_SWIZZLE=0 builds without it (A/B measurements).
+// Measured per kernel (round 3, profiles/README.md) and kept only where it pays: k_lap_up at level 1 117 -> 105 us per 32
+// frames, k_rz_final 400 -> 391; the Riesz blur kernel got SLOWER (730 -> 875 us: eight distant regions of seven planes
+// streamed at once) and keeps the launch order, the split / collapse / phase kernels did not move.
+#ifndef LVM_XCD_SWIZZLE
+#define LVM_XCD_SWIZZLE 1
+#endif
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned nb) {
+#if LVM_XCD_SWIZZLE
+    const unsigned q = nb >> 3, r = nb & 7u, x = b & 7u, i = b >> 3;
+    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + i;
+#else
+    (void)nb; return b;
+#endif
+}
+struct Bid3 { int x, y, z; };
+// the same for a 3-D grid (dispatch order: x fastest)
+__device__ __forceinline__ Bid3 xcd_swizzle3() {
+    Bid3 r;
+#if LVM_XCD_SWIZZLE
+    const unsigned gx = gridDim.x, gy = gridDim.y;
+    const unsigned s = xcd_swizzle(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+    const unsigned t = s / gx;
+    r.x = (int)(s - t * gx); r.z = (int)(t / gy); r.y = (int)(t - (unsigned)r.z * gy);
+#else
+    r.x = blockIdx.x; r.y = blockIdx.y; r.z = blockIdx.z;
+#endif
+    return r;
+}
+
 // Lab conversion tables/coefficients (reference: MagnifyCore.hpp:90,152,219,275 call
 // cv::cvtColor COLOR_BGR2Lab / COLOR_Lab2BGR on float [0,1]; OpenCV 4 color_lab.cpp float path).
 #ifndef LVM_FAST_FMA
