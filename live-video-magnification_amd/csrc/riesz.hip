@@ -1036,6 +1036,112 @@ __global__ __launch_bounds__(256) void k_rz_collapse(const float* __restrict__ b
     }
 }
 
+// ---- the same stage as wave strips: no LDS tile, no barrier (round 3) ---------------------------------------------------
+// The tiled kernels stage (64 + 16) x (32 + 12) values per 64 x 32 outputs of each of the three blurred planes: measured
+// (calibrated FETCH_SIZE, profiles/) the stage moved 1.68 x its compulsory bytes at the HBM / Infinity-Cache ceiling.  Here a
+// wave owns a strip of 116 columns x `rows` rows of one plane-frame; lane i holds the two adjacent columns
+// c0 = 116 tx - 6 + 2 i, c0 + 1 of the current input row of amp / c / s (REFLECT_101 applied by the loads) and gets the six
+// columns left and right of them from its neighbours with whole-wave DPP shifts (lanes 3 .. 60 produce outputs, the three
+// lanes at either end only feed them).  The row-filtered values of the last 13 input rows of the three planes live in
+// registers (3 x 13 x 2); once 13 rows are in, every new input row completes one output row: column filter, amplify,
+// one 8-byte store.  Horizontal re-reads shrink to 128 / 116, vertical ones to (rows + 12) / rows.  Every output receives
+// its taps in the order of the tiled kernels (RowFilter left to right, SymmColumnFilter centre then +-j): identical bits.
+__device__ __attribute__((noinline)) float rz_amplify_exact_call(float v0, float v1, float v2, float r1, float r2, float band, float alpha, float thr) {
+    return rz_amplify<true>(v0, v1, v2, r1, r2, band, alpha, thr);
+}
+constexpr int BSW = 116, BS_THREADS = 256;
+struct BlurStripLv { const float *amp, *tc, *ts, *band, *R1, *R2; float* bandA; int w, h, sx, sy, rows, task0; };
+struct BlurStripArgs { BlurStripLv lv[kMaxBands]; int nlv, ntasks; float g[13]; float alpha, thr; };
+template <bool EXACT>
+__global__ __launch_bounds__(BS_THREADS) void k_rz_blur_strips(BlurStripArgs aa) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int task = blockIdx.x * (BS_THREADS / 64) + wave;
+    if (task >= aa.ntasks) return;
+    int lvl = 0;
+    while (lvl + 1 < aa.nlv && task >= aa.lv[lvl + 1].task0) ++lvl;
+    const BlurStripLv& a = aa.lv[lvl];
+    const int tq = task - a.task0;
+    const int bs = tq / (a.sx * a.sy), tr = tq - bs * (a.sx * a.sy);
+    const int ty = tr / a.sx, tx = tr - ty * a.sx;
+    const int w = a.w, h = a.h;
+    const int c0 = tx * BSW - 6 + 2 * lane;
+    const unsigned o0 = 4u * (unsigned)reflect101(c0, w), o1 = 4u * (unsigned)reflect101(c0 + 1, w);     // byte offsets inside a row
+    const bool owner = lane >= 3 && lane <= 60 && c0 < w;              // (w even, c0 even: c0 + 1 < w too)
+    const size_t pl = (size_t)bs * w * h;
+    const char* pamp = reinterpret_cast<const char*>(a.amp + pl);
+    const char* ptc = reinterpret_cast<const char*>(a.tc + pl);
+    const char* pts = reinterpret_cast<const char*>(a.ts + pl);
+    const int y0 = ty * a.rows, yend = y0 + a.rows < h ? y0 + a.rows : h;
+    const int nin = yend - y0 + 12;                                    // input rows y0 - 6 .. yend + 5
+    float H[3][13][2];
+    // the lane's raw values of one input row (two columns of amp / c / s); fetched one row AHEAD of their use, so that a
+    // wave has a row of loads in flight while it filters the previous one
+    struct Raw6 { float v[6]; };
+    auto fetch = [&](int i) __attribute__((always_inline)) {
+        const size_t ro = (size_t)reflect101(y0 - 6 + i, h) * w * sizeof(float);
+        Raw6 r;
+        r.v[0] = *reinterpret_cast<const float*>(pamp + ro + o0); r.v[1] = *reinterpret_cast<const float*>(pamp + ro + o1);
+        r.v[2] = *reinterpret_cast<const float*>(ptc + ro + o0); r.v[3] = *reinterpret_cast<const float*>(ptc + ro + o1);
+        r.v[4] = *reinterpret_cast<const float*>(pts + ro + o0); r.v[5] = *reinterpret_cast<const float*>(pts + ro + o1);
+        return r;
+    };
+    // row-filtered pair of one plane from the lane's two values
+    auto hpass = [&](const float v0, const float v1, float (&out)[2]) __attribute__((always_inline)) {
+        const float l1a = dpp_shr1(v0), l1b = dpp_shr1(v1), l2a = dpp_shr1(l1a), l2b = dpp_shr1(l1b), l3a = dpp_shr1(l2a), l3b = dpp_shr1(l2b);
+        const float r1a = dpp_shl1(v0), r1b = dpp_shl1(v1), r2a = dpp_shl1(r1a), r2b = dpp_shl1(r1b), r3a = dpp_shl1(r2a), r3b = dpp_shl1(r2b);
+        const float S[14] = {l3a, l3b, l2a, l2b, l1a, l1b, v0, v1, r1a, r1b, r2a, r2b, r3a, r3b};     // columns c0 - 6 .. c0 + 7
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float acc = aa.g[0] * S[m];
+#pragma unroll
+            for (int j = 1; j < 13; ++j) acc = __builtin_fmaf(aa.g[j], S[m + j], acc);
+            out[m] = acc;
+        }
+    };
+    Raw6 nxt = fetch(0);
+    for (int i0 = 0; i0 < nin; i0 += 13) {
+#pragma unroll
+        for (int ph = 0; ph < 13; ++ph) {
+            const int i = i0 + ph;
+            if (i >= nin) continue;                                    // (wave-uniform; `continue` keeps the phase loop unrollable)
+            const Raw6 cur = nxt;
+            if (i + 1 < nin) nxt = fetch(i + 1);
+            // the amplify operands of the output row this step completes are fetched before the filter arithmetic
+            const int y = y0 + i - 12;                                 // window: row y - 6 + k sits in slot (ph + 1 + k) % 13
+            float2 bd = make_float2(0.f, 0.f), q1 = bd, q2 = bd;
+            const size_t idx = pl + (size_t)(y > 0 ? y : 0) * w + (owner ? c0 : 0);
+            if (i >= 12 && owner) {
+                bd = *reinterpret_cast<const float2*>(a.band + idx); q1 = *reinterpret_cast<const float2*>(a.R1 + idx);
+                q2 = *reinterpret_cast<const float2*>(a.R2 + idx);
+            }
+            hpass(cur.v[0], cur.v[1], H[0][ph]); hpass(cur.v[2], cur.v[3], H[1][ph]); hpass(cur.v[4], cur.v[5], H[2][ph]);
+            if (i >= 12) {
+                float v[3][2];
+#pragma unroll
+                for (int f = 0; f < 3; ++f)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        float acc = aa.g[6] * H[f][(ph + 7) % 13][m];
+#pragma unroll
+                        for (int j = 1; j <= 6; ++j) acc = __builtin_fmaf(aa.g[6 + j], H[f][(ph + 7 + j) % 13][m] + H[f][(ph + 7 - j + 13) % 13][m], acc);
+                        v[f][m] = acc;
+                    }
+                if (owner) {
+                    float2 o;
+                    if (EXACT) {      // the libm sine / cosine of the exact flavour is large: out of line, or the 13-phase loop does not unroll
+                        o.x = rz_amplify_exact_call(v[0][0], v[1][0], v[2][0], q1.x, q2.x, bd.x, aa.alpha, aa.thr);
+                        o.y = rz_amplify_exact_call(v[0][1], v[1][1], v[2][1], q1.y, q2.y, bd.y, aa.alpha, aa.thr);
+                    } else {
+                        o.x = rz_amplify<false>(v[0][0], v[1][0], v[2][0], q1.x, q2.x, bd.x, aa.alpha, aa.thr);
+                        o.y = rz_amplify<false>(v[0][1], v[1][1], v[2][1], q1.y, q2.y, bd.y, aa.alpha, aa.thr);
+                    }
+                    *reinterpret_cast<float2*>(a.bandA + idx) = o;
+                }
+            }
+        }
+    }
+}
+
 // level-0 collapse (or plain L plane when there are no bands) + Lab2BGR + u8 (MagnifyCore.hpp:272-277).
 // 4 pixels per thread; VEC = the frame's 4-pixel groups are dword aligned (12-byte loads/stores).
 struct __attribute__((packed, aligned(4))) RzPx4 { uint32_t a, b, c; };
@@ -1161,6 +1267,9 @@ struct RieszState : ModeState {
     bool compact = true;             // compact zero-injected tile in the collapse kernels (LVM_RZ_COMPACT=0: the full 24 x 72 tile)
     bool split2 = true;              // 64 x 32 tiles with 4 x 2 outputs per thread in the 9x9 split (LVM_RZ_SPLIT2=0: k_rz_split)
     bool blur4 = true;               // register-blocked Gaussian/amplify kernel on the large levels (LVM_RZ_BLUR4=0: scalar kernel everywhere)
+    bool blur_strips = true;         // LDS-free wave-strip Gaussian/amplify kernel (LVM_RZ_BLUR_STRIPS=0: the tiled kernels) ...
+    long blur_strips_min = 1 << 19;  // ... for levels of at least this many plane-pixels per launch (LVM_RZ_BLUR_STRIPS_MIN; 1080p x 32 frames: levels 0 .. 3)
+    int blur_strip_rows = 64;        // rows per strip (LVM_RZ_BLUR_STRIP_ROWS), halved until a level has 4096 strips
     double lo_freq = 0, hi_freq = 0, fps = 0;
     double la[3] = {}, lb[3] = {}, ha[3] = {}, hb[3] = {};
     bool steady(const lvm_params& p) const override {
@@ -1301,8 +1410,25 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
         a.alpha = (float)p.amplification; a.thr = (float)(p.coWavelength * PI_PERCENT);
         // levels whose width is a multiple of 4 (and not tiny) take the register-blocked kernel, the rest the scalar one
         BlurArgs a4 = a;
+        BlurStripArgs as;
+        for (int i = 0; i < 13; ++i) as.g[i] = a.g[i];
+        as.alpha = a.alpha; as.thr = a.thr; as.nlv = 0; as.ntasks = 0;
         int blocks = 0, blocks4 = 0, n1 = 0, n4 = 0;
         for (int l = 0; l < nb; ++l) {
+            // wave strips (no LDS) for the large levels with an even width: rows per strip chosen so that the launch keeps
+            // the resident waves busy (a strip of r rows walks r + 12)
+            if (st->blur_strips && st->g[l].w % 2 == 0 && (long)st->g[l].n * NZ >= st->blur_strips_min) {
+                BlurStripLv& v = as.lv[as.nlv++];
+                float** q = B.pf[l];
+                v.amp = q[F_AMP]; v.tc = q[F_TC]; v.ts = q[F_TS]; v.band = q[F_BAND]; v.R1 = q[F_R1C]; v.R2 = q[F_R2C]; v.bandA = q[F_BANDA];
+                v.w = st->g[l].w; v.h = st->g[l].h;
+                v.sx = (v.w + BSW - 1) / BSW;
+                int rows = st->blur_strip_rows;
+                while (rows > 16 && (long)v.sx * ((v.h + rows - 1) / rows) * NZ < 4096) rows >>= 1;
+                v.rows = rows; v.sy = (v.h + rows - 1) / rows;
+                v.task0 = as.ntasks; as.ntasks += v.sx * v.sy * NZ;
+                continue;
+            }
             const bool big = st->blur4 && st->g[l].w % 4 == 0 && st->g[l].w >= 128 && st->g[l].h >= 64;
             BlurLv& v = big ? a4.lv[n4++] : a.lv[n1++];
             float** q = B.pf[l];
@@ -1312,7 +1438,9 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
             else { v.tx = (v.w + BT - 1) / BT; v.ty = (v.h + BTH - 1) / BTH; v.block0 = blocks; blocks += v.tx * v.ty * NZ; }
         }
         a.nlv = n1; a4.nlv = n4;
-        if (n4) LVM_LAUNCH(c, "rz_blur_amp", (lab_flavour(c) != FL_LUT_FAST) ? k_rz_blur_amp4<true> : k_rz_blur_amp4<false>, dim3(blocks4), dim3(B2T), s, a4);
+        if (as.nlv) LVM_LAUNCH(c, "rz_blur_amp", (lab_flavour(c) != FL_LUT_FAST) ? k_rz_blur_strips<true> : k_rz_blur_strips<false>,
+                               dim3((unsigned)((as.ntasks + BS_THREADS / 64 - 1) / (BS_THREADS / 64))), dim3(BS_THREADS), s, as);
+        if (n4) LVM_LAUNCH(c, as.nlv ? "rz_blur_amp_tiles" : "rz_blur_amp", (lab_flavour(c) != FL_LUT_FAST) ? k_rz_blur_amp4<true> : k_rz_blur_amp4<false>, dim3(blocks4), dim3(B2T), s, a4);
         if (n1) LVM_LAUNCH(c, "rz_blur_amp_small", (lab_flavour(c) != FL_LUT_FAST) ? k_rz_blur_amp<true> : k_rz_blur_amp<false>, dim3(blocks), blk, s, a);
     }
     const float* resn = B.oct[levels - 1];       // res_{L-1} = residual octave
@@ -1367,6 +1495,9 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
     if (!st) {
         st = new RieszState();
         if (const char* e = std::getenv("LVM_RZ_BLUR4")) st->blur4 = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_RZ_BLUR_STRIPS")) st->blur_strips = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_RZ_BLUR_STRIPS_MIN")) st->blur_strips_min = std::atol(e);
+        if (const char* e = std::getenv("LVM_RZ_BLUR_STRIP_ROWS")) st->blur_strip_rows = std::atoi(e);
         if (const char* e = std::getenv("LVM_RZ_SPLIT2")) st->split2 = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_RZ_COMPACT")) st->compact = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_RZ_PHASE4")) st->phase4 = std::atoi(e) != 0;

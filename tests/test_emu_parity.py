@@ -71,6 +71,24 @@ def test_riesz_emu_register_blocked_blur(lvm, po, emu, blur4, monkeypatch):
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0, exact=True)
 
 
+@pytest.mark.parametrize("w,h,levels,rows,exact", [(264, 150, 3, "16", True), (134, 78, 2, "64", True), (520, 70, 3, "32", True), (264, 150, 3, "16", False)])
+def test_riesz_emu_strip_blur(lvm, po, emu, w, h, levels, rows, exact, monkeypatch):
+    """k_rz_blur_strips (three 13-tap Gaussians + amplify as wave strips: DPP halo exchange over three lanes either side, a
+    13-row register window per plane) forced onto small levels: several strips per row with mirrored edge columns, a last
+    strip ending short of the wave, strips shorter than the 12 halo rows, odd heights, level widths 2 mod 4.
+    exact=False: the default flavour (hardware sine / cosine) against the parity bars."""
+    monkeypatch.setenv("LVM_RZ_BLUR_STRIPS_MIN", "0")
+    monkeypatch.setenv("LVM_RZ_BLUR_STRIP_ROWS", rows)
+    ck, pk = lvm.synth.config(2, (w, h, levels))
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0 if exact else 1e-4, exact=exact)
+
+
+def test_riesz_emu_tiled_blur_still_matches(lvm, po, emu, monkeypatch):
+    monkeypatch.setenv("LVM_RZ_BLUR_STRIPS", "0")
+    ck, pk = lvm.synth.config(2, (264, 150, 3))
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 3, 0.0, exact=True)
+
+
 @pytest.mark.parametrize("compact", ["1", "0"])
 def test_riesz_emu_collapse_tile_variants(lvm, po, emu, compact, monkeypatch):
     """The collapse kernels' zero-injected tile, compact (even rows / columns only; planes with even width and height) and
