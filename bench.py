@@ -450,8 +450,9 @@ def main():
                  "bars": "u8 <= 1 LSB, >= 99.9 % identical; float <= 1e-4 of max|ref|", "oracle_frames_replayed": n_verify}
         ref_check = None
         if po.RefOracle.available():
-            # the REAL reference stage (oracle/_ref/libref_magnify.so, built where OpenCV 4 exists): reported, not part of
-            # `verified` -- OpenCV's LUT-interpolated forward Lab alone moves the frames by ~5e-3
+            # the REAL reference stage (oracle/_ref/libref_magnify.so, built where OpenCV 4 exists): reported next to
+            # `verified`.  Since round 3 the library computes OpenCV's interpolated forward Lab; whether its restated table
+            # equals the one of this OpenCV build is reported too (a differing table can be installed with lvm_set_lab_lut)
             nref = min(n_verify, base + min(K, 64))
             rkeep, _, rdt = oracle_replay(po, np, host, pk, ring, nref, [i for i in check if i < nref], nthreads, real_reference=True)
             dmax, fmin = 0, 1.0
@@ -460,6 +461,8 @@ def main():
                     du = np.abs(ref.astype(np.int16) - R.d_out[i % R.oring, 0].cpu().numpy().astype(np.int16))
                     dmax, fmin = max(dmax, int(du.max())), min(fmin, float((du == 0).mean()))
             ref_check = {"frames": len(rkeep), "u8_max_diff": dmax, "u8_identical_min": round(fmin, 6), "fps": round(nref / rdt, 3)}
+            rt = po.RefOracle.recover_lab_lut()
+            ref_check["lab_lut_equals_opencv"] = None if rt is None else bool(np.array_equal(rt, R.ctx.lab_lut()))
         cpu = {"value": round(n_verify / cdt, 3), "unit": "frames/s", "cores": nthreads, "kind": "port",
                "sample": "%d frames of the same %dx%d L%d %s clip (the verification replay), CPU oracle = restatement of the "
                          "reference, OpenMP over rows" % (n_verify, w, h, levels, args.mode),

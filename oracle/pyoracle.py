@@ -375,6 +375,14 @@ class RefOracle:
             cls._lib = R
         return True
 
+    @classmethod
+    def recover_lab_lut(cls):
+        """The forward Lab table of the OpenCV build behind the real reference (None: not built / not interpolating)."""
+        if not cls.available() or not hasattr(cls._lib, "ref_recover_lab_lut"):
+            return None
+        t = np.empty(33 * 33 * 33 * 3, np.int16)
+        return t if cls._lib.ref_recover_lab_lut(t.ctypes.data_as(C.c_void_p)) == 0 else None
+
     def __init__(self):
         if not self.available():
             raise RuntimeError("oracle/_ref/libref_magnify.so is not built (no OpenCV 4 on the build host)")

@@ -1,22 +1,31 @@
 #!/bin/bash
-# Reproduces the round-2 files under profiles/ on a GPU box (`gpurun -- 'bash tools/refresh_profiles.sh'`): the bench
+# Reproduces the round-3 files under profiles/ on a GPU box (`gpurun -- 'bash tools/refresh_profiles.sh'`): the bench
 # lines of every mode (driver-shaped and default), the rocprofv3 kernel-trace summaries and the PMC passes (FETCH_SIZE,
-# WRITE_SIZE, SQ counters: each in its own run, never combined with other trace domains).  Outputs land in
-# gpurun_out/profiles_r02/; copy what is to be judged into profiles/.
+# WRITE_SIZE, SQ counters: each in its own run, never combined with other trace domains), the HBM counter calibration and
+# the two-stream (chunked) schedule's kernel trace.  Outputs land in gpurun_out/profiles_r03/; copy what is to be judged
+# into profiles/.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$ROOT/gpurun_out/profiles_r02; mkdir -p $O; cd $ROOT
-timeout 400 python bench.py --steps 20 --warmup 5 > $O/r02_bench_laplace_driver_shape.json 2> $O/err.txt
-timeout 600 python bench.py > $O/r02_bench_laplace.json 2>> $O/err.txt
-timeout 400 python bench.py --mode riesz --no-subrecords > $O/r02_bench_riesz.json 2>> $O/err.txt
-timeout 400 python bench.py --mode color --no-subrecords > $O/r02_bench_color.json 2>> $O/err.txt
+R=r03
+O=$ROOT/gpurun_out/profiles_$R; mkdir -p $O; cd $ROOT
+timeout 600 python bench.py --steps 20 --warmup 5 > $O/${R}_bench_laplace_driver_shape.json 2> $O/err.txt
+timeout 600 python bench.py --no-subrecords > $O/${R}_bench_laplace.json 2>> $O/err.txt
+timeout 400 python bench.py --mode riesz --no-subrecords > $O/${R}_bench_riesz.json 2>> $O/err.txt
+timeout 400 python bench.py --mode color --no-subrecords > $O/${R}_bench_color.json 2>> $O/err.txt
 SQ1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
 SQ2="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"
-for m in laplace riesz color; do
-  bash tools/pmc.sh profiles_r02/pmc_$m "--mode $m --steps 128 --warmup 32" "$SQ1" "$SQ2" "FETCH_SIZE" "WRITE_SIZE" > /dev/null 2>&1
-  cp $O/pmc_$m/summary.txt $O/r02_rocprof_${m}_kernels_and_sq_counters.txt
-  cp $O/pmc_$m/p0/t_kernel_stats.csv $O/r02_rocprof_${m}_kernel_stats.csv
-  w=1920; h=1080
-  python tools/pmc_traffic.py $m "$m|${w}x${h}|L6|B1|T32" $O/pmc_$m/p0 $O/pmc_$m/p3 $O/pmc_$m/p4 > $O/r02_pmc_traffic_$m.json
+for m in ${MODES:-laplace riesz color}; do
+  bash tools/pmc.sh profiles_$R/pmc_$m "--mode $m --steps 128 --warmup 32" "$SQ1" "$SQ2" "FETCH_SIZE" "WRITE_SIZE" > /dev/null 2>&1
+  cp $O/pmc_$m/summary.txt $O/${R}_rocprof_${m}_kernels_and_sq_counters.txt
+  cp $O/pmc_$m/p0/t_kernel_stats.csv $O/${R}_rocprof_${m}_kernel_stats.csv
+  python tools/pmc_traffic.py $m "$m|1920x1080|L6|B1|T32" $O/pmc_$m/p0 $O/pmc_$m/p3 $O/pmc_$m/p4 > $O/${R}_pmc_traffic_$m.json
+  rm -rf $O/pmc_$m/p1 $O/pmc_$m/p2 $O/pmc_$m/p3 $O/pmc_$m/p4       # the per-dispatch counter CSVs are large; the summaries stay
 done
-ls -la $O | head -30
+# two-stream schedule: table conversion + first kernel of the next chunk on the auxiliary stream (half the CUs), the rest on
+# the caller's stream -- per-dispatch start / end times show what did and did not overlap
+cd /tmp; export TMPDIR=/tmp
+LVM_LAP_CHUNKS=4 LVM_D0_FUSED_GRID=128 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/chunks -o t -- \
+  python $ROOT/bench.py --no-cpu-baseline --no-subrecords --profile-steps 0 --steps 128 --warmup 32 > $O/chunks.log 2>&1
+cd $ROOT
+python tools/overlap_report.py $O/chunks > $O/${R}_two_stream_overlap.txt 2>&1
+ls -la $O | head -40

@@ -31,7 +31,20 @@ __global__ __launch_bounds__(256) void k_analytic(const uint8_t* in, float4* out
     for (int q = 0; q < 4; ++q) lin_bgr_to_lab<false>(Bl[q], Gl[q], Rl[q], lab.fwd, L[q], a[q], b[q]);
     out[gi] = make_float4(L[0] + L[1] + L[2] + L[3], a[0] + a[1] + a[2] + a[3], b[0] + b[1] + b[2] + b[3], 0.f);
 }
-// ---- layout D: 16-byte nodes (lab_lut.h) ----
+// ---- layout D: 16-byte nodes { L[r], L[r+1], a[r], a[r+1], b[r], b[r+1], 0, 0 } per grid point, 575 KB, 4 gathers per pixel ----
+__device__ __forceinline__ void lut_lab(uint32_t B, uint32_t G, uint32_t R, const uint4* __restrict__ nodes, float& L, float& a, float& b) {
+    const uint32_t fr = lut_fine(R), fg = lut_fine(G), fb = lut_fine(B);
+    const uint32_t x = fr & 15u, y = fg & 15u, z = fb & 15u;
+    const uint32_t n = (fr >> 4) + 33u * (fg >> 4) + 1089u * (fb >> 4);
+    const uint4 n00 = nodes[n], n10 = nodes[n + 1], n01 = nodes[n + 33], n11 = nodes[n + 34];
+    const uint32_t wz = (16u - z) | (z << 16), x0 = 16u - x, y0 = 16u - y;
+    const uint32_t w00 = (x0 * y0) * wz, w10 = (x * y0) * wz, w01 = (x0 * y) * wz, w11 = (x * y) * wz;
+    const int rnd = 1 << 11;
+    const int iL = lut_dot2(n11.x, w11, lut_dot2(n01.x, w01, lut_dot2(n10.x, w10, lut_dot2(n00.x, w00, rnd)))) >> 12;
+    const int ia = lut_dot2(n11.y, w11, lut_dot2(n01.y, w01, lut_dot2(n10.y, w10, lut_dot2(n00.y, w00, rnd)))) >> 12;
+    const int ib = lut_dot2(n11.z, w11, lut_dot2(n01.z, w01, lut_dot2(n10.z, w10, lut_dot2(n00.z, w00, rnd)))) >> 12;
+    L = lut_L(iL); a = lut_ab(ia); b = lut_ab(ib);
+}
 __global__ __launch_bounds__(256) void k_lut_nodes(const uint8_t* in, float4* out, int ngroups, const uint4* nodes) {
     const int gi = blockIdx.x * 256 + threadIdx.x;
     if (gi >= ngroups) return;
@@ -141,7 +154,9 @@ __global__ __launch_bounds__(1024) void k_lut_hybrid(const uint8_t* in, float4* 
             // L cell: corner index 4 dp + 2 dq + dr -> dwords (dp, dq) = x: (0,0) y: (0,1) z: (1,0) w: (1,1)
             const int iL = lut_dot2(cL.w, w11, lut_dot2(cL.z, w10, lut_dot2(cL.y, w01, lut_dot2(cL.x, w00, rnd)))) >> 12;
             // pairs along B: low halves = a, high halves = b
-            #define LO(d, e) __builtin_amdgcn_perm((e), (d), 0x05040100u)
+            #undef LO
+#undef HI
+#define LO(d, e) __builtin_amdgcn_perm((e), (d), 0x05040100u)
             #define HI(d, e) __builtin_amdgcn_perm((e), (d), 0x07060302u)
             const int ia = lut_dot2(LO(d11, e11), w11, lut_dot2(LO(d01, e01), w01, lut_dot2(LO(d10, e10), w10, lut_dot2(LO(d00, e00), w00, rnd)))) >> 12;
             const int ib = lut_dot2(HI(d11, e11), w11, lut_dot2(HI(d01, e01), w01, lut_dot2(HI(d10, e10), w10, lut_dot2(HI(d00, e00), w00, rnd)))) >> 12;
@@ -219,7 +234,18 @@ __global__ __launch_bounds__(1024) void k_lut_hybrid_sched(const uint8_t* in, fl
     }
 }
 
-namespace lvm { void build_lab_lut_nodes(std::vector<int16_t>& compact, std::vector<uint16_t>& nodes); }
+namespace lvm { void build_lab_lut_compact(std::vector<int16_t>& compact); }
+static void build_lab_lut_nodes(std::vector<int16_t>& compact, std::vector<uint16_t>& nodes) {
+    lvm::build_lab_lut_compact(compact);
+    nodes.assign((size_t)(33 * 33 * 33 + 35) * 8, 0);
+    for (int r = 0; r < 33; ++r) for (int q = 0; q < 33; ++q) for (int p = 0; p < 33; ++p) {
+        const int r1 = r < 32 ? r + 1 : 32;
+        const int16_t* e0 = &compact[(((size_t)r * 33 + q) * 33 + p) * 3];
+        const int16_t* e1 = &compact[(((size_t)r1 * 33 + q) * 33 + p) * 3];
+        uint16_t* n = &nodes[((size_t)p + 33 * q + 1089 * r) * 8];
+        for (int ch = 0; ch < 3; ++ch) { n[2 * ch] = (uint16_t)e0[ch]; n[2 * ch + 1] = (uint16_t)e1[ch]; }
+    }
+}
 
 static void make_frames(std::vector<uint8_t>& f, int w, int h, int nf, bool noisy) {
     f.resize((size_t)nf * w * h * 3);
@@ -271,9 +297,9 @@ int main() {
     CK(hipMalloc(&d_cells, cells.size() * 2)); CK(hipMemcpy(d_cells, cells.data(), cells.size() * 2, hipMemcpyHostToDevice));
     CK(hipMalloc(&d_lw, lw.size() * 4)); CK(hipMemcpy(d_lw, lw.data(), lw.size() * 4, hipMemcpyHostToDevice));
     CK(hipFuncSetAttribute((const void*)k_lut_lds_L, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLWords * 4));
-    uint8_t* d_in; float4 *d_o0, *d_o1, *d_o2, *d_o3, *d_o4;
+    uint8_t* d_in; float4 *d_o0, *d_o1, *d_o2, *d_o3, *d_o4, *d_o5;
     CK(hipMalloc(&d_in, (size_t)ngroups * 12));
-    for (float4** p : { &d_o0, &d_o1, &d_o2, &d_o3, &d_o4 }) CK(hipMalloc(p, (size_t)ngroups * 16));
+    for (float4** p : { &d_o0, &d_o1, &d_o2, &d_o3, &d_o4, &d_o5 }) CK(hipMalloc(p, (size_t)ngroups * 16));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int noisy = 1; noisy >= 0; --noisy) {
         std::vector<uint8_t> fr; make_frames(fr, w, h, nf, noisy != 0);
@@ -291,19 +317,19 @@ int main() {
                 case 5: hipLaunchKernelGGL(k_lut_hybrid<false>, dim3(256), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
                 case 6: hipLaunchKernelGGL(k_lut_hybrid<true>, dim3(256), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
                 case 8: hipLaunchKernelGGL(k_lut_hybrid_sched<0>, dim3(256), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
-                case 9: hipLaunchKernelGGL(k_lut_hybrid_sched<1>, dim3(256), dim3(1024), 0, 0, d_in, d_o3, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
-                case 11: hipLaunchKernelGGL(k_lut_hybrid_sched<3>, dim3(256), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
-                case 12: hipLaunchKernelGGL(k_lut_hybrid_sched<4>, dim3(256), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
-                case 13: hipLaunchKernelGGL(k_lut_hybrid_sched<5>, dim3(256), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
-                case 14: hipLaunchKernelGGL(k_lut_hybrid_sched<6>, dim3(256), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
-                case 10: hipLaunchKernelGGL(k_lut_hybrid_sched<2>, dim3(256), dim3(1024), 0, 0, d_in, d_o3, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
+                case 9: hipLaunchKernelGGL(k_lut_hybrid_sched<1>, dim3(256), dim3(1024), 0, 0, d_in, d_o5, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
+                case 11: hipLaunchKernelGGL(k_lut_hybrid_sched<3>, dim3(256), dim3(1024), 0, 0, d_in, d_o5, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
+                case 12: hipLaunchKernelGGL(k_lut_hybrid_sched<4>, dim3(256), dim3(1024), 0, 0, d_in, d_o5, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
+                case 13: hipLaunchKernelGGL(k_lut_hybrid_sched<5>, dim3(256), dim3(1024), 0, 0, d_in, d_o5, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
+                case 14: hipLaunchKernelGGL(k_lut_hybrid_sched<6>, dim3(256), dim3(1024), 0, 0, d_in, d_o5, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
+                case 10: hipLaunchKernelGGL(k_lut_hybrid_sched<2>, dim3(256), dim3(1024), 0, 0, d_in, d_o5, ngroups, d_abw, d_lcells, (ngroups + 255) / 256); break;
                 case 7: hipLaunchKernelGGL(k_lut_hybrid<true>, dim3(hyb_blocks), dim3(1024), 0, 0, d_in, d_o4, ngroups, d_abw, d_lcells, hyb_per_block); break;
             }
         };
-        const char* names[15] = { "analytic (default flavour)", "LUT 16-byte nodes (575 KB, 4 loads)", "LUT OpenCV cells (1.7 MB, 3 loads)", "LUT L only, LDS 72 KB", "LUT hybrid: (a,b) LDS 144 KB + L cells", "hybrid, 256 persistent workgroups", "hybrid, 256 workgroups, nontemporal in/out", "hybrid, 2048 workgroups, nontemporal", "hybrid, 256 workgroups, hand-scheduled", "   ablation: no L gather (LDS + VALU)", "   ablation: no LDS reads (gather + VALU)", "hand-scheduled, L gather sc1", "hand-scheduled, L gather nt", "hand-scheduled, L gather sc0 sc1", "hand-scheduled, L gather sc0" };
+        const char* names[15] = { "analytic (default flavour)", "LUT 16-byte nodes (575 KB, 4 loads)", "LUT OpenCV cells (1.7 MB, 3 loads)", "LUT L only, LDS 72 KB", "LUT hybrid: (a,b) LDS 144 KB + L cells", "hybrid, 256 persistent workgroups", "hybrid, 256 workgroups, nontemporal in/out", "hybrid, 2048 workgroups, nontemporal", "hybrid, 256 workgroups, hand-scheduled", "   ablation: no L gather (LDS + VALU)", "   ablation: no LDS reads (gather + VALU)", "   timing only: L gather sc1 (L1 bypassed)", "   timing only: L gather nt", "   timing only: L gather sc0 sc1", "   timing only: L gather sc0" };
         for (int rep = 0; rep < 2; ++rep)
             for (int k = 0; k < 15; ++k) {
-                if (k == 3 || k == 1 || k == 7) continue;
+                if (k == 7) continue;
                 for (int i = 0; i < 5; ++i) run(k);
                 CK(hipEventRecord(e0));
                 for (int i = 0; i < 20; ++i) run(k);
