@@ -639,147 +639,192 @@ struct Row3 { float4 c[3]; };            // horizontal-pass results of one sourc
 #else
 #define LVM_FIN_BOUNDS __launch_bounds__(FIN_THREADS)
 #endif
+struct FinArgs {
+    const uint8_t* in; long in_stride, in_sstride;
+    uint8_t* out; long out_stride, out_sstride;
+    int w, h; const float* cur1; int w1, h1;
+    LabCoef lab; float ca; int strips_x, strips_y, nstreams, rows;
+    float* dbg; LabPlanes lp;
+};
+// one wave strip (task) of the last kernel; s_igt = inverse-gamma spline in LDS, s_gam = gamma table (analytic flavour)
 template <bool MOTION, bool DBG, int FL>     // DBG: also store the float frame (lvm_debug_keep_float); a per-pixel branch
-__global__ LVM_FIN_BOUNDS void k_lap_final_v4(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
-                                                       uint8_t* __restrict__ out, long out_stride, long out_sstride,
-                                                       int w, int h, const float* __restrict__ cur1, int w1, int h1,
-                                                       LabCoef lab, float ca, int strips_x, int strips_y, int nstreams,
-                                                       int rows, float* __restrict__ dbg, LabPlanes lp) {
+__device__ __forceinline__ void lap_final_strip(const FinArgs& q, int task, int lane, const float* s_igt, const float* s_gam) {
     constexpr bool EXACT = fl_exact(FL);
     constexpr bool PLANES = fl_lut(FL);
+    const uint8_t* __restrict__ in = q.in; const long in_stride = q.in_stride, in_sstride = q.in_sstride;
+    uint8_t* __restrict__ out = q.out; const long out_stride = q.out_stride, out_sstride = q.out_sstride;
+    const int w = q.w, h = q.h, w1 = q.w1, h1 = q.h1, strips_x = q.strips_x, strips_y = q.strips_y, rows = q.rows;
+    const float* __restrict__ cur1 = q.cur1; const LabCoef& lab = q.lab; const float ca = q.ca;
+    float* __restrict__ dbg = q.dbg; const LabPlanes lp = q.lp;
+    const int b = task / (strips_x * strips_y);
+    const int r = task - b * (strips_x * strips_y);
+    const int ty = r / strips_x, tx = r - ty * strips_x;
+    const int gx = tx * 256 + 4 * lane, y0 = ty * rows;        // rows is even: y0 is even
+    if (gx >= w) return;
+    // uniform (scalar) bases + 32-bit lane offsets
+    const uint8_t* src = in + (size_t)b * in_sstride;
+    const size_t poff = (size_t)b * w * h;
+    uint8_t* dst = out + (size_t)b * out_sstride;
+    const unsigned xoff = (unsigned)gx * 3u;
+    const float* pl = cur1 + (size_t)b * 3 * ((size_t)w1 * h1);
+    const int i0 = gx >> 1;
+    // byte offsets of the four taps.  Default flavour: the border rule is applied by the LOADS (column -1 reads column 1,
+    // column w1 reads column w1 - 1) and every lane runs the interior formulas -- s1 + 6 s0 + s1 = 6 s0 + 2 s1,
+    // s0 + 6 s1 + s1 = s0 + 7 s1, (s1 + s1) 4 = 8 s1: equal up to the rounding of one addition at the two border
+    // columns, 16 selects / border variants less per lane and source row.
+    const unsigned cm1 = 4u * (i0 > 0 ? i0 - 1 : (EXACT ? 0 : 1)), c00 = 4u * i0, cp1 = 4u * (i0 + 1 < w1 ? i0 + 1 : w1 - 1), cp2 = 4u * (i0 + 2 < w1 ? i0 + 2 : w1 - 1);
+    const size_t pstride = (size_t)w1 * h1;
+    // horizontal pass of source row sy (vertical border map: row -1 -> 1, row h1 -> h1 - 1); the row
+    // base is uniform, the four column offsets are per-lane byte offsets
+    auto hrow = [&](int sy) __attribute__((always_inline)) {
+        Row3 o;
+        sy = sy < 0 ? 1 : (sy >= h1 ? h1 - 1 : sy);
+        const char* row = reinterpret_cast<const char*>(pl + (size_t)sy * w1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const char* rc = row + c * pstride * sizeof(float);
+            const float sm1 = *reinterpret_cast<const float*>(rc + cm1), s0 = *reinterpret_cast<const float*>(rc + c00),
+                        s1 = *reinterpret_cast<const float*>(rc + cp1), s2 = *reinterpret_cast<const float*>(rc + cp2);
+            if (EXACT) o.c[c] = pyrup_h4(sm1, s0, s1, s2, i0, w1);
+            else if (LVM_FAST_FMA) {   // one rounding less per even column (fma), a few 1e-8 of the motion image
+                o.c[c].x = __builtin_fmaf(s0, 6.f, sm1 + s1); o.c[c].y = (s0 + s1) * 4.f; o.c[c].z = __builtin_fmaf(s1, 6.f, s0 + s2); o.c[c].w = (s1 + s2) * 4.f;
+            } else { o.c[c].x = sm1 + s0 * 6.f + s1; o.c[c].y = (s0 + s1) * 4.f; o.c[c].z = s0 + s1 * 6.f + s2; o.c[c].w = (s1 + s2) * 4.f; }
+        }
+        return o;
+    };
+    const int yend = (y0 + rows < h) ? y0 + rows : h;
+    int gy = y0, j = y0 >> 1;
+    // one output row: colour math of 4 pixels; m = the motion image of the row (EXACT: scaled by 1/64 as
+    // pyrUp does; otherwise the unscaled vertical sum, whose power-of-two scale `msc` is folded into the
+    // add -- fma(m, 2^-k, L) rounds exactly like L + m * 2^-k)
+    auto emit = [&](const Raw4 pin, const float (&m)[3][4], const float msc) __attribute__((always_inline)) {
+        float L4[4], a4[4], b4[4];
+        raw4_to_lab<FL>(pin, s_gam, lab, L4, a4, b4);
+        float ov[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float o0, o1, o2;
+            float L = L4[k], a = a4[k], bb = b4[k];
+            if (MOTION) {
+                if (EXACT) { L = L + m[0][k]; a = a + m[1][k] * ca; bb = bb + m[2][k] * ca; }
+                else {
+                    L = __builtin_fmaf(m[0][k], msc, L);
+                    a = __builtin_fmaf(m[1][k], msc * ca, a); bb = __builtin_fmaf(m[2][k], msc * ca, bb);
+                }
+            }
+            lab_to_bgr<EXACT>(L, a, bb, EXACT ? lab.inv : lab.inv1024, s_igt, o0, o1, o2);
+            if (DBG && dbg && b == 0) { float* d = dbg + ((size_t)gy * w + gx + k) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
+            if (EXACT) {
+                ov[3 * k] = o0 * 255.0f + lab.a255; ov[3 * k + 1] = o1 * 255.0f + lab.a255; ov[3 * k + 2] = o2 * 255.0f + lab.a255;
+            } else {   // fma(o, 255, 1/255) differs from mul + add only far below the rounding step
+                ov[3 * k] = __builtin_fmaf(o0, 255.0f, lab.a255); ov[3 * k + 1] = __builtin_fmaf(o1, 255.0f, lab.a255);
+                ov[3 * k + 2] = __builtin_fmaf(o2, 255.0f, lab.a255);
+            }
+        }
+        Px4 qo;
+        qo.a = pack_u8x4(ov[0], ov[1], ov[2], ov[3]);
+        qo.b = pack_u8x4(ov[4], ov[5], ov[6], ov[7]);
+        qo.c = pack_u8x4(ov[8], ov[9], ov[10], ov[11]);
+        *reinterpret_cast<Px4*>(dst + (size_t)gy * out_stride + xoff) = qo;
+    };
+    // two output rows (2j, 2j+1) from the window rows A = j-1, B = j, C = j+1; afterwards A holds row
+    // j+2, i.e. the window has rotated to (B, C, A).  Returns false when the strip is finished.
+    auto step = [&](Row3& A, const Row3& B, const Row3& C) __attribute__((always_inline)) {
+        const Raw4 pe = load_raw4<PLANES>(src, in_stride, lp, poff, w, gy, (unsigned)gx);
+        const bool has_odd = gy + 1 < yend;
+        Raw4 po = pe;
+        if (has_odd) po = load_raw4<PLANES>(src, in_stride, lp, poff, w, gy + 1, (unsigned)gx);
+        float m[3][4] = {};
+        if (MOTION) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float sc = EXACT ? (1.f / 64.f) : 1.f;           // (x * 1.f folds away)
+                if (!EXACT && LVM_FAST_FMA) {
+                    m[c][0] = __builtin_fmaf(B.c[c].x, 6.f, A.c[c].x + C.c[c].x); m[c][1] = __builtin_fmaf(B.c[c].y, 6.f, A.c[c].y + C.c[c].y);
+                    m[c][2] = __builtin_fmaf(B.c[c].z, 6.f, A.c[c].z + C.c[c].z); m[c][3] = __builtin_fmaf(B.c[c].w, 6.f, A.c[c].w + C.c[c].w);
+                    continue;
+                }
+                m[c][0] = (A.c[c].x + B.c[c].x * 6.f + C.c[c].x) * sc; m[c][1] = (A.c[c].y + B.c[c].y * 6.f + C.c[c].y) * sc;
+                m[c][2] = (A.c[c].z + B.c[c].z * 6.f + C.c[c].z) * sc; m[c][3] = (A.c[c].w + B.c[c].w * 6.f + C.c[c].w) * sc;
+            }
+        }
+        const bool more = gy + 2 < yend;
+        if (MOTION && more) A = hrow(j + 2);                 // in flight during the colour math of both rows
+        emit(pe, m, 1.f / 64.f);
+        ++gy;
+        if (!has_odd) return false;
+        if (MOTION) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (EXACT) {
+                    m[c][0] = ((B.c[c].x + C.c[c].x) * 4.f) * (1.f / 64.f); m[c][1] = ((B.c[c].y + C.c[c].y) * 4.f) * (1.f / 64.f);
+                    m[c][2] = ((B.c[c].z + C.c[c].z) * 4.f) * (1.f / 64.f); m[c][3] = ((B.c[c].w + C.c[c].w) * 4.f) * (1.f / 64.f);
+                } else {
+                    m[c][0] = B.c[c].x + C.c[c].x; m[c][1] = B.c[c].y + C.c[c].y; m[c][2] = B.c[c].z + C.c[c].z; m[c][3] = B.c[c].w + C.c[c].w;
+                }
+            }
+        }
+        emit(po, m, 1.f / 16.f);
+        ++gy; ++j;
+        return more;
+    };
+    Row3 r0{}, r1{}, r2{};
+    if (MOTION) { r0 = hrow(j - 1); r1 = hrow(j); r2 = hrow(j + 1); }
+    while (true) {
+        if (!step(r0, r1, r2)) break;
+        if (!step(r1, r2, r0)) break;
+        if (!step(r2, r0, r1)) break;
+    }
+}
+template <bool MOTION, bool DBG, int FL>
+__global__ LVM_FIN_BOUNDS void k_lap_final_v4(FinArgs q) {
     __shared__ __attribute__((aligned(16))) float s_igt[4096];
     __shared__ float s_gam[fl_lut(FL) ? 1 : 256];
     {
-        const float4* src = reinterpret_cast<const float4*>(lab.invgamma);
+        const float4* src = reinterpret_cast<const float4*>(q.lab.invgamma);
         for (int i = threadIdx.x; i < 1024; i += FIN_THREADS) reinterpret_cast<float4*>(s_igt)[i] = src[i];
-        if (!fl_lut(FL) && threadIdx.x < 256) s_gam[threadIdx.x] = lab.gamma_u8[threadIdx.x];
+        if (!fl_lut(FL) && threadIdx.x < 256) s_gam[threadIdx.x] = q.lab.gamma_u8[threadIdx.x];
     }
     __syncthreads();
     constexpr int WAVES = FIN_THREADS / 64;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int ntasks = strips_x * strips_y * nstreams;
+    const int ntasks = q.strips_x * q.strips_y * q.nstreams;
     // (strip groups handed out round-robin: a contiguous run per workgroup in XCD-aware order -- the next group is the row of
     // strips below, whose first cur_1 rows the CU has just read -- measured 194-203 -> 222-226 us per 32 frames)
-    for (int task = blockIdx.x * WAVES + wave; task < ntasks; task += gridDim.x * WAVES) {
-        const int b = task / (strips_x * strips_y);
-        const int r = task - b * (strips_x * strips_y);
-        const int ty = r / strips_x, tx = r - ty * strips_x;
-        const int gx = tx * 256 + 4 * lane, y0 = ty * rows;        // rows is even: y0 is even
-        if (gx >= w) continue;
-        // uniform (scalar) bases + 32-bit lane offsets
-        const uint8_t* src = in + (size_t)b * in_sstride;
-        const size_t poff = (size_t)b * w * h;
-        uint8_t* dst = out + (size_t)b * out_sstride;
-        const unsigned xoff = (unsigned)gx * 3u;
-        const float* pl = cur1 + (size_t)b * 3 * ((size_t)w1 * h1);
-        const int i0 = gx >> 1;
-        // byte offsets of the four taps.  Default flavour: the border rule is applied by the LOADS (column -1 reads column 1,
-        // column w1 reads column w1 - 1) and every lane runs the interior formulas -- s1 + 6 s0 + s1 = 6 s0 + 2 s1,
-        // s0 + 6 s1 + s1 = s0 + 7 s1, (s1 + s1) 4 = 8 s1: equal up to the rounding of one addition at the two border
-        // columns, 16 selects / border variants less per lane and source row.
-        const unsigned cm1 = 4u * (i0 > 0 ? i0 - 1 : (EXACT ? 0 : 1)), c00 = 4u * i0, cp1 = 4u * (i0 + 1 < w1 ? i0 + 1 : w1 - 1), cp2 = 4u * (i0 + 2 < w1 ? i0 + 2 : w1 - 1);
-        const size_t pstride = (size_t)w1 * h1;
-        // horizontal pass of source row sy (vertical border map: row -1 -> 1, row h1 -> h1 - 1); the row
-        // base is uniform, the four column offsets are per-lane byte offsets
-        auto hrow = [&](int sy) __attribute__((always_inline)) {
-            Row3 o;
-            sy = sy < 0 ? 1 : (sy >= h1 ? h1 - 1 : sy);
-            const char* row = reinterpret_cast<const char*>(pl + (size_t)sy * w1);
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const char* rc = row + c * pstride * sizeof(float);
-                const float sm1 = *reinterpret_cast<const float*>(rc + cm1), s0 = *reinterpret_cast<const float*>(rc + c00),
-                            s1 = *reinterpret_cast<const float*>(rc + cp1), s2 = *reinterpret_cast<const float*>(rc + cp2);
-                if (EXACT) o.c[c] = pyrup_h4(sm1, s0, s1, s2, i0, w1);
-                else if (LVM_FAST_FMA) {   // one rounding less per even column (fma), a few 1e-8 of the motion image
-                    o.c[c].x = __builtin_fmaf(s0, 6.f, sm1 + s1); o.c[c].y = (s0 + s1) * 4.f; o.c[c].z = __builtin_fmaf(s1, 6.f, s0 + s2); o.c[c].w = (s1 + s2) * 4.f;
-                } else { o.c[c].x = sm1 + s0 * 6.f + s1; o.c[c].y = (s0 + s1) * 4.f; o.c[c].z = s0 + s1 * 6.f + s2; o.c[c].w = (s1 + s2) * 4.f; }
-            }
-            return o;
-        };
-        const int yend = (y0 + rows < h) ? y0 + rows : h;
-        int gy = y0, j = y0 >> 1;
-        // one output row: colour math of 4 pixels; m = the motion image of the row (EXACT: scaled by 1/64 as
-        // pyrUp does; otherwise the unscaled vertical sum, whose power-of-two scale `msc` is folded into the
-        // add -- fma(m, 2^-k, L) rounds exactly like L + m * 2^-k)
-        auto emit = [&](const Raw4 pin, const float (&m)[3][4], const float msc) __attribute__((always_inline)) {
-            float L4[4], a4[4], b4[4];
-            raw4_to_lab<FL>(pin, s_gam, lab, L4, a4, b4);
-            float ov[12];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float o0, o1, o2;
-                float L = L4[k], a = a4[k], bb = b4[k];
-                if (MOTION) {
-                    if (EXACT) { L = L + m[0][k]; a = a + m[1][k] * ca; bb = bb + m[2][k] * ca; }
-                    else {
-                        L = __builtin_fmaf(m[0][k], msc, L);
-                        a = __builtin_fmaf(m[1][k], msc * ca, a); bb = __builtin_fmaf(m[2][k], msc * ca, bb);
-                    }
-                }
-                lab_to_bgr<EXACT>(L, a, bb, EXACT ? lab.inv : lab.inv1024, s_igt, o0, o1, o2);
-                if (DBG && dbg && b == 0) { float* d = dbg + ((size_t)gy * w + gx + k) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
-                if (EXACT) {
-                    ov[3 * k] = o0 * 255.0f + lab.a255; ov[3 * k + 1] = o1 * 255.0f + lab.a255; ov[3 * k + 2] = o2 * 255.0f + lab.a255;
-                } else {   // fma(o, 255, 1/255) differs from mul + add only far below the rounding step
-                    ov[3 * k] = __builtin_fmaf(o0, 255.0f, lab.a255); ov[3 * k + 1] = __builtin_fmaf(o1, 255.0f, lab.a255);
-                    ov[3 * k + 2] = __builtin_fmaf(o2, 255.0f, lab.a255);
-                }
-            }
-            Px4 qo;
-            qo.a = pack_u8x4(ov[0], ov[1], ov[2], ov[3]);
-            qo.b = pack_u8x4(ov[4], ov[5], ov[6], ov[7]);
-            qo.c = pack_u8x4(ov[8], ov[9], ov[10], ov[11]);
-            *reinterpret_cast<Px4*>(dst + (size_t)gy * out_stride + xoff) = qo;
-        };
-        // two output rows (2j, 2j+1) from the window rows A = j-1, B = j, C = j+1; afterwards A holds row
-        // j+2, i.e. the window has rotated to (B, C, A).  Returns false when the strip is finished.
-        auto step = [&](Row3& A, const Row3& B, const Row3& C) __attribute__((always_inline)) {
-            const Raw4 pe = load_raw4<PLANES>(src, in_stride, lp, poff, w, gy, (unsigned)gx);
-            const bool has_odd = gy + 1 < yend;
-            Raw4 po = pe;
-            if (has_odd) po = load_raw4<PLANES>(src, in_stride, lp, poff, w, gy + 1, (unsigned)gx);
-            float m[3][4] = {};
-            if (MOTION) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float sc = EXACT ? (1.f / 64.f) : 1.f;           // (x * 1.f folds away)
-                    if (!EXACT && LVM_FAST_FMA) {
-                        m[c][0] = __builtin_fmaf(B.c[c].x, 6.f, A.c[c].x + C.c[c].x); m[c][1] = __builtin_fmaf(B.c[c].y, 6.f, A.c[c].y + C.c[c].y);
-                        m[c][2] = __builtin_fmaf(B.c[c].z, 6.f, A.c[c].z + C.c[c].z); m[c][3] = __builtin_fmaf(B.c[c].w, 6.f, A.c[c].w + C.c[c].w);
-                        continue;
-                    }
-                    m[c][0] = (A.c[c].x + B.c[c].x * 6.f + C.c[c].x) * sc; m[c][1] = (A.c[c].y + B.c[c].y * 6.f + C.c[c].y) * sc;
-                    m[c][2] = (A.c[c].z + B.c[c].z * 6.f + C.c[c].z) * sc; m[c][3] = (A.c[c].w + B.c[c].w * 6.f + C.c[c].w) * sc;
-                }
-            }
-            const bool more = gy + 2 < yend;
-            if (MOTION && more) A = hrow(j + 2);                 // in flight during the colour math of both rows
-            emit(pe, m, 1.f / 64.f);
-            ++gy;
-            if (!has_odd) return false;
-            if (MOTION) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (EXACT) {
-                        m[c][0] = ((B.c[c].x + C.c[c].x) * 4.f) * (1.f / 64.f); m[c][1] = ((B.c[c].y + C.c[c].y) * 4.f) * (1.f / 64.f);
-                        m[c][2] = ((B.c[c].z + C.c[c].z) * 4.f) * (1.f / 64.f); m[c][3] = ((B.c[c].w + C.c[c].w) * 4.f) * (1.f / 64.f);
-                    } else {
-                        m[c][0] = B.c[c].x + C.c[c].x; m[c][1] = B.c[c].y + C.c[c].y; m[c][2] = B.c[c].z + C.c[c].z; m[c][3] = B.c[c].w + C.c[c].w;
-                    }
-                }
-            }
-            emit(po, m, 1.f / 16.f);
-            ++gy; ++j;
-            return more;
-        };
-        Row3 r0{}, r1{}, r2{};
-        if (MOTION) { r0 = hrow(j - 1); r1 = hrow(j); r2 = hrow(j + 1); }
-        while (true) {
-            if (!step(r0, r1, r2)) break;
-            if (!step(r1, r2, r0)) break;
-            if (!step(r2, r0, r1)) break;
-        }
+    for (int task = blockIdx.x * WAVES + wave; task < ntasks; task += gridDim.x * WAVES)
+        lap_final_strip<MOTION, DBG, FL>(q, task, lane, s_igt, s_gam);
+}
+
+// ---- last kernel of chunk k + first kernel of chunk k + 1 in ONE launch (round 3) -----------------------------------
+// The first kernel of a batch (k_down0_lut_rows) is bound by the Lab table look-ups -- LDS, texture-address and VALU pipes,
+// hardly any HBM traffic -- the last one (k_lap_final_v4) by HBM.  Run one after the other they cost 8.0 + 6.2 us per 1080p
+// frame; on two streams the runtime serves the queues almost one after the other (profiles/r03_two_stream_overlap.txt).
+// Here both are the SAME launch on the same stream: one persistent 1024-thread workgroup per CU holds the (a, b) node table
+// (144 KB) AND the inverse-gamma spline (16 KB) -- 160 268 of the CU's 163 840 bytes of LDS -- and its 16 waves are split
+// between the two kinds of wave strips: the first `d0_waves` walk first-kernel strips of the NEXT chunk, the others
+// last-kernel strips of THIS chunk.  While some waves of a CU wait for the table, others stream: the pipes that idle in either
+// kernel alone are busy at once.  Outputs are disjoint per strip: identical frames.
+constexpr int FUS_THREADS = 1024;
+struct FusedArgs { FinArgs fin; D0LArgs d0; int n_fin, n_d0, d0_waves; };
+template <int FL>
+__global__ __launch_bounds__(FUS_THREADS) void k_lap_final_down0(FusedArgs q) {
+    __shared__ uint32_t s_ab[kLabAbWords];
+    __shared__ __attribute__((aligned(16))) float s_igt[4096];
+    for (int i = threadIdx.x; i < kLabAbWords; i += FUS_THREADS) s_ab[i] = q.d0.lut.ab[i];
+    {
+        const float4* src = reinterpret_cast<const float4*>(q.fin.lab.invgamma);
+        for (int i = threadIdx.x; i < 1024; i += FUS_THREADS) reinterpret_cast<float4*>(s_igt)[i] = src[i];
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    // static split: the first d0_waves waves of every workgroup walk the first-kernel strips of the NEXT chunk, the others the
+    // last-kernel strips of THIS chunk (a shared strip counter was tried first: 17 k same-address device-scope atomics per
+    // launch serialise at the memory side on this 8-XCD part -- 30 us per frame instead of 22)
+    if (wave < q.d0_waves) {
+        for (int t = blockIdx.x * q.d0_waves + wave; t < q.n_d0; t += gridDim.x * q.d0_waves) down0_lut_strip<FL>(q.d0, t, lane, s_ab);
+    } else {
+        const int nf = FUS_THREADS / 64 - q.d0_waves;
+        for (int t = blockIdx.x * nf + (wave - q.d0_waves); t < q.n_fin; t += gridDim.x * nf) lap_final_strip<true, false, FL>(q.fin, t, lane, s_igt, nullptr);
     }
 }
 
@@ -922,6 +967,8 @@ struct LaplaceState : ModeState {
     long up_rows_max_blocks = 1024;       // launches with fewer tiled workgroups than this use k_lap_up_rows (LVM_UP_ROWS_MAX_BLOCKS)
     bool d0_rows_on = true;               // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
     bool d0_fused = true;                 // table conversion fused into the first kernel on large launches (LVM_D0_FUSED=0: separate kernels)
+    int fuse_chunks = 0;                  // temporal batches: chunks whose last kernel shares a launch with the next chunk's first kernel (LVM_LAP_FUSE_CHUNKS; 0 / 1 = off)
+    int fuse_d0_waves = 10;               // ... waves of a workgroup that prefer first-kernel strips (LVM_LAP_FUSE_D0_WAVES, of 16)
     int d0_fused_grid = 0;                // persistent workgroups of the fused kernel (LVM_D0_FUSED_GRID; 0 = one per CU).  Fewer leave CUs to a second stream
     long d0_fused_waves = 0;              // ... = launches with at least this many strips (LVM_D0_FUSED_WAVES; 0 = one per resident wave)
     long d0_min_tasks = 4096;             // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
@@ -1003,6 +1050,8 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     if (const char* e = std::getenv("LVM_D0_FUSED")) st->d0_fused = std::atoi(e) != 0;
     if (const char* e = std::getenv("LVM_D0_FUSED_WAVES")) st->d0_fused_waves = std::atol(e);
     if (const char* e = std::getenv("LVM_D0_FUSED_GRID")) st->d0_fused_grid = std::atoi(e);
+    if (const char* e = std::getenv("LVM_LAP_FUSE_CHUNKS")) st->fuse_chunks = std::atoi(e);
+    if (const char* e = std::getenv("LVM_LAP_FUSE_D0_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= 15) st->fuse_d0_waves = v; }
     if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
     if (const char* e = std::getenv("LVM_LAP_CHUNKS")) st->chunks = std::atoi(e);
     if (const char* e = std::getenv("LVM_LAP_SPLIT")) st->split_levels = std::atoi(e);
@@ -1089,6 +1138,21 @@ static bool lap_split_now(const LaplaceState* st, const LapBufs& B, bool first) 
 // part: 0 = the whole stage; 1 = only the table conversion + first pyramid kernel (-> G_1 and the integer planes: bound by
 // the table look-ups, hardly touches HBM); 2 = only the rest (the pyrDown chain: bound by HBM).  Chunked batches run part 1
 // of the next chunk on the auxiliary stream under parts 2 + stage A of the current one.
+// arguments of k_down0_lut_rows for the frames of B (false: this launch does not take the fused first kernel)
+static bool lap_d0l_args(Ctx* c, LaplaceState* st, const FrameIO& io, const LapBufs& B, D0LArgs* out) {
+    const int NS = c->nstreams * B.nt, levels = st->levels;
+    const LabPlanes lp = lap_planes(c, io, B);
+    if (!(lp.iab && levels >= 2 && st->d0_fused && lap_vec4(io) && st->g[1].w % 2 == 0)) return false;
+    long dl_tasks = 0;
+    const long dl_waves = st->d0_fused_waves > 0 ? st->d0_fused_waves : (long)c->num_cus * (D0L_THREADS / 64);
+    const int dl_rows = down0_lut_rows_choice(st->g[1].w, st->g[1].h, NS, dl_waves, &dl_tasks);
+    if (dl_tasks <= 0) return false;
+    const LevelGeom& g1 = st->g[1];
+    const int sx = (g1.w + D0R_OUT - 1) / D0R_OUT, sy = (g1.h + dl_rows - 1) / dl_rows;
+    *out = D0LArgs{io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h, B.G[1], g1.w, g1.h, c->lab_lut, sx, sy, (int)dl_tasks, dl_rows, B.iL, B.iab};
+    return true;
+}
+
 static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, const LapBufs& B, bool first, hipStream_t s, int part = 0) {
     const int C = io.channels, levels = st->levels;
     const int NS = c->nstreams * B.nt;        // stateless kernels: a frame of the batch is just one more stream
@@ -1097,11 +1161,8 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     // every frame goes through OpenCV's forward table exactly once: here (this stage comes first for every frame)
     const LabPlanes lp = lap_planes(c, io, B);
     // large launches: conversion and first pyramid kernel in one pass (k_down0_lut_rows); LVM_D0_FUSED=0 keeps them apart
-    long dl_tasks = 0;
-    const long dl_waves = st->d0_fused_waves > 0 ? st->d0_fused_waves : (long)c->num_cus * (D0L_THREADS / 64);
-    const int dl_rows = (lp.iab && levels >= 2 && st->d0_fused && lap_vec4(io) && st->g[1].w % 2 == 0)
-                            ? down0_lut_rows_choice(st->g[1].w, st->g[1].h, NS, dl_waves, &dl_tasks) : 0;
-    const bool fused = dl_tasks > 0;
+    D0LArgs da{};
+    const bool fused = lap_d0l_args(c, st, io, B, &da);
     if (part != 2 && lp.iab && !fused) lab_lut_planes(c, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h, NS, B.iL, nullptr, B.iab, s);
     if (levels < 2) return;
     float** G = B.G;
@@ -1114,11 +1175,9 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     const int fl = lab_flavour(c);
     if (part == 2) {
     } else if (fused) {
-        const int sx = (g1.w + D0R_OUT - 1) / D0R_OUT, sy = (g1.h + dl_rows - 1) / dl_rows;
         auto kdl = fl == FL_LUT_EXACT ? k_down0_lut_rows<FL_LUT_EXACT> : k_down0_lut_rows<FL_LUT_FAST>;
         const int dl_grid = (st->d0_fused_grid > 0 && st->d0_fused_grid < c->num_cus) ? st->d0_fused_grid : c->num_cus;
-        LVM_LAUNCH(c, "lap_down0_lut", kdl, dim3((unsigned)dl_grid), dim3(D0L_THREADS), s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
-                   G[1], g1.w, g1.h, c->lab_lut, sx, sy, (int)dl_tasks, dl_rows, B.iL, B.iab);
+        LVM_LAUNCH(c, "lap_down0_lut", kdl, dim3((unsigned)dl_grid), dim3(D0L_THREADS), s, da);
     } else if (lap_vec4(io) && st->d0_rows_on && d0_tasks > 0) {
         auto kd0 = LVM_FL_PICK(fl, k_down0_rows, true);
         const dim3 gridr((unsigned)((d0_tasks + D0R_THREADS / 64 - 1) / (D0R_THREADS / 64)));
@@ -1187,7 +1246,10 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
 }
 
 // Stage A of a frame: the fused band/IIR/collapse steps of the levels below T and the final kernel.
-static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, const LapBufs& B, bool first, hipStream_t s) {
+// fin_out != nullptr: the last kernel is NOT launched; its strip arguments are returned instead (the caller fuses it with the
+// next chunk's first kernel).  Only asked for when lap_vec4(io), motion and no debug frame.
+static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, const LapBufs& B, bool first, hipStream_t s,
+                        FinArgs* fin_out = nullptr) {
     const int C = io.channels, levels = st->levels;
     const int NS = c->nstreams * B.nt;
     const dim3 blk(256);
@@ -1300,8 +1362,10 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         const long groups = ((long)sx * sy * NS + waves - 1) / waves;
         const long cap = st->fin_groups > 0 ? st->fin_groups : 1024;
         const dim3 grid4((unsigned)(groups < cap ? groups : cap)), blk4(FIN_THREADS);
-        LVM_LAUNCH(c, "lap_final", kf4, grid4, blk4, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
-                   (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, sx, sy, NS, rows, dbg, lp);
+        const FinArgs fa{io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out, (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1,
+                         c->lab, ca, sx, sy, NS, rows, dbg, lp};
+        if (fin_out) { *fin_out = fa; return; }
+        LVM_LAUNCH(c, "lap_final", kf4, grid4, blk4, s, fa);
     } else {
         LVM_LAUNCH(c, "lap_final", kf, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
                    (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1, c->lab, ca, tx, ty, NS, dbg, lp);
@@ -1354,6 +1418,56 @@ int laplace_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int n
     const int levels = st->levels;
     if (nt > st->tcap) { const int rc = laplace_reserve_frames(c, st, nt, s); if (rc != LVM_OK) return rc; }
     if (st->pending.valid) { const int rc = laplace_flush(c, s); if (rc != LVM_OK) return rc; }
+    // Fused schedule (LVM_LAP_FUSE_CHUNKS = n >= 2): the batch in n chunks on ONE stream; the last kernel of chunk k and the
+    // first kernel (table conversion + pyrDown) of chunk k + 1 are one launch (k_lap_final_down0).
+    {
+        constexpr int kMaxFuse = 16;
+        int n = st->fuse_chunks;
+        if (n > kMaxFuse) n = kMaxFuse;
+        if (n > nt / 4) n = nt / 4;                              // at least 4 frames per chunk
+        const bool ok = n >= 2 && io.channels == 3 && fl_lut(lab_flavour(c)) && lap_vec4(io) && levels >= 2 && !c->keep_float;
+        if (ok) {
+            const int per = ((nt + n - 1) / n + 3) & ~3;
+            struct Chunk { FrameIO io; float* G[kMaxLevels + 1]; float* cur[kMaxLevels + 1]; LapBufs B; D0LArgs d0; bool d0_ok; };
+            std::vector<Chunk> ch;
+            for (int f0 = 0; f0 < nt; f0 += per) {
+                ch.emplace_back();
+                Chunk& k = ch.back();
+                k.io = io;
+                k.io.d_in = io.d_in + (size_t)f0 * c->nstreams * io.in_sstride;
+                k.io.d_out = io.d_out + (size_t)f0 * c->nstreams * io.out_sstride;
+                for (int l = 1; l <= levels; ++l) k.G[l] = st->Gt[l] + (size_t)f0 * st->planes * st->g[l].n;
+                for (int l = 1; l < levels; ++l) k.cur[l] = st->curt[l] + (size_t)f0 * st->planes * st->g[l].n;
+            }
+            for (size_t q = 0; q < ch.size(); ++q) {             // (pointers into ch are taken only after it stopped growing)
+                Chunk& k = ch[q];
+                const int f0 = (int)q * per, m = nt - f0 < per ? nt - f0 : per;
+                k.B = LapBufs{k.G, k.cur, nullptr, m, true};
+                k.B.iL = st->iLt + (size_t)f0 * c->nstreams * st->g[0].n; k.B.iab = st->iabt + (size_t)f0 * c->nstreams * st->g[0].n;
+                k.d0_ok = lap_d0l_args(c, st, k.io, k.B, &k.d0);
+            }
+            bool all = true;
+            for (auto& k : ch) all = all && k.d0_ok;
+            if (all && ch.size() >= 2) {
+                lap_stage_b(c, st, p, ch[0].io, ch[0].B, false, s, 1);                   // first kernel of chunk 0 on its own
+                const int fl = lab_flavour(c);
+                for (size_t q = 0; q < ch.size(); ++q) {
+                    Chunk& k = ch[q];
+                    lap_stage_b(c, st, p, k.io, k.B, false, s, 2);
+                    if (q + 1 == ch.size()) { lap_stage_a(c, st, p, k.io, k.B, false, s); break; }
+                    FusedArgs fa{};
+                    lap_stage_a(c, st, p, k.io, k.B, false, s, &fa.fin);
+                    fa.d0 = ch[q + 1].d0;
+                    fa.n_fin = fa.fin.strips_x * fa.fin.strips_y * fa.fin.nstreams; fa.n_d0 = fa.d0.ntasks;
+                    fa.d0_waves = st->fuse_d0_waves;
+                    auto kfu = fl == FL_LUT_EXACT ? k_lap_final_down0<FL_LUT_EXACT> : k_lap_final_down0<FL_LUT_FAST>;
+                    LVM_LAUNCH(c, "lap_final_down0", kfu, dim3((unsigned)c->num_cus), dim3(FUS_THREADS), s, fa);
+                }
+                LVM_HIP_TRY(c, hipGetLastError());
+                return LVM_OK;
+            }
+        }
+    }
     // The batch is cut into chunks of consecutive frames.  The down sweeps (stage B: stateless, bound by the
     // Lab arithmetic) of all chunks run on the auxiliary stream, the up sweeps (stage A: the IIR kernels
     // of the coarse levels are a few hundred waves each and leave most of the chip idle) follow chunk by

@@ -389,7 +389,10 @@ __global__ __launch_bounds__(D0R_THREADS) void k_down0_rows(const uint8_t* __res
 // planes the output kernel needs for the pixels it OWNS (lanes 1 .. 62, source rows 2 oy0 .. 2 yend - 1: every pixel of
 // the frame exactly once).  Saves the 6 bytes per pixel k_down0_rows would read and one launch; the table keeps one
 // persistent 1024-thread workgroup per CU, whose 16 waves take strips round-robin.
-constexpr int D0L_THREADS = 1024;
+#ifndef LVM_D0L_THREADS
+#define LVM_D0L_THREADS 1024
+#endif
+constexpr int D0L_THREADS = LVM_D0L_THREADS;
 // strip height for `waves` resident waves (k_down0_rows: one wave per SIMD slot of its 256-thread workgroups)
 inline int down0_lut_rows_choice(int w1, int h1, long frames, long waves, long* tasks_out) {
     const long sx = (w1 + D0R_OUT - 1) / D0R_OUT;
@@ -403,95 +406,107 @@ inline int down0_lut_rows_choice(int w1, int h1, long frames, long waves, long* 
     *tasks_out = best_tasks;
     return best;
 }
+struct D0LArgs {
+    const uint8_t* in; long in_stride, in_sstride; int w, h;
+    float* G1; int w1, h1;
+    LabLut lut;
+    int strips_x, strips_y, ntasks, rows;
+    uint16_t* iLp; uint32_t* iabp;
+};
+// one wave strip (task) of the fused conversion + first pyramid kernel; s_ab = the (a, b) node table in LDS
 template <int FL>
-__global__ __launch_bounds__(D0L_THREADS) void k_down0_lut_rows(const uint8_t* __restrict__ in, long in_stride, long in_sstride,
-                                                                int w, int h, float* __restrict__ G1, int w1, int h1, LabLut lut,
-                                                                int strips_x, int strips_y, int ntasks, int rows,
-                                                                uint16_t* __restrict__ iLp, uint32_t* __restrict__ iabp) {
+__device__ __forceinline__ void down0_lut_strip(const D0LArgs& q, int task, int lane, const uint32_t* s_ab) {
     constexpr bool EXACT = fl_exact(FL);
-    __shared__ uint32_t s_ab[kLabAbWords];
-    for (int i = threadIdx.x; i < kLabAbWords; i += D0L_THREADS) s_ab[i] = lut.ab[i];
-    __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const uint8_t* __restrict__ in = q.in; const long in_stride = q.in_stride, in_sstride = q.in_sstride;
+    const int w = q.w, h = q.h, w1 = q.w1, h1 = q.h1, strips_x = q.strips_x, strips_y = q.strips_y, rows = q.rows;
+    float* __restrict__ G1 = q.G1; const LabLut lut = q.lut;
+    uint16_t* __restrict__ iLp = q.iLp; uint32_t* __restrict__ iabp = q.iabp;
     const int ngroups = w >> 2;                                    // w % 4 == 0
     const size_t plane = (size_t)w1 * h1;
-    for (int task = blockIdx.x * (D0L_THREADS / 64) + wave; task < ntasks; task += gridDim.x * (D0L_THREADS / 64)) {
-        const int b = task / (strips_x * strips_y);
-        const int r = task - b * (strips_x * strips_y);
-        const int ty = r / strips_x, tx = r - ty * strips_x;
-        const int g = tx * (D0R_OUT / 2) - 1 + lane;                    // source group of this lane
-        const bool left_mirror = g < 0, right_mirror = g >= ngroups;    // REFLECT_101 mirrors of the edge groups
-        const int gl = left_mirror ? 0 : (right_mirror ? ngroups - 1 : g);
-        const uint8_t* src = in + (size_t)b * in_sstride;
-        const int ox = 2 * g, oy0 = ty * rows;
-        const bool owner = lane >= 1 && lane <= 62 && g >= 0 && ox < w1;
-        const int yend = oy0 + rows < h1 ? oy0 + rows : h1;
-        const int own_lo = 2 * oy0, own_hi = 2 * yend < h ? 2 * yend : h;    // source rows whose planes this strip stores
-        uint16_t* pL = iLp + (size_t)b * w * h + 4u * (unsigned)gl;
-        uint32_t* pab = iabp + (size_t)b * w * h + 4u * (unsigned)gl;
-        struct __attribute__((packed, aligned(4))) P3 { uint32_t a, b, c; };
-        auto fetch = [&](int sy) __attribute__((always_inline)) {
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(src + (size_t)reflect101(sy, h) * in_stride + 12u * (unsigned)gl);
-            P3 v; v.a = __builtin_nontemporal_load(q); v.b = __builtin_nontemporal_load(q + 1); v.c = __builtin_nontemporal_load(q + 2);
-            return v;
-        };
-        // source row sy: conversion of the lane's 4 pixels, plane stores, the two horizontal pyrDown results per channel
-        auto hrow = [&](const P3 v, int sy, float (&ha)[3], float (&hb)[3]) __attribute__((always_inline)) {
-            const uint32_t pb[12] = {v.a & 255, (v.a >> 8) & 255, (v.a >> 16) & 255, v.a >> 24, v.b & 255, (v.b >> 8) & 255,
-                                     (v.b >> 16) & 255, v.b >> 24, v.c & 255, (v.c >> 8) & 255, (v.c >> 16) & 255, v.c >> 24};
-            int iL[4], ia[4], ib[4];
+    const int b = task / (strips_x * strips_y);
+    const int r = task - b * (strips_x * strips_y);
+    const int ty = r / strips_x, tx = r - ty * strips_x;
+    const int g = tx * (D0R_OUT / 2) - 1 + lane;                    // source group of this lane
+    const bool left_mirror = g < 0, right_mirror = g >= ngroups;    // REFLECT_101 mirrors of the edge groups
+    const int gl = left_mirror ? 0 : (right_mirror ? ngroups - 1 : g);
+    const uint8_t* src = in + (size_t)b * in_sstride;
+    const int ox = 2 * g, oy0 = ty * rows;
+    const bool owner = lane >= 1 && lane <= 62 && g >= 0 && ox < w1;
+    const int yend = oy0 + rows < h1 ? oy0 + rows : h1;
+    const int own_lo = 2 * oy0, own_hi = 2 * yend < h ? 2 * yend : h;    // source rows whose planes this strip stores
+    uint16_t* pL = iLp + (size_t)b * w * h + 4u * (unsigned)gl;
+    uint32_t* pab = iabp + (size_t)b * w * h + 4u * (unsigned)gl;
+    struct __attribute__((packed, aligned(4))) P3 { uint32_t a, b, c; };
+    auto fetch = [&](int sy) __attribute__((always_inline)) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(src + (size_t)reflect101(sy, h) * in_stride + 12u * (unsigned)gl);
+        P3 v; v.a = __builtin_nontemporal_load(q); v.b = __builtin_nontemporal_load(q + 1); v.c = __builtin_nontemporal_load(q + 2);
+        return v;
+    };
+    // source row sy: conversion of the lane's 4 pixels, plane stores, the two horizontal pyrDown results per channel
+    auto hrow = [&](const P3 v, int sy, float (&ha)[3], float (&hb)[3]) __attribute__((always_inline)) {
+        const uint32_t pb[12] = {v.a & 255, (v.a >> 8) & 255, (v.a >> 16) & 255, v.a >> 24, v.b & 255, (v.b >> 8) & 255,
+                                 (v.b >> 16) & 255, v.b >> 24, v.c & 255, (v.c >> 8) & 255, (v.c >> 16) & 255, v.c >> 24};
+        int iL[4], ia[4], ib[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) lut_lab_int(pb[3 * k], pb[3 * k + 1], pb[3 * k + 2], s_ab, lut.Lcells, iL[k], ia[k], ib[k]);
-            if (owner && sy >= own_lo && sy < own_hi) {
-                const size_t o = (size_t)sy * w;
-                uint32_t* dL = reinterpret_cast<uint32_t*>(pL + o);
-                __builtin_nontemporal_store((uint32_t)iL[0] | ((uint32_t)iL[1] << 16), dL);
-                __builtin_nontemporal_store((uint32_t)iL[2] | ((uint32_t)iL[3] << 16), dL + 1);
+        for (int k = 0; k < 4; ++k) lut_lab_int(pb[3 * k], pb[3 * k + 1], pb[3 * k + 2], s_ab, lut.Lcells, iL[k], ia[k], ib[k]);
+        if (owner && sy >= own_lo && sy < own_hi) {
+            const size_t o = (size_t)sy * w;
+            uint32_t* dL = reinterpret_cast<uint32_t*>(pL + o);
+            __builtin_nontemporal_store((uint32_t)iL[0] | ((uint32_t)iL[1] << 16), dL);
+            __builtin_nontemporal_store((uint32_t)iL[2] | ((uint32_t)iL[3] << 16), dL + 1);
 #pragma unroll
-                for (int k = 0; k < 4; ++k) __builtin_nontemporal_store((uint32_t)ia[k] | ((uint32_t)ib[k] << 16), pab + o + k);
+            for (int k = 0; k < 4; ++k) __builtin_nontemporal_store((uint32_t)ia[k] | ((uint32_t)ib[k] << 16), pab + o + k);
+        }
+        float P[3][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { P[0][k] = lut_L(iL[k]); P[1][k] = lut_ab(ia[k]); P[2][k] = lut_ab(ib[k]); }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float give2 = P[c][2], give3 = left_mirror ? P[c][1] : P[c][3], give0 = right_mirror ? P[c][2] : P[c][0];
+            const float L2 = dpp_shr1(give2), L3 = dpp_shr1(give3), R0 = dpp_shl1(give0);
+            if (!EXACT && LVM_FAST_FMA) {
+                ha[c] = __builtin_fmaf(P[c][0], 6.f, __builtin_fmaf(L3 + P[c][1], 4.f, L2 + P[c][2]));
+                hb[c] = __builtin_fmaf(P[c][2], 6.f, __builtin_fmaf(P[c][1] + P[c][3], 4.f, P[c][0] + R0));
+            } else {
+                ha[c] = P[c][0] * 6.f + (L3 + P[c][1]) * 4.f + L2 + P[c][2];
+                hb[c] = P[c][2] * 6.f + (P[c][1] + P[c][3]) * 4.f + P[c][0] + R0;
             }
-            float P[3][4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { P[0][k] = lut_L(iL[k]); P[1][k] = lut_ab(ia[k]); P[2][k] = lut_ab(ib[k]); }
+        }
+    };
+    float a0[3], a1[3], a2[3], a3[3], a4[3], b0[3], b1[3], b2[3], b3[3], b4[3];
+    hrow(fetch(2 * oy0 - 2), 2 * oy0 - 2, a0, b0); hrow(fetch(2 * oy0 - 1), 2 * oy0 - 1, a1, b1); hrow(fetch(2 * oy0), 2 * oy0, a2, b2);
+    float* dst = G1 + (size_t)b * 3 * plane;
+    P3 n3 = fetch(2 * oy0 + 1), n4 = fetch(2 * oy0 + 2);
+    for (int oy = oy0; oy < yend; ++oy) {
+        const P3 c3 = n3, c4 = n4;
+        if (oy + 1 < yend) { n3 = fetch(2 * oy + 3); n4 = fetch(2 * oy + 4); }
+        hrow(c3, 2 * oy + 1, a3, b3); hrow(c4, 2 * oy + 2, a4, b4);
+        if (owner) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float give2 = P[c][2], give3 = left_mirror ? P[c][1] : P[c][3], give0 = right_mirror ? P[c][2] : P[c][0];
-                const float L2 = dpp_shr1(give2), L3 = dpp_shr1(give3), R0 = dpp_shl1(give0);
+                float va, vb;
                 if (!EXACT && LVM_FAST_FMA) {
-                    ha[c] = __builtin_fmaf(P[c][0], 6.f, __builtin_fmaf(L3 + P[c][1], 4.f, L2 + P[c][2]));
-                    hb[c] = __builtin_fmaf(P[c][2], 6.f, __builtin_fmaf(P[c][1] + P[c][3], 4.f, P[c][0] + R0));
+                    va = __builtin_fmaf(a2[c], 6.f, __builtin_fmaf(a1[c] + a3[c], 4.f, a0[c] + a4[c])) * (1.f / 256.f);
+                    vb = __builtin_fmaf(b2[c], 6.f, __builtin_fmaf(b1[c] + b3[c], 4.f, b0[c] + b4[c])) * (1.f / 256.f);
                 } else {
-                    ha[c] = P[c][0] * 6.f + (L3 + P[c][1]) * 4.f + L2 + P[c][2];
-                    hb[c] = P[c][2] * 6.f + (P[c][1] + P[c][3]) * 4.f + P[c][0] + R0;
+                    va = (a2[c] * 6.f + (a1[c] + a3[c]) * 4.f + a0[c] + a4[c]) * (1.f / 256.f);
+                    vb = (b2[c] * 6.f + (b1[c] + b3[c]) * 4.f + b0[c] + b4[c]) * (1.f / 256.f);
                 }
+                *reinterpret_cast<float2*>(dst + c * plane + (size_t)oy * w1 + ox) = make_float2(va, vb);
             }
-        };
-        float a0[3], a1[3], a2[3], a3[3], a4[3], b0[3], b1[3], b2[3], b3[3], b4[3];
-        hrow(fetch(2 * oy0 - 2), 2 * oy0 - 2, a0, b0); hrow(fetch(2 * oy0 - 1), 2 * oy0 - 1, a1, b1); hrow(fetch(2 * oy0), 2 * oy0, a2, b2);
-        float* dst = G1 + (size_t)b * 3 * plane;
-        P3 n3 = fetch(2 * oy0 + 1), n4 = fetch(2 * oy0 + 2);
-        for (int oy = oy0; oy < yend; ++oy) {
-            const P3 c3 = n3, c4 = n4;
-            if (oy + 1 < yend) { n3 = fetch(2 * oy + 3); n4 = fetch(2 * oy + 4); }
-            hrow(c3, 2 * oy + 1, a3, b3); hrow(c4, 2 * oy + 2, a4, b4);
-            if (owner) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float va, vb;
-                    if (!EXACT && LVM_FAST_FMA) {
-                        va = __builtin_fmaf(a2[c], 6.f, __builtin_fmaf(a1[c] + a3[c], 4.f, a0[c] + a4[c])) * (1.f / 256.f);
-                        vb = __builtin_fmaf(b2[c], 6.f, __builtin_fmaf(b1[c] + b3[c], 4.f, b0[c] + b4[c])) * (1.f / 256.f);
-                    } else {
-                        va = (a2[c] * 6.f + (a1[c] + a3[c]) * 4.f + a0[c] + a4[c]) * (1.f / 256.f);
-                        vb = (b2[c] * 6.f + (b1[c] + b3[c]) * 4.f + b0[c] + b4[c]) * (1.f / 256.f);
-                    }
-                    *reinterpret_cast<float2*>(dst + c * plane + (size_t)oy * w1 + ox) = make_float2(va, vb);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { a0[c] = a2[c]; a1[c] = a3[c]; a2[c] = a4[c]; b0[c] = b2[c]; b1[c] = b3[c]; b2[c] = b4[c]; }
         }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { a0[c] = a2[c]; a1[c] = a3[c]; a2[c] = a4[c]; b0[c] = b2[c]; b1[c] = b3[c]; b2[c] = b4[c]; }
     }
+}
+template <int FL>
+__global__ __launch_bounds__(D0L_THREADS) void k_down0_lut_rows(D0LArgs q) {
+    __shared__ uint32_t s_ab[kLabAbWords];
+    for (int i = threadIdx.x; i < kLabAbWords; i += D0L_THREADS) s_ab[i] = q.lut.ab[i];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    for (int task = blockIdx.x * (D0L_THREADS / 64) + wave; task < q.ntasks; task += gridDim.x * (D0L_THREADS / 64))
+        down0_lut_strip<FL>(q, task, lane, s_ab);
 }
 
 // ---- pyrDown of large float planes: wave strips, no LDS ---------------------------------------------

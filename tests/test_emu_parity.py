@@ -264,6 +264,16 @@ def test_emu_chunked_batches(lvm, po, emu, chunks, fused, monkeypatch):
     _frames_clip(lvm, po, emu, 0, 264, 90, 3, 1, (1, 12, 9))
 
 
+@pytest.mark.parametrize("chunks,d0_waves,ns", [("2", "10", 1), ("3", "1", 1), ("2", "15", 2)])
+def test_emu_last_kernel_fused_with_next_first_kernel(lvm, po, emu, chunks, d0_waves, ns, monkeypatch):
+    """LVM_LAP_FUSE_CHUNKS: the last kernel of chunk k and the table conversion + first kernel of chunk k + 1 as ONE launch
+    whose waves are split between the two kinds of strips (k_lap_final_down0), incl. the extreme splits 1 : 15 and 15 : 1."""
+    monkeypatch.setenv("LVM_LAP_FUSE_CHUNKS", chunks)
+    monkeypatch.setenv("LVM_LAP_FUSE_D0_WAVES", d0_waves)
+    monkeypatch.setenv("LVM_D0_FUSED_WAVES", "1")
+    _frames_clip(lvm, po, emu, 0, 264, 90, 3, ns, (1, 12, 9, 5))
+
+
 def test_emu_fused_conversion_in_batches_two_streams(lvm, po, emu, monkeypatch):
     monkeypatch.setenv("LVM_D0_FUSED_WAVES", "1")
     _frames_clip(lvm, po, emu, 0, 264, 90, 3, 2, (1, 5, 4))
