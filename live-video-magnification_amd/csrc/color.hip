@@ -608,13 +608,17 @@ __global__ __launch_bounds__(256) void k_col_out_rows(OutArgs a, int strips_x, i
             const int yend = y0 + rows < a.h ? y0 + rows : a.h;
             int js = (a.yofs[y0] - 1) >> 1;
             HRow3 A = hrow(js), B = hrow(js + 1), C = hrow(js + 2);
+            // the input pixels of the NEXT row are fetched before the current row's arithmetic (the Laplace first kernel's fix
+            // for the same per-row dependent load): a wave keeps a row of loads in flight
+            Px4 pnext = *reinterpret_cast<const Px4*>(src + (size_t)y0 * a.in_stride + xoff);
             for (int gy = y0; gy < yend; ++gy) {
                 const int sy0 = a.yofs[gy];
                 const float b1 = a.ya[gy], b0 = 1.f - b1;
                 const bool clamp1 = sy0 + 1 > uh - 1;                // sy1 = sy0 (last row)
                 const int jn = (sy0 - 1) >> 1;
+                const Px4 pin = pnext;
+                if (gy + 1 < yend) pnext = *reinterpret_cast<const Px4*>(src + (size_t)(gy + 1) * a.in_stride + xoff);
                 while (js < jn) { A = B; B = C; C = hrow(js + 3); ++js; }
-                const Px4 pin = *reinterpret_cast<const Px4*>(src + (size_t)gy * a.in_stride + xoff);
                 float val[3][4];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
