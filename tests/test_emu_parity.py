@@ -20,6 +20,16 @@ def test_laplace_emu_bit_exact(lvm, po, emu, w, h, levels, ch):
     run_pair(lvm, po, emu, clip, pk, 6, 0.0, exact=True)
 
 
+@pytest.mark.parametrize("idx,w,h,levels", [(0, 135, 77, 4), (0, 328, 109, 3), (2, 135, 77, 3), (2, 264, 150, 3)])
+def test_analytic_flavour_emu_bit_exact(lvm, po, emu, idx, w, h, levels, monkeypatch):
+    """lvm_debug_lab_analytic: the cube-root forward Lab (OpenCV with its interpolation switched off) in the kernels that
+    convert from the u8 frame themselves, against the oracle with lvmo_set_lab_lut(0); scalar and 4-pixel variants, strip
+    first kernel forced on."""
+    monkeypatch.setenv("LVM_D0_MIN_TASKS", "0")
+    ck, pk = lvm.synth.config(idx, (w, h, levels))
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 5, 0.0, exact=True, analytic=True)
+
+
 def test_laplace_emu_param_changes_and_reset(lvm, po, emu):
     ck, pk = lvm.synth.config(0, (96, 64, 3))
     clip = lvm.synth.Clip(**ck)

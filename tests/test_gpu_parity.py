@@ -435,3 +435,22 @@ def test_color_temporal_batches_device(lvm, po, hip):
                     assert du.max() <= 1 and (du == 0).mean() >= 0.999, (t + f, s_, du.max(), (du == 0).mean())
         t += nf
     ctx.close()
+
+
+@pytest.mark.parametrize("idx,size", [(0, (640, 360, 4)), (2, (320, 180, 4)), (0, (323, 211, 5))])
+def test_analytic_flavour_on_the_gpu(lvm, po, hip, idx, size):
+    """lvm_debug_lab_analytic (OpenCV with its Lab interpolation switched off; implies OpenCV's operation order) against the
+    oracle in the same mode, at the usual bars."""
+    ck, pk = lvm.synth.config(idx, size)
+    worst = run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 12, FLOAT_TOL, analytic=True)
+    print("analytic flavour", idx, size, worst)
+
+
+def test_lab_table_of_the_gpu_library_equals_the_oracles(lvm, po, hip):
+    t = np.empty(33 * 33 * 33 * 3, np.int16)
+    po.lib().lvmo_lab_lut_table(t.ctypes.data)
+    ctx = lvm.Context(0, 1, hip)
+    try:
+        assert np.array_equal(ctx.lab_lut(), t)
+    finally:
+        ctx.close()
