@@ -397,7 +397,7 @@ constexpr int D0L_THREADS = LVM_D0L_THREADS;
 inline int down0_lut_rows_choice(int w1, int h1, long frames, long waves, long* tasks_out) {
     const long sx = (w1 + D0R_OUT - 1) / D0R_OUT;
     int best = 8; long best_cost = -1, best_tasks = 0;
-    for (int r = 6; r <= 32; ++r) {
+    for (int r = 6; r <= 48; ++r) {
         const long tasks = sx * ((h1 + r - 1) / r) * frames;
         if (tasks * 5 < waves * 3) continue;                    // at least 60 % of the resident waves get a strip
         const long cost = ((tasks + waves - 1) / waves) * (2 * r + 3);

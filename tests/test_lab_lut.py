@@ -79,3 +79,69 @@ def test_set_lab_lut_round_trip(lvm, po, emu):
         run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 3, 0.0, exact=True, lab_lut=t2)
     finally:
         po.lib().lvmo_lab_lut_override(None)
+
+
+def _numpy_table():
+    """initLabTabs' interpolation table restated a THIRD time, in numpy binary32 arithmetic (independent of the two C / C++
+    builders apart from cv::cubeRoot, taken from the oracle)."""
+    f32 = np.float32
+    M = np.array([[0.412453, 0.357580, 0.180423], [0.212671, 0.715160, 0.072169], [0.019334, 0.119193, 0.950227]], np.float64)
+    D65 = np.array([0.950456, 1.0, 1.088754], np.float64)
+    C = (M * np.array([1.0 / D65[0], 1.0, 1.0 / D65[2]])[:, None]).astype(f32)
+    g = np.arange(33, dtype=f32) / f32(32)
+    thr, low, shift, power = f32(809) / f32(20000), f32(323) / f32(25), f32(11) / f32(200), f32(12) / f32(5)
+    base = ((g + shift) / (f32(1) + shift)).astype(f32)
+    with np.errstate(divide="ignore"):
+        lg = np.log(base.astype(np.float64)).astype(f32)
+    hi = np.exp((power * lg).astype(f32).astype(np.float64)).astype(f32)
+    gam = np.where(g <= thr, (g / low).astype(f32), hi).astype(f32)
+    R, G, B = gam[None, None, :], gam[None, :, None], gam[:, None, None]          # [r][q][p]: p = R fastest
+    def lin(c):
+        return ((R * c[0]).astype(f32) + (G * c[1]).astype(f32)).astype(f32) + (B * c[2]).astype(f32)
+    X, Y, Z = (lin(C[i]).astype(f32) for i in range(3))
+    return X, Y, Z
+
+
+def test_table_against_a_numpy_restatement(po):
+    """Same formulas, third implementation (numpy float32, vectorised): every entry equal to the oracle's table."""
+    f32 = np.float32
+    X, Y, Z = _numpy_table()
+    lth, lsc, lb = f32(216) / f32(24389), f32(841) / f32(108), f32(16) / f32(116)
+    cbrt = np.vectorize(lambda v: po.lib().lvmo_cube_root(float(v)), otypes=[np.float32])
+    def f(t):
+        lin = (t.astype(np.float64) * np.float64(lsc) + np.float64(lb)).astype(f32)     # fma: one rounding (exact product in float64)
+        return np.where(t > lth, cbrt(t), lin).astype(f32)
+    FX, FY, FZ = f(X), f(Y), f(Z)
+    L = np.where(Y > lth, (f32(116) * FY).astype(f32) - f32(16), (Y * (f32(24389) / f32(27))).astype(f32)).astype(f32)
+    a = (f32(500) * (FX - FY).astype(f32)).astype(f32)
+    b = (f32(200) * (FY - FZ).astype(f32)).astype(f32)
+    tL = np.rint(((f32(16384) * L).astype(f32) / f32(100)).astype(f32)).astype(np.int64)
+    ta = np.rint(((f32(16384) * (a + f32(128)).astype(f32)).astype(f32) / f32(256)).astype(f32)).astype(np.int64)
+    tb = np.rint(((f32(16384) * (b + f32(128)).astype(f32)).astype(f32) / f32(256)).astype(f32)).astype(np.int64)
+    t = _oracle_table(po).reshape(33, 33, 33, 3).astype(np.int64)
+    assert np.array_equal(tL, t[..., 0]) and np.array_equal(ta, t[..., 1]) and np.array_equal(tb, t[..., 2])
+
+
+def test_trilinear_interpolation_against_a_numpy_restatement(po):
+    """trilinearInterpolate + the float scaling restated in vectorised numpy integer arithmetic on the oracle's table:
+    bit-equal to lvmo_bgr2lab on 20 000 random u8 colours plus the corners of the cube."""
+    rng = np.random.default_rng(11)
+    u = rng.integers(0, 256, size=(20000, 3))
+    u = np.concatenate([u, np.array([[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [254, 255, 1]])])
+    s = (u.astype(np.float32) * np.float32(1.0 / np.float32(255.0))).astype(np.float32)       # B, G, R in [0, 1]
+    c = np.rint(s * np.float32(16384)).astype(np.int64)[:, ::-1]                               # -> (R, G, B) at 1/16384
+    t = _oracle_table(po).reshape(33, 33, 33, 3).astype(np.int64)                              # [r][q][p][ch]
+    cell, w1 = c >> 9, (c >> 5) & 15
+    acc = np.zeros((len(u), 3), np.int64)
+    for dp in (0, 1):
+        for dq in (0, 1):
+            for dr in (0, 1):
+                p = np.minimum(cell[:, 0] + dp, 32); q = np.minimum(cell[:, 1] + dq, 32); r = np.minimum(cell[:, 2] + dr, 32)
+                wgt = (w1[:, 0] if dp else 16 - w1[:, 0]) * (w1[:, 1] if dq else 16 - w1[:, 1]) * (w1[:, 2] if dr else 16 - w1[:, 2])
+                acc += t[r, q, p] * wgt[:, None]
+    acc = (acc + 2048) >> 12
+    want = np.stack([acc[:, 0].astype(np.float32) * np.float32(1.0 / 16384) * np.float32(100),
+                     acc[:, 1].astype(np.float32) * np.float32(1.0 / 16384) * np.float32(256) - np.float32(128),
+                     acc[:, 2].astype(np.float32) * np.float32(1.0 / 16384) * np.float32(256) - np.float32(128)], -1).astype(np.float32)
+    got = po.bgr2lab(s.reshape(-1, 1, 3)).reshape(-1, 3)
+    assert np.array_equal(got, want)
