@@ -1071,20 +1071,31 @@ __global__ __launch_bounds__(BS_THREADS) void k_rz_blur_strips(BlurStripArgs aa)
     const char* pamp = reinterpret_cast<const char*>(a.amp + pl);
     const char* ptc = reinterpret_cast<const char*>(a.tc + pl);
     const char* pts = reinterpret_cast<const char*>(a.ts + pl);
+    const char* pband = reinterpret_cast<const char*>(a.band + pl);
     const int y0 = ty * a.rows, yend = y0 + a.rows < h ? y0 + a.rows : h;
     const int nin = yend - y0 + 12;                                    // input rows y0 - 6 .. yend + 5
     float H[3][13][2];
     // the lane's raw values of one input row (two columns of amp / c / s); fetched one row AHEAD of their use, so that a
     // wave has a row of loads in flight while it filters the previous one
-    struct Raw6 { float v[6]; };
+    // ... plus the two columns of band row y0 - 10 + i: the amplify step's Riesz pair (5-tap horizontal / vertical filters of
+    // the band, RieszPyramid.cpp:71; what k_rz_phase computes and used to store per frame) is RECOMPUTED here from a 5-row
+    // window of the band -- 8 bytes per pixel less to write in the phase kernel and 8 less to read here, both of which run
+    // at the bandwidth ceiling.  Same fma chains: identical bits.
+    struct Raw6 { float v[8]; };
     auto fetch = [&](int i) __attribute__((always_inline)) {
         const size_t ro = (size_t)reflect101(y0 - 6 + i, h) * w * sizeof(float);
         Raw6 r;
         r.v[0] = *reinterpret_cast<const float*>(pamp + ro + o0); r.v[1] = *reinterpret_cast<const float*>(pamp + ro + o1);
         r.v[2] = *reinterpret_cast<const float*>(ptc + ro + o0); r.v[3] = *reinterpret_cast<const float*>(ptc + ro + o1);
         r.v[4] = *reinterpret_cast<const float*>(pts + ro + o0); r.v[5] = *reinterpret_cast<const float*>(pts + ro + o1);
+        r.v[6] = r.v[7] = 0.f;
+        if (i >= 8) {                                                  // band rows y0 - 2 .. yend + 1 (wave-uniform)
+            const size_t rb = (size_t)reflect101(y0 - 10 + i, h) * w * sizeof(float);
+            r.v[6] = *reinterpret_cast<const float*>(pband + rb + o0); r.v[7] = *reinterpret_cast<const float*>(pband + rb + o1);
+        }
         return r;
     };
+    float bw[5][2] = {};                                               // band rows y - 2 .. y + 2 of the output row being completed
     // row-filtered pair of one plane from the lane's two values
     auto hpass = [&](const float v0, const float v1, float (&out)[2]) __attribute__((always_inline)) {
         const float l1a = dpp_shr1(v0), l1b = dpp_shr1(v1), l2a = dpp_shr1(l1a), l2b = dpp_shr1(l1b), l3a = dpp_shr1(l2a), l3b = dpp_shr1(l2b);
@@ -1106,14 +1117,11 @@ __global__ __launch_bounds__(BS_THREADS) void k_rz_blur_strips(BlurStripArgs aa)
             if (i >= nin) continue;                                    // (wave-uniform; `continue` keeps the phase loop unrollable)
             const Raw6 cur = nxt;
             if (i + 1 < nin) nxt = fetch(i + 1);
-            // the amplify operands of the output row this step completes are fetched before the filter arithmetic
             const int y = y0 + i - 12;                                 // window: row y - 6 + k sits in slot (ph + 1 + k) % 13
-            float2 bd = make_float2(0.f, 0.f), q1 = bd, q2 = bd;
-            const size_t idx = pl + (size_t)(y > 0 ? y : 0) * w + (owner ? c0 : 0);
-            if (i >= 12 && owner) {
-                bd = *reinterpret_cast<const float2*>(a.band + idx); q1 = *reinterpret_cast<const float2*>(a.R1 + idx);
-                q2 = *reinterpret_cast<const float2*>(a.R2 + idx);
-            }
+            // band window: rows y - 2 .. y + 2 (the row fetched for this step is y + 2)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { bw[k][0] = bw[k + 1][0]; bw[k][1] = bw[k + 1][1]; }
+            bw[4][0] = cur.v[6]; bw[4][1] = cur.v[7];
             hpass(cur.v[0], cur.v[1], H[0][ph]); hpass(cur.v[2], cur.v[3], H[1][ph]); hpass(cur.v[4], cur.v[5], H[2][ph]);
             if (i >= 12) {
                 float v[3][2];
@@ -1126,7 +1134,20 @@ __global__ __launch_bounds__(BS_THREADS) void k_rz_blur_strips(BlurStripArgs aa)
                         for (int j = 1; j <= 6; ++j) acc = __builtin_fmaf(aa.g[6 + j], H[f][(ph + 7 + j) % 13][m] + H[f][(ph + 7 - j + 13) % 13][m], acc);
                         v[f][m] = acc;
                     }
+                // Riesz pair of the band at the lane's two columns: [-0.2 -0.48 0 0.48 0.2] along the row (neighbour columns from
+                // the adjacent lanes) and along the column (the window); every lane takes part in the DPP exchange
+                float2 bd, q1, q2;
+                {
+                    const float c0v = bw[2][0], c1v = bw[2][1];
+                    const float lm2 = dpp_shr1(c0v), lm1 = dpp_shr1(c1v), rp2 = dpp_shl1(c0v), rp3 = dpp_shl1(c1v);   // columns c0-2, c0-1, c0+2, c0+3
+                    bd.x = c0v; bd.y = c1v;
+                    q1.x = __builtin_fmaf(0.2f, rp2, __builtin_fmaf(0.48f, c1v, __builtin_fmaf(-0.48f, lm1, __builtin_fmaf(-0.2f, lm2, 0.f))));
+                    q1.y = __builtin_fmaf(0.2f, rp3, __builtin_fmaf(0.48f, rp2, __builtin_fmaf(-0.48f, c0v, __builtin_fmaf(-0.2f, lm1, 0.f))));
+                    q2.x = __builtin_fmaf(0.2f, bw[4][0], __builtin_fmaf(0.48f, bw[3][0], __builtin_fmaf(-0.48f, bw[1][0], __builtin_fmaf(-0.2f, bw[0][0], 0.f))));
+                    q2.y = __builtin_fmaf(0.2f, bw[4][1], __builtin_fmaf(0.48f, bw[3][1], __builtin_fmaf(-0.48f, bw[1][1], __builtin_fmaf(-0.2f, bw[0][1], 0.f))));
+                }
                 if (owner) {
+                    const size_t idx = pl + (size_t)y * w + c0;
                     float2 o;
                     if (EXACT) {      // the libm sine / cosine of the exact flavour is large: out of line, or the 13-phase loop does not unroll
                         o.x = rz_amplify_exact_call(v[0][0], v[1][0], v[2][0], q1.x, q2.x, bd.x, aa.alpha, aa.thr);
@@ -1313,6 +1334,8 @@ static void riesz_coeffs(double frq, double fps, double a[3], double b[3]) {   /
 
 // One buffer set = where the per-frame arrays of nt frames live ([frame][stream] planes).
 struct RzBufs { float** oct; float** res; float* (*pf)[F_ALL_N]; int nt; uint32_t* iab; };
+struct RieszState;
+static bool rz_level_uses_strips(const RieszState* st, int l, int NZ);
 
 // pyramid of the nt frames: L plane + 9x9 split chain
 static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B, hipStream_t s) {
@@ -1384,6 +1407,8 @@ static void rz_phase(Ctx* c, RieszState* st, const RzBufs& B, int mode, hipStrea
         v.lo0c = f[F_LO0C]; v.lo0s = f[F_LO0S]; v.lo1c = f[F_LO1C]; v.lo1s = f[F_LO1S];
         v.hi0c = f[F_HI0C]; v.hi0s = f[F_HI0S]; v.hi1c = f[F_HI1C]; v.hi1s = f[F_HI1S];
         v.amp = q[F_AMP]; v.tc = q[F_TC]; v.ts = q[F_TS]; v.R1c = q[F_R1C]; v.R2c = q[F_R2C];
+        // the strip form of the amplify stage recomputes the Riesz pair from the band: no per-frame copy for its levels
+        if (rz_level_uses_strips(st, l, NS * B.nt)) { v.R1c = v.R1p; v.R2c = v.R2p; }
         v.w = st->g[l].w; v.h = st->g[l].h;
         v.tx = (v.w + (vec ? P4_W : PT_W) - 1) / (vec ? P4_W : PT_W); v.ty = (v.h + (vec ? P4_H : PT_H) - 1) / (vec ? P4_H : PT_H);
         v.block0 = vec ? blocks4 : blocks;
@@ -1393,6 +1418,10 @@ static void rz_phase(Ctx* c, RieszState* st, const RzBufs& B, int mode, hipStrea
     a.nlv = n1; a4.nlv = n4;
     if (n4) LVM_LAUNCH(c, mode ? "rz_seed" : "rz_phase", (lab_flavour(c) != FL_LUT_FAST) ? k_rz_phase4<true> : k_rz_phase4<false>, dim3(blocks4), dim3(256), s, a4);
     if (n1) LVM_LAUNCH(c, mode ? "rz_seed_small" : "rz_phase_small", (lab_flavour(c) != FL_LUT_FAST) ? k_rz_phase<true> : k_rz_phase<false>, dim3(blocks), dim3(256), s, a);
+}
+
+static bool rz_level_uses_strips(const RieszState* st, int l, int NZ) {
+    return st->blur_strips && st->g[l].w % 2 == 0 && (long)st->g[l].n * NZ >= st->blur_strips_min;
 }
 
 // amplify + collapse + output of the nt frames (RieszPyramid.cpp:248-252, 304-325; MagnifyCore.hpp:269-277)
@@ -1417,7 +1446,7 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
         for (int l = 0; l < nb; ++l) {
             // wave strips (no LDS) for the large levels with an even width: rows per strip chosen so that the launch keeps
             // the resident waves busy (a strip of r rows walks r + 12)
-            if (st->blur_strips && st->g[l].w % 2 == 0 && (long)st->g[l].n * NZ >= st->blur_strips_min) {
+            if (rz_level_uses_strips(st, l, NZ)) {
                 BlurStripLv& v = as.lv[as.nlv++];
                 float** q = B.pf[l];
                 v.amp = q[F_AMP]; v.tc = q[F_TC]; v.ts = q[F_TS]; v.band = q[F_BAND]; v.R1 = q[F_R1C]; v.R2 = q[F_R2C]; v.bandA = q[F_BANDA];

@@ -93,6 +93,14 @@ def test_riesz_emu_strip_blur(lvm, po, emu, w, h, levels, rows, exact, monkeypat
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0 if exact else 1e-4, exact=exact)
 
 
+def test_riesz_emu_strip_blur_in_temporal_batches(lvm, po, emu, monkeypatch):
+    """Batched frames with the strip form forced onto every level: the phase kernel then stores no per-frame Riesz pair for
+    those levels and the amplify stage recomputes it from the band (two streams, calls of several lengths)."""
+    monkeypatch.setenv("LVM_RZ_BLUR_STRIPS_MIN", "0")
+    monkeypatch.setenv("LVM_RZ_BLUR_STRIP_ROWS", "32")
+    _frames_clip(lvm, po, emu, 2, 264, 150, 3, 2, (2, 5, 4))
+
+
 def test_riesz_emu_tiled_blur_still_matches(lvm, po, emu, monkeypatch):
     monkeypatch.setenv("LVM_RZ_BLUR_STRIPS", "0")
     ck, pk = lvm.synth.config(2, (264, 150, 3))
