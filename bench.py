@@ -113,15 +113,21 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, S, T, Twin=0):
         if base == "rz_split" and lvl is not None:
             return T * 4 * S * (2 * n[lvl] + n[lvl + 1])
         vec4 = lambda l: sizes[l][0] % 4 == 0 and sizes[l][0] >= 8  # noqa: E731  (levels of the 4-pixels-per-thread phase kernel)
+        # round 3: levels of >= 2^19 plane-pixels per launch with an even width take the strip form of the blur / amplify stage,
+        # which recomputes the Riesz pair from the band: no per-frame pair written by the phase kernel nor read back (-8 B each)
+        strips = lambda l: sizes[l][0] % 2 == 0 and n[l] * S * T >= (1 << 19)  # noqa: E731
         if base in ("rz_phase", "rz_phase_small"):
-            # per frame: band in, amp/tc/ts/R1/R2 out (24 B per band pixel); 13 state floats R + W once per launch
-            return sum((T * 24 + 104) * S * n[l] for l in range(nb) if vec4(l) == (base == "rz_phase"))
+            # per frame: band in, amp/tc/ts (+ R1/R2) out; 13 state floats R + W once per launch
+            return sum((T * (16 if strips(l) else 24) + 104) * S * n[l] for l in range(nb) if vec4(l) == (base == "rz_phase"))
         if base in ("rz_seed", "rz_seed_small"):
             return sum((4 + 13 * 4) * S * n[l] for l in range(nb) if vec4(l) == (base == "rz_seed"))
-        if base == "rz_blur_amp":
-            return T * sum(28 * S * n[l] for l in range(nb) if big(l))
+        any_strips = any(strips(l) for l in range(nb))
+        if base == "rz_blur_amp" and any_strips:
+            return T * sum(20 * S * n[l] for l in range(nb) if strips(l))
+        if base in ("rz_blur_amp", "rz_blur_amp_tiles"):
+            return T * sum(28 * S * n[l] for l in range(nb) if big(l) and not strips(l))
         if base == "rz_blur_amp_small":
-            return T * sum(28 * S * n[l] for l in range(nb) if not big(l))
+            return T * sum(28 * S * n[l] for l in range(nb) if not big(l) and not strips(l))
         if base == "rz_collapse" and lvl is not None:
             return T * 4 * S * (2 * n[lvl] + n[lvl + 1])
         if base == "rz_final":
