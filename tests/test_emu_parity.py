@@ -153,6 +153,26 @@ def test_color_emu_output_kernel_variants(lvm, po, emu, w, h, levels, rows, monk
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 6, 0.0, exact=True)
 
 
+@pytest.mark.parametrize("w,h,levels", [(264, 90, 3), (96, 77, 2), (256, 64, 3)])
+def test_color_emu_output_kernel_with_the_fused_second_pyrup(lvm, po, emu, w, h, levels, monkeypatch):
+    """LVM_COL_OUT_FUSE2=1: the pyrUp BEFORE the last one inside the strip output kernels too (three register-resident rows of
+    the level-2 image per lane) instead of a level-1 image written by the last generic pyrUp launch."""
+    monkeypatch.setenv("LVM_COL_OUT_FUSE2", "1")
+    monkeypatch.setenv("LVM_COL_OUT_MIN_TASKS", "0")
+    ck, pk = lvm.synth.config(3, (w, h, levels))
+    ck["fps"] = 15.0; pk["framerate"] = 15.0
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 5, 0.0, exact=True)
+
+
+def test_color_emu_fused_second_pyrup_wide_frame(lvm, po, emu, monkeypatch):
+    """Several strips per row (first / last level-2 column cases in different lanes), four levels."""
+    monkeypatch.setenv("LVM_COL_OUT_FUSE2", "1")
+    monkeypatch.setenv("LVM_COL_OUT_MIN_TASKS", "0")
+    ck, pk = lvm.synth.config(3, (512, 128, 4))
+    ck["fps"] = 15.0; pk["framerate"] = 15.0
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 5, 0.0, exact=True)
+
+
 def test_color_emu_wide_band_and_fps_change(lvm, po, emu):
     ck, pk = lvm.synth.config(3, (64, 48, 2))
     pk["coLow"] = 0.0; pk["coHigh"] = 40.0                   # every packed element passes (lo == 0 -> 0.01)
