@@ -154,6 +154,12 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, S, T, Twin=0):
             return T * (S * ch * n[0] + 4 * P * nV)
         if base == "col_out":
             return T * (2 * S * ch * n[0] + 4 * P * nV)
+        # round 3: k_col_out_strips makes the last TWO pyrUps itself: it reads the level-2 image of the up chain instead of V
+        nU2 = nL * 4 ** max(levels - 2, 0)
+        if base == "col_minmax_u2":
+            return T * (S * ch * n[0] + 4 * P * nU2)
+        if base == "col_out_u2":
+            return T * (2 * S * ch * n[0] + 4 * P * nU2)
         return None
     return None
 

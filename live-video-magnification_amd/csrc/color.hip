@@ -75,6 +75,22 @@ __device__ __forceinline__ void block_minmax_waves(float mn, float mx, MinMax* m
     }
 }
 
+// Barrier-free variant: six ds_bpermute butterfly steps per extreme fold the wave (no LDS memory, no workgroup barrier at the
+// tail of every workgroup: the LDS scan above cost the min/max pass 10 of its 140 us per 32 frames), lane 0 issues the atomics.
+__device__ __forceinline__ void wave_minmax(float mn, float mx, MinMax* mm, int z, bool active) {
+    const int lane = (int)(threadIdx.x & 63u);
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) {
+        const float on = __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ k) << 2, __float_as_int(mn)));
+        const float ox = __int_as_float(__builtin_amdgcn_ds_bpermute((lane ^ k) << 2, __float_as_int(mx)));
+        mn = on < mn ? on : mn; mx = ox > mx ? ox : mx;
+    }
+    if (lane == 0 && active) {
+        const int cell = (int)((blockIdx.x * 4u + (unsigned)(threadIdx.x >> 6)) % kMMCells);
+        atomicMin(mm[z].mn2 + cell, fkey(mn)); atomicMax(mm[z].mx2 + cell, fkey(mx));
+    }
+}
+
 // img2tempMat (SpatialFilter.cpp:63-84): one window column per frame.  Window layout: win[row][slot]
 // (time-contiguous per row, ring of `cap` slots) so that a wave reads one row's history as one
 // contiguous run.
@@ -363,6 +379,11 @@ constexpr int CT_W = 64, CT_H = 16;                 // output tile
 constexpr int CU_W = 100, CU_H = 28;                // max extent of the pyrUp'ed tile (scale < 1.5)
 constexpr int CV_W = 54, CV_H = 18;                 // max extent of its source tile
 
+// row slots of k_col_out_strips: the inverse of the vertical resize map with its blend weight, padded so that the kernel's
+// look-ahead needs no bounds checks (one s_load_dwordx8 = the four slots of an iteration)
+struct __attribute__((aligned(8))) YSlot { int row; float b1; };
+struct YSlot4 { YSlot s[4]; };
+constexpr int kYSlotPad = 8, kYSlotTail = 40;
 struct OutArgs {
     const uint8_t* in; long in_stride, in_sstride;
     uint8_t* out; long out_stride, out_sstride;
@@ -370,6 +391,7 @@ struct OutArgs {
     const float* V; int vw, vh;                     // source of the last pyrUp (planes); U = 2vw x 2vh
     const float* U2; int w2, h2;                    // FUSE2: source of the pyrUp BEFORE the last one (vw = 2 w2, vh = 2 h2); V is not read
     const int* xofs; const float* xa; const int* yofs; const float* ya;
+    const struct YSlot* yslot;                      // k_col_out_strips: entry kYSlotPad + s = {the output row gy with yofs[gy] == s or -1, ya[gy]}
     MinMax* mm;
     int tiles_x, tiles_y;
     float* dbg;
@@ -711,6 +733,277 @@ __global__ __launch_bounds__(256) void k_col_out_rows(OutArgs a, int strips_x, i
     }
 }
 
+// ---- strip output kernels, second form (round 3): both pyrUps inside, packed FP32, loads a whole iteration ahead -------------
+// What the measurements of k_col_out_rows said (1080p, 32 frames per launch, min/max pass):
+//   * its ISA: ~290 vector + ~150 scalar instructions and ~36 scalar branches per row of 4-pixel groups;
+//   * with the loads replaced by constants it takes 63 us, the loads alone need ~80 us (400 MB) -- and the kernel takes 140:
+//     compute and memory time ADD UP.  The loop fetched one row ahead and every wait in it was s_waitcnt vmcnt(0): the window
+//     advance was a data-dependent `while` around loads (unknown number of loads in flight -> the compiler drains them all), and
+//     with 4-5 resident waves the bytes in flight per SIMD (~5 KB) were a third of what 5 TB/s x 2-3 us of loaded latency asks for;
+//   * a FIFO of prefetch registers does not help: the v_mov that shifts it is a use of the register in flight.
+// This form therefore
+//   * makes the V rows (source of the last pyrUp) from three register-resident rows of the level-2 image U2 instead of loading
+//     them (k_pyr_up_rows' arithmetic and order): the last generic pyrUp launch and its 25 MB per frame written once and read
+//     twice are gone, and the only bulk loads left are the input rows;
+//   * walks WINDOW POSITIONS: position js (horizontal passes of V rows js .. js + 2 in A, B, C) serves the output rows whose
+//     first source row sy0 = yofs[gy] is 2 js + 1 (rows O(A, B), E(A, B, C) of the up-sampled image) or 2 js + 2 (E(A, B, C),
+//     O(B, C)): at most one each, the row map being strictly increasing (host-checked); yinv[s] is that row.  One iteration =
+//     two positions = four row slots, and its loads -- the four input rows and the one U2 row of the NEXT iteration -- are
+//     issued at its top, unconditionally (a slot without a row re-reads row y0), into registers that were copied out just
+//     before: the wait at the top of an iteration is legitimately "everything issued one iteration ago", and the loads fly for
+//     a whole iteration (four rows of arithmetic x the resident waves: 2-3 us);
+//   * keeps a lane's 4 outputs per channel as two float pairs, (x, z) = the even pyrUp columns (three-term formula) and
+//     (y, w) = the odd ones (two-term formula): every step is one v_pk_{add,mul}_f32;
+//   * evaluates every row of the up-sampled image once (O(B, C) of a position is O(A, B) of the next), selects row parity by
+//     code position instead of per value, and confines the border formulas to the strips that contain a border lane (i0 and
+//     vw are even: only the first and the last 4-pixel group of a row have one; U2: also column vw - 4).
+typedef float f2 __attribute__((vector_size(8)));
+__device__ __forceinline__ f2 mk2(float a, float b) { f2 v = {a, b}; return v; }
+__device__ __forceinline__ f2 bc2(float a) { f2 v = {a, a}; return v; }
+struct HRowP { f2 xz[3], yw[3]; };                  // horizontal pyrUp pass of one V row at the lane's 4 output columns
+struct URowP { f2 xz[3], yw[3]; };                  // one row of the up-sampled image, same layout
+struct U2Raw { float um[3], u0[3], u1[3], u2[3]; }; // U2 columns k0 - 1 .. k0 + 2 (clamped) per channel
+struct U2H { f2 a[3], b[3]; };                      // U2's horizontal pass at level-1 columns (i0 - 1, i0) and (i0 + 1, i0 + 2)
+
+// The U2 window (three rows of U2's horizontal pass = 36 floats per lane) lives in LDS, not in registers: every lane owns a private
+// column of a ring of three row slots (logical U2 row r in slot (r + 3) % 3: no sharing, no barrier, the shift is an index step),
+// read twice and written once per iteration through lgkmcnt -- with it in VGPRs the kernel needed 190-200 of them (two waves per
+// SIMD, or scratch spills that count on vmcnt and drain the prefetches).
+constexpr int kU2RingFloats = 3 * 6 * 2 * 256;      // [slot][a0 a1 a2 b0 b1 b2][x, y][thread]
+template <bool WRITE, bool DBG, bool BORDER>
+__device__ __forceinline__ void col_out_strip(const OutArgs& a, int b, int tx, int ty, int rows, int lane, float& vmin, float& vmax, f2* ring) {
+    const int gx = tx * 256 + 4 * lane, y0 = ty * rows;
+    if (gx >= a.w) return;
+    const int uh = 2 * a.vh;
+    const const_tab<int> yofs = as_const_tab(a.yofs);              // (scalar loads also in the storing pass)
+    const const_tab<YSlot> yslot = as_const_tab(a.yslot) + kYSlotPad;
+    const uint8_t* src = a.in + (size_t)b * a.in_sstride;
+    uint8_t* dst = a.out + (size_t)b * a.out_sstride;
+    const unsigned xoff = (unsigned)gx * 3u;
+    const int i0 = gx >> 1;                                        // even
+    const bool f0 = BORDER && i0 == 0, l1 = BORDER && i0 + 2 == a.vw;
+    // k_pyr_up_rows' arithmetic for the lane's four level-1 columns i0 - 1 .. i0 + 2 out of U2 columns k0 - 1 .. k0 + 2
+    const int k0 = i0 >> 1;
+    // All bulk accesses go through buffer resources built from wave-uniform values (frame base pointers): resource + per-lane 32-bit
+    // offset + scalar 32-bit row offset, i.e. no 64-bit address arithmetic in vector registers.  (With generic pointers hipcc 7.2
+    // kept the lanes' column offsets as 64-bit VGPR pairs whose zero high halves it re-materialised by copying a register that no
+    // longer held zero on one path: memory faults on the GPU -- the faulting address had the right low and a foreign high dword --
+    // while the CPU emulation build of the same source was clean under ASan and a guard-page allocator.)
+    const unsigned w2b = (unsigned)a.w2 * 4u, pstride2 = w2b * (unsigned)a.h2;
+    const BufRsrc ru2 = buf_rsrc(reinterpret_cast<const char*>(a.U2) + (size_t)b * 3 * (size_t)pstride2, 3u * pstride2);
+    const unsigned in_stride = (unsigned)a.in_stride, out_stride = (unsigned)a.out_stride;    // (host-checked: positive, frame < 2 GB)
+    const BufRsrc rin = buf_rsrc(src, in_stride * (unsigned)(a.h - 1) + (unsigned)a.w * 3u);
+    const BufRsrc rout = buf_rsrc(dst, out_stride * (unsigned)(a.h - 1) + (unsigned)a.w * 3u);
+    const bool g0 = BORDER && k0 == 0, gl0 = BORDER && k0 == a.w2 - 1, gl1 = BORDER && k0 + 1 == a.w2 - 1;
+    const unsigned dm1 = 4u * (unsigned)(k0 > 0 ? k0 - 1 : 0), d00 = 4u * (unsigned)k0, dp1 = 4u * (unsigned)(k0 + 1 < a.w2 ? k0 + 1 : a.w2 - 1),
+                   dp2 = 4u * (unsigned)(k0 + 2 < a.w2 ? k0 + 2 : a.w2 - 1);
+    auto u2load = [&](int j) __attribute__((always_inline)) {     // vertical border map of pyrUp: row -1 -> 1, row h2 -> h2 - 1
+        U2Raw r;
+        j = j < 0 ? 1 : (j >= a.h2 ? a.h2 - 1 : j);
+        const unsigned row = (unsigned)j * w2b;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const unsigned rc = row + c * pstride2;
+            r.um[c] = buf_ld_f32(ru2, dm1, rc); r.u0[c] = buf_ld_f32(ru2, d00, rc);
+            r.u1[c] = buf_ld_f32(ru2, dp1, rc); r.u2[c] = buf_ld_f32(ru2, dp2, rc);
+        }
+        return r;
+    };
+    auto u2h = [&](const U2Raw& r) __attribute__((always_inline)) {
+        U2H o;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            // (scalar on purpose: as packed operations these need the overlapping pairs (um, u0), (u0, u1), (u1, u2), which the
+            // compiler built through a stack slot; 10 plain operations against 5 packed ones + 10 register moves)
+            const float um = r.um[c], u0 = r.u0[c], u1 = r.u1[c], u2 = r.u2[c];
+            float odd[2] = {(um + u0) * 4.f, (u0 + u1) * 4.f};    // columns i0 - 1 (source k0 - 1) and i0 + 1 (source k0)
+            float even[2] = {(um + u0 * 6.f) + u1, (u0 + u1 * 6.f) + u2};   // columns i0 (source k0) and i0 + 2 (source k0 + 1)
+            if (BORDER) {
+                even[0] = sel(g0, u0 * 6.f + u1 * 2.f, sel(gl0, um + u0 * 7.f, even[0]));
+                odd[1] = sel(gl0, u0 * 8.f, odd[1]);
+                even[1] = sel(gl1, u0 + u1 * 7.f, even[1]);
+            }
+            o.a[c] = mk2(odd[0], even[0]); o.b[c] = mk2(odd[1], even[1]);
+        }
+        return o;
+    };
+    // ring[(slot * 6 + k) * 256 + thread]: consecutive lanes, consecutive 8-byte words (conflict-free ds_read_b64 / ds_write_b64)
+    f2* const mine = ring + threadIdx.x;
+    auto ring_put = [&](int r, const U2H& h) __attribute__((always_inline)) {      // logical U2 row r (may be -1 or h2: border-mapped data)
+        f2* q = mine + ((r + 3) % 3) * (6 * 256);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { q[c * 256] = h.a[c]; q[(3 + c) * 256] = h.b[c]; }
+    };
+    auto ring_get = [&](int r) __attribute__((always_inline)) {
+        U2H h;
+        const f2* q = mine + ((r + 3) % 3) * (6 * 256);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { h.a[c] = q[c * 256]; h.b[c] = q[(3 + c) * 256]; }
+        return h;
+    };
+    int jcur = -1000;                                              // the ring holds the logical U2 rows jcur - 1, jcur, jcur + 1
+    // horizontal pass of V row vy (border-mapped, made from the U2 window, which must stand at vy >> 1)
+    auto hrow = [&](int vy) __attribute__((always_inline)) {
+        HRowP o;
+        const U2H Q = ring_get(jcur), R = ring_get(jcur + 1);
+        U2H P{};
+        if ((vy & 1) == 0) P = ring_get(jcur - 1);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f2 va, vb;                                             // V columns (i0 - 1, i0) and (i0 + 1, i0 + 2)
+            if ((vy & 1) == 0) { va = ((P.a[c] + Q.a[c] * bc2(6.f)) + R.a[c]) * bc2(1.f / 64.f); vb = ((P.b[c] + Q.b[c] * bc2(6.f)) + R.b[c]) * bc2(1.f / 64.f); }
+            else { va = ((Q.a[c] + R.a[c]) * bc2(4.f)) * bc2(1.f / 64.f); vb = ((Q.b[c] + R.b[c]) * bc2(4.f)) * bc2(1.f / 64.f); }
+            const f2 c01 = mk2(va[1], vb[0]);
+            o.xz[c] = (va + c01 * bc2(6.f)) + vb;                   // x = s[-1] + s0*6 + s1, z = s0 + s1*6 + s2
+            o.yw[c] = (c01 + vb) * bc2(4.f);                        // y = (s0 + s1)*4,       w = (s1 + s2)*4
+            if (BORDER) {
+                const float s0 = va[1], s1 = vb[0];
+                o.xz[c][0] = sel(f0, s0 * 6.f + s1 * 2.f, o.xz[c][0]);
+                o.xz[c][1] = sel(l1, s0 + s1 * 7.f, o.xz[c][1]);
+                o.yw[c][1] = sel(l1, s1 * 8.f, o.yw[c][1]);
+            }
+        }
+        return o;
+    };
+    auto hrow_init = [&](int vy) __attribute__((always_inline)) { // any row order (strip start): positions the U2 window with its own loads
+        vy = vy < 0 ? 1 : (vy >= a.vh ? a.vh - 1 : vy);
+        const int jj = vy >> 1;
+        if (jj == jcur + 1) ring_put(jj + 1, u2h(u2load(jj + 1)));
+        else if (jj != jcur) { ring_put(jj - 1, u2h(u2load(jj - 1))); ring_put(jj, u2h(u2load(jj))); ring_put(jj + 1, u2h(u2load(jj + 1))); }
+        jcur = jj;
+        return hrow(vy);
+    };
+    float osc = 0.f, osh = 0.f;
+    if (WRITE) {   // convertTo(CV_8U, 255/(max-min), -min*255/(max-min)) (MagnifyCore.hpp:202)
+        const double mn = (double)mm_min(a.mm[b].mn2), mx = (double)mm_max(a.mm[b].mx2);
+        osc = (float)(255.0 / (mx - mn)); osh = (float)(-mn * 255.0 / (mx - mn));
+    }
+    const int yend = y0 + rows < a.h ? y0 + rows : a.h;
+    int js = (yofs[y0] - 1) >> 1;
+    const int jlast = (yofs[yend - 1] - 1) >> 1;
+    HRowP A = hrow_init(js), B = hrow_init(js + 1), C = hrow_init(js + 2);
+    auto even_row = [&]() __attribute__((always_inline)) {        // up-sampled row 2 (js + 1)
+        URowP u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            u.xz[c] = ((A.xz[c] + B.xz[c] * bc2(6.f)) + C.xz[c]) * bc2(1.f / 64.f);
+            u.yw[c] = ((A.yw[c] + B.yw[c] * bc2(6.f)) + C.yw[c]) * bc2(1.f / 64.f);
+        }
+        return u;
+    };
+    auto odd_row = [&](const HRowP& p, const HRowP& q) __attribute__((always_inline)) {   // row 2 j + 1 from H rows j, j + 1
+        URowP u;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            u.xz[c] = ((p.xz[c] + q.xz[c]) * bc2(4.f)) * bc2(1.f / 64.f);
+            u.yw[c] = ((p.yw[c] + q.yw[c]) * bc2(4.f)) * bc2(1.f / 64.f);
+        }
+        return u;
+    };
+    // output row gy = input + (u0 * b0 + u1 * b1): resize INTER_LINEAR with horizontal taps (1, 0), vertical D = S0*b0 + S1*b1, then
+    // the unscaled input (:169, :197)
+    auto emit = [&](int gy, float b1, const URowP& u0, const URowP& u1, const B96 pin) __attribute__((always_inline)) {
+        const float b0 = 1.f - b1;
+        const int Bv[4] = {(int)(pin.a & 255), (int)(pin.a >> 24), (int)((pin.b >> 16) & 255), (int)((pin.c >> 8) & 255)};
+        const int Gv[4] = {(int)((pin.a >> 8) & 255), (int)(pin.b & 255), (int)(pin.b >> 24), (int)((pin.c >> 16) & 255)};
+        const int Rv[4] = {(int)((pin.a >> 16) & 255), (int)((pin.b >> 8) & 255), (int)(pin.c & 255), (int)(pin.c >> 24)};
+        const f2 vb0 = bc2(b0), vb1 = bc2(b1);
+        f2 oxz[3], oyw[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int* iv = c == 0 ? Bv : (c == 1 ? Gv : Rv);
+            oxz[c] = mk2((float)iv[0], (float)iv[2]) + (u0.xz[c] * vb0 + u1.xz[c] * vb1);
+            oyw[c] = mk2((float)iv[1], (float)iv[3]) + (u0.yw[c] * vb0 + u1.yw[c] * vb1);
+        }
+        if (WRITE) {
+            if (DBG && a.dbg && b == 0) {
+                float* d = a.dbg + ((size_t)gy * a.w + gx) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { d[c] = oxz[c][0]; d[3 + c] = oyw[c][0]; d[6 + c] = oxz[c][1]; d[9 + c] = oyw[c][1]; }
+            }
+            const f2 vsc = bc2(osc), vsh = bc2(osh);
+            f2 sxz[3], syw[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { sxz[c] = oxz[c] * vsc + vsh; syw[c] = oyw[c] * vsc + vsh; }
+            // pixel k, channel c = byte 3 k + c: k = 0 -> xz[.][0], 1 -> yw[.][0], 2 -> xz[.][1], 3 -> yw[.][1]
+            B96 q;
+            q.a = pack_u8x4(sxz[0][0], sxz[1][0], sxz[2][0], syw[0][0]);
+            q.b = pack_u8x4(syw[1][0], syw[2][0], sxz[0][1], sxz[1][1]);
+            q.c = pack_u8x4(sxz[2][1], syw[0][1], syw[1][1], syw[2][1]);
+            buf_st_b96(q, rout, xoff, (unsigned)gy * out_stride);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                vmin = fminf(vmin, fminf(fminf(oxz[c][0], oxz[c][1]), fminf(oyw[c][0], oyw[c][1])));
+                vmax = fmaxf(vmax, fmaxf(fmaxf(oxz[c][0], oxz[c][1]), fmaxf(oyw[c][0], oyw[c][1])));
+            }
+        }
+    };
+    // the four row slots 2 j + 1 .. 2 j + 4 of the iteration at window position j (rows outside this strip: -1)
+    auto slots_at = [&](int j) __attribute__((always_inline)) {
+        YSlot4 q;
+        const const_tab<YSlot> p = yslot + (2 * j + 1);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = p[k].row; q.s[k].row = r >= y0 && r < yend ? r : -1; q.s[k].b1 = p[k].b1;
+        }
+        return q;
+    };
+    auto row_load = [&](int r) __attribute__((always_inline)) {    // (a slot without a row re-reads row y0)
+        return buf_ld_b96(rin, xoff, (unsigned)(r >= 0 ? r : y0) * in_stride);
+    };
+    U2Raw u2c{};
+    // one window position: its two row slots, then the window advances by V row j + 3 (clamped to vh - 1: the U2 window stands still)
+    // (the input row of a slot is re-loaded for the NEXT iteration's slot right after its use: one register set per slot, no copies)
+    auto step = [&](int j, const YSlot sO, const YSlot sE, int nO, int nE, B96& pO, B96& pE, const URowP& Oin, URowP& Oout) __attribute__((always_inline)) {
+        URowP Ecur = even_row();
+        Oout = odd_row(B, C);
+        // sy1 = min(sy0 + 1, uh - 1): the last row of the up-sampled image blends with itself (no later row can need the original)
+        if (2 * j + 2 > uh - 1) Ecur = Oin;
+        if (2 * j + 3 > uh - 1) Oout = Ecur;
+        if (sO.row >= 0) emit(sO.row, sO.b1, Oin, Ecur, pO);
+        pO = row_load(nO);
+        if (sE.row >= 0) emit(sE.row, sE.b1, Ecur, Oout, pE);
+        pE = row_load(nE);
+        const int vy = j + 3 < a.vh ? j + 3 : a.vh - 1;            // (j + 3 >= 2 in the loop)
+        if ((vy >> 1) == jcur + 1) { jcur = vy >> 1; ring_put(jcur + 1, u2h(u2c)); }
+        A = B; B = C; C = hrow(vy);
+    };
+    // the U2 window shifts once per iteration (V rows js + 3, js + 4 -> js + 2 and js + 4 differ by one U2 row), to U2 row
+    // (js + 4) >> 1, and takes in row ((js + 4) >> 1) + 1 = (js + 6) >> 1.  The slot table entries are read one iteration ahead
+    // (scalar loads: the rows of the next iteration's slots are needed for the input loads of this one).
+    YSlot4 S0, S1 = slots_at(js);
+    B96 p0 = row_load(S1.s[0].row), p1 = row_load(S1.s[1].row), p2 = row_load(S1.s[2].row), p3 = row_load(S1.s[3].row);
+    U2Raw u2n = u2load((js + 6) >> 1);
+    URowP O0 = odd_row(A, B), O1;
+    for (; js <= jlast; js += 2) {                                 // (the second position of the last pair may be past the strip: no row, no output)
+        u2c = u2n;
+        S0 = S1; S1 = slots_at(js + 2);
+        u2n = u2load((js + 8) >> 1);
+        step(js, S0.s[0], S0.s[1], S1.s[0].row, S1.s[1].row, p0, p1, O0, O1);
+        step(js + 1, S0.s[2], S0.s[3], S1.s[2].row, S1.s[3].row, p2, p3, O1, O0);
+    }
+}
+
+template <bool WRITE, bool DBG>
+__global__ __launch_bounds__(256) void k_col_out_strips(OutArgs a, int strips_x, int strips_y, int ntasks, int rows) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int task = blockIdx.x * 4 + wave;
+    __shared__ __attribute__((aligned(16))) float s_ring[kU2RingFloats];
+    f2* ring = reinterpret_cast<f2*>(s_ring);
+    float vmin = INFINITY, vmax = -INFINITY;
+    int b = 0;
+    if (task < ntasks) {
+        b = task / (strips_x * strips_y);
+        const int r = task - b * (strips_x * strips_y);
+        const int ty = r / strips_x, tx = r - ty * strips_x;
+        // strips holding a lane with a border formula: the first, the last, and (U2 column vw - 4) the one before a last strip of one group
+        if (tx == 0 || 256 * (tx + 1) + 4 >= a.w) col_out_strip<WRITE, DBG, true>(a, b, tx, ty, rows, lane, vmin, vmax, ring);
+        else col_out_strip<WRITE, DBG, false>(a, b, tx, ty, rows, lane, vmin, vmax, ring);
+    }
+    if (!WRITE) wave_minmax(vmin, vmax, a.mm, b, task < ntasks);
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -725,6 +1018,7 @@ struct ColorState : ModeState {
     float* win = nullptr; float* Y = nullptr; int cap = 0;
     int n = 0, slot0 = 0;            // logical window: n columns starting at ring slot slot0
     int max_images = 0;
+    bool yofs_strict = false;        // the vertical resize map yofs[] is strictly increasing (always, for sizes the up chain produces)
     bool co_rows_ok = false;         // the vectorised output kernel's LDS tile covers every output tile
     bool thin_dft = true;            // thread-per-row DFT for narrow bands (LVM_COL_THIN_DFT=0: wave-per-row kernel)
     long out_min_tasks = 2048;       // strips are shortened until a launch has this many (LVM_COL_OUT_MIN_TASKS)
@@ -732,6 +1026,8 @@ struct ColorState : ModeState {
     bool d0_rows_on = true;          // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
     long d0_min_tasks = 4096;        // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
     int out_rows = 16;               // rows per wave strip of k_col_out_rows (LVM_COL_OUT_ROWS; 0 = tiled k_col_out_v4)
+    int out_rows_lean = 36;          // ... of k_col_out_strips (strip start-up = 3 V rows + 3 U2 rows: longer strips; 1080 = 30 x 36)
+    bool out_lean = true;            // k_col_out_strips (both pyrUps inside, packed FP32, loads an iteration ahead); LVM_COL_OUT_LEAN=0: k_col_out_rows
     bool out_fuse2 = false;          // LVM_COL_OUT_FUSE2=1: the pyrUp before the last one inside the output kernels too (25 MB per frame less, measured equal: off)
     int thin_min_frames = 4;         // ... from this many frames per launch (LVM_COL_THIN_MIN_FRAMES)
     long rows_min_elems = 1 << 20;   // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
@@ -739,11 +1035,11 @@ struct ColorState : ModeState {
     double* tw_all = nullptr; int tw_all_max = 0; std::vector<size_t> tw_off;   // tables of every length 2 .. tw_all_max
     double* tw_own = nullptr;
     MinMax* mm = nullptr;
-    int *xofs = nullptr, *yofs = nullptr; float *xa = nullptr, *ya = nullptr;
+    int *xofs = nullptr, *yofs = nullptr; float *xa = nullptr, *ya = nullptr; YSlot* yslot = nullptr;
     // temporal batching
     int tcap = 0; float* tarena = nullptr; float* Gt[kMaxLevels + 1] = {}; float* upt[kMaxLevels + 1] = {}; float* col1t = nullptr; MinMax* mmt = nullptr;
     ~ColorState() override {
-        void* p[] = {arena, win, Y, tw_all, tw_own, mm, xofs, yofs, xa, ya, tarena, mmt};
+        void* p[] = {arena, win, Y, tw_all, tw_own, mm, xofs, yofs, yslot, xa, ya, tarena, mmt};
         for (void* q : p) if (q) (void)hipFree(q);
     }
 };
@@ -793,10 +1089,18 @@ static int color_alloc(Ctx* c, ColorState* st, int w, int h, int channels, int l
     LVM_HIP_TRY(c, hipMemcpy(st->xa, xa.data(), w * sizeof(float), hipMemcpyHostToDevice));
     LVM_HIP_TRY(c, hipMemcpy(st->yofs, yo.data(), h * sizeof(int), hipMemcpyHostToDevice));
     LVM_HIP_TRY(c, hipMemcpy(st->ya, ya.data(), h * sizeof(float), hipMemcpyHostToDevice));
+    {   // inverse of the row map over the rows of the up chain's last image, with the blend weights (k_col_out_strips)
+        std::vector<YSlot> ys((size_t)kYSlotPad + UH + kYSlotTail, YSlot{-1, 0.f});
+        for (int i = h - 1; i >= 0; --i) if (yo[i] >= 0 && yo[i] < UH) ys[(size_t)kYSlotPad + yo[i]] = YSlot{i, ya[i]};
+        LVM_HIP_TRY(c, hipMalloc((void**)&st->yslot, ys.size() * sizeof(YSlot)));
+        LVM_HIP_TRY(c, hipMemcpy(st->yslot, ys.data(), ys.size() * sizeof(YSlot), hipMemcpyHostToDevice));
+    }
     LVM_HIP_TRY(c, hipMalloc((void**)&st->mm, sizeof(MinMax) * c->nstreams));
     // the kernel's LDS tiles assume the resize never shrinks by more than 1.5 (true for every size
     // calculateMaxLevels admits); verify the per-tile extents once
     for (int x0 = 0; x0 < w; x0 += CT_W) { const int xe = (x0 + CT_W < w ? x0 + CT_W : w) - 1; if (xo[xe] + 1 - xo[x0] + 1 > CU_W) { c->err = "color: resize tile too wide"; return LVM_ERR_INVALID; } }
+    st->yofs_strict = true;                         // k_col_out_strips walks window positions: needs a strictly increasing row map
+    for (int i = 1; i < h; ++i) if (yo[i] <= yo[i - 1]) st->yofs_strict = false;
     st->co_rows_ok = true;
     for (int y0 = 0; y0 < h; y0 += CT_H) {
         const int ye = (y0 + CT_H < h ? y0 + CT_H : h) - 1;
@@ -928,7 +1232,11 @@ static void col_up_out(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs&
     const int vw_f = levels >= 1 ? st->g[levels].w << (levels - 1) : 0;
     const bool vec4_f = C == 3 && io.w == 2 * vw_f && io.w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && io.out_stride % 4 == 0 &&
                         io.out_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0 && ((uintptr_t)io.d_out % 4) == 0 && st->co_rows_ok;
-    const bool fuse2 = st->out_fuse2 && vec4_f && st->out_rows > 0 && levels >= 2;
+    // k_col_out_strips: both pyrUps inside (strictly increasing row map; a level-2 image of at least 2 x 2 for the border maps)
+    const bool lean = st->out_lean && st->yofs_strict && vec4_f && st->out_rows > 0 && levels >= 2 &&
+                      (st->g[levels].w << (levels - 2)) >= 2 && (st->g[levels].h << (levels - 2)) >= 2 &&
+                      io.in_stride > 0 && io.out_stride > 0 && (long)io.in_stride * io.h < (1L << 31) && (long)io.out_stride * io.h < (1L << 31);
+    const bool fuse2 = lean || (st->out_fuse2 && vec4_f && st->out_rows > 0 && levels >= 2);
     for (int k = 0; k + 1 < levels - (fuse2 ? 1 : 0); ++k) {      // L-1 generic pyrUps, the last one is fused into k_col_out (FUSE2: the last two)
         if (st->up_rows && (2 * uw) % 4 == 0) {      // barrier-free blocks of 4 x 2 outputs per lane (pyramid.h)
             const long ngroups = (long)(2 * uw / 4) * uh;
@@ -946,7 +1254,7 @@ static void col_up_out(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs&
     a.U2 = nullptr; a.w2 = a.h2 = 0;
     if (fuse2) { a.U2 = B.up[levels - 2]; a.w2 = uw; a.h2 = uh; uw *= 2; uh *= 2; }
     a.w = io.w; a.h = io.h; a.V = B.up[levels - 1]; a.vw = uw; a.vh = uh;
-    a.xofs = st->xofs; a.xa = st->xa; a.yofs = st->yofs; a.ya = st->ya; a.mm = B.mm;
+    a.xofs = st->xofs; a.xa = st->xa; a.yofs = st->yofs; a.ya = st->ya; a.yslot = st->yslot; a.mm = B.mm;
     a.tiles_x = (io.w + CT_W - 1) / CT_W; a.tiles_y = (io.h + CT_H - 1) / CT_H;
     a.dbg = c->keep_float ? c->d_float : nullptr;
     const dim3 grid(a.tiles_x, a.tiles_y, NZ);
@@ -955,12 +1263,16 @@ static void col_up_out(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs&
                       st->co_rows_ok;
     if (vec4 && st->out_rows > 0) {
         const int sx = (io.w + 255) / 256;
-        int rows = st->out_rows;
+        int rows = lean ? st->out_rows_lean : st->out_rows;
         while (rows > 2 && (long)sx * ((io.h + rows - 1) / rows) * NZ < st->out_min_tasks) rows >>= 1;
         const int sy = (io.h + rows - 1) / rows;
         const long ntasks = (long)sx * sy * NZ;
         const dim3 g2((unsigned)((ntasks + 3) / 4));
-        if (fuse2) {
+        if (lean) {
+            LVM_LAUNCH(c, "col_minmax_u2", (k_col_out_strips<false, false>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
+            if (a.dbg) LVM_LAUNCH(c, "col_out_u2", (k_col_out_strips<true, true>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
+            else LVM_LAUNCH(c, "col_out_u2", (k_col_out_strips<true, false>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
+        } else if (fuse2) {
             LVM_LAUNCH(c, "col_minmax", (k_col_out_rows<false, false, true>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
             if (a.dbg) LVM_LAUNCH(c, "col_out", (k_col_out_rows<true, true, true>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
             else LVM_LAUNCH(c, "col_out", (k_col_out_rows<true, false, true>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
@@ -990,8 +1302,9 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         if (const char* e = std::getenv("LVM_COL_UP_ROWS")) st->up_rows = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
-        if (const char* e = std::getenv("LVM_COL_OUT_ROWS")) st->out_rows = std::atoi(e);
+        if (const char* e = std::getenv("LVM_COL_OUT_ROWS")) st->out_rows = st->out_rows_lean = std::atoi(e);
         if (const char* e = std::getenv("LVM_COL_OUT_FUSE2")) st->out_fuse2 = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_COL_OUT_LEAN")) st->out_lean = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_COL_OUT_MIN_TASKS")) st->out_min_tasks = std::atol(e);
         if (const char* e = std::getenv("LVM_COL_THIN_MIN_FRAMES")) st->thin_min_frames = std::atoi(e);
         if (const char* e = std::getenv("LVM_ROWS_MIN_ELEMS")) st->rows_min_elems = std::atol(e);

@@ -2,10 +2,40 @@
 #include <hip/hip_runtime.h>
 #include <ucontext.h>
 
+#include <sys/mman.h>
+
 #include <cstdlib>
+#include <map>
+#include <mutex>
 #include <vector>
 
 namespace hipemu {
+namespace {
+std::mutex g_guard_mu;
+std::map<void*, std::pair<void*, size_t>> g_guard;      // user pointer -> (mapping, length)
+bool guard_on() { static const bool on = [] { const char* e = std::getenv("HIPEMU_GUARD"); return e && std::atoi(e) != 0; }(); return on; }
+}  // namespace
+void* guard_malloc(size_t n) {
+    if (!guard_on()) return nullptr;
+    constexpr size_t kMargin = 16u << 20, kPage = 4096;
+    const size_t body = (n + kPage - 1) / kPage * kPage, total = body + 2 * kMargin;
+    char* base = (char*)mmap(nullptr, total, PROT_NONE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (base == (char*)MAP_FAILED) return nullptr;
+    if (mprotect(base + kMargin, body, PROT_READ | PROT_WRITE) != 0) { munmap(base, total); return nullptr; }
+    char* user = base + kMargin + body - (n + 255) / 256 * 256;          // 256-byte aligned like hipMalloc, as close to the end as that allows
+    if (user < base + kMargin) user = base + kMargin;
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guard[user] = {base, total};
+    return user;
+}
+bool guard_free(void* p) {
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    auto it = g_guard.find(p);
+    if (it == g_guard.end()) return false;
+    munmap(it->second.first, it->second.second);
+    g_guard.erase(it);
+    return true;
+}
 thread_local State st;
 namespace {
 struct Fiber { ucontext_t ctx; char* stack = nullptr; bool done = true; dim3 tid; };
@@ -34,6 +64,17 @@ int dpp_wave_shift(int old, int src, int ctrl) {
     if (ctrl == 0x138) { if (lane > 0) r = slot[t - 1]; }
     else if (ctrl == 0x130) { if (lane < 63) r = slot[t + 1]; }
     else std::abort();
+    sync();
+    return r;
+}
+// ds_bpermute_b32: lane i receives the value of lane (byte_addr / 4) % 64 of its wave (same deposit / yield / read scheme;
+// every lane of the wave must execute it)
+int wave_bpermute(int byte_addr, int src) {
+    static thread_local int slot[1024];
+    const unsigned t = st.tid.x + st.bdim.x * (st.tid.y + st.bdim.y * st.tid.z);
+    slot[t] = src;
+    sync();
+    const int r = slot[(t & ~63u) + (((unsigned)byte_addr >> 2) & 63u)];
     sync();
     return r;
 }

@@ -40,6 +40,7 @@ extern thread_local State st;
 void sync();
 void launch(const std::function<void()>& body, dim3 grid, dim3 block);
 int dpp_wave_shift(int old, int src, int ctrl);
+int wave_bpermute(int byte_addr, int src);
 }  // namespace hipemu
 #define threadIdx (hipemu::st.tid)
 #define blockIdx (hipemu::st.bid)
@@ -57,6 +58,8 @@ struct uint4 { unsigned x, y, z, w; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 #define LVM_EMU_NO_DOT2 1      // lab_lut.h: v_dot2_i32_i16 spelled out
+#define LVM_EMU_NO_CONST_AS 1  // lvm_internal.h: no constant address space on the host
+#define LVM_EMU_NO_BUFFER_OPS 1 // lvm_internal.h: buffer resource loads / stores as bounds-checked host accesses
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
@@ -82,6 +85,7 @@ static inline float __builtin_amdgcn_sinf(float rev) { return sinf(rev * 6.28318
 static inline float __builtin_amdgcn_cosf(float rev) { return cosf(rev * 6.283185307179586f); }
 // DPP wave_shr:1 (0x138) / wave_shl:1 (0x130): every lane of the wave must execute it (uniform control flow)
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) { return hipemu::dpp_wave_shift(old, src, ctrl); }
+static inline int __builtin_amdgcn_ds_bpermute(int byte_addr, int src) { return hipemu::wave_bpermute(byte_addr, src); }
 static inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
 // wave-uniform shortcuts compute what the general path selects, so a per-lane answer is equivalent here
 static inline unsigned long long __builtin_amdgcn_ballot_w64(bool c) { return c ? 1ull : 0ull; }   // only ever applied to wave-uniform values
@@ -97,8 +101,17 @@ static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "hip-emu error"; }
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); if (!*p) return hipErrorOutOfMemory; std::memset(*p, 0xFF, n); return hipSuccess; }
-static inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+// HIPEMU_GUARD=1: every "device" buffer is its own mmap region with 16 MiB of PROT_NONE either side and its end on a page end, so
+// that an access far outside a buffer faults like it does on the GPU (malloc neighbours would silently absorb it; ASan's redzones
+// only catch near misses)
+namespace hipemu { void* guard_malloc(size_t n); bool guard_free(void* p); }
+static inline hipError_t hipMalloc(void** p, size_t n) {
+    *p = hipemu::guard_malloc(n ? n : 1);
+    if (!*p) *p = std::malloc(n ? n : 1);
+    if (!*p) return hipErrorOutOfMemory;
+    std::memset(*p, 0xFF, n); return hipSuccess;
+}
+static inline hipError_t hipFree(void* p) { if (!hipemu::guard_free(p)) std::free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 static inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }

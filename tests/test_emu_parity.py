@@ -141,11 +141,12 @@ def test_color_emu_bit_exact(lvm, po, emu, w, h, levels, ch, fps):
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 20, 0.0, exact=True)
 
 
-@pytest.mark.parametrize("rows", ["0", "2", "8", "16"])
+@pytest.mark.parametrize("rows", ["0", "2", "8", "16", "36"])
 @pytest.mark.parametrize("w,h,levels", [(264, 90, 3), (96, 77, 2)])
 def test_color_emu_output_kernel_variants(lvm, po, emu, w, h, levels, rows, monkeypatch):
-    """The vectorised output kernels: tiled (rows = 0) and wave strips of 2 / 8 / 16 rows, on heights the
-    up chain overshoots (the bilinear row map skips source rows) and widths with a partly filled wave."""
+    """The vectorised output kernels: tiled (rows = 0) and wave strips of 2 ... 36 rows (k_col_out_strips: both pyrUps inside, window
+    positions of two row slots each, U2 window in an LDS ring, buffer loads / stores), on heights the up chain overshoots (the
+    bilinear row map skips source rows) and widths with a partly filled wave."""
     monkeypatch.setenv("LVM_COL_OUT_ROWS", rows)
     monkeypatch.setenv("LVM_COL_OUT_MIN_TASKS", "0")
     ck, pk = lvm.synth.config(3, (w, h, levels))
@@ -153,22 +154,33 @@ def test_color_emu_output_kernel_variants(lvm, po, emu, w, h, levels, rows, monk
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 6, 0.0, exact=True)
 
 
-@pytest.mark.parametrize("w,h,levels", [(264, 90, 3), (96, 77, 2), (256, 64, 3)])
-def test_color_emu_output_kernel_with_the_fused_second_pyrup(lvm, po, emu, w, h, levels, monkeypatch):
-    """LVM_COL_OUT_FUSE2=1: the pyrUp BEFORE the last one inside the strip output kernels too (three register-resident rows of
-    the level-2 image per lane) instead of a level-1 image written by the last generic pyrUp launch."""
-    monkeypatch.setenv("LVM_COL_OUT_FUSE2", "1")
+@pytest.mark.parametrize("w,h,levels", [(516, 40, 2), (520, 52, 3), (1028, 36, 2), (256, 64, 3), (512, 128, 4)])
+def test_color_emu_strip_kernel_border_lanes(lvm, po, emu, w, h, levels, monkeypatch):
+    """k_col_out_strips: widths whose last strip holds one group (516: the U2 border column vw - 4 sits in the strip BEFORE the last
+    one), several interior strips (1028), exact multiples of the strip width, four levels."""
     monkeypatch.setenv("LVM_COL_OUT_MIN_TASKS", "0")
     ck, pk = lvm.synth.config(3, (w, h, levels))
     ck["fps"] = 15.0; pk["framerate"] = 15.0
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 5, 0.0, exact=True)
 
 
-def test_color_emu_fused_second_pyrup_wide_frame(lvm, po, emu, monkeypatch):
-    """Several strips per row (first / last level-2 column cases in different lanes), four levels."""
-    monkeypatch.setenv("LVM_COL_OUT_FUSE2", "1")
+@pytest.mark.parametrize("fuse2", ["0", "1"])
+@pytest.mark.parametrize("w,h,levels", [(264, 90, 3), (96, 77, 2), (512, 128, 4)])
+def test_color_emu_previous_strip_kernels_still_match(lvm, po, emu, w, h, levels, fuse2, monkeypatch):
+    """LVM_COL_OUT_LEAN=0: k_col_out_rows (the fallback for row maps that are not strictly increasing / one-level pyramids), with
+    and without its own fused second pyrUp."""
+    monkeypatch.setenv("LVM_COL_OUT_LEAN", "0")
+    monkeypatch.setenv("LVM_COL_OUT_FUSE2", fuse2)
     monkeypatch.setenv("LVM_COL_OUT_MIN_TASKS", "0")
-    ck, pk = lvm.synth.config(3, (512, 128, 4))
+    ck, pk = lvm.synth.config(3, (w, h, levels))
+    ck["fps"] = 15.0; pk["framerate"] = 15.0
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 5, 0.0, exact=True)
+
+
+def test_color_emu_one_level_uses_the_single_pyrup_kernels(lvm, po, emu, monkeypatch):
+    """levels = 1: no level-2 image exists, the strip kernels with one pyrUp inside run."""
+    monkeypatch.setenv("LVM_COL_OUT_MIN_TASKS", "0")
+    ck, pk = lvm.synth.config(3, (128, 48, 1))
     ck["fps"] = 15.0; pk["framerate"] = 15.0
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 5, 0.0, exact=True)
 
