@@ -137,6 +137,8 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, S, T, Twin=0):
         nL = n[levels]
         if base == "col_down0":
             return T * (S * ch * n[0] + 4 * P * n[1])
+        if base == "col_down01":         # round 3: the first two levels in one pass, level 1 never written
+            return T * (S * ch * n[0] + 4 * P * n[2])
         if base in ("pyr_down", "pyr_down_rows") and lvl is not None:
             return T * 4 * P * (n[lvl] + n[lvl + 1])
         if base == "pyr_down2" and lvl is not None:

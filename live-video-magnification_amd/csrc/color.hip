@@ -881,16 +881,22 @@ __device__ __forceinline__ void col_out_strip(const OutArgs& a, int b, int tx, i
     const int yend = y0 + rows < a.h ? y0 + rows : a.h;
     int js = (yofs[y0] - 1) >> 1;
     const int jlast = (yofs[yend - 1] - 1) >> 1;
-    HRowP A = hrow_init(js), B = hrow_init(js + 1), C = hrow_init(js + 2);
-    auto even_row = [&]() __attribute__((always_inline)) {        // up-sampled row 2 (js + 1)
-        URowP u;
+    // The vertical pass keeps, instead of the three H rows (A, B, C) of a window position, the partial sum T = A + B*6 of the even row
+    // E = ((A + B*6) + C) / 64 (same operations in the same order) and the rows B, C: the next position's T is B + C*6 and its
+    // (B, C) are (C, new row) -- with two positions written out per iteration the two row variables just swap roles and nothing
+    // is moved (rotating A, B, C cost 24 of the ~180 vector instructions per output row).
+    HRowP X, Y;                                                    // the H rows B, C of the position (roles alternate)
+    URowP T;
+    URowP O0, O1;
+    {
+        const HRowP A0 = hrow_init(js);
+        X = hrow_init(js + 1); Y = hrow_init(js + 2);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            u.xz[c] = ((A.xz[c] + B.xz[c] * bc2(6.f)) + C.xz[c]) * bc2(1.f / 64.f);
-            u.yw[c] = ((A.yw[c] + B.yw[c] * bc2(6.f)) + C.yw[c]) * bc2(1.f / 64.f);
+            T.xz[c] = A0.xz[c] + X.xz[c] * bc2(6.f); T.yw[c] = A0.yw[c] + X.yw[c] * bc2(6.f);
+            O0.xz[c] = ((A0.xz[c] + X.xz[c]) * bc2(4.f)) * bc2(1.f / 64.f); O0.yw[c] = ((A0.yw[c] + X.yw[c]) * bc2(4.f)) * bc2(1.f / 64.f);
         }
-        return u;
-    };
+    }
     auto odd_row = [&](const HRowP& p, const HRowP& q) __attribute__((always_inline)) {   // row 2 j + 1 from H rows j, j + 1
         URowP u;
 #pragma unroll
@@ -955,9 +961,12 @@ __device__ __forceinline__ void col_out_strip(const OutArgs& a, int b, int tx, i
     U2Raw u2c{};
     // one window position: its two row slots, then the window advances by V row j + 3 (clamped to vh - 1: the U2 window stands still)
     // (the input row of a slot is re-loaded for the NEXT iteration's slot right after its use: one register set per slot, no copies)
-    auto step = [&](int j, const YSlot sO, const YSlot sE, int nO, int nE, B96& pO, B96& pE, const URowP& Oin, URowP& Oout) __attribute__((always_inline)) {
-        URowP Ecur = even_row();
-        Oout = odd_row(B, C);
+    auto step = [&](int j, const YSlot sO, const YSlot sE, int nO, int nE, B96& pO, B96& pE, const URowP& Oin, URowP& Oout, HRowP& Bm, const HRowP& Cm)
+        __attribute__((always_inline)) {
+        URowP Ecur;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { Ecur.xz[c] = (T.xz[c] + Cm.xz[c]) * bc2(1.f / 64.f); Ecur.yw[c] = (T.yw[c] + Cm.yw[c]) * bc2(1.f / 64.f); }
+        Oout = odd_row(Bm, Cm);
         // sy1 = min(sy0 + 1, uh - 1): the last row of the up-sampled image blends with itself (no later row can need the original)
         if (2 * j + 2 > uh - 1) Ecur = Oin;
         if (2 * j + 3 > uh - 1) Oout = Ecur;
@@ -965,9 +974,11 @@ __device__ __forceinline__ void col_out_strip(const OutArgs& a, int b, int tx, i
         pO = row_load(nO);
         if (sE.row >= 0) emit(sE.row, sE.b1, Ecur, Oout, pE);
         pE = row_load(nE);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { T.xz[c] = Bm.xz[c] + Cm.xz[c] * bc2(6.f); T.yw[c] = Bm.yw[c] + Cm.yw[c] * bc2(6.f); }
         const int vy = j + 3 < a.vh ? j + 3 : a.vh - 1;            // (j + 3 >= 2 in the loop)
         if ((vy >> 1) == jcur + 1) { jcur = vy >> 1; ring_put(jcur + 1, u2h(u2c)); }
-        A = B; B = C; C = hrow(vy);
+        Bm = hrow(vy);                                             // the new row takes the place of the oldest one
     };
     // the U2 window shifts once per iteration (V rows js + 3, js + 4 -> js + 2 and js + 4 differ by one U2 row), to U2 row
     // (js + 4) >> 1, and takes in row ((js + 4) >> 1) + 1 = (js + 6) >> 1.  The slot table entries are read one iteration ahead
@@ -975,13 +986,12 @@ __device__ __forceinline__ void col_out_strip(const OutArgs& a, int b, int tx, i
     YSlot4 S0, S1 = slots_at(js);
     B96 p0 = row_load(S1.s[0].row), p1 = row_load(S1.s[1].row), p2 = row_load(S1.s[2].row), p3 = row_load(S1.s[3].row);
     U2Raw u2n = u2load((js + 6) >> 1);
-    URowP O0 = odd_row(A, B), O1;
     for (; js <= jlast; js += 2) {                                 // (the second position of the last pair may be past the strip: no row, no output)
         u2c = u2n;
         S0 = S1; S1 = slots_at(js + 2);
         u2n = u2load((js + 8) >> 1);
-        step(js, S0.s[0], S0.s[1], S1.s[0].row, S1.s[1].row, p0, p1, O0, O1);
-        step(js + 1, S0.s[2], S0.s[3], S1.s[2].row, S1.s[3].row, p2, p3, O1, O0);
+        step(js, S0.s[0], S0.s[1], S1.s[0].row, S1.s[1].row, p0, p1, O0, O1, X, Y);
+        step(js + 1, S0.s[2], S0.s[3], S1.s[2].row, S1.s[3].row, p2, p3, O1, O0, Y, X);
     }
 }
 
@@ -1024,6 +1034,8 @@ struct ColorState : ModeState {
     long out_min_tasks = 2048;       // strips are shortened until a launch has this many (LVM_COL_OUT_MIN_TASKS)
     bool up_rows = true;             // barrier-free pyrUp of the up chain (LVM_COL_UP_ROWS=0: tiled k_pyr_up)
     bool d0_rows_on = true;          // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
+    bool d01_on = true;              // first TWO pyramid levels in one pass for large launches (LVM_COL_DOWN01=0: level 1 through HBM)
+    int d01_rows_forced = 0;         // LVM_COL_DOWN01_ROWS: strip height of k_down01_rows (tests)
     long d0_min_tasks = 4096;        // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
     int out_rows = 16;               // rows per wave strip of k_col_out_rows (LVM_COL_OUT_ROWS; 0 = tiled k_col_out_v4)
     int out_rows_lean = 36;          // ... of k_col_out_strips (strip start-up = 3 V rows + 3 U2 rows: longer strips; 1080 = 30 x 36)
@@ -1139,7 +1151,25 @@ static void col_down(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs& B
     const int d0_sx = (g1.w + D0R_OUT - 1) / D0R_OUT;
     long d0_tasks = 0;
     const int d0_rows = down0_rows_choice(g1.w, g1.h, NZ, st->d0_min_tasks, &d0_tasks);
-    if (vec4 && st->d0_rows_on && d0_tasks > 0) {   // wave strips with DPP halo exchange (pyramid.h)
+    // two levels in one pass (k_down01_rows): G_1 is never written.  Large launches only (temporal batches / many streams)
+    long d01_tasks = 0;
+    int d01_rows = (levels >= 2 && st->g[2].w >= 2) ? down01_rows_choice(st->g[2].w, st->g[2].h, NZ, st->d0_min_tasks, &d01_tasks) : 0;
+    if (st->d01_rows_forced > 0 && d01_tasks > 0) {     // tests: a given strip height
+        d01_rows = st->d01_rows_forced;
+        d01_tasks = (long)((st->g[2].w + D01_OUT - 1) / D01_OUT) * ((st->g[2].h + d01_rows - 1) / d01_rows) * NZ;
+    }
+    const bool d01 = st->d01_on && vec4 && w % 8 == 0 && levels >= 2 && d01_tasks > 0 && st->g[1].w * 2 == w && st->g[2].w * 4 == w &&
+                     io.in_stride > 0 && (long)io.in_stride * h < (1L << 31);
+    int l = 1;
+    if (d01) {
+        D01Args q;
+        q.in = io.d_in; q.in_stride = (long)io.in_stride; q.in_sstride = (long)io.in_sstride; q.w = w; q.h = h;
+        q.G2 = B.G[2]; q.w2 = st->g[2].w; q.h2 = st->g[2].h; q.h1 = st->g[1].h;
+        q.strips_x = (st->g[2].w + D01_OUT - 1) / D01_OUT; q.rows = d01_rows; q.strips_y = (st->g[2].h + d01_rows - 1) / d01_rows;
+        q.ntasks = (int)d01_tasks;
+        LVM_LAUNCH(c, "col_down01", k_down01_rows<1>, dim3((unsigned)((d01_tasks + D01_THREADS / 64 - 1) / (D01_THREADS / 64))), dim3(D01_THREADS), s, q);
+        l = 2;
+    } else if (vec4 && st->d0_rows_on && d0_tasks > 0) {   // wave strips with DPP halo exchange (pyramid.h)
         const dim3 gridr((unsigned)((d0_tasks + D0R_THREADS / 64 - 1) / (D0R_THREADS / 64)));
         LVM_LAUNCH(c, "col_down0", (k_down0_rows<false, FL_LUT_EXACT>), gridr, dim3(D0R_THREADS), s, io.d_in, (long)io.in_stride, (long)io.in_sstride,
                    w, h, B.G[1], g1.w, g1.h, c->lab, d0_sx, (g1.h + d0_rows - 1) / d0_rows, (int)d0_tasks, d0_rows, LabPlanes{nullptr, nullptr});
@@ -1150,7 +1180,6 @@ static void col_down(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs& B
         auto kd0 = (C == 3) ? k_down0<3, false, FL_LUT_EXACT> : k_down0<1, false, FL_LUT_EXACT>;
         LVM_LAUNCH(c, "col_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, B.G[1], g1.w, g1.h, c->lab, 1.0f, LabPlanes{nullptr, nullptr});
     }
-    int l = 1;
     while (l < levels) {            // two pyramid levels per launch while possible
         if (st->g[l].w % 4 == 0 && (long)st->g[l].n * planes >= st->rows_min_elems) {
             // large planes (temporal batches / many streams): barrier-free wave strips (pyramid.h)
@@ -1305,6 +1334,8 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         if (const char* e = std::getenv("LVM_COL_OUT_ROWS")) st->out_rows = st->out_rows_lean = std::atoi(e);
         if (const char* e = std::getenv("LVM_COL_OUT_FUSE2")) st->out_fuse2 = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_COL_OUT_LEAN")) st->out_lean = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_COL_DOWN01")) st->d01_on = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_COL_DOWN01_ROWS")) st->d01_rows_forced = std::atoi(e);
         if (const char* e = std::getenv("LVM_COL_OUT_MIN_TASKS")) st->out_min_tasks = std::atol(e);
         if (const char* e = std::getenv("LVM_COL_THIN_MIN_FRAMES")) st->thin_min_frames = std::atoi(e);
         if (const char* e = std::getenv("LVM_ROWS_MIN_ELEMS")) st->rows_min_elems = std::atol(e);

@@ -509,6 +509,129 @@ __global__ __launch_bounds__(D0L_THREADS) void k_down0_lut_rows(D0LArgs q) {
         down0_lut_strip<FL>(q, task, lane, s_ab);
 }
 
+// ---- u8 BGR -> pyrDown -> pyrDown -> G_2 in one pass (colour mode) ------------------------------------------------------------
+// Colour magnification only keeps the SMALLEST level of its Gaussian pyramid (the temporal window); G_1 is written by
+// k_down0_rows and read once by the next pyrDown: 12.4 MB per 1080p frame of traffic for an image nobody else reads.  This kernel
+// keeps k_down0_rows' strip walk for the first level (lane = one 4-pixel source group, DPP halo, 5-row register window) and runs the
+// second pyrDown on the level-1 pixels while they are in registers: a lane's two level-1 pixels (columns 2g, 2g + 1) plus three
+// neighbours by DPP give level-2 column g, whose horizontal sums slide down a second 5-row window.
+// Exactness: the planes are unscaled u8 values, so every level-1 value is k / 256 with k < 2^16 and every level-2 value k / 65536
+// with k < 2^24 -- all partial sums are exactly representable floats, and ANY summation order (fma included) gives the reference's
+// bits.  (From level 3 on the sums round and the order is pyrdown_tile's again: those levels stay with the generic kernels.)
+// Borders: BORDER_REFLECT_101 of the SOURCE comes from the mirrored row / group loads as in k_down0_rows; REFLECT_101 of LEVEL 1 is
+// a property of level-1 values -- columns -2, -1 are columns 2, 1 and column w1 is column w1 - 2 (per-lane selects in the border
+// lanes), rows -2, -1 are rows 2, 1 (the top strip starts at level-1 row 0 and mirrors its window) and rows >= h1 are copies of
+// window entries.  Requires w % 8 == 0 (w1 even, one level-2 column per source group) and buffer-addressable frames.
+constexpr int D01_THREADS = 256, D01_OUT = 60;      // level-2 columns per wave (lanes 2 .. 61)
+// strip height: a strip of r level-2 rows converts 4 r + 9 source rows; as down0_rows_choice
+inline int down01_rows_choice(int w2, int h2, long frames, long min_tasks, long* tasks_out) {
+    const long sx = (w2 + D01_OUT - 1) / D01_OUT;
+    int best = 8; long best_cost = -1, best_tasks = 0;
+    for (int r = 4; r <= 34; ++r) {
+        const long tasks = sx * ((h2 + r - 1) / r) * frames;
+        if (tasks < min_tasks) continue;
+        const long cost = ((tasks + 1023) / 1024) * (4 * r + 9);
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; best_tasks = tasks; }
+    }
+    *tasks_out = best_tasks;
+    return best;
+}
+struct D01Args {
+    const uint8_t* in; long in_stride, in_sstride; int w, h;
+    float* G2; int w2, h2, h1;
+    int strips_x, strips_y, ntasks, rows;
+};
+template <int TU>
+__global__ __launch_bounds__(D01_THREADS) void k_down01_rows(D01Args q) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int task = blockIdx.x * (D01_THREADS / 64) + wave;
+    if (task >= q.ntasks) return;
+    const int w = q.w, h = q.h, w2 = q.w2, h2 = q.h2, h1 = q.h1, rows = q.rows;
+    const int b = task / (q.strips_x * q.strips_y);
+    const int r = task - b * (q.strips_x * q.strips_y);
+    const int ty = r / q.strips_x, tx = r - ty * q.strips_x;
+    const int ngroups = w >> 2;                                    // == w2
+    const int g = tx * D01_OUT - 2 + lane;                          // source group = level-2 column of this lane
+    const bool left_mirror = g < 0, right_mirror = g >= ngroups;    // source REFLECT_101 mirrors of the edge groups (only g = -1, ngroups are used)
+    const int gl = left_mirror ? 0 : (right_mirror ? ngroups - 1 : g);
+    const bool first2 = g == 0, last2 = g == w2 - 1;               // level-1 REFLECT_101 lanes
+    const bool owner = lane >= 2 && lane <= 61 && g >= 0 && g < w2;
+    const unsigned in_stride = (unsigned)q.in_stride;
+    const BufRsrc rin = buf_rsrc(q.in + (size_t)b * q.in_sstride, in_stride * (unsigned)(h - 1) + (unsigned)w * 3u);
+    const unsigned voff = 12u * (unsigned)gl;
+    auto fetch = [&](int sy) __attribute__((always_inline)) { return buf_ld_b96(rin, voff, (unsigned)reflect101(sy, h) * in_stride); };
+    // horizontal level-1 sums of one source row at the lane's two level-1 columns (k_down0_rows' exchange)
+    auto hrow = [&](const B96 v, float (&ha)[3], float (&hb)[3]) __attribute__((always_inline)) {
+        const uint32_t pb[12] = {v.a & 255, (v.a >> 8) & 255, (v.a >> 16) & 255, v.a >> 24, v.b & 255, (v.b >> 8) & 255,
+                                 (v.b >> 16) & 255, v.b >> 24, v.c & 255, (v.c >> 8) & 255, (v.c >> 16) & 255, v.c >> 24};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float p0 = (float)pb[c], p1 = (float)pb[3 + c], p2 = (float)pb[6 + c], p3 = (float)pb[9 + c];
+            const float give2 = p2, give3 = left_mirror ? p1 : p3, give0 = right_mirror ? p2 : p0;
+            const float L2 = dpp_shr1(give2), L3 = dpp_shr1(give3), R0 = dpp_shl1(give0);
+            ha[c] = __builtin_fmaf(p0, 6.f, __builtin_fmaf(L3 + p1, 4.f, L2 + p2));
+            hb[c] = __builtin_fmaf(p2, 6.f, __builtin_fmaf(p1 + p3, 4.f, p0 + R0));
+        }
+    };
+    const int Y0 = ty * rows, Yend = Y0 + rows < h2 ? Y0 + rows : h2;
+    const bool top = Y0 == 0;
+    int rv = top ? 0 : 2 * Y0 - 2;                                 // next level-1 row to make
+    float a0[3], a1[3], a2[3], a3[3], a4[3], b0[3], b1[3], b2[3], b3[3], b4[3];
+    hrow(fetch(2 * rv - 2), a0, b0); hrow(fetch(2 * rv - 1), a1, b1); hrow(fetch(2 * rv), a2, b2);
+    // two alternating sets of prefetched source rows: the rows of level-1 row rv (set A), rv + 1 (set B), and so on -- a set is
+    // re-loaded right after its use for the level-1 row two steps later, so no register in flight is ever copied
+    B96 nA0 = fetch(2 * rv + 1), nA1 = fetch(2 * rv + 2), nB0 = fetch(2 * rv + 3), nB1 = fetch(2 * rv + 4);
+    // level-1 row rv from the source window -> its level-2 horizontal sums at column g (one value per channel)
+    auto l1 = [&](B96& n0, B96& n1, float (&H2)[3]) __attribute__((always_inline)) {
+        hrow(n0, a3, b3); hrow(n1, a4, b4);
+        n0 = fetch(2 * rv + 5); n1 = fetch(2 * rv + 6);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float va = __builtin_fmaf(a2[c], 6.f, __builtin_fmaf(a1[c] + a3[c], 4.f, a0[c] + a4[c])) * (1.f / 256.f);
+            const float vb = __builtin_fmaf(b2[c], 6.f, __builtin_fmaf(b1[c] + b3[c], 4.f, b0[c] + b4[c])) * (1.f / 256.f);
+            float Lm2 = dpp_shr1(va), Lm1 = dpp_shr1(vb), Rp = dpp_shl1(va);
+            Lm2 = sel(first2, Rp, Lm2); Lm1 = sel(first2, vb, Lm1);   // level-1 columns -2, -1 = columns 2, 1
+            Rp = sel(last2, va, Rp);                                  // level-1 column w1 = column w1 - 2
+            H2[c] = __builtin_fmaf(va, 6.f, __builtin_fmaf(Lm1 + vb, 4.f, Lm2 + Rp));
+            a0[c] = a2[c]; a1[c] = a3[c]; a2[c] = a4[c]; b0[c] = b2[c]; b1[c] = b3[c]; b2[c] = b4[c];
+        }
+        ++rv;
+    };
+    float w0[3] = {0.f, 0.f, 0.f}, w1[3] = {0.f, 0.f, 0.f}, w2r[3], w3[3], w4[3];
+    // an odd number of rows before the loop (1 for the top strip, 3 otherwise): the loop continues with set B, then A
+    if (top) l1(nA0, nA1, w2r);
+    else { l1(nA0, nA1, w0); l1(nB0, nB1, w1); l1(nA0, nA1, w2r); }
+    const size_t plane = (size_t)w2 * h2;
+    float* dst = q.G2 + (size_t)b * 3 * plane + g;
+    for (int Y = Y0; Y < Yend; ++Y) {
+        // window rows 2Y - 2 .. 2Y + 2 in w0, w1, w2r, w3, w4; rows past the last level-1 row are REFLECT_101 copies of window entries
+        // (row h1 + k = row h1 - 2 - k), but their source rows are still loaded and converted (static schedule; the results are dropped)
+        float t3[3], t4[3];
+        const int r3 = rv;
+        l1(nB0, nB1, t3);
+        const int r4 = rv;
+        l1(nA0, nA1, t4);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float e3 = t3[c], e4 = t4[c];
+            if (r3 >= h1) { const int k = 2 * h1 - 2 - r3 - (2 * Y - 2); e3 = k == 0 ? w0[c] : (k == 1 ? w1[c] : w2r[c]); }
+            if (r4 >= h1) { const int k = 2 * h1 - 2 - r4 - (2 * Y - 2); e4 = k == 0 ? w0[c] : (k == 1 ? w1[c] : (k == 2 ? w2r[c] : e3)); }
+            w3[c] = e3; w4[c] = e4;
+        }
+        if (top && Y == 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { w0[c] = w4[c]; w1[c] = w3[c]; }
+        }
+        if (owner) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                dst[c * plane + (size_t)Y * w2] = __builtin_fmaf(w2r[c], 6.f, __builtin_fmaf(w1[c] + w3[c], 4.f, w0[c] + w4[c])) * (1.f / 256.f);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { w0[c] = w2r[c]; w1[c] = w3[c]; w2r[c] = w4[c]; }
+    }
+}
+
 // ---- pyrDown of large float planes: wave strips, no LDS ---------------------------------------------
 // Every wave owns a strip of 128 output columns x `rows` output rows of one plane; a lane produces two
 // adjacent outputs per row.  The 7 source values a lane needs from a source row (columns 2x-2 .. 2x+4)

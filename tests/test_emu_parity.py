@@ -133,6 +133,8 @@ def test_riesz_emu_cutoff_change_gray_and_reset(lvm, po, emu):
 
 
 # ---- Colour ----------------------------------------------------------------------------------------
+# (at least 12 frames per clip: with a window of a few columns the ideal band-pass passes nothing, the magnified signal is zero
+# and neither the pyramid nor the up-chain arithmetic would influence the output -- checked by mutating the kernels)
 @pytest.mark.parametrize("w,h,levels,ch,fps", [(96, 64, 3, 3, 60.0), (135, 77, 4, 3, 30.0), (64, 48, 1, 3, 7.0),
                                                 (67, 131, 2, 1, 15.0)])
 def test_color_emu_bit_exact(lvm, po, emu, w, h, levels, ch, fps):
@@ -151,7 +153,7 @@ def test_color_emu_output_kernel_variants(lvm, po, emu, w, h, levels, rows, monk
     monkeypatch.setenv("LVM_COL_OUT_MIN_TASKS", "0")
     ck, pk = lvm.synth.config(3, (w, h, levels))
     ck["fps"] = 15.0; pk["framerate"] = 15.0
-    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 6, 0.0, exact=True)
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 12, 0.0, exact=True)
 
 
 @pytest.mark.parametrize("w,h,levels", [(516, 40, 2), (520, 52, 3), (1028, 36, 2), (256, 64, 3), (512, 128, 4)])
@@ -161,7 +163,7 @@ def test_color_emu_strip_kernel_border_lanes(lvm, po, emu, w, h, levels, monkeyp
     monkeypatch.setenv("LVM_COL_OUT_MIN_TASKS", "0")
     ck, pk = lvm.synth.config(3, (w, h, levels))
     ck["fps"] = 15.0; pk["framerate"] = 15.0
-    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 5, 0.0, exact=True)
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 12, 0.0, exact=True)
 
 
 @pytest.mark.parametrize("fuse2", ["0", "1"])
@@ -174,7 +176,7 @@ def test_color_emu_previous_strip_kernels_still_match(lvm, po, emu, w, h, levels
     monkeypatch.setenv("LVM_COL_OUT_MIN_TASKS", "0")
     ck, pk = lvm.synth.config(3, (w, h, levels))
     ck["fps"] = 15.0; pk["framerate"] = 15.0
-    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 5, 0.0, exact=True)
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 12, 0.0, exact=True)
 
 
 def test_color_emu_one_level_uses_the_single_pyrup_kernels(lvm, po, emu, monkeypatch):
@@ -182,7 +184,29 @@ def test_color_emu_one_level_uses_the_single_pyrup_kernels(lvm, po, emu, monkeyp
     monkeypatch.setenv("LVM_COL_OUT_MIN_TASKS", "0")
     ck, pk = lvm.synth.config(3, (128, 48, 1))
     ck["fps"] = 15.0; pk["framerate"] = 15.0
-    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 5, 0.0, exact=True)
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 12, 0.0, exact=True)
+
+
+@pytest.mark.parametrize("rows", ["1", "4", "7", "17"])
+@pytest.mark.parametrize("w,h,levels", [(264, 90, 3), (96, 77, 2), (512, 128, 4), (520, 52, 3), (64, 48, 2), (128, 37, 3)])
+def test_color_emu_first_two_levels_in_one_pass(lvm, po, emu, w, h, levels, rows, monkeypatch):
+    """k_down01_rows (u8 -> level 2 without writing level 1; large launches only in production, forced here): strips of 1 ... 17
+    level-2 rows -- top strip (mirrored level-1 rows -2, -1), interior strips, bottom rows with an even and an odd number of level-1
+    rows (rows h1, h1 + 1 are window copies), one and several strips per row, the level-1 border columns."""
+    monkeypatch.setenv("LVM_D0_MIN_TASKS", "0")
+    monkeypatch.setenv("LVM_COL_DOWN01_ROWS", rows)
+    monkeypatch.setenv("LVM_COL_OUT_MIN_TASKS", "0")
+    ck, pk = lvm.synth.config(3, (w, h, levels))
+    ck["fps"] = 15.0; pk["framerate"] = 15.0
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 12, 0.0, exact=True)    # (12 frames: the band-pass passes something)
+
+
+def test_color_emu_two_level_pass_can_be_switched_off(lvm, po, emu, monkeypatch):
+    monkeypatch.setenv("LVM_D0_MIN_TASKS", "0")
+    monkeypatch.setenv("LVM_COL_DOWN01", "0")
+    ck, pk = lvm.synth.config(3, (264, 90, 3))
+    ck["fps"] = 15.0; pk["framerate"] = 15.0
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 12, 0.0, exact=True)
 
 
 def test_color_emu_wide_band_and_fps_change(lvm, po, emu):

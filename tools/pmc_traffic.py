@@ -15,7 +15,7 @@ NAMES = {  # kernel symbol prefix -> bench.py report name (default flavour: FL_L
     "k_lab_planes": "lab_lut", "k_lap_up<false, 1>": "lap_up_l1", "k_lap_iir_levels": "lap_iir", "k_lap_collapse": "lap_collapse", "k_pyr_down_rows": "pyr_down_rows_l1",
     "k_rz_final<true, 0, true, true, false>": "rz_final", "k_rz_blur_amp4<false>": "rz_blur_amp", "k_rz_blur_strips": "rz_blur_amp", "k_rz_phase4<false>": "rz_phase", "k_rz_phase<false>": "rz_phase_small",
     "k_rz_split_rows": "rz_split_l0", "k_col_out_rows<true, false>": "col_out", "k_col_out_rows<false, false>": "col_minmax",
-    "k_col_out_strips<true, false>": "col_out_u2", "k_col_out_strips<false, false>": "col_minmax_u2",
+    "k_down01_rows": "col_down01", "k_col_out_strips<true, false>": "col_out_u2", "k_col_out_strips<false, false>": "col_minmax_u2",
 }
 HERE = os.path.dirname(os.path.abspath(__file__))
 
