@@ -275,6 +275,31 @@ def test_color_small(lvm, po, hip, w, h, levels, ch, fps):
     print("color", (w, h, levels, ch, fps), "worst", worst)
 
 
+@pytest.mark.parametrize("rows", ["4", "17"])
+@pytest.mark.parametrize("w,h,levels", [(320, 180, 4), (264, 90, 3), (520, 77, 3)])
+def test_color_two_level_first_pass_on_the_gpu(lvm, po, hip, w, h, levels, rows, monkeypatch):
+    """k_down01_rows (production: launches of >= 4096 strips) forced onto small frames on the GPU: strip heights, an odd number of
+    level-1 rows (77 -> 39), several strips per row; and k_col_out_strips on the same frames (bit-exactness is the emulation suite's
+    job, this is the hardware run of the same code: DPP, ds_bpermute, buffer loads / stores, constant-address-space tables)."""
+    monkeypatch.setenv("LVM_D0_MIN_TASKS", "0")
+    monkeypatch.setenv("LVM_COL_DOWN01_ROWS", rows)
+    monkeypatch.setenv("LVM_COL_OUT_MIN_TASKS", "0")
+    ck, pk = lvm.synth.config(3, (w, h, levels))
+    ck["fps"] = 15.0; pk["framerate"] = 15.0
+    run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 24, FLOAT_TOL)
+
+
+@pytest.mark.parametrize("fuse2", ["0", "1"])
+def test_color_previous_strip_kernels_on_the_gpu(lvm, po, hip, fuse2, monkeypatch):
+    """LVM_COL_OUT_LEAN=0: k_col_out_rows (fallback of k_col_out_strips) still matches."""
+    monkeypatch.setenv("LVM_COL_OUT_LEAN", "0")
+    monkeypatch.setenv("LVM_COL_OUT_FUSE2", fuse2)
+    monkeypatch.setenv("LVM_COL_OUT_MIN_TASKS", "0")
+    ck, pk = lvm.synth.config(3, (320, 180, 4))
+    ck["fps"] = 15.0; pk["framerate"] = 15.0
+    run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 24, FLOAT_TOL)
+
+
 def test_color_1080p_window_fill(lvm, po, hip):
     """BASELINE.json configs[3] geometry (1080p, 6 levels, fps 60 => T = 128): run past the point
     where the window is full and starts rolling."""
