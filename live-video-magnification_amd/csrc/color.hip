@@ -1032,6 +1032,8 @@ struct ColorState : ModeState {
     bool co_rows_ok = false;         // the vectorised output kernel's LDS tile covers every output tile
     bool thin_dft = true;            // thread-per-row DFT for narrow bands (LVM_COL_THIN_DFT=0: wave-per-row kernel)
     long out_min_tasks = 2048;       // strips are shortened until a launch has this many (LVM_COL_OUT_MIN_TASKS)
+    long out_min_tasks_lean = 900;   // ... k_col_out_strips: ~1 wave per SIMD is enough (per-frame 1080p: 960 strips of 9 rows, min/max pass 31 -> 21 us:
+                                     // fewer strip start-ups and fewer atomics on the frame's 64 min/max cells)
     bool up_rows = true;             // barrier-free pyrUp of the up chain (LVM_COL_UP_ROWS=0: tiled k_pyr_up)
     bool d0_rows_on = true;          // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
     bool d01_on = true;              // first TWO pyramid levels in one pass for large launches (LVM_COL_DOWN01=0: level 1 through HBM)
@@ -1293,7 +1295,8 @@ static void col_up_out(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs&
     if (vec4 && st->out_rows > 0) {
         const int sx = (io.w + 255) / 256;
         int rows = lean ? st->out_rows_lean : st->out_rows;
-        while (rows > 2 && (long)sx * ((io.h + rows - 1) / rows) * NZ < st->out_min_tasks) rows >>= 1;
+        const long min_tasks = lean ? st->out_min_tasks_lean : st->out_min_tasks;
+        while (rows > 2 && (long)sx * ((io.h + rows - 1) / rows) * NZ < min_tasks) rows >>= 1;
         const int sy = (io.h + rows - 1) / rows;
         const long ntasks = (long)sx * sy * NZ;
         const dim3 g2((unsigned)((ntasks + 3) / 4));
@@ -1336,7 +1339,7 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         if (const char* e = std::getenv("LVM_COL_OUT_LEAN")) st->out_lean = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_COL_DOWN01")) st->d01_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_COL_DOWN01_ROWS")) st->d01_rows_forced = std::atoi(e);
-        if (const char* e = std::getenv("LVM_COL_OUT_MIN_TASKS")) st->out_min_tasks = std::atol(e);
+        if (const char* e = std::getenv("LVM_COL_OUT_MIN_TASKS")) st->out_min_tasks = st->out_min_tasks_lean = std::atol(e);
         if (const char* e = std::getenv("LVM_COL_THIN_MIN_FRAMES")) st->thin_min_frames = std::atoi(e);
         if (const char* e = std::getenv("LVM_ROWS_MIN_ELEMS")) st->rows_min_elems = std::atol(e);
         int rc = color_alloc(c, st, io.w, io.h, io.channels, levels);
