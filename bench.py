@@ -710,6 +710,16 @@ def sub_records(lvm, torch, np, args, cfg_idx, small, local_rank, rank, world, d
         v = world * Bn * Kq / dtq
         pfs["B%d" % Bn] = {"value": round(v, 2), "unit": "frames/s", "streams": Bn, "frames_per_call": 1, "us_per_frame": round(1e6 * dtq / (Kq * Bn), 3),
                            "frame_roofline_frac": round(b_alg1 * v / world / (HBM_PEAK_GBS * 1e9), 5)}
+        if Bn == 4 and R.pk["mode"] == lvm.synth.MODE_LAPLACE:
+            # the same calls with the library's depth-1 cross-frame pipeline (lvm_set_pipeline: the down-sweep of call t runs on a
+            # second stream under the up-sweep of call t - 1; the output of call t is complete once call t + 1 -- or lvm_flush --
+            # has been enqueued: a throughput schedule, NOT the one-call latency surface above)
+            Rp.ctx.set_pipeline(1)
+            dtp = timed_run(lvm, torch, Rp, Kq, 16, dist, red_dev)
+            Rp.ctx.set_pipeline(0)
+            vp = world * Bn * Kq / dtp
+            pfs["B4_pipeline_depth1"] = {"value": round(vp, 2), "unit": "frames/s", "streams": Bn, "frames_per_call": 1, "us_per_frame": round(1e6 * dtp / (Kq * Bn), 3),
+                                         "note": "output of call t complete when call t + 1 (or lvm_flush) is enqueued"}
         Rp.close()
         del Rp
         torch.cuda.empty_cache()
