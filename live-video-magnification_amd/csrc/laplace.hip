@@ -960,7 +960,8 @@ struct LaplaceState : ModeState {
     uint16_t* iLt = nullptr; uint32_t* iabt = nullptr;
     int split_min_nt = 1;                 // frames per launch from which levels >= 2 run as IIR + collapse launches (LVM_LAP_SPLIT_MIN_NT)
     long fin_min_tasks = 4096;            // strips are shortened until a launch has this many of them (LVM_FIN_MIN_TASKS)
-    long rows_min_elems = 1 << 20;        // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
+    long rows_min_elems = 2000000;        // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS): 32-frame batches keep the strips on
+                                          // levels 1-3 (3.1 M at level 3), four streams per per-frame call take the two-level kernel from level 2 (one launch less)
     int split_levels = 1;                 // temporal batches: levels >= 2 as one IIR launch + one collapse launch (LVM_LAP_SPLIT=0: level-by-level chain)
     int up_rows4 = 0;                     // large launches: k_lap_up_rows<4, D> instead of the tiled kernel (LVM_UP_ROWS4=1|2 = ring depth)
     int up_rows = 1;                      // barrier-free k_lap_up_rows for the steady state (LVM_UP_ROWS=0: tiled k_lap_up)
@@ -1198,7 +1199,8 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     int l = 1;
     while (l < down_end) {          // G_l -> next levels, three (or two) per launch when possible
         const int left = down_end - l;
-        if (st->g[l].w % 4 == 0 && (long)st->g[l].n * planes >= st->rows_min_elems) {
+        // (level 1 keeps the strips from half the size: a single 1080p stream per call, 1.55 M, was measured better with them)
+        if (st->g[l].w % 4 == 0 && (long)st->g[l].n * planes >= (l == 1 ? st->rows_min_elems / 2 : st->rows_min_elems)) {
             // large planes (temporal batches / many streams): barrier-free wave strips, one level per launch
             const LevelGeom &a = st->g[l], &b = st->g[l + 1];
             const int sx = (b.w + 127) / 128;
