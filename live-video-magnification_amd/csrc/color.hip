@@ -852,7 +852,7 @@ __device__ __forceinline__ void col_out_strip(const OutArgs& a, int b, int tx, i
         for (int c = 0; c < 3; ++c) {
             f2 va, vb;                                             // V columns (i0 - 1, i0) and (i0 + 1, i0 + 2)
             if ((vy & 1) == 0) { va = ((P.a[c] + Q.a[c] * bc2(6.f)) + R.a[c]) * bc2(1.f / 64.f); vb = ((P.b[c] + Q.b[c] * bc2(6.f)) + R.b[c]) * bc2(1.f / 64.f); }
-            else { va = ((Q.a[c] + R.a[c]) * bc2(4.f)) * bc2(1.f / 64.f); vb = ((Q.b[c] + R.b[c]) * bc2(4.f)) * bc2(1.f / 64.f); }
+            else { va = (Q.a[c] + R.a[c]) * bc2(1.f / 16.f); vb = (Q.b[c] + R.b[c]) * bc2(1.f / 16.f); }   // ((x * 4) * (1/64): two exact power-of-two scalings = one)
             const f2 c01 = mk2(va[1], vb[0]);
             o.xz[c] = (va + c01 * bc2(6.f)) + vb;                   // x = s[-1] + s0*6 + s1, z = s0 + s1*6 + s2
             o.yw[c] = (c01 + vb) * bc2(4.f);                        // y = (s0 + s1)*4,       w = (s1 + s2)*4
@@ -894,15 +894,15 @@ __device__ __forceinline__ void col_out_strip(const OutArgs& a, int b, int tx, i
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             T.xz[c] = A0.xz[c] + X.xz[c] * bc2(6.f); T.yw[c] = A0.yw[c] + X.yw[c] * bc2(6.f);
-            O0.xz[c] = ((A0.xz[c] + X.xz[c]) * bc2(4.f)) * bc2(1.f / 64.f); O0.yw[c] = ((A0.yw[c] + X.yw[c]) * bc2(4.f)) * bc2(1.f / 64.f);
+            O0.xz[c] = (A0.xz[c] + X.xz[c]) * bc2(1.f / 16.f); O0.yw[c] = (A0.yw[c] + X.yw[c]) * bc2(1.f / 16.f);
         }
     }
     auto odd_row = [&](const HRowP& p, const HRowP& q) __attribute__((always_inline)) {   // row 2 j + 1 from H rows j, j + 1
         URowP u;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            u.xz[c] = ((p.xz[c] + q.xz[c]) * bc2(4.f)) * bc2(1.f / 64.f);
-            u.yw[c] = ((p.yw[c] + q.yw[c]) * bc2(4.f)) * bc2(1.f / 64.f);
+            u.xz[c] = (p.xz[c] + q.xz[c]) * bc2(1.f / 16.f);      // = ((p + q) * 4) * (1/64): both scalings are exact
+            u.yw[c] = (p.yw[c] + q.yw[c]) * bc2(1.f / 16.f);
         }
         return u;
     };
