@@ -430,10 +430,11 @@ def test_riesz_temporal_batches_device(lvm, po, hip, w, h, levels, ns, nf):
     ctx.close()
 
 
-def test_color_temporal_batches_device(lvm, po, hip):
-    """Colour mode, fps 15 (window of 32 columns): per-frame until the window is full, then batches."""
+@pytest.mark.parametrize("w,h,levels,ns,calls", [(320, 180, 4, 2, (34, 8, 13, 5)), (1920, 1080, 6, 2, (34, 32))])
+def test_color_temporal_batches_device(lvm, po, hip, w, h, levels, ns, calls):
+    """Colour mode, fps 15 (window of 32 columns): per-frame until the window is full, then batches.  The 1080p case is the production
+    shape of the round-3 kernels: two streams x 32 frames per launch take k_down01_rows unforced and k_col_out_strips with 36-row strips."""
     import torch
-    w, h, levels, ns = 320, 180, 4, 2
     ck, pk = lvm.synth.config(3, (w, h, levels))
     ck["fps"] = 15.0; pk["framerate"] = 15.0; pk["coLow"] = 0.5; pk["coHigh"] = 2.0
     clips = [lvm.synth.Clip(seed=1234 + s, **ck) for s in range(ns)]
@@ -444,7 +445,7 @@ def test_color_temporal_batches_device(lvm, po, hip):
     stream = torch.cuda.current_stream().cuda_stream
     fb = w * h * 3
     t = 0
-    for nf in (34, 8, 13, 5):
+    for nf in calls:
         fin = np.stack([np.stack([c.frame(t + f) for c in clips]) for f in range(nf)])
         d_in = torch.from_numpy(fin).cuda()
         d_out = torch.zeros_like(d_in)
