@@ -370,7 +370,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # One rank per GPU under the launcher (torch.distributed.run sets WORLD_SIZE, also for --nproc-per-node 1): the process
+    # group exists at EVERY world size then, so that the barrier and the MAX-reduce of the timed region run through RCCL
+    # (backend "nccl" on ROCm) at N = 1 exactly as they will at N = 8.  A plain `python bench.py` has no rendezvous and none.
+    if world > 1 or ("WORLD_SIZE" in os.environ and "MASTER_ADDR" in os.environ):
         import torch.distributed as dist_mod
         dist = dist_mod
         if args.dist_backend == "nccl":
@@ -378,6 +381,14 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
     red_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
+    dist_info = {"initialized": dist is not None, "backend": (dist.get_backend() if dist is not None else None),
+                 "world_size": (dist.get_world_size() if dist is not None else 1)}
+    if dist is not None:
+        # first contact: a device-tensor all-reduce (SUM of ones = the number of ranks RCCL really connected) + barrier
+        one = torch.ones(1, dtype=torch.int32, device=red_dev)
+        dist.all_reduce(one)
+        dist.barrier()
+        dist_info["ranks_seen_by_allreduce"] = int(one.item())
 
     lvm = importlib.import_module("live-video-magnification_amd")
     cfg_idx = MODES[args.mode]
@@ -477,9 +488,12 @@ def main():
             ref_check = {"frames": len(rkeep), "u8_max_diff": dmax, "u8_identical_min": round(fmin, 6), "fps": round(nref / rdt, 3)}
             rt = po.RefOracle.recover_lab_lut()
             ref_check["lab_lut_equals_opencv"] = None if rt is None else bool(np.array_equal(rt, R.ctx.lab_lut()))
+        _, _, cdt1 = oracle_replay(po, np, host, pk, ring, 8, [], 1)     # the same clip's first 8 frames on ONE thread
         cpu = {"value": round(n_verify / cdt, 3), "unit": "frames/s", "cores": nthreads, "kind": "port",
+               "host_cores": os.cpu_count(), "threads_used": nthreads,
+               "single_thread": {"value": round(8 / cdt1, 3), "unit": "frames/s", "cores": 1, "sample": "first 8 frames of the same clip"},
                "sample": "%d frames of the same %dx%d L%d %s clip (the verification replay), CPU oracle = restatement of the "
-                         "reference, OpenMP over rows" % (n_verify, w, h, levels, args.mode),
+                         "reference, OpenMP over rows, %d threads of the host's %s cores" % (n_verify, w, h, levels, args.mode, nthreads, os.cpu_count()),
                "reference_probe": probe_reference(), "real_reference_check": ref_check}
         if ref_check:
             cpu.update({"kind": "reference", "value": ref_check["fps"], "cores": 1,
@@ -490,7 +504,10 @@ def main():
         nthreads = max(1, min(16, os.cpu_count() or 1))
         host = R.d_in[:, 0].cpu().numpy()
         _, _, cdt = oracle_replay(po, np, host, pk, ring, 64, [], nthreads)
+        _, _, cdt1 = oracle_replay(po, np, host, pk, ring, 8, [], 1)
         cpu = {"value": round(64 / cdt, 3), "unit": "frames/s", "cores": nthreads, "kind": "port",
+               "host_cores": os.cpu_count(), "threads_used": nthreads,
+               "single_thread": {"value": round(8 / cdt1, 3), "unit": "frames/s", "cores": 1, "sample": "first 8 frames of the same clip"},
                "sample": "64 frames of the same clip, CPU oracle", "reference_probe": probe_reference()}
 
     # ---- per-kernel timing pass (HIP events on the launch stream) -> roofline ----
@@ -568,7 +585,9 @@ def main():
     b_bat = batched_frame_bytes(args.mode, w, h, ch, levels, T, Twin)
 
     # ---- gather per-rank facts (tests check value == world * B * K / max dt and every rank's verification) ----
-    rank_facts = [{"rank": rank, "verified": verified, "stream_ids": ids}]
+    props = torch.cuda.get_device_properties(local_rank)
+    rank_facts = [{"rank": rank, "verified": verified, "stream_ids": ids, "device": "cuda:%d" % local_rank,
+                   "device_name": props.name, "device_uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()}]
     if dist is not None:
         gathered = [None] * world
         dist.all_gather_object(gathered, rank_facts[0])
@@ -602,6 +621,7 @@ def main():
             "frame_alg_bytes": b_alg, "frame_roofline_frac": round(frame_frac, 5),
             "frame_batched_alg_bytes": round(b_bat), "frame_batched_roofline_frac": round(b_bat * (fps / world / B) / (HBM_PEAK_GBS * 1e9), 5),
             "timed_seconds_max_over_ranks": dt,
+            "dist": dist_info,
             "ranks": rank_facts,
             "kernels": kernels,
         }

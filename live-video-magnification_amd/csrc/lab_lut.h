@@ -43,12 +43,17 @@ __device__ __forceinline__ int lut_dot2(uint32_t pair, uint32_t wts, int acc) {
 // (lo16(d), lo16(e)) and (hi16(d), hi16(e)) of two dwords
 __device__ __forceinline__ uint32_t lut_lo2(uint32_t d, uint32_t e) { return __builtin_amdgcn_perm(e, d, 0x05040100u); }
 __device__ __forceinline__ uint32_t lut_hi2(uint32_t d, uint32_t e) { return __builtin_amdgcn_perm(e, d, 0x07060302u); }
+// 24-bit x 24-bit -> low 32 bits as ONE full-rate v_mul_u32_u24.  Spelled as an instruction: a plain product is re-associated by the
+// compiler ((x0 y0) wz -> (wz x0) y0, whose intermediate no longer fits 24 bits) and then becomes the quarter-rate v_mul_lo_u32 --
+// four of them per pixel in round 3's ISA, ~12 issue slots of the conversion's ~94
+__device__ __forceinline__ uint32_t lut_mul24(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 #else           // tests/emu (g++): the same values spelled out
 __device__ __forceinline__ int lut_dot2(uint32_t pair, uint32_t wts, int acc) {
     return acc + (int)(int16_t)(pair & 0xffff) * (int)(int16_t)(wts & 0xffff) + (int)(int16_t)(pair >> 16) * (int)(int16_t)(wts >> 16);
 }
 __device__ __forceinline__ uint32_t lut_lo2(uint32_t d, uint32_t e) { return (d & 0xffffu) | (e << 16); }
 __device__ __forceinline__ uint32_t lut_hi2(uint32_t d, uint32_t e) { return (d >> 16) | (e & 0xffff0000u); }
+__device__ __forceinline__ uint32_t lut_mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 #endif
 
 // fine grid coordinate of a u8 channel value: bits 4.. = cell, bits 0..3 = weight of the upper neighbour
@@ -77,7 +82,8 @@ __device__ __forceinline__ void lut_lab_int(uint32_t B, uint32_t G, uint32_t R, 
     const uint32_t wz = (16u - z) | (z << 16);                 // (16 - z, z) as an int16 pair
     const uint32_t x0 = 16u - x, y0 = 16u - y;
     // w(dp, dq) * (16 - z | z): each half <= 4096, no carry between the halves
-    const uint32_t w00 = (x0 * y0) * wz, w10 = (x * y0) * wz, w01 = (x0 * y) * wz, w11 = (x * y) * wz;
+    const uint32_t w00 = lut_mul24(lut_mul24(x0, y0), wz), w10 = lut_mul24(lut_mul24(x, y0), wz), w01 = lut_mul24(lut_mul24(x0, y), wz),
+                   w11 = lut_mul24(lut_mul24(x, y), wz);
     const int rnd = 1 << 11;                                  // CV_DESCALE(v, 12) = (v + 2048) >> 12
     ia = lut_dot2(lut_lo2(d11, e11), w11, lut_dot2(lut_lo2(d01, e01), w01, lut_dot2(lut_lo2(d10, e10), w10, lut_dot2(lut_lo2(d00, e00), w00, rnd)))) >> 12;
     ib = lut_dot2(lut_hi2(d11, e11), w11, lut_dot2(lut_hi2(d01, e01), w01, lut_dot2(lut_hi2(d10, e10), w10, lut_dot2(lut_hi2(d00, e00), w00, rnd)))) >> 12;

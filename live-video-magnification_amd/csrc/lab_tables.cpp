@@ -60,10 +60,14 @@ void build_lab_tables(float gamma_u8[256], float invgamma[4096], float fwd[9], f
     static const double D65[3] = {0.950456, 1.0, 1.088754};
     float f[kTab + 1], g[kTab + 1];
     static float gam[kTab * 4];
+    // color_lab.cpp applyGamma / applyInvGamma: the argument and the binary32 constants (809/20000, 7827/2500000, 323/25,
+    // 12/5, 11/200 as softfloat quotients) are promoted to softdouble, pow runs in binary64, ONE rounding to binary32
+    const double thr = (double)(809.f / 20000.f), ithr = (double)(7827.f / 2500000.f), low = (double)(323.f / 25.f),
+                 power = (double)(12.f / 5.f), shift = (double)(11.f / 200.f);
     for (int i = 0; i <= kTab; ++i) {
-        const double x = (double)i / kTab;
-        f[i] = (float)(x <= 0.04045 ? x / 12.92 : std::pow((x + 0.055) / 1.055, 2.4));
-        g[i] = (float)(x <= 0.0031308 ? x * 12.92 : 1.055 * std::pow(x, 1.0 / 2.4) - 0.055);
+        const double x = (double)((float)i * (1.0f / kTab));
+        f[i] = (float)(x <= thr ? x / low : std::pow((x + shift) / (1.0 + shift), power));
+        g[i] = (float)(x <= ithr ? x * low : std::pow(x, 1.0 / power) * (1.0 + shift) - shift);
     }
     spline_build(f, kTab, gam);
     spline_build(g, kTab, invgamma);
@@ -89,9 +93,9 @@ void build_lab_tables(float gamma_u8[256], float invgamma[4096], float fwd[9], f
 // ---- OpenCV 4's RGB2Lab interpolation table (color_lab.cpp initLabTabs, the enableRGB2LabInterpolation block) ----------
 // OpenCV builds the 33^3 table with its softfloat type, i.e. IEEE binary32 operations rounded one by one; the same
 // sequence is restated here on native floats (this translation unit is built with -ffp-contract=off):
-//   R, G, B = applyGamma(p / 32): x <= 809/20000 ? x / (323/25) : pow((x + 11/200) / (1 + 11/200), 12/5), where softfloat's
-//   pow is exp(y * log(x)) with log, the product and exp each rounded to binary32 (log / exp are evaluated in binary64
-//   inside and rounded once: restated with the C library's double log / exp);
+//   R, G, B = applyGamma(p / 32): x <= 809/20000 ? x / (323/25) : pow((x + 11/200) / (1 + 11/200), 12/5), evaluated in
+//   softdouble on the promoted argument and binary32 constants and rounded once (sf_gamma below; the C library's pow stands
+//   in for softdouble's, whose ~1e-15 relative error changes a binary32 result with p ~ 1e-8 per node);
 //   X, Y, Z = R C0 + G C1 + B C2 (coefficients = double(sRGB2XYZ_D65 * 1 / D65) rounded to binary32);
 //   f(t) = t > 216/24389 ? cbrt(t) : fma(t, 841/108, 16/116)   (softfloat cbrt = the cv::cubeRoot polynomial);
 //   L = Y > 216/24389 ? 116 fY - 16 : Y * (24389/27);  a = 500 (fX - fY);  b = 200 (fY - fZ);
@@ -121,13 +125,13 @@ float cube_root_f32(float value) {              // cv::cubeRoot / softfloat f32_
     float out; std::memcpy(&out, &r, 4);
     return out;
 }
+// applyGamma(softfloat): "softdouble xd = x; xd <= gammaThreshold ? xd / gammaLowScale : pow((xd + gammaXshift) / (one + gammaXshift),
+// softdouble(gammaPower))" -- promoted argument, promoted binary32 constants, binary64 pow, one rounding (round 4; the three
+// binary32 operations of rounds 1-3 moved ~20 of the 107 811 entries by one unit)
 float sf_gamma(float x) {
     const float thr = 809.f / 20000.f, low = 323.f / 25.f, shift = 11.f / 200.f, power = 12.f / 5.f;
-    if (x <= thr) return x / low;
-    const float base = (x + shift) / (1.f + shift);
-    const float lg = (float)std::log((double)base);
-    const float pr = power * lg;
-    return (float)std::exp((double)pr);
+    const double xd = (double)x;
+    return (float)(xd <= (double)thr ? xd / (double)low : std::pow((xd + (double)shift) / (1.0 + (double)shift), (double)power));
 }
 }  // namespace
 

@@ -646,6 +646,42 @@ struct FinArgs {
     LabCoef lab; float ca; int strips_x, strips_y, nstreams, rows;
     float* dbg; LabPlanes lp;
 };
+// One output row of 4 pixels: Lab(in) + [1, ca, ca] * motion -> Lab2BGR -> u8 (MagnifyCore.hpp:143-153).  m = the motion image of the
+// row (EXACT: scaled by 1/64 as pyrUp does; otherwise the unscaled vertical sum, whose power-of-two scale `msc` is folded into the
+// add -- fma(m, 2^-k, L) rounds exactly like L + m * 2^-k).  dbg_px: where the float pixels go (lvm_debug_keep_float) or null.
+template <bool MOTION, bool DBG, int FL>
+__device__ __forceinline__ void lap_emit_row(const Raw4 pin, const float (&m)[3][4], const float msc, const float ca, const LabCoef& lab,
+                                             const float* s_igt, const float* s_gam, float* dbg_px, uint8_t* out_px) {
+    constexpr bool EXACT = fl_exact(FL);
+    float L4[4], a4[4], b4[4];
+    raw4_to_lab<FL>(pin, s_gam, lab, L4, a4, b4);
+    float ov[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float o0, o1, o2;
+        float L = L4[k], a = a4[k], bb = b4[k];
+        if (MOTION) {
+            if (EXACT) { L = L + m[0][k]; a = a + m[1][k] * ca; bb = bb + m[2][k] * ca; }
+            else {
+                L = __builtin_fmaf(m[0][k], msc, L);
+                a = __builtin_fmaf(m[1][k], msc * ca, a); bb = __builtin_fmaf(m[2][k], msc * ca, bb);
+            }
+        }
+        lab_to_bgr<EXACT>(L, a, bb, EXACT ? lab.inv : lab.inv1024, s_igt, o0, o1, o2);
+        if (DBG && dbg_px) { float* d = dbg_px + k * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
+        if (EXACT) {
+            ov[3 * k] = o0 * 255.0f + lab.a255; ov[3 * k + 1] = o1 * 255.0f + lab.a255; ov[3 * k + 2] = o2 * 255.0f + lab.a255;
+        } else {   // fma(o, 255, 1/255) differs from mul + add only far below the rounding step
+            ov[3 * k] = __builtin_fmaf(o0, 255.0f, lab.a255); ov[3 * k + 1] = __builtin_fmaf(o1, 255.0f, lab.a255);
+            ov[3 * k + 2] = __builtin_fmaf(o2, 255.0f, lab.a255);
+        }
+    }
+    Px4 qo;
+    qo.a = pack_u8x4(ov[0], ov[1], ov[2], ov[3]);
+    qo.b = pack_u8x4(ov[4], ov[5], ov[6], ov[7]);
+    qo.c = pack_u8x4(ov[8], ov[9], ov[10], ov[11]);
+    *reinterpret_cast<Px4*>(out_px) = qo;
+}
 // one wave strip (task) of the last kernel; s_igt = inverse-gamma spline in LDS, s_gam = gamma table (analytic flavour)
 template <bool MOTION, bool DBG, int FL>     // DBG: also store the float frame (lvm_debug_keep_float); a per-pixel branch
 __device__ __forceinline__ void lap_final_strip(const FinArgs& q, int task, int lane, const float* s_igt, const float* s_gam) {
@@ -694,38 +730,9 @@ __device__ __forceinline__ void lap_final_strip(const FinArgs& q, int task, int 
     };
     const int yend = (y0 + rows < h) ? y0 + rows : h;
     int gy = y0, j = y0 >> 1;
-    // one output row: colour math of 4 pixels; m = the motion image of the row (EXACT: scaled by 1/64 as
-    // pyrUp does; otherwise the unscaled vertical sum, whose power-of-two scale `msc` is folded into the
-    // add -- fma(m, 2^-k, L) rounds exactly like L + m * 2^-k)
     auto emit = [&](const Raw4 pin, const float (&m)[3][4], const float msc) __attribute__((always_inline)) {
-        float L4[4], a4[4], b4[4];
-        raw4_to_lab<FL>(pin, s_gam, lab, L4, a4, b4);
-        float ov[12];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float o0, o1, o2;
-            float L = L4[k], a = a4[k], bb = b4[k];
-            if (MOTION) {
-                if (EXACT) { L = L + m[0][k]; a = a + m[1][k] * ca; bb = bb + m[2][k] * ca; }
-                else {
-                    L = __builtin_fmaf(m[0][k], msc, L);
-                    a = __builtin_fmaf(m[1][k], msc * ca, a); bb = __builtin_fmaf(m[2][k], msc * ca, bb);
-                }
-            }
-            lab_to_bgr<EXACT>(L, a, bb, EXACT ? lab.inv : lab.inv1024, s_igt, o0, o1, o2);
-            if (DBG && dbg && b == 0) { float* d = dbg + ((size_t)gy * w + gx + k) * 3; d[0] = o0; d[1] = o1; d[2] = o2; }
-            if (EXACT) {
-                ov[3 * k] = o0 * 255.0f + lab.a255; ov[3 * k + 1] = o1 * 255.0f + lab.a255; ov[3 * k + 2] = o2 * 255.0f + lab.a255;
-            } else {   // fma(o, 255, 1/255) differs from mul + add only far below the rounding step
-                ov[3 * k] = __builtin_fmaf(o0, 255.0f, lab.a255); ov[3 * k + 1] = __builtin_fmaf(o1, 255.0f, lab.a255);
-                ov[3 * k + 2] = __builtin_fmaf(o2, 255.0f, lab.a255);
-            }
-        }
-        Px4 qo;
-        qo.a = pack_u8x4(ov[0], ov[1], ov[2], ov[3]);
-        qo.b = pack_u8x4(ov[4], ov[5], ov[6], ov[7]);
-        qo.c = pack_u8x4(ov[8], ov[9], ov[10], ov[11]);
-        *reinterpret_cast<Px4*>(dst + (size_t)gy * out_stride + xoff) = qo;
+        lap_emit_row<MOTION, DBG, FL>(pin, m, msc, ca, lab, s_igt, s_gam, (DBG && dbg && b == 0) ? dbg + ((size_t)gy * w + gx) * 3 : nullptr,
+                                      dst + (size_t)gy * out_stride + xoff);
     };
     // two output rows (2j, 2j+1) from the window rows A = j-1, B = j, C = j+1; afterwards A holds row
     // j+2, i.e. the window has rotated to (B, C, A).  Returns false when the strip is finished.
@@ -795,37 +802,276 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(FinArgs q) {
         lap_final_strip<MOTION, DBG, FL>(q, task, lane, s_igt, s_gam);
 }
 
-// ---- last kernel of chunk k + first kernel of chunk k + 1 in ONE launch (round 3) -----------------------------------
-// The first kernel of a batch (k_down0_lut_rows) is bound by the Lab table look-ups -- LDS, texture-address and VALU pipes,
-// hardly any HBM traffic -- the last one (k_lap_final_v4) by HBM.  Run one after the other they cost 8.0 + 6.2 us per 1080p
-// frame; on two streams the runtime serves the queues almost one after the other (profiles/r03_two_stream_overlap.txt).
-// Here both are the SAME launch on the same stream: one persistent 1024-thread workgroup per CU holds the (a, b) node table
-// (144 KB) AND the inverse-gamma spline (16 KB) -- 160 268 of the CU's 163 840 bytes of LDS -- and its 16 waves are split
-// between the two kinds of wave strips: the first `d0_waves` walk first-kernel strips of the NEXT chunk, the others
-// last-kernel strips of THIS chunk.  While some waves of a CU wait for the table, others stream: the pipes that idle in either
-// kernel alone are busy at once.  Outputs are disjoint per strip: identical frames.
-constexpr int FUS_THREADS = 1024;
-struct FusedArgs { FinArgs fin; D0LArgs d0; int n_fin, n_d0, d0_waves; };
-template <int FL>
-__global__ __launch_bounds__(FUS_THREADS) void k_lap_final_down0(FusedArgs q) {
-    __shared__ uint32_t s_ab[kLabAbWords];
+// ---- level-1 step + last kernel in ONE launch (round 4) --------------------------------------------------------------------------
+// Until round 3 the level-1 step (k_lap_up: band_1 = G_1 - pyrUp(G_2), both IIR low-passes, cur_1 = pyrUp(cur_2) + gain_1 m_1) wrote
+// cur_1 to HBM and the last kernel read it back: 12.4 MB per 1080p frame each way, and one launch whose only other traffic is G_1 in.
+// Here ONE workgroup owns a 128 x 16 tile of the OUTPUT frame for all frames of the batch and does, per frame,
+//   phase 1  horizontal pyrUp pass of the level-2 rows the tile depends on (G_2 and cur_2 side by side as float pairs: the same
+//            formulas, one packed operation): lane <-> level-2 column, neighbours by whole-wave DPP shifts, results -> LDS;
+//   phase 2  vertical pass, band_1, both IIR steps (states in registers for the whole batch) and cur_1 for the tile's 64 x 8 level-1
+//            pixels plus a one-pixel ring (the ring's states are recomputed copies: 29 % more level-1 work, no exchange between
+//            workgroups) -> cur_1 tile in LDS, never in HBM;
+//   phase 3  the last kernel on that tile: pyrUp(cur_1) from LDS, Lab(in) from the integer planes, add, Lab2BGR, u8 out
+//            (a thread = 4 columns x 2 rows; the arithmetic is lap_final_strip's).
+// The states are double-buffered per launch (every level-1 pixel is owned, i.e. written, by exactly one workgroup).
+// Two barriers per frame.  The loads of frame t + 1 (level-2 taps, G_1, integer planes) are issued before frame t is computed.
+// Why tiles and not wave strips: with the frame loop inside, a launch's parallelism is pixels / (pixels per lane), not x frames; 8
+// pixels per lane and 4 waves per SIMD is what fills an MI355X with ONE 1080p stream (1020 workgroups for 1024 resident slots), and a
+// strip with its own halo rows would need 32 pixels per lane.  Same operations in the same order as k_lap_up + k_lap_final_v4:
+// bit-identical frames in the exact flavour (tests/test_emu_parity.py).
+typedef float f2 __attribute__((vector_size(8)));
+__device__ __forceinline__ f2 f2bc(float a) { f2 v = {a, a}; return v; }
+__device__ __forceinline__ f2 f2sel(bool c, f2 a, f2 b) { f2 v = {sel(c, a[0], b[0]), sel(c, a[1], b[1])}; return v; }
+constexpr int F1_W = 128, F1_H = 16;                          // output tile of a workgroup
+constexpr int F1_RW = F1_W / 2 + 2, F1_RH = F1_H / 2 + 2;      // level-1 region with its ring: 66 x 10; region (rx, ry) <-> level-1 (X1 - 1 + rx, Y1 - 1 + ry)
+constexpr int F1_HR = F1_H / 4 + 3;                            // level-2 rows a region depends on: m0 - 1 .. m0 + 5
+constexpr int F1_HW = F1_RW + 2;                               // pitch of a horizontal-pass row (float pairs; region column rx at rx + 1: 16-byte aligned pairs)
+constexpr int F1_CP = F1_RW + 1;                               // pitch of the cur_1 tile
+constexpr int F1_U1 = (3 * F1_HR + 3) / 4;                     // phase 1: (channel, level-2 row) units per wave
+constexpr int F1_U2 = 3 * F1_RH;                               // phase 2: (region row, channel) units of 64 lanes ...
+constexpr int F1_NQ = (F1_U2 + 3) / 4;                         // ... per wave; the region's last two columns are one more item of wave 2
+static_assert(F1_W / 4 + 3 <= 64 && F1_RW == 66 && 2 * F1_U2 <= 64 && F1_W * F1_H == 8 * 256, "k_lap_final1: tile / thread mapping");
+struct Fin1Args {
+    const uint8_t* in; long in_stride, in_sstride;            // frame f of stream b at in + (f * nstreams + b) * in_sstride
+    uint8_t* out; long out_stride, out_sstride;
+    int w, h, w1, h1, w2, h2;
+    const float* G1; const float* G2; const float* cur2;      // [frame][stream * 3 + channel][h_l][w_l]; cur2 unused without HC
+    const float* hi; const float* lo;                          // level-1 IIR states [stream * 3 + channel][h1 * w1], as the previous launch left them
+    float* hi_out; float* lo_out;                              // ... as this launch leaves them: a SECOND pair of planes.  The ring pixels of a tile are state
+                                                               // copies read from the planes of a neighbouring workgroup, which may have finished already
+    long fs1, fs2;                                             // frame strides (floats) of the level-1 / level-2 arrays
+    float aHi, bHi, aLo, bLo, gain, ca;
+    int nt, nstreams, tiles_x, tiles_y;
+    LabCoef lab; LabPlanes lp; float* dbg;
+};
+template <bool HC, bool DBG, int FL>                           // HC: cur_2 exists (L >= 3); otherwise level 1 is the top live level
+__global__ __launch_bounds__(256, 4) void k_lap_final1(Fin1Args q) {
+    constexpr bool EXACT = fl_exact(FL);
+    constexpr bool PLANES = fl_lut(FL);
     __shared__ __attribute__((aligned(16))) float s_igt[4096];
-    for (int i = threadIdx.x; i < kLabAbWords; i += FUS_THREADS) s_ab[i] = q.d0.lut.ab[i];
+    __shared__ float s_gam[fl_lut(FL) ? 1 : 256];
+    __shared__ __attribute__((aligned(16))) f2 s_H[3][F1_HR][F1_HW];
+    __shared__ float s_C[3][F1_RH][F1_CP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     {
-        const float4* src = reinterpret_cast<const float4*>(q.fin.lab.invgamma);
-        for (int i = threadIdx.x; i < 1024; i += FUS_THREADS) reinterpret_cast<float4*>(s_igt)[i] = src[i];
+        const float4* src = reinterpret_cast<const float4*>(q.lab.invgamma);
+        for (int i = tid; i < 1024; i += 256) reinterpret_cast<float4*>(s_igt)[i] = src[i];
+        if (!fl_lut(FL)) s_gam[tid] = q.lab.gamma_u8[tid];
+    }                                                          // (visible after the first barrier of the frame loop)
+    const int tiles = q.tiles_x * q.tiles_y;
+    const int sb = (int)blockIdx.x / tiles;
+    const int tr = (int)blockIdx.x - sb * tiles;
+    const int by = tr / q.tiles_x, bx = tr - by * q.tiles_x;
+    const int w = q.w, h = q.h, w1 = q.w1, h1 = q.h1, w2 = q.w2, h2 = q.h2;
+    const int X0 = bx * F1_W, Y0 = by * F1_H, X1 = X0 / 2, Y1 = Y0 / 2, k0 = X1 / 2, m0 = Y1 / 2;
+    const size_t n1 = (size_t)w1 * h1, n2 = (size_t)w2 * h2;
+    const float aHi = q.aHi, bHi = q.bHi, aLo = q.aLo, bLo = q.bLo, gain = q.gain, ca = q.ca;
+
+    // ---- phase 1 set-up: lane <-> level-2 column k0 - 1 + lane (35 of them feed the region), unit <-> (channel, level-2 row).
+    // Everything that depends on the unit only is wave-uniform and recomputed per frame on the scalar unit; per lane there is the column.
+    const int k2 = k0 - 1 + lane;
+    const int kc = k2 < 0 ? 0 : (k2 > w2 - 1 ? w2 - 1 : k2);
+    const bool fi = k2 == 0, la = k2 == w2 - 1;
+    const bool hborder = bx == 0 || k0 + F1_W / 4 + 1 >= w2 - 1;       // (uniform) a lane of this tile sits on the first / last level-2 column
+    auto unit1 = [&](int i, int& ch, int& mr, int& m) __attribute__((always_inline)) {   // false: this wave has no unit i
+        const int u = wave + 4 * i;
+        if (u >= 3 * F1_HR) { ch = mr = m = 0; return false; }
+        ch = u / F1_HR; mr = u - ch * F1_HR;
+        m = m0 - 1 + mr;
+        m = m < 0 ? 1 : (m > h2 - 1 ? h2 - 1 : m);                    // pyrUp's vertical border map (row -1 -> 1, row h2 -> h2 - 1)
+        return true;
+    };
+    // ---- phase 2 set-up: item q <-> unit u = wave + 4 q = (region row ry, channel), lane <-> region column rx (0 .. 63); the columns
+    // 64, 65 of all 30 units are the lanes 0 .. 59 of one more item of wave 2.  Per lane: the level-1 column (clamped for the loads).
+    const int cx = X1 - 1 + lane;
+    const bool vx = cx >= 0 && cx < w1;
+    const int cxc = cx < 0 ? 0 : (cx > w1 - 1 ? w1 - 1 : cx);
+    auto unit2 = [&](int qi, int& ch, int& ry, int& cy) __attribute__((always_inline)) {   // false: no such unit, or its row lies outside the plane
+        const int u = wave + 4 * qi;
+        ry = u < F1_U2 ? u / 3 : 0; ch = u < F1_U2 ? u - 3 * ry : 0;
+        cy = Y1 - 1 + ry;
+        return u < F1_U2 && cy >= 0 && cy <= h1 - 1;
+    };
+    const int xu = lane >> 1;                                          // the extra item: per-lane unit and column
+    const int xry = xu < F1_U2 ? xu / 3 : 0, xch = xu < F1_U2 ? xu - 3 * xry : 0, xrx = 64 + (lane & 1);
+    const int xcy = Y1 - 1 + xry, xcx = X1 - 1 + xrx;
+    const bool xok = wave == 2 && xu < F1_U2 && xcx >= 0 && xcx < w1 && xcy >= 0 && xcy <= h1 - 1;
+    const unsigned xoffg = xok ? (unsigned)((size_t)(sb * 3 + xch) * n1 + (size_t)xcy * w1 + xcx) : 0u;
+    float hi_r[F1_NQ + 1], lo_r[F1_NQ + 1];
+#pragma unroll
+    for (int qi = 0; qi < F1_NQ; ++qi) {
+        int ch, ry, cy;
+        const bool ok = unit2(qi, ch, ry, cy) && vx;
+        const size_t o = (size_t)(sb * 3 + ch) * n1 + (size_t)(ok ? cy : 0) * w1 + cxc;
+        hi_r[qi] = ok ? q.hi[o] : 0.f;
+        lo_r[qi] = ok ? q.lo[o] : 0.f;
     }
-    __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    // static split: the first d0_waves waves of every workgroup walk the first-kernel strips of the NEXT chunk, the others the
-    // last-kernel strips of THIS chunk (a shared strip counter was tried first: 17 k same-address device-scope atomics per
-    // launch serialise at the memory side on this 8-XCD part -- 30 us per frame instead of 22)
-    if (wave < q.d0_waves) {
-        for (int t = blockIdx.x * q.d0_waves + wave; t < q.n_d0; t += gridDim.x * q.d0_waves) down0_lut_strip<FL>(q.d0, t, lane, s_ab);
-    } else {
-        const int nf = FUS_THREADS / 64 - q.d0_waves;
-        for (int t = blockIdx.x * nf + (wave - q.d0_waves); t < q.n_fin; t += gridDim.x * nf) lap_final_strip<true, false, FL>(q.fin, t, lane, s_igt, nullptr);
+    hi_r[F1_NQ] = xok ? q.hi[xoffg] : 0.f;
+    lo_r[F1_NQ] = xok ? q.lo[xoffg] : 0.f;
+    // ---- phase 3 set-up: thread <-> output columns gx .. gx + 3, rows gy, gy + 1 (one level-1 row j = Y1 + p)
+    const int g4 = tid & 31, p = tid >> 5;
+    const int gx = X0 + 4 * g4, gy = Y0 + 2 * p;
+    const bool act = gx < w && gy < h, act1 = act && gy + 1 < h;
+    const int i0 = gx >> 1;
+    // region rows of the level-1 rows j - 1, j, j + 1 (row -1 is row 1, row h1 is row h1 - 1) and region columns of the four taps
+    // i0 - 1 .. i0 + 2 (default flavour: the border rule is applied by the taps -- column -1 reads column 1, column w1 reads column
+    // w1 - 1 -- and every thread runs the interior formulas, as lap_final_strip does)
+    const int rb = p + 1;
+    const int ra = (Y1 + p - 1 < 0) ? 2 : rb - 1;
+    const int rc = (Y1 + p + 1 > h1 - 1) ? h1 - Y1 : rb + 1;
+    const int cb = 2 * g4 + 1;
+    const int cm1 = i0 > 0 ? cb - 1 : (EXACT ? cb : 2), cp1 = i0 + 1 < w1 ? cb + 1 : w1 - X1, cp2 = i0 + 2 < w1 ? cb + 2 : w1 - X1;
+    const uint8_t* src = q.in + (size_t)sb * q.in_sstride;
+    uint8_t* dst = q.out + (size_t)sb * q.out_sstride;
+    const size_t in_fs = (size_t)q.nstreams * q.in_sstride, out_fs = (size_t)q.nstreams * q.out_sstride, px_fs = (size_t)q.nstreams * w * h;
+    const size_t poff = (size_t)sb * w * h;
+    const unsigned xoff = (unsigned)gx * 3u;
+    const int gyl = act ? gy : 0, gyl1 = act1 ? gy + 1 : gyl;          // rows the inactive threads load instead (never stored)
+    const unsigned gxl = act ? (unsigned)gx : 0u;
+
+    // loads of one frame: level-2 taps (G_2, cur_2), G_1 of the items, the two rows of integer planes
+    f2 n2v[F1_U1]; float ng1[F1_NQ + 1]; Raw4 npe, npo;
+    auto fetch = [&](int t) __attribute__((always_inline)) {
+        const float* G2t = q.G2 + (size_t)t * q.fs2;
+        const float* C2t = (HC ? q.cur2 : q.G2) + (size_t)t * q.fs2;
+        const float* G1t = q.G1 + (size_t)t * q.fs1;
+#pragma unroll
+        for (int i = 0; i < F1_U1; ++i) {
+            int ch, mr, m;
+            unit1(i, ch, mr, m);
+            const size_t rowb = (size_t)(sb * 3 + ch) * n2 + (size_t)m * w2;     // (uniform)
+            n2v[i][0] = (G2t + rowb)[kc]; n2v[i][1] = HC ? (C2t + rowb)[kc] : 0.f;
+        }
+#pragma unroll
+        for (int qi = 0; qi < F1_NQ; ++qi) {
+            int ch, ry, cy;
+            const bool vy = unit2(qi, ch, ry, cy);
+            ng1[qi] = (G1t + (size_t)(sb * 3 + ch) * n1 + (size_t)(vy ? cy : 0) * w1)[cxc];
+        }
+        ng1[F1_NQ] = G1t[xoffg];
+        LabPlanes lpt = q.lp;
+        npe = load_raw4<PLANES>(src + (size_t)t * in_fs, q.in_stride, lpt, poff + (size_t)t * px_fs, w, gyl, gxl);
+        npo = load_raw4<PLANES>(src + (size_t)t * in_fs, q.in_stride, lpt, poff + (size_t)t * px_fs, w, gyl1, gxl);
+    };
+    fetch(0);
+    for (int t = 0; t < q.nt; ++t) {
+        f2 c2v[F1_U1]; float g1[F1_NQ + 1];
+#pragma unroll
+        for (int i = 0; i < F1_U1; ++i) c2v[i] = n2v[i];
+#pragma unroll
+        for (int qi = 0; qi <= F1_NQ; ++qi) g1[qi] = ng1[qi];
+        const Raw4 pe = npe, po = npo;
+        fetch(t + 1 < q.nt ? t + 1 : q.nt - 1);                       // (unconditional: the prefetch registers are refilled every iteration)
+
+        // ---- phase 1: horizontal pyrUp pass of the level-2 rows (OpenCV pyrUp_ border rules as pyrup_h)
+#pragma unroll
+        for (int i = 0; i < F1_U1; ++i) {
+            int ch, mr, m;
+            const bool have = unit1(i, ch, mr, m);
+            const f2 s0 = c2v[i];
+            f2 sm1, s1;
+            sm1[0] = dpp_shr1(s0[0]); sm1[1] = dpp_shr1(s0[1]); s1[0] = dpp_shl1(s0[0]); s1[1] = dpp_shl1(s0[1]);
+            const f2 p6 = s0 * f2bc(6.f);
+            f2 ev = (sm1 + p6) + s1, od = (s0 + s1) * f2bc(4.f);
+            if (hborder) {
+                ev = f2sel(fi, p6 + s1 * f2bc(2.f), f2sel(la, sm1 + s0 * f2bc(7.f), ev));
+                od = f2sel(la, s0 * f2bc(8.f), od);
+            }
+            // lane l holds the level-1 columns 2 k and 2 k + 1 = region columns 2 l - 1 and 2 l, stored at 2 l and 2 l + 1
+            if (have && lane < F1_HW / 2) { f2* d = &s_H[ch][mr][2 * lane]; d[0] = ev; d[1] = od; }
+        }
+        __syncthreads();
+        // ---- phase 2: vertical pass, band, IIR x 2, gain, collapse step -> cur_1 tile
+#pragma unroll
+        for (int qi = 0; qi < F1_NQ; ++qi) {
+            int ch, ry, cy;
+            if (!unit2(qi, ch, ry, cy)) continue;                       // (uniform) no unit / a ring row outside the plane: phase 3 reads the mapped row instead
+            const int j = cy >> 1;
+            const int mb = j - (m0 - 1), ma = (j == 0 ? 1 : j - 1) - (m0 - 1), mc = (j == h2 - 1 ? h2 - 1 : j + 1) - (m0 - 1);
+            const f2* Hc = &s_H[ch][0][lane + 1];
+            f2 up;
+            if ((cy & 1) == 0) up = ((Hc[ma * F1_HW] + Hc[mb * F1_HW] * f2bc(6.f)) + Hc[mc * F1_HW]) * f2bc(1.f / 64.f);
+            else up = ((Hc[mb * F1_HW] + Hc[mc * F1_HW]) * f2bc(4.f)) * f2bc(1.f / 64.f);
+            const float band = g1[qi] - up[0];                          // SpatialFilter.cpp:33
+            const float t1 = hi_r[qi] * aHi + band * bHi;               // TemporalFilter.cpp:16
+            const float t2 = lo_r[qi] * aLo + band * bLo;               // :17
+            hi_r[qi] = t1; lo_r[qi] = t2;
+            const float m = (t1 - t2) * gain;                           // :21, MagnifyCore.hpp:129-132
+            s_C[ch][ry][lane] = (HC ? up[1] : 0.f) + m;                 // SpatialFilter.cpp:58  (columns outside the plane: never read)
+        }
+        if (wave == 2) {                                                // the region's columns 64, 65 (per-lane unit: both row parities evaluated)
+            int cy = xcy < 0 ? 1 : (xcy > h1 - 1 ? h1 - 1 : xcy);       // (rows outside the plane: xok is false, any row of the region will do)
+            const int j = cy >> 1;
+            const int mb = j - (m0 - 1), ma = (j == 0 ? 1 : j - 1) - (m0 - 1), mc = (j == h2 - 1 ? h2 - 1 : j + 1) - (m0 - 1);
+            const f2* Hc = &s_H[xch][0][xrx + 1];
+            const f2 A = Hc[ma * F1_HW], B = Hc[mb * F1_HW], C = Hc[mc * F1_HW];
+            const f2 up = f2sel((cy & 1) == 0, ((A + B * f2bc(6.f)) + C) * f2bc(1.f / 64.f), ((B + C) * f2bc(4.f)) * f2bc(1.f / 64.f));
+            const float band = g1[F1_NQ] - up[0];
+            const float t1 = hi_r[F1_NQ] * aHi + band * bHi;
+            const float t2 = lo_r[F1_NQ] * aLo + band * bLo;
+            hi_r[F1_NQ] = t1; lo_r[F1_NQ] = t2;
+            const float m = (t1 - t2) * gain;
+            if (xu < F1_U2) s_C[xch][xry][xrx] = (HC ? up[1] : 0.f) + m;
+        }
+        __syncthreads();
+        // ---- phase 3: out = u8(Lab2BGR(Lab(in) + [1, ca, ca] * pyrUp(cur_1))) for the thread's 4 x 2 pixels
+        if (act) {
+            Row3 A, B, C;
+            auto hrow = [&](int r) __attribute__((always_inline)) {
+                Row3 o;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float* rowp = &s_C[c][r][0];
+                    const float sm1 = rowp[cm1], s0 = rowp[cb], s1 = rowp[cp1], s2 = rowp[cp2];
+                    if (EXACT) o.c[c] = pyrup_h4(sm1, s0, s1, s2, i0, w1);
+                    else if (LVM_FAST_FMA) {
+                        o.c[c].x = __builtin_fmaf(s0, 6.f, sm1 + s1); o.c[c].y = (s0 + s1) * 4.f; o.c[c].z = __builtin_fmaf(s1, 6.f, s0 + s2); o.c[c].w = (s1 + s2) * 4.f;
+                    } else { o.c[c].x = sm1 + s0 * 6.f + s1; o.c[c].y = (s0 + s1) * 4.f; o.c[c].z = s0 + s1 * 6.f + s2; o.c[c].w = (s1 + s2) * 4.f; }
+                }
+                return o;
+            };
+            A = hrow(ra); B = hrow(rb); C = hrow(rc);
+            float* dbgp = (DBG && q.dbg && sb == 0 && t == 0) ? q.dbg : nullptr;
+            uint8_t* orow = dst + (size_t)t * out_fs + (size_t)gy * q.out_stride + xoff;
+            float m[3][4];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                if (!EXACT && LVM_FAST_FMA) {
+                    m[c][0] = __builtin_fmaf(B.c[c].x, 6.f, A.c[c].x + C.c[c].x); m[c][1] = __builtin_fmaf(B.c[c].y, 6.f, A.c[c].y + C.c[c].y);
+                    m[c][2] = __builtin_fmaf(B.c[c].z, 6.f, A.c[c].z + C.c[c].z); m[c][3] = __builtin_fmaf(B.c[c].w, 6.f, A.c[c].w + C.c[c].w);
+                    continue;
+                }
+                const float sc = EXACT ? (1.f / 64.f) : 1.f;
+                m[c][0] = (A.c[c].x + B.c[c].x * 6.f + C.c[c].x) * sc; m[c][1] = (A.c[c].y + B.c[c].y * 6.f + C.c[c].y) * sc;
+                m[c][2] = (A.c[c].z + B.c[c].z * 6.f + C.c[c].z) * sc; m[c][3] = (A.c[c].w + B.c[c].w * 6.f + C.c[c].w) * sc;
+            }
+            lap_emit_row<true, DBG, FL>(pe, m, 1.f / 64.f, ca, q.lab, s_igt, s_gam, dbgp ? dbgp + ((size_t)gy * w + gx) * 3 : nullptr, orow);
+            if (act1) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (EXACT) {
+                        m[c][0] = ((B.c[c].x + C.c[c].x) * 4.f) * (1.f / 64.f); m[c][1] = ((B.c[c].y + C.c[c].y) * 4.f) * (1.f / 64.f);
+                        m[c][2] = ((B.c[c].z + C.c[c].z) * 4.f) * (1.f / 64.f); m[c][3] = ((B.c[c].w + C.c[c].w) * 4.f) * (1.f / 64.f);
+                    } else {
+                        m[c][0] = B.c[c].x + C.c[c].x; m[c][1] = B.c[c].y + C.c[c].y; m[c][2] = B.c[c].z + C.c[c].z; m[c][3] = B.c[c].w + C.c[c].w;
+                    }
+                }
+                lap_emit_row<true, DBG, FL>(po, m, 1.f / 16.f, ca, q.lab, s_igt, s_gam, dbgp ? dbgp + ((size_t)(gy + 1) * w + gx) * 3 : nullptr, orow + q.out_stride);
+            }
+        }
     }
+    // the states of the pixels this workgroup owns (the ring's are copies of a neighbour's)
+#pragma unroll
+    for (int qi = 0; qi < F1_NQ; ++qi) {
+        int ch, ry, cy;
+        const bool ok = unit2(qi, ch, ry, cy) && vx;
+        if (ok && lane >= 1 && ry >= 1 && ry <= F1_H / 2) {
+            const size_t o = (size_t)(sb * 3 + ch) * n1 + (size_t)cy * w1 + cxc;
+            q.hi_out[o] = hi_r[qi]; q.lo_out[o] = lo_r[qi];
+        }
+    }
+    if (xok && xrx <= F1_W / 2 && xry >= 1 && xry <= F1_H / 2) { q.hi_out[xoffg] = hi_r[F1_NQ]; q.lo_out[xoffg] = lo_r[F1_NQ]; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -948,6 +1194,9 @@ struct LaplaceState : ModeState {
     float* G[kMaxLevels + 1] = {};
     float *hi[kMaxLevels + 1] = {}, *lo[kMaxLevels + 1] = {}, *cur[kMaxLevels + 1] = {};
     bool seeded = false;
+    float *hi1x = nullptr, *lo1x = nullptr;   // second pair of level-1 state planes (k_lap_final1 reads one pair and writes the other; swapped per launch)
+    int state_par = 0;                        // which pair is current (part of the graph key: the kernels see different pointers)
+    bool used_final1 = false;                 // the last steady frame ran k_lap_final1 (graph replay: advance() swaps the pairs as the launch code does)
     float* Gp[2][kMaxLevels + 1] = {};    // Gaussian pyramid, double-buffered by frame parity (pipelined mode)
     float* curT[2] = {};                  // cur_T written by the tail kernel, double-buffered likewise
     struct Pending { bool valid = false; FrameIO io{}; lvm_params p{}; int par = 0; } pending;
@@ -963,37 +1212,34 @@ struct LaplaceState : ModeState {
     long rows_min_elems = 2000000;        // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS): 32-frame batches keep the strips on
                                           // levels 1-3 (3.1 M at level 3), four streams per per-frame call take the two-level kernel from level 2 (one launch less)
     int split_levels = 1;                 // temporal batches: levels >= 2 as one IIR launch + one collapse launch (LVM_LAP_SPLIT=0: level-by-level chain)
-    int up_rows4 = 0;                     // large launches: k_lap_up_rows<4, D> instead of the tiled kernel (LVM_UP_ROWS4=1|2 = ring depth)
     int up_rows = 1;                      // barrier-free k_lap_up_rows for the steady state (LVM_UP_ROWS=0: tiled k_lap_up)
     long up_rows_max_blocks = 1024;       // launches with fewer tiled workgroups than this use k_lap_up_rows (LVM_UP_ROWS_MAX_BLOCKS)
     bool d0_rows_on = true;               // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
     bool d0_fused = true;                 // table conversion fused into the first kernel on large launches (LVM_D0_FUSED=0: separate kernels)
-    int fuse_chunks = 0;                  // temporal batches: chunks whose last kernel shares a launch with the next chunk's first kernel (LVM_LAP_FUSE_CHUNKS; 0 / 1 = off)
-    int fuse_d0_waves = 10;               // ... waves of a workgroup that prefer first-kernel strips (LVM_LAP_FUSE_D0_WAVES, of 16)
-    int d0_fused_grid = 0;                // persistent workgroups of the fused kernel (LVM_D0_FUSED_GRID; 0 = one per CU).  Fewer leave CUs to a second stream
     long d0_fused_waves = 0;              // ... = launches with at least this many strips (LVM_D0_FUSED_WAVES; 0 = one per resident wave)
     long d0_min_tasks = 4096;             // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
     long fin_groups = 0;                  // workgroups of the persistent last kernel (LVM_FIN_GROUPS; 0 = 1024)
     int fin_rows = 8;                     // rows per wave strip of k_lap_final_v4 (LVM_FIN_ROWS, power of two)
     int up_depth_big = 1;                 // ... at the levels with >= 1024 workgroups (LVM_UP_DEPTH_BIG)
     int up_depth = 8;                     // frame-loop prefetch depth of k_lap_up at the coarse levels (LVM_UP_DEPTH=1|2|4|8)
-    int chunks = 1;                       // temporal batches: > 1 = chunks whose down sweep overlaps the previous chunk's up sweep on a second stream (LVM_LAP_CHUNKS; measured slower: 27.7k fps at 4 chunks, 30.5k at 2, 34.8k at 1)
-    std::vector<hipEvent_t> chunk_ev;
+    bool final1 = true;                   // level-1 step fused into the last kernel, cur_1 never in HBM (k_lap_final1; LVM_LAP_FINAL1=0: k_lap_up + k_lap_final_v4)
     int pd_rows = 16;                     // output rows per wave strip of k_pyr_down_rows (LVM_PD_ROWS)
     int fuse_down = 2;                    // pyramid levels per pyrDown launch (LVM_FUSE_DOWN=2|3 selects the fused kernels)
     int tailT = 0;                       // first level handled by k_lap_tail (0 = tail disabled)
     TailArgs tail{};
     bool steady(const lvm_params&) const override { return seeded && (depth == 0 || pending.valid); }
+    void swap_level1_states() { std::swap(hi[1], hi1x); std::swap(lo[1], lo1x); state_par ^= 1; }
     void advance(const lvm_params& p, const FrameIO& io) override {
+        if (used_final1) swap_level1_states();
         if (depth == 0) return;
         pending.valid = true; pending.io = io; pending.p = p; pending.par = par;
         par ^= 1;
     }
     size_t key_extra(uint8_t* buf, size_t cap) const override {
-        struct { FrameIO io; lvm_params p; int par, cur, depth; } k;
+        struct { FrameIO io; lvm_params p; int par, cur, depth, state_par; } k;
         std::memset(&k, 0, sizeof(k));
         if (pending.valid) { k.io = pending.io; k.p = pending.p; k.par = pending.par; }
-        k.cur = par; k.depth = depth;
+        k.cur = par; k.depth = depth; k.state_par = state_par;
         if (sizeof(k) > cap) return 0;
         std::memcpy(buf, &k, sizeof(k));
         return sizeof(k);
@@ -1001,7 +1247,6 @@ struct LaplaceState : ModeState {
     ~LaplaceState() override {
         if (arena) (void)hipFree(arena);
         if (tarena) (void)hipFree(tarena);
-        for (hipEvent_t e : chunk_ev) (void)hipEventDestroy(e);
     }
 };
 
@@ -1020,6 +1265,7 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
     for (int l = 1; l <= levels; ++l) total += 2 * pad(st->g[l].n * st->planes);
     for (int l = 1; l < levels; ++l) total += 5 * pad(st->g[l].n * st->planes);
+    if (levels >= 2) total += 2 * pad(st->g[1].n * st->planes);
     const size_t npx = st->g[0].n * c->nstreams;                 // pixels of one frame set
     if (channels == 3) total += 2 * (pad(npx) + pad((npx + 1) / 2));
     if (total == 0) total = 64;
@@ -1042,6 +1288,7 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
         st->lo[l] = p; p += pad(st->g[l].n * st->planes);
         st->cur[l] = p; p += pad(st->g[l].n * st->planes);
     }
+    if (levels >= 2) { st->hi1x = p; p += pad(st->g[1].n * st->planes); st->lo1x = p; p += pad(st->g[1].n * st->planes); }
     laplace_tail_plan(st);
     if (const char* e = std::getenv("LVM_FUSE_DOWN")) st->fuse_down = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_DEPTH")) st->up_depth = std::atoi(e);
@@ -1050,15 +1297,11 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
     if (const char* e = std::getenv("LVM_D0_FUSED")) st->d0_fused = std::atoi(e) != 0;
     if (const char* e = std::getenv("LVM_D0_FUSED_WAVES")) st->d0_fused_waves = std::atol(e);
-    if (const char* e = std::getenv("LVM_D0_FUSED_GRID")) st->d0_fused_grid = std::atoi(e);
-    if (const char* e = std::getenv("LVM_LAP_FUSE_CHUNKS")) st->fuse_chunks = std::atoi(e);
-    if (const char* e = std::getenv("LVM_LAP_FUSE_D0_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= 15) st->fuse_d0_waves = v; }
     if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
-    if (const char* e = std::getenv("LVM_LAP_CHUNKS")) st->chunks = std::atoi(e);
     if (const char* e = std::getenv("LVM_LAP_SPLIT")) st->split_levels = std::atoi(e);
     if (const char* e = std::getenv("LVM_LAP_SPLIT_MIN_NT")) st->split_min_nt = std::atoi(e);
-    if (const char* e = std::getenv("LVM_UP_ROWS4")) st->up_rows4 = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_ROWS")) st->up_rows = std::atoi(e);
+    if (const char* e = std::getenv("LVM_LAP_FINAL1")) st->final1 = std::atoi(e) != 0;
     if (const char* e = std::getenv("LVM_UP_ROWS_MAX_BLOCKS")) st->up_rows_max_blocks = std::atol(e);
     if (const char* e = std::getenv("LVM_ROWS_MIN_ELEMS")) st->rows_min_elems = std::atol(e);
     if (const char* e = std::getenv("LVM_FIN_MIN_TASKS")) st->fin_min_tasks = std::atol(e);
@@ -1136,9 +1379,6 @@ static bool lap_split_now(const LaplaceState* st, const LapBufs& B, bool first) 
     return split;
 }
 
-// part: 0 = the whole stage; 1 = only the table conversion + first pyramid kernel (-> G_1 and the integer planes: bound by
-// the table look-ups, hardly touches HBM); 2 = only the rest (the pyrDown chain: bound by HBM).  Chunked batches run part 1
-// of the next chunk on the auxiliary stream under parts 2 + stage A of the current one.
 // arguments of k_down0_lut_rows for the frames of B (false: this launch does not take the fused first kernel)
 static bool lap_d0l_args(Ctx* c, LaplaceState* st, const FrameIO& io, const LapBufs& B, D0LArgs* out) {
     const int NS = c->nstreams * B.nt, levels = st->levels;
@@ -1154,7 +1394,7 @@ static bool lap_d0l_args(Ctx* c, LaplaceState* st, const FrameIO& io, const LapB
     return true;
 }
 
-static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, const LapBufs& B, bool first, hipStream_t s, int part = 0) {
+static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, const LapBufs& B, bool first, hipStream_t s) {
     const int C = io.channels, levels = st->levels;
     const int NS = c->nstreams * B.nt;        // stateless kernels: a frame of the batch is just one more stream
     const int planes = st->planes * B.nt;
@@ -1164,7 +1404,7 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     // large launches: conversion and first pyramid kernel in one pass (k_down0_lut_rows); LVM_D0_FUSED=0 keeps them apart
     D0LArgs da{};
     const bool fused = lap_d0l_args(c, st, io, B, &da);
-    if (part != 2 && lp.iab && !fused) lab_lut_planes(c, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h, NS, B.iL, nullptr, B.iab, s);
+    if (lp.iab && !fused) lab_lut_planes(c, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h, NS, B.iL, nullptr, B.iab, s);
     if (levels < 2) return;
     float** G = B.G;
     const LevelGeom& g1 = st->g[1];
@@ -1174,11 +1414,9 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     long d0_tasks = 0;
     const int d0_rows = down0_rows_choice(g1.w, g1.h, NS, st->d0_min_tasks, &d0_tasks);
     const int fl = lab_flavour(c);
-    if (part == 2) {
-    } else if (fused) {
+    if (fused) {
         auto kdl = fl == FL_LUT_EXACT ? k_down0_lut_rows<FL_LUT_EXACT> : k_down0_lut_rows<FL_LUT_FAST>;
-        const int dl_grid = (st->d0_fused_grid > 0 && st->d0_fused_grid < c->num_cus) ? st->d0_fused_grid : c->num_cus;
-        LVM_LAUNCH(c, "lap_down0_lut", kdl, dim3((unsigned)dl_grid), dim3(D0L_THREADS), s, da);
+        LVM_LAUNCH(c, "lap_down0_lut", kdl, dim3((unsigned)c->num_cus), dim3(D0L_THREADS), s, da);
     } else if (lap_vec4(io) && st->d0_rows_on && d0_tasks > 0) {
         auto kd0 = LVM_FL_PICK(fl, k_down0_rows, true);
         const dim3 gridr((unsigned)((d0_tasks + D0R_THREADS / 64 - 1) / (D0R_THREADS / 64)));
@@ -1193,7 +1431,6 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         LVM_LAUNCH(c, "lap_down0", kd0, grid0, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h,
                    G[1], g1.w, g1.h, c->lab, c->lab.a255, lp);
     }
-    if (part == 1) return;
     const bool use_tail = st->tailT && B.nt == 1 && !B.no_tail && !lap_split_now(st, B, first);   // batched frames: every level gets many workgroups anyway
     const int down_end = use_tail ? st->tailT : levels;            // the tail builds G_{T+1..L} itself
     int l = 1;
@@ -1248,10 +1485,7 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
 }
 
 // Stage A of a frame: the fused band/IIR/collapse steps of the levels below T and the final kernel.
-// fin_out != nullptr: the last kernel is NOT launched; its strip arguments are returned instead (the caller fuses it with the
-// next chunk's first kernel).  Only asked for when lap_vec4(io), motion and no debug frame.
-static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, const LapBufs& B, bool first, hipStream_t s,
-                        FinArgs* fin_out = nullptr) {
+static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, const LapBufs& B, bool first, hipStream_t s) {
     const int C = io.channels, levels = st->levels;
     const int NS = c->nstreams * B.nt;
     const dim3 blk(256);
@@ -1297,7 +1531,13 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         }
         up_start = 1;
     }
-    for (int l = up_start; l >= 1; --l) {
+    // Level 1 inside the last kernel (k_lap_final1: cur_1 stays in LDS)?  3-channel frames with dword-aligned pixel groups, a level 2
+    // of at least 2 x 2 pixels; not for the seeding frame (no motion yet), not with an odd level-1 width, and not when the tail kernel
+    // has already run level 1 (tiny frames).
+    const bool fuse1 = st->final1 && !first && levels >= 2 && up_start >= 1 /* level 1 not inside the tail kernel */ && C == 3 && lap_vec4(io) && st->g[1].w % 2 == 0 && st->g[2].w >= 2 && st->g[2].h >= 2 &&
+                       st->g[1].h >= 2 && (size_t)st->planes * st->g[1].n * (size_t)B.nt < ((size_t)1 << 31);
+    st->used_final1 = false;
+    for (int l = up_start; l >= (fuse1 ? 2 : 1); --l) {
         UpArgs a;
         a.Gl = G[l]; a.Gn = G[l + 1];
         a.curn = (l + 1 <= levels - 1) ? ((use_tail && l + 1 == st->tailT) ? B.curT : B.cur[l + 1]) : nullptr;
@@ -1324,15 +1564,6 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
             LVM_LAUNCH(c, LName("lap_up", l), kr, g2, blk, s, a, gw, (int)ngroups);
             continue;
         }
-        if (!first && st->up_rows4 && a.w % 4 == 0 && a.curn != nullptr) {
-            // large launches (level 1): 4 x 2 pixels per lane, 16-byte accesses of level l, no LDS
-            const int gw = a.w / 4;
-            const long ngroups = (long)gw * ((a.h + 1) / 2);
-            const dim3 g2((unsigned)((ngroups + 255) / 256), (unsigned)st->planes);
-            if (st->up_rows4 == 2 && a.nt % 2 == 0) LVM_LAUNCH(c, LName("lap_up", l), (k_lap_up_rows<4, 2, true>), g2, blk, s, a, gw, (int)ngroups);
-            else LVM_LAUNCH(c, LName("lap_up", l), (k_lap_up_rows<4, 1, true>), g2, blk, s, a, gw, (int)ngroups);
-            continue;
-        }
         int depth = (blocks >= 1024) ? st->up_depth_big : st->up_depth;   // frame ring of the tiled kernel
         while (depth > 1 && a.nt % depth != 0) depth >>= 1;           // the ring depth must divide the frame count
         if (first) LVM_LAUNCH(c, LName("lap_seed", l), (k_lap_up<true, 1>), grid, blk, s, a);
@@ -1341,6 +1572,31 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         else if (depth <= 4) LVM_LAUNCH(c, LName("lap_up", l), (k_lap_up<false, 4>), grid, blk, s, a);
         else LVM_LAUNCH(c, LName("lap_up", l), (k_lap_up<false, 8>), grid, blk, s, a);
     }
+    const int fl = lab_flavour(c);
+    float* dbg = (c->keep_float && B.dbg_frame) ? c->d_float : nullptr;   // (the float frame kept is the first one of the batch)
+    if (fuse1) {
+        Fin1Args a{};
+        a.in = io.d_in; a.in_stride = (long)io.in_stride; a.in_sstride = (long)io.in_sstride;
+        a.out = io.d_out; a.out_stride = (long)io.out_stride; a.out_sstride = (long)io.out_sstride;
+        a.w = io.w; a.h = io.h; a.w1 = st->g[1].w; a.h1 = st->g[1].h; a.w2 = st->g[2].w; a.h2 = st->g[2].h;
+        a.G1 = G[1]; a.G2 = G[2];
+        a.cur2 = levels >= 3 ? ((use_tail && st->tailT == 2) ? B.curT : B.cur[2]) : nullptr;
+        a.hi = st->hi[1]; a.lo = st->lo[1]; a.hi_out = st->hi1x; a.lo_out = st->lo1x;
+        a.fs1 = (long)st->planes * (long)st->g[1].n; a.fs2 = (long)st->planes * (long)st->g[2].n;
+        a.aHi = (float)(1 - cHi); a.bHi = (float)cHi; a.aLo = (float)(1 - cLo); a.bLo = (float)cLo; a.gain = gains[1];
+        a.ca = (float)p.chromAttenuation;
+        a.nt = B.nt; a.nstreams = c->nstreams;
+        a.tiles_x = (io.w + F1_W - 1) / F1_W; a.tiles_y = (io.h + F1_H - 1) / F1_H;
+        a.lab = c->lab; a.lp = lp; a.dbg = dbg;
+        const dim3 grid1((unsigned)(a.tiles_x * a.tiles_y * c->nstreams));
+        const bool hc = a.cur2 != nullptr;
+        auto k1 = dbg ? (hc ? LVM_FL_PICK(fl, k_lap_final1, true, true) : LVM_FL_PICK(fl, k_lap_final1, false, true))
+                      : (hc ? LVM_FL_PICK(fl, k_lap_final1, true, false) : LVM_FL_PICK(fl, k_lap_final1, false, false));
+        LVM_LAUNCH(c, "lap_final1", k1, grid1, blk, s, a);
+        st->swap_level1_states();
+        st->used_final1 = true;
+        return;
+    }
     const int tx = (io.w + UT_W - 1) / UT_W, ty = (io.h + UT_H - 1) / UT_H;
     const int ntiles = tx * ty * NS;
     const dim3 grid(ntiles < 2048 ? ntiles : 2048);
@@ -1348,8 +1604,6 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     const float ca = (float)p.chromAttenuation;
     const float* cur1 = motion ? ((use_tail && st->tailT == 1) ? B.curT : B.cur[1]) : nullptr;
     const int w1 = st->g[1].w, h1 = st->g[1].h;
-    float* dbg = (c->keep_float && B.dbg_frame) ? c->d_float : nullptr;   // (the float frame kept is the first one of the batch)
-    const int fl = lab_flavour(c);
     auto kf4 = dbg ? (motion ? LVM_FL_PICK(fl, k_lap_final_v4, true, true) : LVM_FL_PICK(fl, k_lap_final_v4, false, true))
                    : (motion ? LVM_FL_PICK(fl, k_lap_final_v4, true, false) : LVM_FL_PICK(fl, k_lap_final_v4, false, false));
     auto kf = (C == 3) ? (motion ? LVM_FL_PICK(fl, k_lap_final, 3, true) : LVM_FL_PICK(fl, k_lap_final, 3, false))
@@ -1366,7 +1620,6 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         const dim3 grid4((unsigned)(groups < cap ? groups : cap)), blk4(FIN_THREADS);
         const FinArgs fa{io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out, (long)io.out_stride, (long)io.out_sstride, io.w, io.h, cur1, w1, h1,
                          c->lab, ca, sx, sy, NS, rows, dbg, lp};
-        if (fin_out) { *fin_out = fa; return; }
         LVM_LAUNCH(c, "lap_final", kf4, grid4, blk4, s, fa);
     } else {
         LVM_LAUNCH(c, "lap_final", kf, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
@@ -1420,100 +1673,16 @@ int laplace_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int n
     const int levels = st->levels;
     if (nt > st->tcap) { const int rc = laplace_reserve_frames(c, st, nt, s); if (rc != LVM_OK) return rc; }
     if (st->pending.valid) { const int rc = laplace_flush(c, s); if (rc != LVM_OK) return rc; }
-    // Fused schedule (LVM_LAP_FUSE_CHUNKS = n >= 2): the batch in n chunks on ONE stream; the last kernel of chunk k and the
-    // first kernel (table conversion + pyrDown) of chunk k + 1 are one launch (k_lap_final_down0).
-    {
-        constexpr int kMaxFuse = 16;
-        int n = st->fuse_chunks;
-        if (n > kMaxFuse) n = kMaxFuse;
-        if (n > nt / 4) n = nt / 4;                              // at least 4 frames per chunk
-        const bool ok = n >= 2 && io.channels == 3 && fl_lut(lab_flavour(c)) && lap_vec4(io) && levels >= 2 && !c->keep_float;
-        if (ok) {
-            const int per = ((nt + n - 1) / n + 3) & ~3;
-            struct Chunk { FrameIO io; float* G[kMaxLevels + 1]; float* cur[kMaxLevels + 1]; LapBufs B; D0LArgs d0; bool d0_ok; };
-            std::vector<Chunk> ch;
-            for (int f0 = 0; f0 < nt; f0 += per) {
-                ch.emplace_back();
-                Chunk& k = ch.back();
-                k.io = io;
-                k.io.d_in = io.d_in + (size_t)f0 * c->nstreams * io.in_sstride;
-                k.io.d_out = io.d_out + (size_t)f0 * c->nstreams * io.out_sstride;
-                for (int l = 1; l <= levels; ++l) k.G[l] = st->Gt[l] + (size_t)f0 * st->planes * st->g[l].n;
-                for (int l = 1; l < levels; ++l) k.cur[l] = st->curt[l] + (size_t)f0 * st->planes * st->g[l].n;
-            }
-            for (size_t q = 0; q < ch.size(); ++q) {             // (pointers into ch are taken only after it stopped growing)
-                Chunk& k = ch[q];
-                const int f0 = (int)q * per, m = nt - f0 < per ? nt - f0 : per;
-                k.B = LapBufs{k.G, k.cur, nullptr, m, true};
-                k.B.iL = st->iLt + (size_t)f0 * c->nstreams * st->g[0].n; k.B.iab = st->iabt + (size_t)f0 * c->nstreams * st->g[0].n;
-                k.d0_ok = lap_d0l_args(c, st, k.io, k.B, &k.d0);
-            }
-            bool all = true;
-            for (auto& k : ch) all = all && k.d0_ok;
-            if (all && ch.size() >= 2) {
-                lap_stage_b(c, st, p, ch[0].io, ch[0].B, false, s, 1);                   // first kernel of chunk 0 on its own
-                const int fl = lab_flavour(c);
-                for (size_t q = 0; q < ch.size(); ++q) {
-                    Chunk& k = ch[q];
-                    lap_stage_b(c, st, p, k.io, k.B, false, s, 2);
-                    if (q + 1 == ch.size()) { lap_stage_a(c, st, p, k.io, k.B, false, s); break; }
-                    FusedArgs fa{};
-                    lap_stage_a(c, st, p, k.io, k.B, false, s, &fa.fin);
-                    fa.d0 = ch[q + 1].d0;
-                    fa.n_fin = fa.fin.strips_x * fa.fin.strips_y * fa.fin.nstreams; fa.n_d0 = fa.d0.ntasks;
-                    fa.d0_waves = st->fuse_d0_waves;
-                    auto kfu = fl == FL_LUT_EXACT ? k_lap_final_down0<FL_LUT_EXACT> : k_lap_final_down0<FL_LUT_FAST>;
-                    LVM_LAUNCH(c, "lap_final_down0", kfu, dim3((unsigned)c->num_cus), dim3(FUS_THREADS), s, fa);
-                }
-                LVM_HIP_TRY(c, hipGetLastError());
-                return LVM_OK;
-            }
-        }
-    }
-    // The batch is cut into chunks of consecutive frames.  The down sweeps (stage B: stateless, bound by the
-    // Lab arithmetic) of all chunks run on the auxiliary stream, the up sweeps (stage A: the IIR kernels
-    // of the coarse levels are a few hundred waves each and leave most of the chip idle) follow chunk by
-    // chunk, in temporal order, on the caller's stream: stage B of chunk k+1 overlaps stage A of chunk k.
-    // Every chunk has its own slice of the batch buffers, so the only dependencies are B(k) -> A(k)
-    // (one event each) and the temporal order of the A stages (stream order).
-    int chunks = st->chunks;
-    if (chunks > nt / 4) chunks = nt / 4;                       // at least 4 frames per chunk
-    if (chunks < 2 || !c->aux_stream || c->profiling) chunks = 1;
-    while ((int)st->chunk_ev.size() < chunks) {
-        hipEvent_t e = nullptr;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { chunks = 1; break; }
-        st->chunk_ev.push_back(e);
-    }
-    const int per = ((nt + chunks - 1) / chunks + 3) & ~3;      // chunk length: a multiple of 4 (ring depth of k_lap_up_rows)
-    if (chunks > 1) {
-        LVM_HIP_TRY(c, hipEventRecord(c->ev_fork, s));
-        LVM_HIP_TRY(c, hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
-    }
-    struct Chunk { FrameIO io; float* G[kMaxLevels + 1]; float* cur[kMaxLevels + 1]; LapBufs B; };
-    std::vector<Chunk> ch((size_t)chunks);
-    int nch = 0;
-    for (int f0 = 0; f0 < nt; f0 += per, ++nch) {
-        Chunk& k = ch[(size_t)nch];
-        const int n = nt - f0 < per ? nt - f0 : per;
-        k.io = io;
-        k.io.d_in = io.d_in + (size_t)f0 * c->nstreams * io.in_sstride;
-        k.io.d_out = io.d_out + (size_t)f0 * c->nstreams * io.out_sstride;
-        for (int l = 1; l <= levels; ++l) k.G[l] = st->Gt[l] + (size_t)f0 * st->planes * st->g[l].n;
-        for (int l = 1; l < levels; ++l) k.cur[l] = st->curt[l] + (size_t)f0 * st->planes * st->g[l].n;
-        k.B = LapBufs{k.G, k.cur, nullptr, n, true};          // (the tail kernel filters inside stage B: not for overlapped chunks)
-        k.B.dbg_frame = f0 == 0;
-        if (st->iabt) { k.B.iL = st->iLt + (size_t)f0 * c->nstreams * st->g[0].n; k.B.iab = st->iabt + (size_t)f0 * c->nstreams * st->g[0].n; }
-        if (chunks > 1) {
-            lap_stage_b(c, st, p, k.io, k.B, false, c->aux_stream, 1);
-            LVM_HIP_TRY(c, hipEventRecord(st->chunk_ev[(size_t)nch], c->aux_stream));
-        }
-    }
-    for (int q = 0; q < nch; ++q) {
-        Chunk& k = ch[(size_t)q];
-        if (chunks > 1) { LVM_HIP_TRY(c, hipStreamWaitEvent(s, st->chunk_ev[(size_t)q], 0)); lap_stage_b(c, st, p, k.io, k.B, false, s, 2); }
-        else lap_stage_b(c, st, p, k.io, k.B, false, s);
-        lap_stage_a(c, st, p, k.io, k.B, false, s);
-    }
+    // One pass over the batch: the stateless kernels take the frames as one more batch dimension, the IIR kernels walk over them
+    // inside the launch.  (Rounds 1-3 also carried two chunked schedules -- the next chunk's table conversion on a second stream, and the
+    // last kernel of a chunk sharing a launch with the next chunk's first kernel; both measured slower, profiles/README.md, and were removed.)
+    float* G[kMaxLevels + 1]; float* cur[kMaxLevels + 1];
+    for (int l = 1; l <= levels; ++l) G[l] = st->Gt[l];
+    for (int l = 1; l < levels; ++l) cur[l] = st->curt[l];
+    LapBufs B{G, cur, nullptr, nt, true};            // (the tail kernel filters inside stage B: per-frame calls only)
+    if (st->iabt) { B.iL = st->iLt; B.iab = st->iabt; }
+    lap_stage_b(c, st, p, io, B, false, s);
+    lap_stage_a(c, st, p, io, B, false, s);
     LVM_HIP_TRY(c, hipGetLastError());
     return LVM_OK;
 }

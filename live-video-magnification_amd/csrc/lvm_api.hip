@@ -38,7 +38,8 @@ void sync_streams(Ctx* c) {
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     for (auto& e : c->caller_events) (void)hipEventSynchronize(e.second);
-    if (c->caller_overflow) (void)hipDeviceSynchronize();
+    // the device-wide wait has covered everything enqueued so far, on any stream: the flag starts afresh (it is not sticky)
+    if (c->caller_overflow) { (void)hipDeviceSynchronize(); c->caller_overflow = false; }
     (void)hipGetLastError();
 }
 void mark_enqueued(Ctx* c, hipStream_t s) {
@@ -46,9 +47,20 @@ void mark_enqueued(Ctx* c, hipStream_t s) {
     for (auto& e : c->caller_events)
         if (e.first == s) { if (hipEventRecord(e.second, s) != hipSuccess) { (void)hipGetLastError(); c->caller_overflow = true; } return; }
     hipEvent_t ev = nullptr;
-    if (c->caller_events.size() >= kMaxCallerStreams || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
-        (void)hipGetLastError(); c->caller_overflow = true; return;
+    if (c->caller_events.size() >= kMaxCallerStreams) {
+        // full: recycle a slot whose event has completed (its stream's work is done -- the stream may not even exist any
+        // more; stream-per-call callers and framework stream pools would otherwise fill the list for good)
+        for (auto& e : c->caller_events)
+            if (hipEventQuery(e.second) == hipSuccess) {
+                if (hipEventRecord(e.second, s) != hipSuccess) { (void)hipGetLastError(); c->caller_overflow = true; return; }
+                e.first = s;
+                return;
+            }
+        (void)hipGetLastError();        // hipErrorNotReady of the queries
+        c->caller_overflow = true;
+        return;
     }
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); c->caller_overflow = true; return; }
     if (hipEventRecord(ev, s) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(ev); c->caller_overflow = true; return; }
     c->caller_events.emplace_back(s, ev);
 }
@@ -235,7 +247,8 @@ int lvm_create(int device, int n_streams, lvm_ctx** out) {
         // OpenCV's forward Lab table (lab_tables.cpp) and the closed form of its cell index (lab_lut.h)
         if (!lvm::lab_lut_fine_index_ok()) { lvm_destroy(c); return LVM_ERR_INVALID; }
         lvm::build_lab_lut_compact(c->lab_lut_compact);
-        ok = lvm::upload_lab_lut(c) == LVM_OK;
+        const int rc = lvm::upload_lab_lut(c);
+        if (rc != LVM_OK) { lvm_destroy(c); return rc; }                 // LVM_ERR_OOM stays LVM_ERR_OOM
     }
     if (!ok) { lvm_destroy(c); return LVM_ERR_HIP; }
     c->lab.gamma_u8 = c->d_gamma_u8;
@@ -547,8 +560,7 @@ int lvm_set_lab_lut(lvm_ctx* c, const int16_t* src) {
     (void)hipSetDevice(c->device);
     for (size_t i = 0; i < (size_t)LVM_LAB_LUT_ENTRIES; ++i)
         if (src[i] < 0 || src[i] > 16384) { c->err = "lvm_set_lab_lut: entry outside [0, 16384]"; return LVM_ERR_INVALID; }
-    lvm::sync_streams(c);                        // kernels in flight read the old table
-    LVM_HIP_TRY(c, hipDeviceSynchronize());
+    lvm::sync_streams(c);                        // kernels in flight read the old table (this context's buffers: no device-wide wait)
     c->lab_lut_compact.assign(src, src + LVM_LAB_LUT_ENTRIES);
     return lvm::upload_lab_lut(c);
 }

@@ -2,8 +2,9 @@
 //
 // Replaces magcore::magnifyRiesz (reference: processing/magnification/MagnifyCore.hpp:209-279)
 // with RieszPyramid / RieszPyramidLevel (RieszPyramid.cpp:8-339) and RieszTemporalFilter
-// (TemporalFilter.cpp:299-362).  Only the Lab L plane is processed; a,b are recomputed from the
-// u8 frame in the last kernel.
+// (TemporalFilter.cpp:299-362).  Only the Lab L plane is processed; the frame goes through OpenCV's forward Lab table
+// exactly once (labconv.hip): L becomes the float plane oct_0 of the pyramid, (ia, ib) one dword per pixel that the
+// last kernel reads back for the inverse conversion (lvm_debug_lab_analytic: the cube-root L plane of k_rz_lab4 instead).
 //
 // HBM layout per context (planar float32, plane = stream): for every band level l = 0..L-2
 //   band_l   current high-pass band                       (RieszPyramidLevel::itsLowpass)
@@ -12,17 +13,19 @@
 //   lo_l[4], hi_l[4]    Direct-Form-II registers of the two order-2 Butterworth low-passes
 //   amp_l, tc_l, ts_l   sqrt amplitude and (hi - lo) * amp   (inputs of the 13-tap blurs)
 //   bandA_l  amplified band (collapse input)
-// plus the octaves oct_l (oct_0 = L plane) and the collapse results res_l.
+// plus the octaves oct_l (oct_0 = L plane), the collapse results res_l and the (ia, ib) dword plane of the frame.
 //
 // Launch sequence (one frame, or a temporal batch of T frames of every stream):
-//   k_rz_lab4 | k_rz_lab             u8 BGR -> L plane (exact float64 cube root)
-//   k_rz_split2 | k_rz_split x (L-1) 9x9 high-pass (band) + 9x9 low-pass at even pixels (next octave), one LDS tile
-//   k_rz_phase (one launch, all band levels)   Riesz pair (5-tap H/V), quaternion phase difference vs prior, amplitude,
-//                                    phase accumulation, both IIR filters, prior <- current; in a batch the frame loop
-//                                    runs inside the kernel with the 13 state values in registers
-//   k_rz_blur_amp4 | k_rz_blur_amp   three separable 13-tap Gaussians (amp, c, s) + phase-shift of the band
+//   k_lab_planes (labconv.hip)       u8 BGR -> forward table -> float L plane + (ia, ib) plane
+//   k_rz_split_rows | k_rz_split2 | k_rz_split x (L-1)   9x9 high-pass (band) + 9x9 low-pass at even pixels (next octave):
+//                                    wave strips with DPP halo (large levels) | one LDS tile
+//   k_rz_phase4 | k_rz_phase (one launch per variant, all band levels)   Riesz pair (5-tap H/V), quaternion phase difference
+//                                    vs prior, amplitude, phase accumulation, both IIR filters, prior <- current; in a batch
+//                                    the frame loop runs inside the kernel with the 13 state values in registers
+//   k_rz_blur_strips | k_rz_blur_amp4 | k_rz_blur_amp   three separable 13-tap Gaussians (amp, c, s) + phase-shift of the
+//                                    band (strips: register window + DPP halo, Riesz pair recomputed from the band)
 //   k_rz_collapse x (L-2)            res_l = lp(zero-inject(res_{l+1})) (polyphase) + hp(bandA_l)
-//   k_rz_final                       level-0 collapse + Lab2BGR(L', a, b) -> u8
+//   k_rz_final                       level-0 collapse + Lab2BGR(L', a, b) -> u8, (a, b) from the dword plane
 // Summation order of every filter equals the oracle's (row-major non-zero taps, fma chain).
 #include <cmath>
 #include <type_traits>
@@ -1577,14 +1580,22 @@ static int riesz_reserve_frames(Ctx* c, RieszState* st, int nt, hipStream_t s) {
     static const int kPer[] = {F_BAND, F_AMP, F_TC, F_TS, F_BANDA, F_R1C, F_R2C};
     size_t total = 64;
     for (int l = 0; l < levels; ++l) total += 2 * pad(st->g[l].n * NS * nt);
-    for (int l = 0; l < levels - 1; ++l) total += 7 * pad(st->g[l].n * NS * nt);
+    // Levels whose amplify stage runs as strips for EVERY batch size of this context (rz_level_uses_strips already at one
+    // frame per launch: level 0 of a 1080p stream) never touch a per-frame copy of the Riesz pair -- rz_phase points those
+    // slots at the state planes and the strip kernel recomputes the pair -- so none is allocated (0.5 GB per 32 frames of
+    // 1080p at level 0 alone).
+    auto needs_pair = [&](int l) { return !rz_level_uses_strips(st, l, NS); };
+    for (int l = 0; l < levels - 1; ++l) total += (needs_pair(l) ? 7 : 5) * pad(st->g[l].n * NS * nt);
     total += pad(st->g[0].n * NS * nt);
     if (hipMalloc((void**)&st->tarena, total * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); st->tarena = nullptr; c->err = "riesz: hipMalloc (frames) failed"; return LVM_ERR_OOM; }
     float* q = st->tarena;
     for (int l = 0; l < levels; ++l) { st->oct_t[l] = q; q += pad(st->g[l].n * NS * nt); st->res_t[l] = q; q += pad(st->g[l].n * NS * nt); }
     for (int l = 0; l < levels - 1; ++l) {
         for (int k = 0; k < F_ALL_N; ++k) st->ft[l][k] = st->f[l][k];          // state planes are shared
-        for (int k : kPer) { st->ft[l][k] = q; q += pad(st->g[l].n * NS * nt); }
+        for (int k : kPer) {
+            if ((k == F_R1C || k == F_R2C) && !needs_pair(l)) { st->ft[l][k] = st->f[l][k == F_R1C ? F_R1 : F_R2]; continue; }   // as riesz_alloc does for per-frame calls
+            st->ft[l][k] = q; q += pad(st->g[l].n * NS * nt);
+        }
     }
     st->iab_t = reinterpret_cast<uint32_t*>(q); q += pad(st->g[0].n * NS * nt);
     st->tcap = nt;

@@ -66,6 +66,23 @@ void lvmo_set_threads(int n) {
 #endif
 }
 
+/* ---- unpinned OpenCV build choices as SWITCHES (tests/test_oracle_variants.py) -------------
+ * No OpenCV exists in this image, so a handful of choices that depend on the OpenCV build (CPU dispatch of its SIMD
+ * loops, scalar type of Mat * double) cannot be checked.  Each is a bit here; 0 = the restatement every parity test
+ * runs against.  The variant tests run whole clips under every bit and report how far the frames move: that envelope,
+ * not an argument, is what bounds "oracle vs a real OpenCV build".                                                    */
+static unsigned g_var = 0;
+static void lab_lut_drop(void);
+void lvmo_set_variant(unsigned mask) {
+    const unsigned lut_bits = LVMO_VAR_GAMMA_F32 | LVMO_VAR_LUT_NUDGE_UP | LVMO_VAR_LUT_NUDGE_DOWN;
+    if ((mask ^ g_var) & lut_bits) lab_lut_drop();
+    g_var = mask;
+}
+unsigned lvmo_get_variant(void) { return g_var; }
+/* one filter / pyramid tap: s + k * v.  [cv] v_muladd == v_fma in the AVX2 / AVX-512 / NEON dispatches (one rounding);
+ * the baseline SSE2 dispatch rounds the product first (LVMO_VAR_FILTER_UNFUSED).                                      */
+static inline float tap(float k, float v, float s) { return (g_var & LVMO_VAR_FILTER_UNFUSED) ? s + k * v : fmaf(k, v, s); }
+
 /* ------------------------------------------------------------------------------------- */
 /* scalar helpers of the reference that need no OpenCV                                     */
 /* ------------------------------------------------------------------------------------- */
@@ -163,9 +180,13 @@ void lvmo_pyr_down(const float* src, int w, int h, int cn, float* dst) {
         for (int x = 0; x < dw; ++x) {
             const int x0 = reflect101(2 * x - 2, w), x1 = reflect101(2 * x - 1, w), x2 = 2 * x,
                       x3 = reflect101(2 * x + 1, w), x4 = reflect101(2 * x + 2, w);
-            for (int c = 0; c < cn; ++c)
-                r[x * cn + c] = s[x2 * cn + c] * 6.f + (s[x1 * cn + c] + s[x3 * cn + c]) * 4.f +
-                                s[x0 * cn + c] + s[x4 * cn + c];
+            for (int c = 0; c < cn; ++c) {
+                const float t0 = s[x0 * cn + c], t1 = s[x1 * cn + c], t2 = s[x2 * cn + c], t3 = s[x3 * cn + c], t4 = s[x4 * cn + c];
+                /* [cv] scalar loop (and the form every parity test uses); LVMO_VAR_PYR_SIMD: PyrDownVecH's
+                 * v_muladd(r2, 6, v_muladd(r1 + r3, 4, r0 + r4)) */
+                r[x * cn + c] = (g_var & LVMO_VAR_PYR_SIMD) ? fmaf(t2, 6.f, fmaf(t1 + t3, 4.f, t0 + t4))
+                                                            : t2 * 6.f + (t1 + t3) * 4.f + t0 + t4;
+            }
         }
     }
 #pragma omp parallel for schedule(static)
@@ -176,6 +197,9 @@ void lvmo_pyr_down(const float* src, int w, int h, int cn, float* dst) {
         const float* r3 = rows + (size_t)reflect101(2 * y + 1, h) * dw * cn;
         const float* r4 = rows + (size_t)reflect101(2 * y + 2, h) * dw * cn;
         float* d = dst + (size_t)y * dw * cn;
+        if (g_var & LVMO_VAR_PYR_SIMD)         /* [cv] PyrDownVecV<float>: v_muladd(r1 + r3 + r2, 4, r0 + r4 + (r2 + r2)) * scale */
+            for (int i = 0; i < dw * cn; ++i) d[i] = fmaf(r1[i] + r3[i] + r2[i], 4.f, r0[i] + r4[i] + (r2[i] + r2[i])) * (1.f / 256.f);
+        else
         for (int i = 0; i < dw * cn; ++i)
             d[i] = (r2[i] * 6.f + (r1[i] + r3[i]) * 4.f + r0[i] + r4[i]) * (1.f / 256.f);
     }
@@ -221,7 +245,10 @@ void lvmo_pyr_up(const float* src, int w, int h, int cn, float* dst, int dw, int
         float* d1 = dst + (size_t)y1 * dw * cn;
         for (int i = 0; i < ncol; ++i) {
             const float t1 = ((r1[i] + r2[i]) * 4.f) * (1.f / 64.f);
-            const float t0 = (r0[i] + r1[i] * 6.f + r2[i]) * (1.f / 64.f);
+            /* LVMO_VAR_PYR_SIMD: [cv] PyrUpVecV<float>: scale * (v_muladd(6, r1, r0) + r2); the odd row's scale * 4 * (r1 + r2)
+             * equals ((r1 + r2) * 4) * scale (power-of-two factors) */
+            const float t0 = (g_var & LVMO_VAR_PYR_SIMD) ? (fmaf(6.f, r1[i], r0[i]) + r2[i]) * (1.f / 64.f)
+                                                         : (r0[i] + r1[i] * 6.f + r2[i]) * (1.f / 64.f);
             d1[i] = t1;
             d0[i] = t0;
         }
@@ -305,10 +332,18 @@ static void lab_init(void) {
                                             0.041556, 0.055648, -0.204043, 1.057311 };
     static const double D65[3] = { 0.950456, 1.0, 1.088754 };
     float f[GAMMA_TAB_SIZE + 1], g[GAMMA_TAB_SIZE + 1];
-    for (int i = 0; i <= GAMMA_TAB_SIZE; ++i) {
-        double x = (double)i / GAMMA_TAB_SIZE;
-        f[i] = (float)(x <= 0.04045 ? x / 12.92 : pow((x + 0.055) / 1.055, 2.4));
-        g[i] = (float)(x <= 0.0031308 ? x * 12.92 : 1.055 * pow(x, 1.0 / 2.4) - 0.055);
+    /* [cv] initLabTabs: g[i] = applyGamma(x), ig[i] = applyInvGamma(x), x = softfloat(i) / 1024; both promote x to
+     * softdouble, use the BINARY32 constants 809/20000, 7827/2500000, 323/25, 12/5, 11/200 promoted likewise, evaluate pow
+     * in binary64 and round once (round 4: rounds 1-3 used the binary64 constants 0.04045, 12.92, 2.4, 0.055, which moves
+     * some knots by one binary32 step) */
+    {
+        const double thr = (double)(809.f / 20000.f), ithr = (double)(7827.f / 2500000.f), low = (double)(323.f / 25.f),
+                     power = (double)(12.f / 5.f), shift = (double)(11.f / 200.f);
+        for (int i = 0; i <= GAMMA_TAB_SIZE; ++i) {
+            const double x = (double)((float)i * (1.0f / GAMMA_TAB_SIZE));
+            f[i] = (float)(x <= thr ? x / low : pow((x + shift) / (1.0 + shift), power));
+            g[i] = (float)(x <= ithr ? x * low : pow(x, 1.0 / power) * (1.0 + shift) - shift);
+        }
     }
     spline_build(f, GAMMA_TAB_SIZE, g_gamma_tab);
     spline_build(g, GAMMA_TAB_SIZE, g_invgamma_tab);
@@ -375,13 +410,31 @@ static int16_t* g_lab_lut = NULL;               /* RGB2Labprev order: [3 (p + 33
                                                    (OpenCV then replicates the 8 corners of every cell: same values) */
 static int g_lab_use_lut = 1;
 void lvmo_set_lab_lut(int on) { g_lab_use_lut = on != 0; }
-static float lut_apply_gamma(float x) {         /* applyGamma(softfloat) */
+static void lab_lut_drop(void) { if (g_lab_lut) { free(g_lab_lut); g_lab_lut = NULL; } }
+/* [cv] applyGamma(softfloat x): "softdouble xd = x; return xd <= gammaThreshold ? xd / gammaLowScale :
+ * pow((xd + gammaXshift) / (softdouble::one() + gammaXshift), softdouble(gammaPower))" -- the argument is PROMOTED, the
+ * constants are binary32 values (softfloat(809) / softfloat(20000) ...) promoted likewise, pow runs in binary64 and the
+ * result is rounded ONCE to binary32 (round 4; rounds 1-3 restated it as three binary32 operations, which moves 24 of the
+ * 33 gamma nodes by up to 3e-7 relative and ~20 of the 107 811 table entries by one unit: LVMO_VAR_GAMMA_F32 keeps that
+ * form as a variant).  softdouble's pow is exp(y log x) evaluated with ~1e-15 relative error; the C library's pow stands
+ * in for it (a different binary32 result needs the binary64 value within ~1e-15 of a rounding boundary: p ~ 1e-8 per node). */
+static float lut_apply_gamma(float x) {
     const float thr = 809.f / 20000.f, low = 323.f / 25.f, shift = 11.f / 200.f, power = 12.f / 5.f;
-    if (x <= thr) return x / low;
-    const float base = (x + shift) / (1.f + shift);
-    const float lg = (float)log((double)base);
-    const float pr = power * lg;
-    return (float)exp((double)pr);
+    if (g_var & LVMO_VAR_GAMMA_F32) {
+        if (x <= thr) return x / low;
+        const float base = (x + shift) / (1.f + shift);
+        const float lg = (float)log((double)base);
+        const float pr = power * lg;
+        return (float)exp((double)pr);
+    }
+    const double xd = (double)x;
+    float g = (float)(xd <= (double)thr ? xd / (double)low : pow((xd + (double)shift) / (1.0 + (double)shift), (double)power));
+    /* the residual of the stand-in, as switches: every interior gamma node one binary32 step up / down */
+    if (x > 0.f && x < 1.f) {
+        if (g_var & LVMO_VAR_LUT_NUDGE_UP) g = nextafterf(g, 2.f);
+        if (g_var & LVMO_VAR_LUT_NUDGE_DOWN) g = nextafterf(g, -1.f);
+    }
+    return g;
 }
 static void lab_lut_init(void) {
     if (g_lab_lut) return;
@@ -413,7 +466,7 @@ static void lab_lut_init(void) {
 }
 void lvmo_lab_lut_table(int16_t* out) { lab_lut_init(); memcpy(out, g_lab_lut, sizeof(int16_t) * LAB_LUT_ENTRIES); }
 void lvmo_lab_lut_override(const int16_t* tab) {     /* NULL: back to the restated table */
-    if (g_lab_lut) { free(g_lab_lut); g_lab_lut = NULL; }
+    lab_lut_drop();
     if (!tab) return;
     g_lab_lut = (int16_t*)malloc(sizeof(int16_t) * LAB_LUT_ENTRIES);
     memcpy(g_lab_lut, tab, sizeof(int16_t) * LAB_LUT_ENTRIES);
@@ -512,10 +565,10 @@ void lvmo_filter2d(const float* src, int w, int h, const float* k, int kw, int k
         for (int x = 0; x < w; ++x) {
             float s = 0.f;
             if (x >= ax && x < w - ax && y >= ay && y < h - ay) {
-                for (int t = 0; t < nt; ++t) s = fmaf(tk[t], src[(size_t)(y + ty[t]) * w + x + tx[t]], s);
+                for (int t = 0; t < nt; ++t) s = tap(tk[t], src[(size_t)(y + ty[t]) * w + x + tx[t]], s);
             } else {
                 for (int t = 0; t < nt; ++t)
-                    s = fmaf(tk[t], src[(size_t)reflect101(y + ty[t], h) * w + reflect101(x + tx[t], w)], s);
+                    s = tap(tk[t], src[(size_t)reflect101(y + ty[t], h) * w + reflect101(x + tx[t], w)], s);
             }
             dst[(size_t)y * w + x] = s;
         }
@@ -546,7 +599,7 @@ void lvmo_sep_filter(const float* src, int w, int h, const float* k, int n, floa
         const float* s = src + (size_t)y * w;
         for (int x = 0; x < w; ++x) {
             float acc = k[0] * s[reflect101(x - r, w)];
-            for (int j = 1; j < n; ++j) acc = fmaf(k[j], s[reflect101(x - r + j, w)], acc);
+            for (int j = 1; j < n; ++j) acc = tap(k[j], s[reflect101(x - r + j, w)], acc);
             tmp[(size_t)y * w + x] = acc;
         }
     }
@@ -555,8 +608,8 @@ void lvmo_sep_filter(const float* src, int w, int h, const float* k, int n, floa
         for (int x = 0; x < w; ++x) {
             float acc = k[r] * tmp[(size_t)y * w + x];
             for (int j = 1; j <= r; ++j)
-                acc = fmaf(k[r + j], tmp[(size_t)reflect101(y + j, h) * w + x] +
-                                      tmp[(size_t)reflect101(y - j, h) * w + x], acc);
+                acc = tap(k[r + j], tmp[(size_t)reflect101(y + j, h) * w + x] +
+                                     tmp[(size_t)reflect101(y - j, h) * w + x], acc);
             dst[(size_t)y * w + x] = acc;
         }
     }
@@ -886,8 +939,11 @@ static int magnify_motion(lvmo_ctx* c, const uint8_t* in, int w, int h, int chan
             float *hi = c->m_hi[l].d, *lo = c->m_lo[l].d; const float* s = pyr[l].d; float* m = motion[l].d;
 #pragma omp parallel for schedule(static)
             for (size_t i = 0; i < n; ++i) {
-                const float t1 = hi[i] * aHi + s[i] * bHi;               /* TemporalFilter.cpp:16 */
-                const float t2 = lo[i] * aLo + s[i] * bLo;               /* :17 */
+                /* [cv] MatExpr a*alpha + b*beta = addWeighted; scalar loop a*alpha + b*beta (two products, one sum);
+                 * LVMO_VAR_ADDW_FUSED: the SIMD loop's v_fma(a, alpha, v_fma(b, beta, gamma = 0)) */
+                const int fw = (g_var & LVMO_VAR_ADDW_FUSED) != 0;
+                const float t1 = fw ? fmaf(hi[i], aHi, s[i] * bHi) : hi[i] * aHi + s[i] * bHi;   /* TemporalFilter.cpp:16 */
+                const float t2 = fw ? fmaf(lo[i], aLo, s[i] * bLo) : lo[i] * aLo + s[i] * bLo;   /* :17 */
                 hi[i] = t1; lo[i] = t2;
                 m[i] = t1 - t2;                                          /* :21 */
             }
@@ -1101,7 +1157,7 @@ static void rfilt_reset_mat(RieszFilt* f) {                             /* :353-
     }
 }
 /* [cv] multiply(Mat32f, double scalar): evaluated in float64, rounded once to float32 */
-static inline float mul_sd(float x, double s) { return (float)((double)x * s); }
+static inline float mul_sd(float x, double s) { return (g_var & LVMO_VAR_MUL_F32) ? x * (float)s : (float)((double)x * s); }   /* LVMO_VAR_MUL_F32: a build that narrows the scalar first */
 /* RieszTemporalFilter::IIRTemporalFilter (TemporalFilter.cpp:340-351), one component */
 static void rfilt_iir_comp(float* ph, float* r0, float* r1, const float* d, float* res, size_t n,
                            const double* a, const double* b) {

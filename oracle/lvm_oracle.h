@@ -107,6 +107,20 @@ void lvmo_set_lab_lut(int on);
 void lvmo_lab_lut_table(int16_t* out);
 void lvmo_lab_lut_override(const int16_t* tab);
 
+/* Unpinned OpenCV build choices as switches (bit mask, 0 = the restatement the parity tests use; lvm_oracle.c "unpinned OpenCV
+ * build choices").  tests/test_oracle_variants.py runs BASELINE configs under every bit and records the envelope. */
+enum {
+    LVMO_VAR_PYR_SIMD        = 1,    /* pyrDown / pyrUp sums in the association of OpenCV's SIMD loops (PyrDownVecH/V, PyrUpVecV) instead of the scalar loops' */
+    LVMO_VAR_FILTER_UNFUSED  = 2,    /* filter2D / sepFilter2D taps as multiply + add (SSE2 baseline dispatch) instead of fma (AVX2 / NEON) */
+    LVMO_VAR_ADDW_FUSED      = 4,    /* Laplace IIR a*alpha + b*beta as addWeighted's SIMD form fma(a, alpha, b*beta) instead of two products + sum */
+    LVMO_VAR_MUL_F32         = 8,    /* Riesz IIR Mat * double with the scalar narrowed to float first instead of a float64 product rounded once */
+    LVMO_VAR_GAMMA_F32       = 16,   /* forward Lab table: applyGamma as three binary32 operations (the rounds 1-3 restatement) instead of softdouble pow rounded once */
+    LVMO_VAR_LUT_NUDGE_UP    = 32,   /* forward Lab table: every interior gamma node one binary32 step up (bounds a last-bit disagreement of pow) */
+    LVMO_VAR_LUT_NUDGE_DOWN  = 64    /* ... one step down */
+};
+void     lvmo_set_variant(unsigned mask);
+unsigned lvmo_get_variant(void);
+
 /* Exporter::compose (export/Exporter.cpp:53-88) without the text overlay */
 int lvmo_compose_geometry(int split, int ow, int oh, int pw, int ph, int* cw, int* ch);
 int lvmo_compose(int split, const uint8_t* orig, int ow, int oh, int och, ptrdiff_t ostride, const uint8_t* proc, int pw, int ph,

@@ -94,6 +94,9 @@ def lib():
         L.lvmo_lab_lut_table.restype = None
         L.lvmo_lab_lut_override.argtypes = [C.c_void_p]
         L.lvmo_lab_lut_override.restype = None
+        L.lvmo_set_variant.argtypes = [C.c_uint]
+        L.lvmo_set_variant.restype = None
+        L.lvmo_get_variant.restype = C.c_uint
         L.lvmo_compose_geometry.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip]
         L.lvmo_compose.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                    C.c_ssize_t, C.c_void_p, C.c_ssize_t]
@@ -101,6 +104,21 @@ def lib():
         L.lvmo_set_threads(max(1, min(8, os.cpu_count() or 1)))
         _lib = L
     return _lib
+
+
+# lvm_oracle.h LVMO_VAR_*: the unpinned OpenCV build choices as switches (0 = the restatement the parity tests use)
+VARIANTS = {"pyr_simd": 1, "filter_unfused": 2, "addw_fused": 4, "mul_f32": 8, "gamma_f32": 16, "lut_nudge_up": 32,
+            "lut_nudge_down": 64}
+
+
+def set_variant(mask):
+    lib().lvmo_set_variant(int(mask))
+
+
+def lab_lut_table():
+    t = np.empty(33 * 33 * 33 * 3, np.int16)
+    lib().lvmo_lab_lut_table(t.ctypes.data)
+    return t
 
 
 def ref_slices():

@@ -326,24 +326,37 @@ def test_emu_unfused_conversion_in_batches(lvm, po, emu, monkeypatch):
     _frames_clip(lvm, po, emu, 0, 320, 180, 4, 1, (1, 6, 5))
 
 
-@pytest.mark.parametrize("chunks,fused", [("2", "1"), ("3", "0")])
-def test_emu_chunked_batches(lvm, po, emu, chunks, fused, monkeypatch):
-    """LVM_LAP_CHUNKS: a temporal batch cut into chunks whose table conversion + first kernel are issued on the auxiliary
-    stream ahead of the rest (per-chunk slices of the batch buffers and of the integer planes)."""
-    monkeypatch.setenv("LVM_LAP_CHUNKS", chunks)
-    monkeypatch.setenv("LVM_D0_FUSED_WAVES", "1")
-    monkeypatch.setenv("LVM_D0_FUSED", fused)
-    _frames_clip(lvm, po, emu, 0, 264, 90, 3, 1, (1, 12, 9))
+@pytest.mark.parametrize("w,h,levels,ns,calls", [
+    (320, 180, 2, 1, (1, 4, 3)),        # two levels: level 1 is the top live level (no cur_2), too large for the tail kernel
+    (264, 74, 3, 1, (1, 6, 1, 2)),      # partial tiles right and below, per-frame calls in between
+    (132, 70, 3, 2, (1, 5, 3)),         # level 2 with an odd width: level chain for level 2, then the fused kernel; two streams
+    (160, 91, 3, 1, (1, 4, 4)),         # odd frame height (pyrUp with dsize = 2 n - 1 on both steps)
+    (520, 150, 4, 1, (1, 9)),           # five tiles across: interior tiles without any border lane
+    (128, 16, 2, 1, (1, 3, 3)),         # exactly one tile
+])
+def test_laplace_emu_level1_fused_into_the_last_kernel(lvm, po, emu, w, h, levels, ns, calls):
+    """k_lap_final1: level-1 band / IIR / collapse step + last kernel in one launch, cur_1 in LDS, the level-1 states in
+    registers for the whole batch and double-buffered across launches (a tile's ring pixels are state copies read from a
+    neighbour's planes).  Bit-identical to the oracle over several calls, i.e. across the buffer swap."""
+    _frames_clip(lvm, po, emu, 0, w, h, levels, ns, calls)
 
 
-@pytest.mark.parametrize("chunks,d0_waves,ns", [("2", "10", 1), ("3", "1", 1), ("2", "15", 2)])
-def test_emu_last_kernel_fused_with_next_first_kernel(lvm, po, emu, chunks, d0_waves, ns, monkeypatch):
-    """LVM_LAP_FUSE_CHUNKS: the last kernel of chunk k and the table conversion + first kernel of chunk k + 1 as ONE launch
-    whose waves are split between the two kinds of strips (k_lap_final_down0), incl. the extreme splits 1 : 15 and 15 : 1."""
-    monkeypatch.setenv("LVM_LAP_FUSE_CHUNKS", chunks)
-    monkeypatch.setenv("LVM_LAP_FUSE_D0_WAVES", d0_waves)
-    monkeypatch.setenv("LVM_D0_FUSED_WAVES", "1")
-    _frames_clip(lvm, po, emu, 0, 264, 90, 3, ns, (1, 12, 9, 5))
+@pytest.mark.parametrize("w,h,levels,calls", [(264, 74, 3, (1, 6, 1, 2)), (320, 180, 4, (1, 8))])
+def test_laplace_emu_unfused_level1_still_matches(lvm, po, emu, w, h, levels, calls, monkeypatch):
+    """LVM_LAP_FINAL1=0: k_lap_up at level 1 + k_lap_final_v4 (what odd level-1 widths and non-vector frames always use)."""
+    monkeypatch.setenv("LVM_LAP_FINAL1", "0")
+    _frames_clip(lvm, po, emu, 0, w, h, levels, 1, calls)
+
+
+def test_laplace_emu_fused_and_unfused_level1_share_their_states(lvm, po, emu):
+    """A parameter change between calls (the fused kernel swaps the level-1 state planes every launch) and a frame geometry that
+    switches between the two forms (4-aligned width vs. not) keep matching the oracle frame by frame."""
+    ck, pk = lvm.synth.config(0, (264, 74, 3))
+    def vary(t, q):
+        if t >= 5:
+            q["amplification"] = 35.0; q["chromAttenuation"] = 0.4
+        return q
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 9, 0.0, exact=True, param_fn=vary)
 
 
 def test_emu_fused_conversion_in_batches_two_streams(lvm, po, emu, monkeypatch):

@@ -92,6 +92,15 @@ def test_laplace_1080p_64_frames_state_drift(lvm, po, hip):
     print("laplace 1080p 64 frames worst rel/u8/frac", worst)
 
 
+def test_riesz_1080p_64_frames_state_drift(lvm, po, hip):
+    """BASELINE.json configs[2] at full size for 64 frames: the float metric and the u8 bars on EVERY frame, temporal
+    state (phase accumulators, both Butterworth register pairs, prior pyramid) drifting for the whole clip -- SURVEY 8c(i)
+    for the ill-conditioned mode (the Laplace twin is the test above)."""
+    ck, pk = lvm.synth.config(2)
+    worst = run_pair(lvm, po, hip, lvm.synth.Clip(**ck), pk, 64, 1e-4)
+    print("riesz 1080p 64 frames worst rel/u8/frac", worst)
+
+
 def _bench(args, timeout=900):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
@@ -138,6 +147,33 @@ def test_bench_two_ranks_from_a_plain_shell():
     expect = 2 * 1 * 8 / out["timed_seconds_max_over_ranks"]
     assert abs(out["value"] - expect) <= 1e-6 * expect + 0.01
     assert out["cfg4_riesz_4k"]["n_gpus"] == 2
+
+
+def test_bench_one_rank_over_rccl():
+    """First contact with RCCL before the driver's 8-GPU box: bench.py launched the way the driver launches it
+    (`python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1`) initialises the `nccl` (= RCCL on ROCm)
+    process group at world size 1, runs the device-tensor all-reduce, the barriers and the MAX-reduce of the timed region
+    through it, and reports what RCCL saw."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dist-backend", "nccl", "--steps", "8",
+           "--warmup", "4", "--width", "320", "--height", "180", "--levels", "4", "--no-subrecords", "--frames-per-call", "4", "--ring", "8"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["dist"] == {"initialized": True, "backend": "nccl", "world_size": 1, "ranks_seen_by_allreduce": 1}, out["dist"]
+    assert out["n_gpus"] == 1 and out["verified"] is True, out["verification"]
+    assert out["ranks"][0]["device"] == "cuda:0" and out["ranks"][0]["device_name"]
+    assert out["cpu_baseline"]["host_cores"] == os.cpu_count() and out["cpu_baseline"]["single_thread"]["cores"] == 1
 
 
 def test_bench_eight_ranks_dry_run():

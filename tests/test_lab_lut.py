@@ -90,11 +90,11 @@ def _numpy_table():
     C = (M * np.array([1.0 / D65[0], 1.0, 1.0 / D65[2]])[:, None]).astype(f32)
     g = np.arange(33, dtype=f32) / f32(32)
     thr, low, shift, power = f32(809) / f32(20000), f32(323) / f32(25), f32(11) / f32(200), f32(12) / f32(5)
-    base = ((g + shift) / (f32(1) + shift)).astype(f32)
-    with np.errstate(divide="ignore"):
-        lg = np.log(base.astype(np.float64)).astype(f32)
-    hi = np.exp((power * lg).astype(f32).astype(np.float64)).astype(f32)
-    gam = np.where(g <= thr, (g / low).astype(f32), hi).astype(f32)
+    # applyGamma: argument and binary32 constants promoted to binary64, pow in binary64, ONE rounding (color_lab.cpp's softdouble form)
+    f64 = np.float64
+    gd = g.astype(f64)
+    hi = np.power((gd + f64(shift)) / (f64(1) + f64(shift)), f64(power))
+    gam = np.where(gd <= f64(thr), gd / f64(low), hi).astype(f32)
     R, G, B = gam[None, None, :], gam[None, :, None], gam[:, None, None]          # [r][q][p]: p = R fastest
     def lin(c):
         return ((R * c[0]).astype(f32) + (G * c[1]).astype(f32)).astype(f32) + (B * c[2]).astype(f32)
