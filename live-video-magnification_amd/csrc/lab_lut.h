@@ -25,6 +25,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <lvm_gfx950.h>
 
 namespace lvm {
 
@@ -35,26 +36,7 @@ constexpr int kLabLutNodes = kLabLutDim * kLabLutDim * kLabLutDim;
 constexpr int kLabAbWords = kLabLutNodes + 34;
 constexpr int kLabLCells = 17 * 17 * 17 * 8;       // cells in 2 x 2 x 2 blocks (lcell_index)
 
-#ifndef LVM_EMU_NO_DOT2
-typedef short lut_s2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int lut_dot2(uint32_t pair, uint32_t wts, int acc) {
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(lut_s2, pair), __builtin_bit_cast(lut_s2, wts), acc, false);
-}
-// (lo16(d), lo16(e)) and (hi16(d), hi16(e)) of two dwords
-__device__ __forceinline__ uint32_t lut_lo2(uint32_t d, uint32_t e) { return __builtin_amdgcn_perm(e, d, 0x05040100u); }
-__device__ __forceinline__ uint32_t lut_hi2(uint32_t d, uint32_t e) { return __builtin_amdgcn_perm(e, d, 0x07060302u); }
-// 24-bit x 24-bit -> low 32 bits as ONE full-rate v_mul_u32_u24.  Spelled as an instruction: a plain product is re-associated by the
-// compiler ((x0 y0) wz -> (wz x0) y0, whose intermediate no longer fits 24 bits) and then becomes the quarter-rate v_mul_lo_u32 --
-// four of them per pixel in round 3's ISA, ~12 issue slots of the conversion's ~94
-__device__ __forceinline__ uint32_t lut_mul24(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-#else           // tests/emu (g++): the same values spelled out
-__device__ __forceinline__ int lut_dot2(uint32_t pair, uint32_t wts, int acc) {
-    return acc + (int)(int16_t)(pair & 0xffff) * (int)(int16_t)(wts & 0xffff) + (int)(int16_t)(pair >> 16) * (int)(int16_t)(wts >> 16);
-}
-__device__ __forceinline__ uint32_t lut_lo2(uint32_t d, uint32_t e) { return (d & 0xffffu) | (e << 16); }
-__device__ __forceinline__ uint32_t lut_hi2(uint32_t d, uint32_t e) { return (d >> 16) | (e & 0xffff0000u); }
-__device__ __forceinline__ uint32_t lut_mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
-#endif
+// lut_dot2 / lut_lo2 / lut_hi2 / lut_mul24 (v_dot2_i32_i16, v_perm_b32, v_mul_u32_u24): lvm_gfx950.h
 
 // fine grid coordinate of a u8 channel value: bits 4.. = cell, bits 0..3 = weight of the upper neighbour
 __device__ __forceinline__ uint32_t lut_fine(uint32_t u) { return (u * 514u + 4u) >> 8; }

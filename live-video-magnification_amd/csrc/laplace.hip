@@ -814,7 +814,7 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(FinArgs q) {
 //   phase 3  the last kernel on that tile: pyrUp(cur_1) from LDS, Lab(in) from the integer planes, add, Lab2BGR, u8 out
 //            (a thread = 4 columns x 2 rows; the arithmetic is lap_final_strip's).
 // The states are double-buffered per launch (every level-1 pixel is owned, i.e. written, by exactly one workgroup).
-// Two barriers per frame.  The loads of frame t + 1 (level-2 taps, G_1, integer planes) are issued before frame t is computed.
+// Two barriers per frame.
 // Why tiles and not wave strips: with the frame loop inside, a launch's parallelism is pixels / (pixels per lane), not x frames; 8
 // pixels per lane and 4 waves per SIMD is what fills an MI355X with ONE 1080p stream (1020 workgroups for 1024 resident slots), and a
 // strip with its own halo rows would need 32 pixels per lane.  Same operations in the same order as k_lap_up + k_lap_final_v4:
@@ -930,12 +930,13 @@ __global__ __launch_bounds__(256, 4) void k_lap_final1(Fin1Args q) {
     const int gyl = act ? gy : 0, gyl1 = act1 ? gy + 1 : gyl;          // rows the inactive threads load instead (never stored)
     const unsigned gxl = act ? (unsigned)gx : 0u;
 
-    // loads of one frame: level-2 taps (G_2, cur_2), G_1 of the items, the two rows of integer planes
-    f2 n2v[F1_U1]; float ng1[F1_NQ + 1]; Raw4 npe, npo;
-    auto fetch = [&](int t) __attribute__((always_inline)) {
+    // Loads of a frame.  The level-2 taps (first use: phase 1) of frame t + 1 are issued before phase 3 of frame t and fly through it; G_1
+    // (phase 2) and the two rows of integer planes (phase 3) are issued at the top of their own frame, ahead of phase 1.  (All three a
+    // whole frame ahead would hold 33 more registers across phase 3, the widest part: 128 VGPRs + scratch spills.)
+    f2 n2v[F1_U1];
+    auto fetch_l2 = [&](int t) __attribute__((always_inline)) {
         const float* G2t = q.G2 + (size_t)t * q.fs2;
         const float* C2t = (HC ? q.cur2 : q.G2) + (size_t)t * q.fs2;
-        const float* G1t = q.G1 + (size_t)t * q.fs1;
 #pragma unroll
         for (int i = 0; i < F1_U1; ++i) {
             int ch, mr, m;
@@ -943,26 +944,24 @@ __global__ __launch_bounds__(256, 4) void k_lap_final1(Fin1Args q) {
             const size_t rowb = (size_t)(sb * 3 + ch) * n2 + (size_t)m * w2;     // (uniform)
             n2v[i][0] = (G2t + rowb)[kc]; n2v[i][1] = HC ? (C2t + rowb)[kc] : 0.f;
         }
-#pragma unroll
-        for (int qi = 0; qi < F1_NQ; ++qi) {
-            int ch, ry, cy;
-            const bool vy = unit2(qi, ch, ry, cy);
-            ng1[qi] = (G1t + (size_t)(sb * 3 + ch) * n1 + (size_t)(vy ? cy : 0) * w1)[cxc];
-        }
-        ng1[F1_NQ] = G1t[xoffg];
-        LabPlanes lpt = q.lp;
-        npe = load_raw4<PLANES>(src + (size_t)t * in_fs, q.in_stride, lpt, poff + (size_t)t * px_fs, w, gyl, gxl);
-        npo = load_raw4<PLANES>(src + (size_t)t * in_fs, q.in_stride, lpt, poff + (size_t)t * px_fs, w, gyl1, gxl);
     };
-    fetch(0);
+    fetch_l2(0);
     for (int t = 0; t < q.nt; ++t) {
         f2 c2v[F1_U1]; float g1[F1_NQ + 1];
 #pragma unroll
         for (int i = 0; i < F1_U1; ++i) c2v[i] = n2v[i];
+        {
+            const float* G1t = q.G1 + (size_t)t * q.fs1;
 #pragma unroll
-        for (int qi = 0; qi <= F1_NQ; ++qi) g1[qi] = ng1[qi];
-        const Raw4 pe = npe, po = npo;
-        fetch(t + 1 < q.nt ? t + 1 : q.nt - 1);                       // (unconditional: the prefetch registers are refilled every iteration)
+            for (int qi = 0; qi < F1_NQ; ++qi) {
+                int ch, ry, cy;
+                const bool vy = unit2(qi, ch, ry, cy);
+                g1[qi] = (G1t + (size_t)(sb * 3 + ch) * n1 + (size_t)(vy ? cy : 0) * w1)[cxc];
+            }
+            g1[F1_NQ] = G1t[xoffg];
+        }
+        const Raw4 pe = load_raw4<PLANES>(src + (size_t)t * in_fs, q.in_stride, q.lp, poff + (size_t)t * px_fs, w, gyl, gxl);
+        const Raw4 po = load_raw4<PLANES>(src + (size_t)t * in_fs, q.in_stride, q.lp, poff + (size_t)t * px_fs, w, gyl1, gxl);
 
         // ---- phase 1: horizontal pyrUp pass of the level-2 rows (OpenCV pyrUp_ border rules as pyrup_h)
 #pragma unroll
@@ -1015,6 +1014,7 @@ __global__ __launch_bounds__(256, 4) void k_lap_final1(Fin1Args q) {
             if (xu < F1_U2) s_C[xch][xry][xrx] = (HC ? up[1] : 0.f) + m;
         }
         __syncthreads();
+        fetch_l2(t + 1 < q.nt ? t + 1 : q.nt - 1);                   // (unconditional: the same registers are refilled every iteration)
         // ---- phase 3: out = u8(Lab2BGR(Lab(in) + [1, ca, ca] * pyrUp(cur_1))) for the thread's 4 x 2 pixels
         if (act) {
             Row3 A, B, C;
@@ -1222,7 +1222,8 @@ struct LaplaceState : ModeState {
     int fin_rows = 8;                     // rows per wave strip of k_lap_final_v4 (LVM_FIN_ROWS, power of two)
     int up_depth_big = 1;                 // ... at the levels with >= 1024 workgroups (LVM_UP_DEPTH_BIG)
     int up_depth = 8;                     // frame-loop prefetch depth of k_lap_up at the coarse levels (LVM_UP_DEPTH=1|2|4|8)
-    bool final1 = true;                   // level-1 step fused into the last kernel, cur_1 never in HBM (k_lap_final1; LVM_LAP_FINAL1=0: k_lap_up + k_lap_final_v4)
+    bool final1 = false;                  // level-1 step fused into the last kernel, cur_1 never in HBM (k_lap_final1; LVM_LAP_FINAL1=1).  Off: first GPU measurement 504 us
+                                          // per 32 frames against 106 + 208 us for k_lap_up + k_lap_final_v4 (profiles/README.md, round 4)
     int pd_rows = 16;                     // output rows per wave strip of k_pyr_down_rows (LVM_PD_ROWS)
     int fuse_down = 2;                    // pyramid levels per pyrDown launch (LVM_FUSE_DOWN=2|3 selects the fused kernels)
     int tailT = 0;                       // first level handled by k_lap_tail (0 = tail disabled)

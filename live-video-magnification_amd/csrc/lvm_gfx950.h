@@ -1,0 +1,50 @@
+// lvm_gfx950.h -- the gfx950-only primitives of liblvm_hip.so: instructions and address spaces that have no portable spelling.
+// Included as <lvm_gfx950.h> (the Makefile passes -I.).  The CPU emulation build of the TEST SUITE (tests/emu, test infrastructure)
+// puts its own lvm_gfx950.h first on the include path and never sees this file; nothing in the product refers to the emulation.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace lvm {
+
+// Read-only tables (written by the host before the launch, never by a kernel) read through the CONSTANT address space: in a kernel
+// that also stores, a plain global pointer cannot be assumed unmodified, so a wave-uniform table look-up becomes a vector load +
+// s_waitcnt vmcnt(0) + v_readfirstlane -- which drains every load the wave has in flight.  Through address space 4 it is an s_load.
+template <class T> using const_tab = const T __attribute__((address_space(4)))*;
+template <class T> __device__ __forceinline__ const_tab<T> as_const_tab(const T* p) { return (const_tab<T>)p; }
+
+// Buffer-resource loads / stores (raw buffer ops, stride 0): address = resource base (four SGPRs, built from wave-uniform values) +
+// per-lane 32-bit byte offset (VGPR) + wave-uniform 32-bit byte offset (SGPR).  No 64-bit address arithmetic in vector registers
+// (the generic form costs a VGPR pair and a v_lshl_add_u64 per load); an access outside [0, bytes) reads 0 / is dropped.
+struct B96 { uint32_t a, b, c; };
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+typedef unsigned int lvm_u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ BufRsrc buf_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld_f32(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ B96 buf_ld_b96(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    const lvm_u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, (int)soff, 0);
+    return B96{v.x, v.y, v.z};
+}
+__device__ __forceinline__ void buf_st_b96(const B96& v, const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    lvm_u32x3 q; q.x = v.a; q.y = v.b; q.z = v.c;
+    __builtin_amdgcn_raw_buffer_store_b96(q, r, (int)voff, (int)soff, 0);
+}
+
+// ---- forward Lab table (lab_lut.h) ----
+typedef short lut_s2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int lut_dot2(uint32_t pair, uint32_t wts, int acc) {
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(lut_s2, pair), __builtin_bit_cast(lut_s2, wts), acc, false);
+}
+// (lo16(d), lo16(e)) and (hi16(d), hi16(e)) of two dwords
+__device__ __forceinline__ uint32_t lut_lo2(uint32_t d, uint32_t e) { return __builtin_amdgcn_perm(e, d, 0x05040100u); }
+__device__ __forceinline__ uint32_t lut_hi2(uint32_t d, uint32_t e) { return __builtin_amdgcn_perm(e, d, 0x07060302u); }
+// 24-bit x 24-bit -> low 32 bits as ONE full-rate v_mul_u32_u24.  Spelled as an instruction: a plain product is re-associated by the
+// compiler ((x0 y0) wz -> (wz x0) y0, whose intermediate no longer fits 24 bits) and then becomes the quarter-rate v_mul_lo_u32 --
+// four of them per pixel in round 3's ISA, ~12 issue slots of the conversion's ~94
+__device__ __forceinline__ uint32_t lut_mul24(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+}  // namespace lvm

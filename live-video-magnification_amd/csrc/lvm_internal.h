@@ -17,6 +17,7 @@
 
 #include "lvm_hip.h"
 #include "lab_lut.h"
+#include <lvm_gfx950.h>   // gfx950-only primitives (constant-address-space tables, raw buffer loads / stores, v_dot2 / v_perm / v_mul_u32_u24)
 
 namespace lvm {
 
@@ -52,59 +53,6 @@ __device__ __forceinline__ uint32_t pack_u8x4(float v0, float v1, float v2, floa
     r = __builtin_amdgcn_cvt_pk_u8_f32(v2, 2, r);
     return __builtin_amdgcn_cvt_pk_u8_f32(v3, 3, r);
 }
-
-// Read-only tables (written by the host before the launch, never by a kernel) read through the CONSTANT address space: in a kernel
-// that also stores, a plain global pointer cannot be assumed unmodified, so a wave-uniform table look-up becomes a vector load +
-// s_waitcnt vmcnt(0) + v_readfirstlane -- which drains every load the wave has in flight.  Through address space 4 it is an s_load.
-#ifdef LVM_EMU_NO_CONST_AS
-template <class T> using const_tab = const T*;
-template <class T> __device__ __forceinline__ const_tab<T> as_const_tab(const T* p) { return p; }
-#else
-template <class T> using const_tab = const T __attribute__((address_space(4)))*;
-template <class T> __device__ __forceinline__ const_tab<T> as_const_tab(const T* p) { return (const_tab<T>)p; }
-#endif
-
-// Buffer-resource loads / stores (raw buffer ops, stride 0): address = resource base (four SGPRs, built from wave-uniform values) +
-// per-lane 32-bit byte offset (VGPR) + wave-uniform 32-bit byte offset (SGPR).  No 64-bit address arithmetic in vector registers
-// (the generic form costs a VGPR pair and a v_lshl_add_u64 per load); an access outside [0, bytes) reads 0 / is dropped.
-struct B96 { uint32_t a, b, c; };
-#ifdef LVM_EMU_NO_BUFFER_OPS
-struct BufRsrc { char* base; uint32_t bytes; };
-__device__ __forceinline__ BufRsrc buf_rsrc(const void* base, uint32_t bytes) { return BufRsrc{(char*)base, bytes}; }
-__device__ __forceinline__ float buf_ld_f32(const BufRsrc& r, uint32_t voff, uint32_t soff) {
-    const uint64_t o = (uint64_t)voff + soff;
-    float v = 0.f;
-    if (o + 4 <= r.bytes) std::memcpy(&v, r.base + o, 4);
-    return v;
-}
-__device__ __forceinline__ B96 buf_ld_b96(const BufRsrc& r, uint32_t voff, uint32_t soff) {
-    const uint64_t o = (uint64_t)voff + soff;
-    B96 v{0, 0, 0};
-    if (o + 12 <= r.bytes) std::memcpy(&v, r.base + o, 12);
-    return v;
-}
-__device__ __forceinline__ void buf_st_b96(const B96& v, const BufRsrc& r, uint32_t voff, uint32_t soff) {
-    const uint64_t o = (uint64_t)voff + soff;
-    if (o + 12 <= r.bytes) std::memcpy(r.base + o, &v, 12);
-}
-#else
-typedef __amdgpu_buffer_rsrc_t BufRsrc;
-typedef unsigned int lvm_u32x3 __attribute__((ext_vector_type(3)));
-__device__ __forceinline__ BufRsrc buf_rsrc(const void* base, uint32_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float buf_ld_f32(const BufRsrc& r, uint32_t voff, uint32_t soff) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
-}
-__device__ __forceinline__ B96 buf_ld_b96(const BufRsrc& r, uint32_t voff, uint32_t soff) {
-    const lvm_u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, (int)soff, 0);
-    return B96{v.x, v.y, v.z};
-}
-__device__ __forceinline__ void buf_st_b96(const B96& v, const BufRsrc& r, uint32_t voff, uint32_t soff) {
-    lvm_u32x3 q; q.x = v.a; q.y = v.b; q.z = v.c;
-    __builtin_amdgcn_raw_buffer_store_b96(q, r, (int)voff, (int)soff, 0);
-}
-#endif
 
 // Whole-wave shifts by one lane (DPP wave_shr:1 / wave_shl:1 cross all 64 lanes on gfx950, tools/probe_isa.hip):
 // lane i receives lane i - 1's (shr) / lane i + 1's (shl) value; lane 0 / lane 63 receive 0.

@@ -57,9 +57,9 @@ struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 static inline uint2 make_uint2(unsigned x, unsigned y) { uint2 r; r.x = x; r.y = y; return r; }
 static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { uint4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
-#define LVM_EMU_NO_DOT2 1      // lab_lut.h: v_dot2_i32_i16 spelled out
-#define LVM_EMU_NO_CONST_AS 1  // lvm_internal.h: no constant address space on the host
-#define LVM_EMU_NO_BUFFER_OPS 1 // lvm_internal.h: buffer resource loads / stores as bounds-checked host accesses
+
+
+
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }

@@ -1,0 +1,39 @@
+// TEST INFRASTRUCTURE ONLY -- the CPU spelling of the product's lvm_gfx950.h (csrc/lvm_gfx950.h: constant address space, raw buffer
+// loads / stores, v_dot2_i32_i16 / v_perm_b32 / v_mul_u32_u24), same names and semantics, for the emulation build of tests/emu.
+// tests/emu/build_emu.sh puts this directory first on the include path, so <lvm_gfx950.h> resolves here.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstring>
+
+namespace lvm {
+
+template <class T> using const_tab = const T*;
+template <class T> __device__ __forceinline__ const_tab<T> as_const_tab(const T* p) { return p; }
+struct B96 { uint32_t a, b, c; };
+struct BufRsrc { char* base; uint32_t bytes; };
+__device__ __forceinline__ BufRsrc buf_rsrc(const void* base, uint32_t bytes) { return BufRsrc{(char*)base, bytes}; }
+__device__ __forceinline__ float buf_ld_f32(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    const uint64_t o = (uint64_t)voff + soff;
+    float v = 0.f;
+    if (o + 4 <= r.bytes) std::memcpy(&v, r.base + o, 4);
+    return v;
+}
+__device__ __forceinline__ B96 buf_ld_b96(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    const uint64_t o = (uint64_t)voff + soff;
+    B96 v{0, 0, 0};
+    if (o + 12 <= r.bytes) std::memcpy(&v, r.base + o, 12);
+    return v;
+}
+__device__ __forceinline__ void buf_st_b96(const B96& v, const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    const uint64_t o = (uint64_t)voff + soff;
+    if (o + 12 <= r.bytes) std::memcpy(r.base + o, &v, 12);
+}
+__device__ __forceinline__ int lut_dot2(uint32_t pair, uint32_t wts, int acc) {
+    return acc + (int)(int16_t)(pair & 0xffff) * (int)(int16_t)(wts & 0xffff) + (int)(int16_t)(pair >> 16) * (int)(int16_t)(wts >> 16);
+}
+__device__ __forceinline__ uint32_t lut_lo2(uint32_t d, uint32_t e) { return (d & 0xffffu) | (e << 16); }
+__device__ __forceinline__ uint32_t lut_hi2(uint32_t d, uint32_t e) { return (d >> 16) | (e & 0xffff0000u); }
+__device__ __forceinline__ uint32_t lut_mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
+
+}  // namespace lvm

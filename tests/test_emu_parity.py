@@ -334,23 +334,26 @@ def test_emu_unfused_conversion_in_batches(lvm, po, emu, monkeypatch):
     (520, 150, 4, 1, (1, 9)),           # five tiles across: interior tiles without any border lane
     (128, 16, 2, 1, (1, 3, 3)),         # exactly one tile
 ])
-def test_laplace_emu_level1_fused_into_the_last_kernel(lvm, po, emu, w, h, levels, ns, calls):
+def test_laplace_emu_level1_fused_into_the_last_kernel(lvm, po, emu, w, h, levels, ns, calls, monkeypatch):
     """k_lap_final1: level-1 band / IIR / collapse step + last kernel in one launch, cur_1 in LDS, the level-1 states in
     registers for the whole batch and double-buffered across launches (a tile's ring pixels are state copies read from a
     neighbour's planes).  Bit-identical to the oracle over several calls, i.e. across the buffer swap."""
+    monkeypatch.setenv("LVM_LAP_FINAL1", "1")
     _frames_clip(lvm, po, emu, 0, w, h, levels, ns, calls)
 
 
 @pytest.mark.parametrize("w,h,levels,calls", [(264, 74, 3, (1, 6, 1, 2)), (320, 180, 4, (1, 8))])
 def test_laplace_emu_unfused_level1_still_matches(lvm, po, emu, w, h, levels, calls, monkeypatch):
-    """LVM_LAP_FINAL1=0: k_lap_up at level 1 + k_lap_final_v4 (what odd level-1 widths and non-vector frames always use)."""
+    """LVM_LAP_FINAL1=0: k_lap_up at level 1 + k_lap_final_v4 (the default until the fused kernel is faster; what odd level-1 widths
+    and non-vector frames always use)."""
     monkeypatch.setenv("LVM_LAP_FINAL1", "0")
     _frames_clip(lvm, po, emu, 0, w, h, levels, 1, calls)
 
 
-def test_laplace_emu_fused_and_unfused_level1_share_their_states(lvm, po, emu):
+def test_laplace_emu_fused_and_unfused_level1_share_their_states(lvm, po, emu, monkeypatch):
     """A parameter change between calls (the fused kernel swaps the level-1 state planes every launch) and a frame geometry that
     switches between the two forms (4-aligned width vs. not) keep matching the oracle frame by frame."""
+    monkeypatch.setenv("LVM_LAP_FINAL1", "1")
     ck, pk = lvm.synth.config(0, (264, 74, 3))
     def vary(t, q):
         if t >= 5:
