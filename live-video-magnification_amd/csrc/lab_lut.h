@@ -48,8 +48,11 @@ struct LabLut {
 };
 
 // integer Lab of one pixel: iL in [0, 16384], ia, ib = (a + 128) / 256 * 16384.  s_ab = the node table in LDS.
-__device__ __forceinline__ void lut_lab_int(uint32_t B, uint32_t G, uint32_t R, const uint32_t* s_ab, const uint4* __restrict__ Lcells,
-                                            int& iL, int& ia, int& ib) {
+// Two halves, so that a caller can have the look-ups of the NEXT pixel in flight while this one is interpolated: lut_issue computes
+// the addresses and weights and issues the nine reads (one 16-byte gather from L2, four ds_read2_b32), lut_finish interpolates.
+struct LutRefs { uint4 cL; uint32_t d00, d10, d01, d11, e00, e10, e01, e11, w00, w10, w01, w11; };
+__device__ __forceinline__ LutRefs lut_issue(uint32_t B, uint32_t G, uint32_t R, const uint32_t* s_ab, const uint4* __restrict__ Lcells) {
+    LutRefs q;
     const uint32_t fr = lut_fine(R), fg = lut_fine(G), fb = lut_fine(B);
     const uint32_t x = fr & 15u, y = fg & 15u, z = fb & 15u, tb = fb >> 4;
     const uint32_t n = (fr >> 4) + 33u * (fg >> 4) + 1089u * tb;
@@ -58,19 +61,27 @@ __device__ __forceinline__ void lut_lab_int(uint32_t B, uint32_t G, uint32_t R, 
     // 128-byte line each, lcell_index): neighbouring colours share lines, the gathers hit the CU's L1 more often
     // (fused first kernel 265-275 -> 248-251 us per 32 frames at 1080p against the linear order p + 33 q + 1089 r)
     const uint32_t nc = (((fr >> 5) + 17u * (fg >> 5) + 289u * (fb >> 5)) << 3) | ((fr >> 4) & 1u) | ((fg >> 3) & 2u) | ((fb >> 2) & 4u);
-    const uint4 cL = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Lcells) + (nc << 4));
-    const uint32_t d00 = s_ab[n], d10 = s_ab[n + 1], d01 = s_ab[n + 33], d11 = s_ab[n + 34];
-    const uint32_t e00 = s_ab[n1], e10 = s_ab[n1 + 1], e01 = s_ab[n1 + 33], e11 = s_ab[n1 + 34];
+    q.cL = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Lcells) + (nc << 4));
+    q.d00 = s_ab[n]; q.d10 = s_ab[n + 1]; q.d01 = s_ab[n + 33]; q.d11 = s_ab[n + 34];
+    q.e00 = s_ab[n1]; q.e10 = s_ab[n1 + 1]; q.e01 = s_ab[n1 + 33]; q.e11 = s_ab[n1 + 34];
     const uint32_t wz = (16u - z) | (z << 16);                 // (16 - z, z) as an int16 pair
     const uint32_t x0 = 16u - x, y0 = 16u - y;
     // w(dp, dq) * (16 - z | z): each half <= 4096, no carry between the halves
-    const uint32_t w00 = lut_mul24(lut_mul24(x0, y0), wz), w10 = lut_mul24(lut_mul24(x, y0), wz), w01 = lut_mul24(lut_mul24(x0, y), wz),
-                   w11 = lut_mul24(lut_mul24(x, y), wz);
+    q.w00 = lut_mul24(lut_mul24(x0, y0), wz); q.w10 = lut_mul24(lut_mul24(x, y0), wz); q.w01 = lut_mul24(lut_mul24(x0, y), wz);
+    q.w11 = lut_mul24(lut_mul24(x, y), wz);
+    return q;
+}
+__device__ __forceinline__ void lut_finish(const LutRefs& q, int& iL, int& ia, int& ib) {
     const int rnd = 1 << 11;                                  // CV_DESCALE(v, 12) = (v + 2048) >> 12
-    ia = lut_dot2(lut_lo2(d11, e11), w11, lut_dot2(lut_lo2(d01, e01), w01, lut_dot2(lut_lo2(d10, e10), w10, lut_dot2(lut_lo2(d00, e00), w00, rnd)))) >> 12;
-    ib = lut_dot2(lut_hi2(d11, e11), w11, lut_dot2(lut_hi2(d01, e01), w01, lut_dot2(lut_hi2(d10, e10), w10, lut_dot2(lut_hi2(d00, e00), w00, rnd)))) >> 12;
+    ia = lut_dot2(lut_lo2(q.d11, q.e11), q.w11, lut_dot2(lut_lo2(q.d01, q.e01), q.w01, lut_dot2(lut_lo2(q.d10, q.e10), q.w10, lut_dot2(lut_lo2(q.d00, q.e00), q.w00, rnd)))) >> 12;
+    ib = lut_dot2(lut_hi2(q.d11, q.e11), q.w11, lut_dot2(lut_hi2(q.d01, q.e01), q.w01, lut_dot2(lut_hi2(q.d10, q.e10), q.w10, lut_dot2(lut_hi2(q.d00, q.e00), q.w00, rnd)))) >> 12;
     // cell dwords: x = (dp 0, dq 0), y = (0, 1), z = (1, 0), w = (1, 1), each the (dr 0, dr 1) pair
-    iL = lut_dot2(cL.w, w11, lut_dot2(cL.y, w01, lut_dot2(cL.z, w10, lut_dot2(cL.x, w00, rnd)))) >> 12;
+    iL = lut_dot2(q.cL.w, q.w11, lut_dot2(q.cL.y, q.w01, lut_dot2(q.cL.z, q.w10, lut_dot2(q.cL.x, q.w00, rnd)))) >> 12;
+}
+__device__ __forceinline__ void lut_lab_int(uint32_t B, uint32_t G, uint32_t R, const uint32_t* s_ab, const uint4* __restrict__ Lcells,
+                                            int& iL, int& ia, int& ib) {
+    const LutRefs q = lut_issue(B, G, R, s_ab, Lcells);
+    lut_finish(q, iL, ia, ib);
 }
 // the float values RGB2Labfloat stores (each product is exact in float32: a power-of-two scale, 25 * iL < 2^24)
 __device__ __forceinline__ float lut_L(int iL) { return (float)iL * (100.0f / 16384.0f); }

@@ -28,6 +28,10 @@
 
 #include "pyramid.h"
 
+#ifndef LVM_EXPERIMENTAL
+#define LVM_EXPERIMENTAL 0        // 1: also build the schedules that were measured slower and are kept for the next attempt (k_lap_final1)
+#endif
+
 namespace lvm {
 
 struct UpArgs {
@@ -646,6 +650,9 @@ struct FinArgs {
     LabCoef lab; float ca; int strips_x, strips_y, nstreams, rows;
     float* dbg; LabPlanes lp;
 };
+#ifndef LVM_FIN_PACKED
+#define LVM_FIN_PACKED LVM_EXPERIMENTAL   // the default flavour's inverse colour arithmetic on pixel pairs (v_pk_*_f32): 12 % fewer vector instructions in
+#endif                                    // k_lap_final_v4 and NO change of its time (207 -> 211 us per 32 frames: the kernel waits for HBM, not for issue slots)
 // One output row of 4 pixels: Lab(in) + [1, ca, ca] * motion -> Lab2BGR -> u8 (MagnifyCore.hpp:143-153).  m = the motion image of the
 // row (EXACT: scaled by 1/64 as pyrUp does; otherwise the unscaled vertical sum, whose power-of-two scale `msc` is folded into the
 // add -- fma(m, 2^-k, L) rounds exactly like L + m * 2^-k).  dbg_px: where the float pixels go (lvm_debug_keep_float) or null.
@@ -656,6 +663,23 @@ __device__ __forceinline__ void lap_emit_row(const Raw4 pin, const float (&m)[3]
     float L4[4], a4[4], b4[4];
     raw4_to_lab<FL>(pin, s_gam, lab, L4, a4, b4);
     float ov[12];
+#if LVM_FIN_PACKED
+    if (!EXACT && !DBG) {                                   // default flavour: two pixels per packed FP32 operation
+#pragma unroll
+        for (int k = 0; k < 4; k += 2) {
+            lvm_f2 L = f2_set(L4[k], L4[k + 1]), a = f2_set(a4[k], a4[k + 1]), bb = f2_set(b4[k], b4[k + 1]);
+            if (MOTION) {
+                L = f2_fma(f2_set(m[0][k], m[0][k + 1]), f2_all(msc), L);
+                a = f2_fma(f2_set(m[1][k], m[1][k + 1]), f2_all(msc * ca), a);
+                bb = f2_fma(f2_set(m[2][k], m[2][k + 1]), f2_all(msc * ca), bb);
+            }
+            lvm_f2 o0, o1, o2;
+            lab_to_bgr_pair(L, a, bb, lab.inv1024, s_igt, o0, o1, o2);
+            o0 = f2_fma(o0, f2_all(255.0f), f2_all(lab.a255)); o1 = f2_fma(o1, f2_all(255.0f), f2_all(lab.a255)); o2 = f2_fma(o2, f2_all(255.0f), f2_all(lab.a255));
+            ov[3 * k] = o0[0]; ov[3 * k + 1] = o1[0]; ov[3 * k + 2] = o2[0]; ov[3 * k + 3] = o0[1]; ov[3 * k + 4] = o1[1]; ov[3 * k + 5] = o2[1];
+        }
+    } else
+#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float o0, o1, o2;
@@ -802,7 +826,13 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(FinArgs q) {
         lap_final_strip<MOTION, DBG, FL>(q, task, lane, s_igt, s_gam);
 }
 
+#if LVM_EXPERIMENTAL
 // ---- level-1 step + last kernel in ONE launch (round 4) --------------------------------------------------------------------------
+// EXPERIMENTAL (built only with -DLVM_EXPERIMENTAL=1; the emulation build of the test suite has it, liblvm_hip.so does not): correct
+// -- bit-identical to the oracle in the exact flavour, verified on the GPU -- but SLOWER than the two kernels it replaces: 504-529 us
+// per 32 frames of 1080p against 106 + 208.  Why (ISA + counters, profiles/README.md round 4): with the frame loop inside, one thread
+// carries three roles (18 state registers, its share of two prefetches, the 4 x 2-pixel colour arithmetic) -- 128 VGPRs + 200 bytes of
+// scratch + ~100 SGPRs spilled to VGPR lanes, ~1000 vector instructions per thread and frame, and every spill reload is a vmcnt(0).
 // Until round 3 the level-1 step (k_lap_up: band_1 = G_1 - pyrUp(G_2), both IIR low-passes, cur_1 = pyrUp(cur_2) + gain_1 m_1) wrote
 // cur_1 to HBM and the last kernel read it back: 12.4 MB per 1080p frame each way, and one launch whose only other traffic is G_1 in.
 // Here ONE workgroup owns a 128 x 16 tile of the OUTPUT frame for all frames of the batch and does, per frame,
@@ -1073,6 +1103,8 @@ __global__ __launch_bounds__(256, 4) void k_lap_final1(Fin1Args q) {
     }
     if (xok && xrx <= F1_W / 2 && xry >= 1 && xry <= F1_H / 2) { q.hi_out[xoffg] = hi_r[F1_NQ]; q.lo_out[xoffg] = lo_r[F1_NQ]; }
 }
+
+#endif  // LVM_EXPERIMENTAL
 
 // ------------------------------------------------------------------------------------------
 // Tail kernel: every pyramid level from T upwards (G_T has at most kTailMax pixels) is handled by
@@ -1535,8 +1567,12 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     // Level 1 inside the last kernel (k_lap_final1: cur_1 stays in LDS)?  3-channel frames with dword-aligned pixel groups, a level 2
     // of at least 2 x 2 pixels; not for the seeding frame (no motion yet), not with an odd level-1 width, and not when the tail kernel
     // has already run level 1 (tiny frames).
+#if LVM_EXPERIMENTAL
     const bool fuse1 = st->final1 && !first && levels >= 2 && up_start >= 1 /* level 1 not inside the tail kernel */ && C == 3 && lap_vec4(io) && st->g[1].w % 2 == 0 && st->g[2].w >= 2 && st->g[2].h >= 2 &&
                        st->g[1].h >= 2 && (size_t)st->planes * st->g[1].n * (size_t)B.nt < ((size_t)1 << 31);
+#else
+    const bool fuse1 = false;
+#endif
     st->used_final1 = false;
     for (int l = up_start; l >= (fuse1 ? 2 : 1); --l) {
         UpArgs a;
@@ -1575,6 +1611,7 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     }
     const int fl = lab_flavour(c);
     float* dbg = (c->keep_float && B.dbg_frame) ? c->d_float : nullptr;   // (the float frame kept is the first one of the batch)
+#if LVM_EXPERIMENTAL
     if (fuse1) {
         Fin1Args a{};
         a.in = io.d_in; a.in_stride = (long)io.in_stride; a.in_sstride = (long)io.in_sstride;
@@ -1598,6 +1635,7 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         st->used_final1 = true;
         return;
     }
+#endif
     const int tx = (io.w + UT_W - 1) / UT_W, ty = (io.h + UT_H - 1) / UT_H;
     const int ntiles = tx * ty * NS;
     const dim3 grid(ntiles < 2048 ? ntiles : 2048);

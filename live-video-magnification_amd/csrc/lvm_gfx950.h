@@ -34,6 +34,10 @@ __device__ __forceinline__ void buf_st_b96(const B96& v, const BufRsrc& r, uint3
     __builtin_amdgcn_raw_buffer_store_b96(q, r, (int)voff, (int)soff, 0);
 }
 
+// ---- packed FP32: two floats in a register pair, one v_pk_{add,mul,fma}_f32 per operation (full rate on gfx950) ----
+typedef float lvm_f2 __attribute__((vector_size(8)));
+__device__ __forceinline__ lvm_f2 f2_fma(lvm_f2 a, lvm_f2 b, lvm_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 // ---- forward Lab table (lab_lut.h) ----
 typedef short lut_s2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int lut_dot2(uint32_t pair, uint32_t wts, int acc) {

@@ -247,6 +247,35 @@ __device__ __forceinline__ void lab_to_bgr(float li, float ai, float bi, const f
         o2 = spline1024<false>(clip1024_open(c2), igt);
     }
 }
+// The default flavour's Lab2RGBfloat for a PAIR of pixels: the same operations as lab_to_bgr<false>, two pixels per v_pk_*_f32
+// (gfx950 issues a packed FP32 operation at the rate of a scalar one: the matrix, the cube / linear branches and the scalings are
+// half the instructions; the spline look-ups, clamps and selects stay per pixel).  iv = inv1024.
+// (lvm_f2 / f2_fma: lvm_gfx950.h -- v_pk_fma_f32)
+__device__ __forceinline__ lvm_f2 f2_set(float a, float b) { lvm_f2 v = {a, b}; return v; }
+__device__ __forceinline__ lvm_f2 f2_all(float a) { lvm_f2 v = {a, a}; return v; }
+__device__ __forceinline__ void lab_to_bgr_pair(lvm_f2 li, lvm_f2 ai, lvm_f2 bi, const float* iv, const float* igt, lvm_f2& o0, lvm_f2& o1, lvm_f2& o2) {
+    const float lThresh = 0.008856f * 903.3f;
+    const float fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
+    const lvm_f2 ylin = li * f2_all(1.0f / 903.3f), fyc = (li + f2_all(16.0f)) * f2_all(1.0f / 116.0f);
+    const lvm_f2 fyl = f2_fma(f2_all(7.787f), ylin, f2_all(16.0f / 116.0f)), yc = fyc * fyc * fyc;
+    lvm_f2 fy, y;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const bool lo = li[k] <= lThresh; fy[k] = lo ? fyl[k] : fyc[k]; y[k] = lo ? ylin[k] : yc[k]; }
+    lvm_f2 fx = f2_fma(ai, f2_all(1.0f / 500.0f), fy), fz = f2_fma(bi, f2_all(-1.0f / 200.0f), fy);
+    const lvm_f2 fxl = (fx - f2_all(16.0f / 116.0f)) * f2_all(1.0f / 7.787f), fxc = fx * fx * fx;
+    const lvm_f2 fzl = (fz - f2_all(16.0f / 116.0f)) * f2_all(1.0f / 7.787f), fzc = fz * fz * fz;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { fx[k] = (fx[k] <= fThresh) ? fxl[k] : fxc[k]; fz[k] = (fz[k] <= fThresh) ? fzl[k] : fzc[k]; }
+    const lvm_f2 c0 = f2_fma(f2_all(iv[0]), fx, f2_fma(f2_all(iv[1]), y, f2_all(iv[2]) * fz));
+    const lvm_f2 c1 = f2_fma(f2_all(iv[3]), fx, f2_fma(f2_all(iv[4]), y, f2_all(iv[5]) * fz));
+    const lvm_f2 c2 = f2_fma(f2_all(iv[6]), fx, f2_fma(f2_all(iv[7]), y, f2_all(iv[8]) * fz));
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        o0[k] = spline1024<false>(clip1024_open(c0[k]), igt);
+        o1[k] = spline1024<false>(clip1024_open(c1[k]), igt);
+        o2[k] = spline1024<false>(clip1024_open(c2[k]), igt);
+    }
+}
 // ---- flavours of the colour arithmetic (template parameter FL of every kernel that converts) ------------------------
 // FL_LUT_FAST  (default): forward = OpenCV 4's interpolated 33^3 table (integer, bit-exact against the oracle), inverse and
 //              pyramid taps with reciprocal multiplies / fma chains / selects;

@@ -29,6 +29,8 @@ __device__ __forceinline__ void buf_st_b96(const B96& v, const BufRsrc& r, uint3
     const uint64_t o = (uint64_t)voff + soff;
     if (o + 12 <= r.bytes) std::memcpy(r.base + o, &v, 12);
 }
+typedef float lvm_f2 __attribute__((vector_size(8)));
+__device__ __forceinline__ lvm_f2 f2_fma(lvm_f2 a, lvm_f2 b, lvm_f2 c) { lvm_f2 v = {__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1])}; return v; }
 __device__ __forceinline__ int lut_dot2(uint32_t pair, uint32_t wts, int acc) {
     return acc + (int)(int16_t)(pair & 0xffff) * (int)(int16_t)(wts & 0xffff) + (int)(int16_t)(pair >> 16) * (int)(int16_t)(wts >> 16);
 }
