@@ -470,6 +470,8 @@ __device__ __forceinline__ void down0_lut_strip(const D0LArgs& q, int task, int 
         if (owner && sy >= own_lo && sy < own_hi) {
             const size_t o = (size_t)sy * w;
             uint32_t* dL = reinterpret_cast<uint32_t*>(pL + o);
+            // (nontemporal: plain stores measured 229 -> 232 us for this kernel and 49 -> 63 us for the pyrDown that follows -- the planes
+            //  evict G_1 from the caches; profiles/README.md round 4)
             __builtin_nontemporal_store((uint32_t)iL[0] | ((uint32_t)iL[1] << 16), dL);
             __builtin_nontemporal_store((uint32_t)iL[2] | ((uint32_t)iL[3] << 16), dL + 1);
 #pragma unroll
