@@ -875,7 +875,13 @@ struct Fin1Args {
     LabCoef lab; LabPlanes lp; float* dbg;
 };
 template <bool HC, bool DBG, int FL>                           // HC: cur_2 exists (L >= 3); otherwise level 1 is the top live level
-__global__ __launch_bounds__(256, 4) void k_lap_final1(Fin1Args q) {
+#ifndef LVM_F1_WAVES
+#define LVM_F1_WAVES 4
+#endif
+#ifndef LVM_F1_PREFETCH_L2
+#define LVM_F1_PREFETCH_L2 1     // the level-2 taps of frame t + 1 fly through phase 3 of frame t (12 registers across the widest phase)
+#endif
+__global__ __launch_bounds__(256, LVM_F1_WAVES) void k_lap_final1(Fin1Args q) {
     constexpr bool EXACT = fl_exact(FL);
     constexpr bool PLANES = fl_lut(FL);
     __shared__ __attribute__((aligned(16))) float s_igt[4096];
@@ -978,6 +984,9 @@ __global__ __launch_bounds__(256, 4) void k_lap_final1(Fin1Args q) {
     fetch_l2(0);
     for (int t = 0; t < q.nt; ++t) {
         f2 c2v[F1_U1]; float g1[F1_NQ + 1];
+#if !LVM_F1_PREFETCH_L2
+        if (t > 0) fetch_l2(t);
+#endif
 #pragma unroll
         for (int i = 0; i < F1_U1; ++i) c2v[i] = n2v[i];
         {
@@ -1044,51 +1053,44 @@ __global__ __launch_bounds__(256, 4) void k_lap_final1(Fin1Args q) {
             if (xu < F1_U2) s_C[xch][xry][xrx] = (HC ? up[1] : 0.f) + m;
         }
         __syncthreads();
+#if LVM_F1_PREFETCH_L2
         fetch_l2(t + 1 < q.nt ? t + 1 : q.nt - 1);                   // (unconditional: the same registers are refilled every iteration)
+#endif
         // ---- phase 3: out = u8(Lab2BGR(Lab(in) + [1, ca, ca] * pyrUp(cur_1))) for the thread's 4 x 2 pixels
         if (act) {
-            Row3 A, B, C;
-            auto hrow = [&](int r) __attribute__((always_inline)) {
-                Row3 o;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float* rowp = &s_C[c][r][0];
-                    const float sm1 = rowp[cm1], s0 = rowp[cb], s1 = rowp[cp1], s2 = rowp[cp2];
-                    if (EXACT) o.c[c] = pyrup_h4(sm1, s0, s1, s2, i0, w1);
-                    else if (LVM_FAST_FMA) {
-                        o.c[c].x = __builtin_fmaf(s0, 6.f, sm1 + s1); o.c[c].y = (s0 + s1) * 4.f; o.c[c].z = __builtin_fmaf(s1, 6.f, s0 + s2); o.c[c].w = (s1 + s2) * 4.f;
-                    } else { o.c[c].x = sm1 + s0 * 6.f + s1; o.c[c].y = (s0 + s1) * 4.f; o.c[c].z = s0 + s1 * 6.f + s2; o.c[c].w = (s1 + s2) * 4.f; }
-                }
-                return o;
-            };
-            A = hrow(ra); B = hrow(rb); C = hrow(rc);
-            float* dbgp = (DBG && q.dbg && sb == 0 && t == 0) ? q.dbg : nullptr;
-            uint8_t* orow = dst + (size_t)t * out_fs + (size_t)gy * q.out_stride + xoff;
-            float m[3][4];
+            // motion image of the two rows, channel by channel: the horizontal pass of the three cur_1 rows of ONE channel (12 values), then
+            // both vertical formulas -- 24 values live at the end instead of three Row3 (36) + the row being emitted (12)
+            float me[3][4], mo[3][4];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
+                float4 hA, hB, hC;
+                auto hrow1 = [&](int r) __attribute__((always_inline)) {
+                    const float* rowp = &s_C[c][r][0];
+                    const float sm1 = rowp[cm1], s0 = rowp[cb], s1 = rowp[cp1], s2 = rowp[cp2];
+                    float4 o;
+                    if (EXACT) o = pyrup_h4(sm1, s0, s1, s2, i0, w1);
+                    else if (LVM_FAST_FMA) { o.x = __builtin_fmaf(s0, 6.f, sm1 + s1); o.y = (s0 + s1) * 4.f; o.z = __builtin_fmaf(s1, 6.f, s0 + s2); o.w = (s1 + s2) * 4.f; }
+                    else { o.x = sm1 + s0 * 6.f + s1; o.y = (s0 + s1) * 4.f; o.z = s0 + s1 * 6.f + s2; o.w = (s1 + s2) * 4.f; }
+                    return o;
+                };
+                hA = hrow1(ra); hB = hrow1(rb); hC = hrow1(rc);
                 if (!EXACT && LVM_FAST_FMA) {
-                    m[c][0] = __builtin_fmaf(B.c[c].x, 6.f, A.c[c].x + C.c[c].x); m[c][1] = __builtin_fmaf(B.c[c].y, 6.f, A.c[c].y + C.c[c].y);
-                    m[c][2] = __builtin_fmaf(B.c[c].z, 6.f, A.c[c].z + C.c[c].z); m[c][3] = __builtin_fmaf(B.c[c].w, 6.f, A.c[c].w + C.c[c].w);
-                    continue;
+                    me[c][0] = __builtin_fmaf(hB.x, 6.f, hA.x + hC.x); me[c][1] = __builtin_fmaf(hB.y, 6.f, hA.y + hC.y);
+                    me[c][2] = __builtin_fmaf(hB.z, 6.f, hA.z + hC.z); me[c][3] = __builtin_fmaf(hB.w, 6.f, hA.w + hC.w);
+                } else {
+                    const float sc = EXACT ? (1.f / 64.f) : 1.f;
+                    me[c][0] = (hA.x + hB.x * 6.f + hC.x) * sc; me[c][1] = (hA.y + hB.y * 6.f + hC.y) * sc;
+                    me[c][2] = (hA.z + hB.z * 6.f + hC.z) * sc; me[c][3] = (hA.w + hB.w * 6.f + hC.w) * sc;
                 }
-                const float sc = EXACT ? (1.f / 64.f) : 1.f;
-                m[c][0] = (A.c[c].x + B.c[c].x * 6.f + C.c[c].x) * sc; m[c][1] = (A.c[c].y + B.c[c].y * 6.f + C.c[c].y) * sc;
-                m[c][2] = (A.c[c].z + B.c[c].z * 6.f + C.c[c].z) * sc; m[c][3] = (A.c[c].w + B.c[c].w * 6.f + C.c[c].w) * sc;
+                if (EXACT) {
+                    mo[c][0] = ((hB.x + hC.x) * 4.f) * (1.f / 64.f); mo[c][1] = ((hB.y + hC.y) * 4.f) * (1.f / 64.f);
+                    mo[c][2] = ((hB.z + hC.z) * 4.f) * (1.f / 64.f); mo[c][3] = ((hB.w + hC.w) * 4.f) * (1.f / 64.f);
+                } else { mo[c][0] = hB.x + hC.x; mo[c][1] = hB.y + hC.y; mo[c][2] = hB.z + hC.z; mo[c][3] = hB.w + hC.w; }
             }
-            lap_emit_row<true, DBG, FL>(pe, m, 1.f / 64.f, ca, q.lab, s_igt, s_gam, dbgp ? dbgp + ((size_t)gy * w + gx) * 3 : nullptr, orow);
-            if (act1) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    if (EXACT) {
-                        m[c][0] = ((B.c[c].x + C.c[c].x) * 4.f) * (1.f / 64.f); m[c][1] = ((B.c[c].y + C.c[c].y) * 4.f) * (1.f / 64.f);
-                        m[c][2] = ((B.c[c].z + C.c[c].z) * 4.f) * (1.f / 64.f); m[c][3] = ((B.c[c].w + C.c[c].w) * 4.f) * (1.f / 64.f);
-                    } else {
-                        m[c][0] = B.c[c].x + C.c[c].x; m[c][1] = B.c[c].y + C.c[c].y; m[c][2] = B.c[c].z + C.c[c].z; m[c][3] = B.c[c].w + C.c[c].w;
-                    }
-                }
-                lap_emit_row<true, DBG, FL>(po, m, 1.f / 16.f, ca, q.lab, s_igt, s_gam, dbgp ? dbgp + ((size_t)(gy + 1) * w + gx) * 3 : nullptr, orow + q.out_stride);
-            }
+            float* dbgp = (DBG && q.dbg && sb == 0 && t == 0) ? q.dbg : nullptr;
+            uint8_t* orow = dst + (size_t)t * out_fs + (size_t)gy * q.out_stride + xoff;
+            lap_emit_row<true, DBG, FL>(pe, me, 1.f / 64.f, ca, q.lab, s_igt, s_gam, dbgp ? dbgp + ((size_t)gy * w + gx) * 3 : nullptr, orow);
+            if (act1) lap_emit_row<true, DBG, FL>(po, mo, 1.f / 16.f, ca, q.lab, s_igt, s_gam, dbgp ? dbgp + ((size_t)(gy + 1) * w + gx) * 3 : nullptr, orow + q.out_stride);
         }
     }
     // the states of the pixels this workgroup owns (the ring's are copies of a neighbour's)
