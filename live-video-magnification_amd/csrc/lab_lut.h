@@ -33,18 +33,30 @@ constexpr int kLabLutDim = 33;
 constexpr int kLabLutNodes = kLabLutDim * kLabLutDim * kLabLutDim;
 // node index n = p + 33 q + 1089 r (p, q, r = R, G, B grid index).  Neighbours n + 1, n + 33, n + 34 of an edge cell carry
 // weight 0 and may index past the cube: the node table is padded by 34 entries (the B neighbour is clamped instead).
-constexpr int kLabAbWords = kLabLutNodes + 34;
-constexpr int kLabLCells = 17 * 17 * 17 * 8;       // cells in 2 x 2 x 2 blocks (lcell_index)
+// Device layouts (round 4: two instruction diets of the conversion, ~94 -> ~89 vector instructions per pixel):
+//  * every entry is stored as 2 v + 1 (uint16): sum w (2 v + 1) = 2 sum w v + 4096 (the eight weights always add up to 16^3), so
+//    CV_DESCALE(sum w v, 12) = (sum w v + 2048) >> 12 = (sum w (2 v + 1)) >> 13 -- the rounding constant rides in the table and the
+//    accumulator chains start from the inline constant 0 (three v_mov per pixel less); unsigned dot products (2 v + 1 <= 32769);
+//  * the B neighbour of a node is ALWAYS n + 1089: for u = 255 (cell 32) its weight is 0 and the node table is padded by one more
+//    B plane of zeros instead of clamping the index (compare + select + add -> add);
+//  * (measured and NOT taken: the L cell indexed by its origin node n -- the index the (a, b) look-up needs anyway, ~10 instructions per
+//    pixel less than the 2 x 2 x 2-blocked cell number -- made the fused first kernel SLOWER, 247 -> 297 us per 32 frames, and the
+//    conversion kernel 239 -> 270: the kernels are bound by the L gather's L1 misses, not by vector issue; LVM_LUT_LCELL_BLOCKED=0 builds it)
+#ifndef LVM_LUT_LCELL_BLOCKED
+#define LVM_LUT_LCELL_BLOCKED 1
+#endif
+constexpr int kLabAbWords = kLabLutNodes + 1089 + 34 + 1;
+constexpr int kLabLCells = LVM_LUT_LCELL_BLOCKED ? 17 * 17 * 17 * 8 : kLabLutNodes;       // cells in 2 x 2 x 2 blocks (lcell_index) | by origin node
 
-// lut_dot2 / lut_lo2 / lut_hi2 / lut_mul24 (v_dot2_i32_i16, v_perm_b32, v_mul_u32_u24): lvm_gfx950.h
+// lut_dot2 / lut_lo2 / lut_hi2 / lut_mul24 (v_dot2_u32_u16, v_perm_b32, v_mul_u32_u24): lvm_gfx950.h
 
 // fine grid coordinate of a u8 channel value: bits 4.. = cell, bits 0..3 = weight of the upper neighbour
 __device__ __forceinline__ uint32_t lut_fine(uint32_t u) { return (u * 514u + 4u) >> 8; }
 
 // device tables of a context (lab_tables.cpp builds them from the compact table)
 struct LabLut {
-    const uint32_t* ab;       // [kLabAbWords]  a | b << 16 per node (copied into LDS by the conversion kernel)
-    const uint4* Lcells;      // [kLabLCells]   the 8 L corners of a cell (int16 index 4 dp + 2 dq + dr), cells in 2 x 2 x 2 blocks
+    const uint32_t* ab;       // [kLabAbWords]  (2 a + 1) | (2 b + 1) << 16 per node (copied into LDS by the conversion kernel)
+    const uint4* Lcells;      // [kLabLCells]   the 8 L corners of a cell as 2 L + 1 (uint16 index 4 dp + 2 dq + dr), by origin node
 };
 
 // integer Lab of one pixel: iL in [0, 16384], ia, ib = (a + 128) / 256 * 16384.  s_ab = the node table in LDS.
@@ -56,11 +68,14 @@ __device__ __forceinline__ LutRefs lut_issue(uint32_t B, uint32_t G, uint32_t R,
     const uint32_t fr = lut_fine(R), fg = lut_fine(G), fb = lut_fine(B);
     const uint32_t x = fr & 15u, y = fg & 15u, z = fb & 15u, tb = fb >> 4;
     const uint32_t n = (fr >> 4) + 33u * (fg >> 4) + 1089u * tb;
-    const uint32_t n1 = n + (tb < 32u ? 1089u : 0u);            // B neighbour (tb == 32 only for u = 255, where z == 0)
-    // the L cell: one 16-byte gather at a 32-bit byte offset from the uniform base.  Cells are stored in 2 x 2 x 2 blocks (one
-    // 128-byte line each, lcell_index): neighbouring colours share lines, the gathers hit the CU's L1 more often
-    // (fused first kernel 265-275 -> 248-251 us per 32 frames at 1080p against the linear order p + 33 q + 1089 r)
+    const uint32_t n1 = n + 1089u;                               // B neighbour (tb == 32 only for u = 255, where z == 0: the padding plane)
+    // the L cell: one 16-byte gather at a 32-bit byte offset from the uniform base
+#if LVM_LUT_LCELL_BLOCKED
+    // cells in 2 x 2 x 2 blocks (one 128-byte line each): neighbouring colours share lines, the gathers hit the CU's L1 more often
     const uint32_t nc = (((fr >> 5) + 17u * (fg >> 5) + 289u * (fb >> 5)) << 3) | ((fr >> 4) & 1u) | ((fg >> 3) & 2u) | ((fb >> 2) & 4u);
+#else
+    const uint32_t nc = n;
+#endif
     q.cL = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(Lcells) + (nc << 4));
     q.d00 = s_ab[n]; q.d10 = s_ab[n + 1]; q.d01 = s_ab[n + 33]; q.d11 = s_ab[n + 34];
     q.e00 = s_ab[n1]; q.e10 = s_ab[n1 + 1]; q.e01 = s_ab[n1 + 33]; q.e11 = s_ab[n1 + 34];
@@ -72,11 +87,11 @@ __device__ __forceinline__ LutRefs lut_issue(uint32_t B, uint32_t G, uint32_t R,
     return q;
 }
 __device__ __forceinline__ void lut_finish(const LutRefs& q, int& iL, int& ia, int& ib) {
-    const int rnd = 1 << 11;                                  // CV_DESCALE(v, 12) = (v + 2048) >> 12
-    ia = lut_dot2(lut_lo2(q.d11, q.e11), q.w11, lut_dot2(lut_lo2(q.d01, q.e01), q.w01, lut_dot2(lut_lo2(q.d10, q.e10), q.w10, lut_dot2(lut_lo2(q.d00, q.e00), q.w00, rnd)))) >> 12;
-    ib = lut_dot2(lut_hi2(q.d11, q.e11), q.w11, lut_dot2(lut_hi2(q.d01, q.e01), q.w01, lut_dot2(lut_hi2(q.d10, q.e10), q.w10, lut_dot2(lut_hi2(q.d00, q.e00), q.w00, rnd)))) >> 12;
+    // entries are 2 v + 1: (sum w (2 v + 1)) >> 13 == CV_DESCALE(sum w v, 12)
+    ia = (int)(lut_dot2(lut_lo2(q.d11, q.e11), q.w11, lut_dot2(lut_lo2(q.d01, q.e01), q.w01, lut_dot2(lut_lo2(q.d10, q.e10), q.w10, lut_dot2(lut_lo2(q.d00, q.e00), q.w00, 0u)))) >> 13);
+    ib = (int)(lut_dot2(lut_hi2(q.d11, q.e11), q.w11, lut_dot2(lut_hi2(q.d01, q.e01), q.w01, lut_dot2(lut_hi2(q.d10, q.e10), q.w10, lut_dot2(lut_hi2(q.d00, q.e00), q.w00, 0u)))) >> 13);
     // cell dwords: x = (dp 0, dq 0), y = (0, 1), z = (1, 0), w = (1, 1), each the (dr 0, dr 1) pair
-    iL = lut_dot2(q.cL.w, q.w11, lut_dot2(q.cL.y, q.w01, lut_dot2(q.cL.z, q.w10, lut_dot2(q.cL.x, q.w00, rnd)))) >> 12;
+    iL = (int)(lut_dot2(q.cL.w, q.w11, lut_dot2(q.cL.y, q.w01, lut_dot2(q.cL.z, q.w10, lut_dot2(q.cL.x, q.w00, 0u)))) >> 13);
 }
 __device__ __forceinline__ void lut_lab_int(uint32_t B, uint32_t G, uint32_t R, const uint32_t* s_ab, const uint4* __restrict__ Lcells,
                                             int& iL, int& ia, int& ib) {

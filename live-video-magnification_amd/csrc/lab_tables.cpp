@@ -167,27 +167,32 @@ void build_lab_lut_compact(std::vector<int16_t>& compact) {
             }
 }
 
-// device layouts (lab_lut.h): ab[n] = a | b << 16 of node n = p + 33 q + 1089 r (padded by 34 zero entries);
-// lcells[8 n + 4 dp + 2 dq + dr] = L of node (p + dp, q + dq, r + dr), indices clamped to 32
-// position of cell (p, q, r) in the L table: 2 x 2 x 2 blocks of cells, one 128-byte line per block (lab_lut.h)
+// device layouts (lab_lut.h): every entry as 2 v + 1 (the rounding constant of CV_DESCALE rides in the table).
+// ab[n] = (2 a + 1) | (2 b + 1) << 16 of node n = p + 33 q + 1089 r, padded by one B plane + 35 zero entries (upper neighbours of
+// the edge nodes carry weight 0 and are read unclamped); lcells[8 c + 4 dp + 2 dq + dr] = 2 L + 1 of node (p + dp, q + dq, r + dr),
+// indices clamped to 32, c = the cell's origin node (or its position in 2 x 2 x 2 blocks, LVM_LUT_LCELL_BLOCKED)
 static size_t lcell_index(int p, int q, int r) {
+#if LVM_LUT_LCELL_BLOCKED
     return (((size_t)(p >> 1) + 17 * (q >> 1) + 289 * (r >> 1)) << 3) | (p & 1) | ((q & 1) << 1) | ((r & 1) << 2);
+#else
+    return (size_t)p + 33 * q + 1089 * r;
+#endif
 }
 void lab_lut_device_tables(const int16_t* compact, std::vector<uint32_t>& ab, std::vector<int16_t>& lcells) {
-    ab.assign((size_t)33 * 33 * 33 + 34, 0u);
+    ab.assign((size_t)kLabAbWords, 0u);
     lcells.assign((size_t)kLabLCells * 8, 0);
     auto at = [&](int p, int q, int r, int ch) {
         p = p > 32 ? 32 : p; q = q > 32 ? 32 : q; r = r > 32 ? 32 : r;
-        return compact[(((size_t)r * 33 + q) * 33 + p) * 3 + ch];
+        return (uint32_t)(2 * (int)compact[(((size_t)r * 33 + q) * 33 + p) * 3 + ch] + 1);         // <= 2 * 16384 + 1: fits uint16
     };
     for (int r = 0; r < 33; ++r)
         for (int q = 0; q < 33; ++q)
             for (int p = 0; p < 33; ++p) {
                 const size_t n = (size_t)p + 33 * q + 1089 * r;
-                ab[n] = (uint32_t)(uint16_t)at(p, q, r, 1) | ((uint32_t)(uint16_t)at(p, q, r, 2) << 16);
+                ab[n] = at(p, q, r, 1) | (at(p, q, r, 2) << 16);
                 for (int dp = 0; dp < 2; ++dp)
                     for (int dq = 0; dq < 2; ++dq)
-                        for (int dr = 0; dr < 2; ++dr) lcells[lcell_index(p, q, r) * 8 + 4 * dp + 2 * dq + dr] = at(p + dp, q + dq, r + dr, 0);
+                        for (int dr = 0; dr < 2; ++dr) lcells[lcell_index(p, q, r) * 8 + 4 * dp + 2 * dq + dr] = (int16_t)(uint16_t)at(p + dp, q + dq, r + dr, 0);
             }
 }
 // lab_lut.h takes cell and weight of a u8 channel value from (514 u + 4) >> 8 instead of rounding float(u) * a255 * 16384:

@@ -39,9 +39,9 @@ typedef float lvm_f2 __attribute__((vector_size(8)));
 __device__ __forceinline__ lvm_f2 f2_fma(lvm_f2 a, lvm_f2 b, lvm_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // ---- forward Lab table (lab_lut.h) ----
-typedef short lut_s2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ int lut_dot2(uint32_t pair, uint32_t wts, int acc) {
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(lut_s2, pair), __builtin_bit_cast(lut_s2, wts), acc, false);
+typedef unsigned short lut_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t lut_dot2(uint32_t pair, uint32_t wts, uint32_t acc) {      // v_dot2_u32_u16
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(lut_u2, pair), __builtin_bit_cast(lut_u2, wts), acc, false);
 }
 // (lo16(d), lo16(e)) and (hi16(d), hi16(e)) of two dwords
 __device__ __forceinline__ uint32_t lut_lo2(uint32_t d, uint32_t e) { return __builtin_amdgcn_perm(e, d, 0x05040100u); }

@@ -31,8 +31,8 @@ __device__ __forceinline__ void buf_st_b96(const B96& v, const BufRsrc& r, uint3
 }
 typedef float lvm_f2 __attribute__((vector_size(8)));
 __device__ __forceinline__ lvm_f2 f2_fma(lvm_f2 a, lvm_f2 b, lvm_f2 c) { lvm_f2 v = {__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1])}; return v; }
-__device__ __forceinline__ int lut_dot2(uint32_t pair, uint32_t wts, int acc) {
-    return acc + (int)(int16_t)(pair & 0xffff) * (int)(int16_t)(wts & 0xffff) + (int)(int16_t)(pair >> 16) * (int)(int16_t)(wts >> 16);
+__device__ __forceinline__ uint32_t lut_dot2(uint32_t pair, uint32_t wts, uint32_t acc) {
+    return acc + (pair & 0xffffu) * (wts & 0xffffu) + (pair >> 16) * (wts >> 16);
 }
 __device__ __forceinline__ uint32_t lut_lo2(uint32_t d, uint32_t e) { return (d & 0xffffu) | (e << 16); }
 __device__ __forceinline__ uint32_t lut_hi2(uint32_t d, uint32_t e) { return (d >> 16) | (e & 0xffff0000u); }
