@@ -49,7 +49,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MODES = {"laplace": 1, "riesz": 2, "color": 3}  # -> BASELINE.json configs index
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 def level_sizes(w, h, levels):
@@ -345,7 +345,6 @@ def main():
     ap.add_argument("--verify-all-ranks", action="store_true", help="every rank checks its own stream against the oracle (tests)")
     ap.add_argument("--subrecords", action="store_true", help="run the sub-records also at N > 1 (default: N = 1 only)")
     ap.add_argument("--no-subrecords", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay steady-state frames from a captured hipGraph (per-frame calls)")
     ap.add_argument("--frames-per-call", type=int, default=32, help="consecutive frames of the stream(s) handed to one lvm_process_device_frames call (1 = per-frame calls)")
     ap.add_argument("--pipeline", type=int, default=0, help="cross-frame pipeline depth of lvm_process_device (0 or 1)")
     ap.add_argument("--profile-steps", type=int, default=-1, help="frames of the per-kernel timing pass (default: two calls of T frames; 0 = skip)")
@@ -413,7 +412,6 @@ def main():
     out_frames = expect_frames if verify and expect_frames * fb <= (24 << 30) else ring
     R = Runner(lvm, torch, np, cfg_idx, small, B, ring, T, local_rank, ids, out_frames)
     w, h, levels, ch, pk = R.w, R.h, R.levels, R.ch, R.pk
-    R.ctx.set_graph(bool(args.graph))
     R.ctx.set_pipeline(args.pipeline)
     stream = R.stream
 
@@ -614,7 +612,7 @@ def main():
             "config": {"workload": "%s %dx%d, %d levels, %d stream(s)/GPU, device-resident u8 BGR in/out" %
                                    (args.mode, w, h, levels, B),
                        "baseline_config": cfg_idx, "streams_per_gpu": B, "ring_frames": ring,
-                       "frames_per_call": T, "priming_frames": primed, "ramp_ms": args.ramp_ms, "ramp_frames_scratch_context": ramp_frames, "pipeline_depth": args.pipeline, "hip_graph": bool(args.graph)},
+                       "frames_per_call": T, "priming_frames": primed, "ramp_ms": args.ramp_ms, "ramp_frames_scratch_context": ramp_frames, "pipeline_depth": args.pipeline},
             "verified": verified, "verification": vinfo,
             "roofline": roofline,
             "cpu_baseline": cpu,
@@ -802,6 +800,40 @@ def sub_records(lvm, torch, np, args, cfg_idx, small, local_rank, rank, world, d
             lib.lvm_host_free(pin); lib.lvm_host_free(pout)
     out["e2e_host"] = dict(e2e, surface="lvm_process: host u8 in -> host u8 out, synchronous, one frame in flight "
                                         "(replaces MagnificationProcessor::process, MagnificationProcessor.cpp:17-67)")
+    # (2b) the export loop body: 32 page-locked host frames in, 32 side-by-side canvases out per lvm_export_frames call
+    # (runChainOnce + Exporter::compose, Exporter.cpp:216-259; the temporal batch inside, the canvases composed on the device)
+    try:
+        Te = 32
+        cpre = lvm.LvmPreprocessParams(1, 0, 0.0, 0.0, 1.0, 1.0, 0)
+        cw, chh = C.c_int(0), C.c_int(0)
+        lib.lvm_export_geometry(C.byref(cpre), 1, w, h, ch, C.byref(cw), C.byref(chh))
+        cb = cw.value * chh.value * 3
+        pin, pout = C.c_void_p(), C.c_void_p()
+        if cb > 0 and lib.lvm_host_alloc(fb * Te, C.byref(pin)) == 0 and lib.lvm_host_alloc(cb * Te, C.byref(pout)) == 0:
+            src = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(Te, h, w, ch))
+            for i in range(Te):
+                src[i] = host[i % host.shape[0]]
+            vp = C.c_void_p
+            pi = (vp * Te)(*[pin.value + i * fb for i in range(Te)])
+            pc = (vp * Te)(*[pout.value + i * cb for i in range(Te)])
+            prod = (C.c_int * Te)()
+            ex = lvm.Context(local_rank, 1)
+            ex.set_max_frames(Te)
+            for _ in range(2):
+                ex._check(lib.lvm_export_frames(ex.h, C.byref(cpre), R.p_ref, 1, Te, pi, w, h, ch, w * ch, pc, cw.value * 3, prod))
+            Kx = 6
+            t0 = time.perf_counter()
+            for _ in range(Kx):
+                ex._check(lib.lvm_export_frames(ex.h, C.byref(cpre), R.p_ref, 1, Te, pi, w, h, ch, w * ch, pc, cw.value * 3, prod))
+            dx = time.perf_counter() - t0
+            ex.close()
+            out["export_host"] = {"value": round(Kx * Te / dx, 2), "unit": "frames/s", "frames_per_call": Te, "us_per_frame": round(1e6 * dx / (Kx * Te), 1),
+                                  "pcie_bytes_per_frame": fb + cb, "pcie_gbs": round((fb + cb) * Kx * Te / dx / 1e9, 2),
+                                  "surface": "lvm_export_frames: pinned host frames in -> side-by-side canvases (original | processed) out; replaces the loop "
+                                             "body of Exporter::run (Exporter.cpp:216-259: runChainOnce + compose), host/HipExportRunner.hpp is the loop"}
+            lib.lvm_host_free(pin); lib.lvm_host_free(pout)
+    except Exception as e:      # a sub-record must never take the headline line down
+        out["export_host"] = {"error": str(e)[:200]}
     R.close()
     del R
     torch.cuda.empty_cache()

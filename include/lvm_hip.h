@@ -170,6 +170,19 @@ int  lvm_compose_device(lvm_ctx* ctx, int split, const uint8_t* d_orig, int ow, 
                         int pch, ptrdiff_t proc_stride, ptrdiff_t proc_stream_stride, uint8_t* d_canvas,
                         ptrdiff_t canvas_stride, ptrdiff_t canvas_stream_stride, void* hip_stream);
 
+/* The loop body of Exporter::run (export/Exporter.cpp:216-259) for n_frames CONSECUTIVE host frames of a 1-stream context:
+ *   runChainOnce (ChainBuilder.cpp:19-29: PreprocessProcessor -> GrayscaleProcessor -> MagnificationProcessor) on every frame in
+ *   order, then Exporter::compose(original, processed, split) (Exporter.cpp:53-88) -- `original` = the frame the magnifier saw,
+ *   `processed` = its output or, on passthrough (produced[i] == 0), that same frame (MagnificationProcessor.cpp:61).
+ * frames[i] -> canvases[i]: canvas_w x canvas_h x 3 bytes (lvm_export_geometry), row stride canvas_stride.  Only the ROI rows of
+ * the inputs and the canvases cross PCIe; the magnifier runs as ONE temporal batch (lvm_process_device_frames) and the canvases are
+ * composed on the device (lvm_compose_device).  The text overlay (Exporter.cpp:36-50) and cv::VideoWriter::write (:259) stay on
+ * the host: host/HipExportRunner.hpp is the reference-side loop around this call.  Synchronous.                               */
+int  lvm_export_geometry(const lvm_preprocess_params* pp, int split, int w, int h, int channels, int* canvas_w, int* canvas_h);
+int  lvm_export_frames(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames,
+                       const uint8_t* const* frames, int w, int h, int channels, ptrdiff_t in_stride,
+                       uint8_t* const* canvases, ptrdiff_t canvas_stride, int* produced);
+
 /* Cross-frame software pipeline for lvm_process_device (throughput mode, default depth 0).
  * depth 1 (implemented for the Laplace mode; other modes ignore it): a call enqueues the
  * down-sweep of ITS frame on an internal second stream concurrently with the up-sweep + output of
@@ -226,9 +239,6 @@ int  lvm_profile_collect(lvm_ctx* ctx);
 int  lvm_profile_only(lvm_ctx* ctx, const char* name);
 int  lvm_profile_entry(lvm_ctx* ctx, int idx, char* name, size_t name_cap, double* total_ms,
                        long long* launches);
-/* Capture the steady-state launch sequence in a hipGraph and replay it (default off: on MI355X /
- * ROCm 7.2 the plain schedule is already GPU-bound and replay measured ~5 us/frame slower). */
-int  lvm_set_graph(lvm_ctx* ctx, int on);
 /* Algorithmic bytes per frame per stream for the current geometry/mode. */
 double lvm_algorithmic_bytes(int mode, int w, int h, int channels, int levels, double framerate);
 

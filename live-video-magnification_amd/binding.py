@@ -97,7 +97,7 @@ class LvmError(RuntimeError):
 SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process_device", "lvm_process_device_frames", "lvm_set_pipeline", "lvm_flush", "lvm_synchronize",
            "lvm_last_error", "lvm_max_levels", "lvm_optimal_buffer_size", "lvm_butterworth2",
            "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_debug_lab_analytic", "lvm_get_lab_lut", "lvm_set_lab_lut", "lvm_profile_enable", "lvm_profile_collect", "lvm_profile_only",
-           "lvm_profile_entry", "lvm_set_graph", "lvm_algorithmic_bytes",
+           "lvm_profile_entry", "lvm_algorithmic_bytes", "lvm_export_geometry", "lvm_export_frames",
            "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process", "lvm_chain_process_batch",
            "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free", "lvm_compose_geometry", "lvm_compose_device", "lvm_chain_process_batch_ex"]
 
@@ -136,7 +136,6 @@ def bind(lib):
     lib.lvm_profile_only.argtypes = [vp, C.c_char_p]
     lib.lvm_profile_entry.argtypes = [vp, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double),
                                       C.POINTER(C.c_longlong)]
-    lib.lvm_set_graph.argtypes = [vp, C.c_int]
     lib.lvm_algorithmic_bytes.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double]
     lib.lvm_algorithmic_bytes.restype = C.c_double
     ip = C.POINTER(C.c_int)
@@ -149,6 +148,9 @@ def bind(lib):
                                             C.c_int, C.c_ssize_t, C.POINTER(vp), C.c_ssize_t, ip]
     lib.lvm_chain_process_batch_ex.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), C.POINTER(vp), C.c_int, C.c_int,
                                                C.c_int, C.c_ssize_t, C.POINTER(vp), C.c_ssize_t, C.POINTER(vp), C.c_ssize_t, ip]
+    lib.lvm_export_geometry.argtypes = [C.POINTER(LvmPreprocessParams), C.c_int, C.c_int, C.c_int, C.c_int, ip, ip]
+    lib.lvm_export_frames.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), C.c_int, C.c_int, C.POINTER(vp), C.c_int, C.c_int,
+                                      C.c_int, C.c_ssize_t, C.POINTER(vp), C.c_ssize_t, ip]
     lib.lvm_compose_geometry.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip]
     lib.lvm_compose_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, C.c_int, C.c_int, C.c_int,
                                        C.c_ssize_t, C.c_ssize_t, vp, C.c_ssize_t, C.c_ssize_t, vp]
@@ -235,6 +237,24 @@ class Context:
         self._check(self.lib.lvm_chain_process_batch(self.h, C.byref(cpre), C.byref(cparams), pin, w, h, ch, w * ch, pout, ow * och,
                                                      C.byref(produced)))
         return outs, bool(produced.value)
+
+    def export_frames(self, frames, cpre, cparams, split):
+        """lvm_export_frames: Exporter::run's loop body (runChainOnce + Exporter::compose) for consecutive host frames of a 1-stream
+        context.  Returns (canvases, produced flags)."""
+        frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+        h, w = frames[0].shape[:2]
+        ch = 1 if frames[0].ndim == 2 else frames[0].shape[2]
+        cw, chh = C.c_int(0), C.c_int(0)
+        self._check(self.lib.lvm_export_geometry(C.byref(cpre), int(split), w, h, ch, C.byref(cw), C.byref(chh)))
+        if cw.value <= 0 or chh.value <= 0:
+            raise LvmError("export_frames: empty canvas for this geometry (Exporter::compose returns an empty Mat)")
+        canvases = [np.empty((chh.value, cw.value, 3), dtype=np.uint8) for _ in frames]
+        pin = (C.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
+        pout = (C.c_void_p * len(frames))(*[o.ctypes.data for o in canvases])
+        produced = (C.c_int * len(frames))()
+        self._check(self.lib.lvm_export_frames(self.h, C.byref(cpre), C.byref(cparams), int(split), len(frames), pin, w, h, ch, w * ch,
+                                               pout, cw.value * 3, produced))
+        return canvases, [bool(x) for x in produced]
 
     def chain_process(self, frame, cpre, cparams):
         """Preprocess -> Grayscale -> Magnification on a host frame (lvm_chain_process).  Returns (out, produced);
@@ -355,9 +375,6 @@ class Context:
             self.lib.lvm_profile_entry(self.h, i, name, 64, C.byref(ms), C.byref(cnt))
             out[name.value.decode()] = (ms.value, cnt.value)
         return out
-
-    def set_graph(self, on):
-        self._check(self.lib.lvm_set_graph(self.h, int(on)))
 
 
 class MagnificationProcessor:

@@ -389,7 +389,7 @@ struct OutArgs {
     uint8_t* out; long out_stride, out_sstride;
     int w, h;
     const float* V; int vw, vh;                     // source of the last pyrUp (planes); U = 2vw x 2vh
-    const float* U2; int w2, h2;                    // FUSE2: source of the pyrUp BEFORE the last one (vw = 2 w2, vh = 2 h2); V is not read
+    const float* U2; int w2, h2;                    // k_col_out_strips: source of the pyrUp BEFORE the last one (vw = 2 w2, vh = 2 h2); V is not read
     const int* xofs; const float* xa; const int* yofs; const float* ya;
     const struct YSlot* yslot;                      // k_col_out_strips: entry kYSlotPad + s = {the output row gy with yofs[gy] == s or -1, ya[gy]}
     MinMax* mm;
@@ -584,12 +584,8 @@ __global__ __launch_bounds__(256) void k_col_out_v4(OutArgs a) {
 // from global memory and keeps the three rows in registers, advancing the window as js grows (js and
 // the row parity are uniform across the wave: no divergence, no LDS, no barrier until the final
 // min/max reduction of the workgroup).
-// FUSE2 (round 3): the pyrUp BEFORE the last one runs inside this kernel too -- the lane keeps the horizontal pass of three
-// rows of the level-2 image U2 in registers (its 4 level-1 columns i0 - 1 .. i0 + 2 come from 4 U2 columns), turns them into
-// the level-1 row it needs with pyrUp's vertical formulas and goes on as before.  V (25 MB per 1080p frame written by the last
-// generic pyrUp launch and read by both passes) never exists; arithmetic and operation order are those of k_pyr_up_rows.
 struct HRow3 { float4 c[3]; };
-template <bool WRITE, bool DBG, bool FUSE2>     // DBG: also store the float frame (compile time: no per-pixel branch in the production kernel)
+template <bool WRITE, bool DBG>     // DBG: also store the float frame (compile time: no per-pixel branch in the production kernel)
 __global__ __launch_bounds__(256) void k_col_out_rows(OutArgs a, int strips_x, int strips_y, int ntasks, int rows) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int task = blockIdx.x * 4 + wave;
@@ -610,55 +606,15 @@ __global__ __launch_bounds__(256) void k_col_out_rows(OutArgs a, int strips_x, i
             const int i0 = gx >> 1;
             const unsigned cm1 = 4u * (i0 > 0 ? i0 - 1 : 0), c00 = 4u * i0, cp1 = 4u * (i0 + 1 < a.vw ? i0 + 1 : a.vw - 1),
                            cp2 = 4u * (i0 + 2 < a.vw ? i0 + 2 : a.vw - 1);
-            // FUSE2: horizontal pyrUp pass of U2 row j at the lane's four level-1 columns i0 - 1 .. i0 + 2 (k_pyr_up_rows' formulas)
-            const int k0 = i0 >> 1;                                        // i0 is even (gx % 4 == 0)
-            const float* pl2 = FUSE2 ? a.U2 + (size_t)b * 3 * ((size_t)a.w2 * a.h2) : nullptr;
-            const size_t pstride2 = (size_t)a.w2 * a.h2;
-            const unsigned dm1 = 4u * (k0 > 0 ? k0 - 1 : 0), d00 = 4u * k0, dp1 = 4u * (k0 + 1 < a.w2 ? k0 + 1 : a.w2 - 1), dp2 = 4u * (k0 + 2 < a.w2 ? k0 + 2 : a.w2 - 1);
-            auto u2row = [&](int j) __attribute__((always_inline)) {
-                HRow3 o;
-                j = j < 0 ? 1 : (j >= a.h2 ? a.h2 - 1 : j);                // vertical border map of pyrUp: row -1 -> 1, row h2 -> h2 - 1
-                const char* row = reinterpret_cast<const char*>(pl2 + (size_t)j * a.w2);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const char* rc = row + c * pstride2 * sizeof(float);
-                    const float um = *reinterpret_cast<const float*>(rc + dm1), u0 = *reinterpret_cast<const float*>(rc + d00),
-                                u1 = *reinterpret_cast<const float*>(rc + dp1), u2 = *reinterpret_cast<const float*>(rc + dp2);
-                    const bool f0 = k0 == 0, l0 = k0 == a.w2 - 1, l1 = k0 + 1 == a.w2 - 1;
-                    o.c[c].x = (um + u0) * 4.f;                                                            // column i0 - 1 (odd, source k0 - 1; unused when k0 == 0)
-                    o.c[c].y = sel(f0, u0 * 6.f + u1 * 2.f, sel(l0, um + u0 * 7.f, um + u0 * 6.f + u1));     // column i0 (even, source k0)
-                    o.c[c].z = sel(l0, u0 * 8.f, (u0 + u1) * 4.f);                                          // column i0 + 1
-                    o.c[c].w = sel(l1, u0 + u1 * 7.f, u0 + u1 * 6.f + u2);                                  // column i0 + 2 (unused past the last column)
-                }
-                return o;
-            };
-            HRow3 P{}, Q{}, R{};                                           // U2 rows jcur - 1, jcur, jcur + 1 (border-mapped), horizontal pass done
-            int jcur = -1000;
             auto hrow = [&](int vy) __attribute__((always_inline)) {       // horizontal pyrUp pass of V row vy (border map -1 -> 1, vh -> vh - 1)
                 HRow3 o;
                 vy = vy < 0 ? 1 : (vy >= a.vh ? a.vh - 1 : vy);
                 const char* row = reinterpret_cast<const char*>(pl + (size_t)vy * a.vw);
-                if (FUSE2) {                                               // (vy is uniform across the wave: scalar branches)
-                    const int jj = vy >> 1;
-                    if (jj == jcur + 1) { P = Q; Q = R; R = u2row(jj + 1); }
-                    else if (jj != jcur) { P = u2row(jj - 1); Q = u2row(jj); R = u2row(jj + 1); }
-                    jcur = jj;
-                }
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    float sm1, s0, s1, s2;
-                    if (FUSE2) {
-                        const float* pp = &P.c[c].x; const float* pq = &Q.c[c].x; const float* pr = &R.c[c].x;
-                        float v[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            v[k] = (vy & 1) == 0 ? (pp[k] + pq[k] * 6.f + pr[k]) * (1.f / 64.f) : ((pq[k] + pr[k]) * 4.f) * (1.f / 64.f);
-                        sm1 = v[0]; s0 = v[1]; s1 = v[2]; s2 = v[3];
-                    } else {
-                        const char* rc = row + c * pstride * sizeof(float);
-                        sm1 = *reinterpret_cast<const float*>(rc + cm1); s0 = *reinterpret_cast<const float*>(rc + c00);
-                        s1 = *reinterpret_cast<const float*>(rc + cp1); s2 = *reinterpret_cast<const float*>(rc + cp2);
-                    }
+                    const char* rc = row + c * pstride * sizeof(float);
+                    const float sm1 = *reinterpret_cast<const float*>(rc + cm1), s0 = *reinterpret_cast<const float*>(rc + c00),
+                                s1 = *reinterpret_cast<const float*>(rc + cp1), s2 = *reinterpret_cast<const float*>(rc + cp2);
                     const bool f0 = i0 == 0, l0 = i0 == a.vw - 1, l1 = i0 + 1 == a.vw - 1;
                     o.c[c].x = sel(f0, s0 * 6.f + s1 * 2.f, sel(l0, sm1 + s0 * 7.f, sm1 + s0 * 6.f + s1));
                     o.c[c].y = sel(l0, s0 * 8.f, (s0 + s1) * 4.f);
@@ -1042,7 +998,6 @@ struct ColorState : ModeState {
     int out_rows = 16;               // rows per wave strip of k_col_out_rows (LVM_COL_OUT_ROWS; 0 = tiled k_col_out_v4)
     int out_rows_lean = 36;          // ... of k_col_out_strips (strip start-up = 3 V rows + 3 U2 rows: longer strips; 1080 = 30 x 36)
     bool out_lean = true;            // k_col_out_strips (both pyrUps inside, packed FP32, loads an iteration ahead); LVM_COL_OUT_LEAN=0: k_col_out_rows
-    bool out_fuse2 = false;          // LVM_COL_OUT_FUSE2=1: the pyrUp before the last one inside the output kernels too (25 MB per frame less, measured equal: off)
     int thin_min_frames = 4;         // ... from this many frames per launch (LVM_COL_THIN_MIN_FRAMES)
     long rows_min_elems = 1 << 20;   // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
     double* tw = nullptr; int tw_n = 0;          // table of the current window length (points into tw_all or at tw_own)
@@ -1267,8 +1222,8 @@ static void col_up_out(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs&
     const bool lean = st->out_lean && st->yofs_strict && vec4_f && st->out_rows > 0 && levels >= 2 &&
                       (st->g[levels].w << (levels - 2)) >= 2 && (st->g[levels].h << (levels - 2)) >= 2 &&
                       io.in_stride > 0 && io.out_stride > 0 && (long)io.in_stride * io.h < (1L << 31) && (long)io.out_stride * io.h < (1L << 31);
-    const bool fuse2 = lean || (st->out_fuse2 && vec4_f && st->out_rows > 0 && levels >= 2);
-    for (int k = 0; k + 1 < levels - (fuse2 ? 1 : 0); ++k) {      // L-1 generic pyrUps, the last one is fused into k_col_out (FUSE2: the last two)
+    const bool fuse2 = lean;                      // k_col_out_strips makes the last TWO pyrUps itself
+    for (int k = 0; k + 1 < levels - (fuse2 ? 1 : 0); ++k) {      // L-1 generic pyrUps, the last one is fused into k_col_out (k_col_out_strips: the last two)
         if (st->up_rows && (2 * uw) % 4 == 0) {      // barrier-free blocks of 4 x 2 outputs per lane (pyramid.h)
             const long ngroups = (long)(2 * uw / 4) * uh;
             LVM_LAUNCH(c, LName("pyr_up", k), k_pyr_up_rows<1>, dim3((unsigned)((ngroups + 255) / 256), planes), blk, s, (const float*)B.up[k], uw, uh,
@@ -1304,14 +1259,10 @@ static void col_up_out(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs&
             LVM_LAUNCH(c, "col_minmax_u2", (k_col_out_strips<false, false>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
             if (a.dbg) LVM_LAUNCH(c, "col_out_u2", (k_col_out_strips<true, true>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
             else LVM_LAUNCH(c, "col_out_u2", (k_col_out_strips<true, false>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
-        } else if (fuse2) {
-            LVM_LAUNCH(c, "col_minmax", (k_col_out_rows<false, false, true>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
-            if (a.dbg) LVM_LAUNCH(c, "col_out", (k_col_out_rows<true, true, true>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
-            else LVM_LAUNCH(c, "col_out", (k_col_out_rows<true, false, true>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
         } else {
-            LVM_LAUNCH(c, "col_minmax", (k_col_out_rows<false, false, false>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
-            if (a.dbg) LVM_LAUNCH(c, "col_out", (k_col_out_rows<true, true, false>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
-            else LVM_LAUNCH(c, "col_out", (k_col_out_rows<true, false, false>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
+            LVM_LAUNCH(c, "col_minmax", (k_col_out_rows<false, false>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
+            if (a.dbg) LVM_LAUNCH(c, "col_out", (k_col_out_rows<true, true>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
+            else LVM_LAUNCH(c, "col_out", (k_col_out_rows<true, false>), g2, blk, s, a, sx, sy, (int)ntasks, rows);
         }
     } else if (vec4) {
         LVM_LAUNCH(c, "col_minmax", k_col_out_v4<false>, grid, blk, s, a);
@@ -1335,7 +1286,6 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
         if (const char* e = std::getenv("LVM_COL_OUT_ROWS")) st->out_rows = st->out_rows_lean = std::atoi(e);
-        if (const char* e = std::getenv("LVM_COL_OUT_FUSE2")) st->out_fuse2 = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_COL_OUT_LEAN")) st->out_lean = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_COL_DOWN01")) st->d01_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_COL_DOWN01_ROWS")) st->d01_rows_forced = std::atoi(e);

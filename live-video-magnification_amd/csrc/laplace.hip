@@ -1229,8 +1229,6 @@ struct LaplaceState : ModeState {
     float *hi[kMaxLevels + 1] = {}, *lo[kMaxLevels + 1] = {}, *cur[kMaxLevels + 1] = {};
     bool seeded = false;
     float *hi1x = nullptr, *lo1x = nullptr;   // second pair of level-1 state planes (k_lap_final1 reads one pair and writes the other; swapped per launch)
-    int state_par = 0;                        // which pair is current (part of the graph key: the kernels see different pointers)
-    bool used_final1 = false;                 // the last steady frame ran k_lap_final1 (graph replay: advance() swaps the pairs as the launch code does)
     float* Gp[2][kMaxLevels + 1] = {};    // Gaussian pyramid, double-buffered by frame parity (pipelined mode)
     float* curT[2] = {};                  // cur_T written by the tail kernel, double-buffered likewise
     struct Pending { bool valid = false; FrameIO io{}; lvm_params p{}; int par = 0; } pending;
@@ -1262,23 +1260,7 @@ struct LaplaceState : ModeState {
     int fuse_down = 2;                    // pyramid levels per pyrDown launch (LVM_FUSE_DOWN=2|3 selects the fused kernels)
     int tailT = 0;                       // first level handled by k_lap_tail (0 = tail disabled)
     TailArgs tail{};
-    bool steady(const lvm_params&) const override { return seeded && (depth == 0 || pending.valid); }
-    void swap_level1_states() { std::swap(hi[1], hi1x); std::swap(lo[1], lo1x); state_par ^= 1; }
-    void advance(const lvm_params& p, const FrameIO& io) override {
-        if (used_final1) swap_level1_states();
-        if (depth == 0) return;
-        pending.valid = true; pending.io = io; pending.p = p; pending.par = par;
-        par ^= 1;
-    }
-    size_t key_extra(uint8_t* buf, size_t cap) const override {
-        struct { FrameIO io; lvm_params p; int par, cur, depth, state_par; } k;
-        std::memset(&k, 0, sizeof(k));
-        if (pending.valid) { k.io = pending.io; k.p = pending.p; k.par = pending.par; }
-        k.cur = par; k.depth = depth; k.state_par = state_par;
-        if (sizeof(k) > cap) return 0;
-        std::memcpy(buf, &k, sizeof(k));
-        return sizeof(k);
-    }
+    void swap_level1_states() { std::swap(hi[1], hi1x); std::swap(lo[1], lo1x); }
     ~LaplaceState() override {
         if (arena) (void)hipFree(arena);
         if (tarena) (void)hipFree(tarena);
@@ -1575,7 +1557,6 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
 #else
     const bool fuse1 = false;
 #endif
-    st->used_final1 = false;
     for (int l = up_start; l >= (fuse1 ? 2 : 1); --l) {
         UpArgs a;
         a.Gl = G[l]; a.Gn = G[l + 1];
@@ -1634,7 +1615,6 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
                       : (hc ? LVM_FL_PICK(fl, k_lap_final1, true, false) : LVM_FL_PICK(fl, k_lap_final1, false, false));
         LVM_LAUNCH(c, "lap_final1", k1, grid1, blk, s, a);
         st->swap_level1_states();
-        st->used_final1 = true;
         return;
     }
 #endif

@@ -65,14 +65,7 @@ void mark_enqueued(Ctx* c, hipStream_t s) {
     c->caller_events.emplace_back(s, ev);
 }
 
-static void drop_graphs(Ctx* c) {
-    for (auto& g : c->graphs) {
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-        if (g.graph) (void)hipGraphDestroy(g.graph);
-    }
-    c->graphs.clear();
-}
-static void drop_state(Ctx* c) { drop_graphs(c); delete c->state; c->state = nullptr; }
+static void drop_state(Ctx* c) { delete c->state; c->state = nullptr; }
 
 // (re)build the device layouts of the forward Lab table from c->lab_lut_compact
 int upload_lab_lut(Ctx* c) {
@@ -96,58 +89,6 @@ static int run_mode(Ctx* c, const lvm_params* p, int levels, const FrameIO& io, 
     return LVM_OK;
 }
 
-// Steady-state frames replay a captured hipGraph: one graph launch instead of 8-20 kernel launches.
-// The key holds every value a kernel of the sequence can see (pointers, strides, geometry, parameters).
-// A sequence is captured the second time its key is seen; capture failure permanently falls back to
-// plain launches for this context.
-static int run_mode_graphed(Ctx* c, const lvm_params* p, int levels, const FrameIO& io, hipStream_t s, int* produced) {
-    struct Key { FrameIO io; lvm_params p; int levels; int exact; float* dbg; size_t nx; uint8_t extra[256]; } k;
-    std::memset(&k, 0, sizeof(k));
-    k.io = io; k.p = *p; k.levels = levels; k.exact = lvm::lab_flavour(c); k.dbg = c->keep_float ? c->d_float : nullptr;
-    k.nx = c->state->key_extra(k.extra, sizeof(k.extra));
-    const uint8_t* kb = reinterpret_cast<const uint8_t*>(&k);
-    GraphEntry* e = nullptr;
-    for (auto& g : c->graphs)
-        if (g.key.size() == sizeof(k) && std::memcmp(g.key.data(), kb, sizeof(k)) == 0) { e = &g; break; }
-    if (e && e->exec) {
-        LVM_HIP_TRY(c, hipGraphLaunch(e->exec, s));
-        c->state->advance(*p, io);
-        *produced = e->produced;
-        return LVM_OK;
-    }
-    if (!e) {   // first sighting: remember the key, run plainly
-        if (c->graphs.size() >= 64) drop_graphs(c);
-        GraphEntry ne; ne.key.assign(kb, kb + sizeof(k));
-        c->graphs.push_back(ne);
-        return run_mode(c, p, levels, io, s, produced);
-    }
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
-        (void)hipGetLastError();
-        c->use_graph = false;
-        return run_mode(c, p, levels, io, s, produced);
-    }
-    int prod = 0;
-    const int rc = run_mode(c, p, levels, io, s, &prod);
-    hipGraph_t graph = nullptr;
-    const hipError_t ee = hipStreamEndCapture(s, &graph);
-    if (rc != LVM_OK || ee != hipSuccess || !graph) {
-        if (graph) (void)hipGraphDestroy(graph);
-        (void)hipGetLastError();
-        c->use_graph = false;
-        if (rc != LVM_OK) return rc;
-        return run_mode(c, p, levels, io, s, produced);   // nothing ran during the failed capture
-    }
-    hipGraphExec_t exec = nullptr;
-    if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) {
-        (void)hipGraphDestroy(graph); (void)hipGetLastError();
-        c->use_graph = false;
-        return run_mode(c, p, levels, io, s, produced);
-    }
-    e->graph = graph; e->exec = exec; e->produced = prod;
-    LVM_HIP_TRY(c, hipGraphLaunch(exec, s));
-    *produced = prod;
-    return LVM_OK;
-}
 // A failed call (allocation failure, launch error) must not leave a half-built state installed: the next call
 // would launch kernels on null buffers.  Drop it and disarm the tracker so that the next frame starts afresh,
 // which is also what the reference's recovery path does (ProcessingChain.cpp:50-62 resets every stage).
@@ -207,9 +148,7 @@ static int process_device(Ctx* c, const lvm_params* p, const FrameIO& io, hipStr
         const int rc = ensure_float(c, (size_t)io.w * io.h * io.channels);
         if (rc != LVM_OK) return rc;
     }
-    int rc;
-    if (c->use_graph && !c->profiling && c->state && c->state->steady(*p)) rc = run_mode_graphed(c, p, levels, io, s, produced);
-    else rc = run_mode(c, p, levels, io, s, produced);
+    const int rc = run_mode(c, p, levels, io, s, produced);
     mark_enqueued(c, s);
     if (rc != LVM_OK) fail_state(c, s);
     return rc;
@@ -262,7 +201,6 @@ void lvm_destroy(lvm_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     lvm::sync_streams(c);
-    lvm::drop_graphs(c);
     delete c->state; c->state = nullptr;
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
     if (c->d_gamma_u8) (void)hipFree(c->d_gamma_u8);
@@ -277,6 +215,8 @@ void lvm_destroy(lvm_ctx* c) {
     if (c->d_pre_out) (void)hipFree(c->d_pre_out);
     if (c->d_chain_out) (void)hipFree(c->d_chain_out);
     c->d_pre_in = c->d_pre_out = c->d_chain_out = nullptr; c->pre_in_cap = c->pre_out_cap = c->chain_out_cap = 0;
+    if (c->d_canvas) (void)hipFree(c->d_canvas);
+    c->d_canvas = nullptr; c->canvas_cap = 0;
     for (auto& e : c->caller_events) (void)hipEventDestroy(e.second);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
@@ -475,6 +415,85 @@ int lvm_chain_process_batch_ex(lvm_ctx* c, const lvm_preprocess_params* pp, cons
     return LVM_OK;
 }
 
+int lvm_export_geometry(const lvm_preprocess_params* pp, int split, int w, int h, int channels, int* cw, int* ch) {
+    if (!pp || w <= 0 || h <= 0 || (channels != 1 && channels != 3) || !cw || !ch) return LVM_ERR_INVALID;
+    if (split < LVM_SPLIT_NONE || split > LVM_SPLIT_TOP_BOTTOM) return LVM_ERR_INVALID;
+    int rx, ry, rw, rh, ow, oh, och, pw, ph;
+    lvm::preprocess_geometry(*pp, w, h, channels, &rx, &ry, &rw, &rh, &ow, &oh, &och);
+    (void)lvm::compose_geometry(split, ow, oh, ow, oh, &pw, &ph, cw, ch);      // 0 x 0 where Exporter::compose returns an empty Mat
+    return LVM_OK;
+}
+
+// Exporter::run's loop body for a batch of host frames (export/Exporter.cpp:216-259); see include/lvm_hip.h
+int lvm_export_frames(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames,
+                      const uint8_t* const* frames, int w, int h, int channels, ptrdiff_t in_stride, uint8_t* const* canvases,
+                      ptrdiff_t canvas_stride, int* produced) {
+    if (!c || !pp || !p || !frames || !canvases || !produced || n_frames < 1) return LVM_ERR_INVALID;
+    if (c->nstreams != 1) { c->err = "lvm_export_frames needs a 1-stream context"; return LVM_ERR_INVALID; }
+    if (w <= 0 || h <= 0 || (channels != 1 && channels != 3) || in_stride < (ptrdiff_t)w * channels) { c->err = "bad frame arguments"; return LVM_ERR_INVALID; }
+    for (int k = 0; k < n_frames; ++k) { produced[k] = 0; if (!frames[k] || !canvases[k]) { c->err = "null frame pointer"; return LVM_ERR_INVALID; } }
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    int rx, ry, rw, rh, ow, oh, och, pw, ph, cw, chh;
+    lvm::preprocess_geometry(*pp, w, h, channels, &rx, &ry, &rw, &rh, &ow, &oh, &och);
+    if (split < LVM_SPLIT_NONE || split > LVM_SPLIT_TOP_BOTTOM) { c->err = "invalid split mode"; return LVM_ERR_INVALID; }
+    if (!lvm::compose_geometry(split, ow, oh, ow, oh, &pw, &ph, &cw, &chh) || cw <= 0 || chh <= 0) {
+        c->err = "lvm_export_frames: empty canvas (Exporter::compose returns an empty Mat for this geometry)"; return LVM_ERR_INVALID;
+    }
+    if (canvas_stride < (ptrdiff_t)cw * 3) { c->err = "canvas stride too small"; return LVM_ERR_INVALID; }
+    const size_t roi_row = (size_t)rw * channels, roi_bytes = roi_row * rh;
+    const size_t out_row = (size_t)ow * och, out_bytes = out_row * oh;
+    const size_t can_row = (size_t)cw * 3, can_bytes = can_row * chh;
+    auto reserve = [&](uint8_t*& ptr, size_t& cap, size_t need) -> int {
+        if (need <= cap) return LVM_OK;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; cap = 0;
+        LVM_HIP_TRY(c, hipMalloc((void**)&ptr, need));
+        cap = need;
+        return LVM_OK;
+    };
+    hipStream_t s = c->own_stream;
+    LVM_HIP_TRY(c, hipStreamSynchronize(s));      // staging buffers may be replaced below
+    int rc = reserve(c->d_pre_in, c->pre_in_cap, roi_bytes * n_frames); if (rc != LVM_OK) return rc;
+    rc = reserve(c->d_pre_out, c->pre_out_cap, out_bytes * n_frames); if (rc != LVM_OK) return rc;
+    rc = reserve(c->d_chain_out, c->chain_out_cap, out_bytes * n_frames); if (rc != LVM_OK) return rc;
+    rc = reserve(c->d_canvas, c->canvas_cap, can_bytes * n_frames); if (rc != LVM_OK) return rc;
+    for (int k = 0; k < n_frames; ++k)            // only the ROI rows cross PCIe (the crop is the pitch of the 2-D copy)
+        LVM_HIP_TRY(c, hipMemcpy2DAsync(c->d_pre_in + (size_t)k * roi_bytes, roi_row, frames[k] + (size_t)ry * in_stride + (size_t)rx * channels,
+                                        (size_t)in_stride, roi_row, (size_t)rh, hipMemcpyHostToDevice, s));
+    const uint8_t* mag_in = c->d_pre_in;
+    const bool identity = ow == rw && oh == rh && och == channels;      // PreprocessProcessor.cpp:15, GrayscaleProcessor.cpp:8-9
+    if (!identity) {
+        lvm_preprocess_params q = *pp;
+        q.roi_enabled = 0;                                               // already cropped by the copy
+        for (int k = 0; k < n_frames; ++k) {                             // (stateless: a frame of the batch is one more "stream" of a 1-stream context)
+            rc = lvm::preprocess_device(c, q, c->d_pre_in + (size_t)k * roi_bytes, rw, rh, channels, (ptrdiff_t)roi_row, (ptrdiff_t)roi_bytes,
+                                        c->d_pre_out + (size_t)k * out_bytes, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, s);
+            if (rc != LVM_OK) { (void)hipStreamSynchronize(s); return rc; }
+        }
+        mag_in = c->d_pre_out;
+    }
+    lvm_params mp = *p;
+    mp.preprocess_key = preprocess_key_of(*pp);
+    const int saved_depth = c->pipeline_depth;
+    c->pipeline_depth = 0;
+    rc = lvm_process_device_frames(c, &mp, n_frames, mag_in, ow, oh, och, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, (ptrdiff_t)out_bytes,
+                                   c->d_chain_out, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, (ptrdiff_t)out_bytes, produced, s);
+    c->pipeline_depth = saved_depth;
+    if (rc != LVM_OK) { (void)hipStreamSynchronize(s); return rc; }
+    for (int k = 0; k < n_frames; ++k) {
+        const uint8_t* orig = mag_in + (size_t)k * out_bytes;
+        const uint8_t* proc = produced[k] ? c->d_chain_out + (size_t)k * out_bytes : orig;     // MagnificationProcessor.cpp:61
+        rc = lvm::compose_device(c, split, orig, ow, oh, och, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, proc, ow, oh, och, (ptrdiff_t)out_row,
+                                 (ptrdiff_t)out_bytes, c->d_canvas + (size_t)k * can_bytes, (ptrdiff_t)can_row, (ptrdiff_t)can_bytes, s);
+        if (rc != LVM_OK) { (void)hipStreamSynchronize(s); return rc; }
+        LVM_HIP_TRY(c, hipMemcpy2DAsync(canvases[k], (size_t)canvas_stride, c->d_canvas + (size_t)k * can_bytes, can_row, can_row, (size_t)chh,
+                                        hipMemcpyDeviceToHost, s));
+    }
+    lvm::mark_enqueued(c, s);
+    LVM_HIP_TRY(c, hipStreamSynchronize(s));
+    return LVM_OK;
+}
+
 int lvm_chain_process(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, const uint8_t* in, int w, int h, int channels,
                       ptrdiff_t in_stride, uint8_t* out, ptrdiff_t out_stride, int* produced) {
     if (!c || !produced) return LVM_ERR_INVALID;
@@ -615,8 +634,7 @@ int lvm_set_pipeline(lvm_ctx* c, int depth) {
         lvm::sync_streams(c);
         if (c->t_mode == LVM_MODE_LAPLACE) (void)lvm::laplace_flush(c, c->own_stream);
         lvm::sync_streams(c);
-        lvm::drop_graphs(c);
-        c->pipeline_depth = depth;
+            c->pipeline_depth = depth;
     }
     return LVM_OK;
 }
@@ -628,8 +646,6 @@ int lvm_flush(lvm_ctx* c, void* hip_stream) {
     if (c->t_mode == LVM_MODE_LAPLACE) return lvm::laplace_flush(c, s);
     return LVM_OK;
 }
-
-int lvm_set_graph(lvm_ctx* c, int on) { if (!c) return LVM_ERR_INVALID; c->use_graph = on != 0; return LVM_OK; }
 
 // compulsory traffic only -- every input byte read once, every output byte
 // written once, every live persistent state word read once and written once.

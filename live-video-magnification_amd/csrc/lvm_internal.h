@@ -376,17 +376,7 @@ struct FrameIO {
 
 struct ModeState {
     virtual ~ModeState() {}
-    // true when the next frame with parameters `p` issues a fixed launch sequence (no allocation, no
-    // host synchronisation, no per-frame varying kernel argument) and produces an output: such frames
-    // may be captured in a hipGraph and replayed.
-    virtual bool steady(const lvm_params& p) const { (void)p; return false; }
-    // extra bytes for the graph key (mode-private values kernels of the sequence can see)
-    virtual size_t key_extra(uint8_t* buf, size_t cap) const { (void)buf; (void)cap; return 0; }
-    // host-side bookkeeping of one steady frame when its launches come from a replayed graph
-    virtual void advance(const lvm_params& p, const FrameIO& io) { (void)p; (void)io; }
 };
-
-struct GraphEntry { std::vector<uint8_t> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int produced = 0; };
 
 struct Ctx {
     int device = 0;
@@ -412,8 +402,6 @@ struct Ctx {
     std::string prof_only; bool prof_skip = false;   // lvm_profile_only: bracket launches of this report name only
     std::vector<ProfEvent> prof_events;
     std::vector<ProfTotal> prof_totals;
-    bool use_graph = false;           // measured on MI355X/ROCm 7.2: plain launches are GPU-bound already and graph replay adds ~5 us/frame
-    std::vector<GraphEntry> graphs;   // steady-state launch sequences, keyed by every kernel-visible input
     int pipeline_depth = 0;           // 0 = every call completes its own frame; 1 = outputs lag one call (Laplace)
     hipStream_t aux_stream = nullptr; // second stream of the cross-frame pipeline
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -429,6 +417,7 @@ struct Ctx {
     // preprocess stage (preprocess.hip): area tables of the current geometry, staging of the host chain
     void* pre_tables = nullptr;
     uint8_t *d_pre_in = nullptr, *d_pre_out = nullptr, *d_chain_out = nullptr; size_t pre_in_cap = 0, pre_out_cap = 0, chain_out_cap = 0;
+    uint8_t* d_canvas = nullptr; size_t canvas_cap = 0;     // lvm_export_frames: the composed canvases of a batch
 };
 
 inline int lab_flavour(const Ctx* c) { return c->lab_analytic ? FL_ANALYTIC : (c->exact_lab ? FL_LUT_EXACT : FL_LUT_FAST); }

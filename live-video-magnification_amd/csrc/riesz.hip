@@ -1297,7 +1297,7 @@ struct RieszState : ModeState {
     int blur_strip_rows = 64;        // rows per strip (LVM_RZ_BLUR_STRIP_ROWS), halved until a level has 4096 strips
     double lo_freq = 0, hi_freq = 0, fps = 0;
     double la[3] = {}, lb[3] = {}, ha[3] = {}, hb[3] = {};
-    bool steady(const lvm_params& p) const override {
+    bool steady(const lvm_params& p) const {
         return inited && lo_freq == p.coLow && hi_freq == p.coHigh && !std::isnan(la[0]) && !std::isnan(ha[0]);
     }
     ~RieszState() override { if (arena) (void)hipFree(arena); if (tarena) (void)hipFree(tarena); }

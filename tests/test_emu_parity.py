@@ -165,12 +165,10 @@ def test_color_emu_strip_kernel_border_lanes(lvm, po, emu, w, h, levels, monkeyp
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 12, 0.0, exact=True)
 
 
-@pytest.mark.parametrize("w,h,levels,fuse2", [(264, 90, 3, "0"), (264, 90, 3, "1"), (512, 128, 4, "1")])
-def test_color_emu_previous_strip_kernels_still_match(lvm, po, emu, w, h, levels, fuse2, monkeypatch):
-    """LVM_COL_OUT_LEAN=0: k_col_out_rows (the fallback for row maps that are not strictly increasing / one-level pyramids), with
-    and without its own fused second pyrUp."""
+@pytest.mark.parametrize("w,h,levels", [(264, 90, 3), (512, 128, 4)])
+def test_color_emu_previous_strip_kernels_still_match(lvm, po, emu, w, h, levels, monkeypatch):
+    """LVM_COL_OUT_LEAN=0: k_col_out_rows (the fallback for row maps that are not strictly increasing / one-level pyramids)."""
     monkeypatch.setenv("LVM_COL_OUT_LEAN", "0")
-    monkeypatch.setenv("LVM_COL_OUT_FUSE2", fuse2)
     monkeypatch.setenv("LVM_COL_OUT_MIN_TASKS", "0")
     ck, pk = lvm.synth.config(3, (w, h, levels))
     ck["fps"] = 15.0; pk["framerate"] = 15.0

@@ -1,5 +1,5 @@
-"""The three reference-side shims (host/HipMagnificationProcessor.hpp, HipProcessingStages.hpp,
-HipBatchedProcessingChain.hpp with LVM_WITH_LIVIM_HEADERS) compiled against the REFERENCE'S OWN headers
+"""The four reference-side shims (host/HipMagnificationProcessor.hpp, HipProcessingStages.hpp,
+HipBatchedProcessingChain.hpp and HipExportRunner.hpp with LVM_WITH_LIVIM_HEADERS) compiled against the REFERENCE'S OWN headers
 (/root/reference/src: IProcessor.hpp, core/Frame.hpp, FrameQueue, LatestFrameMailbox, AtomicConfig, Instrumentation),
 which are Qt-free.  OpenCV is not in this image, so <opencv2/core.hpp> is a small stand-in written here that declares just
 the cv::Mat surface the shims and those headers use (constructors, data / rows / cols / step, channels(), type(), empty(),
@@ -25,6 +25,7 @@ CV_STUB = r'''
 #define CV_8UC1 0
 #define CV_8UC3 16
 namespace cv {
+struct Size { int width = 0, height = 0; Size() = default; Size(int w, int h) : width(w), height(h) {} };
 struct MatStep { size_t v = 0; operator size_t() const { return v; } };
 class Mat {
 public:
@@ -53,6 +54,7 @@ SRC = r'''
 #include "HipMagnificationProcessor.hpp"
 #include "HipProcessingStages.hpp"
 #include "HipBatchedProcessingChain.hpp"
+#include "HipExportRunner.hpp"
 #include <cstdio>
 #include <vector>
 int main() {
@@ -74,6 +76,24 @@ int main() {
         AtomicConfig<ProcessorConfig> ac(cfg);
         HipBatchedProcessingChain chain({&q0, &q1}, {&m0, &m1}, nullptr, &ac, 0);
         std::printf("sources %zu\n", chain.sources());
+        // the export loop bound to IExportFrameSource / cv::Mat (Exporter.cpp:216-259): a two-frame source, a sink that counts
+        struct TwoFrames : IExportFrameSource {
+            int n = 0;
+            bool open() override { return true; }
+            int frameCount() const override { return 2; }
+            cv::Size size() const override { return cv::Size(64, 48); }
+            bool next(cv::Mat& out) override { if (n >= 2) return false; out = cv::Mat(48, 64, CV_8UC3); std::memset(out.data, 80 + 10 * n, 48 * 64 * 3); ++n; return true; }
+            void close() override {}
+        } two;
+        ExportRequest req; req.config = cfg; req.split = SplitMode::LeftRight;
+        std::atomic<bool> abort_flag{false}; std::atomic<int> done{0};
+        LivimExportSink sink;
+        sink.abort = &abort_flag; sink.frames_done = &done;
+        sink.write_canvas = [](cv::Mat& canvas) { return canvas.cols == 128 && canvas.rows == 48; };
+        LivimExportTraits::Source src{&two, cv::Mat()};
+        HipExportLoop loop(0, 8);
+        const auto written = loop.run(src, sink, export_pre_params(req.config), export_mag_params(req.config), export_split(req.split), 30.0);
+        std::printf("export wrote %llu done %d\n", (unsigned long long)written, done.load());
     } catch (const std::exception& e) { std::printf("exception: %s\n", e.what()); return 3; }
     return 0;
 }
@@ -95,6 +115,6 @@ def test_shims_compile_against_the_reference_headers(tmp_path):
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     import torch
     if torch.cuda.is_available():
-        assert run.returncode == 0 and "out 64x48" in run.stdout and "sources 2" in run.stdout, run.stdout + run.stderr
+        assert run.returncode == 0 and "out 64x48" in run.stdout and "sources 2" in run.stdout and "export wrote 2 done 2" in run.stdout, run.stdout + run.stderr
     else:                                                               # no device here: the constructors fail loudly
         assert run.returncode == 3 and "lvm_create failed" in run.stdout, run.stdout + run.stderr

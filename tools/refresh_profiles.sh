@@ -1,12 +1,11 @@
 #!/bin/bash
-# Reproduces the round-3 files under profiles/ on a GPU box (`gpurun -- 'bash tools/refresh_profiles.sh'`): the bench
+# Reproduces the round-4 files under profiles/ on a GPU box (`gpurun -- 'bash tools/refresh_profiles.sh'`): the bench
 # lines of every mode (driver-shaped and default), the rocprofv3 kernel-trace summaries and the PMC passes (FETCH_SIZE,
-# WRITE_SIZE, SQ counters: each in its own run, never combined with other trace domains), the HBM counter calibration and
-# the two-stream (chunked) schedule's kernel trace.  Outputs land in gpurun_out/profiles_r03/; copy what is to be judged
+# WRITE_SIZE, SQ counters: each in its own run, never combined with other trace domains).  Outputs land in gpurun_out/profiles_r04/; copy what is to be judged
 # into profiles/.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-R=r03
+R=r04
 O=$ROOT/gpurun_out/profiles_$R; mkdir -p $O; cd $ROOT
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/${R}_bench_laplace_driver_shape.json 2> $O/err.txt
 timeout 600 python bench.py --no-subrecords > $O/${R}_bench_laplace.json 2>> $O/err.txt
@@ -21,11 +20,4 @@ for m in ${MODES:-laplace riesz color}; do
   python tools/pmc_traffic.py $m "$m|1920x1080|L6|B1|T32" $O/pmc_$m/p0 $O/pmc_$m/p3 $O/pmc_$m/p4 > $O/${R}_pmc_traffic_$m.json
   rm -rf $O/pmc_$m/p1 $O/pmc_$m/p2 $O/pmc_$m/p3 $O/pmc_$m/p4       # the per-dispatch counter CSVs are large; the summaries stay
 done
-# two-stream schedule: table conversion + first kernel of the next chunk on the auxiliary stream (half the CUs), the rest on
-# the caller's stream -- per-dispatch start / end times show what did and did not overlap
-cd /tmp; export TMPDIR=/tmp
-LVM_LAP_CHUNKS=4 LVM_D0_FUSED_GRID=128 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O/chunks -o t -- \
-  python $ROOT/bench.py --no-cpu-baseline --no-subrecords --profile-steps 0 --steps 128 --warmup 32 > $O/chunks.log 2>&1
-cd $ROOT
-python tools/overlap_report.py $O/chunks > $O/${R}_two_stream_overlap.txt 2>&1
 ls -la $O | head -40
