@@ -37,22 +37,41 @@ __global__ __launch_bounds__(LC_THREADS) void k_lab_planes(const uint8_t* __rest
     int y, xu;
     { const int r = (int)(u - (long)f * upf); y = r / upr; xu = r - y * upr; }
     const int step_y = LC_THREADS / upr, step_x = LC_THREADS - step_y * upr;
-    for (; u < uend; u += LC_THREADS, xu += step_x, y += step_y) {
+    auto advance = [&]() __attribute__((always_inline)) {          // the lane's next unit
+        u += LC_THREADS; xu += step_x; y += step_y;
         if (xu >= upr) { xu -= upr; ++y; }
         while (y >= h) { y -= h; ++f; }
-        const uint8_t* p = in + (size_t)f * in_sstride + (size_t)y * in_stride;
-        const size_t o = ((size_t)f * h + y) * w;
-        if (VEC) {
+    };
+    if (VEC) {
+        // The group of the NEXT step is loaded before this step's look-ups (the 12-byte load used to be issued and waited for in the
+        // same step), and inside a step the table reads of the pixels k + 1, k + 2 are issued before pixel k is interpolated
+        // (lut_issue / lut_finish, as in the fused first kernel of the Laplace path).
+        auto fetch = [&]() __attribute__((always_inline)) {
             // streaming data bypasses the caches' retention (nontemporal): the L cells a CU keeps re-reading stay in its L1
             LcPx4 v;
-            { const uint32_t* pi = reinterpret_cast<const uint32_t*>(p + (size_t)xu * 12);
-              v.a = __builtin_nontemporal_load(pi); v.b = __builtin_nontemporal_load(pi + 1); v.c = __builtin_nontemporal_load(pi + 2); }
+            const uint32_t* pi = reinterpret_cast<const uint32_t*>(in + (size_t)f * in_sstride + (size_t)y * in_stride + (size_t)xu * 12);
+            v.a = __builtin_nontemporal_load(pi); v.b = __builtin_nontemporal_load(pi + 1); v.c = __builtin_nontemporal_load(pi + 2);
+            return v;
+        };
+        LcPx4 vn{};
+        if (u < uend) vn = fetch();
+        while (u < uend) {
+            const LcPx4 v = vn;
+            const size_t q = ((size_t)f * h + y) * w + (size_t)xu * 4;
+            advance();
+            if (u < uend) vn = fetch();
             const uint32_t pb[12] = {v.a & 255, (v.a >> 8) & 255, (v.a >> 16) & 255, v.a >> 24, v.b & 255, (v.b >> 8) & 255,
                                      (v.b >> 16) & 255, v.b >> 24, v.c & 255, (v.c >> 8) & 255, (v.c >> 16) & 255, v.c >> 24};
             int iL[4], ia[4], ib[4];
+            LutRefs r[4];
+            r[0] = lut_issue(pb[0], pb[1], pb[2], s_ab, lut.Lcells);
+            r[1] = lut_issue(pb[3], pb[4], pb[5], s_ab, lut.Lcells);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) lut_lab_int(pb[3 * k], pb[3 * k + 1], pb[3 * k + 2], s_ab, lut.Lcells, iL[k], ia[k], ib[k]);
-            const size_t q = o + (size_t)xu * 4;
+            for (int k = 0; k < 4; ++k) {
+                if (k + 2 < 4) r[k + 2] = lut_issue(pb[3 * (k + 2)], pb[3 * (k + 2) + 1], pb[3 * (k + 2) + 2], s_ab, lut.Lcells);
+                __builtin_amdgcn_sched_barrier(0);
+                lut_finish(r[k], iL[k], ia[k], ib[k]);
+            }
             if (LFLOAT) {
                 float* d = Lfp + q;
 #pragma unroll
@@ -64,8 +83,11 @@ __global__ __launch_bounds__(LC_THREADS) void k_lab_planes(const uint8_t* __rest
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) __builtin_nontemporal_store((uint32_t)ia[k] | ((uint32_t)ib[k] << 16), iabp + q + k);
-        } else {
-            const uint8_t* px = p + (size_t)xu * 3;
+        }
+    } else {
+        for (; u < uend; advance()) {
+            const uint8_t* px = in + (size_t)f * in_sstride + (size_t)y * in_stride + (size_t)xu * 3;
+            const size_t o = ((size_t)f * h + y) * w;
             int iL, ia, ib;
             lut_lab_int(px[0], px[1], px[2], s_ab, lut.Lcells, iL, ia, ib);
             if (LFLOAT) Lfp[o + xu] = lut_L(iL); else iLp[o + xu] = (uint16_t)iL;
@@ -79,7 +101,7 @@ void lab_lut_planes(Ctx* c, const uint8_t* d_in, long in_stride, long in_sstride
                     uint32_t* iab, hipStream_t s) {
     const bool vec = w % 4 == 0 && in_stride % 4 == 0 && in_sstride % 4 == 0 && ((uintptr_t)d_in % 4) == 0;
     const long units = (long)(vec ? w / 4 : w) * h * nframes;
-    // one workgroup per CU (the table takes 144 KB of the CU's 160 KB); few units: fewer workgroups, >= 1024 units each
+    // one workgroup per CU (the table takes 148 KB of the CU's 160 KB); few units: fewer workgroups, >= 1024 units each
     long blocks = (units + LC_THREADS - 1) / LC_THREADS;
     if (blocks > c->num_cus) blocks = c->num_cus;
     if (blocks < 1) blocks = 1;
