@@ -26,11 +26,11 @@
 #include <cstring>
 #include <vector>
 
-#include "pyramid.h"
-
 #ifndef LVM_EXPERIMENTAL
-#define LVM_EXPERIMENTAL 0        // 1: also build the schedules that were measured slower and are kept for the next attempt (k_lap_final1)
+#define LVM_EXPERIMENTAL 0        // 1: also build the schedules that were measured slower and are kept for the next attempt (k_lap_final1, k_down01_lut_rows)
 #endif
+
+#include "pyramid.h"
 
 namespace lvm {
 
@@ -1248,6 +1248,8 @@ struct LaplaceState : ModeState {
     long up_rows_max_blocks = 1024;       // launches with fewer tiled workgroups than this use k_lap_up_rows (LVM_UP_ROWS_MAX_BLOCKS)
     bool d0_rows_on = true;               // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
     bool d0_fused = true;                 // table conversion fused into the first kernel on large launches (LVM_D0_FUSED=0: separate kernels)
+    bool d0_l2 = false;                   // ... with the second pyramid level inside (experimental build only: k_down01_lut_rows, LVM_D0_L2=1; measured not faster)
+    int d0_l2_rows = 0;                   // ... level-2 rows per strip (LVM_D0_L2_ROWS; 0 = chosen against wave-level quantisation)
     long d0_fused_waves = 0;              // ... = launches with at least this many strips (LVM_D0_FUSED_WAVES; 0 = one per resident wave)
     long d0_min_tasks = 4096;             // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
     long fin_groups = 0;                  // workgroups of the persistent last kernel (LVM_FIN_GROUPS; 0 = 1024)
@@ -1313,6 +1315,8 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     if (const char* e = std::getenv("LVM_PD_ROWS")) st->pd_rows = std::atoi(e);
     if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
     if (const char* e = std::getenv("LVM_D0_FUSED")) st->d0_fused = std::atoi(e) != 0;
+    if (const char* e = std::getenv("LVM_D0_L2")) st->d0_l2 = std::atoi(e) != 0;
+    if (const char* e = std::getenv("LVM_D0_L2_ROWS")) st->d0_l2_rows = std::atoi(e);
     if (const char* e = std::getenv("LVM_D0_FUSED_WAVES")) st->d0_fused_waves = std::atol(e);
     if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
     if (const char* e = std::getenv("LVM_LAP_SPLIT")) st->split_levels = std::atoi(e);
@@ -1411,6 +1415,28 @@ static bool lap_d0l_args(Ctx* c, LaplaceState* st, const FrameIO& io, const LapB
     return true;
 }
 
+#if LVM_EXPERIMENTAL
+// ... and of k_down01_lut_rows (the same launch with the second pyramid level inside): G_2 comes out of the first kernel, the level-1
+// pyrDown launch disappears.  Needs a level 2 of at least 2 rows and a level 1 of at least 3 (the REFLECT_101 copies of the bottom rows).
+static bool lap_d01l_args(Ctx* c, LaplaceState* st, const FrameIO& io, const LapBufs& B, D01LArgs* out) {
+    const int NS = c->nstreams * B.nt, levels = st->levels;
+    const LabPlanes lp = lap_planes(c, io, B);
+    if (!(st->d0_l2 && lp.iab && levels >= 2 && st->d0_fused && lap_vec4(io) && st->g[1].w % 2 == 0 && st->g[1].h >= 3 && st->g[2].h >= 2 &&
+          st->g[2].w == io.w / 4)) return false;
+    long tasks = 0;
+    const long waves = st->d0_fused_waves > 0 ? st->d0_fused_waves : (long)c->num_cus * (D0L_THREADS / 64);
+    const LevelGeom &g1 = st->g[1], &g2 = st->g[2];
+    int rows = down01_lut_rows_choice(g2.w, g2.h, NS, waves, &tasks);
+    if (st->d0_l2_rows > 0) { rows = st->d0_l2_rows; tasks = (long)((g2.w + D01L_OUT - 1) / D01L_OUT) * ((g2.h + rows - 1) / rows) * NS; }
+    if (tasks <= 0) return false;
+    const int sx = (g2.w + D01L_OUT - 1) / D01L_OUT, sy = (g2.h + rows - 1) / rows;
+    *out = D01LArgs{io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h, B.G[1], g1.w, g1.h, B.G[2], g2.w, g2.h, c->lab_lut, sx, sy, (int)tasks, rows,
+                    B.iL, B.iab};
+    return true;
+}
+
+#endif
+
 static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, const LapBufs& B, bool first, hipStream_t s) {
     const int C = io.channels, levels = st->levels;
     const int NS = c->nstreams * B.nt;        // stateless kernels: a frame of the batch is just one more stream
@@ -1420,7 +1446,13 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     const LabPlanes lp = lap_planes(c, io, B);
     // large launches: conversion and first pyramid kernel in one pass (k_down0_lut_rows); LVM_D0_FUSED=0 keeps them apart
     D0LArgs da{};
-    const bool fused = lap_d0l_args(c, st, io, B, &da);
+#if LVM_EXPERIMENTAL
+    D01LArgs da2{};
+    const bool fused2 = lap_d01l_args(c, st, io, B, &da2);
+#else
+    const bool fused2 = false;
+#endif
+    const bool fused = fused2 || lap_d0l_args(c, st, io, B, &da);
     if (lp.iab && !fused) lab_lut_planes(c, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h, NS, B.iL, nullptr, B.iab, s);
     if (levels < 2) return;
     float** G = B.G;
@@ -1431,6 +1463,12 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     long d0_tasks = 0;
     const int d0_rows = down0_rows_choice(g1.w, g1.h, NS, st->d0_min_tasks, &d0_tasks);
     const int fl = lab_flavour(c);
+#if LVM_EXPERIMENTAL
+    if (fused2) {
+        auto kdl = fl == FL_LUT_EXACT ? k_down01_lut_rows<FL_LUT_EXACT> : k_down01_lut_rows<FL_LUT_FAST>;
+        LVM_LAUNCH(c, "lap_down01_lut", kdl, dim3((unsigned)c->num_cus), dim3(D0L_THREADS), s, da2);
+    } else
+#endif
     if (fused) {
         auto kdl = fl == FL_LUT_EXACT ? k_down0_lut_rows<FL_LUT_EXACT> : k_down0_lut_rows<FL_LUT_FAST>;
         LVM_LAUNCH(c, "lap_down0_lut", kdl, dim3((unsigned)c->num_cus), dim3(D0L_THREADS), s, da);
@@ -1450,7 +1488,7 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     }
     const bool use_tail = st->tailT && B.nt == 1 && !B.no_tail && !lap_split_now(st, B, first);   // batched frames: every level gets many workgroups anyway
     const int down_end = use_tail ? st->tailT : levels;            // the tail builds G_{T+1..L} itself
-    int l = 1;
+    int l = fused2 ? 2 : 1;         // (k_down01_lut_rows has made G_2 already)
     while (l < down_end) {          // G_l -> next levels, three (or two) per launch when possible
         const int left = down_end - l;
         // (level 1 keeps the strips from half the size: a single 1080p stream per call, 1.55 M, was measured better with them)

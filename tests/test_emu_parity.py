@@ -318,6 +318,22 @@ def test_emu_fused_table_conversion_and_first_kernel(lvm, po, emu, w, h, levels,
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0 if exact else 1e-4, exact=exact)
 
 
+@pytest.mark.parametrize("w,h,levels,rows,ns,calls", [
+    (264, 90, 3, "3", 1, (1, 6, 4)),      # two strips across (66 level-2 columns), 8 strips down, h2 = 23 odd
+    (264, 91, 3, "5", 1, (1, 5)),         # odd frame height: h1 = 46, the last level-2 row takes its rows 2Y + 1, 2Y + 2 from the REFLECT_101 copies
+    (248, 66, 2, "24", 2, (1, 4, 3)),     # ONE strip per frame (top and bottom strip at once), two streams, level 2 is the residual
+    (480, 54, 4, "4", 1, (1, 7)),         # exactly two full strips across (120 = 2 x 60 level-2 columns): border lanes 2 and 61
+    (484, 38, 3, "0", 1, (1, 9)),         # a third strip with a single owned column; strip height from the chooser
+])
+def test_emu_first_kernel_with_the_second_level_inside(lvm, po, emu, w, h, levels, rows, ns, calls, monkeypatch):
+    """k_down01_lut_rows (experimental build, LVM_D0_L2=1): table conversion + G_1 + G_2 + integer planes in one pass: level-1
+    REFLECT_101 on level-1 values (border lanes, mirrored top window, window copies past h1), every strip height."""
+    monkeypatch.setenv("LVM_D0_FUSED_WAVES", "1")
+    monkeypatch.setenv("LVM_D0_L2", "1")
+    monkeypatch.setenv("LVM_D0_L2_ROWS", rows)
+    _frames_clip(lvm, po, emu, 0, w, h, levels, ns, calls)
+
+
 def test_emu_unfused_conversion_in_batches(lvm, po, emu, monkeypatch):
     """LVM_D0_FUSED=0: labconv.hip's conversion kernel + the plane-reading first kernels in temporal batches."""
     monkeypatch.setenv("LVM_D0_FUSED", "0")
