@@ -55,9 +55,11 @@ __device__ __forceinline__ uint32_t pack_u8x4(float v0, float v1, float v2, floa
 }
 
 // Whole-wave shifts by one lane (DPP wave_shr:1 / wave_shl:1 cross all 64 lanes on gfx950, tools/probe_isa.hip):
-// lane i receives lane i - 1's (shr) / lane i + 1's (shl) value; lane 0 / lane 63 receive 0.
-__device__ __forceinline__ float dpp_shr1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, false)); }
-__device__ __forceinline__ float dpp_shl1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false)); }
+// lane i receives lane i - 1's (shr) / lane i + 1's (shl) value; lane 0 / lane 63 receive 0.  bound_ctrl = 1 ("out-of-range source
+// lanes read 0"): without it the instruction KEEPS the destination for those lanes, so the compiler has to write the 0 first -- one
+// v_mov_b32 in front of every DPP move, 520 of the 4435 vector instructions of k_rz_blur_strips until round 4.
+__device__ __forceinline__ float dpp_shr1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true)); }
+__device__ __forceinline__ float dpp_shl1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true)); }
 
 // ---- XCD-aware workgroup order ---------------------------------------------------------------------------------------
 // MI355X has 8 XCDs with private 4 MB L2s and places workgroup b of a launch on XCD b % 8 (observed, not contractual --

@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_rz_blur_strips(BlurStripArgs aa)
     const char* pband = reinterpret_cast<const char*>(a.band + pl);
     const int y0 = ty * a.rows, yend = y0 + a.rows < h ? y0 + a.rows : h;
     const int nin = yend - y0 + 12;                                    // input rows y0 - 6 .. yend + 5
-    float H[3][13][2];
+    lvm_f2 H[3][13];                                                   // (column c0, column c0 + 1) per slot: every filter step below is ONE packed operation
     // the lane's raw values of one input row (two columns of amp / c / s); fetched one row AHEAD of their use, so that a
     // wave has a row of loads in flight while it filters the previous one
     // ... plus the two columns of band row y0 - 10 + i: the amplify step's Riesz pair (5-tap horizontal / vertical filters of
@@ -1099,19 +1099,27 @@ __global__ __launch_bounds__(BS_THREADS) void k_rz_blur_strips(BlurStripArgs aa)
         }
         return r;
     };
-    float bw[5][2] = {};                                               // band rows y - 2 .. y + 2 of the output row being completed
-    // row-filtered pair of one plane from the lane's two values
-    auto hpass = [&](const float v0, const float v1, float (&out)[2]) __attribute__((always_inline)) {
-        const float l1a = dpp_shr1(v0), l1b = dpp_shr1(v1), l2a = dpp_shr1(l1a), l2b = dpp_shr1(l1b), l3a = dpp_shr1(l2a), l3b = dpp_shr1(l2b);
-        const float r1a = dpp_shl1(v0), r1b = dpp_shl1(v1), r2a = dpp_shl1(r1a), r2b = dpp_shl1(r1b), r3a = dpp_shl1(r2a), r3b = dpp_shl1(r2b);
-        const float S[14] = {l3a, l3b, l2a, l2b, l1a, l1b, v0, v1, r1a, r1b, r2a, r2b, r3a, r3b};     // columns c0 - 6 .. c0 + 7
+    lvm_f2 bw[5] = {};                                                 // band rows y - 2 .. y + 2 of the output row being completed
+    // Row-filtered pair of one plane from the lane's two values.  Round 4: the kernel is bound by vector issue (2.9e8 wave instructions
+    // per 32 frames, profiles/r04), and a lane's TWO columns are a natural float pair: out = sum_j g[j] * (S[j], S[j + 1]) is 13 packed
+    // fma (v_pk_fma_f32, full rate on gfx950) instead of 26 scalar ones.  The pairs with even j are the lanes' own pairs as they arrive
+    // over DPP, those with odd j are re-paired neighbours (v_pk_mov_b32).  Each element still receives its taps left to right: same bits.
+    auto hpass = [&](const float v0, const float v1) __attribute__((always_inline)) {
+        // A[k] = columns (c0 - 6 + 2 k, c0 - 5 + 2 k): the pairs of the lanes 3 - k to the left ... 3 to the right, written by the DPP moves
+        // straight into register pairs; B[k] = (A[k].hi, A[k + 1].lo) = the pairs that start at an odd column
+        lvm_f2 A[7];
+        A[3] = f2_set(v0, v1);
+        A[2][0] = dpp_shr1(A[3][0]); A[2][1] = dpp_shr1(A[3][1]); A[1][0] = dpp_shr1(A[2][0]); A[1][1] = dpp_shr1(A[2][1]);
+        A[0][0] = dpp_shr1(A[1][0]); A[0][1] = dpp_shr1(A[1][1]);
+        A[4][0] = dpp_shl1(A[3][0]); A[4][1] = dpp_shl1(A[3][1]); A[5][0] = dpp_shl1(A[4][0]); A[5][1] = dpp_shl1(A[4][1]);
+        A[6][0] = dpp_shl1(A[5][0]); A[6][1] = dpp_shl1(A[5][1]);
+        lvm_f2 acc = f2_all(aa.g[0]) * A[0];
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            float acc = aa.g[0] * S[m];
-#pragma unroll
-            for (int j = 1; j < 13; ++j) acc = __builtin_fmaf(aa.g[j], S[m + j], acc);
-            out[m] = acc;
+        for (int k = 0; k < 6; ++k) {
+            acc = f2_fma(f2_all(aa.g[2 * k + 1]), f2_set(A[k][1], A[k + 1][0]), acc);
+            acc = f2_fma(f2_all(aa.g[2 * k + 2]), A[k + 1], acc);
         }
+        return acc;
     };
     Raw6 nxt = fetch(0);
     for (int i0 = 0; i0 < nin; i0 += 13) {
@@ -1124,41 +1132,37 @@ __global__ __launch_bounds__(BS_THREADS) void k_rz_blur_strips(BlurStripArgs aa)
             const int y = y0 + i - 12;                                 // window: row y - 6 + k sits in slot (ph + 1 + k) % 13
             // band window: rows y - 2 .. y + 2 (the row fetched for this step is y + 2)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { bw[k][0] = bw[k + 1][0]; bw[k][1] = bw[k + 1][1]; }
-            bw[4][0] = cur.v[6]; bw[4][1] = cur.v[7];
-            hpass(cur.v[0], cur.v[1], H[0][ph]); hpass(cur.v[2], cur.v[3], H[1][ph]); hpass(cur.v[4], cur.v[5], H[2][ph]);
+            for (int k = 0; k < 4; ++k) bw[k] = bw[k + 1];
+            bw[4] = f2_set(cur.v[6], cur.v[7]);
+            H[0][ph] = hpass(cur.v[0], cur.v[1]); H[1][ph] = hpass(cur.v[2], cur.v[3]); H[2][ph] = hpass(cur.v[4], cur.v[5]);
             if (i >= 12) {
-                float v[3][2];
+                lvm_f2 v[3];
 #pragma unroll
-                for (int f = 0; f < 3; ++f)
+                for (int f = 0; f < 3; ++f) {
+                    lvm_f2 acc = f2_all(aa.g[6]) * H[f][(ph + 7) % 13];
 #pragma unroll
-                    for (int m = 0; m < 2; ++m) {
-                        float acc = aa.g[6] * H[f][(ph + 7) % 13][m];
-#pragma unroll
-                        for (int j = 1; j <= 6; ++j) acc = __builtin_fmaf(aa.g[6 + j], H[f][(ph + 7 + j) % 13][m] + H[f][(ph + 7 - j + 13) % 13][m], acc);
-                        v[f][m] = acc;
-                    }
+                    for (int j = 1; j <= 6; ++j) acc = f2_fma(f2_all(aa.g[6 + j]), H[f][(ph + 7 + j) % 13] + H[f][(ph + 7 - j + 13) % 13], acc);
+                    v[f] = acc;
+                }
                 // Riesz pair of the band at the lane's two columns: [-0.2 -0.48 0 0.48 0.2] along the row (neighbour columns from
                 // the adjacent lanes) and along the column (the window); every lane takes part in the DPP exchange
-                float2 bd, q1, q2;
+                lvm_f2 bd, q1, q2;
                 {
                     const float c0v = bw[2][0], c1v = bw[2][1];
                     const float lm2 = dpp_shr1(c0v), lm1 = dpp_shr1(c1v), rp2 = dpp_shl1(c0v), rp3 = dpp_shl1(c1v);   // columns c0-2, c0-1, c0+2, c0+3
-                    bd.x = c0v; bd.y = c1v;
-                    q1.x = __builtin_fmaf(0.2f, rp2, __builtin_fmaf(0.48f, c1v, __builtin_fmaf(-0.48f, lm1, __builtin_fmaf(-0.2f, lm2, 0.f))));
-                    q1.y = __builtin_fmaf(0.2f, rp3, __builtin_fmaf(0.48f, rp2, __builtin_fmaf(-0.48f, c0v, __builtin_fmaf(-0.2f, lm1, 0.f))));
-                    q2.x = __builtin_fmaf(0.2f, bw[4][0], __builtin_fmaf(0.48f, bw[3][0], __builtin_fmaf(-0.48f, bw[1][0], __builtin_fmaf(-0.2f, bw[0][0], 0.f))));
-                    q2.y = __builtin_fmaf(0.2f, bw[4][1], __builtin_fmaf(0.48f, bw[3][1], __builtin_fmaf(-0.48f, bw[1][1], __builtin_fmaf(-0.2f, bw[0][1], 0.f))));
+                    bd = bw[2];
+                    q1 = f2_fma(f2_all(0.2f), f2_set(rp2, rp3), f2_fma(f2_all(0.48f), f2_set(c1v, rp2), f2_fma(f2_all(-0.48f), f2_set(lm1, c0v), f2_fma(f2_all(-0.2f), f2_set(lm2, lm1), f2_all(0.f)))));
+                    q2 = f2_fma(f2_all(0.2f), bw[4], f2_fma(f2_all(0.48f), bw[3], f2_fma(f2_all(-0.48f), bw[1], f2_fma(f2_all(-0.2f), bw[0], f2_all(0.f)))));
                 }
                 if (owner) {
                     const size_t idx = pl + (size_t)y * w + c0;
                     float2 o;
                     if (EXACT) {      // the libm sine / cosine of the exact flavour is large: out of line, or the 13-phase loop does not unroll
-                        o.x = rz_amplify_exact_call(v[0][0], v[1][0], v[2][0], q1.x, q2.x, bd.x, aa.alpha, aa.thr);
-                        o.y = rz_amplify_exact_call(v[0][1], v[1][1], v[2][1], q1.y, q2.y, bd.y, aa.alpha, aa.thr);
+                        o.x = rz_amplify_exact_call(v[0][0], v[1][0], v[2][0], q1[0], q2[0], bd[0], aa.alpha, aa.thr);
+                        o.y = rz_amplify_exact_call(v[0][1], v[1][1], v[2][1], q1[1], q2[1], bd[1], aa.alpha, aa.thr);
                     } else {
-                        o.x = rz_amplify<false>(v[0][0], v[1][0], v[2][0], q1.x, q2.x, bd.x, aa.alpha, aa.thr);
-                        o.y = rz_amplify<false>(v[0][1], v[1][1], v[2][1], q1.y, q2.y, bd.y, aa.alpha, aa.thr);
+                        o.x = rz_amplify<false>(v[0][0], v[1][0], v[2][0], q1[0], q2[0], bd[0], aa.alpha, aa.thr);
+                        o.y = rz_amplify<false>(v[0][1], v[1][1], v[2][1], q1[1], q2[1], bd[1], aa.alpha, aa.thr);
                     }
                     *reinterpret_cast<float2*>(a.bandA + idx) = o;
                 }
