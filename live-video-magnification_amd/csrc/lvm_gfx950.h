@@ -29,14 +29,49 @@ __device__ __forceinline__ B96 buf_ld_b96(const BufRsrc& r, uint32_t voff, uint3
     const lvm_u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, (int)soff, 0);
     return B96{v.x, v.y, v.z};
 }
+typedef float lvm_f2 __attribute__((vector_size(8)));
+typedef float lvm_f32x4 __attribute__((ext_vector_type(4)));
+typedef float lvm_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int lvm_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int lvm_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 buf_ld_f32x4(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    const lvm_f32x4 v = __builtin_bit_cast(lvm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ lvm_f2 buf_ld_f32x2(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(lvm_f2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+// Stores of MORE than 64 bits put the whole offset into the vector register and leave the scalar-offset field at zero.  The store reads
+// its data registers some cycles after it issues; the compiler's hazard recogniser pads a following write to those registers with
+// wait states ONLY for stores without a register in the soffset field (GCNHazardRecognizer: "this hazard only exists if the
+// instruction is not using a register in the soffset field") -- and on gfx950 the hazard is there with an SGPR soffset too: measured in
+// round 4, `buffer_store_dwordx3 v[4:6], v64, s[40:43], s14 offen` directly followed by `v_mov_b64 v[6:7], ...` stored the NEW v6 for
+// lanes 12-15 of every row of 16 lanes (the last ones the store reads), a few hundred pixels of a 4K frame, not reproducible in the
+// emulation build.  One v_add per store buys the compiler's own padding.
+__device__ __forceinline__ void buf_st_f32x4(float a, float b, float c, float d, const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    lvm_f32x4 q; q.x = a; q.y = b; q.z = c; q.w = d;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lvm_u32x4, q), r, (int)(voff + soff), 0, 0);
+}
+__device__ __forceinline__ void buf_st_f32x2(float a, float b, const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    lvm_f32x2 q; q.x = a; q.y = b;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(lvm_u32x2, q), r, (int)voff, (int)soff, 0);
+}
 __device__ __forceinline__ void buf_st_b96(const B96& v, const BufRsrc& r, uint32_t voff, uint32_t soff) {
     lvm_u32x3 q; q.x = v.a; q.y = v.b; q.z = v.c;
-    __builtin_amdgcn_raw_buffer_store_b96(q, r, (int)voff, (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b96(q, r, (int)(voff + soff), 0, 0);      // (offset in the vector register: see buf_st_f32x4)
 }
 
 // ---- packed FP32: two floats in a register pair, one v_pk_{add,mul,fma}_f32 per operation (full rate on gfx950) ----
-typedef float lvm_f2 __attribute__((vector_size(8)));
 __device__ __forceinline__ lvm_f2 f2_fma(lvm_f2 a, lvm_f2 b, lvm_f2 c) { return __builtin_elementwise_fma(a, b, c); }
+// A zero-instruction fence on VALUES: the operands pass through an empty asm statement, so everything that produces them is
+// emitted before this point and everything that consumes them after it.  (Instruction selection orders a basic block by data
+// dependence, not by source order: without it the long fma chains of k_rz_split_rows are emitted next to the store that needs them,
+// with the operand rows of up to nine steps still live.)
+__device__ __forceinline__ void lvm_pin(lvm_f2& a, lvm_f2& b) { asm volatile("" : "+v"(a), "+v"(b)); }
+// Memory instructions stay on their side of this point (a compiler-level fence, no instruction): a prefetching load is not sunk
+// towards its first use.
+__device__ __forceinline__ void lvm_issue_fence() { asm volatile("" ::: "memory"); }
+__device__ __forceinline__ void lvm_pin(float& a, float& b) { asm volatile("" : "+v"(a), "+v"(b)); }
 
 // ---- forward Lab table (lab_lut.h) ----
 typedef unsigned short lut_u2 __attribute__((ext_vector_type(2)));

@@ -295,13 +295,19 @@ __global__ __launch_bounds__(256) void k_rz_split2(const float* __restrict__ oct
 // partial output rows live in registers (9 x 4 accumulators for the high-pass, 9 x 2 for the low-pass at even
 // pixels); the row that just received kernel row 8 is complete, is stored and its slot cleared for the row nine
 // further down.  Every output still receives its 81 taps in row-major order (kernel rows arrive top to bottom, taps
-// left to right within a row): the same fma chain as conv9x4, bit for bit.  The loop is unrolled over the nine slot
-// phases so that every accumulator index is a compile-time constant.
+// left to right within a row): the same fma chain as conv9x4, bit for bit.  The loop is unrolled over 18 steps (nine slot
+// phases x the two row parities) so that every accumulator index and the rows that carry a low-pass output are compile-time
+// constants; no control flow between the steps of a group of nine.
 // REFLECT_101: rows by reflecting the row index of the load; columns at the image edge from the lane's own and its
 // inner neighbour's values (columns -4..-1 are columns 4, 3, 2, 1; columns w..w+3 are w-2, w-3, w-4, w-5).
 constexpr int SR_THREADS = 256, SR_OWN = 62;
+// The high-pass accumulators of a slot are two register pairs -- outputs (0, 1) and (2, 3) -- and a tap is ONE v_pk_fma_f32 per
+// pair: tap j of outputs (m, m + 1) multiplies (v[j + m], v[j + m + 1]), which is the pair V[(j + m) / 2] of the row for an even
+// j + m and W[(j + m - 1) / 2] -- the same row shifted by one column -- for an odd one (VGPR pairs are even-aligned on gfx950, so
+// the shifted copy costs five register pairs; 154 packed + 81 scalar instead of 389 scalar fmas per lane and input row).
+// Each half of a packed fma is an IEEE fma: the chain per output is the one of conv9x4, bit for bit.
 template <int PHASE>
-__device__ __forceinline__ void split_row_taps(const float (&v)[12], float (&hp)[9][4], float (&lp)[9][2], bool even_row) {
+__device__ __forceinline__ void hp_row_taps(const lvm_f2 (&V)[6], const lvm_f2 (&W)[5], lvm_f2 (&hp)[9][2]) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const int slot = (PHASE + 9 - i) % 9;
@@ -309,12 +315,18 @@ __device__ __forceinline__ void split_row_taps(const float (&v)[12], float (&hp)
         for (int j = 0; j < 9; ++j) {
             const float kv = kHp9[i * 9 + j];
             if (kv != 0.f) {
-                hp[slot][0] = __builtin_fmaf(kv, v[j], hp[slot][0]); hp[slot][1] = __builtin_fmaf(kv, v[j + 1], hp[slot][1]);
-                hp[slot][2] = __builtin_fmaf(kv, v[j + 2], hp[slot][2]); hp[slot][3] = __builtin_fmaf(kv, v[j + 3], hp[slot][3]);
+                const lvm_f2 k2 = f2_all(kv);
+                hp[slot][0] = f2_fma(k2, (j & 1) ? W[(j - 1) / 2] : V[j / 2], hp[slot][0]);
+                hp[slot][1] = f2_fma(k2, (j & 1) ? W[(j + 1) / 2] : V[j / 2 + 1], hp[slot][1]);
             }
         }
     }
+}
+template <int PHASE, bool even_row>
+__device__ __forceinline__ void split_row_taps(const lvm_f2 (&V)[6], const lvm_f2 (&W)[5], lvm_f2 (&hp)[9][2], float (&lp)[9][2]) {
+    hp_row_taps<PHASE>(V, W, hp);
     // low-pass only at even output rows: kernel rows of this input row's parity
+    auto v = [&](int j) __attribute__((always_inline)) { return V[j >> 1][j & 1]; };
     if (even_row) {
 #pragma unroll
         for (int i = 0; i < 9; i += 2) {
@@ -322,7 +334,7 @@ __device__ __forceinline__ void split_row_taps(const float (&v)[12], float (&hp)
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
                 const float kv = kLp9[i * 9 + j] * 2.0f;
-                if (kv != 0.f) { lp[slot][0] = __builtin_fmaf(kv, v[j], lp[slot][0]); lp[slot][1] = __builtin_fmaf(kv, v[j + 2], lp[slot][1]); }
+                if (kv != 0.f) { lp[slot][0] = __builtin_fmaf(kv, v(j), lp[slot][0]); lp[slot][1] = __builtin_fmaf(kv, v(j + 2), lp[slot][1]); }
             }
         }
     } else {
@@ -332,24 +344,24 @@ __device__ __forceinline__ void split_row_taps(const float (&v)[12], float (&hp)
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
                 const float kv = kLp9[i * 9 + j] * 2.0f;
-                if (kv != 0.f) { lp[slot][0] = __builtin_fmaf(kv, v[j], lp[slot][0]); lp[slot][1] = __builtin_fmaf(kv, v[j + 2], lp[slot][1]); }
+                if (kv != 0.f) { lp[slot][0] = __builtin_fmaf(kv, v(j), lp[slot][0]); lp[slot][1] = __builtin_fmaf(kv, v(j + 2), lp[slot][1]); }
             }
         }
     }
 }
 // columns c-4 .. c+7 of one row from the lane's own four and its neighbours' (first / last: the lane owns the image's
-// first / last column group)
-__device__ __forceinline__ void row12(const float4 v, bool first, bool last, float (&o)[12]) {
+// first / last column group), as the pairs V[k] = (column c-4+2k, c-3+2k) and W[k] = (c-3+2k, c-2+2k)
+__device__ __forceinline__ void row12(const float4 v, bool first, bool last, lvm_f2 (&V)[6], lvm_f2 (&W)[5]) {
     float4 L, R;
     L.x = dpp_shr1(v.x); L.y = dpp_shr1(v.y); L.z = dpp_shr1(v.z); L.w = dpp_shr1(v.w);
     R.x = dpp_shl1(v.x); R.y = dpp_shl1(v.y); R.z = dpp_shl1(v.z); R.w = dpp_shl1(v.w);
     const float4 Lf = make_float4(R.x, v.w, v.z, v.y), Rl = make_float4(v.z, v.y, v.x, L.w);
     L.x = sel(first, Lf.x, L.x); L.y = sel(first, Lf.y, L.y); L.z = sel(first, Lf.z, L.z); L.w = sel(first, Lf.w, L.w);
     R.x = sel(last, Rl.x, R.x); R.y = sel(last, Rl.y, R.y); R.z = sel(last, Rl.z, R.z); R.w = sel(last, Rl.w, R.w);
-    o[0] = L.x; o[1] = L.y; o[2] = L.z; o[3] = L.w; o[4] = v.x; o[5] = v.y; o[6] = v.z; o[7] = v.w;
-    o[8] = R.x; o[9] = R.y; o[10] = R.z; o[11] = R.w;
+    V[0] = f2_set(L.x, L.y); V[1] = f2_set(L.z, L.w); V[2] = f2_set(v.x, v.y); V[3] = f2_set(v.z, v.w); V[4] = f2_set(R.x, R.y); V[5] = f2_set(R.z, R.w);
+    W[0] = f2_set(L.y, L.z); W[1] = f2_set(L.w, v.x); W[2] = f2_set(v.y, v.z); W[3] = f2_set(v.w, R.x); W[4] = f2_set(R.y, R.z);
 }
-__global__ __launch_bounds__(SR_THREADS) void k_rz_split_rows(const float* __restrict__ oct, int w, int h, float* __restrict__ band,
+__global__ __launch_bounds__(SR_THREADS, 4) void k_rz_split_rows(const float* __restrict__ oct, int w, int h, float* __restrict__ band,
                                                                   float* __restrict__ next, int nw, int nh, int strips_x, int strips_y,
                                                                   int ntasks, int rows) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -363,38 +375,63 @@ __global__ __launch_bounds__(SR_THREADS) void k_rz_split_rows(const float* __res
     const int gl = g < 0 ? 0 : (g > G - 1 ? G - 1 : g);
     const bool owner = lane >= 1 && lane <= SR_OWN && g >= 0 && g < G;
     const bool first = g == 0, last = g == G - 1;
-    const float* src = oct + (size_t)z * w * h + 4 * gl;
-    float* bp = band + (size_t)z * w * h + 4 * gl;
-    float* np = next + (size_t)z * nw * nh + 2 * gl;
+    // raw buffer addressing: one resource per plane (wave-uniform base), the lane's column group as a 32-bit byte offset, the row as
+    // a scalar byte offset.  Stores are UNCONDITIONAL instructions: a lane that owns nothing (and every lane while the rows above
+    // the strip complete) stores at an offset outside the resource, which the hardware drops.  (With the stores inside a branch the
+    // compiler sinks the whole fma chain of the completed row into that branch and keeps nine rows of operands alive for it.)
+    const uint32_t pbytes = (uint32_t)w * (uint32_t)h * 4u, nbytes = (uint32_t)nw * (uint32_t)nh * 4u;
+    const BufRsrc rs = buf_rsrc(oct + (size_t)z * w * h, pbytes);
+    const BufRsrc rb = buf_rsrc(band + (size_t)z * w * h, pbytes);
+    const BufRsrc rn = buf_rsrc(next + (size_t)z * nw * nh, nbytes);
+    constexpr uint32_t kDrop = 0x80000000u;                         // + any row offset (< 2^31) stays outside every plane (< 2^31 bytes)
+    const uint32_t lsrc = 16u * (uint32_t)gl, lband = owner ? 16u * (uint32_t)gl : kDrop, lnext = owner ? 8u * (uint32_t)gl : kDrop;
     const int y0 = ty * rows;                                       // rows is even: the strip starts on an even row
     const int yend = y0 + rows < h ? y0 + rows : h;
     const int nq = yend - y0 + 8;                                   // input rows y0 - 4 .. yend + 3
-    float hp[9][4], lp[9][2];
+    lvm_f2 hp[9][2];
+    float lp[9][2];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { hp[k][0] = hp[k][1] = hp[k][2] = hp[k][3] = 0.f; lp[k][0] = lp[k][1] = 0.f; }
-    float4 nxt = *reinterpret_cast<const float4*>(src + (size_t)reflect101(y0 - 4, h) * w);
+    for (int k = 0; k < 9; ++k) { hp[k][0] = hp[k][1] = f2_all(0.f); lp[k][0] = lp[k][1] = 0.f; }
+    // REFLECT_101 row index of the NEXT load, advanced by selects: no control flow between the steps (a branch there -- reflect101's
+    // loop -- splits the steps into basic blocks, and the compiler then sinks every fma chain down to the block of its store, keeping
+    // the operand rows of nine steps alive: 1 KB of scratch per lane in the ISA)
+    int ry = reflect101(y0 - 4, h), rdir = reflect101(y0 - 3, h) - ry;    // rdir = +1 / -1 (0: a one-row plane)
+    auto advance_row = [&]() __attribute__((always_inline)) {       // ry <- the reflected index of the row after it
+        const int t = ry + rdir;
+        const bool lo = t < 0, hi = t > h - 1;
+        ry = lo ? (h > 1 ? 1 : 0) : (hi ? (h > 1 ? h - 2 : 0) : t);
+        rdir = lo ? 1 : (hi ? -1 : rdir);
+    };
+    float4 nxt = buf_ld_f32x4(rs, lsrc, (uint32_t)ry * (uint32_t)w * 4u);
     int q = 0;
-#define LVM_SPLIT_STEP(P)                                                                                          \
-    if (q < nq) {                                                                                                   \
+#define LVM_SPLIT_STEP(P18)                                                                                        \
+    {                                                                                                               \
+        if ((P18) % 9 == 0 && q >= nq) break;                       /* two exits per 18 steps: up to 8 extra rows (loads reflected, stores dropped) */ \
+        constexpr int P = (P18) % 9;                                /* q = P18 (mod 18): slot phase and row parity are compile-time */ \
+        constexpr bool EVEN = ((P18) & 1) == 0;                     /* input row y0 - 4 + q and output row y0 - 8 + q, y0 even */ \
         const float4 cur = nxt;                                                                                     \
-        if (q + 1 < nq) nxt = *reinterpret_cast<const float4*>(src + (size_t)reflect101(y0 - 3 + q, h) * w);       \
-        float v[12];                                                                                                \
-        row12(cur, first, last, v);                                                                                 \
-        split_row_taps<P>(v, hp, lp, (q & 1) == 0);                 /* input row y0 - 4 + q, y0 even */             \
-        constexpr int E = (P + 1) % 9;                              /* output row y0 - 8 + q is complete */         \
-        if (q >= 8) {                                               /* (rows above the strip: cleared, not stored) */ \
-            const int o = y0 - 8 + q;                                                                               \
-            if (owner) {                                                                                            \
-                *reinterpret_cast<float4*>(bp + (size_t)o * w) = make_float4(hp[E][0], hp[E][1], hp[E][2], hp[E][3]);   /* RieszPyramid.cpp:227 */ \
-                if ((o & 1) == 0) *reinterpret_cast<float2*>(np + (size_t)(o >> 1) * nw) = make_float2(lp[E][0], lp[E][1]);   /* :232-234, subsample :254-278 */ \
-            }                                                                                                       \
-        }                                                                                                           \
-        hp[E][0] = hp[E][1] = hp[E][2] = hp[E][3] = 0.f; lp[E][0] = lp[E][1] = 0.f;                                 \
+        advance_row();                                              /* row y0 - 3 + q, reflected */                 \
+        nxt = buf_ld_f32x4(rs, lsrc, (uint32_t)ry * (uint32_t)w * 4u);                                              \
+        lvm_issue_fence();                                          /* the load is ISSUED here, a whole step ahead of its use */ \
+        lvm_f2 V[6], W[5];                                                                                          \
+        row12(cur, first, last, V, W);                                                                              \
+        split_row_taps<P, EVEN>(V, W, hp, lp);                                                                      \
+        constexpr int E = (P + 1) % 9;                              /* output row o = y0 - 8 + q is complete */     \
+        const bool inside = q >= 8 && q < nq;                       /* (rows above and below the strip: dropped) */ \
+        const uint32_t o = inside ? (uint32_t)(y0 - 8 + q) : 0u;                                                    \
+        buf_st_f32x4(hp[E][0][0], hp[E][0][1], hp[E][1][0], hp[E][1][1], rb, inside ? lband : kDrop, o * (uint32_t)w * 4u);   /* RieszPyramid.cpp:227 */ \
+        if (EVEN) buf_st_f32x2(lp[E][0], lp[E][1], rn, inside ? lnext : kDrop, (o >> 1) * (uint32_t)nw * 4u);   /* :232-234, subsample :254-278 */ \
+        hp[E][0] = hp[E][1] = f2_all(0.f); lp[E][0] = lp[E][1] = 0.f;                                               \
         ++q;                                                                                                        \
+        _Pragma("unroll") for (int d = 1; d < 9; ++d) {             /* one row at a time: every partial sum exists HERE (lvm_pin) */ \
+            lvm_pin(hp[(E + d) % 9][0], hp[(E + d) % 9][1]);                                                        \
+            if ((((P18) + d) & 1) == 0) lvm_pin(lp[(E + d) % 9][0], lp[(E + d) % 9][1]);   /* slots of even output rows */ \
+        }                                                                                                           \
     }
-    while (q < nq) {
-        LVM_SPLIT_STEP(0) LVM_SPLIT_STEP(1) LVM_SPLIT_STEP(2) LVM_SPLIT_STEP(3) LVM_SPLIT_STEP(4)
-        LVM_SPLIT_STEP(5) LVM_SPLIT_STEP(6) LVM_SPLIT_STEP(7) LVM_SPLIT_STEP(8)
+    for (;;) {
+        LVM_SPLIT_STEP(0) LVM_SPLIT_STEP(1) LVM_SPLIT_STEP(2) LVM_SPLIT_STEP(3) LVM_SPLIT_STEP(4) LVM_SPLIT_STEP(5)
+        LVM_SPLIT_STEP(6) LVM_SPLIT_STEP(7) LVM_SPLIT_STEP(8) LVM_SPLIT_STEP(9) LVM_SPLIT_STEP(10) LVM_SPLIT_STEP(11)
+        LVM_SPLIT_STEP(12) LVM_SPLIT_STEP(13) LVM_SPLIT_STEP(14) LVM_SPLIT_STEP(15) LVM_SPLIT_STEP(16) LVM_SPLIT_STEP(17)
     }
 #undef LVM_SPLIT_STEP
 }
@@ -1272,6 +1309,176 @@ __global__ __launch_bounds__(256) void k_rz_final(const uint8_t* __restrict__ in
     }
 }
 
+// ---- collapse and output as WAVE STRIPS (planes with even width and height, width a multiple of 4) ---------------------------
+// The tiled kernels above read every fma operand from LDS (k_rz_final: 2.1 TB/s, neither pipe saturated).  Here a wave walks down
+// the rows of bandA_l exactly as k_rz_split_rows walks down the octave: lane i holds columns 4g .. 4g+3, the 9x9 high-pass is the
+// same nine-slot scatter (packed pairs (0, 1), (2, 3)).  The zero-injected image only has samples at even rows and columns, so at
+// every EVEN input row the lane also takes the coarse row res_{l+1}[y / 2] -- its own two values 2g, 2g+1 plus two from each
+// neighbour -- and scatters kernel row i of 2 lp9 into slot y + 4 - i: output m (column parity m & 1) meets the taps j = m (mod 2),
+// i.e. the coarse columns 2g-2 .. 2g+2 (m = 0), 2g-1 .. 2g+2 (1), 2g-1 .. 2g+3 (2), 2g .. 2g+3 (3).  Outputs (0, 2) and (1, 3)
+// share their weights and read adjacent coarse values, so the low-pass accumulators are the pairs (0, 2), (1, 3).  Every output
+// receives the taps of collapse_px4 in the same order: the visited taps of 2 lp9 row-major, the taps of hp9 row-major, lp + hp.
+// REFLECT_101 of the zero-injected image: rows through the reflected row index (even planes: parity is kept); columns -4, -2 are
+// the coarse columns 2, 1 and columns w, w + 2 the coarse columns nw - 1, nw - 2.
+// FINAL: the completed row of L' goes through Lab2BGR with (a, b) of the frame's integer plane and leaves as u8 (MagnifyCore.hpp:272-277).
+constexpr int CS_THREADS = 256;
+struct CollapseStripArgs {
+    const float* bandA; const float* resn; float* res;          // [z][h][w], [z][nh][nw], [z][h][w] (res: !FINAL)
+    int w, h, nw, nh, strips_x, strips_y, ntasks, rows;
+    const uint32_t* iab; uint8_t* out; long out_stride, out_sstride; float* dbg; LabCoef lab;   // FINAL
+};
+// coarse columns 2g-2 .. 2g+3 as the pairs A[k] = (c[2k], c[2k+1]), B[k] = (c[2k+1], c[2k+2])
+__device__ __forceinline__ void coarse6(const float2 v, bool first, bool last, lvm_f2 (&A)[3], lvm_f2 (&B)[2]) {
+    const float Lx = dpp_shr1(v.x), Ly = dpp_shr1(v.y), Rx = dpp_shl1(v.x), Ry = dpp_shl1(v.y);
+    const float c0 = sel(first, Rx, Lx), c1 = sel(first, v.y, Ly), c4 = sel(last, v.y, Rx), c5 = sel(last, v.x, Ry);
+    A[0] = f2_set(c0, c1); A[1] = f2_set(v.x, v.y); A[2] = f2_set(c4, c5);
+    B[0] = f2_set(c1, v.x); B[1] = f2_set(v.y, c4);
+}
+template <int PHASE>
+__device__ __forceinline__ void collapse_lp_taps(const lvm_f2 (&A)[3], const lvm_f2 (&B)[2], lvm_f2 (&lp)[9][2]) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int slot = (PHASE + 9 - i) % 9;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const lvm_f2 k2 = f2_all(kLp9[i * 9 + j] * 2.0f);
+            const int t = (j & 1) ? (j + 1) / 2 : j / 2;                 // first coarse column of the pair
+            const lvm_f2 c = (t & 1) ? B[(t - 1) / 2] : A[t / 2];
+            if ((j & 1) == 0) lp[slot][0] = f2_fma(k2, c, lp[slot][0]);   // outputs 0, 2
+            else lp[slot][1] = f2_fma(k2, c, lp[slot][1]);                // outputs 1, 3
+        }
+    }
+}
+// one completed row of L' (four pixels of a lane) -> Lab2BGR with the frame's (a, b) -> u8 (and the float frame when DBG)
+template <int FL, bool DBG>
+__device__ __forceinline__ void collapse_emit(float L0, float L1, float L2, float L3, const float4 iabq, const LabCoef& lab, const float* s_igt,
+                                              const BufRsrc& ro, uint32_t voff, uint32_t soff, const BufRsrc& rd, uint32_t dvoff, uint32_t dsoff) {
+    constexpr bool EXACT = fl_exact(FL);
+    const float Lc[4] = {L0, L1, L2, L3};
+    const uint32_t q[4] = {__float_as_uint(iabq.x), __float_as_uint(iabq.y), __float_as_uint(iabq.z), __float_as_uint(iabq.w)};
+    float o[4][3];
+    if (EXACT) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+            lab_to_bgr<true>(Lc[m], lut_ab((int)(q[m] & 0xffffu)), lut_ab((int)(q[m] >> 16)), lab.inv, s_igt, o[m][0], o[m][1], o[m][2]);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; m += 2) {
+            lvm_f2 o0, o1, o2;
+            lab_to_bgr_pair(f2_set(Lc[m], Lc[m + 1]), f2_set(lut_ab((int)(q[m] & 0xffffu)), lut_ab((int)(q[m + 1] & 0xffffu))),
+                            f2_set(lut_ab((int)(q[m] >> 16)), lut_ab((int)(q[m + 1] >> 16))), lab.inv1024, s_igt, o0, o1, o2);
+            o[m][0] = o0[0]; o[m][1] = o1[0]; o[m][2] = o2[0]; o[m + 1][0] = o0[1]; o[m + 1][1] = o1[1]; o[m + 1][2] = o2[1];
+        }
+    }
+    if (DBG) {
+        buf_st_f32x4(o[0][0], o[0][1], o[0][2], o[1][0], rd, dvoff, dsoff);
+        buf_st_f32x4(o[1][1], o[1][2], o[2][0], o[2][1], rd, dvoff, dsoff + 16u);
+        buf_st_f32x4(o[2][2], o[3][0], o[3][1], o[3][2], rd, dvoff, dsoff + 32u);
+    }
+    float t[4][3];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[m][k] = o[m][k] * 255.0f + lab.a255;
+    B96 v;
+    v.a = pack_u8x4(t[0][0], t[0][1], t[0][2], t[1][0]);
+    v.b = pack_u8x4(t[1][1], t[1][2], t[2][0], t[2][1]);
+    v.c = pack_u8x4(t[2][2], t[3][0], t[3][1], t[3][2]);
+    buf_st_b96(v, ro, voff, soff);
+}
+template <bool FINAL, int FL, bool DBG>
+__global__ __launch_bounds__(CS_THREADS, 3) void k_rz_collapse_strips(CollapseStripArgs a) {
+    constexpr bool EXACT = fl_exact(FL);
+    __shared__ __attribute__((aligned(16))) float s_igt[FINAL ? 4096 : 4];
+    if (FINAL) { load_invgamma(s_igt, a.lab.invgamma); __syncthreads(); }
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int task = blockIdx.x * (CS_THREADS / 64) + wave;
+    if (task >= a.ntasks) return;
+    const int w = a.w, h = a.h, nw = a.nw, nh = a.nh;
+    const int z = task / (a.strips_x * a.strips_y);
+    const int r = task - z * (a.strips_x * a.strips_y);
+    const int ty = r / a.strips_x, tx = r - ty * a.strips_x;
+    const int G = w >> 2;                                           // w % 4 == 0, G >= 2
+    const int g = tx * SR_OWN - 1 + lane;
+    const int gl = g < 0 ? 0 : (g > G - 1 ? G - 1 : g);
+    const bool owner = lane >= 1 && lane <= SR_OWN && g >= 0 && g < G;
+    const bool first = g == 0, last = g == G - 1;
+    constexpr uint32_t kDrop = 0x80000000u;
+    const uint32_t pbytes = (uint32_t)w * (uint32_t)h * 4u;
+    const BufRsrc rb = buf_rsrc(a.bandA + (size_t)z * w * h, pbytes);
+    const BufRsrc rc = buf_rsrc(a.resn + (size_t)z * nw * nh, (uint32_t)nw * (uint32_t)nh * 4u);
+    const BufRsrc ro = FINAL ? buf_rsrc(a.out + (size_t)z * a.out_sstride, (uint32_t)h * (uint32_t)a.out_stride)
+                             : buf_rsrc(a.res + (size_t)z * w * h, pbytes);
+    const BufRsrc ri = buf_rsrc(FINAL ? (const void*)(a.iab + (size_t)z * w * h) : (const void*)a.bandA, FINAL ? pbytes : 0u);
+    const BufRsrc rd = buf_rsrc(a.dbg, (DBG && FINAL && a.dbg && z == 0) ? pbytes * 3u : 0u);   // float frame of stream 0
+    const uint32_t lband = 16u * (uint32_t)gl, lcoarse = 8u * (uint32_t)gl;
+    const uint32_t lout = owner ? (FINAL ? 12u : 16u) * (uint32_t)gl : kDrop, ldbg = owner ? 48u * (uint32_t)gl : kDrop;
+    const uint32_t ostride = FINAL ? (uint32_t)a.out_stride : (uint32_t)w * 4u;
+    const int y0 = ty * a.rows;                                     // rows is even
+    const int yend = y0 + a.rows < h ? y0 + a.rows : h;
+    const int nq = yend - y0 + 8;                                   // input rows y0 - 4 .. yend + 3
+    lvm_f2 hp[9][2], lp[9][2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { hp[k][0] = hp[k][1] = f2_all(0.f); lp[k][0] = lp[k][1] = f2_all(0.f); }
+    int ry = reflect101(y0 - 4, h), rdir = reflect101(y0 - 3, h) - ry;
+    auto advance_row = [&]() __attribute__((always_inline)) {
+        const int t = ry + rdir;
+        const bool lo = t < 0, hi = t > h - 1;
+        ry = lo ? (h > 1 ? 1 : 0) : (hi ? (h > 1 ? h - 2 : 0) : t);
+        rdir = lo ? 1 : (hi ? -1 : rdir);
+    };
+    // in flight per wave: the band row of the next step, the coarse row of the next even step, the (a, b) row of the next output row
+    float4 nxt = buf_ld_f32x4(rb, lband, (uint32_t)ry * (uint32_t)w * 4u);
+    float2 nxtc;
+    { const lvm_f2 c = buf_ld_f32x2(rc, lcoarse, (uint32_t)(ry >> 1) * (uint32_t)nw * 4u); nxtc = make_float2(c[0], c[1]); }
+    float4 nxti = make_float4(0.f, 0.f, 0.f, 0.f);
+    int q = 0;
+#define LVM_COLLAPSE_STEP(P18)                                                                                     \
+    {                                                                                                               \
+        if ((P18) % 9 == 0 && q >= nq) break;                                                                       \
+        constexpr int P = (P18) % 9;                                                                                \
+        constexpr bool EVEN = ((P18) & 1) == 0;                     /* input row y0 - 4 + q and output row y0 - 8 + q, y0 even */ \
+        const float4 cur = nxt;                                                                                     \
+        const float2 curc = nxtc;                                                                                   \
+        const float4 curi = nxti;                                                                                   \
+        advance_row();                                              /* row y0 - 3 + q, reflected */                 \
+        nxt = buf_ld_f32x4(rb, lband, (uint32_t)ry * (uint32_t)w * 4u);                                             \
+        if (!EVEN) { const lvm_f2 c = buf_ld_f32x2(rc, lcoarse, (uint32_t)(ry >> 1) * (uint32_t)nw * 4u); nxtc = make_float2(c[0], c[1]); }   /* that row is even */ \
+        if (FINAL) {                                                /* (a, b) of output row y0 - 7 + q: complete one step from now */ \
+            const int orow = y0 - 7 + q;                                                                            \
+            nxti = buf_ld_f32x4(ri, lband, (uint32_t)(orow < 0 ? 0 : (orow > h - 1 ? h - 1 : orow)) * (uint32_t)w * 4u);   \
+        }                                                                                                           \
+        lvm_issue_fence();                                                                                          \
+        lvm_f2 V[6], W[5];                                                                                          \
+        row12(cur, first, last, V, W);                                                                              \
+        hp_row_taps<P>(V, W, hp);                                                                                   \
+        if (EVEN) {                                                                                                 \
+            lvm_f2 A[3], B[2];                                                                                      \
+            coarse6(curc, first, last, A, B);                                                                       \
+            collapse_lp_taps<P>(A, B, lp);                                                                          \
+        }                                                                                                           \
+        constexpr int E = (P + 1) % 9;                              /* output row o = y0 - 8 + q is complete */     \
+        const bool inside = q >= 8 && q < nq;                                                                       \
+        const uint32_t o = inside ? (uint32_t)(y0 - 8 + q) : 0u;                                                    \
+        const float L0 = lp[E][0][0] + hp[E][0][0], L1 = lp[E][1][0] + hp[E][0][1];   /* RieszPyramid.cpp:322 */    \
+        const float L2 = lp[E][0][1] + hp[E][1][0], L3 = lp[E][1][1] + hp[E][1][1];                                 \
+        if (!FINAL) buf_st_f32x4(L0, L1, L2, L3, ro, inside ? lout : kDrop, o * ostride);                           \
+        else collapse_emit<FL, DBG>(L0, L1, L2, L3, curi, a.lab, s_igt, ro, inside ? lout : kDrop, o * ostride, rd, inside ? ldbg : kDrop, o * (uint32_t)w * 12u); \
+        hp[E][0] = hp[E][1] = f2_all(0.f); lp[E][0] = lp[E][1] = f2_all(0.f);                                      \
+        ++q;                                                                                                        \
+        _Pragma("unroll") for (int d = 1; d < 9; ++d) {                                                             \
+            lvm_pin(hp[(E + d) % 9][0], hp[(E + d) % 9][1]);                                                        \
+            lvm_pin(lp[(E + d) % 9][0], lp[(E + d) % 9][1]);                                                        \
+        }                                                                                                           \
+    }
+    for (;;) {
+        LVM_COLLAPSE_STEP(0) LVM_COLLAPSE_STEP(1) LVM_COLLAPSE_STEP(2) LVM_COLLAPSE_STEP(3) LVM_COLLAPSE_STEP(4) LVM_COLLAPSE_STEP(5)
+        LVM_COLLAPSE_STEP(6) LVM_COLLAPSE_STEP(7) LVM_COLLAPSE_STEP(8) LVM_COLLAPSE_STEP(9) LVM_COLLAPSE_STEP(10) LVM_COLLAPSE_STEP(11)
+        LVM_COLLAPSE_STEP(12) LVM_COLLAPSE_STEP(13) LVM_COLLAPSE_STEP(14) LVM_COLLAPSE_STEP(15) LVM_COLLAPSE_STEP(16) LVM_COLLAPSE_STEP(17)
+    }
+#undef LVM_COLLAPSE_STEP
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1293,6 +1500,9 @@ struct RieszState : ModeState {
     bool phase4 = true;              // 4-pixels-per-thread phase kernel on levels whose width is a multiple of 4 (LVM_RZ_PHASE4=0: scalar kernel)
     int fin_groups = 0;              // workgroups of the persistent last kernel (LVM_RZ_FIN_GROUPS; 0 = a sixth of the tiles, at least 2048)
     int split_strip = 0;             // rows per strip of k_rz_split_rows (LVM_RZ_SPLIT_STRIP; 0 = chosen per launch)
+    bool collapse_strips = true;     // collapse / output as wave strips (LVM_RZ_COLLAPSE_STRIPS=0: the tiled kernels) ...
+    long collapse_strips_min = 10000000;   // ... for launches of at least this many plane-pixels (LVM_RZ_COLLAPSE_STRIPS_MIN)
+    int collapse_strip = 0;          // rows per strip of k_rz_collapse_strips (LVM_RZ_COLLAPSE_STRIP; 0 = chosen per launch)
     bool compact = true;             // compact zero-injected tile in the collapse kernels (LVM_RZ_COMPACT=0: the full 24 x 72 tile)
     bool split2 = true;              // 64 x 32 tiles with 4 x 2 outputs per thread in the 9x9 split (LVM_RZ_SPLIT2=0: k_rz_split)
     bool blur4 = true;               // register-blocked Gaussian/amplify kernel on the large levels (LVM_RZ_BLUR4=0: scalar kernel everywhere)
@@ -1344,6 +1554,21 @@ static void riesz_coeffs(double frq, double fps, double a[3], double b[3]) {   /
 struct RzBufs { float** oct; float** res; float* (*pf)[F_ALL_N]; int nt; uint32_t* iab; };
 struct RieszState;
 static bool rz_level_uses_strips(const RieszState* st, int l, int NZ);
+// Rows per strip of a 9x9 strip kernel (k_rz_split_rows, k_rz_collapse_strips).  A strip of r rows runs r + 8 steps rounded up to groups
+// of nine, the kernels are bound by their fma issue and a launch hands every SIMD ceil(strips / 1024) waves (workgroups of four waves,
+// one per SIMD): cost = steps x waves per SIMD, with at least four waves per SIMD assumed (fewer do not hide the loads).
+static int strip_rows_by_work(int sx, int h, int NZ) {
+    long best = -1;
+    int rows = 8;
+    for (int r = 8; r <= 256; r += 2) {
+        const long tasks = (long)sx * ((h + r - 1) / r) * NZ;
+        const long steps = (r + 8 + 8) / 9 * 9;
+        const long per_simd = (tasks + 1023) / 1024;
+        const long cost = steps * (per_simd < 4 ? 4 : per_simd);
+        if (best < 0 || cost < best) { best = cost; rows = r; }
+    }
+    return rows;
+}
 
 // pyramid of the nt frames: L plane + 9x9 split chain
 static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B, hipStream_t s) {
@@ -1362,20 +1587,11 @@ static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B,
     for (int l = 0; l < nb; ++l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
         if (st->split_rows && a.w % 4 == 0 && a.w >= 8 && (long)a.n * NZ >= st->split_rows_min) {
-            // wave strips (no LDS).  A strip of r output rows walks r + 8 input rows and every strip costs the same, so the
-            // launch takes ceil(strips / resident waves) rounds of r + 8 rows: 1080p with 64-row strips is 4352 strips for
-            // 4096 resident waves (126 VGPRs: 4 waves on each of the 1024 SIMDs) -- two rounds, the second one 6 % full;
-            // 68-row strips are exactly one round.  LVM_RZ_SPLIT_STRIP overrides the choice.
+            // wave strips (no LDS), rows per strip by strip_rows_by_work: 32 frames of 1080p run 68-row strips -- 4096 strips of 81
+            // steps, four waves on every SIMD (100 VGPRs).  LVM_RZ_SPLIT_STRIP overrides the choice.
             const int sx = (a.w / 4 + SR_OWN - 1) / SR_OWN;
             int rows = st->split_strip;
-            if (rows <= 0) {
-                long best_cost = -1;
-                for (int r = 8; r <= 256; r += 2) {
-                    const long tasks = (long)sx * ((a.h + r - 1) / r) * NZ;
-                    const long cost = ((tasks + 4095) / 4096) * (r + 8);
-                    if (best_cost < 0 || cost < best_cost) { best_cost = cost; rows = r; }
-                }
-            }
+            if (rows <= 0) rows = strip_rows_by_work(sx, a.h, NZ);
             const int sy = (a.h + rows - 1) / rows;
             const long ntasks = (long)sx * sy * NZ;
             LVM_LAUNCH(c, LName("rz_split", l), k_rz_split_rows, dim3((unsigned)((ntasks + SR_THREADS / 64 - 1) / (SR_THREADS / 64))), dim3(SR_THREADS), s,
@@ -1481,8 +1697,29 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
         if (n1) LVM_LAUNCH(c, "rz_blur_amp_small", (lab_flavour(c) != FL_LUT_FAST) ? k_rz_blur_amp<true> : k_rz_blur_amp<false>, dim3(blocks), blk, s, a);
     }
     const float* resn = B.oct[levels - 1];       // res_{L-1} = residual octave
+    // wave strips (k_rz_collapse_strips) for large launches on planes with even sizes and a width that is a multiple of 4
+    auto strips_ok = [&](const LevelGeom& a, const LevelGeom& b) {
+        return st->collapse_strips && a.w % 4 == 0 && a.w >= 8 && a.h % 2 == 0 && a.h >= 2 && b.w == a.w / 2 && b.h == a.h / 2 &&
+               (long)a.n * NZ >= st->collapse_strips_min;
+    };
+    auto strips_geom = [&](CollapseStripArgs& ca, const LevelGeom& a, const LevelGeom& b) {
+        ca.w = a.w; ca.h = a.h; ca.nw = b.w; ca.nh = b.h;
+        ca.strips_x = (a.w / 4 + SR_OWN - 1) / SR_OWN;
+        ca.rows = st->collapse_strip > 0 ? st->collapse_strip : strip_rows_by_work(ca.strips_x, a.h, NZ);
+        ca.strips_y = (a.h + ca.rows - 1) / ca.rows;
+        ca.ntasks = ca.strips_x * ca.strips_y * NZ;
+    };
     for (int l = nb - 1; l >= 1; --l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
+        if (strips_ok(a, b)) {
+            CollapseStripArgs ca{};
+            ca.bandA = B.pf[l][F_BANDA]; ca.resn = resn; ca.res = B.res[l];
+            strips_geom(ca, a, b);
+            LVM_LAUNCH(c, LName("rz_collapse", l), (k_rz_collapse_strips<false, FL_LUT_FAST, false>),
+                       dim3((unsigned)((ca.ntasks + CS_THREADS / 64 - 1) / (CS_THREADS / 64))), dim3(CS_THREADS), s, ca);
+            resn = B.res[l];
+            continue;
+        }
         const dim3 grid((a.w + CW - 1) / CW, (a.h + CH - 1) / CH, NZ);
         const bool compact = st->compact && a.w % 2 == 0 && a.h % 2 == 0;
         LVM_LAUNCH(c, LName("rz_collapse", l), compact ? k_rz_collapse<true> : k_rz_collapse<false>, grid, blk, s, (const float*)B.pf[l][F_BANDA], resn,
@@ -1515,7 +1752,16 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
     };
     auto kfb = pick(std::true_type{});
     auto kfn = pick(std::false_type{});
-    if (nb >= 1)
+    const bool out_ok = io.out_stride % 4 == 0 && io.out_sstride % 4 == 0 && ((uintptr_t)io.d_out % 4) == 0 && (long)io.out_stride * h < (1L << 31);
+    if (nb >= 1 && fl != FL_ANALYTIC && out_ok && strips_ok(st->g[0], st->g[1])) {
+        CollapseStripArgs ca{};
+        ca.bandA = B.pf[0][F_BANDA]; ca.resn = resn; ca.res = nullptr;
+        ca.iab = B.iab; ca.out = (uint8_t*)io.d_out; ca.out_stride = (long)io.out_stride; ca.out_sstride = (long)io.out_sstride; ca.dbg = dbg; ca.lab = c->lab;
+        strips_geom(ca, st->g[0], st->g[1]);
+        auto kf = fl == FL_LUT_EXACT ? (dbg ? k_rz_collapse_strips<true, FL_LUT_EXACT, true> : k_rz_collapse_strips<true, FL_LUT_EXACT, false>)
+                                     : (dbg ? k_rz_collapse_strips<true, FL_LUT_FAST, true> : k_rz_collapse_strips<true, FL_LUT_FAST, false>);
+        LVM_LAUNCH(c, "rz_final", kf, dim3((unsigned)((ca.ntasks + CS_THREADS / 64 - 1) / (CS_THREADS / 64))), dim3(CS_THREADS), s, ca);
+    } else if (nb >= 1)
         LVM_LAUNCH(c, "rz_final", kfb, grid, blk, s, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.d_out,
                    (long)io.out_stride, (long)io.out_sstride, w, h, (const float*)B.pf[0][F_BANDA], resn, st->g[1].w, st->g[1].h,
                    c->lab, tx, ty, NZ, dbg, (const float*)B.oct[0], (const uint32_t*)B.iab);
@@ -1541,6 +1787,9 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         if (const char* e = std::getenv("LVM_RZ_FIN_GROUPS")) st->fin_groups = std::atoi(e);
         if (const char* e = std::getenv("LVM_RZ_SPLIT_STRIP")) { const int v = std::atoi(e); if (v >= 2 && v % 2 == 0) st->split_strip = v; }
         if (const char* e = std::getenv("LVM_RZ_SPLIT_ROWS")) st->split_rows = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_RZ_COLLAPSE_STRIPS")) st->collapse_strips = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_RZ_COLLAPSE_STRIPS_MIN")) st->collapse_strips_min = std::atol(e);
+        if (const char* e = std::getenv("LVM_RZ_COLLAPSE_STRIP")) { const int v = std::atoi(e); if (v >= 2 && v % 2 == 0) st->collapse_strip = v; }
         if (const char* e = std::getenv("LVM_RZ_SPLIT_ROWS_MIN")) st->split_rows_min = std::atol(e);
         c->state = st;
         int rc = riesz_alloc(c, st, io.w, io.h, levels);

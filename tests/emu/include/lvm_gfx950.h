@@ -11,6 +11,7 @@ namespace lvm {
 template <class T> using const_tab = const T*;
 template <class T> __device__ __forceinline__ const_tab<T> as_const_tab(const T* p) { return p; }
 struct B96 { uint32_t a, b, c; };
+typedef float lvm_f2 __attribute__((vector_size(8)));
 struct BufRsrc { char* base; uint32_t bytes; };
 __device__ __forceinline__ BufRsrc buf_rsrc(const void* base, uint32_t bytes) { return BufRsrc{(char*)base, bytes}; }
 __device__ __forceinline__ float buf_ld_f32(const BufRsrc& r, uint32_t voff, uint32_t soff) {
@@ -25,12 +26,36 @@ __device__ __forceinline__ B96 buf_ld_b96(const BufRsrc& r, uint32_t voff, uint3
     if (o + 12 <= r.bytes) std::memcpy(&v, r.base + o, 12);
     return v;
 }
+__device__ __forceinline__ float4 buf_ld_f32x4(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    const uint64_t o = (uint64_t)voff + soff;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (o + 16 <= r.bytes) std::memcpy(v, r.base + o, 16);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ lvm_f2 buf_ld_f32x2(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    const uint64_t o = (uint64_t)voff + soff;
+    lvm_f2 v = {0.f, 0.f};
+    if (o + 8 <= r.bytes) std::memcpy(&v, r.base + o, 8);
+    return v;
+}
+__device__ __forceinline__ void buf_st_f32x4(float a, float b, float c, float d, const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    const uint64_t o = (uint64_t)voff + soff;
+    const float v[4] = {a, b, c, d};
+    if (o + 16 <= r.bytes) std::memcpy(r.base + o, v, 16);
+}
+__device__ __forceinline__ void buf_st_f32x2(float a, float b, const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    const uint64_t o = (uint64_t)voff + soff;
+    const float v[2] = {a, b};
+    if (o + 8 <= r.bytes) std::memcpy(r.base + o, v, 8);
+}
 __device__ __forceinline__ void buf_st_b96(const B96& v, const BufRsrc& r, uint32_t voff, uint32_t soff) {
     const uint64_t o = (uint64_t)voff + soff;
     if (o + 12 <= r.bytes) std::memcpy(r.base + o, &v, 12);
 }
-typedef float lvm_f2 __attribute__((vector_size(8)));
 __device__ __forceinline__ lvm_f2 f2_fma(lvm_f2 a, lvm_f2 b, lvm_f2 c) { lvm_f2 v = {__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1])}; return v; }
+__device__ __forceinline__ void lvm_pin(lvm_f2&, lvm_f2&) {}
+__device__ __forceinline__ void lvm_pin(float&, float&) {}
+__device__ __forceinline__ void lvm_issue_fence() {}
 __device__ __forceinline__ uint32_t lut_dot2(uint32_t pair, uint32_t wts, uint32_t acc) {
     return acc + (pair & 0xffffu) * (wts & 0xffffu) + (pair >> 16) * (wts >> 16);
 }

@@ -606,14 +606,52 @@ def test_fast_final_kernel_strips_and_shortcut_paths(lvm, po, emu, w, h, levels)
     print("fast final kernel", (w, h, levels), worst)
 
 
-@pytest.mark.parametrize("strip", ["0", "10", "68"])
-@pytest.mark.parametrize("w,h,levels", [(520, 70, 3), (256, 41, 2), (1000, 24, 2)])
+@pytest.mark.parametrize("strip", ["0", "10", "54"])
+@pytest.mark.parametrize("w,h,levels", [(520, 70, 3), (256, 41, 2), (1000, 24, 2), (128, 5, 2)])
 def test_riesz_emu_wave_strip_stencils(lvm, po, emu, w, h, levels, strip, monkeypatch):
     """The LDS-free 9x9 strip kernels (forced onto these small planes): several 248-column strips per row (a full one, a
     partial one, a strip whose last lane owns the image's last column group), strips cut by the image height, odd heights,
-    the strip height chosen by the launch code (0) or forced (10 rows: several strips per column; 68: the 1080p choice),
-    bit-exact against the oracle."""
+    the strip height chosen by the launch code (0) or forced (10 rows: several strips per column; 54: the 1080p choice), a
+    plane of five rows (the row index of the loads bounces off both edges inside one group of steps), bit-exact against the oracle."""
     monkeypatch.setenv("LVM_RZ_SPLIT_ROWS_MIN", "1")
     monkeypatch.setenv("LVM_RZ_SPLIT_STRIP", strip)
     ck, pk = lvm.synth.config(2, (w, h, levels))
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0, exact=True)
+
+
+@pytest.mark.parametrize("strip", ["0", "10", "64"])
+@pytest.mark.parametrize("w,h,levels", [(512, 64, 4), (520, 70, 2), (1000, 24, 2), (8, 4, 2)])
+def test_riesz_emu_wave_strip_collapse_and_output(lvm, po, emu, w, h, levels, strip, monkeypatch):
+    """k_rz_collapse_strips forced onto small planes with even sizes: the collapse of levels 1 and 2 and the output kernel of a
+    512 x 64 frame, several 248-column strips per row, strips cut by the image height, the smallest plane the kernel accepts
+    (two column groups, four rows: every row index is a reflection), strip height chosen by the launch code or forced;
+    OpenCV-order Lab arithmetic: bit-exact against the oracle."""
+    monkeypatch.setenv("LVM_RZ_COLLAPSE_STRIPS_MIN", "1")
+    monkeypatch.setenv("LVM_RZ_COLLAPSE_STRIP", strip)
+    ck, pk = lvm.synth.config(2, (w, h, levels))
+    run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0, exact=True)
+
+
+def test_riesz_emu_strip_output_fast_flavour_equals_the_tiled_kernel(lvm, emu, monkeypatch):
+    """The default flavour (reciprocal multiplies, packed Lab2BGR) of the strip output kernel against the tiled k_rz_final on the
+    same frames: identical bytes and identical float frames (both evaluate the same operations per pixel)."""
+    ck, pk = lvm.synth.config(2, (256, 48, 3))
+    clip = lvm.synth.Clip(**ck)
+    from helpers import c_params
+    outs = []
+    for strips in ("1", "0"):
+        monkeypatch.setenv("LVM_RZ_COLLAPSE_STRIPS_MIN", "1")
+        monkeypatch.setenv("LVM_RZ_COLLAPSE_STRIPS", strips)
+        ctx = lvm.Context(0, 1, emu)
+        ctx.keep_float(True)
+        try:
+            got = []
+            for t in range(5):
+                out, produced = ctx.process(clip.frame(t), c_params(lvm, pk))
+                got.append((np.array(out, copy=True), ctx.read_float((48, 256, 3)).copy() if produced else None))
+        finally:
+            ctx.close()
+        outs.append(got)
+    for (a, fa), (b, fb) in zip(*outs):
+        assert np.array_equal(a, b)
+        assert (fa is None and fb is None) or np.array_equal(fa, fb)
