@@ -101,6 +101,47 @@ def test_riesz_1080p_64_frames_state_drift(lvm, po, hip):
     print("riesz 1080p 64 frames worst rel/u8/frac", worst)
 
 
+@pytest.mark.parametrize("strips", [{}, {"LVM_RZ_SPLIT_STRIP": "10", "LVM_RZ_COLLAPSE_STRIP": "10"}, {"LVM_RZ_SPLIT_STRIP": "54", "LVM_RZ_COLLAPSE_STRIP": "46"}])
+def test_riesz_4k_strip_kernels_equal_the_tiled_kernels(lvm, hip, monkeypatch, strips):
+    """Five-frame batches of 3840 x 2160, 8 levels: the 9x9 wave-strip kernels (k_rz_split_rows, k_rz_collapse_strips as collapse and as
+    output kernel) against the LDS-tiled kernels on the same frames -- identical bytes, twice in a row.  Both families evaluate the
+    same fma chains, so any difference is a hardware-level fault of one of them: this is the case in which a `buffer_store_dwordx3`
+    with an SGPR offset lost its third dword for the last four lanes of every 16 (the next instruction overwrote the register; the
+    compiler pads that hazard only without a register in the soffset field) -- a few hundred pixels of a 4K frame, never at 1080p,
+    never in the emulation build."""
+    import torch
+    from helpers import c_params
+    ck, pk = lvm.synth.config(4)
+    clip = lvm.synth.Clip(**ck)
+    w, h, T = ck["w"], ck["h"], 5
+    frames = np.stack([clip.frame(t) for t in range(T)])
+    fb = w * h * 3
+
+    def run(env):
+        for k in ("LVM_RZ_COLLAPSE_STRIPS", "LVM_RZ_SPLIT_ROWS", "LVM_RZ_COLLAPSE_STRIP", "LVM_RZ_SPLIT_STRIP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = lvm.Context(0, 1, hip)
+        try:
+            d_in = torch.from_numpy(frames).cuda()
+            d_out = torch.zeros_like(d_in)
+            prod = ctx.process_device_frames(c_params(lvm, pk), T, d_in.data_ptr(), w, h, 3, w * 3, fb, fb, d_out.data_ptr(), w * 3, fb, fb,
+                                             torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            return list(prod), d_out.cpu().numpy()
+        finally:
+            ctx.close()
+
+    p0, tiled = run({"LVM_RZ_COLLAPSE_STRIPS": "0", "LVM_RZ_SPLIT_ROWS": "0"})
+    assert any(p0)
+    for _ in range(2):
+        p1, got = run(strips)
+        assert p1 == p0
+        bad = np.argwhere(got != tiled)
+        assert len(bad) == 0, (len(bad), bad[:8])
+
+
 def _bench(args, timeout=900):
     env = dict(os.environ)
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
