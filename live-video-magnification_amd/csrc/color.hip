@@ -305,6 +305,117 @@ __global__ __launch_bounds__(256) void k_col_dft_thin(const float* __restrict__ 
     block_minmax(vmin, vmax, mm[b].mn1, mm[b].mx1);
 }
 
+// The same narrow-band filter with EIGHT lanes per window row (at most four entries, i.e. eight real sums).  One thread per row is a
+// chain of 2 n dependent float64 steps behind an LDS look-up each, and a 32-frame batch of the smallest 1080p level is 49 k rows:
+// 192 workgroups, one wave per SIMD, nothing to hide the latencies behind (39 us per batch).  Here lane s of a row runs forward sum
+// s (entry s / 2, real or imaginary part: the in-order float64 sum over the window, as before), the eight partial results meet in
+// LDS, and every lane runs the inverse sums of the samples t = s, s + 8, ... (each sample's sum over the entries in ascending order,
+// as before).  Same values, eight times the threads.
+constexpr int kThin8Bins = 4, kThin8Rows = 32, kThin8MaxN = 256;   // windows up to 256 frames (NMAX = 128 / 256: 21 / 40 KB of LDS per workgroup;
+                                                                    // with 21 KB the 1536 workgroups of a 32-frame 1080p batch are resident at once)
+template <int NMAX>
+__global__ __launch_bounds__(256) void k_col_dft_thin8(const float* __restrict__ win, int slot0, int n, int cap,
+                                                       int rows_per_stream, int live_per_stream,
+                                                       const double* __restrict__ tw, float* __restrict__ col1, MinMax* mm,
+                                                       ThinBins eb) {
+    const int sub = threadIdx.x & 7, lr = threadIdx.x >> 3;
+    const int r = blockIdx.x * kThin8Rows + lr, b = blockIdx.y, fr = blockIdx.z;
+    slot0 += fr; if (slot0 >= cap) slot0 -= cap;
+    col1 += (size_t)fr * gridDim.y * rows_per_stream;
+    mm += fr * gridDim.y;
+    const bool live = r < live_per_stream;
+    const size_t grow = (size_t)b * rows_per_stream + (live ? r : 0);
+    __shared__ double s_tw[2 * NMAX];
+    __shared__ float s_row[kThin8Rows][NMAX + 1];
+    __shared__ float s_sum[kThin8Rows][8];
+    for (int i = threadIdx.x; i < 2 * n; i += 256) s_tw[i] = tw[i];
+    {
+        const float* wr = win + grow * cap;
+        for (int t0 = 0; t0 < n; t0 += 64) {                       // eight loads in flight per lane (a rolled loop serialises the round trips)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + 8 * u + sub;
+                int slot = slot0 + (t < n ? t : n - 1); if (slot >= cap) slot -= cap;
+                v[u] = wr[slot];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int t = t0 + 8 * u + sub; if (t < n) s_row[lr][t] = v[u]; }
+        }
+    }
+    __syncthreads();
+    const double* cs = s_tw;
+    const double* sn = s_tw + n;
+    const bool pow2 = (n & (n - 1)) == 0;
+    const double inv_n = 1.0 / (double)n;
+    {   // forward: the 2 ne sums of the 32 rows on the first 64 ne threads -- ne whole waves run the n-step chains, the others wait at
+        // the barrier without issuing (dft + the 1 / n of DFT_SCALE)
+        const int nch = 2 * eb.ne;
+        if ((int)threadIdx.x < kThin8Rows * nch) {
+            const int frow = threadIdx.x / nch, ch = threadIdx.x - frow * nch;
+            const int bin = eb.bin[ch >> 1];
+            const bool im = (ch & 1) != 0;
+            double acc = 0;
+            int idx = 0;
+            // eight products at a time (their LDS reads and multiplies do not depend on the running sum), then the eight in-order adds
+            for (int t0 = 0; t0 < n; t0 += 8) {
+                double pr[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int t = t0 + u < n ? t0 + u : n - 1;
+                    const double v = (double)s_row[frow][t];
+                    pr[u] = im ? -v * sn[idx] : v * cs[idx];
+                    idx += bin; if (idx >= n) idx -= n;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (t0 + u < n) acc += pr[u];
+            }
+            s_sum[frow][ch] = (float)(pow2 ? acc * inv_n : acc / n);
+        }
+    }
+    __syncthreads();
+    float yre[kThin8Bins], yim[kThin8Bins];
+#pragma unroll
+    for (int j = 0; j < kThin8Bins; ++j) {                                            // mulSpectrums with the packed mask
+        yre[j] = yim[j] = 0.f;
+        if (j >= eb.ne) continue;
+        const float a = s_sum[lr][2 * j], bq = s_sum[lr][2 * j + 1];
+        if (eb.kind[j] == 0) { yre[j] = a * eb.ma[j] - bq * eb.mb[j]; yim[j] = bq * eb.ma[j] + a * eb.mb[j]; }
+        else yre[j] = a * eb.ma[j];
+    }
+    const bool has_dc = eb.ne > 0 && eb.kind[0] == 1;
+    const bool has_ny = eb.ne > 0 && eb.kind[eb.ne - 1] == 2;
+    float yny = 0.f;
+#pragma unroll
+    for (int j = 0; j < kThin8Bins; ++j) if (has_ny && j == eb.ne - 1) yny = yre[j];
+    float vmin = INFINITY, vmax = -INFINITY;
+    if (live) {
+        int idx[kThin8Bins], step[kThin8Bins];
+#pragma unroll
+        for (int j = 0; j < kThin8Bins; ++j) {
+            const int bin = j < eb.ne ? eb.bin[j] : 0;
+            idx[j] = (int)(((unsigned)bin * (unsigned)sub) % (unsigned)n);
+            step[j] = (int)(((unsigned)bin * 8u) % (unsigned)n);
+        }
+#pragma unroll 4
+        for (int t = sub; t < n; t += 8) {                                            // idft of the samples t = sub (mod 8)
+            double acc = has_dc ? yre[0] : 0.f;
+#pragma unroll
+            for (int j = 0; j < kThin8Bins; ++j) {
+                if (j >= eb.ne) break;
+                if (eb.kind[j] != 0) continue;
+                acc += 2.0 * ((double)yre[j] * cs[idx[j]] - (double)yim[j] * sn[idx[j]]);
+                idx[j] += step[j]; if (idx[j] >= n) idx[j] -= n;
+            }
+            if (n % 2 == 0) acc += (t % 2 ? -1.0 : 1.0) * (double)yny;
+            const float v = (float)(pow2 ? acc * inv_n : acc / n);
+            vmin = v < vmin ? v : vmin; vmax = v > vmax ? v : vmax;
+            if (t == 1) col1[grow] = v;                                               // MagnifyCore.hpp:190-192
+        }
+    }
+    block_minmax(vmin, vmax, mm[b].mn1, mm[b].mx1);
+}
+
 // Serial fallback for very long windows (n > kDftMaxN): one thread per row, same arithmetic.
 __global__ __launch_bounds__(256) void k_col_dft_serial(const float* __restrict__ win, int slot0, int n, int cap,
                                                         int rows_per_stream, int live_per_stream, double fl, double fh,
@@ -987,6 +1098,7 @@ struct ColorState : ModeState {
     bool yofs_strict = false;        // the vertical resize map yofs[] is strictly increasing (always, for sizes the up chain produces)
     bool co_rows_ok = false;         // the vectorised output kernel's LDS tile covers every output tile
     bool thin_dft = true;            // thread-per-row DFT for narrow bands (LVM_COL_THIN_DFT=0: wave-per-row kernel)
+    bool thin8_dft = true;           // ... eight lanes per row for at most four entries and windows up to 256 frames (LVM_COL_THIN8_DFT=0)
     long out_min_tasks = 2048;       // strips are shortened until a launch has this many (LVM_COL_OUT_MIN_TASKS)
     long out_min_tasks_lean = 900;   // ... k_col_out_strips: ~1 wave per SIMD is enough (per-frame 1080p: 960 strips of 9 rows, min/max pass 31 -> 21 us:
                                      // fewer strip start-ups and fewer atomics on the frame's 64 min/max cells)
@@ -1190,7 +1302,10 @@ static int col_filter(Ctx* c, ColorState* st, const lvm_params& p, const ColBufs
         if (n % 2 == 0 && m(n - 1) != 0.f) push(n / 2, 2, m(n - 1), 0.f);
         eb.ne = ne;
     }
-    if (ne <= kThinBins && n <= kDftMaxN && st->thin_dft && B.nt >= st->thin_min_frames) {
+    if (ne <= kThin8Bins && n <= kThin8MaxN && st->thin_dft && st->thin8_dft && B.nt >= st->thin_min_frames) {
+        LVM_LAUNCH(c, "col_dft", n <= 128 ? k_col_dft_thin8<128> : k_col_dft_thin8<kThin8MaxN>, dim3((live + kThin8Rows - 1) / kThin8Rows, NS, B.nt), blk, s, (const float*)st->win, slot0, n, st->cap,
+                   st->rows_ps, live, (const double*)st->tw, B.col1, B.mm, eb);
+    } else if (ne <= kThinBins && n <= kDftMaxN && st->thin_dft && B.nt >= st->thin_min_frames) {
         LVM_LAUNCH(c, "col_dft", k_col_dft_thin, dim3((live + 255) / 256, NS, B.nt), blk, s, (const float*)st->win, slot0, n, st->cap,
                    st->rows_ps, live, (const double*)st->tw, B.col1, B.mm, eb);
     } else if (n <= kDftMaxN) {
@@ -1282,6 +1397,7 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         st = new ColorState();
         c->state = st;
         if (const char* e = std::getenv("LVM_COL_THIN_DFT")) st->thin_dft = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_COL_THIN8_DFT")) st->thin8_dft = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_COL_UP_ROWS")) st->up_rows = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);

@@ -463,6 +463,16 @@ def test_color_emu_temporal_batches(lvm, po, emu, w, h, levels, ns, calls):
     _frames_clip(lvm, po, emu, 3, w, h, levels, ns, calls, over={"framerate": 7.0, "coLow": 0.4, "coHigh": 2.0}, clip_over={"fps": 7.0})
 
 
+@pytest.mark.parametrize("lo,hi", [(0.8, 1.6), (2.9, 3.5), (0.8, 0.95)])
+@pytest.mark.parametrize("thin8", ["1", "0"])
+def test_color_emu_narrow_band_dft_eight_lanes_per_row(lvm, po, emu, lo, hi, thin8, monkeypatch):
+    """k_col_dft_thin8 (at most four spectrum entries: eight lanes per window row) on temporal batches: three complex bins (0.8-1.6 Hz
+    at 7 fps, 16-frame window), one complex bin + the Nyquist element (2.9-3.5 Hz), a single bin (0.8-0.95 Hz); LVM_COL_THIN8_DFT=0
+    runs the one-thread-per-row kernel on the same clips.  Bit-exact against the oracle either way."""
+    monkeypatch.setenv("LVM_COL_THIN8_DFT", thin8)
+    _frames_clip(lvm, po, emu, 3, 64, 48, 2, 1, (18, 5, 7, 9), over={"framerate": 7.0, "coLow": lo, "coHigh": hi}, clip_over={"fps": 7.0})
+
+
 # ---- ragged rows: strides larger than the row ---------------------------------------------------------
 @pytest.mark.parametrize("idx,pad_in,pad_out", [(0, 4, 8), (0, 1, 3), (2, 4, 4), (2, 7, 1), (3, 8, 4), (3, 5, 5)])
 def test_emu_padded_row_strides(lvm, po, emu, idx, pad_in, pad_out):
