@@ -13,7 +13,7 @@ from collections import defaultdict
 NAMES = {  # kernel symbol prefix -> bench.py report name (default flavour: FL_LUT_FAST = 0)
     "k_lap_final_v4<true, false, 0>": "lap_final", "k_down0_lut_rows<0>": "lap_down0_lut", "k_down0_rows<true, 0>": "lap_down0", "k_down0_rows<false, 1>": "col_down0",
     "k_lab_planes": "lab_lut", "k_lap_up<false, 1>": "lap_up_l1", "k_lap_iir_levels": "lap_iir", "k_lap_collapse": "lap_collapse", "k_pyr_down_rows": "pyr_down_rows_l1",
-    "k_rz_final<true, 0, true, true, false>": "rz_final", "k_rz_blur_amp4<false>": "rz_blur_amp", "k_rz_blur_strips": "rz_blur_amp", "k_rz_phase4<false>": "rz_phase", "k_rz_phase<false>": "rz_phase_small",
+    "k_rz_final<true, 0, true, true, false>": "rz_final", "k_rz_collapse_strips<true, 0, false>": "rz_final", "k_rz_collapse_strips<false, 0, false>": "rz_collapse_l1", "k_rz_blur_amp4<false>": "rz_blur_amp", "k_rz_blur_strips": "rz_blur_amp", "k_rz_phase4<false>": "rz_phase", "k_rz_phase<false>": "rz_phase_small",
     "k_rz_split_rows": "rz_split_l0", "k_col_out_rows<true, false>": "col_out", "k_col_out_rows<false, false>": "col_minmax",
     "k_down01_rows": "col_down01", "k_col_out_strips<true, false>": "col_out_u2", "k_col_out_strips<false, false>": "col_minmax_u2",
 }
