@@ -584,7 +584,7 @@ def main():
 
     # ---- gather per-rank facts (tests check value == world * B * K / max dt and every rank's verification) ----
     props = torch.cuda.get_device_properties(local_rank)
-    rank_facts = [{"rank": rank, "verified": verified, "stream_ids": ids, "device": "cuda:%d" % local_rank,
+    rank_facts = [{"rank": rank, "verified": verified, "verification": vinfo, "stream_ids": ids, "device": "cuda:%d" % local_rank,
                    "device_name": props.name, "device_uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()}]
     if dist is not None:
         gathered = [None] * world

@@ -184,7 +184,7 @@ def test_bench_two_ranks_from_a_plain_shell():
     ranks = sorted(out["ranks"], key=lambda r: r["rank"])
     assert [r["rank"] for r in ranks] == [0, 1]
     assert [r["stream_ids"] for r in ranks] == [[0], [1]]
-    assert all(r["verified"] is True for r in ranks), ranks
+    assert all(r["verified"] is True for r in ranks), [(r["rank"], r["verified"], r.get("verification")) for r in ranks]
     expect = 2 * 1 * 8 / out["timed_seconds_max_over_ranks"]
     assert abs(out["value"] - expect) <= 1e-6 * expect + 0.01
     assert out["cfg4_riesz_4k"]["n_gpus"] == 2
@@ -228,7 +228,7 @@ def test_bench_eight_ranks_dry_run():
     ranks = sorted(out["ranks"], key=lambda r: r["rank"])
     assert [r["rank"] for r in ranks] == list(range(8))
     assert [r["stream_ids"] for r in ranks] == [[i] for i in range(8)]
-    assert all(r["verified"] is True for r in ranks), ranks
+    assert all(r["verified"] is True for r in ranks), [(r["rank"], r["verified"], r.get("verification")) for r in ranks]
     expect = 8 * 1 * 8 / out["timed_seconds_max_over_ranks"]
     assert abs(out["value"] - expect) <= 1e-6 * expect + 0.01
     assert out["cfg4_riesz_4k"]["n_gpus"] == 8

@@ -88,7 +88,13 @@ int main() {
                 std::vector<unsigned char> ref((size_t)(W / 2) * (H / 2) * 3);
                 const bool produced = single.chain_process(cfg.s.pre, cfg.s.mag, in->px.data(), W, H, 3, W * 3, ref.data(), (W / 2) * 3);
                 const auto& pr = mb[s].all[(size_t)t];
-                if (!produced || pr.first->w != W / 2 || pr.first->seq != t || pr.first->px != ref) { std::printf("source %d frame %ld differs\n", s, t); ++bad; }
+                if (!produced || pr.first->w != W / 2 || pr.first->seq != t || pr.first->px != ref) {
+                    size_t nd = 0; int md = 0;
+                    if (pr.first->px.size() == ref.size())
+                        for (size_t i = 0; i < ref.size(); ++i) { const int d = std::abs((int)pr.first->px[i] - (int)ref[i]); nd += d != 0; md = d > md ? d : md; }
+                    std::printf("source %d frame %ld differs (produced %d, w %d, seq %ld, %zu of %zu bytes, max %d)\n", s, t, (int)produced, pr.first->w, (long)pr.first->seq, nd, ref.size(), md);
+                    ++bad;
+                }
                 if (pr.second->w != W / 2 || pr.second->px.size() != ref.size() || pr.second->seq != t) { std::printf("source %d frame %ld: bad original pane\n", s, t); ++bad; }
             }
             const auto& er = mb[s].all[(size_t)T];
