@@ -207,6 +207,8 @@ class Runner:
     def __init__(self, lvm, torch, np, cfg_idx, small, B, ring, T, device, stream_ids, out_frames, time_shift=False):
         self.lvm, self.torch, self.np = lvm, torch, np
         ck, pk = lvm.synth.config(cfg_idx, small)
+        if CLIP_NOISE is not None:
+            ck = dict(ck, noise=float(CLIP_NOISE))
         self.ck, self.pk = ck, pk
         self.w, self.h, self.levels, self.ch = ck["w"], ck["h"], pk["levels"], 3
         self.B, self.ring, self.T = B, ring, T
@@ -327,6 +329,9 @@ def oracle_replay(po, np, host_frames, pk, ring, n_frames, check, threads, float
     return keep, fl, dt
 
 
+CLIP_NOISE = None     # --clip-noise
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -339,6 +344,8 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--levels", type=int, default=0)
+    ap.add_argument("--clip-noise", type=float, default=None, help="amplitude of the synthetic clip's per-channel uniform noise in levels (default 12: the headline clip; "
+                    "2-3 is a camera's -- the table look-ups of the Lab modes run faster on it; the JSON's `data` says which)")
     ap.add_argument("--ring", type=int, default=64, help="distinct input frames kept in HBM (rounded up to a multiple of T)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle replay (implies --no-verify)")
     ap.add_argument("--no-verify", action="store_true")
@@ -351,6 +358,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (smoke-testing the N > 1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
     args = ap.parse_args()
+    global CLIP_NOISE
+    CLIP_NOISE = args.clip_noise
     global RAMP_SECONDS
     RAMP_SECONDS = args.ramp_ms * 1e-3
 
@@ -608,7 +617,7 @@ def main():
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(1e3 * dt / K, 5),
             "host_enqueue_ms_per_step": round(1e3 * host_enqueue / K, 5), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic" if CLIP_NOISE is None else "synthetic (clip noise +-%g levels instead of +-12)" % CLIP_NOISE,
             "config": {"workload": "%s %dx%d, %d levels, %d stream(s)/GPU, device-resident u8 BGR in/out" %
                                    (args.mode, w, h, levels, B),
                        "baseline_config": cfg_idx, "streams_per_gpu": B, "ring_frames": ring,
@@ -685,7 +694,7 @@ def other_mode_record(lvm, torch, np, cfg_idx, local_rank, rank, world, dist, re
     dt = lvm.sharding.timed_steps(lambda i: R.run(K), 1, dist, torch.cuda.synchronize, red_dev, finish=lambda: R.ctx.flush(R.stream))
     fps = world * K / dt
     b_alg = lvm.load().lvm_algorithmic_bytes(R.pk["mode"], R.w, R.h, R.ch, R.levels, R.pk["framerate"])
-    rec = {"workload": "%s 1920x1080, 6 levels, 1 stream per GPU, %d frames per call" % ({2: "riesz", 3: "color"}[cfg_idx], T),
+    rec = {"workload": "%s 1920x1080, 6 levels, 1 stream per GPU, %d frames per call" % ({1: "laplace", 2: "riesz", 3: "color"}[cfg_idx], T),
            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "us_per_frame": round(1e6 * dt / K, 2),
            "frame_alg_bytes": b_alg, "frame_roofline_frac": round(b_alg * fps / world / (HBM_PEAK_GBS * 1e9), 5)}
     if rank == 0 and R.oring >= R.n:
@@ -856,6 +865,17 @@ def sub_records(lvm, torch, np, args, cfg_idx, small, local_rank, rank, world, d
     if cfg_idx == 1 and not small:
         out["cfg2_riesz_1080p"] = other_mode_record(lvm, torch, np, 2, local_rank, rank, world, dist, red_dev)
         out["cfg3_color_1080p"] = other_mode_record(lvm, torch, np, 3, local_rank, rank, world, dist, red_dev)
+        # (6) content sensitivity: the headline clip carries +-12 levels of per-channel noise -- neighbouring pixels land in different
+        # cells of the forward Lab table, the worst case for its gathers; the same stream with a camera's +-2 levels
+        global CLIP_NOISE
+        if CLIP_NOISE is None:
+            CLIP_NOISE = 2.0
+            try:
+                rec = other_mode_record(lvm, torch, np, 1, local_rank, rank, world, dist, red_dev, K=128)
+            finally:
+                CLIP_NOISE = None
+            rec["workload"] += ", clip noise +-2 levels instead of the headline's +-12"
+            out["camera_noise_clip"] = rec
     return out
 
 

@@ -21,13 +21,14 @@ def motion_hz_to_blend(hz, fps):
     return min(max(a, 0.0), 0.999999)
 
 
-def texture(w, h, seed=1234, pad=2):
-    """float64 texture (h, w+2*pad, 3) in [4, 251]."""
+def texture(w, h, seed=1234, pad=2, noise=12.0):
+    """float64 texture (h, w+2*pad, 3) in [4, 251]: two sine gratings + uniform per-channel noise of +- `noise` levels (12: far
+    above a camera's -- neighbouring pixels land in different cells of the Lab table, the worst case for its gathers)."""
     rng = np.random.default_rng(seed)
     x = np.arange(-pad, w + pad, dtype=np.float64)[None, :]
     y = np.arange(h, dtype=np.float64)[:, None]
     base = 96.0 + 48.0 * np.sin(2 * np.pi * (x / 37.0 + y / 53.0)) + 32.0 * np.sin(2 * np.pi * (x / 11.0 - y / 7.0))
-    noise = rng.uniform(-12.0, 12.0, size=(h, w + 2 * pad, 3))
+    noise = rng.uniform(-noise, noise, size=(h, w + 2 * pad, 3))
     return np.clip(base[:, :, None] + noise, 4.0, 251.0)
 
 
@@ -35,13 +36,13 @@ class Clip:
     """Frame t = texture sampled at (x + A sin(2 pi f_m t / fps), y) (bilinear) + colour pulse."""
 
     def __init__(self, w, h, fps=30.0, f_motion=1.5, amp_px=0.5, f_color=0.0, amp_color=0.0,
-                 seed=1234, channels=3):
+                 seed=1234, channels=3, noise=12.0):
         self.w, self.h, self.fps = w, h, fps
         self.f_motion, self.amp_px = f_motion, amp_px
         self.f_color, self.amp_color = f_color, amp_color
         self.channels = channels
         self.pad = 2
-        self.tex = texture(w, h, seed, self.pad)
+        self.tex = texture(w, h, seed, self.pad, noise)
 
     def frame(self, t):
         d = self.amp_px * math.sin(2 * math.pi * self.f_motion * t / self.fps)
