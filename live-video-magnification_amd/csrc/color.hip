@@ -485,6 +485,52 @@ __global__ __launch_bounds__(256) void k_col_norm(const float* __restrict__ col1
     up0[r] = (col1[r] * fs + fsh) * amp;
 }
 
+// k_col_norm and the FIRST pyrUp of the up chain in one launch: k_pyr_up_rows' blocks of 4 x 2 outputs (pyramid.h) whose source values
+// are normalised on the fly -- (col1 * fs + fsh) * amp, the same three operations per value -- instead of read from a normalised copy.
+// One dependent launch less per batch (6 us of launch + latency for 49 k values); plane = (frame * streams + stream) * C + channel.
+__global__ __launch_bounds__(256) void k_pyr_up_rows_norm(const float* __restrict__ col1, int rows_per_stream, int C, int sw, int sh,
+                                                          float* __restrict__ dst, int ngroups, const MinMax* mm, float amp) {
+    __shared__ float s_sc[2];
+    const int plane = blockIdx.y, z = plane / C, ch = plane - z * C;
+    if (threadIdx.x == 0) {
+        const double mn = (double)mm_min(mm[z].mn1), mx = (double)mm_max(mm[z].mx1);
+        const double scale = (mx - mn > 2.220446049250313e-16) ? 1. / (mx - mn) : 0.;
+        const double shift = 0. - mn * scale;
+        s_sc[0] = (float)scale; s_sc[1] = (float)shift;
+    }
+    __syncthreads();
+    const int gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi >= ngroups) return;
+    const float fs = s_sc[0], fsh = s_sc[1];
+    const int dw = 2 * sw, gw = dw >> 2;
+    const int j = gi / gw, gx = (gi - j * gw) * 4;
+    const float* sp = col1 + (size_t)z * rows_per_stream + (size_t)ch * sw * sh;
+    float* dp = dst + (size_t)plane * (size_t)dw * (2 * sh);
+    const int i0 = gx >> 1;
+    const int cm1 = i0 > 0 ? i0 - 1 : 0, cp1 = i0 + 1 < sw ? i0 + 1 : sw - 1, cp2 = i0 + 2 < sw ? i0 + 2 : sw - 1;
+    const bool f0 = i0 == 0, l0 = i0 == sw - 1, l1 = i0 + 1 == sw - 1;
+    float h[3][4];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        int sy = j - 1 + q; sy = sy < 0 ? 1 : (sy >= sh ? sh - 1 : sy);
+        const float* r = sp + (size_t)sy * sw;
+        const float sm1 = (r[cm1] * fs + fsh) * amp, s0 = (r[i0] * fs + fsh) * amp, s1 = (r[cp1] * fs + fsh) * amp, s2 = (r[cp2] * fs + fsh) * amp;
+        h[q][0] = sel(f0, s0 * 6.f + s1 * 2.f, sel(l0, sm1 + s0 * 7.f, sm1 + s0 * 6.f + s1));
+        h[q][1] = sel(l0, s0 * 8.f, (s0 + s1) * 4.f);
+        h[q][2] = sel(l1, s0 + s1 * 7.f, s0 + s1 * 6.f + s2);
+        h[q][3] = sel(l1, s1 * 8.f, (s1 + s2) * 4.f);
+    }
+    float e[4], o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        e[k] = (h[0][k] + h[1][k] * 6.f + h[2][k]) * (1.f / 64.f);
+        o[k] = ((h[1][k] + h[2][k]) * 4.f) * (1.f / 64.f);
+    }
+    float* d0 = dp + (size_t)(2 * j) * dw + gx;
+    *reinterpret_cast<float4*>(d0) = make_float4(e[0], e[1], e[2], e[3]);
+    *reinterpret_cast<float4*>(d0 + dw) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // ---- last pyrUp + resize(INTER_LINEAR) + input add (SpatialFilter.cpp:45-48, MagnifyCore.hpp:197-203)
 constexpr int CT_W = 64, CT_H = 16;                 // output tile
 constexpr int CU_W = 100, CU_H = 28;                // max extent of the pyrUp'ed tile (scale < 1.5)
@@ -1098,6 +1144,8 @@ struct ColorState : ModeState {
     bool yofs_strict = false;        // the vertical resize map yofs[] is strictly increasing (always, for sizes the up chain produces)
     bool co_rows_ok = false;         // the vectorised output kernel's LDS tile covers every output tile
     bool thin_dft = true;            // thread-per-row DFT for narrow bands (LVM_COL_THIN_DFT=0: wave-per-row kernel)
+    bool norm_in_up = true;          // normalisation inside the first pyrUp launch (LVM_COL_NORM_IN_UP=0: k_col_norm as its own launch)
+    float amp = 0.f;                 // amplification of the current call (col_filter -> col_up_out)
     bool thin8_dft = true;           // ... eight lanes per row for at most four entries and windows up to 256 frames (LVM_COL_THIN8_DFT=0)
     long out_min_tasks = 2048;       // strips are shortened until a launch has this many (LVM_COL_OUT_MIN_TASKS)
     long out_min_tasks_lean = 900;   // ... k_col_out_strips: ~1 wave per SIMD is enough (per-frame 1080p: 960 strips of 9 rows, min/max pass 31 -> 21 us:
@@ -1317,8 +1365,7 @@ static int col_filter(Ctx* c, ColorState* st, const lvm_params& p, const ColBufs
         LVM_LAUNCH(c, "col_dft", k_col_dft_serial, dim3((live + 255) / 256, NS), blk, s, (const float*)st->win, slot0, n, st->cap,
                    st->rows_ps, live, fl, fh, (const double*)st->tw, st->Y, B.col1, B.mm);
     }
-    LVM_LAUNCH(c, "col_norm", k_col_norm, dim3((live + 255) / 256, NS * B.nt), blk, s, (const float*)B.col1, B.up[0], live, st->rows_ps,
-               (const MinMax*)B.mm, (float)p.amplification);
+    st->amp = (float)p.amplification;          // the normalisation runs at the head of col_up_out (on its own or inside the first pyrUp)
     return LVM_OK;
 }
 
@@ -1338,8 +1385,20 @@ static void col_up_out(Ctx* c, ColorState* st, const FrameIO& io, const ColBufs&
                       (st->g[levels].w << (levels - 2)) >= 2 && (st->g[levels].h << (levels - 2)) >= 2 &&
                       io.in_stride > 0 && io.out_stride > 0 && (long)io.in_stride * io.h < (1L << 31) && (long)io.out_stride * io.h < (1L << 31);
     const bool fuse2 = lean;                      // k_col_out_strips makes the last TWO pyrUps itself
+    const int n_generic = levels - (fuse2 ? 1 : 0) - 1;            // generic pyrUp launches of the chain
+    // normalize(0, 1, NORM_MINMAX) x amplification (TemporalFilter.cpp:55, MagnifyCore.hpp:185): inside the first pyrUp when that is a
+    // k_pyr_up_rows launch, a kernel of its own otherwise (no generic pyrUp left, or the tiled pyrUp)
+    const int nL = (int)st->g[levels].n, live = nL * C;
+    const bool norm_in_up = st->norm_in_up && n_generic >= 1 && st->up_rows && (2 * uw) % 4 == 0;
+    if (!norm_in_up)
+        LVM_LAUNCH(c, "col_norm", k_col_norm, dim3((live + 255) / 256, c->nstreams * B.nt), blk, s, (const float*)B.col1, B.up[0], live, st->rows_ps,
+                   (const MinMax*)B.mm, st->amp);
     for (int k = 0; k + 1 < levels - (fuse2 ? 1 : 0); ++k) {      // L-1 generic pyrUps, the last one is fused into k_col_out (k_col_out_strips: the last two)
-        if (st->up_rows && (2 * uw) % 4 == 0) {      // barrier-free blocks of 4 x 2 outputs per lane (pyramid.h)
+        if (k == 0 && norm_in_up) {
+            const long ngroups = (long)(2 * uw / 4) * uh;
+            LVM_LAUNCH(c, "pyr_up_l0", k_pyr_up_rows_norm, dim3((unsigned)((ngroups + 255) / 256), planes), blk, s, (const float*)B.col1, st->rows_ps, C, uw, uh,
+                       B.up[1], (int)ngroups, (const MinMax*)B.mm, st->amp);
+        } else if (st->up_rows && (2 * uw) % 4 == 0) {      // barrier-free blocks of 4 x 2 outputs per lane (pyramid.h)
             const long ngroups = (long)(2 * uw / 4) * uh;
             LVM_LAUNCH(c, LName("pyr_up", k), k_pyr_up_rows<1>, dim3((unsigned)((ngroups + 255) / 256), planes), blk, s, (const float*)B.up[k], uw, uh,
                        B.up[k + 1], (int)ngroups);
@@ -1398,6 +1457,7 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         c->state = st;
         if (const char* e = std::getenv("LVM_COL_THIN_DFT")) st->thin_dft = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_COL_THIN8_DFT")) st->thin8_dft = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_COL_NORM_IN_UP")) st->norm_in_up = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_COL_UP_ROWS")) st->up_rows = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
