@@ -1586,7 +1586,7 @@ static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B,
     }
     for (int l = 0; l < nb; ++l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
-        if (st->split_rows && a.w % 4 == 0 && a.w >= 8 && (long)a.n * NZ >= st->split_rows_min) {
+        if (st->split_rows && a.w % 4 == 0 && a.w >= 8 && (long)a.n * NZ >= st->split_rows_min && (long)a.n * 4 < (1L << 31)) {   // (32-bit byte offsets inside a plane)
             // wave strips (no LDS), rows per strip by strip_rows_by_work: 32 frames of 1080p run 68-row strips -- 4096 strips of 81
             // steps, four waves on every SIMD (100 VGPRs).  LVM_RZ_SPLIT_STRIP overrides the choice.
             const int sx = (a.w / 4 + SR_OWN - 1) / SR_OWN;
@@ -1700,7 +1700,7 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
     // wave strips (k_rz_collapse_strips) for large launches on planes with even sizes and a width that is a multiple of 4
     auto strips_ok = [&](const LevelGeom& a, const LevelGeom& b) {
         return st->collapse_strips && a.w % 4 == 0 && a.w >= 8 && a.h % 2 == 0 && a.h >= 2 && b.w == a.w / 2 && b.h == a.h / 2 &&
-               (long)a.n * NZ >= st->collapse_strips_min;
+               (long)a.n * NZ >= st->collapse_strips_min && (long)a.n * 4 < (1L << 31);      // (32-bit byte offsets inside a plane)
     };
     auto strips_geom = [&](CollapseStripArgs& ca, const LevelGeom& a, const LevelGeom& b) {
         ca.w = a.w; ca.h = a.h; ca.nw = b.w; ca.nh = b.h;
