@@ -480,6 +480,10 @@ def main():
         vinfo = {"frames_compared": n_cmp, "timed_frames_compared": len([i for i in check if base <= i < base + K]),
                  "u8_max_diff": worst_du, "u8_identical_min": round(worst_frac, 6), "float_rel_err_probe": rel,
                  "bars": "u8 <= 1 LSB, >= 99.9 % identical; float <= 1e-4 of max|ref|", "oracle_frames_replayed": n_verify}
+        if not np.isfinite(float_gpu).all() or not np.isfinite(fl_ref).all():      # say where: a non-finite probe must be diagnosable from the record
+            bad = np.argwhere(~np.isfinite(float_gpu))
+            vinfo["float_nonfinite"] = {"gpu_count": int(len(bad)), "gpu_first": bad[:6].tolist(), "gpu_last": bad[-3:].tolist(),
+                                        "oracle_count": int((~np.isfinite(fl_ref)).sum()), "probe_frames": int(probe_n), "probe_first": int(probe_first)}
         ref_check = None
         if po.RefOracle.available():
             # the REAL reference stage (oracle/_ref/libref_magnify.so, built where OpenCV 4 exists): reported next to
