@@ -23,9 +23,15 @@ namespace {
 constexpr int kTab = 1024;
 
 // natural cubic spline through f[0..n]; 4 coefficients per interval (float arithmetic)
+// OpenCV's splineBuild never writes tab[4 (n - 1)] and tab[4 (n - 1) + 1] in its first sweep and READS them in the second: its
+// tables are static arrays, so it reads zeros.  Written here, because the caller's array need not be (until round 4 it was an
+// uninitialised stack array of lvm_create: whatever the stack held went into the top knots of the inverse-gamma table -- harmless for
+// the usual small junk, every pixel NaN when it happened to be a NaN pattern: one GPU test run in four inside a full pytest session,
+// never in isolation, found with -ftrivial-auto-var-init=pattern on the emulation build, tools/emu_uninit.sh).
 void spline_build(const float* f, int n, float* tab) {
     float cn = 0.f;
     tab[0] = tab[1] = 0.f;
+    tab[(n - 1) * 4] = tab[(n - 1) * 4 + 1] = 0.f;
     for (int i = 1; i < n - 1; ++i) {
         const float t = 3.f * (f[i + 1] - 2.f * f[i] + f[i - 1]);
         const float l = 1.f / (4.f - tab[(i - 1) * 4]);

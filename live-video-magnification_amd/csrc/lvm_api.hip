@@ -171,7 +171,7 @@ int lvm_create(int device, int n_streams, lvm_ctx** out) {
     c->device = device;
     c->nstreams = n_streams;
     { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) c->num_cus = n; }
-    float g[256], ig[4096];
+    float g[256] = {}, ig[4096] = {};
     lvm::build_lab_tables(g, ig, c->lab.fwd, c->lab.inv);
     for (int i = 0; i < 9; ++i) c->lab.inv1024[i] = c->lab.inv[i] * 1024.0f;
     bool ok = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;

@@ -64,8 +64,10 @@ struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
 static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+#ifndef __clang__        // (clang has both as builtins: tools/emu_uninit.sh builds this emulation with clang for -ftrivial-auto-var-init)
 template <class T> static inline T __builtin_nontemporal_load(const T* p) { return *p; }
 template <class T, class U> static inline void __builtin_nontemporal_store(U v, T* p) { *p = (T)v; }
+#endif
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
