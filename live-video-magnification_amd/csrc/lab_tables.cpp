@@ -65,7 +65,8 @@ void build_lab_tables(float gamma_u8[256], float invgamma[4096], float fwd[9], f
                                  0.041556, 0.055648, -0.204043, 1.057311};
     static const double D65[3] = {0.950456, 1.0, 1.088754};
     float f[kTab + 1], g[kTab + 1];
-    static float gam[kTab * 4];
+    std::vector<float> gam_v((size_t)kTab * 4, 0.f);     // (not static: two threads may create contexts at the same time)
+    float* gam = gam_v.data();
     // color_lab.cpp applyGamma / applyInvGamma: the argument and the binary32 constants (809/20000, 7827/2500000, 323/25,
     // 12/5, 11/200 as softfloat quotients) are promoted to softdouble, pow runs in binary64, ONE rounding to binary32
     const double thr = (double)(809.f / 20000.f), ithr = (double)(7827.f / 2500000.f), low = (double)(323.f / 25.f),
