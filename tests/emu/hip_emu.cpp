@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace hipemu {
@@ -87,9 +88,14 @@ void launch(const std::function<void()>& fn, dim3 grid, dim3 block) {
     }
     body = &fn;
     st.gdim = grid; st.bdim = block;
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-        for (unsigned by = 0; by < grid.y; ++by)
-            for (unsigned bx = 0; bx < grid.x; ++bx) {
+    // HIPEMU_ORDER=reverse: workgroups from the last to the first, and inside a workgroup the work-items from the last to the first
+    // between barriers -- a kernel whose result depends on the order (a missing barrier, a workgroup that reads what another one of the
+    // same launch writes) computes something else then.  Default: ascending.
+    static const bool reverse = [] { const char* e = std::getenv("HIPEMU_ORDER"); return e && std::string(e) == "reverse"; }();
+    for (unsigned bz0 = 0; bz0 < grid.z; ++bz0)
+        for (unsigned by0 = 0; by0 < grid.y; ++by0)
+            for (unsigned bx0 = 0; bx0 < grid.x; ++bx0) {
+                const unsigned bx = reverse ? grid.x - 1 - bx0 : bx0, by = reverse ? grid.y - 1 - by0 : by0, bz = reverse ? grid.z - 1 - bz0 : bz0;
                 st.bid = dim3(bx, by, bz);
                 for (unsigned t = 0; t < n; ++t) {
                     Fiber& f = fibers[t];
@@ -104,7 +110,8 @@ void launch(const std::function<void()>& fn, dim3 grid, dim3 block) {
                 unsigned alive = n;
                 while (alive) {
                     alive = 0;
-                    for (unsigned t = 0; t < n; ++t) {
+                    for (unsigned t0 = 0; t0 < n; ++t0) {
+                        const unsigned t = reverse ? n - 1 - t0 : t0;
                         Fiber& f = fibers[t];
                         if (f.done) continue;
                         cur = &f;
