@@ -10,6 +10,10 @@
 #include <string>
 #include <vector>
 
+#ifdef HIPEMU_POISON_LDS
+#include <cstring>
+extern "C" char __start_lds_emu, __stop_lds_emu;
+#endif
 namespace hipemu {
 namespace {
 std::mutex g_guard_mu;
@@ -97,6 +101,9 @@ void launch(const std::function<void()>& fn, dim3 grid, dim3 block) {
             for (unsigned bx0 = 0; bx0 < grid.x; ++bx0) {
                 const unsigned bx = reverse ? grid.x - 1 - bx0 : bx0, by = reverse ? grid.y - 1 - by0 : by0, bz = reverse ? grid.z - 1 - bz0 : bz0;
                 st.bid = dim3(bx, by, bz);
+#ifdef HIPEMU_POISON_LDS
+                std::memset(&__start_lds_emu, 0xFF, (size_t)(&__stop_lds_emu - &__start_lds_emu));
+#endif
                 for (unsigned t = 0; t < n; ++t) {
                     Fiber& f = fibers[t];
                     getcontext(&f.ctx);

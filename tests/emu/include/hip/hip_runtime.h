@@ -29,7 +29,13 @@ enum { hipStreamNonBlocking = 1 };
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
+#ifdef HIPEMU_POISON_LDS
+// Special build (tools/emu_lds_poison.sh): every __shared__ array lives in one linker section that the launcher fills with 0xFF (NaN as
+// float) before each workgroup -- on the GPU a workgroup finds whatever the previous one left in LDS.  Single-threaded use only.
+#define __shared__ static __attribute__((section("lds_emu")))
+#else
 #define __shared__ static thread_local
+#endif
 #define __launch_bounds__(...)
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 #define __builtin_unpredictable(x) (x)   // clang-only optimiser hint
