@@ -14,7 +14,7 @@ def test_emulation_results_do_not_depend_on_the_execution_order():
     env = dict(os.environ, HIPEMU_ORDER="reverse")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "tests/test_emu_parity.py", "tests/test_emu_bench_pattern.py", "-k",
                         "laplace_emu_bit_exact and 135 or riesz_emu_bit_exact and 135 or color_emu_bit_exact and 135 or temporal_batches and 64-48 "
-                        "or wave_strip_collapse and 512 or level1_fused_into_the_last_kernel or eight_lanes or poisoned_memory and size2"],
+                        "or wave_strip_collapse and 512 and 10 or level1_fused_into_the_last_kernel and 132 or eight_lanes and 0.8-1.6 or poisoned_memory and size2"],
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=1500)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "passed" in r.stdout

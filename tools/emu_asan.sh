@@ -7,11 +7,11 @@ set -e
 root=$(cd "$(dirname "$0")/.." && pwd); here=$root/tests/emu; src=$root/live-video-magnification_amd/csrc
 out=${LVM_ASAN_DIR:-/tmp/lvm_emu_asan}; mkdir -p "$out"
 for f in lvm_api.hip labconv.hip laplace.hip riesz.hip color.hip preprocess.hip compose.hip lab_tables.cpp; do
-  g++ -x c++ -std=c++17 -O1 -g -march=x86-64-v3 -ffp-contract=off -fPIC -DLVM_EXPERIMENTAL=1 -fsanitize=address --param asan-stack=0 \
+  g++ -x c++ -std=c++17 -O1 -g1 -march=x86-64-v3 -ffp-contract=off -fPIC -DLVM_EXPERIMENTAL=1 -fsanitize=address --param asan-stack=0 \
       -I"$here/include" -I"$root/include" -I"$src" -Wno-unused-function -c "$src/$f" -o "$out/$f.o" &
 done
 wait
-g++ -std=c++17 -O1 -g -fPIC -fsanitize=address --param asan-stack=0 -I"$here/include" -c "$here/hip_emu.cpp" -o "$out/hip_emu.o"
+g++ -std=c++17 -O1 -g1 -fPIC -fsanitize=address --param asan-stack=0 -I"$here/include" -c "$here/hip_emu.cpp" -o "$out/hip_emu.o"
 g++ -shared -fPIC -fsanitize=address -Wl,-Bsymbolic -o "$out/liblvm_emu.so" "$out"/*.o
 cd "$root"
 [ $# -gt 0 ] || set -- tests/test_emu_parity.py tests/test_emu_random.py tests/test_compose.py tests/test_preprocess.py -m "not gpu"
