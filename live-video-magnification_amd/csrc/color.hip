@@ -1049,7 +1049,7 @@ __device__ __forceinline__ void col_out_strip(const OutArgs& a, int b, int tx, i
             q.a = pack_u8x4(sxz[0][0], sxz[1][0], sxz[2][0], syw[0][0]);
             q.b = pack_u8x4(syw[1][0], syw[2][0], sxz[0][1], sxz[1][1]);
             q.c = pack_u8x4(sxz[2][1], syw[0][1], syw[1][1], syw[2][1]);
-            buf_st_b96(q, rout, xoff, (unsigned)gy * out_stride);
+            buf_sts_b96(q, rout, xoff, (unsigned)gy * out_stride);      // streaming store: the output frame is not read again on the device
         } else {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {

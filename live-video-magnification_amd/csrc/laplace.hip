@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void k_lap_up(UpArgs a) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) { rg[d][k] = Gn[soff[k]]; rc[d][k] = has_cur ? Cn[soff[k]] : 0.f; }
 #pragma unroll
-        for (int k = 0; k < NP; ++k) gl[d][k] = Gl[idx_r[k]];
+        for (int k = 0; k < NP; ++k) gl[d][k] = ld_stream_f32(Gl + idx_r[k]);   // (last reader of G_l: streaming load)
     }
     for (int t0 = 0; t0 < a.nt; t0 += D) {
 #pragma unroll
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void k_lap_up(UpArgs a) {
 #pragma unroll
                 for (int k = 0; k < NS; ++k) { rg[d][k] = Gn[soff[k]]; rc[d][k] = has_cur ? Cn[soff[k]] : 0.f; }
 #pragma unroll
-                for (int k = 0; k < NP; ++k) gl[d][k] = Gl[idx_r[k]];
+                for (int k = 0; k < NP; ++k) gl[d][k] = ld_stream_f32(Gl + idx_r[k]);   // (last reader of G_l: streaming load)
             }
             pyrup_hpass(h_g, s_g, x0, sx0, a.wn, a.w);
             if (has_cur) pyrup_hpass(h_c, s_c, x0, sx0, a.wn, a.w);
@@ -700,11 +700,8 @@ __device__ __forceinline__ void lap_emit_row(const Raw4 pin, const float (&m)[3]
             ov[3 * k + 2] = __builtin_fmaf(o2, 255.0f, lab.a255);
         }
     }
-    Px4 qo;
-    qo.a = pack_u8x4(ov[0], ov[1], ov[2], ov[3]);
-    qo.b = pack_u8x4(ov[4], ov[5], ov[6], ov[7]);
-    qo.c = pack_u8x4(ov[8], ov[9], ov[10], ov[11]);
-    *reinterpret_cast<Px4*>(out_px) = qo;
+    // (the output frame is not read again on the device: streaming store)
+    st_stream_b96(out_px, pack_u8x4(ov[0], ov[1], ov[2], ov[3]), pack_u8x4(ov[4], ov[5], ov[6], ov[7]), pack_u8x4(ov[8], ov[9], ov[10], ov[11]));
 }
 // one wave strip (task) of the last kernel; s_igt = inverse-gamma spline in LDS, s_gam = gamma table (analytic flavour)
 template <bool MOTION, bool DBG, int FL>     // DBG: also store the float frame (lvm_debug_keep_float); a per-pixel branch
@@ -761,10 +758,10 @@ __device__ __forceinline__ void lap_final_strip(const FinArgs& q, int task, int 
     // two output rows (2j, 2j+1) from the window rows A = j-1, B = j, C = j+1; afterwards A holds row
     // j+2, i.e. the window has rotated to (B, C, A).  Returns false when the strip is finished.
     auto step = [&](Row3& A, const Row3& B, const Row3& C) __attribute__((always_inline)) {
-        const Raw4 pe = load_raw4<PLANES>(src, in_stride, lp, poff, w, gy, (unsigned)gx);
+        const Raw4 pe = load_raw4<PLANES, true>(src, in_stride, lp, poff, w, gy, (unsigned)gx);
         const bool has_odd = gy + 1 < yend;
         Raw4 po = pe;
-        if (has_odd) po = load_raw4<PLANES>(src, in_stride, lp, poff, w, gy + 1, (unsigned)gx);
+        if (has_odd) po = load_raw4<PLANES, true>(src, in_stride, lp, poff, w, gy + 1, (unsigned)gx);
         float m[3][4] = {};
         if (MOTION) {
 #pragma unroll

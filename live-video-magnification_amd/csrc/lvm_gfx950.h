@@ -61,6 +61,91 @@ __device__ __forceinline__ void buf_st_b96(const B96& v, const BufRsrc& r, uint3
     __builtin_amdgcn_raw_buffer_store_b96(q, r, (int)(voff + soff), 0, 0);      // (offset in the vector register: see buf_st_f32x4)
 }
 
+// ---- streaming cache policy (round 5) ----
+// Data that a kernel reads ONCE or writes for a much later launch (planes of a 32-frame batch, output frames) carries the nontemporal
+// hint (`nt`): tools/ubench_stream.hip measured the byte mix of the last Laplace kernel (8 + 16 B in, 12 B out per lane) at 5.9 TB/s
+// with plain and 6.4-6.5 TB/s with nontemporal accesses on MI355X (profiles/r05_ubench_stream.txt), the strip skeleton of the same kernel
+// 9 % faster (tools/ubench_strips.hip).  -DLVM_NT=0 builds the plain forms (A/B measurements).
+#ifndef LVM_NT
+#define LVM_NT 1
+#endif
+constexpr int kAuxStream = LVM_NT ? 2 : 0;          // aux / cache-policy operand of the raw buffer builtins: bit 1 = nt on gfx950
+__device__ __forceinline__ float ld_stream_f32(const void* p) {
+#if LVM_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const float*>(p));
+#else
+    return *reinterpret_cast<const float*>(p);
+#endif
+}
+__device__ __forceinline__ uint2 ld_stream_u32x2(const void* p) {
+#if LVM_NT
+    const lvm_u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const lvm_u32x2*>(p));
+    return make_uint2(v.x, v.y);
+#else
+    return *reinterpret_cast<const uint2*>(p);
+#endif
+}
+__device__ __forceinline__ uint4 ld_stream_u32x4(const void* p) {
+#if LVM_NT
+    const lvm_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const lvm_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const uint4*>(p);
+#endif
+}
+__device__ __forceinline__ float4 ld_stream_f32x4(const void* p) {
+#if LVM_NT
+    const lvm_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const lvm_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+#else
+    return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void st_stream_b96(void* p, uint32_t a, uint32_t b, uint32_t c) {      // 4-byte aligned
+    typedef unsigned int u3a4 __attribute__((ext_vector_type(3), aligned(4)));
+    u3a4 q; q.x = a; q.y = b; q.z = c;
+#if LVM_NT
+    __builtin_nontemporal_store(q, reinterpret_cast<u3a4*>(p));
+#else
+    *reinterpret_cast<u3a4*>(p) = q;
+#endif
+}
+__device__ __forceinline__ void st_stream_f32x4(void* p, float a, float b, float c, float d) {
+    lvm_f32x4 q; q.x = a; q.y = b; q.z = c; q.w = d;
+#if LVM_NT
+    __builtin_nontemporal_store(q, reinterpret_cast<lvm_f32x4*>(p));
+#else
+    *reinterpret_cast<lvm_f32x4*>(p) = q;
+#endif
+}
+// the buffer-resource forms of the same
+__device__ __forceinline__ float buf_lds_f32(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, kAuxStream));
+}
+__device__ __forceinline__ B96 buf_lds_b96(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    const lvm_u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, (int)soff, kAuxStream);
+    return B96{v.x, v.y, v.z};
+}
+__device__ __forceinline__ float4 buf_lds_f32x4(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    const lvm_f32x4 v = __builtin_bit_cast(lvm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, kAuxStream));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ lvm_f2 buf_lds_f32x2(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    return __builtin_bit_cast(lvm_f2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, kAuxStream));
+}
+__device__ __forceinline__ void buf_sts_f32x4(float a, float b, float c, float d, const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    lvm_f32x4 q; q.x = a; q.y = b; q.z = c; q.w = d;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(lvm_u32x4, q), r, (int)(voff + soff), 0, kAuxStream);     // (offset in the vector register: see buf_st_f32x4)
+}
+__device__ __forceinline__ void buf_sts_f32x2(float a, float b, const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    lvm_f32x2 q; q.x = a; q.y = b;
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(lvm_u32x2, q), r, (int)voff, (int)soff, kAuxStream);
+}
+__device__ __forceinline__ void buf_sts_b96(const B96& v, const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    lvm_u32x3 q; q.x = v.a; q.y = v.b; q.z = v.c;
+    __builtin_amdgcn_raw_buffer_store_b96(q, r, (int)(voff + soff), 0, kAuxStream);
+}
+
 // ---- packed FP32: two floats in a register pair, one v_pk_{add,mul,fma}_f32 per operation (full rate on gfx950) ----
 __device__ __forceinline__ lvm_f2 f2_fma(lvm_f2 a, lvm_f2 b, lvm_f2 c) { return __builtin_elementwise_fma(a, b, c); }
 // A zero-instruction fence on VALUES: the operands pass through an empty asm statement, so everything that produces them is

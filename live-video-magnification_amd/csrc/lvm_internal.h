@@ -304,13 +304,13 @@ __device__ __forceinline__ void fetch_lab_px(const uint8_t* __restrict__ frame, 
 // A group of 4 adjacent pixels as loaded: u8 flavour d[0..2] = 12 bytes of BGR; plane flavour d[0..1] = 4 x iL,
 // d[2..5] = 4 x (ia | ib << 16).  (gx % 4 == 0, rows dword aligned.)
 struct Raw4 { uint32_t d[6]; };
-template <bool PLANES>
+template <bool PLANES, bool STREAM = false>     // STREAM: the planes are read once by this launch (nontemporal, lvm_gfx950.h)
 __device__ __forceinline__ Raw4 load_raw4(const uint8_t* __restrict__ frame, long in_stride, const LabPlanes& lp, size_t plane_off, int w, int gy, unsigned gx) {
     Raw4 r{};
     if (PLANES) {
         const size_t i = plane_off + (size_t)gy * w + gx;
-        const uint2 l = *reinterpret_cast<const uint2*>(lp.iL + i);
-        const uint4 ab = *reinterpret_cast<const uint4*>(lp.iab + i);
+        const uint2 l = STREAM ? ld_stream_u32x2(lp.iL + i) : *reinterpret_cast<const uint2*>(lp.iL + i);
+        const uint4 ab = STREAM ? ld_stream_u32x4(lp.iab + i) : *reinterpret_cast<const uint4*>(lp.iab + i);
         r.d[0] = l.x; r.d[1] = l.y; r.d[2] = ab.x; r.d[3] = ab.y; r.d[4] = ab.z; r.d[5] = ab.w;
     } else {
         struct __attribute__((packed, aligned(4))) P3 { uint32_t a, b, c; };

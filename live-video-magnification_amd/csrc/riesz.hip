@@ -644,10 +644,10 @@ __global__ __launch_bounds__(256) void k_rz_phase4(PhaseArgs aa) {
     float Pp[4] = {}, R1[4] = {}, R2[4] = {}, phc[4] = {}, phs[4] = {};
     float lo0c[4] = {}, lo0s[4] = {}, lo1c[4] = {}, lo1s[4] = {}, hi0c[4] = {}, hi0s[4] = {}, hi1c[4] = {}, hi1s[4] = {};
     auto ld4 = [&](const float* p, float (&o)[4]) __attribute__((always_inline)) {
-        const float4 v = *reinterpret_cast<const float4*>(p + idx); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        const float4 v = ld_stream_f32x4(p + idx); o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;      // (state: read once per launch)
     };
-    auto st4 = [&](float* p, size_t at, const float (&o)[4]) __attribute__((always_inline)) {
-        *reinterpret_cast<float4*>(p + at) = make_float4(o[0], o[1], o[2], o[3]);
+    auto st4 = [&](float* p, size_t at, const float (&o)[4]) __attribute__((always_inline)) {      // state / per-frame outputs: next read by a later launch
+        st_stream_f32x4(p + at, o[0], o[1], o[2], o[3]);
     };
     if (aa.mode == 0 && ok) {
         ld4(a.P, Pp); ld4(a.R1p, R1); ld4(a.R2p, R2); ld4(a.phc, phc); ld4(a.phs, phs);
@@ -1126,6 +1126,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_rz_blur_strips(BlurStripArgs aa)
     auto fetch = [&](int i) __attribute__((always_inline)) {
         const size_t ro = (size_t)reflect101(y0 - 6 + i, h) * w * sizeof(float);
         Raw6 r;
+        // (plain loads: the nontemporal form measured 505-510 -> 532 us per 32 frames here, round 5 -- strips re-read their neighbours' halo rows / columns)
         r.v[0] = *reinterpret_cast<const float*>(pamp + ro + o0); r.v[1] = *reinterpret_cast<const float*>(pamp + ro + o1);
         r.v[2] = *reinterpret_cast<const float*>(ptc + ro + o0); r.v[3] = *reinterpret_cast<const float*>(ptc + ro + o1);
         r.v[4] = *reinterpret_cast<const float*>(pts + ro + o0); r.v[5] = *reinterpret_cast<const float*>(pts + ro + o1);
@@ -1384,7 +1385,7 @@ __device__ __forceinline__ void collapse_emit(float L0, float L1, float L2, floa
     v.a = pack_u8x4(t[0][0], t[0][1], t[0][2], t[1][0]);
     v.b = pack_u8x4(t[1][1], t[1][2], t[2][0], t[2][1]);
     v.c = pack_u8x4(t[2][2], t[3][0], t[3][1], t[3][2]);
-    buf_st_b96(v, ro, voff, soff);
+    buf_sts_b96(v, ro, voff, soff);                 // (the output frame is not read again on the device: streaming store)
 }
 template <bool FINAL, int FL, bool DBG>
 __global__ __launch_bounds__(CS_THREADS, 3) void k_rz_collapse_strips(CollapseStripArgs a) {
@@ -1446,7 +1447,7 @@ __global__ __launch_bounds__(CS_THREADS, 3) void k_rz_collapse_strips(CollapseSt
         if (!EVEN) { const lvm_f2 c = buf_ld_f32x2(rc, lcoarse, (uint32_t)(ry >> 1) * (uint32_t)nw * 4u); nxtc = make_float2(c[0], c[1]); }   /* that row is even */ \
         if (FINAL) {                                                /* (a, b) of output row y0 - 7 + q: complete one step from now */ \
             const int orow = y0 - 7 + q;                                                                            \
-            nxti = buf_ld_f32x4(ri, lband, (uint32_t)(orow < 0 ? 0 : (orow > h - 1 ? h - 1 : orow)) * (uint32_t)w * 4u);   \
+            nxti = buf_lds_f32x4(ri, lband, (uint32_t)(orow < 0 ? 0 : (orow > h - 1 ? h - 1 : orow)) * (uint32_t)w * 4u);   \
         }                                                                                                           \
         lvm_issue_fence();                                                                                          \
         lvm_f2 V[6], W[5];                                                                                          \

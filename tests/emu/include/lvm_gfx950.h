@@ -52,6 +52,20 @@ __device__ __forceinline__ void buf_st_b96(const B96& v, const BufRsrc& r, uint3
     const uint64_t o = (uint64_t)voff + soff;
     if (o + 12 <= r.bytes) std::memcpy(r.base + o, &v, 12);
 }
+// streaming (nontemporal) forms: a cache hint only -- the plain accesses here
+__device__ __forceinline__ float ld_stream_f32(const void* p) { float v; std::memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint2 ld_stream_u32x2(const void* p) { uint2 v; std::memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ uint4 ld_stream_u32x4(const void* p) { uint4 v; std::memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ float4 ld_stream_f32x4(const void* p) { float4 v; std::memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ void st_stream_b96(void* p, uint32_t a, uint32_t b, uint32_t c) { const uint32_t v[3] = {a, b, c}; std::memcpy(p, v, 12); }
+__device__ __forceinline__ void st_stream_f32x4(void* p, float a, float b, float c, float d) { const float v[4] = {a, b, c, d}; std::memcpy(p, v, 16); }
+__device__ __forceinline__ float buf_lds_f32(const BufRsrc& r, uint32_t voff, uint32_t soff) { return buf_ld_f32(r, voff, soff); }
+__device__ __forceinline__ B96 buf_lds_b96(const BufRsrc& r, uint32_t voff, uint32_t soff) { return buf_ld_b96(r, voff, soff); }
+__device__ __forceinline__ float4 buf_lds_f32x4(const BufRsrc& r, uint32_t voff, uint32_t soff) { return buf_ld_f32x4(r, voff, soff); }
+__device__ __forceinline__ lvm_f2 buf_lds_f32x2(const BufRsrc& r, uint32_t voff, uint32_t soff) { return buf_ld_f32x2(r, voff, soff); }
+__device__ __forceinline__ void buf_sts_f32x4(float a, float b, float c, float d, const BufRsrc& r, uint32_t voff, uint32_t soff) { buf_st_f32x4(a, b, c, d, r, voff, soff); }
+__device__ __forceinline__ void buf_sts_f32x2(float a, float b, const BufRsrc& r, uint32_t voff, uint32_t soff) { buf_st_f32x2(a, b, r, voff, soff); }
+__device__ __forceinline__ void buf_sts_b96(const B96& v, const BufRsrc& r, uint32_t voff, uint32_t soff) { buf_st_b96(v, r, voff, soff); }
 __device__ __forceinline__ lvm_f2 f2_fma(lvm_f2 a, lvm_f2 b, lvm_f2 c) { lvm_f2 v = {__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1])}; return v; }
 __device__ __forceinline__ void lvm_pin(lvm_f2&, lvm_f2&) {}
 __device__ __forceinline__ void lvm_pin(float&, float&) {}
