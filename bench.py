@@ -49,7 +49,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MODES = {"laplace": 1, "riesz": 2, "color": 3}  # -> BASELINE.json configs index
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def level_sizes(w, h, levels):
@@ -377,6 +377,7 @@ def main():
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    host_binding = bind_to_gpu_numa_node(torch, local_rank)
     dist = None
     # One rank per GPU under the launcher (torch.distributed.run sets WORLD_SIZE, also for --nproc-per-node 1): the process
     # group exists at EVERY world size then, so that the barrier and the MAX-reduce of the timed region run through RCCL
@@ -528,76 +529,18 @@ def main():
     if args.profile_steps < 0:
         args.profile_steps = 2 * T if T > 1 else 60        # whole calls only: every launch then covers exactly T frames
     if rank == 0 and args.profile_steps > 0:
-        R.ctx.flush(stream)
-        R.ctx.set_pipeline(0)           # per-kernel event timing uses the plain schedule
-        R.run((-R.n) % T)               # whole calls
-        R.run(2 * T if T > 1 else 60)   # un-timed: the oracle replay above left the GPU idle for seconds, let the clocks settle
-        R.ramp(args.ramp_ms * 1e-3)
-        R.ctx.profile(True)
-        R.run(args.profile_steps)
-        torch.cuda.synchronize()
-        prof = R.ctx.profile_collect()
-        R.ctx.profile(False)
-        tot = sum(v[0] for v in prof.values()) or 1.0
-        T_launch = min(T, 32) if args.mode == "color" else T     # the colour mode cuts a call into chunks of <= 32 frames
-        for name, (ms, cnt) in prof.items():
-            avg_us = 1e3 * ms / max(cnt, 1)
-            ab = kernel_alg_bytes(args.mode, name, w, h, ch, levels, B, T_launch, Twin)
-            kernels[name] = {"avg_us": round(avg_us, 3), "launches": cnt, "share": round(ms / tot, 4),
-                             "alg_bytes": ab, "gbs": (round(ab / (avg_us * 1e-6) / 1e9, 1) if ab else None)}
-        dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
-        k = kernels[dom]
-        # the dominant kernel once more with ONLY its launches bracketed: its neighbours then run back to back as in the
-        # timed region (and under rocprofv3); with an event gap on both sides the VALU-bound kernels run ~10 % faster
-        # (the clock recovers in the gaps), which is not the duration the frame pays for
-        R.ctx.profile_only(dom)
-        R.ctx.profile(True)
-        R.run(args.profile_steps)
-        torch.cuda.synchronize()
-        solo = R.ctx.profile_collect().get(dom)
-        R.ctx.profile(False)
-        R.ctx.profile_only(None)
-        k = dict(k)
-        k["avg_us_all_bracketed"] = k["avg_us"]
-        if solo and solo[1]:
-            k["avg_us"] = round(1e3 * solo[0] / solo[1], 3)
-            k["gbs"] = round(k["alg_bytes"] / (k["avg_us"] * 1e-6) / 1e9, 1) if k["alg_bytes"] else None
-        # HBM bytes per launch from the PMC counters (separate rocprofv3 passes, committed under profiles/)
-        # STORED values (a bench run cannot wrap itself in rocprofv3): tools/pmc_traffic.py ran this very command under
-        # `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE in separate passes), applied the calibration factors of
-        # tools/hbm_counter_calib.hip and wrote the file below; a figure under the kernel's compulsory bytes is not printed
-        traffic = None
-        rocprof_avg = None
-        traffic_src = "profiles/%s_pmc_traffic_%s.json" % (PROFILE_ROUND, args.mode)
-        try:
-            pm = json.load(open(os.path.join(ROOT, traffic_src)))
-            if pm.get("key") == "%s|%dx%d|L%d|B%d|T%d" % (args.mode, w, h, levels, B, T):
-                traffic = pm["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
-                rocprof_avg = pm["kernels"].get(dom, {}).get("rocprof_avg_us")
-                if traffic is not None and k["alg_bytes"] and traffic < 0.97 * k["alg_bytes"]:
-                    traffic = None          # cache hits can hide re-reads, never compulsory bytes: an uncalibrated counter
-        except Exception:
-            traffic = None
-        if k["gbs"]:
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(k["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "avg_us": k["avg_us"], "avg_us_all_kernels_bracketed": k["avg_us_all_bracketed"],
-                        "timing": "HIP events on the launch stream around this kernel only (neighbours back to back)",
-                        "alg_bytes_per_launch": k["alg_bytes"],
-                        "traffic_source": ("stored: %s (rocprofv3 --pmc passes of this command, calibrated, tools/pmc_traffic.py)" % traffic_src)
-                                          if traffic is not None else None}
-            if dom in ("lap_down0_lut", "lab_lut"):
-                roofline["limiter"] = ("OpenCV's forward Lab table: 8 random LDS reads + one 16-byte gather from L2 + ~80 VALU "
-                                       "operations per pixel (lab_lut.h); HBM idles")
-            if rocprof_avg is not None:
-                roofline["rocprof_avg_us_stored"] = rocprof_avg
+        kernels, roofline = kernel_pass(lvm, torch, R, args.mode, args.profile_steps, args.ramp_ms * 1e-3)
     b_alg = lvm.load().lvm_algorithmic_bytes(pk["mode"], w, h, ch, levels, pk["framerate"])
     frame_frac = b_alg * (fps / world / B) / (HBM_PEAK_GBS * 1e9)
     b_bat = batched_frame_bytes(args.mode, w, h, ch, levels, T, Twin)
+    if roofline is not None:
+        roofline["frame_frac"] = round(frame_frac, 5)      # SURVEY.md 8d's figure for the WHOLE path next to the dominant kernel's own
+        roofline["frame_frac_definition"] = "B_alg x frames/s / peak: compulsory bytes of the reference algorithm per frame (no credit for intermediates)"
+        roofline["frame_alg_bytes"] = b_alg
 
     # ---- gather per-rank facts (tests check value == world * B * K / max dt and every rank's verification) ----
     props = torch.cuda.get_device_properties(local_rank)
-    rank_facts = [{"rank": rank, "verified": verified, "verification": vinfo, "stream_ids": ids, "device": "cuda:%d" % local_rank,
+    rank_facts = [{"rank": rank, "verified": verified, "verification": vinfo, "stream_ids": ids, "device": "cuda:%d" % local_rank, "host_binding": host_binding,
                    "device_name": props.name, "device_uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()}]
     if dist is not None:
         gathered = [None] * world
@@ -607,19 +550,32 @@ def main():
     del R
     torch.cuda.empty_cache()
 
+    # ---- the timed region's own shape once more WITHOUT the clock ramp (a GPU a few milliseconds out of idle) ----
+    value_cold = None
+    if not args.no_subrecords:
+        Rc = Runner(lvm, torch, np, cfg_idx, small, B, ring, T, local_rank, ids, ring)
+        Rc.ctx.set_pipeline(args.pipeline)
+        dtc = timed_run(lvm, torch, Rc, K, W, dist, red_dev, ramp=0.0)
+        value_cold = {"value": round(lvm.sharding.aggregate_fps(world, B, K, dtc), 2), "unit": "frames/s", "steps": K, "warmup": W, "ramp_ms": 0.0,
+                      "note": "same call shape as `value`, priming + warm-up only: the clocks have not ramped"}
+        Rc.close()
+        del Rc
+        torch.cuda.empty_cache()
+
     # ---- sub-records: the other schedules / surfaces SURVEY.md 8d asks for, measured in the same run ----
     sub = {}
     if do_sub:
         sub = sub_records(lvm, torch, np, args, cfg_idx, small, local_rank, rank, world, dist, red_dev)
     elif world > 1:
-        sub = {"cfg4_riesz_4k": cfg4_record(lvm, torch, np, local_rank, rank, world, dist, red_dev)}
+        sub = {"cfg4_riesz_4k": config_record(lvm, torch, np, 4, local_rank, rank, world, dist, red_dev, K=64, W=16, T=16, ring=16, extras=False),
+               "host_fed": host_fed_record(lvm, torch, np, cfg_idx, small, local_rank, rank, world, dist, red_dev)}
 
     if rank == 0:
         out = {
             "metric": "magnified frames/sec at 1080p, Laplace-motion 6 levels; % HBM roofline" if args.mode == "laplace"
                       else "magnified frames/sec (%s)" % args.mode,
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(1e3 * dt / K, 5),
+            "ms_per_step": round(1e3 * dt / K, 5), "value_cold": value_cold,
             "host_enqueue_ms_per_step": round(1e3 * host_enqueue / K, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if CLIP_NOISE is None else "synthetic (clip noise +-%g levels instead of +-12)" % CLIP_NOISE,
             "config": {"workload": "%s %dx%d, %d levels, %d stream(s)/GPU, device-resident u8 BGR in/out" %
@@ -640,6 +596,81 @@ def main():
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()
+
+
+def kernel_pass(lvm, torch, R, mode, profile_steps, ramp_s):
+    """Per-kernel HIP-event pass over `profile_steps` frames of R's schedule (whole calls) -> (kernel table, roofline of the
+    dominant kernel).  `achieved` = the kernel's algorithmic bytes per launch (kernel_alg_bytes) / its average duration with ONLY
+    its own launches bracketed; `traffic` / `rocprof_avg_us_stored` are STORED values of the rocprofv3 passes of the same command
+    (profiles/<round>_pmc_traffic_<mode>.json, tools/pmc_traffic.py: FETCH_SIZE and WRITE_SIZE in separate passes, calibrated with
+    tools/hbm_counter_calib.hip) -- a bench run cannot wrap itself in rocprofv3."""
+    w, h, ch, levels, B, T, pk = R.w, R.h, R.ch, R.levels, R.B, R.T, R.pk
+    stream = R.stream
+    Twin = lvm.load().lvm_optimal_buffer_size(int(pk["framerate"]))
+    kernels = {}
+    roofline = None
+    R.ctx.flush(stream)
+    R.ctx.set_pipeline(0)           # per-kernel event timing uses the plain schedule
+    R.run((-R.n) % T)               # whole calls
+    R.run(2 * T if T > 1 else 60)   # un-timed: an oracle replay may have left the GPU idle for seconds, let the clocks settle
+    R.ramp(ramp_s)
+    R.ctx.profile(True)
+    R.run(profile_steps)
+    torch.cuda.synchronize()
+    prof = R.ctx.profile_collect()
+    R.ctx.profile(False)
+    if not prof:
+        return kernels, roofline
+    tot = sum(v[0] for v in prof.values()) or 1.0
+    T_launch = min(T, 32) if mode == "color" else T     # the colour mode cuts a call into chunks of <= 32 frames
+    for name, (ms, cnt) in prof.items():
+        avg_us = 1e3 * ms / max(cnt, 1)
+        ab = kernel_alg_bytes(mode, name, w, h, ch, levels, B, T_launch, Twin)
+        kernels[name] = {"avg_us": round(avg_us, 3), "launches": cnt, "share": round(ms / tot, 4),
+                         "alg_bytes": ab, "gbs": (round(ab / (avg_us * 1e-6) / 1e9, 1) if ab else None)}
+    dom = max(prof.items(), key=lambda kv: kv[1][0])[0]
+    k = kernels[dom]
+    # the dominant kernel once more with ONLY its launches bracketed: its neighbours then run back to back as in the
+    # timed region (and under rocprofv3); with an event gap on both sides the VALU-bound kernels run ~10 % faster
+    # (the clock recovers in the gaps), which is not the duration the frame pays for
+    R.ctx.profile_only(dom)
+    R.ctx.profile(True)
+    R.run(profile_steps)
+    torch.cuda.synchronize()
+    solo = R.ctx.profile_collect().get(dom)
+    R.ctx.profile(False)
+    R.ctx.profile_only(None)
+    k = dict(k)
+    k["avg_us_all_bracketed"] = k["avg_us"]
+    if solo and solo[1]:
+        k["avg_us"] = round(1e3 * solo[0] / solo[1], 3)
+        k["gbs"] = round(k["alg_bytes"] / (k["avg_us"] * 1e-6) / 1e9, 1) if k["alg_bytes"] else None
+    traffic = None
+    rocprof_avg = None
+    traffic_src = "profiles/%s_pmc_traffic_%s%s.json" % (PROFILE_ROUND, mode, "" if (w, h) == (1920, 1080) else "_%dx%d" % (w, h))
+    try:
+        pm = json.load(open(os.path.join(ROOT, traffic_src)))
+        if pm.get("key") == "%s|%dx%d|L%d|B%d|T%d" % (mode, w, h, levels, B, T):
+            traffic = pm["kernels"].get(dom, {}).get("hbm_bytes_per_launch")
+            rocprof_avg = pm["kernels"].get(dom, {}).get("rocprof_avg_us")
+            if traffic is not None and k["alg_bytes"] and traffic < 0.97 * k["alg_bytes"]:
+                traffic = None          # cache hits can hide re-reads, never compulsory bytes: an uncalibrated counter
+    except Exception:
+        traffic = None
+    if k["gbs"]:
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": k["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(k["gbs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "avg_us": k["avg_us"], "avg_us_all_kernels_bracketed": k["avg_us_all_bracketed"],
+                    "timing": "HIP events on the launch stream around this kernel only (neighbours back to back)",
+                    "alg_bytes_per_launch": k["alg_bytes"], "frames_per_launch": T_launch,
+                    "traffic_source": ("stored: %s (rocprofv3 --pmc passes of this command, calibrated, tools/pmc_traffic.py)" % traffic_src)
+                                      if traffic is not None else None}
+        if dom in ("lap_down0_lut", "lab_lut"):
+            roofline["limiter"] = ("OpenCV's forward Lab table: 8 random LDS reads + one 16-byte gather from L2 + ~80 VALU "
+                                   "operations per pixel (lab_lut.h); HBM idles")
+        if rocprof_avg is not None:
+            roofline["rocprof_avg_us_stored"] = rocprof_avg
+    return kernels, roofline
 
 
 def probe_reference():
@@ -671,26 +702,184 @@ def timed_run(lvm, torch, R, K, W, dist, red_dev, ramp=None):
     return dt
 
 
-def cfg4_record(lvm, torch, np, local_rank, rank, world, dist, red_dev, K=64, W=16, T=16):
-    """BASELINE.json configs[4]: Riesz 3840x2160, 8 levels, one stream per GPU (seed 1234 + rank)."""
-    R = Runner(lvm, torch, np, 4, None, 1, 16, T, local_rank, lvm.sharding.stream_ids(rank, world, 1), 16)
-    dt = timed_run(lvm, torch, R, K, W, dist, red_dev)
-    b_alg = lvm.load().lvm_algorithmic_bytes(R.pk["mode"], R.w, R.h, R.ch, R.levels, R.pk["framerate"])
+def per_frame_records(lvm, torch, np, cfg_idx, small, local_rank, ids, world, dist, red_dev, streams=(1, 4), K=None):
+    """The schedule MagnificationProcessor::process really runs (MagnificationProcessor.cpp:17-67): ONE frame per call (T = 1), every
+    temporal state word read and written every frame; B independent streams per launch (B in {1, 4, 16}).
+    Device-resident frames.  Returns {"B1": {...}, "B4": {...}, ...}."""
+    out = {}
+    for Bn in streams:
+        R = Runner(lvm, torch, np, cfg_idx, small, Bn, 32 if Bn == 1 else 16, 1, local_rank, ids, 32 if Bn == 1 else 16, time_shift=Bn > 1)
+        big = R.w * R.h > 1920 * 1080
+        Kq = K or ((300 if Bn == 1 else 120) if not big else 48)
+        dt = timed_run(lvm, torch, R, Kq, 16, dist, red_dev)
+        v = world * Bn * Kq / dt
+        b_alg = lvm.load().lvm_algorithmic_bytes(R.pk["mode"], R.w, R.h, R.ch, R.levels, R.pk["framerate"])
+        out["B%d" % Bn] = {"schedule": "T = 1: one lvm_process_device call per frame, device-resident", "value": round(v, 2), "unit": "frames/s",
+                           "streams": Bn, "frames_per_call": 1, "steps": Kq, "us_per_frame": round(1e6 * dt / (Kq * Bn), 3),
+                           "host_enqueue_us_per_frame": round(1e6 * lvm.sharding.timed_steps.host_seconds / (Kq * Bn), 2),
+                           "frame_alg_bytes": b_alg, "frame_roofline_frac": round(b_alg * v / world / (HBM_PEAK_GBS * 1e9), 5)}
+        R.close()
+        del R
+        torch.cuda.empty_cache()
+    return out
+
+
+def e2e_host_record(lvm, np, ctx, cp_ref, host, kinds=("pageable", "pinned"), Ke=150, warm=20):
+    """host u8 frame in -> host u8 frame out through lvm_process (the drop-in surface), one frame in flight."""
+    lib = lvm.load()
+    _, h, w, ch = host.shape
+    fb = h * w * ch
+    e2e = {}
+    for kind in kinds:
+        staged = kind == "pageable_staged_through_pinned"   # what a pinned staging buffer INSIDE lvm_process would cost: two memcpys
+        if kind != "pageable":
+            pin, pout = C.c_void_p(), C.c_void_p()
+            if lib.lvm_host_alloc(fb * 8, C.byref(pin)) != 0 or lib.lvm_host_alloc(fb, C.byref(pout)) != 0:
+                continue
+            src = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(8, h, w, ch))
+            dst = np.ctypeslib.as_array(C.cast(pout, C.POINTER(C.c_uint8)), shape=(h, w, ch))
+            src[:] = host[:8]
+            if staged:
+                pg_src, pg_dst = host[:8].copy(), np.empty((h, w, ch), np.uint8)
+        else:
+            src = host[:8].copy()
+            dst = np.empty((h, w, ch), np.uint8)
+        produced = C.c_int(0)
+        fn = lib.lvm_process
+        ptrs = [src[i].ctypes.data for i in range(8)]
+        po_ = dst.ctypes.data
+        ctx.reset()
+        for i in range(warm):           # (colour mode: until the rolling window is full)
+            fn(ctx.h, cp_ref, ptrs[i % 8], w, h, ch, w * ch, po_, w * ch, C.byref(produced))
+        t0 = time.perf_counter()
+        for i in range(Ke):
+            if staged:
+                np.copyto(src[i % 8], pg_src[i % 8])
+            rc = fn(ctx.h, cp_ref, ptrs[i % 8], w, h, ch, w * ch, po_, w * ch, C.byref(produced))
+            if rc != 0:
+                ctx._check(rc)
+            if staged:
+                np.copyto(pg_dst, dst)
+        de = time.perf_counter() - t0
+        e2e[kind] = {"value": round(Ke / de, 2), "unit": "frames/s", "us_per_frame": round(1e6 * de / Ke, 1),
+                     "pcie_bytes_per_frame": 2 * fb, "pcie_gbs": round(2 * fb * Ke / de / 1e9, 2)}
+        if kind != "pageable":
+            del src, dst
+            lib.lvm_host_free(pin); lib.lvm_host_free(pout)
+    return dict(e2e, surface="lvm_process: host u8 in -> host u8 out, synchronous (upload, kernels and download of ONE frame overlap "
+                             "row-chunk by row-chunk; replaces MagnificationProcessor::process, MagnificationProcessor.cpp:17-67)")
+
+
+def export_host_record(lvm, np, local_rank, cp_ref, host, Te=32, Kx=6):
+    """lvm_export_frames: Te page-locked host frames in, Te side-by-side canvases out per call (the loop body of Exporter::run,
+    Exporter.cpp:216-259: runChainOnce + compose); uploads, kernels and downloads of consecutive sub-batches overlap."""
+    try:
+        lib = lvm.load()
+        _, h, w, ch = host.shape
+        fb = h * w * ch
+        cpre = lvm.LvmPreprocessParams(1, 0, 0.0, 0.0, 1.0, 1.0, 0)
+        cw, chh = C.c_int(0), C.c_int(0)
+        lib.lvm_export_geometry(C.byref(cpre), 1, w, h, ch, C.byref(cw), C.byref(chh))
+        cb = cw.value * chh.value * 3
+        pin, pout = C.c_void_p(), C.c_void_p()
+        if not (cb > 0 and lib.lvm_host_alloc(fb * Te, C.byref(pin)) == 0 and lib.lvm_host_alloc(cb * Te, C.byref(pout)) == 0):
+            return {"error": "page-locked allocation failed"}
+        src = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(Te, h, w, ch))
+        for i in range(Te):
+            src[i] = host[i % host.shape[0]]
+        vp = C.c_void_p
+        pi = (vp * Te)(*[pin.value + i * fb for i in range(Te)])
+        pc = (vp * Te)(*[pout.value + i * cb for i in range(Te)])
+        prod = (C.c_int * Te)()
+        ex = lvm.Context(local_rank, 1)
+        ex.set_max_frames(Te)
+        for _ in range(2):
+            ex._check(lib.lvm_export_frames(ex.h, C.byref(cpre), cp_ref, 1, Te, pi, w, h, ch, w * ch, pc, cw.value * 3, prod))
+        t0 = time.perf_counter()
+        for _ in range(Kx):
+            ex._check(lib.lvm_export_frames(ex.h, C.byref(cpre), cp_ref, 1, Te, pi, w, h, ch, w * ch, pc, cw.value * 3, prod))
+        dx = time.perf_counter() - t0
+        ex.close()
+        del src
+        lib.lvm_host_free(pin); lib.lvm_host_free(pout)
+        return {"value": round(Kx * Te / dx, 2), "unit": "frames/s", "frames_per_call": Te, "us_per_frame": round(1e6 * dx / (Kx * Te), 1),
+                "pcie_bytes_per_frame": fb + cb, "pcie_gbs": round((fb + cb) * Kx * Te / dx / 1e9, 2),
+                "surface": "lvm_export_frames: pinned host frames in -> side-by-side canvases (original | processed) out; replaces the loop "
+                           "body of Exporter::run (Exporter.cpp:216-259: runChainOnce + compose), host/HipExportRunner.hpp is the loop"}
+    except Exception as e:      # a sub-record must never take the headline line down
+        return {"error": str(e)[:200]}
+
+
+def bind_to_gpu_numa_node(torch, local_rank):
+    """One rank per GPU: pin this process (and the threads it starts) to the CPUs of the NUMA node its GPU hangs off, so that
+    page-locked frame buffers are allocated there and the PCIe DMA does not cross the socket interconnect (the
+    host-fed aggregate is limited by host feeding / PCIe).  Returns what was done, for the JSON line."""
+    info = {"bound": False}
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        base = "/sys/bus/pci/devices/" + bdf
+        info["pci"] = bdf
+        node = int(open(base + "/numa_node").read().strip())
+        info["numa_node"] = node
+        cpulist = open(base + "/local_cpulist").read().strip()
+        cpus = set()
+        for part in cpulist.split(","):
+            if "-" in part:
+                a, b = part.split("-")
+                cpus.update(range(int(a), int(b) + 1))
+            elif part:
+                cpus.add(int(part))
+        allowed = os.sched_getaffinity(0)
+        cpus &= allowed
+        if cpus and os.environ.get("LVM_BENCH_BIND", "1") != "0":
+            os.sched_setaffinity(0, cpus)
+            info.update(bound=True, cpus=len(cpus), cpulist=cpulist)
+    except Exception as e:      # no sysfs in the container, no such attribute: run unbound and say so
+        info["note"] = "not bound: %s" % str(e)[:120]
+    return info
+
+
+def host_fed_record(lvm, torch, np, cfg_idx, small, local_rank, rank, world, dist, red_dev):
+    """N > 1: the host-fed surfaces on EVERY rank at the same time (north_star's ">= 6x at 8 GPUs" is limited by host feeding and
+    PCIe, SURVEY.md 8e -- device-resident streams cannot show that): each rank, bound to its GPU's NUMA node, runs lvm_process on
+    page-locked frames and lvm_export_frames on 32-frame batches between barriers; rank 0 reports the aggregate and the per-rank
+    PCIe rates."""
+    ids = lvm.sharding.stream_ids(rank, world, 1)
+    R = Runner(lvm, torch, np, cfg_idx, small, 1, 32, 1, local_rank, ids, 32)
+    host = R.d_in[:, 0].cpu().numpy()
+    if dist is not None:
+        dist.barrier()
+    e2e = e2e_host_record(lvm, np, R.ctx, R.p_ref, host, kinds=("pinned",), Ke=120)
+    if dist is not None:
+        dist.barrier()
+    ex = export_host_record(lvm, np, local_rank, R.p_ref, host, Kx=4)
     R.close()
-    fps = world * K / dt
-    return {"workload": "riesz 3840x2160, 8 levels, 1 stream per GPU, %d frames per call" % T, "value": round(fps, 2), "unit": "frames/s",
-            "n_gpus": world, "steps": K, "ms_per_step": round(1e3 * dt / K, 4), "frame_alg_bytes": b_alg,
-            "frame_roofline_frac": round(b_alg * fps / world / (HBM_PEAK_GBS * 1e9), 5)}
+    mine = {"rank": rank, "e2e_fps": e2e.get("pinned", {}).get("value"), "e2e_pcie_gbs": e2e.get("pinned", {}).get("pcie_gbs"),
+            "export_fps": ex.get("value"), "export_pcie_gbs": ex.get("pcie_gbs")}
+    allr = [mine]
+    if dist is not None:
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+    tot = lambda k: round(sum((r.get(k) or 0.0) for r in allr), 2)      # noqa: E731
+    return {"note": "every rank runs the host -> host surfaces concurrently (own context, own GPU, own page-locked buffers)",
+            "e2e_host_pinned": {"value": tot("e2e_fps"), "unit": "frames/s", "pcie_gbs_total": tot("e2e_pcie_gbs")},
+            "export_host": {"value": tot("export_fps"), "unit": "frames/s", "pcie_gbs_total": tot("export_pcie_gbs")},
+            "per_rank": allr}
 
 
-def other_mode_record(lvm, torch, np, cfg_idx, local_rank, rank, world, dist, red_dev, K=64, W=32, T=32):
-    """BASELINE configs[2] / configs[3] (Riesz / Color at 1920x1080, 6 levels) in the same run as the headline, so that the
-    driver's record carries them: K timed frames in calls of T, and -- on rank 0 -- the timed region's own output
-    against the CPU oracle (8 frames, u8 bars)."""
+def config_record(lvm, torch, np, cfg_idx, local_rank, rank, world, dist, red_dev, K=64, W=32, T=32, ring=64, extras=True, clip_tag=""):
+    """One of BASELINE.json's configs measured in the same run as the headline, so that the driver's record carries it:
+    configs[2] / configs[3] (Riesz / Color at 1920x1080, 6 levels) and configs[4] (Riesz 3840x2160, 8 levels, one stream per GPU;
+    at every N).  K timed frames in calls of T on every rank (MAX over ranks); on rank 0 also: the timed region's own output
+    against the CPU oracle (>= 8 frames, u8 bars) -> `verified`, the replay's rate -> `cpu_baseline`, the per-kernel HIP-event pass
+    -> `roofline` (dominant kernel; `frame_frac` = SURVEY 8d's B_alg x fps / peak), and -- `extras` -- the per-frame schedule
+    (T = 1, B = 1 / 4) and the host -> host surface (lvm_process)."""
     ids = lvm.sharding.stream_ids(rank, world, 1)
     pk = lvm.synth.config(cfg_idx)[1]
     total = prime_total(lvm, pk, T, K, W) + K
-    R = Runner(lvm, torch, np, cfg_idx, None, 1, 64, T, local_rank, ids, total if rank == 0 else 64)
+    R = Runner(lvm, torch, np, cfg_idx, None, 1, ring, T, local_rank, ids, total if rank == 0 else ring)
+    mode = {lvm.synth.MODE_LAPLACE: "laplace", lvm.synth.MODE_PHASE: "riesz", lvm.synth.MODE_COLOR: "color"}[R.pk["mode"]]
     R.prime(K, W)
     R.run(W)
     base = R.n
@@ -698,14 +887,19 @@ def other_mode_record(lvm, torch, np, cfg_idx, local_rank, rank, world, dist, re
     dt = lvm.sharding.timed_steps(lambda i: R.run(K), 1, dist, torch.cuda.synchronize, red_dev, finish=lambda: R.ctx.flush(R.stream))
     fps = world * K / dt
     b_alg = lvm.load().lvm_algorithmic_bytes(R.pk["mode"], R.w, R.h, R.ch, R.levels, R.pk["framerate"])
-    rec = {"workload": "%s 1920x1080, 6 levels, 1 stream per GPU, %d frames per call" % ({1: "laplace", 2: "riesz", 3: "color"}[cfg_idx], T),
+    frame_frac = round(b_alg * fps / world / (HBM_PEAK_GBS * 1e9), 5)
+    rec = {"workload": "%s %dx%d, %d levels, 1 stream per GPU, %d frames per call%s" % (mode, R.w, R.h, R.levels, T, clip_tag),
            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "us_per_frame": round(1e6 * dt / K, 2),
-           "frame_alg_bytes": b_alg, "frame_roofline_frac": round(b_alg * fps / world / (HBM_PEAK_GBS * 1e9), 5)}
+           "ms_per_step": round(1e3 * dt / K, 4), "frame_alg_bytes": b_alg, "frame_roofline_frac": frame_frac}
     if rank == 0 and R.oring >= R.n:
         from oracle import pyoracle as po
+        nthreads = max(1, min(16, os.cpu_count() or 1))
         host = R.d_in[:, 0].cpu().numpy()
-        check = sorted(set(int(round(x)) for x in np.linspace(base, base + K - 1, 8)))
-        keep, _, _ = oracle_replay(po, np, host, R.pk, R.ring, R.n, check, max(1, min(16, os.cpu_count() or 1)))
+        # 4K: the oracle needs ~0.3 s per frame -- the checked frames are the first timed call's (the replay stops there)
+        span = K if R.w * R.h <= 1920 * 1080 else min(K, T)
+        check = sorted(set(int(round(x)) for x in np.linspace(base, base + span - 1, 8)))
+        n_replay = check[-1] + 1
+        keep, _, cdt = oracle_replay(po, np, host, R.pk, R.ring, n_replay, check, nthreads)
         dmax, fmin, ncmp = 0, 1.0, 0
         for i in check:
             ref, produced = keep[i]
@@ -713,10 +907,31 @@ def other_mode_record(lvm, torch, np, cfg_idx, local_rank, rank, world, dist, re
                 du = np.abs(ref.astype(np.int16) - R.d_out[i % R.oring, 0].cpu().numpy().astype(np.int16))
                 dmax, fmin, ncmp = max(dmax, int(du.max())), min(fmin, float((du == 0).mean())), ncmp + 1
         rec["verified"] = bool(ncmp >= 8 and dmax <= 1 and fmin >= 0.999)
-        rec["verification"] = {"timed_frames_compared": ncmp, "u8_max_diff": dmax, "u8_identical_min": round(fmin, 6)}
+        rec["verification"] = {"timed_frames_compared": ncmp, "u8_max_diff": dmax, "u8_identical_min": round(fmin, 6),
+                               "bars": "u8 <= 1 LSB, >= 99.9 % identical", "oracle_frames_replayed": n_replay}
+        rec["cpu_baseline"] = {"value": round(n_replay / cdt, 3), "unit": "frames/s", "cores": nthreads, "kind": "port", "host_cores": os.cpu_count(),
+                               "sample": "%d frames of the same clip (the verification replay), CPU oracle = restatement of the reference, %d threads" % (n_replay, nthreads)}
+        kernels, roofline = kernel_pass(lvm, torch, R, mode, 2 * T, RAMP_SECONDS)
+        if roofline:
+            roofline["frame_frac"] = frame_frac
+            roofline["frame_frac_definition"] = "SURVEY.md 8d: B_alg x frames/s / peak (whole path, compulsory bytes only)"
+        rec["roofline"] = roofline
+        rec["kernels_us_per_launch"] = {k: v["avg_us"] for k, v in kernels.items()}
+    host8 = R.d_in[:8, 0].cpu().numpy() if (extras and rank == 0) else None
+    cp_keep = R.cp
     R.close()
     del R
     torch.cuda.empty_cache()
+    if extras:
+        rec["per_frame"] = per_frame_records(lvm, torch, np, cfg_idx, None, local_rank, ids, world, dist, red_dev)
+        if rank == 0:
+            ctx = lvm.Context(local_rank, 1)
+            try:
+                twin = lvm.load().lvm_optimal_buffer_size(int(pk["framerate"]))
+                rec["e2e_host"] = e2e_host_record(lvm, np, ctx, C.byref(cp_keep), host8, Ke=(150 if host8.shape[1] <= 1080 else 40),
+                                                  warm=(twin + 12 if mode == "color" else 20))
+            finally:
+                ctx.close()
     return rec
 
 
@@ -771,82 +986,13 @@ def sub_records(lvm, torch, np, args, cfg_idx, small, local_rank, rank, world, d
     # (2) host-to-host through lvm_process (the drop-in surface): pageable frames, then page-locked frames
     w, h, ch, fb = R.w, R.h, R.ch, R.frame_bytes
     host = R.d_in[:, 0].cpu().numpy()
-    R.ctx.reset()
-    e2e = {}
     lib = lvm.load()
-    for kind in ("pageable", "pinned", "pageable_staged_through_pinned"):
-        staged = kind == "pageable_staged_through_pinned"   # what a pinned staging buffer INSIDE lvm_process would cost: two memcpys
-        if kind != "pageable":
-            pin, pout = C.c_void_p(), C.c_void_p()
-            if lib.lvm_host_alloc(fb * 8, C.byref(pin)) != 0 or lib.lvm_host_alloc(fb, C.byref(pout)) != 0:
-                continue
-            src = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(8, h, w, ch))
-            dst = np.ctypeslib.as_array(C.cast(pout, C.POINTER(C.c_uint8)), shape=(h, w, ch))
-            src[:] = host[:8]
-            if staged:
-                pg_src, pg_dst = host[:8].copy(), np.empty((h, w, ch), np.uint8)
-        else:
-            src = host[:8].copy()
-            dst = np.empty((h, w, ch), np.uint8)
-        produced = C.c_int(0)
-        fn = lib.lvm_process
-        ptrs = [src[i].ctypes.data for i in range(8)]
-        po_ = dst.ctypes.data
-        R.ctx.reset()
-        for i in range(20):
-            fn(R.ctx.h, R.p_ref, ptrs[i % 8], w, h, ch, w * ch, po_, w * ch, C.byref(produced))
-        Ke = 150
-        t0 = time.perf_counter()
-        for i in range(Ke):
-            if staged:
-                np.copyto(src[i % 8], pg_src[i % 8])
-            rc = fn(R.ctx.h, R.p_ref, ptrs[i % 8], w, h, ch, w * ch, po_, w * ch, C.byref(produced))
-            if rc != 0:
-                R.ctx._check(rc)
-            if staged:
-                np.copyto(pg_dst, dst)
-        de = time.perf_counter() - t0
-        e2e[kind] = {"value": round(Ke / de, 2), "unit": "frames/s", "us_per_frame": round(1e6 * de / Ke, 1),
-                     "pcie_bytes_per_frame": 2 * fb, "pcie_gbs": round(2 * fb * Ke / de / 1e9, 2)}
-        if kind != "pageable":
-            del src, dst
-            lib.lvm_host_free(pin); lib.lvm_host_free(pout)
-    out["e2e_host"] = dict(e2e, surface="lvm_process: host u8 in -> host u8 out, synchronous, one frame in flight "
-                                        "(replaces MagnificationProcessor::process, MagnificationProcessor.cpp:17-67)")
+    twin = lib.lvm_optimal_buffer_size(int(R.pk["framerate"]))
+    out["e2e_host"] = e2e_host_record(lvm, np, R.ctx, R.p_ref, host, kinds=("pageable", "pinned", "pageable_staged_through_pinned"),
+                                      warm=(twin + 12 if R.pk["mode"] == lvm.synth.MODE_COLOR else 20))
     # (2b) the export loop body: 32 page-locked host frames in, 32 side-by-side canvases out per lvm_export_frames call
     # (runChainOnce + Exporter::compose, Exporter.cpp:216-259; the temporal batch inside, the canvases composed on the device)
-    try:
-        Te = 32
-        cpre = lvm.LvmPreprocessParams(1, 0, 0.0, 0.0, 1.0, 1.0, 0)
-        cw, chh = C.c_int(0), C.c_int(0)
-        lib.lvm_export_geometry(C.byref(cpre), 1, w, h, ch, C.byref(cw), C.byref(chh))
-        cb = cw.value * chh.value * 3
-        pin, pout = C.c_void_p(), C.c_void_p()
-        if cb > 0 and lib.lvm_host_alloc(fb * Te, C.byref(pin)) == 0 and lib.lvm_host_alloc(cb * Te, C.byref(pout)) == 0:
-            src = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(Te, h, w, ch))
-            for i in range(Te):
-                src[i] = host[i % host.shape[0]]
-            vp = C.c_void_p
-            pi = (vp * Te)(*[pin.value + i * fb for i in range(Te)])
-            pc = (vp * Te)(*[pout.value + i * cb for i in range(Te)])
-            prod = (C.c_int * Te)()
-            ex = lvm.Context(local_rank, 1)
-            ex.set_max_frames(Te)
-            for _ in range(2):
-                ex._check(lib.lvm_export_frames(ex.h, C.byref(cpre), R.p_ref, 1, Te, pi, w, h, ch, w * ch, pc, cw.value * 3, prod))
-            Kx = 6
-            t0 = time.perf_counter()
-            for _ in range(Kx):
-                ex._check(lib.lvm_export_frames(ex.h, C.byref(cpre), R.p_ref, 1, Te, pi, w, h, ch, w * ch, pc, cw.value * 3, prod))
-            dx = time.perf_counter() - t0
-            ex.close()
-            out["export_host"] = {"value": round(Kx * Te / dx, 2), "unit": "frames/s", "frames_per_call": Te, "us_per_frame": round(1e6 * dx / (Kx * Te), 1),
-                                  "pcie_bytes_per_frame": fb + cb, "pcie_gbs": round((fb + cb) * Kx * Te / dx / 1e9, 2),
-                                  "surface": "lvm_export_frames: pinned host frames in -> side-by-side canvases (original | processed) out; replaces the loop "
-                                             "body of Exporter::run (Exporter.cpp:216-259: runChainOnce + compose), host/HipExportRunner.hpp is the loop"}
-            lib.lvm_host_free(pin); lib.lvm_host_free(pout)
-    except Exception as e:      # a sub-record must never take the headline line down
-        out["export_host"] = {"error": str(e)[:200]}
+    out["export_host"] = export_host_record(lvm, np, local_rank, R.p_ref, host)
     R.close()
     del R
     torch.cuda.empty_cache()
@@ -864,21 +1010,21 @@ def sub_records(lvm, torch, np, args, cfg_idx, small, local_rank, rank, world, d
         torch.cuda.empty_cache()
     out["batched_streams"] = bs
     # (4) BASELINE configs[4]
-    out["cfg4_riesz_4k"] = cfg4_record(lvm, torch, np, local_rank, rank, world, dist, red_dev)
+    out["cfg4_riesz_4k"] = config_record(lvm, torch, np, 4, local_rank, rank, world, dist, red_dev, K=64, W=16, T=16, ring=16)
     # (5) BASELINE configs[2] and configs[3] (the headline run only: `--mode riesz|color` runs them as the main line)
     if cfg_idx == 1 and not small:
-        out["cfg2_riesz_1080p"] = other_mode_record(lvm, torch, np, 2, local_rank, rank, world, dist, red_dev)
-        out["cfg3_color_1080p"] = other_mode_record(lvm, torch, np, 3, local_rank, rank, world, dist, red_dev)
+        out["cfg2_riesz_1080p"] = config_record(lvm, torch, np, 2, local_rank, rank, world, dist, red_dev)
+        out["cfg3_color_1080p"] = config_record(lvm, torch, np, 3, local_rank, rank, world, dist, red_dev)
         # (6) content sensitivity: the headline clip carries +-12 levels of per-channel noise -- neighbouring pixels land in different
         # cells of the forward Lab table, the worst case for its gathers; the same stream with a camera's +-2 levels
         global CLIP_NOISE
         if CLIP_NOISE is None:
             CLIP_NOISE = 2.0
             try:
-                rec = other_mode_record(lvm, torch, np, 1, local_rank, rank, world, dist, red_dev, K=128)
+                rec = config_record(lvm, torch, np, 1, local_rank, rank, world, dist, red_dev, K=128, extras=False,
+                                    clip_tag=", clip noise +-2 levels instead of the headline's +-12")
             finally:
                 CLIP_NOISE = None
-            rec["workload"] += ", clip noise +-2 levels instead of the headline's +-12"
             out["camera_noise_clip"] = rec
     return out
 

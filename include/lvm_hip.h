@@ -100,8 +100,10 @@ int  lvm_process_device_frames(lvm_ctx* ctx, const lvm_params* p, int n_frames, 
 int  lvm_set_max_frames(lvm_ctx* ctx, int n_frames);
 
 /* Page-locked host memory for frame buffers (what the reference's core/FramePool.cpp:29-36 would allocate
- * its pooled cv::Mat storage from): frames in such memory cross PCIe by DMA at link speed in lvm_process /
- * lvm_chain_process.  Pageable frames work too (the HIP runtime pins them on the fly).               */
+ * its pooled cv::Mat storage from).  lvm_process takes NO staging copy for such frames: the first kernel reads
+ * the input and the last kernel writes the output frame directly over PCIe (the input alias only where exactly
+ * one kernel reads the u8 frame: Laplace / Riesz on BGR frames); lvm_export_frames / lvm_chain_process copy them
+ * by DMA at link speed.  Pageable frames work everywhere (staged copies; the HIP runtime pins them on the fly). */
 int  lvm_host_alloc(size_t bytes, void** out);
 void lvm_host_free(void* p);
 
@@ -145,9 +147,11 @@ int  lvm_chain_process_batch(lvm_ctx* ctx, const lvm_preprocess_params* pp, cons
                              const uint8_t* const* in, int w, int h, int channels, ptrdiff_t in_stride,
                              uint8_t* const* out, ptrdiff_t out_stride, int* produced);
 
-/* The same plus the frames the magnifier SAW (runChainOnce's `original`, processing/ChainBuilder.cpp:19-29: what the
- * display shows in its left pane, core/LatestFrameMailbox.hpp:13-16): pre_out[s] (may be NULL, entries may be NULL)
- * receives the preprocessed frame of stream s, same geometry as out[s].                                        */
+/* The same plus runChainOnce's `original` (processing/ChainBuilder.cpp:19-29: the tap after chain[0] = PreprocessProcessor,
+ * BEFORE GrayscaleProcessor; what the display shows in its left pane, core/LatestFrameMailbox.hpp:13-16): pre_out[s] (may
+ * be NULL, entries may be NULL) receives the cropped / decimated frame of stream s -- out_w x out_h like out[s], but with
+ * the SOURCE's channel count: with grayscale on a BGR source the tap is the colour frame (3 bytes per pixel,
+ * pre_stride >= 3 * out_w) while out[s] is gray.                                                                 */
 int  lvm_chain_process_batch_ex(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_params* p,
                                 const uint8_t* const* in, int w, int h, int channels, ptrdiff_t in_stride,
                                 uint8_t* const* out, ptrdiff_t out_stride, uint8_t* const* pre_out,
@@ -172,11 +176,13 @@ int  lvm_compose_device(lvm_ctx* ctx, int split, const uint8_t* d_orig, int ow, 
 
 /* The loop body of Exporter::run (export/Exporter.cpp:216-259) for n_frames CONSECUTIVE host frames of a 1-stream context:
  *   runChainOnce (ChainBuilder.cpp:19-29: PreprocessProcessor -> GrayscaleProcessor -> MagnificationProcessor) on every frame in
- *   order, then Exporter::compose(original, processed, split) (Exporter.cpp:53-88) -- `original` = the frame the magnifier saw,
- *   `processed` = its output or, on passthrough (produced[i] == 0), that same frame (MagnificationProcessor.cpp:61).
+ *   order, then Exporter::compose(original, processed, split) (Exporter.cpp:53-88) -- `original` = PreprocessProcessor's output
+ *   (the tap of ChainBuilder.cpp:25 sits BEFORE GrayscaleProcessor: a colour pane even when the chain grays), `processed` = the
+ *   magnifier's output or, on passthrough (produced[i] == 0), the frame it saw (MagnificationProcessor.cpp:61).
  * frames[i] -> canvases[i]: canvas_w x canvas_h x 3 bytes (lvm_export_geometry), row stride canvas_stride.  Only the ROI rows of
- * the inputs and the canvases cross PCIe; the magnifier runs as ONE temporal batch (lvm_process_device_frames) and the canvases are
- * composed on the device (lvm_compose_device).  The text overlay (Exporter.cpp:36-50) and cv::VideoWriter::write (:259) stay on
+ * the inputs and the canvases cross PCIe, in both directions at once: the frames go through in sub-batches of 8 (each ONE temporal
+ * batch of the magnifier, lvm_process_device_frames), sub-batch k + 1 uploading and sub-batch k - 1 downloading while sub-batch k is
+ * magnified and composed on the device (lvm_compose_device).  The text overlay (Exporter.cpp:36-50) and cv::VideoWriter::write (:259) stay on
  * the host: host/HipExportRunner.hpp is the reference-side loop around this call.  Synchronous.                               */
 int  lvm_export_geometry(const lvm_preprocess_params* pp, int split, int w, int h, int channels, int* canvas_w, int* canvas_h);
 int  lvm_export_frames(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames,

@@ -238,6 +238,49 @@ class Context:
                                                      C.byref(produced)))
         return outs, bool(produced.value)
 
+    def chain_process_batch_ex(self, frames, cpre, cparams):
+        """lvm_chain_process_batch_ex: the batch call plus runChainOnce's `original` tap (PreprocessProcessor's output, before
+        GrayscaleProcessor: the source's channel count).  Returns (outs, originals, produced)."""
+        frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+        if len(frames) != self.n_streams:
+            raise LvmError("chain_process_batch_ex needs one frame per stream")
+        h, w = frames[0].shape[:2]
+        ch = 1 if frames[0].ndim == 2 else frames[0].shape[2]
+        _, _, _, _, ow, oh, och = self.preprocess_geometry(cpre, w, h, ch)
+        outs = [np.empty((oh, ow) if och == 1 else (oh, ow, och), dtype=np.uint8) for _ in frames]
+        taps = [np.empty((oh, ow) if ch == 1 else (oh, ow, ch), dtype=np.uint8) for _ in frames]
+        pin = (C.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
+        pout = (C.c_void_p * len(frames))(*[o.ctypes.data for o in outs])
+        ptap = (C.c_void_p * len(frames))(*[o.ctypes.data for o in taps])
+        produced = C.c_int(0)
+        self._check(self.lib.lvm_chain_process_batch_ex(self.h, C.byref(cpre), C.byref(cparams), pin, w, h, ch, w * ch, pout, ow * och,
+                                                        ptap, ow * ch, C.byref(produced)))
+        return outs, taps, bool(produced.value)
+
+    def process_pinned(self, frame, cparams, pad=0):
+        """lvm_process on PAGE-LOCKED frames (lvm_host_alloc): the zero-copy surface.  `pad` extra bytes per row on both sides."""
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        h, w = frame.shape[:2]
+        ch = 1 if frame.ndim == 2 else frame.shape[2]
+        stride = w * ch + pad
+        pin, pout = C.c_void_p(), C.c_void_p()
+        self._check(self.lib.lvm_host_alloc(stride * h, C.byref(pin)))
+        self._check(self.lib.lvm_host_alloc(stride * h, C.byref(pout)))
+        try:
+            src = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(h, stride))
+            dst = np.ctypeslib.as_array(C.cast(pout, C.POINTER(C.c_uint8)), shape=(h, stride))
+            src[:, :w * ch] = frame.reshape(h, w * ch)
+            dst[:] = 0xA5
+            produced = C.c_int(0)
+            self._check(self.lib.lvm_process(self.h, C.byref(cparams), pin.value, w, h, ch, stride, pout.value, stride, C.byref(produced)))
+            out = dst[:, :w * ch].reshape(frame.shape).copy()
+            untouched = bool((dst[:, w * ch:] == 0xA5).all())
+            if not untouched:
+                raise LvmError("lvm_process wrote outside the output rows")
+        finally:
+            self.lib.lvm_host_free(pin); self.lib.lvm_host_free(pout)
+        return (out, True) if produced.value else (frame, False)
+
     def export_frames(self, frames, cpre, cparams, split):
         """lvm_export_frames: Exporter::run's loop body (runChainOnce + Exporter::compose) for consecutive host frames of a 1-stream
         context.  Returns (canvases, produced flags)."""

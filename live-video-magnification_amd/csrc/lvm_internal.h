@@ -420,6 +420,10 @@ struct Ctx {
     void* pre_tables = nullptr;
     uint8_t *d_pre_in = nullptr, *d_pre_out = nullptr, *d_chain_out = nullptr; size_t pre_in_cap = 0, pre_out_cap = 0, chain_out_cap = 0;
     uint8_t* d_canvas = nullptr; size_t canvas_cap = 0;     // lvm_export_frames: the composed canvases of a batch
+    uint8_t* d_pre_tap = nullptr; size_t pre_tap_cap = 0;   // the colour frames in front of GrayscaleProcessor (runChainOnce's `original`)
+    // lvm_export_frames' three-stage pipeline: uploads, kernels and downloads of consecutive sub-batches on their own queues
+    hipStream_t up_stream = nullptr, down_stream = nullptr;
+    std::vector<hipEvent_t> ev_up, ev_done;
 };
 
 inline int lab_flavour(const Ctx* c) { return c->lab_analytic ? FL_ANALYTIC : (c->exact_lab ? FL_LUT_EXACT : FL_LUT_FAST); }
@@ -470,7 +474,8 @@ void lab_lut_planes(Ctx* c, const uint8_t* d_in, long in_stride, long in_sstride
 void preprocess_geometry(const lvm_preprocess_params& pp, int w, int h, int channels, int* rx, int* ry, int* rw, int* rh,
                          int* ow, int* oh, int* och);
 int preprocess_device(Ctx* c, const lvm_preprocess_params& pp, const uint8_t* d_in, int w, int h, int channels, ptrdiff_t in_stride,
-                      ptrdiff_t in_sstride, uint8_t* d_out, ptrdiff_t out_stride, ptrdiff_t out_sstride, hipStream_t s);
+                      ptrdiff_t in_sstride, uint8_t* d_out, ptrdiff_t out_stride, ptrdiff_t out_sstride, hipStream_t s,
+                      uint8_t* d_tap = nullptr, ptrdiff_t tap_stride = 0, ptrdiff_t tap_sstride = 0);
 void preprocess_release(Ctx* c);
 
 // compose.hip

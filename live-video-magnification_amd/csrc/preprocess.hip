@@ -26,6 +26,7 @@ struct PreArgs {
     uint8_t* out; long out_stride, out_sstride;
     int ow, oh, cn, ocn;                               // output size, input channels, output channels
     int sx, sy;                                        // integer decimation factors (fast path)
+    uint8_t* tap; long tap_stride, tap_sstride;        // optional: the 3-channel frame BEFORE BGR2GRAY (runChainOnce's `original`, ChainBuilder.cpp:25)
     const AreaTab* xtab; const int* xk;                // general path: entries of output column dx are xtab[xk[dx] .. xk[dx+1])
     const AreaTab* ytab; const int* yk;
 };
@@ -81,8 +82,13 @@ __global__ __launch_bounds__(256) void k_preprocess(PreArgs a) {
 #pragma unroll
         for (int c = 0; c < CN; ++c) v[c] = (int)sat_u8(sum[c]);
     }
-    if (CN == 3 && a.ocn == 1) q[0] = gray15(v[0], v[1], v[2]);
-    else {
+    if (CN == 3 && a.ocn == 1) {
+        q[0] = gray15(v[0], v[1], v[2]);
+        if (a.tap) {        // PreprocessProcessor's own output: what the chain hands on as `original` before GrayscaleProcessor runs
+            uint8_t* t = a.tap + (size_t)blockIdx.z * a.tap_sstride + (size_t)dy * a.tap_stride + (size_t)dx * 3;
+            t[0] = (uint8_t)v[0]; t[1] = (uint8_t)v[1]; t[2] = (uint8_t)v[2];
+        }
+    } else {
 #pragma unroll
         for (int c = 0; c < CN; ++c) q[c] = (uint8_t)v[c];
     }
@@ -138,7 +144,8 @@ void preprocess_release(Ctx* c) {
 }
 
 int preprocess_device(Ctx* c, const lvm_preprocess_params& pp, const uint8_t* d_in, int w, int h, int channels, ptrdiff_t in_stride,
-                      ptrdiff_t in_sstride, uint8_t* d_out, ptrdiff_t out_stride, ptrdiff_t out_sstride, hipStream_t s) {
+                      ptrdiff_t in_sstride, uint8_t* d_out, ptrdiff_t out_stride, ptrdiff_t out_sstride, hipStream_t s,
+                      uint8_t* d_tap, ptrdiff_t tap_stride, ptrdiff_t tap_sstride) {
     if (!d_in || !d_out || w <= 0 || h <= 0 || (channels != 1 && channels != 3)) { c->err = "preprocess: bad frame arguments"; return LVM_ERR_INVALID; }
     int rx, ry, rw, rh, ow, oh, och;
     preprocess_geometry(pp, w, h, channels, &rx, &ry, &rw, &rh, &ow, &oh, &och);
@@ -147,6 +154,7 @@ int preprocess_device(Ctx* c, const lvm_preprocess_params& pp, const uint8_t* d_
     a.in = d_in + (size_t)ry * in_stride + (size_t)rx * channels; a.in_stride = (long)in_stride; a.in_sstride = (long)in_sstride;
     a.out = d_out; a.out_stride = (long)out_stride; a.out_sstride = (long)out_sstride;
     a.ow = ow; a.oh = oh; a.cn = channels; a.ocn = och;
+    a.tap = (channels == 3 && och == 1) ? d_tap : nullptr; a.tap_stride = (long)tap_stride; a.tap_sstride = (long)tap_sstride;
     const int divisor = pp.downscale < 1 ? 1 : (pp.downscale > 8 ? 8 : pp.downscale);
     int mode = 0;
     if (divisor > 1) {

@@ -93,13 +93,15 @@ public:
             int ow = 0, oh = 0, och = 0;
             Magnifier::chain_geometry(cfg.pre, v0.w, v0.h, v0.channels, &ow, &oh, &och);
             const bool stages_identity = ow == v0.w && oh == v0.h && och == v0.channels;   // Preprocess + Grayscale returned `in`
+            // `original` is chain[0]'s output, tapped BEFORE GrayscaleProcessor (ChainBuilder.cpp:25): the source's own channel count
+            const int tap_ch = v0.channels;
             std::vector<FrameRef> processed(n), original(n);
             std::vector<std::uint8_t*> dst(n), pre(n, nullptr);
             std::ptrdiff_t dstride = 0, pstride = 0;
             for (std::size_t s = 0; s < n; ++s) {
                 processed[s] = T::make_like(frames[s], ow, oh, och, &dst[s], &dstride);
                 if (stages_identity) original[s] = frames[s];                 // the magnifier saw the input frame itself
-                else original[s] = T::make_like(frames[s], ow, oh, och, &pre[s], &pstride);
+                else original[s] = T::make_like(frames[s], ow, oh, tap_ch, &pre[s], &pstride);
             }
             const lvm_params c = to_c(cfg.mag, 0);
             int produced = 0;

@@ -21,7 +21,7 @@
 //   }                                                             the traits on the host canvas before it is written
 //
 // Frames stay strictly in order (the temporal filters are stateful, Exporter.hpp:18-20); a batch is n consecutive frames, so the
-// results are those of the frame-by-frame loop (tests/test_host_export_runner.py: canvases byte-equal to runChainOnce + compose of
+// results are those of the frame-by-frame loop (tests/test_export.py::test_export_runner_*: canvases byte-equal to runChainOnce + compose of
 // the CPU oracle).  An abort is honoured between batches and between the writes of a batch ("stops at the next frame
 // boundary", Exporter.hpp:33).  Template over a traits type so that it compiles and runs without OpenCV; `livim::HipExportLoop` at
 // the end binds it to cv::Mat / IExportFrameSource / cv::VideoWriter inside the reference tree.
@@ -73,6 +73,8 @@ public:
                 typename T::View raw{};
                 if (!T::next(src, raw)) { more = false; break; }                                // :217
                 if (raw.empty || !raw.data) continue;                                           // :218
+                if (canvas_empty(raw, pre, split)) continue;                                    // :243 `if (canvas.empty()) continue;` (the frame is consumed, nothing is written;
+                                                                                                //  such a frame cannot pass the magnifier either: both of its sizes are < 2)
                 if (!slots_ready(raw)) {
                     if (n == 0) prepare(raw, pre, split);
                     else { keep(raw); break; }                                                  // flush what we have with the old geometry first
@@ -87,6 +89,10 @@ public:
 
 private:
     bool slots_ready(const typename T::View& v) const { return in_ && v.w == w_ && v.h == h_ && v.channels == ch_; }
+    static bool canvas_empty(const typename T::View& v, const lvm_preprocess_params& pre, int split) {
+        int cw = 0, ch = 0;
+        return lvm_export_geometry(&pre, split, v.w, v.h, v.channels, &cw, &ch) != LVM_OK || cw <= 0 || ch <= 0;
+    }
     void keep(const typename T::View& v) {
         cw0_ = v.w; ch0_ = v.h; cc0_ = v.channels;
         carry_.resize((std::size_t)v.w * v.h * v.channels);

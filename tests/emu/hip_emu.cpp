@@ -20,6 +20,17 @@ std::mutex g_guard_mu;
 std::map<void*, std::pair<void*, size_t>> g_guard;      // user pointer -> (mapping, length)
 bool guard_on() { static const bool on = [] { const char* e = std::getenv("HIPEMU_GUARD"); return e && std::atoi(e) != 0; }(); return on; }
 }  // namespace
+// page-locked host allocations (hipHostMalloc): base -> size
+namespace { std::mutex g_host_mu; std::map<char*, size_t> g_host; }
+void host_track(void* p, size_t n) { std::lock_guard<std::mutex> lk(g_host_mu); g_host[(char*)p] = n; }
+void host_untrack(void* p) { std::lock_guard<std::mutex> lk(g_host_mu); g_host.erase((char*)p); }
+void* host_lookup(const void* p) {
+    std::lock_guard<std::mutex> lk(g_host_mu);
+    auto it = g_host.upper_bound((char*)p);
+    if (it == g_host.begin()) return nullptr;
+    --it;
+    return ((const char*)p < it->first + it->second) ? const_cast<void*>(p) : nullptr;
+}
 void* guard_malloc(size_t n) {
     if (!guard_on()) return nullptr;
     constexpr size_t kMargin = 16u << 20, kPage = 4096;

@@ -19,7 +19,7 @@ struct dim3 {
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
 typedef struct ihipStream_t* hipStream_t;
 typedef struct ihipEvent_t* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
@@ -120,8 +120,21 @@ static inline hipError_t hipMalloc(void** p, size_t n) {
     std::memset(*p, 0xFF, n); return hipSuccess;
 }
 static inline hipError_t hipFree(void* p) { if (!hipemu::guard_free(p)) std::free(p); return hipSuccess; }
-static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
-static inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+// page-locked host memory: tracked, so that hipPointerGetAttributes can tell it from pageable memory (the product's zero-copy path)
+namespace hipemu { void host_track(void* p, size_t n); void host_untrack(void* p); void* host_lookup(const void* p); }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) {
+    *p = std::malloc(n ? n : 1);
+    if (!*p) return hipErrorOutOfMemory;
+    hipemu::host_track(*p, n ? n : 1); return hipSuccess;
+}
+static inline hipError_t hipHostFree(void* p) { hipemu::host_untrack(p); std::free(p); return hipSuccess; }
+enum hipMemoryType { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2 };
+struct hipPointerAttribute_t { hipMemoryType type; int device; void* devicePointer; void* hostPointer; };
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {
+    void* q = hipemu::host_lookup(p);
+    a->type = q ? hipMemoryTypeHost : hipMemoryTypeUnregistered; a->device = 0; a->devicePointer = q; a->hostPointer = q;
+    return hipSuccess;
+}
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { std::memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { std::memset(d, v, n); return hipSuccess; }

@@ -26,6 +26,8 @@ def _check(lvm, po, lib, cfg, size, pre, split, batches, exact):
     ck, pk = lvm.synth.config(cfg, size)
     clip = lvm.synth.Clip(**ck)
     cpre, opre = _pre(lvm, po, *pre)
+    # PreprocessProcessor alone: runChainOnce taps `original` after chain[0], BEFORE GrayscaleProcessor (ChainBuilder.cpp:25)
+    _, opre_tap = _pre(lvm, po, pre[0], pre[1], False)
     ctx = lvm.Context(0, 1, lib)
     ctx.exact_lab(exact)
     orc = po.Oracle()
@@ -39,7 +41,8 @@ def _check(lvm, po, lib, cfg, size, pre, split, batches, exact):
                 small = po.preprocess(frames[k], opre)                       # runChainOnce: the two uint8 stages ...
                 ref, pr = orc.process(small, P)                              # ... then the magnifier (passthrough returns its input)
                 assert pr == produced[k], (t + k, pr, produced[k])
-                want = po.compose(split, small, ref if pr else small)        # Exporter::compose(original, cur, split)
+                original = po.preprocess(frames[k], opre_tap)                # the pre-magnification tap: colour even when the chain grays
+                want = po.compose(split, original, ref if pr else small)     # Exporter::compose(original, cur, split)
                 assert want is not None and want.shape == canvases[k].shape, (want.shape if want is not None else None, canvases[k].shape)
                 if exact:
                     assert np.array_equal(canvases[k], want), "frame %d" % (t + k)
@@ -53,7 +56,8 @@ def _check(lvm, po, lib, cfg, size, pre, split, batches, exact):
 
 CASES = [
     (0, (128, 96, 3), (2, (0.05, 0.1, 0.9, 0.8), False), LR, (1, 6, 4)),      # Laplace: seed frame alone, then temporal batches; ROI + downscale 2
-    (0, (96, 64, 2), (1, None, True), TB, (5, 3)),                           # gray chain (BGR2GRAY in front of the magnifier), stacked panes
+    (0, (96, 64, 2), (1, None, True), TB, (5, 3)),                           # gray chain (BGR2GRAY in front of the magnifier), stacked panes: colour original over gray result
+    (0, (128, 96, 3), (2, (0.1, 0.1, 0.8, 0.8), True), LR, (2, 9)),          # the same with ROI + INTER_AREA in front: the tap is the decimated COLOUR frame; sub-batches of 8 + 1
     (3, (96, 64, 2), (1, None, False), NONE, (3, 9)),                        # Color: the first frames pass through (window warm-up)
     (2, (96, 64, 3), (1, None, False), LR, (2, 5)),                          # Riesz: the first frame passes through
 ]

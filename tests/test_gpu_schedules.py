@@ -187,7 +187,8 @@ def test_bench_two_ranks_from_a_plain_shell():
     assert not [r for r in ranks if r["verified"] is not True], "UNVERIFIED RANKS " + json.dumps([(r["rank"], r.get("verification")) for r in ranks if r["verified"] is not True])
     expect = 2 * 1 * 8 / out["timed_seconds_max_over_ranks"]
     assert abs(out["value"] - expect) <= 1e-6 * expect + 0.01
-    assert out["cfg4_riesz_4k"]["n_gpus"] == 2
+    assert out["cfg4_riesz_4k"]["n_gpus"] == 2 and out["cfg4_riesz_4k"]["verified"] is True
+    assert len(out["host_fed"]["per_rank"]) == 2
 
 
 def test_bench_one_rank_over_rccl():
@@ -231,7 +232,31 @@ def test_bench_eight_ranks_dry_run():
     assert not [r for r in ranks if r["verified"] is not True], "UNVERIFIED RANKS " + json.dumps([(r["rank"], r.get("verification")) for r in ranks if r["verified"] is not True])
     expect = 8 * 1 * 8 / out["timed_seconds_max_over_ranks"]
     assert abs(out["value"] - expect) <= 1e-6 * expect + 0.01
-    assert out["cfg4_riesz_4k"]["n_gpus"] == 8
+    c4 = out["cfg4_riesz_4k"]
+    assert c4["n_gpus"] == 8 and c4["verified"] is True and c4["roofline"]["frame_frac"] > 0 and c4["cpu_baseline"]["kind"] == "port", c4
+    # round 5: the host-fed surfaces on every rank at once (per-rank PCIe rates; aggregate = sum over ranks)
+    hf = out["host_fed"]
+    assert sorted(r["rank"] for r in hf["per_rank"]) == list(range(8))
+    assert all(r["e2e_fps"] and r["export_fps"] and r["e2e_pcie_gbs"] and r["export_pcie_gbs"] for r in hf["per_rank"]), hf
+    assert abs(hf["export_host"]["value"] - sum(r["export_fps"] for r in hf["per_rank"])) < 0.1
+    assert all("host_binding" in r for r in out["ranks"])
+
+
+def test_bench_driver_line_carries_every_config():
+    """The line the driver records (`bench.py --steps 20 --warmup 5`): the headline's roofline holds SURVEY 8(d)'s path fraction next
+    to the dominant kernel's, `value_cold` is there, and BASELINE configs[2..4] each carry verified / roofline / cpu_baseline, the
+    per-frame schedule (T = 1, B = 1 and 4 -- what MagnificationProcessor::process runs) and the host -> host surface."""
+    out = _bench(["--steps", "20", "--warmup", "5"], timeout=1500)
+    assert out["verified"] is True and out["roofline"]["frame_frac"] > 0 and out["roofline"]["frac"] <= 1.0
+    assert out["value_cold"]["value"] > 0 and out["value_cold"]["steps"] == 20
+    for key in ("cfg2_riesz_1080p", "cfg3_color_1080p", "cfg4_riesz_4k"):
+        r = out[key]
+        assert r["verified"] is True, (key, r.get("verification"))
+        assert r["roofline"]["frac"] <= 1.0 and r["roofline"]["frame_frac"] > 0 and r["roofline"]["kernel"], (key, r["roofline"])
+        assert r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["kind"] == "port"
+        assert r["per_frame"]["B1"]["frames_per_call"] == 1 and r["per_frame"]["B1"]["value"] > 0 and r["per_frame"]["B4"]["value"] > 0
+        assert r["e2e_host"]["pinned"]["value"] > 0 and r["e2e_host"]["pageable"]["value"] > 0
+    assert out["per_frame"]["value"] > 0 and out["e2e_host"]["pinned"]["value"] > 0 and out["export_host"]["value"] > 0
 
 
 def test_two_contexts_on_two_threads(lvm, po, hip):

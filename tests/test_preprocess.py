@@ -167,6 +167,67 @@ def test_chain_batch_emu_three_streams(lvm, po, emu):
     _check_chain_batch(lvm, po, emu, True)
 
 
+def _check_original_tap(lvm, po, lib):
+    """runChainOnce taps `original` after chain[0] = PreprocessProcessor, BEFORE GrayscaleProcessor (ChainBuilder.cpp:25): with
+    grayscale on a BGR source the tap is the cropped / decimated COLOUR frame while the magnifier sees -- and returns -- gray."""
+    cpre, opre = _params(lvm, po, 2, (0.1, 0.1, 0.8, 0.8), True)
+    _, opre_tap = _params(lvm, po, 2, (0.1, 0.1, 0.8, 0.8), False)
+    ck, pk = lvm.synth.config(0, (96, 64, 2))
+    ctx = lvm.Context(0, 2, lib)
+    try:
+        for t in range(3):
+            frames = [_frame(96, 64, 3, 10 * s + t) for s in range(2)]
+            outs, taps, produced = ctx.chain_process_batch_ex(frames, cpre, c_params(lvm, pk))
+            assert produced
+            for s in range(2):
+                want = po.preprocess(frames[s], opre_tap)
+                assert taps[s].shape == want.shape == (outs[s].shape[0], outs[s].shape[1], 3)
+                assert np.array_equal(taps[s], want), (t, s)
+                assert outs[s].ndim == 2 and outs[s].shape == po.preprocess(frames[s], opre).shape
+    finally:
+        ctx.close()
+
+
+def test_chain_batch_ex_original_tap_is_the_colour_frame_emu(lvm, po, emu):
+    _check_original_tap(lvm, po, emu)
+
+
+@pytest.mark.gpu
+def test_chain_batch_ex_original_tap_is_the_colour_frame_gpu(lvm, po, hip):
+    _check_original_tap(lvm, po, hip)
+
+
+def _check_pinned_equals_pageable(lvm, lib, sizes):
+    """lvm_process on page-locked frames (no staging copy: kernels read / write the caller's buffers) against the same call on
+    pageable frames (staged copies): identical bytes, identical `produced`, nothing written outside the output rows (padded
+    strides).  Laplace / Riesz on BGR take both aliases, the colour mode and gray frames the output alias only."""
+    for cfg, size, gray, pad in sizes:
+        ck, pk = lvm.synth.config(cfg, size)
+        clip = lvm.synth.Clip(**ck)
+        a, b = lvm.Context(0, 1, lib), lvm.Context(0, 1, lib)
+        try:
+            for t in range(6):
+                f = clip.frame(t)
+                if gray:
+                    f = np.ascontiguousarray(f[:, :, 1])
+                o1, p1 = a.process(f, c_params(lvm, pk))
+                o2, p2 = b.process_pinned(f, c_params(lvm, pk), pad=pad)
+                assert p1 == p2, (cfg, t)
+                assert np.array_equal(o1, o2), (cfg, t, int(np.abs(o1.astype(int) - o2.astype(int)).max()))
+        finally:
+            a.close(); b.close()
+
+
+def test_process_pinned_frames_zero_copy_emu(lvm, emu):
+    _check_pinned_equals_pageable(lvm, emu, [(0, (64, 48, 3), False, 0), (2, (64, 48, 3), False, 20), (3, (64, 48, 2), False, 4), (0, (64, 48, 3), True, 8)])
+
+
+@pytest.mark.gpu
+def test_process_pinned_frames_zero_copy_gpu(lvm, hip):
+    _check_pinned_equals_pageable(lvm, hip, [(0, (640, 360, 4), False, 0), (2, (320, 180, 4), False, 20), (3, (320, 180, 3), False, 4),
+                                             (0, (320, 180, 3), True, 8), (1, (1920, 1080, 6), False, 0)])
+
+
 def test_chain_rejects_bad_arguments(lvm, po, emu):
     ctx = lvm.Context(0, 2, emu)
     try:
