@@ -83,12 +83,8 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, S, T, Twin=0):
             return T * (S * (3 + 6) * n[0] + 4 * P * n[1])
         if base == "lap_down0":
             return T * (S * lab_in * n[0] + 4 * P * n[1])
-        if base in ("lap_final", "lap_final1"):
-            b = T * (S * (lab_in + ch) * n[0])
-            if base == "lap_final":
-                return b + T * 4 * P * n[1]                                   # + cur_1 read
-            # fused level-1 step: G_1, G_2, cur_2 read per frame; level-1 IIR states once per launch
-            return b + T * 4 * P * (n[1] + 2 * n[2]) + 16 * P * n[1]
+        if base == "lap_final":
+            return T * (S * (lab_in + ch) * n[0]) + T * 4 * P * n[1]          # planes in, BGR out, + cur_1 read
         if base in ("pyr_down", "pyr_down_rows") and lvl is not None:
             return T * 4 * P * (n[lvl] + n[lvl + 1])
         if base == "pyr_down2" and lvl is not None:

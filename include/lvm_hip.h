@@ -157,6 +157,22 @@ int  lvm_chain_process_batch_ex(lvm_ctx* ctx, const lvm_preprocess_params* pp, c
                                 uint8_t* const* out, ptrdiff_t out_stride, uint8_t* const* pre_out,
                                 ptrdiff_t pre_stride, int* produced);
 
+/* ---- display hand-off on the device (the display half) ---------------------------------
+ * runChainOnce (processing/ChainBuilder.cpp:19-29) for the LIVE path, n_streams == 1: host frame in, the two frames the display
+ * shows left in DEVICE memory.  The reference's ProcessingChain publishes {processed, original} (ProcessingChain.cpp:46-49) and
+ * DisplayWidget::uploadFrame (ui/DisplayWidget.cpp:133-152) uploads both from host memory to GL textures on every frame; here
+ *   d_proc  (out_w x out_h x out_channels, lvm_preprocess_geometry) receives the magnified frame or, on passthrough
+ *           (*produced == 0), the frame the magnifier saw -- i.e. always what the display's main pane shows
+ *           (MagnificationProcessor.cpp:61);
+ *   d_orig  (out_w x out_h x the SOURCE's channels) receives runChainOnce's `original`: PreprocessProcessor's output, tapped before
+ *           GrayscaleProcessor (ChainBuilder.cpp:25);
+ * either may be NULL.  Both are caller-owned device pointers -- e.g. the mapped pointers of two GL pixel-unpack buffers registered
+ * with hipGraphicsGLRegisterBuffer (host/HipDisplayPresenter.hpp does that), from which glTexSubImage2D then copies device to
+ * device: only the ROI rows of the input cross PCIe, nothing comes back.  Synchronous (complete on return).            */
+int  lvm_chain_present(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_params* p, const uint8_t* in, int w, int h,
+                       int channels, ptrdiff_t in_stride, uint8_t* d_proc, ptrdiff_t proc_stride, uint8_t* d_orig,
+                       ptrdiff_t orig_stride, int* produced);
+
 /* ---- export hand-off on the device ---------------------------------------------------
  * export/ExportTypes.hpp:11 -- numeric order of `enum class SplitMode`                                        */
 enum lvm_split { LVM_SPLIT_NONE = 0, LVM_SPLIT_LEFT_RIGHT = 1, LVM_SPLIT_TOP_BOTTOM = 2 };

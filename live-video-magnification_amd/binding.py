@@ -99,7 +99,8 @@ SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process
            "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_debug_lab_analytic", "lvm_get_lab_lut", "lvm_set_lab_lut", "lvm_profile_enable", "lvm_profile_collect", "lvm_profile_only",
            "lvm_profile_entry", "lvm_algorithmic_bytes", "lvm_export_geometry", "lvm_export_frames",
            "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process", "lvm_chain_process_batch",
-           "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free", "lvm_compose_geometry", "lvm_compose_device", "lvm_chain_process_batch_ex"]
+           "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free", "lvm_compose_geometry", "lvm_compose_device", "lvm_chain_process_batch_ex",
+           "lvm_chain_present"]
 
 
 def bind(lib):
@@ -148,6 +149,8 @@ def bind(lib):
                                             C.c_int, C.c_ssize_t, C.POINTER(vp), C.c_ssize_t, ip]
     lib.lvm_chain_process_batch_ex.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), C.POINTER(vp), C.c_int, C.c_int,
                                                C.c_int, C.c_ssize_t, C.POINTER(vp), C.c_ssize_t, C.POINTER(vp), C.c_ssize_t, ip]
+    lib.lvm_chain_present.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t,
+                                      vp, C.c_ssize_t, vp, C.c_ssize_t, ip]
     lib.lvm_export_geometry.argtypes = [C.POINTER(LvmPreprocessParams), C.c_int, C.c_int, C.c_int, C.c_int, ip, ip]
     lib.lvm_export_frames.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), C.c_int, C.c_int, C.POINTER(vp), C.c_int, C.c_int,
                                       C.c_int, C.c_ssize_t, C.POINTER(vp), C.c_ssize_t, ip]
@@ -256,6 +259,16 @@ class Context:
         self._check(self.lib.lvm_chain_process_batch_ex(self.h, C.byref(cpre), C.byref(cparams), pin, w, h, ch, w * ch, pout, ow * och,
                                                         ptap, ow * ch, C.byref(produced)))
         return outs, taps, bool(produced.value)
+
+    def chain_present(self, frame, cpre, cparams, d_proc, proc_stride, d_orig, orig_stride):
+        """lvm_chain_present: host frame in, processed frame and `original` tap left in DEVICE buffers (addresses).  Returns produced."""
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        h, w = frame.shape[:2]
+        ch = 1 if frame.ndim == 2 else frame.shape[2]
+        produced = C.c_int(0)
+        self._check(self.lib.lvm_chain_present(self.h, C.byref(cpre), C.byref(cparams), frame.ctypes.data, w, h, ch, w * ch,
+                                               d_proc, proc_stride, d_orig, orig_stride, C.byref(produced)))
+        return bool(produced.value)
 
     def process_pinned(self, frame, cparams, pad=0):
         """lvm_process on PAGE-LOCKED frames (lvm_host_alloc): the zero-copy surface.  `pad` extra bytes per row on both sides."""

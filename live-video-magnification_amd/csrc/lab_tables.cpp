@@ -28,11 +28,14 @@ constexpr int kTab = 1024;
 // uninitialised stack array of lvm_create: whatever the stack held went into the top knots of the inverse-gamma table -- harmless for
 // the usual small junk, every pixel NaN when it happened to be a NaN pattern: one GPU test run in four inside a full pytest session,
 // never in isolation, found with -ftrivial-auto-var-init=pattern on the emulation build, tools/emu_uninit.sh).
+// Round 5: the OpenCV 4 form of the function (color_lab.cpp, softfloat): the forward sweep runs to i = n - 1 and the back substitution
+// divides by 3 -- rounds 1-4 restated the 3.x form (sweep to n - 2, multiplications by 0.3333333333333333f), which the oracle keeps as
+// the switch LVMO_VAR_SPLINE_CV3 (tests/test_oracle_variants.py: what the difference does to a frame).
 void spline_build(const float* f, int n, float* tab) {
     float cn = 0.f;
     tab[0] = tab[1] = 0.f;
     tab[(n - 1) * 4] = tab[(n - 1) * 4 + 1] = 0.f;
-    for (int i = 1; i < n - 1; ++i) {
+    for (int i = 1; i < n; ++i) {
         const float t = 3.f * (f[i + 1] - 2.f * f[i] + f[i - 1]);
         const float l = 1.f / (4.f - tab[(i - 1) * 4]);
         tab[i * 4] = l;
@@ -40,8 +43,8 @@ void spline_build(const float* f, int n, float* tab) {
     }
     for (int i = n - 1; i >= 0; --i) {
         const float c = tab[i * 4 + 1] - tab[i * 4] * cn;
-        const float b = f[i + 1] - f[i] - (cn + c * 2.f) * 0.3333333333333333f;
-        const float d = (cn - c) * 0.3333333333333333f;
+        const float b = f[i + 1] - f[i] - (cn + c * 2.f) / 3.f;
+        const float d = (cn - c) / 3.f;
         tab[i * 4] = f[i];
         tab[i * 4 + 1] = b;
         tab[i * 4 + 2] = c;

@@ -26,10 +26,6 @@
 #include <cstring>
 #include <vector>
 
-#ifndef LVM_EXPERIMENTAL
-#define LVM_EXPERIMENTAL 0        // 1: also build the schedules that were measured slower and are kept for the next attempt (k_lap_final1, k_down01_lut_rows)
-#endif
-
 #include "pyramid.h"
 
 namespace lvm {
@@ -650,9 +646,6 @@ struct FinArgs {
     LabCoef lab; float ca; int strips_x, strips_y, nstreams, rows;
     float* dbg; LabPlanes lp;
 };
-#ifndef LVM_FIN_PACKED
-#define LVM_FIN_PACKED LVM_EXPERIMENTAL   // the default flavour's inverse colour arithmetic on pixel pairs (v_pk_*_f32): 12 % fewer vector instructions in
-#endif                                    // k_lap_final_v4 and NO change of its time (207 -> 211 us per 32 frames: the kernel waits for HBM, not for issue slots)
 // One output row of 4 pixels: Lab(in) + [1, ca, ca] * motion -> Lab2BGR -> u8 (MagnifyCore.hpp:143-153).  m = the motion image of the
 // row (EXACT: scaled by 1/64 as pyrUp does; otherwise the unscaled vertical sum, whose power-of-two scale `msc` is folded into the
 // add -- fma(m, 2^-k, L) rounds exactly like L + m * 2^-k).  dbg_px: where the float pixels go (lvm_debug_keep_float) or null.
@@ -663,23 +656,6 @@ __device__ __forceinline__ void lap_emit_row(const Raw4 pin, const float (&m)[3]
     float L4[4], a4[4], b4[4];
     raw4_to_lab<FL>(pin, s_gam, lab, L4, a4, b4);
     float ov[12];
-#if LVM_FIN_PACKED
-    if (!EXACT && !DBG) {                                   // default flavour: two pixels per packed FP32 operation
-#pragma unroll
-        for (int k = 0; k < 4; k += 2) {
-            lvm_f2 L = f2_set(L4[k], L4[k + 1]), a = f2_set(a4[k], a4[k + 1]), bb = f2_set(b4[k], b4[k + 1]);
-            if (MOTION) {
-                L = f2_fma(f2_set(m[0][k], m[0][k + 1]), f2_all(msc), L);
-                a = f2_fma(f2_set(m[1][k], m[1][k + 1]), f2_all(msc * ca), a);
-                bb = f2_fma(f2_set(m[2][k], m[2][k + 1]), f2_all(msc * ca), bb);
-            }
-            lvm_f2 o0, o1, o2;
-            lab_to_bgr_pair(L, a, bb, lab.inv1024, s_igt, o0, o1, o2);
-            o0 = f2_fma(o0, f2_all(255.0f), f2_all(lab.a255)); o1 = f2_fma(o1, f2_all(255.0f), f2_all(lab.a255)); o2 = f2_fma(o2, f2_all(255.0f), f2_all(lab.a255));
-            ov[3 * k] = o0[0]; ov[3 * k + 1] = o1[0]; ov[3 * k + 2] = o2[0]; ov[3 * k + 3] = o0[1]; ov[3 * k + 4] = o1[1]; ov[3 * k + 5] = o2[1];
-        }
-    } else
-#endif
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float o0, o1, o2;
@@ -823,287 +799,6 @@ __global__ LVM_FIN_BOUNDS void k_lap_final_v4(FinArgs q) {
         lap_final_strip<MOTION, DBG, FL>(q, task, lane, s_igt, s_gam);
 }
 
-#if LVM_EXPERIMENTAL
-// ---- level-1 step + last kernel in ONE launch (round 4) --------------------------------------------------------------------------
-// EXPERIMENTAL (built only with -DLVM_EXPERIMENTAL=1; the emulation build of the test suite has it, liblvm_hip.so does not): correct
-// -- bit-identical to the oracle in the exact flavour, verified on the GPU -- but SLOWER than the two kernels it replaces: 504-529 us
-// per 32 frames of 1080p against 106 + 208.  Why (ISA + counters, profiles/README.md round 4): with the frame loop inside, one thread
-// carries three roles (18 state registers, its share of two prefetches, the 4 x 2-pixel colour arithmetic) -- 128 VGPRs + 200 bytes of
-// scratch + ~100 SGPRs spilled to VGPR lanes, ~1000 vector instructions per thread and frame, and every spill reload is a vmcnt(0).
-// Until round 3 the level-1 step (k_lap_up: band_1 = G_1 - pyrUp(G_2), both IIR low-passes, cur_1 = pyrUp(cur_2) + gain_1 m_1) wrote
-// cur_1 to HBM and the last kernel read it back: 12.4 MB per 1080p frame each way, and one launch whose only other traffic is G_1 in.
-// Here ONE workgroup owns a 128 x 16 tile of the OUTPUT frame for all frames of the batch and does, per frame,
-//   phase 1  horizontal pyrUp pass of the level-2 rows the tile depends on (G_2 and cur_2 side by side as float pairs: the same
-//            formulas, one packed operation): lane <-> level-2 column, neighbours by whole-wave DPP shifts, results -> LDS;
-//   phase 2  vertical pass, band_1, both IIR steps (states in registers for the whole batch) and cur_1 for the tile's 64 x 8 level-1
-//            pixels plus a one-pixel ring (the ring's states are recomputed copies: 29 % more level-1 work, no exchange between
-//            workgroups) -> cur_1 tile in LDS, never in HBM;
-//   phase 3  the last kernel on that tile: pyrUp(cur_1) from LDS, Lab(in) from the integer planes, add, Lab2BGR, u8 out
-//            (a thread = 4 columns x 2 rows; the arithmetic is lap_final_strip's).
-// The states are double-buffered per launch (every level-1 pixel is owned, i.e. written, by exactly one workgroup).
-// Two barriers per frame.
-// Why tiles and not wave strips: with the frame loop inside, a launch's parallelism is pixels / (pixels per lane), not x frames; 8
-// pixels per lane and 4 waves per SIMD is what fills an MI355X with ONE 1080p stream (1020 workgroups for 1024 resident slots), and a
-// strip with its own halo rows would need 32 pixels per lane.  Same operations in the same order as k_lap_up + k_lap_final_v4:
-// bit-identical frames in the exact flavour (tests/test_emu_parity.py).
-typedef float f2 __attribute__((vector_size(8)));
-__device__ __forceinline__ f2 f2bc(float a) { f2 v = {a, a}; return v; }
-__device__ __forceinline__ f2 f2sel(bool c, f2 a, f2 b) { f2 v = {sel(c, a[0], b[0]), sel(c, a[1], b[1])}; return v; }
-constexpr int F1_W = 128, F1_H = 16;                          // output tile of a workgroup
-constexpr int F1_RW = F1_W / 2 + 2, F1_RH = F1_H / 2 + 2;      // level-1 region with its ring: 66 x 10; region (rx, ry) <-> level-1 (X1 - 1 + rx, Y1 - 1 + ry)
-constexpr int F1_HR = F1_H / 4 + 3;                            // level-2 rows a region depends on: m0 - 1 .. m0 + 5
-constexpr int F1_HW = F1_RW + 2;                               // pitch of a horizontal-pass row (float pairs; region column rx at rx + 1: 16-byte aligned pairs)
-constexpr int F1_CP = F1_RW + 1;                               // pitch of the cur_1 tile
-constexpr int F1_U1 = (3 * F1_HR + 3) / 4;                     // phase 1: (channel, level-2 row) units per wave
-constexpr int F1_U2 = 3 * F1_RH;                               // phase 2: (region row, channel) units of 64 lanes ...
-constexpr int F1_NQ = (F1_U2 + 3) / 4;                         // ... per wave; the region's last two columns are one more item of wave 2
-static_assert(F1_W / 4 + 3 <= 64 && F1_RW == 66 && 2 * F1_U2 <= 64 && F1_W * F1_H == 8 * 256, "k_lap_final1: tile / thread mapping");
-struct Fin1Args {
-    const uint8_t* in; long in_stride, in_sstride;            // frame f of stream b at in + (f * nstreams + b) * in_sstride
-    uint8_t* out; long out_stride, out_sstride;
-    int w, h, w1, h1, w2, h2;
-    const float* G1; const float* G2; const float* cur2;      // [frame][stream * 3 + channel][h_l][w_l]; cur2 unused without HC
-    const float* hi; const float* lo;                          // level-1 IIR states [stream * 3 + channel][h1 * w1], as the previous launch left them
-    float* hi_out; float* lo_out;                              // ... as this launch leaves them: a SECOND pair of planes.  The ring pixels of a tile are state
-                                                               // copies read from the planes of a neighbouring workgroup, which may have finished already
-    long fs1, fs2;                                             // frame strides (floats) of the level-1 / level-2 arrays
-    float aHi, bHi, aLo, bLo, gain, ca;
-    int nt, nstreams, tiles_x, tiles_y;
-    LabCoef lab; LabPlanes lp; float* dbg;
-};
-template <bool HC, bool DBG, int FL>                           // HC: cur_2 exists (L >= 3); otherwise level 1 is the top live level
-#ifndef LVM_F1_WAVES
-#define LVM_F1_WAVES 4
-#endif
-#ifndef LVM_F1_PREFETCH_L2
-#define LVM_F1_PREFETCH_L2 1     // the level-2 taps of frame t + 1 fly through phase 3 of frame t (12 registers across the widest phase)
-#endif
-__global__ __launch_bounds__(256, LVM_F1_WAVES) void k_lap_final1(Fin1Args q) {
-    constexpr bool EXACT = fl_exact(FL);
-    constexpr bool PLANES = fl_lut(FL);
-    __shared__ __attribute__((aligned(16))) float s_igt[4096];
-    __shared__ float s_gam[fl_lut(FL) ? 1 : 256];
-    __shared__ __attribute__((aligned(16))) f2 s_H[3][F1_HR][F1_HW];
-    __shared__ float s_C[3][F1_RH][F1_CP];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    {
-        const float4* src = reinterpret_cast<const float4*>(q.lab.invgamma);
-        for (int i = tid; i < 1024; i += 256) reinterpret_cast<float4*>(s_igt)[i] = src[i];
-        if (!fl_lut(FL)) s_gam[tid] = q.lab.gamma_u8[tid];
-    }                                                          // (visible after the first barrier of the frame loop)
-    const int tiles = q.tiles_x * q.tiles_y;
-    const int sb = (int)blockIdx.x / tiles;
-    const int tr = (int)blockIdx.x - sb * tiles;
-    const int by = tr / q.tiles_x, bx = tr - by * q.tiles_x;
-    const int w = q.w, h = q.h, w1 = q.w1, h1 = q.h1, w2 = q.w2, h2 = q.h2;
-    const int X0 = bx * F1_W, Y0 = by * F1_H, X1 = X0 / 2, Y1 = Y0 / 2, k0 = X1 / 2, m0 = Y1 / 2;
-    const size_t n1 = (size_t)w1 * h1, n2 = (size_t)w2 * h2;
-    const float aHi = q.aHi, bHi = q.bHi, aLo = q.aLo, bLo = q.bLo, gain = q.gain, ca = q.ca;
-
-    // ---- phase 1 set-up: lane <-> level-2 column k0 - 1 + lane (35 of them feed the region), unit <-> (channel, level-2 row).
-    // Everything that depends on the unit only is wave-uniform and recomputed per frame on the scalar unit; per lane there is the column.
-    const int k2 = k0 - 1 + lane;
-    const int kc = k2 < 0 ? 0 : (k2 > w2 - 1 ? w2 - 1 : k2);
-    const bool fi = k2 == 0, la = k2 == w2 - 1;
-    const bool hborder = bx == 0 || k0 + F1_W / 4 + 1 >= w2 - 1;       // (uniform) a lane of this tile sits on the first / last level-2 column
-    auto unit1 = [&](int i, int& ch, int& mr, int& m) __attribute__((always_inline)) {   // false: this wave has no unit i
-        const int u = wave + 4 * i;
-        if (u >= 3 * F1_HR) { ch = mr = m = 0; return false; }
-        ch = u / F1_HR; mr = u - ch * F1_HR;
-        m = m0 - 1 + mr;
-        m = m < 0 ? 1 : (m > h2 - 1 ? h2 - 1 : m);                    // pyrUp's vertical border map (row -1 -> 1, row h2 -> h2 - 1)
-        return true;
-    };
-    // ---- phase 2 set-up: item q <-> unit u = wave + 4 q = (region row ry, channel), lane <-> region column rx (0 .. 63); the columns
-    // 64, 65 of all 30 units are the lanes 0 .. 59 of one more item of wave 2.  Per lane: the level-1 column (clamped for the loads).
-    const int cx = X1 - 1 + lane;
-    const bool vx = cx >= 0 && cx < w1;
-    const int cxc = cx < 0 ? 0 : (cx > w1 - 1 ? w1 - 1 : cx);
-    auto unit2 = [&](int qi, int& ch, int& ry, int& cy) __attribute__((always_inline)) {   // false: no such unit, or its row lies outside the plane
-        const int u = wave + 4 * qi;
-        ry = u < F1_U2 ? u / 3 : 0; ch = u < F1_U2 ? u - 3 * ry : 0;
-        cy = Y1 - 1 + ry;
-        return u < F1_U2 && cy >= 0 && cy <= h1 - 1;
-    };
-    const int xu = lane >> 1;                                          // the extra item: per-lane unit and column
-    const int xry = xu < F1_U2 ? xu / 3 : 0, xch = xu < F1_U2 ? xu - 3 * xry : 0, xrx = 64 + (lane & 1);
-    const int xcy = Y1 - 1 + xry, xcx = X1 - 1 + xrx;
-    const bool xok = wave == 2 && xu < F1_U2 && xcx >= 0 && xcx < w1 && xcy >= 0 && xcy <= h1 - 1;
-    const unsigned xoffg = xok ? (unsigned)((size_t)(sb * 3 + xch) * n1 + (size_t)xcy * w1 + xcx) : 0u;
-    float hi_r[F1_NQ + 1], lo_r[F1_NQ + 1];
-#pragma unroll
-    for (int qi = 0; qi < F1_NQ; ++qi) {
-        int ch, ry, cy;
-        const bool ok = unit2(qi, ch, ry, cy) && vx;
-        const size_t o = (size_t)(sb * 3 + ch) * n1 + (size_t)(ok ? cy : 0) * w1 + cxc;
-        hi_r[qi] = ok ? q.hi[o] : 0.f;
-        lo_r[qi] = ok ? q.lo[o] : 0.f;
-    }
-    hi_r[F1_NQ] = xok ? q.hi[xoffg] : 0.f;
-    lo_r[F1_NQ] = xok ? q.lo[xoffg] : 0.f;
-    // ---- phase 3 set-up: thread <-> output columns gx .. gx + 3, rows gy, gy + 1 (one level-1 row j = Y1 + p)
-    const int g4 = tid & 31, p = tid >> 5;
-    const int gx = X0 + 4 * g4, gy = Y0 + 2 * p;
-    const bool act = gx < w && gy < h, act1 = act && gy + 1 < h;
-    const int i0 = gx >> 1;
-    // region rows of the level-1 rows j - 1, j, j + 1 (row -1 is row 1, row h1 is row h1 - 1) and region columns of the four taps
-    // i0 - 1 .. i0 + 2 (default flavour: the border rule is applied by the taps -- column -1 reads column 1, column w1 reads column
-    // w1 - 1 -- and every thread runs the interior formulas, as lap_final_strip does)
-    const int rb = p + 1;
-    const int ra = (Y1 + p - 1 < 0) ? 2 : rb - 1;
-    const int rc = (Y1 + p + 1 > h1 - 1) ? h1 - Y1 : rb + 1;
-    const int cb = 2 * g4 + 1;
-    const int cm1 = i0 > 0 ? cb - 1 : (EXACT ? cb : 2), cp1 = i0 + 1 < w1 ? cb + 1 : w1 - X1, cp2 = i0 + 2 < w1 ? cb + 2 : w1 - X1;
-    const uint8_t* src = q.in + (size_t)sb * q.in_sstride;
-    uint8_t* dst = q.out + (size_t)sb * q.out_sstride;
-    const size_t in_fs = (size_t)q.nstreams * q.in_sstride, out_fs = (size_t)q.nstreams * q.out_sstride, px_fs = (size_t)q.nstreams * w * h;
-    const size_t poff = (size_t)sb * w * h;
-    const unsigned xoff = (unsigned)gx * 3u;
-    const int gyl = act ? gy : 0, gyl1 = act1 ? gy + 1 : gyl;          // rows the inactive threads load instead (never stored)
-    const unsigned gxl = act ? (unsigned)gx : 0u;
-
-    // Loads of a frame.  The level-2 taps (first use: phase 1) of frame t + 1 are issued before phase 3 of frame t and fly through it; G_1
-    // (phase 2) and the two rows of integer planes (phase 3) are issued at the top of their own frame, ahead of phase 1.  (All three a
-    // whole frame ahead would hold 33 more registers across phase 3, the widest part: 128 VGPRs + scratch spills.)
-    f2 n2v[F1_U1];
-    auto fetch_l2 = [&](int t) __attribute__((always_inline)) {
-        const float* G2t = q.G2 + (size_t)t * q.fs2;
-        const float* C2t = (HC ? q.cur2 : q.G2) + (size_t)t * q.fs2;
-#pragma unroll
-        for (int i = 0; i < F1_U1; ++i) {
-            int ch, mr, m;
-            unit1(i, ch, mr, m);
-            const size_t rowb = (size_t)(sb * 3 + ch) * n2 + (size_t)m * w2;     // (uniform)
-            n2v[i][0] = (G2t + rowb)[kc]; n2v[i][1] = HC ? (C2t + rowb)[kc] : 0.f;
-        }
-    };
-    fetch_l2(0);
-    for (int t = 0; t < q.nt; ++t) {
-        f2 c2v[F1_U1]; float g1[F1_NQ + 1];
-#if !LVM_F1_PREFETCH_L2
-        if (t > 0) fetch_l2(t);
-#endif
-#pragma unroll
-        for (int i = 0; i < F1_U1; ++i) c2v[i] = n2v[i];
-        {
-            const float* G1t = q.G1 + (size_t)t * q.fs1;
-#pragma unroll
-            for (int qi = 0; qi < F1_NQ; ++qi) {
-                int ch, ry, cy;
-                const bool vy = unit2(qi, ch, ry, cy);
-                g1[qi] = (G1t + (size_t)(sb * 3 + ch) * n1 + (size_t)(vy ? cy : 0) * w1)[cxc];
-            }
-            g1[F1_NQ] = G1t[xoffg];
-        }
-        const Raw4 pe = load_raw4<PLANES>(src + (size_t)t * in_fs, q.in_stride, q.lp, poff + (size_t)t * px_fs, w, gyl, gxl);
-        const Raw4 po = load_raw4<PLANES>(src + (size_t)t * in_fs, q.in_stride, q.lp, poff + (size_t)t * px_fs, w, gyl1, gxl);
-
-        // ---- phase 1: horizontal pyrUp pass of the level-2 rows (OpenCV pyrUp_ border rules as pyrup_h)
-#pragma unroll
-        for (int i = 0; i < F1_U1; ++i) {
-            int ch, mr, m;
-            const bool have = unit1(i, ch, mr, m);
-            const f2 s0 = c2v[i];
-            f2 sm1, s1;
-            sm1[0] = dpp_shr1(s0[0]); sm1[1] = dpp_shr1(s0[1]); s1[0] = dpp_shl1(s0[0]); s1[1] = dpp_shl1(s0[1]);
-            const f2 p6 = s0 * f2bc(6.f);
-            f2 ev = (sm1 + p6) + s1, od = (s0 + s1) * f2bc(4.f);
-            if (hborder) {
-                ev = f2sel(fi, p6 + s1 * f2bc(2.f), f2sel(la, sm1 + s0 * f2bc(7.f), ev));
-                od = f2sel(la, s0 * f2bc(8.f), od);
-            }
-            // lane l holds the level-1 columns 2 k and 2 k + 1 = region columns 2 l - 1 and 2 l, stored at 2 l and 2 l + 1
-            if (have && lane < F1_HW / 2) { f2* d = &s_H[ch][mr][2 * lane]; d[0] = ev; d[1] = od; }
-        }
-        __syncthreads();
-        // ---- phase 2: vertical pass, band, IIR x 2, gain, collapse step -> cur_1 tile
-#pragma unroll
-        for (int qi = 0; qi < F1_NQ; ++qi) {
-            int ch, ry, cy;
-            if (!unit2(qi, ch, ry, cy)) continue;                       // (uniform) no unit / a ring row outside the plane: phase 3 reads the mapped row instead
-            const int j = cy >> 1;
-            const int mb = j - (m0 - 1), ma = (j == 0 ? 1 : j - 1) - (m0 - 1), mc = (j == h2 - 1 ? h2 - 1 : j + 1) - (m0 - 1);
-            const f2* Hc = &s_H[ch][0][lane + 1];
-            f2 up;
-            if ((cy & 1) == 0) up = ((Hc[ma * F1_HW] + Hc[mb * F1_HW] * f2bc(6.f)) + Hc[mc * F1_HW]) * f2bc(1.f / 64.f);
-            else up = ((Hc[mb * F1_HW] + Hc[mc * F1_HW]) * f2bc(4.f)) * f2bc(1.f / 64.f);
-            const float band = g1[qi] - up[0];                          // SpatialFilter.cpp:33
-            const float t1 = hi_r[qi] * aHi + band * bHi;               // TemporalFilter.cpp:16
-            const float t2 = lo_r[qi] * aLo + band * bLo;               // :17
-            hi_r[qi] = t1; lo_r[qi] = t2;
-            const float m = (t1 - t2) * gain;                           // :21, MagnifyCore.hpp:129-132
-            s_C[ch][ry][lane] = (HC ? up[1] : 0.f) + m;                 // SpatialFilter.cpp:58  (columns outside the plane: never read)
-        }
-        if (wave == 2) {                                                // the region's columns 64, 65 (per-lane unit: both row parities evaluated)
-            int cy = xcy < 0 ? 1 : (xcy > h1 - 1 ? h1 - 1 : xcy);       // (rows outside the plane: xok is false, any row of the region will do)
-            const int j = cy >> 1;
-            const int mb = j - (m0 - 1), ma = (j == 0 ? 1 : j - 1) - (m0 - 1), mc = (j == h2 - 1 ? h2 - 1 : j + 1) - (m0 - 1);
-            const f2* Hc = &s_H[xch][0][xrx + 1];
-            const f2 A = Hc[ma * F1_HW], B = Hc[mb * F1_HW], C = Hc[mc * F1_HW];
-            const f2 up = f2sel((cy & 1) == 0, ((A + B * f2bc(6.f)) + C) * f2bc(1.f / 64.f), ((B + C) * f2bc(4.f)) * f2bc(1.f / 64.f));
-            const float band = g1[F1_NQ] - up[0];
-            const float t1 = hi_r[F1_NQ] * aHi + band * bHi;
-            const float t2 = lo_r[F1_NQ] * aLo + band * bLo;
-            hi_r[F1_NQ] = t1; lo_r[F1_NQ] = t2;
-            const float m = (t1 - t2) * gain;
-            if (xu < F1_U2) s_C[xch][xry][xrx] = (HC ? up[1] : 0.f) + m;
-        }
-        __syncthreads();
-#if LVM_F1_PREFETCH_L2
-        fetch_l2(t + 1 < q.nt ? t + 1 : q.nt - 1);                   // (unconditional: the same registers are refilled every iteration)
-#endif
-        // ---- phase 3: out = u8(Lab2BGR(Lab(in) + [1, ca, ca] * pyrUp(cur_1))) for the thread's 4 x 2 pixels
-        if (act) {
-            // motion image of the two rows, channel by channel: the horizontal pass of the three cur_1 rows of ONE channel (12 values), then
-            // both vertical formulas -- 24 values live at the end instead of three Row3 (36) + the row being emitted (12)
-            float me[3][4], mo[3][4];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float4 hA, hB, hC;
-                auto hrow1 = [&](int r) __attribute__((always_inline)) {
-                    const float* rowp = &s_C[c][r][0];
-                    const float sm1 = rowp[cm1], s0 = rowp[cb], s1 = rowp[cp1], s2 = rowp[cp2];
-                    float4 o;
-                    if (EXACT) o = pyrup_h4(sm1, s0, s1, s2, i0, w1);
-                    else if (LVM_FAST_FMA) { o.x = __builtin_fmaf(s0, 6.f, sm1 + s1); o.y = (s0 + s1) * 4.f; o.z = __builtin_fmaf(s1, 6.f, s0 + s2); o.w = (s1 + s2) * 4.f; }
-                    else { o.x = sm1 + s0 * 6.f + s1; o.y = (s0 + s1) * 4.f; o.z = s0 + s1 * 6.f + s2; o.w = (s1 + s2) * 4.f; }
-                    return o;
-                };
-                hA = hrow1(ra); hB = hrow1(rb); hC = hrow1(rc);
-                if (!EXACT && LVM_FAST_FMA) {
-                    me[c][0] = __builtin_fmaf(hB.x, 6.f, hA.x + hC.x); me[c][1] = __builtin_fmaf(hB.y, 6.f, hA.y + hC.y);
-                    me[c][2] = __builtin_fmaf(hB.z, 6.f, hA.z + hC.z); me[c][3] = __builtin_fmaf(hB.w, 6.f, hA.w + hC.w);
-                } else {
-                    const float sc = EXACT ? (1.f / 64.f) : 1.f;
-                    me[c][0] = (hA.x + hB.x * 6.f + hC.x) * sc; me[c][1] = (hA.y + hB.y * 6.f + hC.y) * sc;
-                    me[c][2] = (hA.z + hB.z * 6.f + hC.z) * sc; me[c][3] = (hA.w + hB.w * 6.f + hC.w) * sc;
-                }
-                if (EXACT) {
-                    mo[c][0] = ((hB.x + hC.x) * 4.f) * (1.f / 64.f); mo[c][1] = ((hB.y + hC.y) * 4.f) * (1.f / 64.f);
-                    mo[c][2] = ((hB.z + hC.z) * 4.f) * (1.f / 64.f); mo[c][3] = ((hB.w + hC.w) * 4.f) * (1.f / 64.f);
-                } else { mo[c][0] = hB.x + hC.x; mo[c][1] = hB.y + hC.y; mo[c][2] = hB.z + hC.z; mo[c][3] = hB.w + hC.w; }
-            }
-            float* dbgp = (DBG && q.dbg && sb == 0 && t == 0) ? q.dbg : nullptr;
-            uint8_t* orow = dst + (size_t)t * out_fs + (size_t)gy * q.out_stride + xoff;
-            lap_emit_row<true, DBG, FL>(pe, me, 1.f / 64.f, ca, q.lab, s_igt, s_gam, dbgp ? dbgp + ((size_t)gy * w + gx) * 3 : nullptr, orow);
-            if (act1) lap_emit_row<true, DBG, FL>(po, mo, 1.f / 16.f, ca, q.lab, s_igt, s_gam, dbgp ? dbgp + ((size_t)(gy + 1) * w + gx) * 3 : nullptr, orow + q.out_stride);
-        }
-    }
-    // the states of the pixels this workgroup owns (the ring's are copies of a neighbour's)
-#pragma unroll
-    for (int qi = 0; qi < F1_NQ; ++qi) {
-        int ch, ry, cy;
-        const bool ok = unit2(qi, ch, ry, cy) && vx;
-        if (ok && lane >= 1 && ry >= 1 && ry <= F1_H / 2) {
-            const size_t o = (size_t)(sb * 3 + ch) * n1 + (size_t)cy * w1 + cxc;
-            q.hi_out[o] = hi_r[qi]; q.lo_out[o] = lo_r[qi];
-        }
-    }
-    if (xok && xrx <= F1_W / 2 && xry >= 1 && xry <= F1_H / 2) { q.hi_out[xoffg] = hi_r[F1_NQ]; q.lo_out[xoffg] = lo_r[F1_NQ]; }
-}
-
-#endif  // LVM_EXPERIMENTAL
 
 // ------------------------------------------------------------------------------------------
 // Tail kernel: every pyramid level from T upwards (G_T has at most kTailMax pixels) is handled by
@@ -1225,7 +920,6 @@ struct LaplaceState : ModeState {
     float* G[kMaxLevels + 1] = {};
     float *hi[kMaxLevels + 1] = {}, *lo[kMaxLevels + 1] = {}, *cur[kMaxLevels + 1] = {};
     bool seeded = false;
-    float *hi1x = nullptr, *lo1x = nullptr;   // second pair of level-1 state planes (k_lap_final1 reads one pair and writes the other; swapped per launch)
     float* Gp[2][kMaxLevels + 1] = {};    // Gaussian pyramid, double-buffered by frame parity (pipelined mode)
     float* curT[2] = {};                  // cur_T written by the tail kernel, double-buffered likewise
     struct Pending { bool valid = false; FrameIO io{}; lvm_params p{}; int par = 0; } pending;
@@ -1245,21 +939,16 @@ struct LaplaceState : ModeState {
     long up_rows_max_blocks = 1024;       // launches with fewer tiled workgroups than this use k_lap_up_rows (LVM_UP_ROWS_MAX_BLOCKS)
     bool d0_rows_on = true;               // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
     bool d0_fused = true;                 // table conversion fused into the first kernel on large launches (LVM_D0_FUSED=0: separate kernels)
-    bool d0_l2 = false;                   // ... with the second pyramid level inside (experimental build only: k_down01_lut_rows, LVM_D0_L2=1; measured not faster)
-    int d0_l2_rows = 0;                   // ... level-2 rows per strip (LVM_D0_L2_ROWS; 0 = chosen against wave-level quantisation)
     long d0_fused_waves = 0;              // ... = launches with at least this many strips (LVM_D0_FUSED_WAVES; 0 = one per resident wave)
     long d0_min_tasks = 4096;             // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
     long fin_groups = 0;                  // workgroups of the persistent last kernel (LVM_FIN_GROUPS; 0 = 1024)
     int fin_rows = 8;                     // rows per wave strip of k_lap_final_v4 (LVM_FIN_ROWS, power of two)
     int up_depth_big = 1;                 // ... at the levels with >= 1024 workgroups (LVM_UP_DEPTH_BIG)
     int up_depth = 8;                     // frame-loop prefetch depth of k_lap_up at the coarse levels (LVM_UP_DEPTH=1|2|4|8)
-    bool final1 = false;                  // level-1 step fused into the last kernel, cur_1 never in HBM (k_lap_final1; LVM_LAP_FINAL1=1).  Off: first GPU measurement 504 us
-                                          // per 32 frames against 106 + 208 us for k_lap_up + k_lap_final_v4 (profiles/README.md, round 4)
     int pd_rows = 16;                     // output rows per wave strip of k_pyr_down_rows (LVM_PD_ROWS)
     int fuse_down = 2;                    // pyramid levels per pyrDown launch (LVM_FUSE_DOWN=2|3 selects the fused kernels)
     int tailT = 0;                       // first level handled by k_lap_tail (0 = tail disabled)
     TailArgs tail{};
-    void swap_level1_states() { std::swap(hi[1], hi1x); std::swap(lo[1], lo1x); }
     ~LaplaceState() override {
         if (arena) (void)hipFree(arena);
         if (tarena) (void)hipFree(tarena);
@@ -1281,7 +970,6 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     auto pad = [](size_t n) { return (n + 63) & ~(size_t)63; };
     for (int l = 1; l <= levels; ++l) total += 2 * pad(st->g[l].n * st->planes);
     for (int l = 1; l < levels; ++l) total += 5 * pad(st->g[l].n * st->planes);
-    if (levels >= 2) total += 2 * pad(st->g[1].n * st->planes);
     const size_t npx = st->g[0].n * c->nstreams;                 // pixels of one frame set
     if (channels == 3) total += 2 * (pad(npx) + pad((npx + 1) / 2));
     if (total == 0) total = 64;
@@ -1304,7 +992,6 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
         st->lo[l] = p; p += pad(st->g[l].n * st->planes);
         st->cur[l] = p; p += pad(st->g[l].n * st->planes);
     }
-    if (levels >= 2) { st->hi1x = p; p += pad(st->g[1].n * st->planes); st->lo1x = p; p += pad(st->g[1].n * st->planes); }
     laplace_tail_plan(st);
     if (const char* e = std::getenv("LVM_FUSE_DOWN")) st->fuse_down = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_DEPTH")) st->up_depth = std::atoi(e);
@@ -1312,14 +999,11 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     if (const char* e = std::getenv("LVM_PD_ROWS")) st->pd_rows = std::atoi(e);
     if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
     if (const char* e = std::getenv("LVM_D0_FUSED")) st->d0_fused = std::atoi(e) != 0;
-    if (const char* e = std::getenv("LVM_D0_L2")) st->d0_l2 = std::atoi(e) != 0;
-    if (const char* e = std::getenv("LVM_D0_L2_ROWS")) st->d0_l2_rows = std::atoi(e);
     if (const char* e = std::getenv("LVM_D0_FUSED_WAVES")) st->d0_fused_waves = std::atol(e);
     if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
     if (const char* e = std::getenv("LVM_LAP_SPLIT")) st->split_levels = std::atoi(e);
     if (const char* e = std::getenv("LVM_LAP_SPLIT_MIN_NT")) st->split_min_nt = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_ROWS")) st->up_rows = std::atoi(e);
-    if (const char* e = std::getenv("LVM_LAP_FINAL1")) st->final1 = std::atoi(e) != 0;
     if (const char* e = std::getenv("LVM_UP_ROWS_MAX_BLOCKS")) st->up_rows_max_blocks = std::atol(e);
     if (const char* e = std::getenv("LVM_ROWS_MIN_ELEMS")) st->rows_min_elems = std::atol(e);
     if (const char* e = std::getenv("LVM_FIN_MIN_TASKS")) st->fin_min_tasks = std::atol(e);
@@ -1412,27 +1096,6 @@ static bool lap_d0l_args(Ctx* c, LaplaceState* st, const FrameIO& io, const LapB
     return true;
 }
 
-#if LVM_EXPERIMENTAL
-// ... and of k_down01_lut_rows (the same launch with the second pyramid level inside): G_2 comes out of the first kernel, the level-1
-// pyrDown launch disappears.  Needs a level 2 of at least 2 rows and a level 1 of at least 3 (the REFLECT_101 copies of the bottom rows).
-static bool lap_d01l_args(Ctx* c, LaplaceState* st, const FrameIO& io, const LapBufs& B, D01LArgs* out) {
-    const int NS = c->nstreams * B.nt, levels = st->levels;
-    const LabPlanes lp = lap_planes(c, io, B);
-    if (!(st->d0_l2 && lp.iab && levels >= 2 && st->d0_fused && lap_vec4(io) && st->g[1].w % 2 == 0 && st->g[1].h >= 3 && st->g[2].h >= 2 &&
-          st->g[2].w == io.w / 4)) return false;
-    long tasks = 0;
-    const long waves = st->d0_fused_waves > 0 ? st->d0_fused_waves : (long)c->num_cus * (D0L_THREADS / 64);
-    const LevelGeom &g1 = st->g[1], &g2 = st->g[2];
-    int rows = down01_lut_rows_choice(g2.w, g2.h, NS, waves, &tasks);
-    if (st->d0_l2_rows > 0) { rows = st->d0_l2_rows; tasks = (long)((g2.w + D01L_OUT - 1) / D01L_OUT) * ((g2.h + rows - 1) / rows) * NS; }
-    if (tasks <= 0) return false;
-    const int sx = (g2.w + D01L_OUT - 1) / D01L_OUT, sy = (g2.h + rows - 1) / rows;
-    *out = D01LArgs{io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h, B.G[1], g1.w, g1.h, B.G[2], g2.w, g2.h, c->lab_lut, sx, sy, (int)tasks, rows,
-                    B.iL, B.iab};
-    return true;
-}
-
-#endif
 
 static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const FrameIO& io, const LapBufs& B, bool first, hipStream_t s) {
     const int C = io.channels, levels = st->levels;
@@ -1443,13 +1106,7 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     const LabPlanes lp = lap_planes(c, io, B);
     // large launches: conversion and first pyramid kernel in one pass (k_down0_lut_rows); LVM_D0_FUSED=0 keeps them apart
     D0LArgs da{};
-#if LVM_EXPERIMENTAL
-    D01LArgs da2{};
-    const bool fused2 = lap_d01l_args(c, st, io, B, &da2);
-#else
-    const bool fused2 = false;
-#endif
-    const bool fused = fused2 || lap_d0l_args(c, st, io, B, &da);
+    const bool fused = lap_d0l_args(c, st, io, B, &da);
     if (lp.iab && !fused) lab_lut_planes(c, io.d_in, (long)io.in_stride, (long)io.in_sstride, io.w, io.h, NS, B.iL, nullptr, B.iab, s);
     if (levels < 2) return;
     float** G = B.G;
@@ -1460,12 +1117,6 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     long d0_tasks = 0;
     const int d0_rows = down0_rows_choice(g1.w, g1.h, NS, st->d0_min_tasks, &d0_tasks);
     const int fl = lab_flavour(c);
-#if LVM_EXPERIMENTAL
-    if (fused2) {
-        auto kdl = fl == FL_LUT_EXACT ? k_down01_lut_rows<FL_LUT_EXACT> : k_down01_lut_rows<FL_LUT_FAST>;
-        LVM_LAUNCH(c, "lap_down01_lut", kdl, dim3((unsigned)c->num_cus), dim3(D0L_THREADS), s, da2);
-    } else
-#endif
     if (fused) {
         auto kdl = fl == FL_LUT_EXACT ? k_down0_lut_rows<FL_LUT_EXACT> : k_down0_lut_rows<FL_LUT_FAST>;
         LVM_LAUNCH(c, "lap_down0_lut", kdl, dim3((unsigned)c->num_cus), dim3(D0L_THREADS), s, da);
@@ -1485,7 +1136,7 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     }
     const bool use_tail = st->tailT && B.nt == 1 && !B.no_tail && !lap_split_now(st, B, first);   // batched frames: every level gets many workgroups anyway
     const int down_end = use_tail ? st->tailT : levels;            // the tail builds G_{T+1..L} itself
-    int l = fused2 ? 2 : 1;         // (k_down01_lut_rows has made G_2 already)
+    int l = 1;
     while (l < down_end) {          // G_l -> next levels, three (or two) per launch when possible
         const int left = down_end - l;
         // (level 1 keeps the strips from half the size: a single 1080p stream per call, 1.55 M, was measured better with them)
@@ -1583,16 +1234,7 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         }
         up_start = 1;
     }
-    // Level 1 inside the last kernel (k_lap_final1: cur_1 stays in LDS)?  3-channel frames with dword-aligned pixel groups, a level 2
-    // of at least 2 x 2 pixels; not for the seeding frame (no motion yet), not with an odd level-1 width, and not when the tail kernel
-    // has already run level 1 (tiny frames).
-#if LVM_EXPERIMENTAL
-    const bool fuse1 = st->final1 && !first && levels >= 2 && up_start >= 1 /* level 1 not inside the tail kernel */ && C == 3 && lap_vec4(io) && st->g[1].w % 2 == 0 && st->g[2].w >= 2 && st->g[2].h >= 2 &&
-                       st->g[1].h >= 2 && (size_t)st->planes * st->g[1].n * (size_t)B.nt < ((size_t)1 << 31);
-#else
-    const bool fuse1 = false;
-#endif
-    for (int l = up_start; l >= (fuse1 ? 2 : 1); --l) {
+    for (int l = up_start; l >= 1; --l) {
         UpArgs a;
         a.Gl = G[l]; a.Gn = G[l + 1];
         a.curn = (l + 1 <= levels - 1) ? ((use_tail && l + 1 == st->tailT) ? B.curT : B.cur[l + 1]) : nullptr;
@@ -1629,30 +1271,6 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     }
     const int fl = lab_flavour(c);
     float* dbg = (c->keep_float && B.dbg_frame) ? c->d_float : nullptr;   // (the float frame kept is the first one of the batch)
-#if LVM_EXPERIMENTAL
-    if (fuse1) {
-        Fin1Args a{};
-        a.in = io.d_in; a.in_stride = (long)io.in_stride; a.in_sstride = (long)io.in_sstride;
-        a.out = io.d_out; a.out_stride = (long)io.out_stride; a.out_sstride = (long)io.out_sstride;
-        a.w = io.w; a.h = io.h; a.w1 = st->g[1].w; a.h1 = st->g[1].h; a.w2 = st->g[2].w; a.h2 = st->g[2].h;
-        a.G1 = G[1]; a.G2 = G[2];
-        a.cur2 = levels >= 3 ? ((use_tail && st->tailT == 2) ? B.curT : B.cur[2]) : nullptr;
-        a.hi = st->hi[1]; a.lo = st->lo[1]; a.hi_out = st->hi1x; a.lo_out = st->lo1x;
-        a.fs1 = (long)st->planes * (long)st->g[1].n; a.fs2 = (long)st->planes * (long)st->g[2].n;
-        a.aHi = (float)(1 - cHi); a.bHi = (float)cHi; a.aLo = (float)(1 - cLo); a.bLo = (float)cLo; a.gain = gains[1];
-        a.ca = (float)p.chromAttenuation;
-        a.nt = B.nt; a.nstreams = c->nstreams;
-        a.tiles_x = (io.w + F1_W - 1) / F1_W; a.tiles_y = (io.h + F1_H - 1) / F1_H;
-        a.lab = c->lab; a.lp = lp; a.dbg = dbg;
-        const dim3 grid1((unsigned)(a.tiles_x * a.tiles_y * c->nstreams));
-        const bool hc = a.cur2 != nullptr;
-        auto k1 = dbg ? (hc ? LVM_FL_PICK(fl, k_lap_final1, true, true) : LVM_FL_PICK(fl, k_lap_final1, false, true))
-                      : (hc ? LVM_FL_PICK(fl, k_lap_final1, true, false) : LVM_FL_PICK(fl, k_lap_final1, false, false));
-        LVM_LAUNCH(c, "lap_final1", k1, grid1, blk, s, a);
-        st->swap_level1_states();
-        return;
-    }
-#endif
     const int tx = (io.w + UT_W - 1) / UT_W, ty = (io.h + UT_H - 1) / UT_H;
     const int ntiles = tx * ty * NS;
     const dim3 grid(ntiles < 2048 ? ntiles : 2048);

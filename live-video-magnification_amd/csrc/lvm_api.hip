@@ -441,6 +441,70 @@ int lvm_chain_process_batch_ex(lvm_ctx* c, const lvm_preprocess_params* pp, cons
     return LVM_OK;
 }
 
+// runChainOnce for the LIVE DISPLAY (display half): host frame in, both frames the display shows left in DEVICE
+// memory -- see include/lvm_hip.h.  The reference publishes {processed, original} to the display's mailbox (ProcessingChain.cpp:46-49)
+// and DisplayWidget::uploadFrame (ui/DisplayWidget.cpp:133-152) sends both to GL textures from HOST memory every frame; with the two
+// destinations being mapped GL pixel-unpack buffers (host/HipDisplayPresenter.hpp) the frames never come back over PCIe.
+int lvm_chain_present(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, const uint8_t* in, int w, int h, int channels,
+                      ptrdiff_t in_stride, uint8_t* d_proc, ptrdiff_t proc_stride, uint8_t* d_orig, ptrdiff_t orig_stride, int* produced) {
+    if (!c || !pp || !p || !produced || !in) return LVM_ERR_INVALID;
+    *produced = 0;
+    if (c->nstreams != 1) { c->err = "lvm_chain_present needs a 1-stream context"; return LVM_ERR_INVALID; }
+    if (w <= 0 || h <= 0 || (channels != 1 && channels != 3) || in_stride < (ptrdiff_t)w * channels) { c->err = "bad frame arguments"; return LVM_ERR_INVALID; }
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    int rx, ry, rw, rh, ow, oh, och;
+    lvm::preprocess_geometry(*pp, w, h, channels, &rx, &ry, &rw, &rh, &ow, &oh, &och);
+    const size_t roi_row = (size_t)rw * channels, roi_bytes = roi_row * rh;
+    const size_t out_row = (size_t)ow * och, out_bytes = out_row * oh;
+    const size_t tap_row = (size_t)ow * channels;                       // the tap keeps the source's channel count (ChainBuilder.cpp:25)
+    if (d_proc && proc_stride < (ptrdiff_t)out_row) { c->err = "proc stride too small"; return LVM_ERR_INVALID; }
+    if (d_orig && orig_stride < (ptrdiff_t)tap_row) { c->err = "orig stride too small"; return LVM_ERR_INVALID; }
+    auto reserve = [&](uint8_t*& ptr, size_t& cap, size_t need) -> int {
+        if (need <= cap) return LVM_OK;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; cap = 0;
+        LVM_HIP_TRY(c, hipMalloc((void**)&ptr, need));
+        cap = need;
+        return LVM_OK;
+    };
+    hipStream_t s = c->own_stream;
+    LVM_HIP_TRY(c, hipStreamSynchronize(s));      // staging buffers may be replaced below
+    int rc = reserve(c->d_pre_in, c->pre_in_cap, roi_bytes); if (rc != LVM_OK) return rc;
+    rc = reserve(c->d_pre_out, c->pre_out_cap, out_bytes); if (rc != LVM_OK) return rc;
+    rc = reserve(c->d_chain_out, c->chain_out_cap, out_bytes); if (rc != LVM_OK) return rc;
+    LVM_HIP_TRY(c, hipMemcpy2DAsync(c->d_pre_in, roi_row, in + (size_t)ry * in_stride + (size_t)rx * channels, (size_t)in_stride, roi_row, (size_t)rh,
+                                    hipMemcpyHostToDevice, s));
+    const bool identity = ow == rw && oh == rh && och == channels;
+    const bool gray_tap = d_orig && och == 1 && channels == 3;
+    const uint8_t* mag_in = c->d_pre_in;
+    if (!identity) {
+        lvm_preprocess_params q = *pp;
+        q.roi_enabled = 0;                                               // already cropped by the copy
+        // with grayscale on a BGR source the kernel writes the colour tap straight into the caller's `original` buffer
+        rc = lvm::preprocess_device(c, q, c->d_pre_in, rw, rh, channels, (ptrdiff_t)roi_row, (ptrdiff_t)roi_bytes, c->d_pre_out, (ptrdiff_t)out_row,
+                                    (ptrdiff_t)out_bytes, s, gray_tap ? d_orig : nullptr, orig_stride, (ptrdiff_t)orig_stride * oh);
+        if (rc != LVM_OK) { (void)hipStreamSynchronize(s); return rc; }
+        mag_in = c->d_pre_out;
+    }
+    if (d_orig && !gray_tap)        // no gray stage in between: the tap IS the frame the magnifier sees
+        LVM_HIP_TRY(c, hipMemcpy2DAsync(d_orig, (size_t)orig_stride, mag_in, out_row, out_row, (size_t)oh, hipMemcpyDeviceToDevice, s));
+    lvm_params mp = *p;
+    mp.preprocess_key = preprocess_key_of(*pp);
+    // the last kernel writes the processed frame straight into the caller's buffer
+    uint8_t* dst = d_proc ? d_proc : c->d_chain_out;
+    const ptrdiff_t dstride = d_proc ? proc_stride : (ptrdiff_t)out_row;
+    lvm::FrameIO io{mag_in, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, dst, dstride, dstride * oh, ow, oh, och};
+    const int saved_depth = c->pipeline_depth;
+    c->pipeline_depth = 0;
+    rc = lvm::process_device(c, &mp, io, s, produced);
+    c->pipeline_depth = saved_depth;
+    if (rc != LVM_OK) { (void)hipStreamSynchronize(s); return rc; }
+    if (!*produced && d_proc)       // passthrough: the chain hands the magnifier's INPUT on (MagnificationProcessor.cpp:61) -- that is what the display shows
+        LVM_HIP_TRY(c, hipMemcpy2DAsync(d_proc, (size_t)proc_stride, mag_in, out_row, out_row, (size_t)oh, hipMemcpyDeviceToDevice, s));
+    LVM_HIP_TRY(c, hipStreamSynchronize(s));
+    return LVM_OK;
+}
+
 int lvm_export_geometry(const lvm_preprocess_params* pp, int split, int w, int h, int channels, int* cw, int* ch) {
     if (!pp || w <= 0 || h <= 0 || (channels != 1 && channels != 3) || !cw || !ch) return LVM_ERR_INVALID;
     if (split < LVM_SPLIT_NONE || split > LVM_SPLIT_TOP_BOTTOM) return LVM_ERR_INVALID;

@@ -529,193 +529,6 @@ __global__ __launch_bounds__(D0L_THREADS) void k_down0_lut_rows(D0LArgs q) {
         down0_lut_strip<FL>(q, task, lane, s_ab);
 }
 
-#if LVM_EXPERIMENTAL
-// ---- the same with the SECOND pyramid level inside (round 4): u8 BGR -> table -> G_1, G_2 and the integer planes -------------------
-// EXPERIMENTAL (-DLVM_EXPERIMENTAL=1: the emulation build of the test suite has it and checks it bit for bit; liblvm_hip.so does not):
-// measured NOT faster -- 291-297 us per 32 frames of 1080p against 231-251 + 48 for k_down0_lut_rows + k_pyr_down_rows (same run,
-// profiles/README.md round 4).  The conversion is bound by the L-cell gathers; 8.5 % more converted rows, a second register window
-// (128 VGPRs, prologue spills) and three more DPP exchanges per level-1 row cost what the removed launch saved.
-// G_1 used to be written here, read back by the level-1 pyrDown launch (k_pyr_down_rows: 6.2 MB per 1080p frame in, 1.6 MB out, 1.5 us)
-// and read a second time by the level-1 band step.  This kernel runs that pyrDown on the level-1 values while they are in registers --
-// k_down01_rows' structure (colour mode, below): lane = one source group = level-1 columns 2 g, 2 g + 1 = level-2 column g; the
-// level-1 values of the neighbouring columns come over DPP, REFLECT_101 of LEVEL 1 is applied to level-1 values (border lanes select,
-// the top strip mirrors its window, rows past h1 are window copies); the level-2 horizontal sums slide down a second 5-row window.
-// Unlike the colour planes the Lab planes are not small integers, so the sums keep pyrdown_tile's operation order (exact flavour:
-// bit-identical to k_pyr_down_rows; default flavour: the fma form of the first level).  A strip of r level-2 rows converts 4 r + 9
-// source rows for 4 r owned ones (17 rows: 77 for 68, against 71 for 68 without the second level), lanes 2 .. 61 own.
-#ifndef LVM_D01L_DEPTH
-#define LVM_D01L_DEPTH 2         // table look-ups in flight per lane here (three, as in k_down0_lut_rows, need 128 VGPRs + scratch with the second window)
-#endif
-constexpr int D01L_OUT = 60;                        // level-2 columns (= source groups) per wave
-inline int down01_lut_rows_choice(int w2, int h2, long frames, long waves, long* tasks_out) {
-    const long sx = (w2 + D01L_OUT - 1) / D01L_OUT;
-    int best = 8; long best_cost = -1, best_tasks = 0;
-    for (int r = 3; r <= 24; ++r) {
-        const long tasks = sx * ((h2 + r - 1) / r) * frames;
-        if (tasks * 5 < waves * 3) continue;                    // at least 60 % of the resident waves get a strip
-        const long cost = ((tasks + waves - 1) / waves) * (4 * r + 9);
-        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = r; best_tasks = tasks; }
-    }
-    *tasks_out = best_tasks;
-    return best;
-}
-struct D01LArgs {
-    const uint8_t* in; long in_stride, in_sstride; int w, h;
-    float* G1; int w1, h1;
-    float* G2; int w2, h2;
-    LabLut lut;
-    int strips_x, strips_y, ntasks, rows;          // rows = level-2 rows per strip
-    uint16_t* iLp; uint32_t* iabp;
-};
-template <int FL>
-__device__ __forceinline__ void down01_lut_strip(const D01LArgs& q, int task, int lane, const uint32_t* s_ab) {
-    constexpr bool EXACT = fl_exact(FL);
-    const uint8_t* __restrict__ in = q.in; const long in_stride = q.in_stride, in_sstride = q.in_sstride;
-    const int w = q.w, h = q.h, w1 = q.w1, h1 = q.h1, w2 = q.w2, h2 = q.h2, strips_x = q.strips_x, strips_y = q.strips_y, rows = q.rows;
-    float* __restrict__ G1 = q.G1; float* __restrict__ G2 = q.G2; const LabLut lut = q.lut;
-    uint16_t* __restrict__ iLp = q.iLp; uint32_t* __restrict__ iabp = q.iabp;
-    const int ngroups = w >> 2;                                    // w % 4 == 0: ngroups == w2
-    const size_t plane1 = (size_t)w1 * h1, plane2 = (size_t)w2 * h2;
-    const int b = task / (strips_x * strips_y);
-    const int r = task - b * (strips_x * strips_y);
-    const int ty = r / strips_x, tx = r - ty * strips_x;
-    const int g = tx * D01L_OUT - 2 + lane;                        // source group = level-2 column of this lane
-    const bool left_mirror = g < 0, right_mirror = g >= ngroups;    // source REFLECT_101 mirrors of the edge groups (only g = -1, ngroups are used)
-    const int gl = left_mirror ? 0 : (right_mirror ? ngroups - 1 : g);
-    const bool first2 = g == 0, last2 = g == w2 - 1;               // level-1 REFLECT_101 lanes
-    const bool owner = lane >= 2 && lane <= 61 && g >= 0 && g < w2;
-    const uint8_t* src = in + (size_t)b * in_sstride;
-    const int Y0 = ty * rows, Yend = Y0 + rows < h2 ? Y0 + rows : h2;
-    const bool top = Y0 == 0;
-    const int own1_lo = 2 * Y0, own1_hi = 2 * Yend < h1 ? 2 * Yend : h1;        // level-1 rows whose G_1 this strip stores
-    const int own0_lo = 4 * Y0, own0_hi = 4 * Yend < h ? 4 * Yend : h;          // source rows whose planes this strip stores
-    uint16_t* pL = iLp + (size_t)b * w * h + 4u * (unsigned)gl;
-    uint32_t* pab = iabp + (size_t)b * w * h + 4u * (unsigned)gl;
-    struct __attribute__((packed, aligned(4))) P3 { uint32_t a, b, c; };
-    auto fetch = [&](int sy) __attribute__((always_inline)) {
-        const uint32_t* qq = reinterpret_cast<const uint32_t*>(src + (size_t)reflect101(sy, h) * in_stride + 12u * (unsigned)gl);
-        P3 v; v.a = __builtin_nontemporal_load(qq); v.b = __builtin_nontemporal_load(qq + 1); v.c = __builtin_nontemporal_load(qq + 2);
-        return v;
-    };
-    // source row sy: conversion of the lane's 4 pixels, plane stores, the two horizontal level-1 results per channel (down0_lut_strip's)
-    auto hrow = [&](const P3 v, int sy, float (&ha)[3], float (&hb)[3]) __attribute__((always_inline)) {
-        const uint32_t pb[12] = {v.a & 255, (v.a >> 8) & 255, (v.a >> 16) & 255, v.a >> 24, v.b & 255, (v.b >> 8) & 255,
-                                 (v.b >> 16) & 255, v.b >> 24, v.c & 255, (v.c >> 8) & 255, (v.c >> 16) & 255, v.c >> 24};
-        int iL[4], ia[4], ib[4];
-        {   // the look-ups of pixels k + 1, k + 2 are issued before pixel k is interpolated
-            LutRefs rr[4];
-#pragma unroll
-            for (int k = 0; k < LVM_D01L_DEPTH - 1; ++k) rr[k] = lut_issue(pb[3 * k], pb[3 * k + 1], pb[3 * k + 2], s_ab, lut.Lcells);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (k + LVM_D01L_DEPTH - 1 < 4) { const int n = k + LVM_D01L_DEPTH - 1; rr[n] = lut_issue(pb[3 * n], pb[3 * n + 1], pb[3 * n + 2], s_ab, lut.Lcells); }
-                __builtin_amdgcn_sched_barrier(0);
-                lut_finish(rr[k], iL[k], ia[k], ib[k]);
-            }
-        }
-        if (owner && sy >= own0_lo && sy < own0_hi) {
-            const size_t o = (size_t)sy * w;
-            uint32_t* dL = reinterpret_cast<uint32_t*>(pL + o);
-            __builtin_nontemporal_store((uint32_t)iL[0] | ((uint32_t)iL[1] << 16), dL);
-            __builtin_nontemporal_store((uint32_t)iL[2] | ((uint32_t)iL[3] << 16), dL + 1);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) __builtin_nontemporal_store((uint32_t)ia[k] | ((uint32_t)ib[k] << 16), pab + o + k);
-        }
-        float P[3][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { P[0][k] = lut_L(iL[k]); P[1][k] = lut_ab(ia[k]); P[2][k] = lut_ab(ib[k]); }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float give2 = P[c][2], give3 = left_mirror ? P[c][1] : P[c][3], give0 = right_mirror ? P[c][2] : P[c][0];
-            const float L2 = dpp_shr1(give2), L3 = dpp_shr1(give3), R0 = dpp_shl1(give0);
-            if (!EXACT && LVM_FAST_FMA) {
-                ha[c] = __builtin_fmaf(P[c][0], 6.f, __builtin_fmaf(L3 + P[c][1], 4.f, L2 + P[c][2]));
-                hb[c] = __builtin_fmaf(P[c][2], 6.f, __builtin_fmaf(P[c][1] + P[c][3], 4.f, P[c][0] + R0));
-            } else {
-                ha[c] = P[c][0] * 6.f + (L3 + P[c][1]) * 4.f + L2 + P[c][2];
-                hb[c] = P[c][2] * 6.f + (P[c][1] + P[c][3]) * 4.f + P[c][0] + R0;
-            }
-        }
-    };
-    int rv = top ? 0 : 2 * Y0 - 2;                                 // next level-1 row to make
-    float a0[3], a1[3], a2[3], a3[3], a4[3], b0[3], b1[3], b2[3], b3[3], b4[3];
-    hrow(fetch(2 * rv - 2), 2 * rv - 2, a0, b0); hrow(fetch(2 * rv - 1), 2 * rv - 1, a1, b1); hrow(fetch(2 * rv), 2 * rv, a2, b2);
-    float* d1 = G1 + (size_t)b * 3 * plane1;
-    P3 n3 = fetch(2 * rv + 1), n4 = fetch(2 * rv + 2);
-    // level-1 row rv from the source window (stored when this strip owns it) -> its level-2 horizontal sums at column g
-    auto l1 = [&](float (&H2)[3]) __attribute__((always_inline)) {
-        const P3 c3 = n3, c4 = n4;
-        n3 = fetch(2 * rv + 3); n4 = fetch(2 * rv + 4);             // (rows past the frame are reflected: always a valid address)
-        hrow(c3, 2 * rv + 1, a3, b3); hrow(c4, 2 * rv + 2, a4, b4);
-        const bool st1 = owner && rv >= own1_lo && rv < own1_hi;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float va, vb;
-            if (!EXACT && LVM_FAST_FMA) {
-                va = __builtin_fmaf(a2[c], 6.f, __builtin_fmaf(a1[c] + a3[c], 4.f, a0[c] + a4[c])) * (1.f / 256.f);
-                vb = __builtin_fmaf(b2[c], 6.f, __builtin_fmaf(b1[c] + b3[c], 4.f, b0[c] + b4[c])) * (1.f / 256.f);
-            } else {
-                va = (a2[c] * 6.f + (a1[c] + a3[c]) * 4.f + a0[c] + a4[c]) * (1.f / 256.f);
-                vb = (b2[c] * 6.f + (b1[c] + b3[c]) * 4.f + b0[c] + b4[c]) * (1.f / 256.f);
-            }
-            if (st1) *reinterpret_cast<float2*>(d1 + c * plane1 + (size_t)rv * w1 + 2 * g) = make_float2(va, vb);
-            float Lm2 = dpp_shr1(va), Lm1 = dpp_shr1(vb), Rp = dpp_shl1(va);
-            Lm2 = sel(first2, Rp, Lm2); Lm1 = sel(first2, vb, Lm1);   // level-1 columns -2, -1 = columns 2, 1
-            Rp = sel(last2, va, Rp);                                  // level-1 column w1 = column w1 - 2
-            // pyrdown_tile's horizontal order: s[2] * 6 + (s[1] + s[3]) * 4 + s[0] + s[4]
-            if (!EXACT && LVM_FAST_FMA) H2[c] = __builtin_fmaf(va, 6.f, __builtin_fmaf(Lm1 + vb, 4.f, Lm2 + Rp));
-            else H2[c] = va * 6.f + (Lm1 + vb) * 4.f + Lm2 + Rp;
-            a0[c] = a2[c]; a1[c] = a3[c]; a2[c] = a4[c]; b0[c] = b2[c]; b1[c] = b3[c]; b2[c] = b4[c];
-        }
-        ++rv;
-    };
-    float w0[3] = {0.f, 0.f, 0.f}, w1r[3] = {0.f, 0.f, 0.f}, w2r[3], w3[3], w4[3];
-    if (top) l1(w2r);
-    else { l1(w0); l1(w1r); l1(w2r); }
-    float* d2 = G2 + (size_t)b * 3 * plane2 + g;
-    for (int Y = Y0; Y < Yend; ++Y) {
-        // window rows 2Y - 2 .. 2Y + 2 in w0, w1r, w2r, w3, w4; rows past the last level-1 row are REFLECT_101 copies of window entries
-        // (row h1 + k = row h1 - 2 - k); their source rows are still loaded and converted (same schedule for every strip), the results dropped
-        float t3[3], t4[3];
-        const int r3 = rv;
-        l1(t3);
-        const int r4 = rv;
-        l1(t4);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float e3 = t3[c], e4 = t4[c];
-            if (r3 >= h1) { const int k = 2 * h1 - 2 - r3 - (2 * Y - 2); e3 = k == 0 ? w0[c] : (k == 1 ? w1r[c] : w2r[c]); }
-            if (r4 >= h1) { const int k = 2 * h1 - 2 - r4 - (2 * Y - 2); e4 = k == 0 ? w0[c] : (k == 1 ? w1r[c] : (k == 2 ? w2r[c] : e3)); }
-            w3[c] = e3; w4[c] = e4;
-        }
-        if (top && Y == 0) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { w0[c] = w4[c]; w1r[c] = w3[c]; }       // rows -2, -1 = rows 2, 1
-        }
-        if (owner) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float v;
-                if (!EXACT && LVM_FAST_FMA) v = __builtin_fmaf(w2r[c], 6.f, __builtin_fmaf(w1r[c] + w3[c], 4.f, w0[c] + w4[c])) * (1.f / 256.f);
-                else v = (w2r[c] * 6.f + (w1r[c] + w3[c]) * 4.f + w0[c] + w4[c]) * (1.f / 256.f);
-                d2[c * plane2 + (size_t)Y * w2] = v;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { w0[c] = w2r[c]; w1r[c] = w3[c]; w2r[c] = w4[c]; }
-    }
-}
-template <int FL>
-__global__ __launch_bounds__(D0L_THREADS) void k_down01_lut_rows(D01LArgs q) {
-    __shared__ uint32_t s_ab[kLabAbWords];
-    for (int i = threadIdx.x; i < kLabAbWords; i += D0L_THREADS) s_ab[i] = q.lut.ab[i];
-    __syncthreads();
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    for (int task = blockIdx.x * (D0L_THREADS / 64) + wave; task < q.ntasks; task += gridDim.x * (D0L_THREADS / 64))
-        down01_lut_strip<FL>(q, task, lane, s_ab);
-}
-
-#endif  // LVM_EXPERIMENTAL
 
 // ---- u8 BGR -> pyrDown -> pyrDown -> G_2 in one pass (colour mode) ------------------------------------------------------------
 // Colour magnification only keeps the SMALLEST level of its Gaussian pyramid (the temporal window); G_1 is written by

@@ -73,9 +73,11 @@ void lvmo_set_threads(int n) {
  * not an argument, is what bounds "oracle vs a real OpenCV build".                                                    */
 static unsigned g_var = 0;
 static void lab_lut_drop(void);
+static void lab_tabs_drop(void);
 void lvmo_set_variant(unsigned mask) {
     const unsigned lut_bits = LVMO_VAR_GAMMA_F32 | LVMO_VAR_LUT_NUDGE_UP | LVMO_VAR_LUT_NUDGE_DOWN;
     if ((mask ^ g_var) & lut_bits) lab_lut_drop();
+    if ((mask ^ g_var) & LVMO_VAR_SPLINE_CV3) lab_tabs_drop();       /* the gamma splines are rebuilt on the next use */
     g_var = mask;
 }
 unsigned lvmo_get_variant(void) { return g_var; }
@@ -272,12 +274,20 @@ static float g_gamma_tab[GAMMA_TAB_SIZE * 4], g_invgamma_tab[GAMMA_TAB_SIZE * 4]
 static float g_fwd[9], g_inv[9];
 static float g_gamma_u8[256];
 static int g_lab_ready = 0;
+static void lab_tabs_drop(void) { g_lab_ready = 0; }
 
-/* [cv] splineBuild: natural cubic spline through f[0..n] (n intervals), float arithmetic */
+/* [cv] splineBuild: natural cubic spline through f[0..n] (n intervals), binary32 arithmetic.
+ * Default (round 5) = the OpenCV 4 form (color_lab.cpp, softfloat): the forward sweep runs over i = 1 .. n-1 and the back
+ * substitution DIVIDES by 3:  b = f[i+1] - f[i] - (cn + c*2)/3,  d = (cn - c)/3.
+ * LVMO_VAR_SPLINE_CV3 = the OpenCV 3.x form rounds 1-4 restated: forward sweep i = 1 .. n-2 (entry n-1 of the static, hence
+ * zero, table is read unwritten) and multiplications by 0.3333333333333333f.  The two differ in the last bit of b / d at a
+ * fraction of the knots and in the top few knots (x -> 1): tests/test_oracle_variants.py bounds what that does to a frame. */
 static void spline_build(const float* f, int n, float* tab) {
+    const int cv3 = (g_var & LVMO_VAR_SPLINE_CV3) != 0;
     float cn = 0.f;
     tab[0] = tab[1] = 0.f;
-    for (int i = 1; i < n - 1; ++i) {
+    tab[(n - 1) * 4] = tab[(n - 1) * 4 + 1] = 0.f;
+    for (int i = 1; i < (cv3 ? n - 1 : n); ++i) {
         float t = 3.f * (f[i + 1] - 2.f * f[i] + f[i - 1]);
         float l = 1.f / (4.f - tab[(i - 1) * 4]);
         tab[i * 4] = l;
@@ -285,8 +295,8 @@ static void spline_build(const float* f, int n, float* tab) {
     }
     for (int i = n - 1; i >= 0; --i) {
         float c = tab[i * 4 + 1] - tab[i * 4] * cn;
-        float b = f[i + 1] - f[i] - (cn + c * 2.f) * 0.3333333333333333f;
-        float d = (cn - c) * 0.3333333333333333f;
+        float b = cv3 ? f[i + 1] - f[i] - (cn + c * 2.f) * 0.3333333333333333f : f[i + 1] - f[i] - (cn + c * 2.f) / 3.f;
+        float d = cv3 ? (cn - c) * 0.3333333333333333f : (cn - c) / 3.f;
         tab[i * 4] = f[i]; tab[i * 4 + 1] = b; tab[i * 4 + 2] = c; tab[i * 4 + 3] = d;
         cn = c;
     }
@@ -722,6 +732,73 @@ void lvmo_mul_spectrums_rows(const float* a, const float* b, int rows, int n, fl
     }
 }
 
+/* LVMO_VAR_DFT_F32: the two transforms in BINARY32 the way a float32 FFT accumulates them -- power-of-two lengths as an
+ * iterative radix-2 decimation-in-time FFT (twiddles = float(cos), float(sin) of a binary64 angle, like OpenCV's table; butterflies
+ * in binary32; scale 1/n applied at the end in binary32), other lengths as direct sums with binary32 accumulators.  Not OpenCV's
+ * exact factorisation (radix 4 / 2 / 3 / 5 mixes): a SWITCH that bounds what binary32 transform noise does to a colour frame. */
+static void fft32(float* re, float* im, int n, int inverse) {
+    for (int i = 1, j = 0; i < n; ++i) {                       /* bit reversal */
+        int bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { float t = re[i]; re[i] = re[j]; re[j] = t; t = im[i]; im[i] = im[j]; im[j] = t; }
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        for (int k = 0; k < len / 2; ++k) {
+            const double ang = 2.0 * PI_D * k / len * (inverse ? 1.0 : -1.0);
+            const float wr = (float)cos(ang), wi = (float)sin(ang);
+            for (int i = k; i < n; i += len) {
+                const int j = i + len / 2;
+                const float tr = re[j] * wr - im[j] * wi, ti = re[j] * wi + im[j] * wr;
+                re[j] = re[i] - tr; im[j] = im[i] - ti;
+                re[i] = re[i] + tr; im[i] = im[i] + ti;
+            }
+        }
+    }
+}
+/* forward: real row -> CCS-packed, scaled 1/n; inverse: CCS-packed -> real row, scaled 1/n */
+static void dft_row_f32(const float* row, int n, float* X) {
+    float* re = (float*)malloc(sizeof(float) * 2 * n); float* im = re + n;
+    if ((n & (n - 1)) == 0) {
+        for (int t = 0; t < n; ++t) { re[t] = row[t]; im[t] = 0.f; }
+        fft32(re, im, n, 0);
+    } else {
+        for (int k = 0; k < n; ++k) {
+            float ar = 0.f, ai = 0.f;
+            for (int t = 0; t < n; ++t) {
+                const double ang = -2.0 * PI_D * (double)(((long long)k * t) % n) / n;
+                ar += row[t] * (float)cos(ang); ai += row[t] * (float)sin(ang);
+            }
+            re[k] = ar; im[k] = ai;
+        }
+    }
+    const float sc = 1.f / (float)n;
+    for (int x = 0; x < n; ++x) { int bin, isim; ccs_index(x, n, &bin, &isim); X[x] = (isim ? im[bin] : re[bin]) * sc; }
+    free(re);
+}
+static void idft_row_f32(const float* Y, int n, float* out) {
+    float* re = (float*)malloc(sizeof(float) * 2 * n); float* im = re + n;
+    const int half = (n - 1) / 2;
+    re[0] = Y[0]; im[0] = 0.f;
+    for (int k = 1; k <= half; ++k) { re[k] = Y[2 * k - 1]; im[k] = Y[2 * k]; re[n - k] = Y[2 * k - 1]; im[n - k] = -Y[2 * k]; }
+    if (n % 2 == 0) { re[n / 2] = Y[n - 1]; im[n / 2] = 0.f; }
+    const float sc = 1.f / (float)n;
+    if ((n & (n - 1)) == 0) {
+        fft32(re, im, n, 1);
+        for (int t = 0; t < n; ++t) out[t] = re[t] * sc;
+    } else {
+        for (int t = 0; t < n; ++t) {
+            float a = 0.f;
+            for (int k = 0; k < n; ++k) {
+                const double ang = 2.0 * PI_D * (double)(((long long)k * t) % n) / n;
+                a += re[k] * (float)cos(ang) - im[k] * (float)sin(ang);
+            }
+            out[t] = a * sc;
+        }
+    }
+    free(re);
+}
+
 /* TemporalFilter.cpp:24-80: idealFilter + createIdealBandpassFilter.
  * win: rows x cols x cn interleaved (rows = pixels, cols = frames).  dst same shape.
  * full != 0: literal dft -> mask -> mulSpectrums -> idft over every packed element.
@@ -758,6 +835,15 @@ void lvmo_ideal_filter(const float* win, int rows, int cols, int cn, double lo, 
         for (int r = 0; r < rows; ++r) {
             for (int c = 0; c < cn; ++c) {
                 for (int t = 0; t < n; ++t) row[t] = win[((size_t)r * n + t) * cn + c];
+                if (g_var & LVMO_VAR_DFT_F32) {                                                 /* binary32 transforms (switch) */
+                    float* o = (float*)malloc(sizeof(float) * n);
+                    dft_row_f32(row, n, X);
+                    lvmo_mul_spectrums_rows(X, mask, 1, n, Y);
+                    idft_row_f32(Y, n, o);
+                    for (int t = 0; t < n; ++t) dst[((size_t)r * n + t) * cn + c] = o[t];
+                    free(o);
+                    continue;
+                }
                 for (int x = 0; x < n; ++x) X[x] = need[x] ? dft_elem(row, n, x, cs, sn) : 0.f; /* :43 */
                 lvmo_mul_spectrums_rows(X, mask, 1, n, Y);                                     /* :48 */
                 for (int t = 0; t < n; ++t) dst[((size_t)r * n + t) * cn + c] = idft_elem(Y, n, t, cs, sn); /* :49 */

@@ -116,7 +116,10 @@ enum {
     LVMO_VAR_MUL_F32         = 8,    /* Riesz IIR Mat * double with the scalar narrowed to float first instead of a float64 product rounded once */
     LVMO_VAR_GAMMA_F32       = 16,   /* forward Lab table: applyGamma as three binary32 operations (the rounds 1-3 restatement) instead of softdouble pow rounded once */
     LVMO_VAR_LUT_NUDGE_UP    = 32,   /* forward Lab table: every interior gamma node one binary32 step up (bounds a last-bit disagreement of pow) */
-    LVMO_VAR_LUT_NUDGE_DOWN  = 64    /* ... one step down */
+    LVMO_VAR_LUT_NUDGE_DOWN  = 64,   /* ... one step down */
+    LVMO_VAR_SPLINE_CV3      = 128,  /* gamma / inverse-gamma splines in the OpenCV 3.x form of splineBuild (forward sweep to n-2, x 0.3333333333333333f) instead of
+                                        OpenCV 4's (sweep to n-1, / 3): what rounds 1-4 restated */
+    LVMO_VAR_DFT_F32         = 256   /* Color band-pass: both transforms in binary32 (radix-2 FFT for power-of-two windows) instead of float64 direct sums */
 };
 void     lvmo_set_variant(unsigned mask);
 unsigned lvmo_get_variant(void);

@@ -108,11 +108,19 @@ def lib():
 
 # lvm_oracle.h LVMO_VAR_*: the unpinned OpenCV build choices as switches (0 = the restatement the parity tests use)
 VARIANTS = {"pyr_simd": 1, "filter_unfused": 2, "addw_fused": 4, "mul_f32": 8, "gamma_f32": 16, "lut_nudge_up": 32,
-            "lut_nudge_down": 64}
+            "lut_nudge_down": 64, "spline_cv3": 128, "dft_f32": 256}
 
 
 def set_variant(mask):
     lib().lvmo_set_variant(int(mask))
+
+
+def gamma_tab(inverse):
+    """the 1024-knot spline (4 coefficients per knot) of the forward / inverse sRGB gamma (color_lab.cpp splineBuild)"""
+    fn = lib().lvmo_gamma_tab
+    fn.restype = C.POINTER(C.c_float)
+    fn.argtypes = [C.c_int]
+    return np.ctypeslib.as_array(fn(int(bool(inverse))), shape=(4096,)).copy()
 
 
 def lab_lut_table():

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "refpin: golden vectors rendered by the REAL reference + OpenCV 4 (tools/pin_with_opencv.sh); skipped, loudly, while they do not exist")
 
 
 @pytest.fixture(scope="session")

@@ -318,22 +318,6 @@ def test_emu_fused_table_conversion_and_first_kernel(lvm, po, emu, w, h, levels,
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0 if exact else 1e-4, exact=exact)
 
 
-@pytest.mark.parametrize("w,h,levels,rows,ns,calls", [
-    (264, 90, 3, "3", 1, (1, 6, 4)),      # two strips across (66 level-2 columns), 8 strips down, h2 = 23 odd
-    (264, 91, 3, "5", 1, (1, 5)),         # odd frame height: h1 = 46, the last level-2 row takes its rows 2Y + 1, 2Y + 2 from the REFLECT_101 copies
-    (248, 66, 2, "24", 2, (1, 4, 3)),     # ONE strip per frame (top and bottom strip at once), two streams, level 2 is the residual
-    (480, 54, 4, "4", 1, (1, 7)),         # exactly two full strips across (120 = 2 x 60 level-2 columns): border lanes 2 and 61
-    (484, 38, 3, "0", 1, (1, 9)),         # a third strip with a single owned column; strip height from the chooser
-])
-def test_emu_first_kernel_with_the_second_level_inside(lvm, po, emu, w, h, levels, rows, ns, calls, monkeypatch):
-    """k_down01_lut_rows (experimental build, LVM_D0_L2=1): table conversion + G_1 + G_2 + integer planes in one pass: level-1
-    REFLECT_101 on level-1 values (border lanes, mirrored top window, window copies past h1), every strip height."""
-    monkeypatch.setenv("LVM_D0_FUSED_WAVES", "1")
-    monkeypatch.setenv("LVM_D0_L2", "1")
-    monkeypatch.setenv("LVM_D0_L2_ROWS", rows)
-    _frames_clip(lvm, po, emu, 0, w, h, levels, ns, calls)
-
-
 def test_emu_unfused_conversion_in_batches(lvm, po, emu, monkeypatch):
     """LVM_D0_FUSED=0: labconv.hip's conversion kernel + the plane-reading first kernels in temporal batches."""
     monkeypatch.setenv("LVM_D0_FUSED", "0")
@@ -343,31 +327,19 @@ def test_emu_unfused_conversion_in_batches(lvm, po, emu, monkeypatch):
 @pytest.mark.parametrize("w,h,levels,ns,calls", [
     (320, 180, 2, 1, (1, 4, 3)),        # two levels: level 1 is the top live level (no cur_2), too large for the tail kernel
     (264, 74, 3, 1, (1, 6, 1, 2)),      # partial tiles right and below, per-frame calls in between
-    (132, 70, 3, 2, (1, 5, 3)),         # level 2 with an odd width: level chain for level 2, then the fused kernel; two streams
+    (132, 70, 3, 2, (1, 5, 3)),         # level 2 with an odd width: level chain for level 2; two streams
     (160, 91, 3, 1, (1, 4, 4)),         # odd frame height (pyrUp with dsize = 2 n - 1 on both steps)
     (520, 150, 4, 1, (1, 9)),           # five tiles across: interior tiles without any border lane
     (128, 16, 2, 1, (1, 3, 3)),         # exactly one tile
 ])
-def test_laplace_emu_level1_fused_into_the_last_kernel(lvm, po, emu, w, h, levels, ns, calls, monkeypatch):
-    """k_lap_final1: level-1 band / IIR / collapse step + last kernel in one launch, cur_1 in LDS, the level-1 states in
-    registers for the whole batch and double-buffered across launches (a tile's ring pixels are state copies read from a
-    neighbour's planes).  Bit-identical to the oracle over several calls, i.e. across the buffer swap."""
-    monkeypatch.setenv("LVM_LAP_FINAL1", "1")
+def test_laplace_emu_level1_step_and_last_kernel_geometries(lvm, po, emu, w, h, levels, ns, calls):
+    """k_lap_up at level 1 + k_lap_final_v4 over the geometries that the (deleted, round 5) fused level-1 kernel was checked on:
+    bit-identical to the oracle over several calls, per-frame calls between temporal batches included."""
     _frames_clip(lvm, po, emu, 0, w, h, levels, ns, calls)
 
 
-@pytest.mark.parametrize("w,h,levels,calls", [(264, 74, 3, (1, 6, 1, 2)), (320, 180, 4, (1, 8))])
-def test_laplace_emu_unfused_level1_still_matches(lvm, po, emu, w, h, levels, calls, monkeypatch):
-    """LVM_LAP_FINAL1=0: k_lap_up at level 1 + k_lap_final_v4 (the default until the fused kernel is faster; what odd level-1 widths
-    and non-vector frames always use)."""
-    monkeypatch.setenv("LVM_LAP_FINAL1", "0")
-    _frames_clip(lvm, po, emu, 0, w, h, levels, 1, calls)
-
-
-def test_laplace_emu_fused_and_unfused_level1_share_their_states(lvm, po, emu, monkeypatch):
-    """A parameter change between calls (the fused kernel swaps the level-1 state planes every launch) and a frame geometry that
-    switches between the two forms (4-aligned width vs. not) keep matching the oracle frame by frame."""
-    monkeypatch.setenv("LVM_LAP_FINAL1", "1")
+def test_laplace_emu_parameter_change_between_calls(lvm, po, emu):
+    """amplification / chromAttenuation change between calls: the level-1 states carry over, frames keep matching the oracle"""
     ck, pk = lvm.synth.config(0, (264, 74, 3))
     def vary(t, q):
         if t >= 5:

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_planes(const V<8>* __restrict__ a, cons
 
 struct Cfg { int op, W, U, nt, k, mode; double gbs, us; int occ; };
 static void *g_a, *g_b, *g_c; static uint32_t* g_sink;
-static const size_t kFoot = (size_t)1 << 30;
+static size_t kFoot = (size_t)1 << 30;      // UBENCH_FOOT_MB overrides (cache-resident footprints)
 static int g_cus = 256;
 
 template <int OP, int W, int U, int NT>
@@ -182,6 +182,7 @@ static void print(const Cfg& c) {
 
 int main(int argc, char** argv) {
     hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0)); g_cus = prop.multiProcessorCount;
+    if (const char* e = getenv("UBENCH_FOOT_MB")) kFoot = (size_t)atol(e) << 20;
     CK(hipMalloc(&g_a, kFoot + 4096)); CK(hipMalloc(&g_b, kFoot + 4096)); CK(hipMalloc(&g_c, kFoot + 4096)); CK(hipMalloc((void**)&g_sink, 4096));
     CK(hipMemset(g_a, 1, kFoot)); CK(hipMemset(g_b, 2, kFoot)); CK(hipMemset(g_c, 3, kFoot));
     if (argc >= 8 && !strcmp(argv[1], "only")) {
