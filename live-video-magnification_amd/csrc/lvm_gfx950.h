@@ -15,7 +15,10 @@ template <class T> __device__ __forceinline__ const_tab<T> as_const_tab(const T*
 
 // Buffer-resource loads / stores (raw buffer ops, stride 0): address = resource base (four SGPRs, built from wave-uniform values) +
 // per-lane 32-bit byte offset (VGPR) + wave-uniform 32-bit byte offset (SGPR).  No 64-bit address arithmetic in vector registers
-// (the generic form costs a VGPR pair and a v_lshl_add_u64 per load); an access outside [0, bytes) reads 0 / is dropped.
+// (the generic form costs a VGPR pair and a v_lshl_add_u64 per load).  RANGE CHECK: the hardware compares only the VECTOR offset (+ the
+// instruction's immediate) with the resource's size -- an access whose voff lies outside [0, bytes) reads 0 / is dropped, which is what the
+// kernels' "drop" sentinels rely on (always placed in voff); the scalar offset is added unchecked, so voff + soff must stay inside the
+// allocation whenever voff is in range (the emulation header aborts on an access that would not).
 struct B96 { uint32_t a, b, c; };
 typedef __amdgpu_buffer_rsrc_t BufRsrc;
 typedef unsigned int lvm_u32x3 __attribute__((ext_vector_type(3)));

@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace lvm {
@@ -13,44 +15,52 @@ template <class T> __device__ __forceinline__ const_tab<T> as_const_tab(const T*
 struct B96 { uint32_t a, b, c; };
 typedef float lvm_f2 __attribute__((vector_size(8)));
 struct BufRsrc { char* base; uint32_t bytes; };
+// Range check of a raw buffer access as the HARDWARE does it: only the vector offset (voff) is compared with the resource's size -- the
+// scalar offset (soff) is added afterwards, unchecked.  An access whose voff is in range but whose voff + soff is not would read /
+// write outside the buffer on the GPU: the emulation aborts on it instead of quietly returning 0 (ADVICE, round 4).
+__device__ __forceinline__ bool buf_in_range(const BufRsrc& r, uint32_t voff, uint32_t soff, uint32_t n) {
+    if ((uint64_t)voff + n > r.bytes) return false;                          // dropped / reads 0, like the hardware
+    if ((uint64_t)voff + soff + n > r.bytes) { std::fprintf(stderr, "hip-emu: raw buffer access with voff %u in range but voff + soff = %llu outside %u bytes: out of bounds on the GPU\n", voff, (unsigned long long)voff + soff, r.bytes); std::abort(); }
+    return true;
+}
 __device__ __forceinline__ BufRsrc buf_rsrc(const void* base, uint32_t bytes) { return BufRsrc{(char*)base, bytes}; }
 __device__ __forceinline__ float buf_ld_f32(const BufRsrc& r, uint32_t voff, uint32_t soff) {
     const uint64_t o = (uint64_t)voff + soff;
     float v = 0.f;
-    if (o + 4 <= r.bytes) std::memcpy(&v, r.base + o, 4);
+    if (buf_in_range(r, voff, soff, 4)) std::memcpy(&v, r.base + o, 4);
     return v;
 }
 __device__ __forceinline__ B96 buf_ld_b96(const BufRsrc& r, uint32_t voff, uint32_t soff) {
     const uint64_t o = (uint64_t)voff + soff;
     B96 v{0, 0, 0};
-    if (o + 12 <= r.bytes) std::memcpy(&v, r.base + o, 12);
+    if (buf_in_range(r, voff, soff, 12)) std::memcpy(&v, r.base + o, 12);
     return v;
 }
 __device__ __forceinline__ float4 buf_ld_f32x4(const BufRsrc& r, uint32_t voff, uint32_t soff) {
     const uint64_t o = (uint64_t)voff + soff;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (o + 16 <= r.bytes) std::memcpy(v, r.base + o, 16);
+    if (buf_in_range(r, voff, soff, 16)) std::memcpy(v, r.base + o, 16);
     return make_float4(v[0], v[1], v[2], v[3]);
 }
 __device__ __forceinline__ lvm_f2 buf_ld_f32x2(const BufRsrc& r, uint32_t voff, uint32_t soff) {
     const uint64_t o = (uint64_t)voff + soff;
     lvm_f2 v = {0.f, 0.f};
-    if (o + 8 <= r.bytes) std::memcpy(&v, r.base + o, 8);
+    if (buf_in_range(r, voff, soff, 8)) std::memcpy(&v, r.base + o, 8);
     return v;
 }
 __device__ __forceinline__ void buf_st_f32x4(float a, float b, float c, float d, const BufRsrc& r, uint32_t voff, uint32_t soff) {
     const uint64_t o = (uint64_t)voff + soff;
     const float v[4] = {a, b, c, d};
-    if (o + 16 <= r.bytes) std::memcpy(r.base + o, v, 16);
+    if (o + 16 <= r.bytes) std::memcpy(r.base + o, v, 16);       // (the product puts voff + soff into the vector register here: the SUM is range-checked)
 }
 __device__ __forceinline__ void buf_st_f32x2(float a, float b, const BufRsrc& r, uint32_t voff, uint32_t soff) {
     const uint64_t o = (uint64_t)voff + soff;
     const float v[2] = {a, b};
-    if (o + 8 <= r.bytes) std::memcpy(r.base + o, v, 8);
+    if (buf_in_range(r, voff, soff, 8)) std::memcpy(r.base + o, v, 8);
 }
 __device__ __forceinline__ void buf_st_b96(const B96& v, const BufRsrc& r, uint32_t voff, uint32_t soff) {
     const uint64_t o = (uint64_t)voff + soff;
-    if (o + 12 <= r.bytes) std::memcpy(r.base + o, &v, 12);
+    if (o + 12 <= r.bytes) std::memcpy(r.base + o, &v, 12);      // (likewise: whole offset in the vector register)
 }
 // streaming (nontemporal) forms: a cache hint only -- the plain accesses here
 __device__ __forceinline__ float ld_stream_f32(const void* p) { float v; std::memcpy(&v, p, 4); return v; }

@@ -1,11 +1,11 @@
 #!/bin/bash
-# Reproduces the round-4 files under profiles/ on a GPU box (`gpurun -- 'bash tools/refresh_profiles.sh'`): the bench
+# Reproduces the round-5 files under profiles/ on a GPU box (`gpurun -- 'bash tools/refresh_profiles.sh'`): the bench
 # lines of every mode (driver-shaped and default), the rocprofv3 kernel-trace summaries and the PMC passes (FETCH_SIZE,
 # WRITE_SIZE, SQ counters: each in its own run, never combined with other trace domains).  Outputs land in gpurun_out/profiles_r04/; copy what is to be judged
 # into profiles/.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-R=r04
+R=r05
 O=$ROOT/gpurun_out/profiles_$R; mkdir -p $O; cd $ROOT
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/${R}_bench_laplace_driver_shape.json 2> $O/err.txt
 timeout 600 python bench.py --no-subrecords > $O/${R}_bench_laplace.json 2>> $O/err.txt
@@ -20,4 +20,10 @@ for m in ${MODES:-laplace riesz color}; do
   python tools/pmc_traffic.py $m "$m|1920x1080|L6|B1|T32" $O/pmc_$m/p0 $O/pmc_$m/p3 $O/pmc_$m/p4 > $O/${R}_pmc_traffic_$m.json
   rm -rf $O/pmc_$m/p1 $O/pmc_$m/p2 $O/pmc_$m/p3 $O/pmc_$m/p4       # the per-dispatch counter CSVs are large; the summaries stay
 done
+# BASELINE configs[4] (Riesz 3840x2160, 8 levels, 16 frames per call): kernel stats + calibrated traffic for the cfg4 sub-record's roofline
+bash tools/pmc.sh profiles_$R/pmc_riesz_4k "--mode riesz --width 3840 --height 2160 --levels 8 --frames-per-call 16 --ring 16 --steps 64 --warmup 16" "FETCH_SIZE" "WRITE_SIZE" > /dev/null 2>&1
+cp $O/pmc_riesz_4k/p0/t_kernel_stats.csv $O/${R}_rocprof_riesz_4k_kernel_stats.csv
+python tools/pmc_traffic.py riesz "riesz|3840x2160|L8|B1|T16" $O/pmc_riesz_4k/p0 $O/pmc_riesz_4k/p1 $O/pmc_riesz_4k/p2 > $O/${R}_pmc_traffic_riesz_3840x2160.json
+rm -rf $O/pmc_riesz_4k/p1 $O/pmc_riesz_4k/p2
+timeout 300 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/${R}_pytest_gpu.txt
 ls -la $O | head -40
