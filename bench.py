@@ -108,10 +108,10 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, S, T, Twin=0):
             return T * S * (3 * n[0] + 4 * n[0])
         if base == "rz_split" and lvl is not None:
             return T * 4 * S * (2 * n[lvl] + n[lvl + 1])
-        vec4 = lambda l: sizes[l][0] % 4 == 0 and sizes[l][0] >= 8  # noqa: E731  (levels of the 4-pixels-per-thread phase kernel)
+        vec4 = lambda l: sizes[l][0] % 4 == 0 and sizes[l][0] >= 8 and S * T >= 2  # noqa: E731  (levels of the 4-pixels-per-thread phase kernel; one frame of one stream takes the scalar one)
         # round 3: levels of >= 2^19 plane-pixels per launch with an even width take the strip form of the blur / amplify stage,
         # which recomputes the Riesz pair from the band: no per-frame pair written by the phase kernel nor read back (-8 B each)
-        strips = lambda l: sizes[l][0] % 2 == 0 and n[l] * S * T >= (1 << 19)  # noqa: E731
+        strips = lambda l: sizes[l][0] % 2 == 0 and n[l] * S * T >= 2000  # noqa: E731   (riesz.hip: blur_strips_min)
         if base in ("rz_phase", "rz_phase_small"):
             # per frame: band in, amp/tc/ts (+ R1/R2) out; 13 state floats R + W once per launch
             return sum((T * (16 if strips(l) else 24) + 104) * S * n[l] for l in range(nb) if vec4(l) == (base == "rz_phase"))

@@ -1158,7 +1158,8 @@ struct ColorState : ModeState {
     int out_rows = 16;               // rows per wave strip of k_col_out_rows (LVM_COL_OUT_ROWS; 0 = tiled k_col_out_v4)
     int out_rows_lean = 36;          // ... of k_col_out_strips (strip start-up = 3 V rows + 3 U2 rows: longer strips; 1080 = 30 x 36)
     bool out_lean = true;            // k_col_out_strips (both pyrUps inside, packed FP32, loads an iteration ahead); LVM_COL_OUT_LEAN=0: k_col_out_rows
-    int thin_min_frames = 4;         // ... from this many frames per launch (LVM_COL_THIN_MIN_FRAMES)
+    int thin_min_frames = 1;         // ... from this many frames per launch (LVM_COL_THIN_MIN_FRAMES).  Round 5: 4 -> 1 -- the eight-lanes-per-row kernel of round 4 also wins
+                                     // for ONE frame per launch (24 -> 16 us per 1080p frame; the wave-per-row kernel remains for wide bands)
     long rows_min_elems = 1 << 20;   // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS)
     double* tw = nullptr; int tw_n = 0;          // table of the current window length (points into tw_all or at tw_own)
     double* tw_all = nullptr; int tw_all_max = 0; std::vector<size_t> tw_off;   // tables of every length 2 .. tw_all_max

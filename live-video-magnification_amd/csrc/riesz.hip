@@ -1499,6 +1499,8 @@ struct RieszState : ModeState {
     bool split_rows = true;          // LDS-free wave-strip split (LVM_RZ_SPLIT_ROWS=0: the tiled kernels) ...
     long split_rows_min = 10000000;  // ... for launches of at least this many plane-pixels (LVM_RZ_SPLIT_ROWS_MIN); below, the tiled kernels measure equal or faster
     bool phase4 = true;              // 4-pixels-per-thread phase kernel on levels whose width is a multiple of 4 (LVM_RZ_PHASE4=0: scalar kernel)
+    int phase4_min_frames = 2;       // ... from this many frames x streams per launch (LVM_RZ_PHASE4_MIN_FRAMES): ONE frame of one stream has too few 4-pixel threads to
+                                     // hide the state loads -- the one-pixel kernel runs it in 58 us against 64 (round 5)
     int fin_groups = 0;              // workgroups of the persistent last kernel (LVM_RZ_FIN_GROUPS; 0 = a sixth of the tiles, at least 2048)
     int split_strip = 0;             // rows per strip of k_rz_split_rows (LVM_RZ_SPLIT_STRIP; 0 = chosen per launch)
     bool collapse_strips = true;     // collapse / output as wave strips (LVM_RZ_COLLAPSE_STRIPS=0: the tiled kernels) ...
@@ -1506,9 +1508,12 @@ struct RieszState : ModeState {
     int collapse_strip = 0;          // rows per strip of k_rz_collapse_strips (LVM_RZ_COLLAPSE_STRIP; 0 = chosen per launch)
     bool compact = true;             // compact zero-injected tile in the collapse kernels (LVM_RZ_COMPACT=0: the full 24 x 72 tile)
     bool split2 = true;              // 64 x 32 tiles with 4 x 2 outputs per thread in the 9x9 split (LVM_RZ_SPLIT2=0: k_rz_split)
+    long split2_min = 600000;        // ... on launches of at least this many plane-pixels (LVM_RZ_SPLIT2_MIN): a per-frame call's levels >= 1 are a few workgroups whose time is
+                                     // the length of one thread's instruction stream -- one output per thread: 11 -> 8-9 us per launch (round 5)
     bool blur4 = true;               // register-blocked Gaussian/amplify kernel on the large levels (LVM_RZ_BLUR4=0: scalar kernel everywhere)
     bool blur_strips = true;         // LDS-free wave-strip Gaussian/amplify kernel (LVM_RZ_BLUR_STRIPS=0: the tiled kernels) ...
-    long blur_strips_min = 1 << 19;  // ... for levels of at least this many plane-pixels per launch (LVM_RZ_BLUR_STRIPS_MIN; 1080p x 32 frames: levels 0 .. 3)
+    long blur_strips_min = 2000;     // ... for levels of at least this many plane-pixels per launch (LVM_RZ_BLUR_STRIPS_MIN).  Round 5: 2^19 -> 2000 -- per-frame calls used to
+                                     // send level 1 (518 400 px) to the tiled kernel and the small levels to a third launch: 242 -> 205 us per 1080p frame with every even-width level in the ONE strip launch
     int blur_strip_rows = 64;        // rows per strip (LVM_RZ_BLUR_STRIP_ROWS), halved until a level has 4096 strips
     double lo_freq = 0, hi_freq = 0, fps = 0;
     double la[3] = {}, lb[3] = {}, ha[3] = {}, hb[3] = {};
@@ -1599,7 +1604,7 @@ static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B,
                        (const float*)B.oct[l], a.w, a.h, B.pf[l][F_BAND], B.oct[l + 1], b.w, b.h, sx, sy, (int)ntasks, rows);
             continue;
         }
-        if (st->split2 && a.w % 4 == 0) {
+        if (st->split2 && a.w % 4 == 0 && (long)a.n * NZ >= st->split2_min) {
             const dim3 grid2((a.w + CW - 1) / CW, (a.h + C2H - 1) / C2H, NZ);
             LVM_LAUNCH(c, LName("rz_split", l), k_rz_split2, grid2, blk, s, (const float*)B.oct[l], a.w, a.h, B.pf[l][F_BAND], B.oct[l + 1], b.w, b.h);
             continue;
@@ -1624,7 +1629,7 @@ static void rz_phase(Ctx* c, RieszState* st, const RzBufs& B, int mode, hipStrea
     PhaseArgs a4 = a;
     int n1 = 0, n4 = 0, blocks = 0, blocks4 = 0;
     for (int l = 0; l < nb; ++l) {
-        const bool vec = st->phase4 && st->g[l].w % 4 == 0 && st->g[l].w >= 8;
+        const bool vec = st->phase4 && st->g[l].w % 4 == 0 && st->g[l].w >= 8 && NS * B.nt >= st->phase4_min_frames;
         PhaseLv& v = vec ? a4.lv[n4++] : a.lv[n1++];
         float** f = st->f[l];          // state planes
         float** q = B.pf[l];           // per-frame planes
@@ -1783,6 +1788,8 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
         if (const char* e = std::getenv("LVM_RZ_BLUR_STRIPS_MIN")) st->blur_strips_min = std::atol(e);
         if (const char* e = std::getenv("LVM_RZ_BLUR_STRIP_ROWS")) st->blur_strip_rows = std::atoi(e);
         if (const char* e = std::getenv("LVM_RZ_SPLIT2")) st->split2 = std::atoi(e) != 0;
+        if (const char* e = std::getenv("LVM_RZ_SPLIT2_MIN")) st->split2_min = std::atol(e);
+        if (const char* e = std::getenv("LVM_RZ_PHASE4_MIN_FRAMES")) st->phase4_min_frames = std::atoi(e);
         if (const char* e = std::getenv("LVM_RZ_COMPACT")) st->compact = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_RZ_PHASE4")) st->phase4 = std::atoi(e) != 0;
         if (const char* e = std::getenv("LVM_RZ_FIN_GROUPS")) st->fin_groups = std::atoi(e);

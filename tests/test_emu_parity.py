@@ -72,11 +72,25 @@ def test_riesz_emu_bit_exact(lvm, po, emu, w, h, levels):
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 6, 0.0, exact=True)
 
 
+@pytest.mark.parametrize("w,h,levels,calls", [(264, 150, 3, (2, 1, 4, 1)), (160, 90, 5, (2, 3)), (96, 64, 3, (2, 1, 1))])
+@pytest.mark.parametrize("wide", ["1", "0"])
+def test_riesz_emu_wide_and_narrow_tile_kernels(lvm, po, emu, w, h, levels, calls, wide, monkeypatch):
+    """Round 5 picks the tile kernels by launch size: k_rz_split2 (4 x 2 outputs per thread) from 600 000 plane-pixels per launch, else
+    k_rz_split (one output per thread); k_rz_phase4 (four pixels per thread) from two frames x streams per launch, else k_rz_phase.  Both
+    choices forced onto small frames -- per-frame calls between temporal batches, so that the state written by one phase kernel is read
+    by the other."""
+    monkeypatch.setenv("LVM_RZ_SPLIT2_MIN", "0" if wide == "1" else "1000000000")
+    monkeypatch.setenv("LVM_RZ_PHASE4_MIN_FRAMES", "1" if wide == "1" else "2")
+    monkeypatch.setenv("LVM_RZ_SPLIT_ROWS", "0")
+    _frames_clip(lvm, po, emu, 2, w, h, levels, 1, calls)
+
+
 @pytest.mark.parametrize("blur4", ["1", "0"])
 def test_riesz_emu_register_blocked_blur(lvm, po, emu, blur4, monkeypatch):
     """k_rz_blur_amp4 (64 x 32 tiles, vector staging of interior tiles, 4 x 2 outputs per thread) against the
     scalar kernel's arithmetic: a frame with interior, edge and partial tiles on two levels."""
     monkeypatch.setenv("LVM_RZ_BLUR4", blur4)
+    monkeypatch.setenv("LVM_RZ_BLUR_STRIPS", "0")         # (the strip form is the default for every even-width level since round 5)
     ck, pk = lvm.synth.config(2, (264, 150, 3))
     run_pair(lvm, po, emu, lvm.synth.Clip(**ck), pk, 4, 0.0, exact=True)
 
