@@ -858,9 +858,12 @@ def host_fed_record(lvm, torch, np, cfg_idx, small, local_rank, rank, world, dis
         allr = [None] * world
         dist.all_gather_object(allr, mine)
     tot = lambda k: round(sum((r.get(k) or 0.0) for r in allr), 2)      # noqa: E731
-    return {"note": "every rank runs the host -> host surfaces concurrently (own context, own GPU, own page-locked buffers)",
-            "e2e_host_pinned": {"value": tot("e2e_fps"), "unit": "frames/s", "pcie_gbs_total": tot("e2e_pcie_gbs")},
-            "export_host": {"value": tot("export_fps"), "unit": "frames/s", "pcie_gbs_total": tot("export_pcie_gbs")},
+    # every rank moves the same number of frames between the same two barriers: all frames / the SLOWEST rank's time = N x min(rate)
+    agg = lambda k: round(len(allr) * min((r.get(k) or 0.0) for r in allr), 2)      # noqa: E731
+    return {"note": "every rank runs the host -> host surfaces concurrently (own context, own GPU, own page-locked buffers); value = all ranks' frames / the "
+                    "slowest rank's time",
+            "e2e_host_pinned": {"value": agg("e2e_fps"), "unit": "frames/s", "pcie_gbs_total": tot("e2e_pcie_gbs")},
+            "export_host": {"value": agg("export_fps"), "unit": "frames/s", "pcie_gbs_total": tot("export_pcie_gbs")},
             "per_rank": allr}
 
 

@@ -238,7 +238,7 @@ def test_bench_eight_ranks_dry_run():
     hf = out["host_fed"]
     assert sorted(r["rank"] for r in hf["per_rank"]) == list(range(8))
     assert all(r["e2e_fps"] and r["export_fps"] and r["e2e_pcie_gbs"] and r["export_pcie_gbs"] for r in hf["per_rank"]), hf
-    assert abs(hf["export_host"]["value"] - sum(r["export_fps"] for r in hf["per_rank"])) < 0.1
+    assert abs(hf["export_host"]["value"] - 8 * min(r["export_fps"] for r in hf["per_rank"])) < 0.1      # all frames / the slowest rank's time
     assert all("host_binding" in r for r in out["ranks"])
 
 
