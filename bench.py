@@ -735,6 +735,8 @@ def e2e_host_record(lvm, np, ctx, cp_ref, host, kinds=("pageable", "pinned"), Ke
             src = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_uint8)), shape=(8, h, w, ch))
             dst = np.ctypeslib.as_array(C.cast(pout, C.POINTER(C.c_uint8)), shape=(h, w, ch))
             src[:] = host[:8]
+            if kind == "pageable_in_pinned_out":      # the one-line swap as it is: FramePool frames pageable, the shim's output from its pinned pool
+                src = host[:8].copy()
             if staged:
                 pg_src, pg_dst = host[:8].copy(), np.empty((h, w, ch), np.uint8)
         else:
@@ -987,7 +989,7 @@ def sub_records(lvm, torch, np, args, cfg_idx, small, local_rank, rank, world, d
     host = R.d_in[:, 0].cpu().numpy()
     lib = lvm.load()
     twin = lib.lvm_optimal_buffer_size(int(R.pk["framerate"]))
-    out["e2e_host"] = e2e_host_record(lvm, np, R.ctx, R.p_ref, host, kinds=("pageable", "pinned", "pageable_staged_through_pinned"),
+    out["e2e_host"] = e2e_host_record(lvm, np, R.ctx, R.p_ref, host, kinds=("pageable", "pinned", "pageable_in_pinned_out", "pageable_staged_through_pinned"),
                                       warm=(twin + 12 if R.pk["mode"] == lvm.synth.MODE_COLOR else 20))
     # (2b) the export loop body: 32 page-locked host frames in, 32 side-by-side canvases out per lvm_export_frames call
     # (runChainOnce + Exporter::compose, Exporter.cpp:216-259; the temporal batch inside, the canvases composed on the device)

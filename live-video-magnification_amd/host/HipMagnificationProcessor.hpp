@@ -46,13 +46,18 @@ public:
             mag_.process(q, key(cfg.preprocess), nullptr, 0, 0, 3, 0, nullptr, 0);
             return in;
         }
-        cv::Mat dst(src.rows, src.cols, src.type());
+        // the output frame lives in a recycled PAGE-LOCKED buffer: the last kernel writes it there directly (no download);
+        // pageable memory when the pool cannot allocate
+        const std::size_t row = static_cast<std::size_t>(src.cols) * static_cast<std::size_t>(src.channels());
+        std::shared_ptr<std::uint8_t> buf = pool_.acquire(row * static_cast<std::size_t>(src.rows));
+        cv::Mat dst = buf ? cv::Mat(src.rows, src.cols, src.type(), buf.get(), row) : cv::Mat(src.rows, src.cols, src.type());
         const bool produced = mag_.process(q, key(cfg.preprocess), src.data, src.cols, src.rows, src.channels(),
                                            static_cast<std::ptrdiff_t>(src.step), dst.data,
                                            static_cast<std::ptrdiff_t>(dst.step));
         if (!produced) return in;                // warm-up / unsupported input: emit the input unchanged (:61)
-        auto out = std::make_shared<Frame>(*in);
+        auto out = std::make_shared<PinnedFrame>(*in);
         out->image = std::move(dst);             // fresh buffer; never aliases in->image (:63-66)
+        out->keep = std::move(buf);              // returns to the pool with the frame
         out->format = src.channels() >= 3 ? PixelFormat::BGR8 : PixelFormat::Gray8;
         return out;
     }
@@ -74,7 +79,9 @@ private:
         mix(&pp.roiX, sizeof pp.roiX); mix(&pp.roiY, sizeof pp.roiY); mix(&pp.roiW, sizeof pp.roiW); mix(&pp.roiH, sizeof pp.roiH);
         return h ? h : 1;
     }
+    struct PinnedFrame : Frame { explicit PinnedFrame(const Frame& f) : Frame(f) {} std::shared_ptr<std::uint8_t> keep; };
     lvm::Magnifier mag_;
+    lvm::PinnedPool pool_;
 };
 
 }  // namespace livim

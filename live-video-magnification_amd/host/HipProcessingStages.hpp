@@ -50,12 +50,17 @@ public:
         int ow = 0, oh = 0, och = 0;
         lvm::Magnifier::chain_geometry(pre, src.cols, src.rows, src.channels(), &ow, &oh, &och);
         const bool stage_identity = ow == src.cols && oh == src.rows && och == src.channels();
-        cv::Mat dst(oh, ow, och == 1 ? CV_8UC1 : CV_8UC3);
+        // (output in a recycled page-locked buffer: the download is a plain DMA, no runtime-side pinning per frame)
+        const std::size_t row = static_cast<std::size_t>(ow) * static_cast<std::size_t>(och);
+        std::shared_ptr<std::uint8_t> buf = pool_.acquire(row * static_cast<std::size_t>(oh));
+        const int type = och == 1 ? CV_8UC1 : CV_8UC3;
+        cv::Mat dst = buf ? cv::Mat(oh, ow, type, buf.get(), row) : cv::Mat(oh, ow, type);
         const bool produced = mag_.chain_process(pre, q, src.data, src.cols, src.rows, src.channels(),
                                                  static_cast<std::ptrdiff_t>(src.step), dst.data,
                                                  static_cast<std::ptrdiff_t>(dst.step));
         if (!produced && stage_identity) return in;                   // all three stages were identities
-        auto out = std::make_shared<Frame>(*in);
+        auto out = std::make_shared<PinnedFrame>(*in);
+        out->keep = std::move(buf);                                   // returns to the pool with the frame
         out->image = std::move(dst);
         out->width = ow; out->height = oh;                            // PreprocessProcessor.cpp:46-49
         out->format = och >= 3 ? PixelFormat::BGR8 : PixelFormat::Gray8;   // GrayscaleProcessor.cpp:14
@@ -65,7 +70,9 @@ public:
     void reset() override { mag_.reset(); }
 
 private:
+    struct PinnedFrame : Frame { explicit PinnedFrame(const Frame& f) : Frame(f) {} std::shared_ptr<std::uint8_t> keep; };
     lvm::Magnifier mag_;
+    lvm::PinnedPool pool_;
 };
 
 }  // namespace livim

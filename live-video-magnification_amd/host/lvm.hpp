@@ -4,9 +4,12 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <vector>
 
 #include "lvm_hip.h"
 
@@ -109,6 +112,35 @@ private:
         if (rc != LVM_OK) throw Error(rc, std::string("lvm: ") + lvm_last_error(ctx_));
     }
     lvm_ctx* ctx_ = nullptr;
+};
+
+// Page-locked output buffers, recycled: what the shims hand lvm_process as `out`, so that its last kernel writes the frame straight
+// into the caller's buffer over PCIe (no staging copy, no download; include/lvm_hip.h lvm_host_alloc).  A buffer returns to the pool
+// when its last user drops it -- the same rule the reference's FramePool (core/FramePool.cpp:29-36) gives its pooled frames: nobody
+// may keep a cv::Mat header of the pixels longer than the FrameRef.  A size change starts a new generation; the old buffers are freed
+// as they come back.
+class PinnedPool {
+public:
+    std::shared_ptr<std::uint8_t> acquire(std::size_t bytes) {
+        if (!core_ || core_->bytes != bytes) { core_ = std::make_shared<Core>(); core_->bytes = bytes; }
+        void* p = nullptr;
+        {
+            std::lock_guard<std::mutex> lg(core_->m);
+            if (!core_->free.empty()) { p = core_->free.back(); core_->free.pop_back(); }
+        }
+        if (!p && lvm_host_alloc(bytes, &p) != LVM_OK) return nullptr;     // caller falls back to pageable memory
+        std::shared_ptr<Core> core = core_;
+        return std::shared_ptr<std::uint8_t>(static_cast<std::uint8_t*>(p), [core](std::uint8_t* q) {
+            std::lock_guard<std::mutex> lg(core->m);
+            core->free.push_back(q);
+        });
+    }
+private:
+    struct Core {
+        std::mutex m; std::vector<void*> free; std::size_t bytes = 0;
+        ~Core() { for (void* p : free) lvm_host_free(p); }
+    };
+    std::shared_ptr<Core> core_;
 };
 
 }  // namespace lvm
