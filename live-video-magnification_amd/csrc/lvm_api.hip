@@ -572,7 +572,6 @@ int lvm_export_frames(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_par
     lvm_params mp = *p;
     mp.preprocess_key = preprocess_key_of(*pp);
     const int saved_depth = c->pipeline_depth;
-    c->pipeline_depth = 0;
     for (int q = 0; q < nchunks; ++q) {
         const int f0 = q * chunk, nf = (f0 + chunk <= n_frames) ? chunk : n_frames - f0;
         // stage 1 (up_stream): only the ROI rows cross PCIe (the crop is the pitch of the 2-D copy)
@@ -589,19 +588,21 @@ int lvm_export_frames(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_par
                 rc = lvm::preprocess_device(c, qp, c->d_pre_in + (size_t)k * roi_bytes, rw, rh, channels, (ptrdiff_t)roi_row, (ptrdiff_t)roi_bytes,
                                             c->d_pre_out + (size_t)k * out_bytes, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, s,
                                             gray_tap ? c->d_pre_tap + (size_t)k * tap_bytes : nullptr, (ptrdiff_t)tap_row, (ptrdiff_t)tap_bytes);
-                if (rc != LVM_OK) { c->pipeline_depth = saved_depth; drain(); return rc; }
+                if (rc != LVM_OK) { drain(); return rc; }
             }
         }
+        c->pipeline_depth = 0;                                           // (the synchronous surface completes its own frames)
         rc = lvm_process_device_frames(c, &mp, nf, mag_base + (size_t)f0 * out_bytes, ow, oh, och, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, (ptrdiff_t)out_bytes,
                                        c->d_chain_out + (size_t)f0 * out_bytes, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, (ptrdiff_t)out_bytes, produced + f0, s);
-        if (rc != LVM_OK) { c->pipeline_depth = saved_depth; drain(); return rc; }
+        c->pipeline_depth = saved_depth;
+        if (rc != LVM_OK) { drain(); return rc; }
         for (int k = f0; k < f0 + nf; ++k) {
             const uint8_t* seen = mag_base + (size_t)k * out_bytes;                                 // what the magnifier saw
             const uint8_t* proc = produced[k] ? c->d_chain_out + (size_t)k * out_bytes : seen;      // MagnificationProcessor.cpp:61
             const uint8_t* orig = gray_tap ? c->d_pre_tap + (size_t)k * tap_bytes : seen;           // ChainBuilder.cpp:25
             rc = lvm::compose_device(c, split, orig, ow, oh, gray_tap ? 3 : och, (ptrdiff_t)(gray_tap ? tap_row : out_row), (ptrdiff_t)(gray_tap ? tap_bytes : out_bytes),
                                      proc, ow, oh, och, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, c->d_canvas + (size_t)k * can_bytes, (ptrdiff_t)can_row, (ptrdiff_t)can_bytes, s);
-            if (rc != LVM_OK) { c->pipeline_depth = saved_depth; drain(); return rc; }
+            if (rc != LVM_OK) { drain(); return rc; }
         }
         LVM_EXPORT_TRY(hipEventRecord(c->ev_done[q], s));
         // stage 3 (down_stream): the canvases of this sub-batch
@@ -611,7 +612,6 @@ int lvm_export_frames(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_par
                                             hipMemcpyDeviceToHost, c->down_stream));
     }
 #undef LVM_EXPORT_TRY
-    c->pipeline_depth = saved_depth;
     lvm::mark_enqueued(c, s);
     LVM_HIP_TRY(c, hipStreamSynchronize(c->down_stream));     // (the last canvases: everything on `s` and `up_stream` precedes them)
     LVM_HIP_TRY(c, hipStreamSynchronize(s));
