@@ -650,8 +650,8 @@ struct FinArgs {
 // row (EXACT: scaled by 1/64 as pyrUp does; otherwise the unscaled vertical sum, whose power-of-two scale `msc` is folded into the
 // add -- fma(m, 2^-k, L) rounds exactly like L + m * 2^-k).  dbg_px: where the float pixels go (lvm_debug_keep_float) or null.
 template <bool MOTION, bool DBG, int FL>
-__device__ __forceinline__ void lap_emit_row(const Raw4 pin, const float (&m)[3][4], const float msc, const float ca, const LabCoef& lab,
-                                             const float* s_igt, const float* s_gam, float* dbg_px, uint8_t* out_px) {
+__device__ __forceinline__ B96 lap_emit_row(const Raw4 pin, const float (&m)[3][4], const float msc, const float ca, const LabCoef& lab,
+                                            const float* s_igt, const float* s_gam, float* dbg_px) {
     constexpr bool EXACT = fl_exact(FL);
     float L4[4], a4[4], b4[4];
     raw4_to_lab<FL>(pin, s_gam, lab, L4, a4, b4);
@@ -676,8 +676,7 @@ __device__ __forceinline__ void lap_emit_row(const Raw4 pin, const float (&m)[3]
             ov[3 * k + 2] = __builtin_fmaf(o2, 255.0f, lab.a255);
         }
     }
-    // (the output frame is not read again on the device: streaming store)
-    st_stream_b96(out_px, pack_u8x4(ov[0], ov[1], ov[2], ov[3]), pack_u8x4(ov[4], ov[5], ov[6], ov[7]), pack_u8x4(ov[8], ov[9], ov[10], ov[11]));
+    return B96{pack_u8x4(ov[0], ov[1], ov[2], ov[3]), pack_u8x4(ov[4], ov[5], ov[6], ov[7]), pack_u8x4(ov[8], ov[9], ov[10], ov[11])};
 }
 // one wave strip (task) of the last kernel; s_igt = inverse-gamma spline in LDS, s_gam = gamma table (analytic flavour)
 template <bool MOTION, bool DBG, int FL>     // DBG: also store the float frame (lvm_debug_keep_float); a per-pixel branch
@@ -707,17 +706,19 @@ __device__ __forceinline__ void lap_final_strip(const FinArgs& q, int task, int 
     // columns, 16 selects / border variants less per lane and source row.
     const unsigned cm1 = 4u * (i0 > 0 ? i0 - 1 : (EXACT ? 0 : 1)), c00 = 4u * i0, cp1 = 4u * (i0 + 1 < w1 ? i0 + 1 : w1 - 1), cp2 = 4u * (i0 + 2 < w1 ? i0 + 2 : w1 - 1);
     const size_t pstride = (size_t)w1 * h1;
+    // Round 5: every access of the strip goes through a buffer resource (base + size in SGPRs, a 32-bit lane offset, a wave-uniform row
+    // offset): no 64-bit address arithmetic in vector registers (the generic form cost ~55 v_lshl_add_u64 per three steps and 24
+    // VGPRs of address pairs).  The three cur_1 planes of this frame are one resource, the integer planes and the output frame another each.
+    const BufRsrc rcur = buf_rsrc(MOTION ? (const void*)pl : (const void*)in, MOTION ? (uint32_t)(3 * pstride * sizeof(float)) : 0u);
     // horizontal pass of source row sy (vertical border map: row -1 -> 1, row h1 -> h1 - 1); the row
     // base is uniform, the four column offsets are per-lane byte offsets
     auto hrow = [&](int sy) __attribute__((always_inline)) {
         Row3 o;
         sy = sy < 0 ? 1 : (sy >= h1 ? h1 - 1 : sy);
-        const char* row = reinterpret_cast<const char*>(pl + (size_t)sy * w1);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const char* rc = row + c * pstride * sizeof(float);
-            const float sm1 = *reinterpret_cast<const float*>(rc + cm1), s0 = *reinterpret_cast<const float*>(rc + c00),
-                        s1 = *reinterpret_cast<const float*>(rc + cp1), s2 = *reinterpret_cast<const float*>(rc + cp2);
+            const uint32_t rb = (uint32_t)(((size_t)sy * w1 + c * pstride) * sizeof(float));
+            const float sm1 = buf_ld_f32(rcur, cm1, rb), s0 = buf_ld_f32(rcur, c00, rb), s1 = buf_ld_f32(rcur, cp1, rb), s2 = buf_ld_f32(rcur, cp2, rb);
             if (EXACT) o.c[c] = pyrup_h4(sm1, s0, s1, s2, i0, w1);
             else if (LVM_FAST_FMA) {   // one rounding less per even column (fma), a few 1e-8 of the motion image
                 o.c[c].x = __builtin_fmaf(s0, 6.f, sm1 + s1); o.c[c].y = (s0 + s1) * 4.f; o.c[c].z = __builtin_fmaf(s1, 6.f, s0 + s2); o.c[c].w = (s1 + s2) * 4.f;
@@ -727,17 +728,29 @@ __device__ __forceinline__ void lap_final_strip(const FinArgs& q, int task, int 
     };
     const int yend = (y0 + rows < h) ? y0 + rows : h;
     int gy = y0, j = y0 >> 1;
+    // the frame's integer planes (read once by this launch: streaming loads) / the u8 frame of the analytic flavour, and the output frame
+    const BufRsrc rL = buf_rsrc(PLANES ? (const void*)(lp.iL + poff) : (const void*)src, PLANES ? (uint32_t)((size_t)w * h * 2) : 0u);
+    const BufRsrc rAB = buf_rsrc(PLANES ? (const void*)(lp.iab + poff) : (const void*)src, PLANES ? (uint32_t)((size_t)w * h * 4) : 0u);
+    const BufRsrc rout = buf_rsrc(dst, (uint32_t)((size_t)out_stride * (h - 1) + (size_t)w * 3));
+    auto ld_in = [&](int y) __attribute__((always_inline)) {
+        if (!PLANES) return load_raw4<false>(src, in_stride, lp, poff, w, y, (unsigned)gx);
+        Raw4 r{};
+        const uint2 l = buf_lds_u32x2(rL, (uint32_t)gx * 2u, (uint32_t)y * (uint32_t)w * 2u);
+        const uint4 ab = buf_lds_u32x4(rAB, (uint32_t)gx * 4u, (uint32_t)y * (uint32_t)w * 4u);
+        r.d[0] = l.x; r.d[1] = l.y; r.d[2] = ab.x; r.d[3] = ab.y; r.d[4] = ab.z; r.d[5] = ab.w;
+        return r;
+    };
     auto emit = [&](const Raw4 pin, const float (&m)[3][4], const float msc) __attribute__((always_inline)) {
-        lap_emit_row<MOTION, DBG, FL>(pin, m, msc, ca, lab, s_igt, s_gam, (DBG && dbg && b == 0) ? dbg + ((size_t)gy * w + gx) * 3 : nullptr,
-                                      dst + (size_t)gy * out_stride + xoff);
+        const B96 o = lap_emit_row<MOTION, DBG, FL>(pin, m, msc, ca, lab, s_igt, s_gam, (DBG && dbg && b == 0) ? dbg + ((size_t)gy * w + gx) * 3 : nullptr);
+        buf_sts_b96(o, rout, xoff, (uint32_t)gy * (uint32_t)out_stride);      // (the output frame is not read again on the device: streaming store)
     };
     // two output rows (2j, 2j+1) from the window rows A = j-1, B = j, C = j+1; afterwards A holds row
     // j+2, i.e. the window has rotated to (B, C, A).  Returns false when the strip is finished.
     auto step = [&](Row3& A, const Row3& B, const Row3& C) __attribute__((always_inline)) {
-        const Raw4 pe = load_raw4<PLANES, true>(src, in_stride, lp, poff, w, gy, (unsigned)gx);
+        const Raw4 pe = ld_in(gy);
         const bool has_odd = gy + 1 < yend;
         Raw4 po = pe;
-        if (has_odd) po = load_raw4<PLANES, true>(src, in_stride, lp, poff, w, gy + 1, (unsigned)gx);
+        if (has_odd) po = ld_in(gy + 1);
         float m[3][4] = {};
         if (MOTION) {
 #pragma unroll

@@ -133,6 +133,14 @@ __device__ __forceinline__ float4 buf_lds_f32x4(const BufRsrc& r, uint32_t voff,
     const lvm_f32x4 v = __builtin_bit_cast(lvm_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, kAuxStream));
     return make_float4(v.x, v.y, v.z, v.w);
 }
+__device__ __forceinline__ uint2 buf_lds_u32x2(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    const lvm_u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, kAuxStream);
+    return make_uint2(v.x, v.y);
+}
+__device__ __forceinline__ uint4 buf_lds_u32x4(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    const lvm_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, kAuxStream);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ lvm_f2 buf_lds_f32x2(const BufRsrc& r, uint32_t voff, uint32_t soff) {
     return __builtin_bit_cast(lvm_f2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, kAuxStream));
 }

@@ -70,6 +70,16 @@ __device__ __forceinline__ float4 ld_stream_f32x4(const void* p) { float4 v; std
 __device__ __forceinline__ void st_stream_b96(void* p, uint32_t a, uint32_t b, uint32_t c) { const uint32_t v[3] = {a, b, c}; std::memcpy(p, v, 12); }
 __device__ __forceinline__ void st_stream_f32x4(void* p, float a, float b, float c, float d) { const float v[4] = {a, b, c, d}; std::memcpy(p, v, 16); }
 __device__ __forceinline__ float buf_lds_f32(const BufRsrc& r, uint32_t voff, uint32_t soff) { return buf_ld_f32(r, voff, soff); }
+__device__ __forceinline__ uint2 buf_lds_u32x2(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    const uint64_t o = (uint64_t)voff + soff; uint2 v = make_uint2(0, 0);
+    if (buf_in_range(r, voff, soff, 8)) std::memcpy(&v, r.base + o, 8);
+    return v;
+}
+__device__ __forceinline__ uint4 buf_lds_u32x4(const BufRsrc& r, uint32_t voff, uint32_t soff) {
+    const uint64_t o = (uint64_t)voff + soff; uint4 v = make_uint4(0, 0, 0, 0);
+    if (buf_in_range(r, voff, soff, 16)) std::memcpy(&v, r.base + o, 16);
+    return v;
+}
 __device__ __forceinline__ B96 buf_lds_b96(const BufRsrc& r, uint32_t voff, uint32_t soff) { return buf_ld_b96(r, voff, soff); }
 __device__ __forceinline__ float4 buf_lds_f32x4(const BufRsrc& r, uint32_t voff, uint32_t soff) { return buf_ld_f32x4(r, voff, soff); }
 __device__ __forceinline__ lvm_f2 buf_lds_f32x2(const BufRsrc& r, uint32_t voff, uint32_t soff) { return buf_ld_f32x2(r, voff, soff); }
