@@ -1,9 +1,13 @@
 // TEST INFRASTRUCTURE ONLY -- scheduler of the HIP emulation (see include/hip/hip_runtime.h).
 #include <hip/hip_runtime.h>
+#if defined(__SANITIZE_ADDRESS__) || !defined(__x86_64__)
+#define HIPEMU_UCONTEXT 1          // AddressSanitizer knows swapcontext; everything else switches stacks itself
 #include <ucontext.h>
+#endif
 
 #include <sys/mman.h>
 
+#include <cstdint>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -53,20 +57,88 @@ bool guard_free(void* p) {
     return true;
 }
 thread_local State st;
+#ifndef HIPEMU_UCONTEXT
+// swapcontext() makes a system call per switch (the signal mask); a wave shift is two switches per lane.  This switch saves the
+// callee-saved registers + MXCSR / x87 control word on the old stack and resumes the new one: same semantics, ~50 x cheaper.
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hipemu_switch, .-hipemu_switch
+)");
+#endif
 namespace {
-struct Fiber { ucontext_t ctx; char* stack = nullptr; bool done = true; dim3 tid; };
 constexpr size_t kStack = 256 * 1024;
-thread_local std::vector<Fiber> fibers;
+#ifdef HIPEMU_UCONTEXT
+struct Fiber { ucontext_t ctx; char* stack = nullptr; bool done = true; dim3 tid; };
 thread_local ucontext_t sched;
+#else
+struct Fiber { void* sp = nullptr; char* stack = nullptr; bool done = true; dim3 tid; };
+thread_local void* sched = nullptr;
+#endif
+thread_local std::vector<Fiber> fibers;
 thread_local Fiber* cur = nullptr;
 thread_local const std::function<void()>* body = nullptr;
+#ifdef HIPEMU_UCONTEXT
+void to_sched() { swapcontext(&cur->ctx, &sched); }
+void to_fiber(Fiber& f) { swapcontext(&sched, &f.ctx); }
+#else
+void to_sched() { hipemu_switch(&cur->sp, sched); }
+void to_fiber(Fiber& f) { hipemu_switch(&sched, f.sp); }
+#endif
 void entry() {
     (*body)();
     cur->done = true;
-    swapcontext(&cur->ctx, &sched);
+    to_sched();
+    std::abort();          // a finished fibre is never resumed
+}
+void arm(Fiber& f) {
+#ifdef HIPEMU_UCONTEXT
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = f.stack;
+    f.ctx.uc_stack.ss_size = kStack;
+    f.ctx.uc_link = nullptr;
+    makecontext(&f.ctx, entry, 0);
+#else
+    // the frame hipemu_switch pops: MXCSR | x87 CW, r15 r14 r13 r12 rbx rbp, return address = entry; entry() then sees the stack
+    // alignment of a called function (rsp = 16 n + 8)
+    uintptr_t top = ((uintptr_t)f.stack + kStack) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;                       // entry's (never used) return address
+    *--sp = (void*)&entry;
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;
+    --sp;
+    unsigned* cw = (unsigned*)sp;
+    cw[0] = 0x1F80u;                       // MXCSR default: all exceptions masked, round to nearest
+    cw[1] = 0x037Fu;                       // x87 default control word
+    f.sp = sp;
+#endif
 }
 }  // namespace
-void sync() { swapcontext(&cur->ctx, &sched); }
+void sync() { to_sched(); }
 // Cross-lane shift by one lane over a 64-lane wave.  The fibres of a workgroup run round-robin between
 // yields, so "deposit, yield, read the neighbour, yield" is a correct exchange as long as all lanes of the
 // wave execute the same sequence of yields (wave-uniform control flow, as DPP requires on the hardware).
@@ -117,11 +189,7 @@ void launch(const std::function<void()>& fn, dim3 grid, dim3 block) {
 #endif
                 for (unsigned t = 0; t < n; ++t) {
                     Fiber& f = fibers[t];
-                    getcontext(&f.ctx);
-                    f.ctx.uc_stack.ss_sp = f.stack;
-                    f.ctx.uc_stack.ss_size = kStack;
-                    f.ctx.uc_link = nullptr;
-                    makecontext(&f.ctx, entry, 0);
+                    arm(f);
                     f.done = false;
                     f.tid = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
                 }
@@ -134,7 +202,7 @@ void launch(const std::function<void()>& fn, dim3 grid, dim3 block) {
                         if (f.done) continue;
                         cur = &f;
                         st.tid = f.tid;
-                        swapcontext(&sched, &f.ctx);
+                        to_fiber(f);
                         if (!f.done) ++alive;
                     }
                 }

@@ -3,7 +3,7 @@
 // order) can be exercised by the CPU test-suite (`-m "not gpu"`) in a container without a GPU.
 // The build lives in tests/emu/_build/ and is only ever loaded by tests/; the product library
 // (liblvm_hip.so) is always the hipcc/gfx950 build and has no CPU path.
-// One workgroup runs at a time; its work-items are ucontext fibers and __syncthreads() yields
+// One workgroup runs at a time; its work-items are fibres (own stacks, a 20-instruction switch: hip_emu.cpp) and __syncthreads() yields
 // to a round-robin scheduler.  Device allocations are filled with 0xFF (NaN floats) so reads of
 // uninitialised memory surface in the parity checks.
 #pragma once

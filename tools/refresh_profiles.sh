@@ -1,7 +1,7 @@
 #!/bin/bash
 # Reproduces the round-5 files under profiles/ on a GPU box (`gpurun -- 'bash tools/refresh_profiles.sh'`): the bench
 # lines of every mode (driver-shaped and default), the rocprofv3 kernel-trace summaries and the PMC passes (FETCH_SIZE,
-# WRITE_SIZE, SQ counters: each in its own run, never combined with other trace domains).  Outputs land in gpurun_out/profiles_r04/; copy what is to be judged
+# WRITE_SIZE, SQ counters: each in its own run, never combined with other trace domains).  Outputs land in gpurun_out/profiles_r05/; copy what is to be judged
 # into profiles/.
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
