@@ -25,5 +25,5 @@ bash tools/pmc.sh profiles_$R/pmc_riesz_4k "--mode riesz --width 3840 --height 2
 cp $O/pmc_riesz_4k/p0/t_kernel_stats.csv $O/${R}_rocprof_riesz_4k_kernel_stats.csv
 python tools/pmc_traffic.py riesz "riesz|3840x2160|L8|B1|T16" $O/pmc_riesz_4k/p0 $O/pmc_riesz_4k/p1 $O/pmc_riesz_4k/p2 > $O/${R}_pmc_traffic_riesz_3840x2160.json
 rm -rf $O/pmc_riesz_4k/p1 $O/pmc_riesz_4k/p2
-timeout 300 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/${R}_pytest_gpu.txt
+timeout 480 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/${R}_pytest_gpu.txt
 ls -la $O | head -40
