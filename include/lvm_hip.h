@@ -205,6 +205,22 @@ int  lvm_export_frames(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_
                        const uint8_t* const* frames, int w, int h, int channels, ptrdiff_t in_stride,
                        uint8_t* const* canvases, ptrdiff_t canvas_stride, int* produced);
 
+/* Motion-JPEG encode on the device (the encode half): what cv::VideoWriter::write(canvas) does for
+ * ExportFormat::AviMjpg, the reference's AVI export format and the fallback of every other one (export/Exporter.cpp:107-117, :259).
+ * Baseline JPEG (ITU-T T.81), 8 bit, YCbCr 4:2:0 (JFIF), Annex K Huffman tables, one restart interval per MCU row, libjpeg's quality scale
+ * (1..100).  Frames: BGR, 1..8192 x 1..16384.
+ *   lvm_mjpeg_bound            bytes that always suffice for ONE encoded frame of this size (a bound; typical frames are 5-20 % of it)
+ *   lvm_mjpeg_encode_device    n_frames device-resident BGR frames -> out[offsets[i] .. offsets[i + 1]) = frame i, a complete JPEG;
+ *                              offsets has n_frames + 1 entries.  LVM_ERR_INVALID when out_capacity is too small.  Synchronous.
+ *   lvm_export_frames_mjpeg    lvm_export_frames with the canvases encoded on the device: only the ROI rows go up and only the compressed
+ *                              frames come down.  host/HipMjpegWriter.hpp wraps the frames into the AVI container.                       */
+size_t lvm_mjpeg_bound(int w, int h);
+int  lvm_mjpeg_encode_device(lvm_ctx* ctx, const uint8_t* d_bgr, int w, int h, ptrdiff_t stride, ptrdiff_t frame_stride, int n_frames,
+                             int quality, uint8_t* out, size_t out_capacity, size_t* offsets);
+int  lvm_export_frames_mjpeg(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames,
+                             const uint8_t* const* frames, int w, int h, int channels, ptrdiff_t in_stride, int quality,
+                             uint8_t* out, size_t out_capacity, size_t* offsets, int* produced);
+
 /* Cross-frame software pipeline for lvm_process_device (throughput mode, default depth 0).
  * depth 1 (implemented for the Laplace mode; other modes ignore it): a call enqueues the
  * down-sweep of ITS frame on an internal second stream concurrently with the up-sweep + output of

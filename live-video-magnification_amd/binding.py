@@ -100,7 +100,7 @@ SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process
            "lvm_profile_entry", "lvm_algorithmic_bytes", "lvm_export_geometry", "lvm_export_frames",
            "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process", "lvm_chain_process_batch",
            "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free", "lvm_compose_geometry", "lvm_compose_device", "lvm_chain_process_batch_ex",
-           "lvm_chain_present"]
+           "lvm_chain_present", "lvm_mjpeg_bound", "lvm_mjpeg_encode_device", "lvm_export_frames_mjpeg"]
 
 
 def bind(lib):
@@ -154,6 +154,11 @@ def bind(lib):
     lib.lvm_export_geometry.argtypes = [C.POINTER(LvmPreprocessParams), C.c_int, C.c_int, C.c_int, C.c_int, ip, ip]
     lib.lvm_export_frames.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), C.c_int, C.c_int, C.POINTER(vp), C.c_int, C.c_int,
                                       C.c_int, C.c_ssize_t, C.POINTER(vp), C.c_ssize_t, ip]
+    lib.lvm_mjpeg_bound.argtypes = [C.c_int, C.c_int]
+    lib.lvm_mjpeg_bound.restype = C.c_size_t
+    lib.lvm_mjpeg_encode_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.lvm_export_frames_mjpeg.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), C.c_int, C.c_int, C.POINTER(vp), C.c_int, C.c_int,
+                                            C.c_int, C.c_ssize_t, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t), ip]
     lib.lvm_compose_geometry.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip]
     lib.lvm_compose_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, C.c_int, C.c_int, C.c_int,
                                        C.c_ssize_t, C.c_ssize_t, vp, C.c_ssize_t, C.c_ssize_t, vp]
@@ -311,6 +316,35 @@ class Context:
         self._check(self.lib.lvm_export_frames(self.h, C.byref(cpre), C.byref(cparams), int(split), len(frames), pin, w, h, ch, w * ch,
                                                pout, cw.value * 3, produced))
         return canvases, [bool(x) for x in produced]
+
+    def mjpeg_encode_device(self, d_ptr, w, h, n_frames, quality=75, stride=None, frame_stride=None, capacity=None):
+        """lvm_mjpeg_encode_device: device-resident BGR frames (address) -> list of JPEG frames (bytes)."""
+        stride = w * 3 if stride is None else stride
+        frame_stride = stride * h if frame_stride is None else frame_stride
+        cap = int(self.lib.lvm_mjpeg_bound(w, h)) * n_frames if capacity is None else int(capacity)
+        out = np.empty(cap, dtype=np.uint8)
+        offs = (C.c_size_t * (n_frames + 1))()
+        self._check(self.lib.lvm_mjpeg_encode_device(self.h, d_ptr, w, h, stride, frame_stride, n_frames, int(quality), out.ctypes.data, cap, offs))
+        return [out[offs[i]:offs[i + 1]].tobytes() for i in range(n_frames)]
+
+    def export_frames_mjpeg(self, frames, cpre, cparams, split, quality=75, capacity=None):
+        """lvm_export_frames_mjpeg: Exporter::run's loop body with the canvases encoded on the device.  Returns (JPEG frames, produced flags)."""
+        frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+        h, w = frames[0].shape[:2]
+        ch = 1 if frames[0].ndim == 2 else frames[0].shape[2]
+        cw, chh = C.c_int(0), C.c_int(0)
+        self._check(self.lib.lvm_export_geometry(C.byref(cpre), int(split), w, h, ch, C.byref(cw), C.byref(chh)))
+        if cw.value <= 0 or chh.value <= 0:
+            raise LvmError("export_frames_mjpeg: empty canvas for this geometry (Exporter::compose returns an empty Mat)")
+        n = len(frames)
+        cap = int(self.lib.lvm_mjpeg_bound(cw.value, chh.value)) * n if capacity is None else int(capacity)
+        out = np.empty(cap, dtype=np.uint8)
+        offs = (C.c_size_t * (n + 1))()
+        pin = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+        produced = (C.c_int * n)()
+        self._check(self.lib.lvm_export_frames_mjpeg(self.h, C.byref(cpre), C.byref(cparams), int(split), n, pin, w, h, ch, w * ch, int(quality),
+                                                     out.ctypes.data, cap, offs, produced))
+        return [out[offs[i]:offs[i + 1]].tobytes() for i in range(n)], [bool(x) for x in produced]
 
     def chain_process(self, frame, cpre, cparams):
         """Preprocess -> Grayscale -> Magnification on a host frame (lvm_chain_process).  Returns (out, produced);

@@ -224,6 +224,7 @@ void lvm_destroy(lvm_ctx* c) {
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_float) (void)hipFree(c->d_float);
     lvm::preprocess_release(c);
+    lvm::mjpeg_release(c);
     if (c->d_pre_in) (void)hipFree(c->d_pre_in);
     if (c->d_pre_out) (void)hipFree(c->d_pre_out);
     if (c->d_chain_out) (void)hipFree(c->d_chain_out);
@@ -521,13 +522,16 @@ int lvm_export_geometry(const lvm_preprocess_params* pp, int split, int w, int h
 // tools/ubench_pcie.hip: 52-57 GB/s one way, 90-97 GB/s with both directions busy).  The magnifier still sees every frame in order
 // with the state of its predecessor; a sub-batch is one temporal batch (lvm_process_device_frames), so the frames are the ones a
 // single 32-frame batch -- or 32 per-frame calls -- gives.
-int lvm_export_frames(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames,
-                      const uint8_t* const* frames, int w, int h, int channels, ptrdiff_t in_stride, uint8_t* const* canvases,
-                      ptrdiff_t canvas_stride, int* produced) {
-    if (!c || !pp || !p || !frames || !canvases || !produced || n_frames < 1) return LVM_ERR_INVALID;
+// lvm_export_frames and lvm_export_frames_mjpeg: the same three-queue loop; with `mj` the canvases stay on the device and are encoded there
+struct MjpegSink { int quality; uint8_t* out; size_t capacity; size_t* offsets; };
+static int export_frames_impl(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames,
+                              const uint8_t* const* frames, int w, int h, int channels, ptrdiff_t in_stride, uint8_t* const* canvases,
+                              ptrdiff_t canvas_stride, int* produced, const MjpegSink* mj) {
+    if (!c || !pp || !p || !frames || (!canvases && !mj) || !produced || n_frames < 1) return LVM_ERR_INVALID;
+    if (mj && (!mj->out || !mj->offsets)) return LVM_ERR_INVALID;
     if (c->nstreams != 1) { c->err = "lvm_export_frames needs a 1-stream context"; return LVM_ERR_INVALID; }
     if (w <= 0 || h <= 0 || (channels != 1 && channels != 3) || in_stride < (ptrdiff_t)w * channels) { c->err = "bad frame arguments"; return LVM_ERR_INVALID; }
-    for (int k = 0; k < n_frames; ++k) { produced[k] = 0; if (!frames[k] || !canvases[k]) { c->err = "null frame pointer"; return LVM_ERR_INVALID; } }
+    for (int k = 0; k < n_frames; ++k) { produced[k] = 0; if (!frames[k] || (!mj && !canvases[k])) { c->err = "null frame pointer"; return LVM_ERR_INVALID; } }
     LVM_HIP_TRY(c, hipSetDevice(c->device));
     int rx, ry, rw, rh, ow, oh, och, pw, ph, cw, chh;
     lvm::preprocess_geometry(*pp, w, h, channels, &rx, &ry, &rw, &rh, &ow, &oh, &och);
@@ -535,7 +539,7 @@ int lvm_export_frames(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_par
     if (!lvm::compose_geometry(split, ow, oh, ow, oh, &pw, &ph, &cw, &chh) || cw <= 0 || chh <= 0) {
         c->err = "lvm_export_frames: empty canvas (Exporter::compose returns an empty Mat for this geometry)"; return LVM_ERR_INVALID;
     }
-    if (canvas_stride < (ptrdiff_t)cw * 3) { c->err = "canvas stride too small"; return LVM_ERR_INVALID; }
+    if (!mj && canvas_stride < (ptrdiff_t)cw * 3) { c->err = "canvas stride too small"; return LVM_ERR_INVALID; }
     const size_t roi_row = (size_t)rw * channels, roi_bytes = roi_row * rh;
     const size_t out_row = (size_t)ow * och, out_bytes = out_row * oh;
     const size_t can_row = (size_t)cw * 3, can_bytes = can_row * chh;
@@ -558,13 +562,15 @@ int lvm_export_frames(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_par
     rc = reserve(c->d_chain_out, c->chain_out_cap, out_bytes * n_frames); if (rc != LVM_OK) return rc;
     rc = reserve(c->d_canvas, c->canvas_cap, can_bytes * n_frames); if (rc != LVM_OK) return rc;
     if (gray_tap) { rc = reserve(c->d_pre_tap, c->pre_tap_cap, tap_bytes * n_frames); if (rc != LVM_OK) return rc; }
-    int chunk = 2;
-    if (const char* e = std::getenv("LVM_EXPORT_CHUNK")) { const int v = std::atoi(e); if (v >= 1) chunk = v; }
+    int chunk = mj ? 4 : 2;      // (JPEG frames: nothing large to download, the encoder's launches want more frames each)
+    if (const char* e = std::getenv(mj ? "LVM_EXPORT_MJPEG_CHUNK" : "LVM_EXPORT_CHUNK")) { const int v = std::atoi(e); if (v >= 1) chunk = v; }
     const int nchunks = (n_frames + chunk - 1) / chunk;
+
     if (!c->up_stream) LVM_HIP_TRY(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
     if (!c->down_stream) LVM_HIP_TRY(c, hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking));
     while ((int)c->ev_up.size() < nchunks) { hipEvent_t e = nullptr; LVM_HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_up.push_back(e); }
     while ((int)c->ev_done.size() < nchunks) { hipEvent_t e = nullptr; LVM_HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_done.push_back(e); }
+    if (mj) { rc = lvm::mjpeg_begin(c, cw, chh, mj->quality, chunk < n_frames ? chunk : n_frames, (size_t)n_frames, mj->capacity, c->down_stream); if (rc != LVM_OK) return rc; }
     auto drain = [&]() { (void)hipStreamSynchronize(c->up_stream); (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(c->down_stream); };
 #define LVM_EXPORT_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e_); drain(); return LVM_ERR_HIP; } } while (0)
     const bool identity = ow == rw && oh == rh && och == channels;      // PreprocessProcessor.cpp:15, GrayscaleProcessor.cpp:8-9
@@ -605,17 +611,63 @@ int lvm_export_frames(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_par
             if (rc != LVM_OK) { drain(); return rc; }
         }
         LVM_EXPORT_TRY(hipEventRecord(c->ev_done[q], s));
-        // stage 3 (down_stream): the canvases of this sub-batch
         LVM_EXPORT_TRY(hipStreamWaitEvent(c->down_stream, c->ev_done[q], 0));
+        if (mj) {       // stage 3 stays on the device (down_stream, next to the magnifier of the following sub-batch): the canvases become JPEG
+                        // frames behind the earlier ones; nothing to download until the end
+            rc = lvm::mjpeg_encode_device(c, c->d_canvas + (size_t)f0 * can_bytes, (ptrdiff_t)can_row, (ptrdiff_t)can_bytes, nf, f0, mj->capacity, c->down_stream);
+            if (rc != LVM_OK) { drain(); return rc; }
+            continue;
+        }
+        // stage 3 (down_stream): the canvases of this sub-batch
         for (int k = f0; k < f0 + nf; ++k)
             LVM_EXPORT_TRY(hipMemcpy2DAsync(canvases[k], (size_t)canvas_stride, c->d_canvas + (size_t)k * can_bytes, can_row, can_row, (size_t)chh,
                                             hipMemcpyDeviceToHost, c->down_stream));
     }
 #undef LVM_EXPORT_TRY
     lvm::mark_enqueued(c, s);
+    if (mj) {
+        rc = lvm::mjpeg_finish(c, (size_t)n_frames, mj->out, mj->offsets, c->down_stream);       // waits for the encoder, then the compressed bytes come down in one copy
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(c->up_stream);
+        return rc;
+    }
     LVM_HIP_TRY(c, hipStreamSynchronize(c->down_stream));     // (the last canvases: everything on `s` and `up_stream` precedes them)
     LVM_HIP_TRY(c, hipStreamSynchronize(s));
     return LVM_OK;
+}
+
+int lvm_export_frames(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames,
+                      const uint8_t* const* frames, int w, int h, int channels, ptrdiff_t in_stride, uint8_t* const* canvases,
+                      ptrdiff_t canvas_stride, int* produced) {
+    if (!canvases) return LVM_ERR_INVALID;
+    return export_frames_impl(c, pp, p, split, n_frames, frames, w, h, channels, in_stride, canvases, canvas_stride, produced, nullptr);
+}
+
+int lvm_export_frames_mjpeg(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames,
+                            const uint8_t* const* frames, int w, int h, int channels, ptrdiff_t in_stride, int quality,
+                            uint8_t* out, size_t out_capacity, size_t* offsets, int* produced) {
+    const MjpegSink mj{quality, out, out_capacity, offsets};
+    return export_frames_impl(c, pp, p, split, n_frames, frames, w, h, channels, in_stride, nullptr, 0, produced, &mj);
+}
+
+size_t lvm_mjpeg_bound(int w, int h) { return (w < 1 || h < 1) ? 0 : lvm::mjpeg_bound(w, h); }
+
+int lvm_mjpeg_encode_device(lvm_ctx* c, const uint8_t* d_bgr, int w, int h, ptrdiff_t stride, ptrdiff_t frame_stride, int n_frames, int quality,
+                            uint8_t* out, size_t out_capacity, size_t* offsets) {
+    if (!c || !d_bgr || !out || !offsets || n_frames < 1) return LVM_ERR_INVALID;
+    if (stride < (ptrdiff_t)w * 3 || (n_frames > 1 && frame_stride < (ptrdiff_t)h * stride)) { c->err = "bad frame arguments"; return LVM_ERR_INVALID; }
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = c->own_stream;
+    const int per = n_frames < 8 ? n_frames : 8;                 // scratch (coefficients, bit buffers) for eight frames at a time
+    int rc = lvm::mjpeg_begin(c, w, h, quality, per, (size_t)n_frames, out_capacity, s);
+    if (rc != LVM_OK) return rc;
+    for (int f0 = 0; f0 < n_frames; f0 += per) {
+        const int nf = f0 + per <= n_frames ? per : n_frames - f0;
+        rc = lvm::mjpeg_encode_device(c, d_bgr + (size_t)f0 * frame_stride, stride, frame_stride, nf, f0, out_capacity, s);
+        if (rc != LVM_OK) { (void)hipStreamSynchronize(s); return rc; }
+    }
+    lvm::mark_enqueued(c, s);
+    return lvm::mjpeg_finish(c, (size_t)n_frames, out, offsets, s);
 }
 
 int lvm_chain_process(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, const uint8_t* in, int w, int h, int channels,

@@ -182,4 +182,6 @@ __device__ __forceinline__ uint32_t lut_hi2(uint32_t d, uint32_t e) { return __b
 // four of them per pixel in round 3's ISA, ~12 issue slots of the conversion's ~94
 __device__ __forceinline__ uint32_t lut_mul24(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// the lanes of the wave whose predicate holds (v_cmp into an SGPR pair); every lane of the wave must execute it
+__device__ __forceinline__ unsigned long long lvm_ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 }  // namespace lvm

@@ -424,6 +424,7 @@ struct Ctx {
     // lvm_export_frames' three-stage pipeline: uploads, kernels and downloads of consecutive sub-batches on their own queues
     hipStream_t up_stream = nullptr, down_stream = nullptr;
     std::vector<hipEvent_t> ev_up, ev_done;
+    void* mjpeg = nullptr;            // mjpeg.hip: tables, header and scratch of the Motion-JPEG encoder
 };
 
 inline int lab_flavour(const Ctx* c) { return c->lab_analytic ? FL_ANALYTIC : (c->exact_lab ? FL_LUT_EXACT : FL_LUT_FAST); }
@@ -480,6 +481,12 @@ void preprocess_release(Ctx* c);
 
 // compose.hip
 int compose_geometry(int split, int ow, int oh, int pw, int ph, int* pane_w, int* pane_h, int* canvas_w, int* canvas_h);
+// mjpeg.hip: Motion-JPEG encode of device-resident BGR frames (cv::VideoWriter::write for ExportFormat::AviMjpg, Exporter.cpp:107-117, :259)
+size_t mjpeg_bound(int w, int h);
+void mjpeg_release(Ctx* c);
+int mjpeg_begin(Ctx* c, int w, int h, int quality, int max_frames_per_call, size_t total_frames, size_t capacity, hipStream_t s);
+int mjpeg_encode_device(Ctx* c, const uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_t fstride, int nframes, int frame0, size_t capacity, hipStream_t s);
+int mjpeg_finish(Ctx* c, size_t total_frames, uint8_t* out_host, size_t* offsets, hipStream_t s);
 int compose_device(Ctx* c, int split, const uint8_t* d_orig, int ow, int oh, int och, ptrdiff_t ostride, ptrdiff_t osstride,
                    const uint8_t* d_proc, int pw, int ph, int pch, ptrdiff_t pstride, ptrdiff_t psstride, uint8_t* d_canvas,
                    ptrdiff_t cstride, ptrdiff_t csstride, hipStream_t s);

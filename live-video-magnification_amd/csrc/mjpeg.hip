@@ -1,0 +1,589 @@
+// mjpeg.hip -- Motion-JPEG encode of device-resident BGR canvases (the encode half).
+//
+// Replaces what `cv::VideoWriter::write(canvas)` does for ExportFormat::AviMjpg -- the reference's AVI export format and the fallback of
+// every other one (reference: export/Exporter.cpp:107-117 openWriter, :259 writer.write(canvas)): the composed canvas never leaves the
+// device, only the compressed frame crosses PCIe (an order of magnitude fewer bytes than the 12.4 MB canvas that bounds
+// lvm_export_frames), and the host's software codec is gone from the export loop.
+//
+// Format: ITU-T T.81 baseline sequential DCT, 8 bit, YCbCr 4:2:0 (JFIF, BT.601 full range), the Huffman tables of Annex K, one restart
+// interval per MCU row.  JPEG leaves colour rounding, the DCT and the quantiser rounding to the encoder; this one is all-integer and is
+// restated line by line by oracle/mjpeg_oracle.py (the arithmetic is in its header): the bitstream is BYTE-IDENTICAL to the oracle's and
+// is decoded by libjpeg (Pillow) in the tests.
+//
+// Why restart intervals: entropy coding is a serial bit stream, but T.81's restart markers cut it into byte-aligned pieces whose DC
+// predictors start at zero (F.1.1.5.1): one MCU row per piece makes a 1080p side-by-side canvas 68 independent streams per frame.
+// Inside a piece the 64 lanes of a wave ARE the 64 coefficients of a block in zigzag order: zero runs, code lengths and bit positions
+// are three wave scans, every lane ORs its own code word into the bit buffer.
+//
+//   k_mj_transform   BGR -> YCbCr 4:2:0 -> FDCT -> quantise -> zigzag          one wave per 16 x 16 MCU
+//   k_mj_codes<0>    Huffman code length of every coefficient -> bits per block   one wave per block
+//   k_mj_scan        bit position of every block, bit buffer zeroed               one workgroup per restart interval
+//   k_mj_codes<1>    the code words again, ORed into the bit buffer               one wave per block
+//   k_mj_size        stuffed size of every interval (FF -> FF 00)                one workgroup per restart interval
+//   k_mj_offsets     byte offsets of the intervals and frames in the output      one workgroup
+//   k_mj_write       header, stuffed intervals, RSTn / EOI markers               one workgroup per restart interval
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "lvm_internal.h"
+
+namespace lvm {
+namespace {
+
+constexpr int kDct[8][8] = {      // round(8192 * C(u) / 2 * cos((2 x + 1) u pi / 16)), T.81 A.3.3 (tests/test_mjpeg_oracle.py checks the formula)
+    {2896, 2896, 2896, 2896, 2896, 2896, 2896, 2896},
+    {4017, 3406, 2276, 799, -799, -2276, -3406, -4017},
+    {3784, 1567, -1567, -3784, -3784, -1567, 1567, 3784},
+    {3406, -799, -4017, -2276, 2276, 4017, 799, -3406},
+    {2896, -2896, -2896, 2896, 2896, -2896, -2896, 2896},
+    {2276, -4017, 799, 3406, -3406, -799, 4017, -2276},
+    {1567, -3784, 3784, -1567, -1567, 3784, -3784, 1567},
+    {799, -2276, 3406, -4017, 4017, -3406, 2276, -799}};
+const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42,
+                             49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+// T.81 Annex K.1 / K.2, natural order
+const uint8_t kQLuma[64] = {16, 11, 10, 16, 24, 40, 51, 61, 12, 12, 14, 19, 26, 58, 60, 55, 14, 13, 16, 24, 40, 57, 69, 56, 14, 17, 22, 29, 51, 87, 80, 62,
+                            18, 22, 37, 56, 68, 109, 103, 77, 24, 35, 55, 64, 81, 104, 113, 92, 49, 64, 78, 87, 103, 121, 120, 101, 72, 92, 95, 98, 112, 100, 103, 99};
+const uint8_t kQChroma[64] = {17, 18, 24, 47, 99, 99, 99, 99, 18, 21, 26, 66, 99, 99, 99, 99, 24, 26, 56, 99, 99, 99, 99, 99, 47, 66, 99, 99, 99, 99, 99, 99,
+                              99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99, 99};
+// T.81 Annex K.3: number of codes of each length 1..16, then the symbols in code order
+const uint8_t kDcLumaBits[16] = {0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0};
+const uint8_t kDcChromaBits[16] = {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0};
+const uint8_t kDcVals[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11};
+const uint8_t kAcLumaBits[16] = {0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 0x7d};
+const uint8_t kAcLumaVals[162] = {
+    0x01, 0x02, 0x03, 0x00, 0x04, 0x11, 0x05, 0x12, 0x21, 0x31, 0x41, 0x06, 0x13, 0x51, 0x61, 0x07, 0x22, 0x71, 0x14, 0x32, 0x81, 0x91, 0xa1, 0x08, 0x23, 0x42, 0xb1,
+    0xc1, 0x15, 0x52, 0xd1, 0xf0, 0x24, 0x33, 0x62, 0x72, 0x82, 0x09, 0x0a, 0x16, 0x17, 0x18, 0x19, 0x1a, 0x25, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x34, 0x35, 0x36, 0x37,
+    0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69, 0x6a,
+    0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a, 0xa2, 0xa3,
+    0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca, 0xd2, 0xd3,
+    0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe1, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf1, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+const uint8_t kAcChromaBits[16] = {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 0x77};
+const uint8_t kAcChromaVals[162] = {
+    0x00, 0x01, 0x02, 0x03, 0x11, 0x04, 0x05, 0x21, 0x31, 0x06, 0x12, 0x41, 0x51, 0x07, 0x61, 0x71, 0x13, 0x22, 0x32, 0x81, 0x08, 0x14, 0x42, 0x91, 0xa1, 0xb1, 0xc1,
+    0x09, 0x23, 0x33, 0x52, 0xf0, 0x15, 0x62, 0x72, 0xd1, 0x0a, 0x16, 0x24, 0x34, 0xe1, 0x25, 0xf1, 0x17, 0x18, 0x19, 0x1a, 0x26, 0x27, 0x28, 0x29, 0x2a, 0x35, 0x36,
+    0x37, 0x38, 0x39, 0x3a, 0x43, 0x44, 0x45, 0x46, 0x47, 0x48, 0x49, 0x4a, 0x53, 0x54, 0x55, 0x56, 0x57, 0x58, 0x59, 0x5a, 0x63, 0x64, 0x65, 0x66, 0x67, 0x68, 0x69,
+    0x6a, 0x73, 0x74, 0x75, 0x76, 0x77, 0x78, 0x79, 0x7a, 0x82, 0x83, 0x84, 0x85, 0x86, 0x87, 0x88, 0x89, 0x8a, 0x92, 0x93, 0x94, 0x95, 0x96, 0x97, 0x98, 0x99, 0x9a,
+    0xa2, 0xa3, 0xa4, 0xa5, 0xa6, 0xa7, 0xa8, 0xa9, 0xaa, 0xb2, 0xb3, 0xb4, 0xb5, 0xb6, 0xb7, 0xb8, 0xb9, 0xba, 0xc2, 0xc3, 0xc4, 0xc5, 0xc6, 0xc7, 0xc8, 0xc9, 0xca,
+    0xd2, 0xd3, 0xd4, 0xd5, 0xd6, 0xd7, 0xd8, 0xd9, 0xda, 0xe2, 0xe3, 0xe4, 0xe5, 0xe6, 0xe7, 0xe8, 0xe9, 0xea, 0xf2, 0xf3, 0xf4, 0xf5, 0xf6, 0xf7, 0xf8, 0xf9, 0xfa};
+
+// device copy of everything the kernels look up
+struct MjTables {
+    uint32_t ac[2][256];      // (code << 8) | length, 0 where a symbol has no code; [0] luminance, [1] chrominance
+    uint32_t dc[2][12];
+    uint32_t qr[2][64];       // ceil(2^24 / Q) in ZIGZAG order: n / Q == (n * qr) >> 24 for every n * Q < 2^24
+    uint16_t q[2][64];        // Q in zigzag order
+    uint8_t zz[64];
+};
+constexpr int MJ_MAX_MW = 512;                  // MCUs per row the entropy kernel's LDS holds (frames up to 8192 pixels wide)
+constexpr int MJ_BLOCK_WORDS = 54;              // worst case of one block: 20 + 63 * 26 bits = 1658 -> 52 words, + 2 for the straddling word and the pad
+constexpr int MJ_MAX_HEADER = 1024;
+
+struct MjGeom {
+    int w, h, mw, mh;
+    long stride, fstride;
+};
+
+struct MjState {
+    int w = 0, h = 0, quality = -1, frames_cap = 0;
+    MjTables* d_tab = nullptr;
+    uint8_t* d_header = nullptr; int header_bytes = 0;
+    std::vector<uint8_t> header;
+    int16_t* d_coef = nullptr;
+    uint32_t* d_raw = nullptr;
+    uint32_t *d_ibits = nullptr, *d_isize = nullptr, *d_blk = nullptr;
+    unsigned long long *d_ioff = nullptr, *d_foff = nullptr, *d_run = nullptr;     // d_run[0] running byte count, d_run[1] overflow flag
+    uint8_t* d_jpeg = nullptr; size_t jpeg_cap = 0;
+    size_t foff_cap = 0;
+};
+
+void build_huff(const uint8_t* bits, const uint8_t* vals, int nvals, uint32_t* table, int table_len) {      // T.81 Annex C
+    for (int i = 0; i < table_len; ++i) table[i] = 0;
+    uint32_t code = 0;
+    int k = 0;
+    for (int len = 1; len <= 16; ++len) {
+        for (int i = 0; i < bits[len - 1] && k < nvals; ++i, ++k) { table[vals[k]] = (code << 8) | (uint32_t)len; ++code; }
+        code <<= 1;
+    }
+}
+
+// libjpeg's jpeg_quality_scaling + jpeg_add_quant_table (baseline: entries 1..255)
+void scaled_quant(int quality, const uint8_t* base, int* out) {
+    quality = quality < 1 ? 1 : (quality > 100 ? 100 : quality);
+    const int scale = quality < 50 ? 5000 / quality : 200 - 2 * quality;
+    for (int i = 0; i < 64; ++i) {
+        int t = (base[i] * scale + 50) / 100;
+        out[i] = t < 1 ? 1 : (t > 255 ? 255 : t);
+    }
+}
+
+void put16(std::vector<uint8_t>& v, int x) { v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x); }
+void segment(std::vector<uint8_t>& v, int marker, const std::vector<uint8_t>& payload) {
+    v.push_back(0xFF); v.push_back((uint8_t)marker); put16(v, (int)payload.size() + 2);
+    v.insert(v.end(), payload.begin(), payload.end());
+}
+
+// SOI, APP0 (JFIF 1.01), DQT x 2, SOF0 (Y 2x2, Cb 1x1, Cr 1x1), DHT x 4, DRI, SOS
+void build_header(std::vector<uint8_t>& v, int w, int h, const int* ql, const int* qc, int restart_interval) {
+    v.clear();
+    v.push_back(0xFF); v.push_back(0xD8);
+    segment(v, 0xE0, {'J', 'F', 'I', 'F', 0, 1, 1, 0, 0, 1, 0, 1, 0, 0});
+    for (int t = 0; t < 2; ++t) {
+        std::vector<uint8_t> p(1, (uint8_t)t);
+        for (int i = 0; i < 64; ++i) p.push_back((uint8_t)(t ? qc : ql)[kZigzag[i]]);
+        segment(v, 0xDB, p);
+    }
+    segment(v, 0xC0, {8, (uint8_t)(h >> 8), (uint8_t)h, (uint8_t)(w >> 8), (uint8_t)w, 3, 1, 0x22, 0, 2, 0x11, 1, 3, 0x11, 1});
+    const struct { int id; const uint8_t* bits; const uint8_t* vals; int n; } hts[4] = {
+        {0x00, kDcLumaBits, kDcVals, 12}, {0x10, kAcLumaBits, kAcLumaVals, 162}, {0x01, kDcChromaBits, kDcVals, 12}, {0x11, kAcChromaBits, kAcChromaVals, 162}};
+    for (const auto& t : hts) {
+        std::vector<uint8_t> p(1, (uint8_t)t.id);
+        p.insert(p.end(), t.bits, t.bits + 16);
+        p.insert(p.end(), t.vals, t.vals + t.n);
+        segment(v, 0xC4, p);
+    }
+    segment(v, 0xDD, {(uint8_t)(restart_interval >> 8), (uint8_t)restart_interval});
+    segment(v, 0xDA, {3, 1, 0x00, 2, 0x11, 3, 0x11, 0, 63, 0});
+}
+
+// ---- kernels ----------------------------------------------------------------------------------------------------------------------------
+
+// One wave per MCU (four per workgroup).  Lane = one 2 x 2 pixel quad = one chroma sample: the 64 lanes of a wave are the 8 x 8 chroma
+// block and the four 8 x 8 luminance blocks of the MCU.  Pixels outside the frame repeat the last row / column.
+__global__ __launch_bounds__(256) void k_mj_transform(const uint8_t* __restrict__ src, MjGeom g, const MjTables* __restrict__ tb, int16_t* __restrict__ coef) {
+    __shared__ int s_a[4][6][64], s_b[4][6][64];
+    __shared__ uint32_t s_qr[2][64];
+    __shared__ uint16_t s_q[2][64];
+    __shared__ uint8_t s_zz[64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    if (tid < 128) { s_qr[tid >> 6][tid & 63] = tb->qr[tid >> 6][tid & 63]; s_q[tid >> 6][tid & 63] = tb->q[tid >> 6][tid & 63]; }
+    if (tid < 64) s_zz[tid] = tb->zz[tid];
+    const int mx = blockIdx.x * 4 + wave, my = blockIdx.y, f = blockIdx.z;
+    const bool act = mx < g.mw;
+    if (act) {
+        const int qx = lane & 7, qy = lane >> 3;
+        const uint8_t* fr = src + (size_t)f * g.fstride;
+        int cbs = 0, crs = 0;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            int py = my * 16 + 2 * qy + dy; py = py < g.h ? py : g.h - 1;
+            const uint8_t* row = fr + (size_t)py * g.stride;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                int px = mx * 16 + 2 * qx + dx; px = px < g.w ? px : g.w - 1;
+                const int b = row[px * 3], gg = row[px * 3 + 1], r = row[px * 3 + 2];
+                const int y = (19595 * r + 38470 * gg + 7471 * b + 32768) >> 16;
+                cbs += (-11059 * r - 21709 * gg + 32768 * b + 8421375) >> 16;
+                crs += (32768 * r - 27439 * gg - 5329 * b + 8421375) >> 16;
+                const int ly = 2 * qy + dy, lx = 2 * qx + dx;
+                s_a[wave][(ly >> 3) * 2 + (lx >> 3)][(ly & 7) * 8 + (lx & 7)] = y - 128;
+            }
+        }
+        s_a[wave][4][lane] = ((cbs + 2) >> 2) - 128;
+        s_a[wave][5][lane] = ((crs + 2) >> 2) - 128;
+    }
+    __syncthreads();
+    if (act && lane < 48) {               // rows: t[y][u] = (sum_x M[u][x] d[y][x] + 512) >> 10
+        const int blk = lane >> 3, r = lane & 7;
+        int d[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) d[x] = s_a[wave][blk][r * 8 + x];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            int acc = 0;
+#pragma unroll
+            for (int x = 0; x < 8; ++x) acc += kDct[u][x] * d[x];
+            s_b[wave][blk][r * 8 + u] = (acc + 512) >> 10;
+        }
+    }
+    __syncthreads();
+    if (act && lane < 48) {               // columns: S[v][u] = (sum_y M[v][y] t[y][u] + 32768) >> 16
+        const int blk = lane >> 3, u = lane & 7;
+        int d[8];
+#pragma unroll
+        for (int y = 0; y < 8; ++y) d[y] = s_b[wave][blk][y * 8 + u];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            int acc = 0;
+#pragma unroll
+            for (int y = 0; y < 8; ++y) acc += kDct[v][y] * d[y];
+            s_a[wave][blk][v * 8 + u] = (acc + 32768) >> 16;
+        }
+    }
+    __syncthreads();
+    if (act) {                            // quantise, zigzag: lane = zigzag index
+        int16_t* out = coef + ((size_t)(f * g.mh + my) * g.mw + mx) * 384;
+        const int nat = s_zz[lane];
+#pragma unroll
+        for (int blk = 0; blk < 6; ++blk) {
+            const int t = blk < 4 ? 0 : 1;
+            const int s = s_a[wave][blk][nat];
+            const uint32_t n = (uint32_t)(s < 0 ? -s : s) + (uint32_t)(s_q[t][lane] >> 1);
+            const int a = (int)(((unsigned long long)n * s_qr[t][lane]) >> 24);         // = n / Q
+            out[blk * 64 + lane] = (int16_t)(s < 0 ? -a : a);
+        }
+    }
+}
+
+// inclusive prefix sum over the 64 lanes of a wave (ds_bpermute: lane i reads lane i - d)
+__device__ __forceinline__ int wave_scan_add(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __builtin_amdgcn_ds_bpermute((lane - d) * 4, v);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+struct LaneCode { uint32_t code; int len, nzrl, bits; };
+// The code word of zigzag position `lane` of block b of a restart interval (T.81 F.1.2): lane 0 the DC difference, a non-zero lane its
+// (run, size) symbol + amplitude bits behind run / 16 ZRL symbols, the lane behind the last non-zero coefficient the end-of-block symbol.
+// The zero runs come from ONE ballot of the non-zero lanes: the previous non-zero position is the highest set bit below the lane.
+// Every lane of the wave calls it; `act` = the block exists.
+__device__ __forceinline__ LaneCode lane_code(const int16_t* __restrict__ cf, int b, bool act, int lane, const uint32_t (*s_ac)[256], const uint32_t (*s_dc)[12]) {
+    const int m = b / 6, blk = b - m * 6, t = blk < 4 ? 0 : 1;
+    int v = act ? cf[(size_t)b * 64 + lane] : 0;
+    if (lane == 0 && act) {
+        const bool has_pred = (blk >= 1 && blk <= 3) || m > 0;              // the predictor restarts at 0 with the interval
+        const int pb = blk == 0 ? b - 3 : (blk < 4 ? b - 1 : b - 6);       // previous block of the same component
+        v -= has_pred ? cf[(size_t)pb * 64] : 0;
+    }
+    const unsigned long long nz = lvm_ballot64(lane >= 1 && v != 0);
+    const unsigned long long below = nz & ((1ull << lane) - 1ull);
+    const int prev = below ? 63 - __builtin_clzll(below) : 0;              // position of the previous non-zero AC coefficient (0: none)
+    const int last = nz ? 63 - __builtin_clzll(nz) : 0;
+    const int a = v < 0 ? -v : v;
+    const int s = a ? 32 - __builtin_clz((unsigned)a) : 0;
+    const uint32_t amp = (uint32_t)(v + (v >> 31)) & ((1u << s) - 1u);      // v, or v - 1 for v < 0: the low s bits
+    LaneCode lc;
+    lc.code = 0; lc.len = 0; lc.nzrl = 0;
+    if (lane == 0) {
+        const uint32_t e = s_dc[t][s];
+        lc.code = ((e >> 8) << s) | amp; lc.len = (int)(e & 255u) + s;
+    } else if (v != 0) {
+        const int run = lane - prev - 1;
+        lc.nzrl = run >> 4;
+        const uint32_t e = s_ac[t][((run & 15) << 4) | s];
+        lc.code = ((e >> 8) << s) | amp; lc.len = (int)(e & 255u) + s;
+    } else if (lane == last + 1) {
+        const uint32_t e = s_ac[t][0];
+        lc.code = e >> 8; lc.len = (int)(e & 255u);
+    }
+    lc.bits = act ? lc.nzrl * (int)(s_ac[t][0xF0] & 255u) + lc.len : 0;
+    return lc;
+}
+
+// `len` bits of `code` at bit position `off` of a big-endian bit buffer of zeroed 32-bit words
+__device__ __forceinline__ void put_bits(uint32_t* __restrict__ out, uint32_t off, uint32_t code, int len) {
+    const uint32_t w = off >> 5;
+    const int room = 32 - (int)(off & 31u);
+    if (len <= room) atomicOr(out + w, code << (room - len));
+    else { atomicOr(out + w, code >> (len - room)); atomicOr(out + w + 1, code << (32 - (len - room))); }
+}
+
+// exclusive scan of s[0 .. n) in place by the 256 threads of a workgroup (part: 256 words of LDS); returns the total
+__device__ __forceinline__ uint32_t wg_exclusive_scan(uint32_t* s, int n, uint32_t* part, int tid) {
+    const int per = (n + 255) / 256, lo = tid * per, hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (int i = lo; i < hi; ++i) sum += s[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t t = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += t;
+        __syncthreads();
+    }
+    uint32_t run = tid ? part[tid - 1] : 0u;
+    for (int i = lo; i < hi; ++i) { const uint32_t t = s[i]; s[i] = run; run += t; }
+    const uint32_t total = part[255];
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ void load_huff(uint32_t (*s_ac)[256], uint32_t (*s_dc)[12], const MjTables* __restrict__ tb, int tid) {
+    for (int i = tid; i < 512; i += 256) s_ac[i >> 8][i & 255] = tb->ac[i >> 8][i & 255];
+    if (tid < 24) s_dc[tid / 12][tid % 12] = tb->dc[tid / 12][tid % 12];
+}
+
+// PACK = false: the number of bits of every block (a wave per block, MJ_NB blocks one after the other; the blocks of all intervals of the
+// launch side by side);
+// PACK = true: after k_mj_scan turned the counts into bit positions, the same code words again.  A wave assembles its block in LDS at the
+// bit phase the block has in the interval's stream (every lane ORs its own code word in: LDS atomics), so that LDS word j IS word
+// (position / 32) + j of the stream: the inner words are plain stores, only the first and the last one -- shared with the neighbouring
+// blocks -- are atomic ORs into the zeroed buffer.
+constexpr int MJ_NB = 16;
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_mj_codes(const int16_t* __restrict__ coef, MjGeom g, long total_blocks, const MjTables* __restrict__ tb,
+                                                  uint32_t* __restrict__ blk, uint32_t* __restrict__ raw) {
+    __shared__ uint32_t s_ac[2][256], s_dc[2][12];
+    __shared__ uint32_t s_stage[PACK ? 4 : 1][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    load_huff(s_ac, s_dc, tb, tid);
+    __syncthreads();
+    const int nblk = g.mw * 6;
+    for (int it = 0; it < MJ_NB; ++it) {
+        const long gb = ((long)blockIdx.x * MJ_NB + it) * 4 + wave;
+        const bool act = gb < total_blocks;
+        const long interval = act ? gb / nblk : 0;
+        const int b = act ? (int)(gb - interval * nblk) : 0;
+        const int16_t* cf = coef + (size_t)interval * g.mw * 384;
+        const LaneCode lc = lane_code(cf, b, act, lane, s_ac, s_dc);
+        const int incl = wave_scan_add(lc.bits, lane);
+        if (!PACK) {
+            if (act && lane == 63) blk[gb] = (uint32_t)incl;
+        } else {
+            const uint32_t base = act ? blk[gb] : 0u, phase = base & 31u;
+            const int total = __builtin_amdgcn_ds_bpermute(63 * 4, incl);
+            s_stage[wave][lane] = 0u;
+            __syncthreads();
+            if (act && lc.bits) {
+                uint32_t off = phase + (uint32_t)(incl - lc.bits);
+                const uint32_t zrl = s_ac[b - (b / 6) * 6 < 4 ? 0 : 1][0xF0];
+                for (int k = 0; k < lc.nzrl; ++k) { put_bits(s_stage[wave], off, zrl >> 8, (int)(zrl & 255u)); off += zrl & 255u; }
+                put_bits(s_stage[wave], off, lc.code, lc.len);
+            }
+            __syncthreads();
+            const int nwords = (int)((phase + (uint32_t)total + 31u) >> 5);
+            if (act && lane < nwords) {
+                uint32_t* out = raw + (size_t)interval * g.mw * 6 * MJ_BLOCK_WORDS + (base >> 5);
+                const uint32_t v = s_stage[wave][lane];
+                if (lane == 0 || lane == nwords - 1) { if (v) atomicOr(out + lane, v); }
+                else out[lane] = v;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// One workgroup per restart interval: bits of its blocks -> their bit positions, the interval's length, its bit buffer zeroed
+__global__ __launch_bounds__(256) void k_mj_scan(MjGeom g, uint32_t* __restrict__ blk, uint32_t* __restrict__ raw, uint32_t* __restrict__ ibits) {
+    __shared__ uint32_t s_off[MJ_MAX_MW * 6];
+    __shared__ uint32_t s_part[256];
+    const int tid = threadIdx.x, nblk = g.mw * 6;
+    const size_t interval = (size_t)blockIdx.y * g.mh + blockIdx.x;
+    uint32_t* mine = blk + interval * nblk;
+    for (int i = tid; i < nblk; i += 256) s_off[i] = mine[i];
+    __syncthreads();
+    const uint32_t total_bits = wg_exclusive_scan(s_off, nblk, s_part, tid);
+    for (int i = tid; i < nblk; i += 256) mine[i] = s_off[i];
+    if (tid == 0) ibits[interval] = total_bits;
+    uint32_t* out = raw + interval * (size_t)g.mw * 6 * MJ_BLOCK_WORDS;
+    const uint32_t nwords = (total_bits + 31u) / 32u + 1u;
+    for (uint32_t i = tid; i < nwords; i += 256) out[i] = 0u;
+}
+
+// byte i of an interval's bit buffer; the last byte is filled up with 1-bits (T.81 F.1.2.3)
+__device__ __forceinline__ uint32_t raw_byte(const uint32_t* __restrict__ raw, uint32_t i, uint32_t nbytes, uint32_t bits) {
+    uint32_t b = (raw[i >> 2] >> (24u - 8u * (i & 3u))) & 255u;
+    if (i + 1 == nbytes && (bits & 7u)) b |= (1u << (8u - (bits & 7u))) - 1u;
+    return b;
+}
+
+__global__ __launch_bounds__(256) void k_mj_size(const uint32_t* __restrict__ raw, MjGeom g, const uint32_t* __restrict__ ibits, uint32_t* __restrict__ isize) {
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x;
+    const size_t interval = (size_t)blockIdx.y * g.mh + blockIdx.x;
+    const uint32_t* in = raw + interval * (size_t)g.mw * 6 * MJ_BLOCK_WORDS;
+    const uint32_t bits = ibits[interval], nbytes = (bits + 7u) >> 3;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    int cnt = 0;
+    for (uint32_t i = tid; i < nbytes; i += 256) cnt += raw_byte(in, i, nbytes, bits) == 255u;
+    if (cnt) atomicAdd(&s_cnt, cnt);
+    __syncthreads();
+    if (tid == 0) isize[interval] = nbytes + (uint32_t)s_cnt;
+}
+
+// One workgroup: frame f of this launch starts where frame f - 1 ended (run[0] carries the position from launch to launch), its
+// intervals follow the header, each one followed by its two marker bytes.  A frame that does not fit `cap` any more sets run[1] and is
+// given the offset ~0 (k_mj_write skips it).
+__global__ __launch_bounds__(256) void k_mj_offsets(MjGeom g, int nframes, int header_bytes, const uint32_t* __restrict__ isize, unsigned long long* __restrict__ ioff,
+                                                    unsigned long long* __restrict__ foff, unsigned long long* __restrict__ run, unsigned long long cap) {
+    __shared__ uint32_t s_sz[MJ_MAX_MW * 2 + 64];       // (mh <= 1024 intervals per frame: frames up to 16384 rows)
+    __shared__ uint32_t s_part[256];
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_base = run[0];
+    __syncthreads();
+    for (int f = 0; f < nframes; ++f) {
+        for (int i = tid; i < g.mh; i += 256) s_sz[i] = isize[(size_t)f * g.mh + i] + 2u;
+        __syncthreads();
+        const uint32_t body = wg_exclusive_scan(s_sz, g.mh, s_part, tid);
+        const unsigned long long base = s_base, fsize = (unsigned long long)header_bytes + body;
+        const bool fits = base + fsize <= cap;
+        for (int i = tid; i < g.mh; i += 256) ioff[(size_t)f * g.mh + i] = fits ? base + header_bytes + s_sz[i] : ~0ull;
+        __syncthreads();
+        if (tid == 0) {
+            foff[f] = base;
+            if (fits) s_base = base + fsize; else run[1] = 1ull;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { foff[nframes] = s_base; run[0] = s_base; }
+}
+
+__global__ __launch_bounds__(256) void k_mj_write(const uint32_t* __restrict__ raw, MjGeom g, const uint32_t* __restrict__ ibits, const uint32_t* __restrict__ isize,
+                                                  const unsigned long long* __restrict__ ioff, const uint8_t* __restrict__ header, int header_bytes,
+                                                  uint8_t* __restrict__ jpeg) {
+    __shared__ uint32_t s_part[256];
+    const int tid = threadIdx.x;
+    const int my = blockIdx.x;
+    const size_t interval = (size_t)blockIdx.y * g.mh + my;
+    const unsigned long long o = ioff[interval];
+    if (o == ~0ull) return;                               // (uniform: the frame did not fit)
+    const uint32_t* in = raw + interval * (size_t)g.mw * 6 * MJ_BLOCK_WORDS;
+    uint8_t* dst = jpeg + o;
+    if (my == 0) for (int i = tid; i < header_bytes; i += 256) (dst - header_bytes)[i] = header[i];
+    const uint32_t bits = ibits[interval], nbytes = (bits + 7u) >> 3;
+    const uint32_t per = (nbytes + 255u) / 256u, lo = tid * per, hi = lo + per < nbytes ? lo + per : nbytes;
+    uint32_t ff = 0;
+    for (uint32_t i = lo; i < hi; ++i) ff += raw_byte(in, i, nbytes, bits) == 255u;
+    s_part[tid] = ff;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const uint32_t t = tid >= d ? s_part[tid - d] : 0u;
+        __syncthreads();
+        s_part[tid] += t;
+        __syncthreads();
+    }
+    uint32_t pos = lo + (tid ? s_part[tid - 1] : 0u);
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t b = raw_byte(in, i, nbytes, bits);
+        dst[pos++] = (uint8_t)b;
+        if (b == 255u) dst[pos++] = 0;
+    }
+    if (tid == 0) {
+        const uint32_t n = isize[interval];
+        dst[n] = 0xFF;
+        dst[n + 1] = (uint8_t)(my + 1 < g.mh ? 0xD0 + (my & 7) : 0xD9);      // RSTm between the intervals, EOI behind the last one
+    }
+}
+
+template <class T>
+int mj_reserve(Ctx* c, T*& p, size_t count) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    LVM_HIP_TRY(c, hipMalloc((void**)&p, count * sizeof(T)));
+    return LVM_OK;
+}
+
+}  // namespace
+
+size_t mjpeg_bound(int w, int h) {
+    const size_t mw = (size_t)(w + 15) / 16, mh = (size_t)(h + 15) / 16;
+    return (size_t)MJ_MAX_HEADER + mw * mh * 6 * MJ_BLOCK_WORDS * 4 * 2 + mh * 2;      // every entropy byte stuffed: a bound, not an estimate
+}
+
+void mjpeg_release(Ctx* c) {
+    MjState* st = static_cast<MjState*>(c->mjpeg);
+    if (!st) return;
+    void* ptrs[] = {st->d_tab, st->d_header, st->d_coef, st->d_raw, st->d_blk, st->d_ibits, st->d_isize, st->d_ioff, st->d_foff, st->d_run, st->d_jpeg};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete st;
+    c->mjpeg = nullptr;
+}
+
+// Begins a sequence of mjpeg_encode_device calls whose frames are appended to one output buffer of `capacity` bytes on the device.
+int mjpeg_begin(Ctx* c, int w, int h, int quality, int max_frames_per_call, size_t total_frames, size_t capacity, hipStream_t s) {
+    if (w < 1 || h < 1 || w > MJ_MAX_MW * 16 || h > 16384) { c->err = "lvm_mjpeg: frame size out of range (1..8192 x 1..16384)"; return LVM_ERR_INVALID; }
+    if (quality < 1 || quality > 100) { c->err = "lvm_mjpeg: quality must be 1..100"; return LVM_ERR_INVALID; }
+    MjState* st = static_cast<MjState*>(c->mjpeg);
+    if (!st) { st = new MjState; c->mjpeg = st; }
+    const int mw = (w + 15) / 16, mh = (h + 15) / 16;
+    int rc;
+    if (!st->d_tab) { rc = mj_reserve(c, st->d_tab, 1); if (rc != LVM_OK) return rc; }
+    if (!st->d_header) { rc = mj_reserve(c, st->d_header, (size_t)MJ_MAX_HEADER); if (rc != LVM_OK) return rc; }
+    if (!st->d_run) { rc = mj_reserve(c, st->d_run, 2); if (rc != LVM_OK) return rc; }
+    if (st->quality != quality || st->w != w || st->h != h) {
+        LVM_HIP_TRY(c, hipStreamSynchronize(s));                   // (earlier launches may still read the tables)
+        MjTables t;
+        std::memset(&t, 0, sizeof t);
+        build_huff(kDcLumaBits, kDcVals, 12, t.dc[0], 12);
+        build_huff(kDcChromaBits, kDcVals, 12, t.dc[1], 12);
+        build_huff(kAcLumaBits, kAcLumaVals, 162, t.ac[0], 256);
+        build_huff(kAcChromaBits, kAcChromaVals, 162, t.ac[1], 256);
+        int ql[64], qc[64];
+        scaled_quant(quality, kQLuma, ql);
+        scaled_quant(quality, kQChroma, qc);
+        for (int i = 0; i < 64; ++i) {
+            const int a = ql[kZigzag[i]], b = qc[kZigzag[i]];
+            t.q[0][i] = (uint16_t)a; t.q[1][i] = (uint16_t)b;
+            t.qr[0][i] = (uint32_t)(((1u << 24) + a - 1) / a); t.qr[1][i] = (uint32_t)(((1u << 24) + b - 1) / b);
+            t.zz[i] = kZigzag[i];
+        }
+        build_header(st->header, w, h, ql, qc, mw);
+        if ((int)st->header.size() > MJ_MAX_HEADER) { c->err = "lvm_mjpeg: header too long"; return LVM_ERR_INVALID; }
+        LVM_HIP_TRY(c, hipMemcpy(st->d_tab, &t, sizeof t, hipMemcpyHostToDevice));
+        LVM_HIP_TRY(c, hipMemcpy(st->d_header, st->header.data(), st->header.size(), hipMemcpyHostToDevice));
+        st->header_bytes = (int)st->header.size();
+        if (st->w != w || st->h != h) st->frames_cap = 0;          // the scratch buffers are sized per geometry
+        st->quality = quality; st->w = w; st->h = h;
+    }
+    if (st->frames_cap < max_frames_per_call) {
+        LVM_HIP_TRY(c, hipStreamSynchronize(s));
+        const size_t nint = (size_t)mh * max_frames_per_call, nmcu = nint * mw;
+        st->frames_cap = 0;
+        if ((rc = mj_reserve(c, st->d_coef, nmcu * 384)) != LVM_OK) return rc;
+        if ((rc = mj_reserve(c, st->d_raw, nmcu * 6 * MJ_BLOCK_WORDS)) != LVM_OK) return rc;
+        if ((rc = mj_reserve(c, st->d_blk, nmcu * 6)) != LVM_OK) return rc;
+        if ((rc = mj_reserve(c, st->d_ibits, nint)) != LVM_OK) return rc;
+        if ((rc = mj_reserve(c, st->d_isize, nint)) != LVM_OK) return rc;
+        if ((rc = mj_reserve(c, st->d_ioff, nint)) != LVM_OK) return rc;
+        st->frames_cap = max_frames_per_call;
+    }
+    if (st->foff_cap < total_frames + 1) {
+        LVM_HIP_TRY(c, hipStreamSynchronize(s));
+        st->foff_cap = 0;
+        if ((rc = mj_reserve(c, st->d_foff, total_frames + 1)) != LVM_OK) return rc;
+        st->foff_cap = total_frames + 1;
+    }
+    if (st->jpeg_cap < capacity) {
+        LVM_HIP_TRY(c, hipStreamSynchronize(s));
+        st->jpeg_cap = 0;
+        if ((rc = mj_reserve(c, st->d_jpeg, capacity)) != LVM_OK) return rc;
+        st->jpeg_cap = capacity;
+    }
+    LVM_HIP_TRY(c, hipMemsetAsync(st->d_run, 0, 2 * sizeof(unsigned long long), s));
+    return LVM_OK;
+}
+
+// Encodes `nframes` BGR frames (device) and appends them behind the frames of the earlier calls since mjpeg_begin; frame0 = index of the
+// first one in the offsets array.  Everything is enqueued on `s`.
+int mjpeg_encode_device(Ctx* c, const uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_t fstride, int nframes, int frame0, size_t capacity, hipStream_t s) {
+    MjState* st = static_cast<MjState*>(c->mjpeg);
+    if (!st || nframes < 1 || nframes > st->frames_cap || (size_t)(frame0 + nframes + 1) > st->foff_cap || capacity > st->jpeg_cap) { c->err = "lvm_mjpeg: encode without begin"; return LVM_ERR_INVALID; }
+    MjGeom g;
+    g.w = st->w; g.h = st->h; g.mw = (st->w + 15) / 16; g.mh = (st->h + 15) / 16; g.stride = (long)stride; g.fstride = (long)fstride;
+    const dim3 blk(256);
+    LVM_LAUNCH(c, "mj_transform", k_mj_transform, dim3((g.mw + 3) / 4, g.mh, nframes), blk, s, d_bgr, g, (const MjTables*)st->d_tab, st->d_coef);
+    const long total_blocks = (long)nframes * g.mh * g.mw * 6;
+    const dim3 gcodes((unsigned)((total_blocks + 4 * MJ_NB - 1) / (4 * MJ_NB)));
+    LVM_LAUNCH(c, "mj_bits", k_mj_codes<false>, gcodes, blk, s, (const int16_t*)st->d_coef, g, total_blocks, (const MjTables*)st->d_tab, st->d_blk, st->d_raw);
+    LVM_LAUNCH(c, "mj_scan", k_mj_scan, dim3(g.mh, nframes), blk, s, g, st->d_blk, st->d_raw, st->d_ibits);
+    LVM_LAUNCH(c, "mj_pack", k_mj_codes<true>, gcodes, blk, s, (const int16_t*)st->d_coef, g, total_blocks, (const MjTables*)st->d_tab, st->d_blk, st->d_raw);
+    LVM_LAUNCH(c, "mj_size", k_mj_size, dim3(g.mh, nframes), blk, s, (const uint32_t*)st->d_raw, g, (const uint32_t*)st->d_ibits, st->d_isize);
+    LVM_LAUNCH(c, "mj_offsets", k_mj_offsets, dim3(1), blk, s, g, nframes, st->header_bytes, (const uint32_t*)st->d_isize, st->d_ioff, st->d_foff + frame0, st->d_run,
+               (unsigned long long)capacity);
+    LVM_LAUNCH(c, "mj_write", k_mj_write, dim3(g.mh, nframes), blk, s, (const uint32_t*)st->d_raw, g, (const uint32_t*)st->d_ibits, (const uint32_t*)st->d_isize,
+               (const unsigned long long*)st->d_ioff, (const uint8_t*)st->d_header, st->header_bytes, st->d_jpeg);
+    return LVM_OK;
+}
+
+// Completes the sequence: waits for `s`, copies the offsets and the bytes to the host.  offsets[0 .. total_frames] (bytes)
+int mjpeg_finish(Ctx* c, size_t total_frames, uint8_t* out_host, size_t* offsets, hipStream_t s) {
+    MjState* st = static_cast<MjState*>(c->mjpeg);
+    if (!st) { c->err = "lvm_mjpeg: finish without begin"; return LVM_ERR_INVALID; }
+    std::vector<unsigned long long> off(total_frames + 1), run(2);
+    LVM_HIP_TRY(c, hipMemcpyAsync(off.data(), st->d_foff, (total_frames + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    LVM_HIP_TRY(c, hipMemcpyAsync(run.data(), st->d_run, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    LVM_HIP_TRY(c, hipStreamSynchronize(s));
+    if (run[1]) { c->err = "lvm_mjpeg: output buffer too small (lvm_mjpeg_bound() bytes per frame always suffice)"; return LVM_ERR_INVALID; }
+    for (size_t i = 0; i <= total_frames; ++i) offsets[i] = (size_t)off[i];
+    if (off[total_frames]) LVM_HIP_TRY(c, hipMemcpyAsync(out_host, st->d_jpeg, (size_t)off[total_frames], hipMemcpyDeviceToHost, s));
+    LVM_HIP_TRY(c, hipStreamSynchronize(s));
+    return LVM_OK;
+}
+
+}  // namespace lvm

@@ -166,6 +166,18 @@ int wave_bpermute(int byte_addr, int src) {
     sync();
     return r;
 }
+// v_cmp into an SGPR pair: bit i = predicate of lane i of the caller's wave (same deposit / yield / read scheme)
+unsigned long long wave_ballot(int pred) {
+    static thread_local int slot[1024];
+    const unsigned n = st.bdim.x * st.bdim.y * st.bdim.z;
+    const unsigned t = st.tid.x + st.bdim.x * (st.tid.y + st.bdim.y * st.tid.z);
+    slot[t] = pred;
+    sync();
+    unsigned long long m = 0;
+    for (unsigned i = 0; i < 64 && (t & ~63u) + i < n; ++i) if (slot[(t & ~63u) + i]) m |= 1ull << i;
+    sync();
+    return m;
+}
 void launch(const std::function<void()>& fn, dim3 grid, dim3 block) {
     const unsigned n = block.x * block.y * block.z;
     if (fibers.size() < n) {

@@ -47,6 +47,7 @@ void sync();
 void launch(const std::function<void()>& body, dim3 grid, dim3 block);
 int dpp_wave_shift(int old, int src, int ctrl);
 int wave_bpermute(int byte_addr, int src);
+unsigned long long wave_ballot(int pred);
 }  // namespace hipemu
 #define threadIdx (hipemu::st.tid)
 #define blockIdx (hipemu::st.bid)
@@ -156,6 +157,8 @@ static inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) 
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+static inline void __threadfence() {}
 // graphs are not emulated: capture reports failure and the library falls back to plain launches
 typedef struct ihipGraph_t* hipGraph_t;
 typedef struct ihipGraphExec_t* hipGraphExec_t;
