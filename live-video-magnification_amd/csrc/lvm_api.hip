@@ -615,6 +615,7 @@ static int export_frames_impl(lvm_ctx* c, const lvm_preprocess_params* pp, const
         if (mj) {       // stage 3 stays on the device (down_stream, next to the magnifier of the following sub-batch): the canvases become JPEG
                         // frames behind the earlier ones; nothing to download until the end
             rc = lvm::mjpeg_encode_device(c, c->d_canvas + (size_t)f0 * can_bytes, (ptrdiff_t)can_row, (ptrdiff_t)can_bytes, nf, f0, mj->capacity, c->down_stream);
+            if (rc == LVM_OK && q >= 2) rc = lvm::mjpeg_drain(c, mj->out, (size_t)q - 1);       // the frames of sub-batch q - 2 come down meanwhile
             if (rc != LVM_OK) { drain(); return rc; }
             continue;
         }
@@ -664,6 +665,7 @@ int lvm_mjpeg_encode_device(lvm_ctx* c, const uint8_t* d_bgr, int w, int h, ptrd
     for (int f0 = 0; f0 < n_frames; f0 += per) {
         const int nf = f0 + per <= n_frames ? per : n_frames - f0;
         rc = lvm::mjpeg_encode_device(c, d_bgr + (size_t)f0 * frame_stride, stride, frame_stride, nf, f0, out_capacity, s);
+        if (rc == LVM_OK && f0 >= 2 * per) rc = lvm::mjpeg_drain(c, out, (size_t)(f0 / per) - 1);
         if (rc != LVM_OK) { (void)hipStreamSynchronize(s); return rc; }
     }
     lvm::mark_enqueued(c, s);

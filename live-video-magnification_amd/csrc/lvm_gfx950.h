@@ -184,4 +184,25 @@ __device__ __forceinline__ uint32_t lut_mul24(uint32_t a, uint32_t b) { uint32_t
 
 // the lanes of the wave whose predicate holds (v_cmp into an SGPR pair); every lane of the wave must execute it
 __device__ __forceinline__ unsigned long long lvm_ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+// Orders the LDS accesses of ONE wave: what its lanes wrote before is what its lanes read after (the LDS serves a wave's requests in
+// issue order; the wait + the compiler barrier keep loads from moving up).  No other wave is waited for.  Every lane of every wave of the
+// workgroup must execute it the same number of times (the emulation spells it as a yield).
+__device__ __forceinline__ void lvm_wave_lds_sync() {
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+// Inclusive prefix sum over the 64 lanes of a wave in six DPP steps: Hillis-Steele inside the rows of 16 (row_shr 1, 2, 4, 8), then lane 15
+// of rows 0 / 2 added to rows 1 / 3 (row_bcast:15, row mask 0xA) and lane 31 to rows 2 and 3 (row_bcast:31, row mask 0xC).  Lanes without a
+// source, and rows outside the mask, receive 0.
+__device__ __forceinline__ int lvm_wave_prefix_add(int v, int /*lane*/) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+// the value of lane 63, in every lane (v_readlane into an SGPR)
+__device__ __forceinline__ int lvm_wave_last(int v) { return __builtin_amdgcn_readlane(v, 63); }
 }  // namespace lvm

@@ -486,6 +486,7 @@ size_t mjpeg_bound(int w, int h);
 void mjpeg_release(Ctx* c);
 int mjpeg_begin(Ctx* c, int w, int h, int quality, int max_frames_per_call, size_t total_frames, size_t capacity, hipStream_t s);
 int mjpeg_encode_device(Ctx* c, const uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_t fstride, int nframes, int frame0, size_t capacity, hipStream_t s);
+int mjpeg_drain(Ctx* c, uint8_t* out_host, size_t upto_call);
 int mjpeg_finish(Ctx* c, size_t total_frames, uint8_t* out_host, size_t* offsets, hipStream_t s);
 int compose_device(Ctx* c, int split, const uint8_t* d_orig, int ow, int oh, int och, ptrdiff_t ostride, ptrdiff_t osstride,
                    const uint8_t* d_proc, int pw, int ph, int pch, ptrdiff_t pstride, ptrdiff_t psstride, uint8_t* d_canvas,

@@ -15,14 +15,14 @@
 // Inside a piece the 64 lanes of a wave ARE the 64 coefficients of a block in zigzag order: zero runs, code lengths and bit positions
 // are three wave scans, every lane ORs its own code word into the bit buffer.
 //
-//   k_mj_transform   BGR -> YCbCr 4:2:0 -> FDCT -> quantise -> zigzag          one wave per 16 x 16 MCU
-//   k_mj_codes<0>    Huffman code length of every coefficient -> bits per block   one wave per block
+//   k_mj_transform   BGR -> YCbCr 4:2:0 -> FDCT -> quantise -> zigzag, bits per block   one wave per 16 x 16 MCU
 //   k_mj_scan        bit position of every block, bit buffer zeroed               one workgroup per restart interval
-//   k_mj_codes<1>    the code words again, ORed into the bit buffer               one wave per block
+//   k_mj_pack        the code words, ORed into the bit buffer                     one wave per block
 //   k_mj_size        stuffed size of every interval (FF -> FF 00)                one workgroup per restart interval
 //   k_mj_offsets     byte offsets of the intervals and frames in the output      one workgroup
 //   k_mj_write       header, stuffed intervals, RSTn / EOI markers               one workgroup per restart interval
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -75,6 +75,7 @@ struct MjTables {
     uint32_t qr[2][64];       // ceil(2^24 / Q) in ZIGZAG order: n / Q == (n * qr) >> 24 for every n * Q < 2^24
     uint16_t q[2][64];        // Q in zigzag order
     uint8_t zz[64];
+    uint8_t aclen[2][256];    // the lengths of ac[][] alone (k_mj_transform counts bits, it does not build code words)
 };
 constexpr int MJ_MAX_MW = 512;                  // MCUs per row the entropy kernel's LDS holds (frames up to 8192 pixels wide)
 constexpr int MJ_BLOCK_WORDS = 54;              // worst case of one block: 20 + 63 * 26 bits = 1658 -> 52 words, + 2 for the straddling word and the pad
@@ -96,6 +97,13 @@ struct MjState {
     unsigned long long *d_ioff = nullptr, *d_foff = nullptr, *d_run = nullptr;     // d_run[0] running byte count, d_run[1] overflow flag
     uint8_t* d_jpeg = nullptr; size_t jpeg_cap = 0;
     size_t foff_cap = 0;
+    // incremental download: a page-locked mirror of d_foff, one event per encode call, the copy queue, what has been queued so far
+    unsigned long long* h_foff = nullptr;
+    std::vector<hipEvent_t> ev;
+    struct Call { int frame0, nframes; };
+    std::vector<Call> calls;
+    size_t drained = 0, copied = 0;
+    hipStream_t dl = nullptr;
 };
 
 void build_huff(const uint8_t* bits, const uint8_t* vals, int nvals, uint32_t* table, int table_len) {      // T.81 Annex C
@@ -151,14 +159,19 @@ void build_header(std::vector<uint8_t>& v, int w, int h, const int* ql, const in
 
 // One wave per MCU (four per workgroup).  Lane = one 2 x 2 pixel quad = one chroma sample: the 64 lanes of a wave are the 8 x 8 chroma
 // block and the four 8 x 8 luminance blocks of the MCU.  Pixels outside the frame repeat the last row / column.
-__global__ __launch_bounds__(256) void k_mj_transform(const uint8_t* __restrict__ src, MjGeom g, const MjTables* __restrict__ tb, int16_t* __restrict__ coef) {
+__global__ __launch_bounds__(256) void k_mj_transform(const uint8_t* __restrict__ src, MjGeom g, const MjTables* __restrict__ tb, int16_t* __restrict__ coef,
+                                                      uint32_t* __restrict__ acbits) {
     __shared__ int s_a[4][6][64], s_b[4][6][64];
+    __shared__ uint8_t s_len[2][256];
+    __shared__ int s_bits[4][8];
     __shared__ uint32_t s_qr[2][64];
     __shared__ uint16_t s_q[2][64];
     __shared__ uint8_t s_zz[64];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     if (tid < 128) { s_qr[tid >> 6][tid & 63] = tb->qr[tid >> 6][tid & 63]; s_q[tid >> 6][tid & 63] = tb->q[tid >> 6][tid & 63]; }
     if (tid < 64) s_zz[tid] = tb->zz[tid];
+    if (tid < 128) reinterpret_cast<uint32_t*>(&s_len[0][0])[tid] = reinterpret_cast<const uint32_t*>(&tb->aclen[0][0])[tid];
+    if (lane < 8) s_bits[wave][lane] = 0;
     const int mx = blockIdx.x * 4 + wave, my = blockIdx.y, f = blockIdx.z;
     const bool act = mx < g.mw;
     if (act) {
@@ -212,43 +225,43 @@ __global__ __launch_bounds__(256) void k_mj_transform(const uint8_t* __restrict_
         }
     }
     __syncthreads();
-    if (act) {                            // quantise, zigzag: lane = zigzag index
-        int16_t* out = coef + ((size_t)(f * g.mh + my) * g.mw + mx) * 384;
+    // quantise, zigzag: lane = zigzag index.  The bits the AC coefficients of each block will take (T.81 F.1.2.2: run / size symbols, ZRL,
+    // EOB) are counted on the way: one ballot of the non-zero lanes gives every lane its zero run.  (Every wave runs this -- the ballot
+    // needs all lanes -- and only the existing MCUs store.)
+    {
+        int16_t* out = coef + ((size_t)(f * g.mh + my) * g.mw + (act ? mx : 0)) * 384;
         const int nat = s_zz[lane];
 #pragma unroll
         for (int blk = 0; blk < 6; ++blk) {
             const int t = blk < 4 ? 0 : 1;
-            const int s = s_a[wave][blk][nat];
+            const int s = act ? s_a[wave][blk][nat] : 0;
             const uint32_t n = (uint32_t)(s < 0 ? -s : s) + (uint32_t)(s_q[t][lane] >> 1);
-            const int a = (int)(((unsigned long long)n * s_qr[t][lane]) >> 24);         // = n / Q
-            out[blk * 64 + lane] = (int16_t)(s < 0 ? -a : a);
+            const int a = act ? (int)(((unsigned long long)n * s_qr[t][lane]) >> 24) : 0;         // = n / Q
+            if (act) out[blk * 64 + lane] = (int16_t)(s < 0 ? -a : a);
+            const unsigned long long nz = lvm_ballot64(lane >= 1 && a != 0);
+            const unsigned long long below = nz & ((1ull << lane) - 1ull);
+            const int prev = below ? 63 - __builtin_clzll(below) : 0;
+            const int last = nz ? 63 - __builtin_clzll(nz) : 0;
+            int bits = 0;
+            if (lane >= 1 && a != 0) {
+                const int run = lane - prev - 1, cat = 32 - __builtin_clz((unsigned)a);
+                bits = (run >> 4) * s_len[t][0xF0] + s_len[t][((run & 15) << 4) | cat] + cat;
+            } else if (lane == last + 1) {
+                bits = s_len[t][0];
+            }
+            if (bits) atomicAdd(&s_bits[wave][blk], bits);
         }
     }
-}
-
-// inclusive prefix sum over the 64 lanes of a wave (ds_bpermute: lane i reads lane i - d)
-__device__ __forceinline__ int wave_scan_add(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __builtin_amdgcn_ds_bpermute((lane - d) * 4, v);
-        if (lane >= d) v += t;
-    }
-    return v;
+    lvm_wave_lds_sync();
+    if (act && lane < 6) acbits[((size_t)(f * g.mh + my) * g.mw + mx) * 6 + lane] = (uint32_t)s_bits[wave][lane];
 }
 
 struct LaneCode { uint32_t code; int len, nzrl, bits; };
 // The code word of zigzag position `lane` of block b of a restart interval (T.81 F.1.2): lane 0 the DC difference, a non-zero lane its
 // (run, size) symbol + amplitude bits behind run / 16 ZRL symbols, the lane behind the last non-zero coefficient the end-of-block symbol.
 // The zero runs come from ONE ballot of the non-zero lanes: the previous non-zero position is the highest set bit below the lane.
-// Every lane of the wave calls it; `act` = the block exists.
-__device__ __forceinline__ LaneCode lane_code(const int16_t* __restrict__ cf, int b, bool act, int lane, const uint32_t (*s_ac)[256], const uint32_t (*s_dc)[12]) {
-    const int m = b / 6, blk = b - m * 6, t = blk < 4 ? 0 : 1;
-    int v = act ? cf[(size_t)b * 64 + lane] : 0;
-    if (lane == 0 && act) {
-        const bool has_pred = (blk >= 1 && blk <= 3) || m > 0;              // the predictor restarts at 0 with the interval
-        const int pb = blk == 0 ? b - 3 : (blk < 4 ? b - 1 : b - 6);       // previous block of the same component
-        v -= has_pred ? cf[(size_t)pb * 64] : 0;
-    }
+// Every lane of the wave calls it; `act` = the block exists; v = the lane's coefficient, the DC DIFFERENCE in lane 0 (mj_fetch).
+__device__ __forceinline__ LaneCode lane_code(int v, int t, bool act, int lane, const uint32_t (*s_ac)[256], const uint32_t (*s_dc)[12]) {
     const unsigned long long nz = lvm_ballot64(lane >= 1 && v != 0);
     const unsigned long long below = nz & ((1ull << lane) - 1ull);
     const int prev = below ? 63 - __builtin_clzll(below) : 0;              // position of the previous non-zero AC coefficient (0: none)
@@ -277,9 +290,9 @@ __device__ __forceinline__ LaneCode lane_code(const int16_t* __restrict__ cf, in
 // `len` bits of `code` at bit position `off` of a big-endian bit buffer of zeroed 32-bit words
 __device__ __forceinline__ void put_bits(uint32_t* __restrict__ out, uint32_t off, uint32_t code, int len) {
     const uint32_t w = off >> 5;
-    const int room = 32 - (int)(off & 31u);
-    if (len <= room) atomicOr(out + w, code << (room - len));
-    else { atomicOr(out + w, code >> (len - room)); atomicOr(out + w + 1, code << (32 - (len - room))); }
+    const unsigned long long v = (unsigned long long)code << (64 - (int)(off & 31u) - len);      // len <= 27: never shifted out
+    atomicOr(out + w, (uint32_t)(v >> 32));
+    if ((uint32_t)v) atomicOr(out + w + 1, (uint32_t)v);
 }
 
 // exclusive scan of s[0 .. n) in place by the 256 threads of a workgroup (part: 256 words of LDS); returns the total
@@ -307,64 +320,96 @@ __device__ __forceinline__ void load_huff(uint32_t (*s_ac)[256], uint32_t (*s_dc
     if (tid < 24) s_dc[tid / 12][tid % 12] = tb->dc[tid / 12][tid % 12];
 }
 
-// PACK = false: the number of bits of every block (a wave per block, MJ_NB blocks one after the other; the blocks of all intervals of the
-// launch side by side);
-// PACK = true: after k_mj_scan turned the counts into bit positions, the same code words again.  A wave assembles its block in LDS at the
-// bit phase the block has in the interval's stream (every lane ORs its own code word in: LDS atomics), so that LDS word j IS word
-// (position / 32) + j of the stream: the inner words are plain stores, only the first and the last one -- shared with the neighbouring
-// blocks -- are atomic ORs into the zeroed buffer.
-constexpr int MJ_NB = 16;
-template <bool PACK>
-__global__ __launch_bounds__(256) void k_mj_codes(const int16_t* __restrict__ coef, MjGeom g, long total_blocks, const MjTables* __restrict__ tb,
-                                                  uint32_t* __restrict__ blk, uint32_t* __restrict__ raw) {
+// After k_mj_scan turned the bit counts into bit positions: the code words.  A wave owns a run of MJ_NB consecutive blocks of one interval and
+// assembles it in LDS at the bit phase the run has in the interval's stream (every lane ORs its own code word in: LDS atomics), so that LDS
+// word j IS word (position / 32) + j of the stream.  (One block per wave with two global atomics each measured 283 us per 8 canvases, a
+// run of 8 with two atomics per run 150 us; what remains is the loads and the code construction.)
+constexpr int MJ_NB = 8;
+struct MjFetch { int v; uint32_t base; uint32_t interval; int t; bool act; };
+// the loads of block b of an interval: the lane's coefficient (lane 0: minus the DC of the previous block of the same component -- the
+// predictor restarts at 0 with the interval), the block's bit position
+__device__ __forceinline__ MjFetch mj_fetch(const int16_t* __restrict__ coef, const uint32_t* __restrict__ blk, uint32_t interval, int b, bool act, int nblk, int mw, int lane) {
+    MjFetch f;
+    f.act = act;
+    f.interval = interval;
+    const int m = b / 6, k = b - m * 6;
+    f.t = k < 4 ? 0 : 1;
+    const int16_t* cf = coef + (size_t)interval * mw * 384;
+    f.v = act ? cf[(size_t)b * 64 + lane] : 0;
+    if (lane == 0 && act && ((k >= 1 && k <= 3) || m > 0)) f.v -= cf[(size_t)(k == 0 ? b - 3 : (k < 4 ? b - 1 : b - 6)) * 64];
+    f.base = act ? blk[(size_t)interval * nblk + b] : 0u;
+    return f;
+}
+constexpr int MJ_RUN_WORDS = MJ_NB * (MJ_BLOCK_WORDS - 2) + 2;       // LDS words of a run of MJ_NB blocks at any bit phase
+__global__ __launch_bounds__(256) void k_mj_pack(const int16_t* __restrict__ coef, MjGeom g, uint32_t nintervals, const MjTables* __restrict__ tb,
+                                                  const uint32_t* __restrict__ blk, uint32_t* __restrict__ raw) {
     __shared__ uint32_t s_ac[2][256], s_dc[2][12];
-    __shared__ uint32_t s_stage[PACK ? 4 : 1][64];
+    __shared__ uint32_t s_stage[4][MJ_RUN_WORDS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     load_huff(s_ac, s_dc, tb, tid);
-    __syncthreads();
     const int nblk = g.mw * 6;
+    // A wave owns a run of MJ_NB consecutive blocks of ONE interval (the last run of an interval is shorter) and assembles it in LDS at the
+    // bit phase the run has in the interval's stream.  All loads of the run are issued before the first block is coded.
+    const uint32_t rpi = (uint32_t)(nblk + MJ_NB - 1) / MJ_NB, run = (uint32_t)blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t iv = run / rpi;
+    const int b0 = (int)(run - iv * rpi) * MJ_NB;
+    const bool wact = iv < nintervals;
+    MjFetch fs[MJ_NB];
+#pragma unroll
+    for (int it = 0; it < MJ_NB; ++it) fs[it] = mj_fetch(coef, blk, wact ? iv : 0u, wact && b0 + it < nblk ? b0 + it : 0, wact && b0 + it < nblk, nblk, g.mw, lane);
+    for (int j = lane; j < MJ_RUN_WORDS; j += 64) s_stage[wave][j] = 0u;
+    __syncthreads();
+    const uint32_t word0 = fs[0].base >> 5;                 // (block b0 of an existing run always exists)
+    uint32_t end = fs[0].base;
+#pragma unroll
     for (int it = 0; it < MJ_NB; ++it) {
-        const long gb = ((long)blockIdx.x * MJ_NB + it) * 4 + wave;
-        const bool act = gb < total_blocks;
-        const long interval = act ? gb / nblk : 0;
-        const int b = act ? (int)(gb - interval * nblk) : 0;
-        const int16_t* cf = coef + (size_t)interval * g.mw * 384;
-        const LaneCode lc = lane_code(cf, b, act, lane, s_ac, s_dc);
-        const int incl = wave_scan_add(lc.bits, lane);
-        if (!PACK) {
-            if (act && lane == 63) blk[gb] = (uint32_t)incl;
-        } else {
-            const uint32_t base = act ? blk[gb] : 0u, phase = base & 31u;
-            const int total = __builtin_amdgcn_ds_bpermute(63 * 4, incl);
-            s_stage[wave][lane] = 0u;
-            __syncthreads();
-            if (act && lc.bits) {
-                uint32_t off = phase + (uint32_t)(incl - lc.bits);
-                const uint32_t zrl = s_ac[b - (b / 6) * 6 < 4 ? 0 : 1][0xF0];
-                for (int k = 0; k < lc.nzrl; ++k) { put_bits(s_stage[wave], off, zrl >> 8, (int)(zrl & 255u)); off += zrl & 255u; }
-                put_bits(s_stage[wave], off, lc.code, lc.len);
-            }
-            __syncthreads();
-            const int nwords = (int)((phase + (uint32_t)total + 31u) >> 5);
-            if (act && lane < nwords) {
-                uint32_t* out = raw + (size_t)interval * g.mw * 6 * MJ_BLOCK_WORDS + (base >> 5);
-                const uint32_t v = s_stage[wave][lane];
-                if (lane == 0 || lane == nwords - 1) { if (v) atomicOr(out + lane, v); }
-                else out[lane] = v;
-            }
-            __syncthreads();
+        const MjFetch f = fs[it];
+        const LaneCode lc = lane_code(f.v, f.t, f.act, lane, s_ac, s_dc);
+        const int incl = lvm_wave_prefix_add(lc.bits, lane);
+        const int nbits = lvm_wave_last(incl);
+        if (f.act) end = f.base + (uint32_t)nbits;
+        if (f.act && lc.bits) {
+            uint32_t off = f.base - (word0 << 5) + (uint32_t)(incl - lc.bits);
+            const uint32_t zrl = s_ac[f.t][0xF0];
+            for (int k = 0; k < lc.nzrl; ++k) { put_bits(s_stage[wave], off, zrl >> 8, (int)(zrl & 255u)); off += zrl & 255u; }
+            put_bits(s_stage[wave], off, lc.code, lc.len);
+        }
+    }
+    lvm_wave_lds_sync();
+    // LDS word j IS word word0 + j of the stream: the inner words are plain stores, only the first and the last one -- shared with the
+    // neighbouring runs -- are atomic ORs into the zeroed buffer
+    const int nwords = (int)(((end + 31u) >> 5) - word0);
+    if (wact) {
+        uint32_t* out = raw + (size_t)iv * g.mw * 6 * MJ_BLOCK_WORDS + word0;
+        for (int j = lane; j < nwords; j += 64) {
+            const uint32_t v = s_stage[wave][j];
+            if (j == 0 || j == nwords - 1) { if (v) atomicOr(out + j, v); }
+            else out[j] = v;
         }
     }
 }
 
-// One workgroup per restart interval: bits of its blocks -> their bit positions, the interval's length, its bit buffer zeroed
-__global__ __launch_bounds__(256) void k_mj_scan(MjGeom g, uint32_t* __restrict__ blk, uint32_t* __restrict__ raw, uint32_t* __restrict__ ibits) {
+// One workgroup per restart interval: AC bits of its blocks (k_mj_transform) + the bits of their DC differences (F.1.2.1) -> the bit
+// position of every block, the interval's length; its bit buffer zeroed
+__global__ __launch_bounds__(256) void k_mj_scan(const int16_t* __restrict__ coef, MjGeom g, const MjTables* __restrict__ tb, uint32_t* __restrict__ blk,
+                                                 uint32_t* __restrict__ raw, uint32_t* __restrict__ ibits) {
     __shared__ uint32_t s_off[MJ_MAX_MW * 6];
     __shared__ uint32_t s_part[256];
+    __shared__ uint32_t s_dc[2][12];
     const int tid = threadIdx.x, nblk = g.mw * 6;
     const size_t interval = (size_t)blockIdx.y * g.mh + blockIdx.x;
+    if (tid < 24) s_dc[tid / 12][tid % 12] = tb->dc[tid / 12][tid % 12];
+    __syncthreads();
     uint32_t* mine = blk + interval * nblk;
-    for (int i = tid; i < nblk; i += 256) s_off[i] = mine[i];
+    const int16_t* cf = coef + interval * (size_t)g.mw * 384;
+    for (int b = tid; b < nblk; b += 256) {
+        const int m = b / 6, k = b - m * 6;
+        const bool has_pred = (k >= 1 && k <= 3) || m > 0;
+        const int pb = k == 0 ? b - 3 : (k < 4 ? b - 1 : b - 6);
+        const int diff = cf[(size_t)b * 64] - (has_pred ? cf[(size_t)pb * 64] : 0);
+        const int a = diff < 0 ? -diff : diff, cat = a ? 32 - __builtin_clz((unsigned)a) : 0;
+        s_off[b] = mine[b] + (s_dc[k < 4 ? 0 : 1][cat] & 255u) + (uint32_t)cat;
+    }
     __syncthreads();
     const uint32_t total_bits = wg_exclusive_scan(s_off, nblk, s_part, tid);
     for (int i = tid; i < nblk; i += 256) mine[i] = s_off[i];
@@ -374,11 +419,18 @@ __global__ __launch_bounds__(256) void k_mj_scan(MjGeom g, uint32_t* __restrict_
     for (uint32_t i = tid; i < nwords; i += 256) out[i] = 0u;
 }
 
-// byte i of an interval's bit buffer; the last byte is filled up with 1-bits (T.81 F.1.2.3)
-__device__ __forceinline__ uint32_t raw_byte(const uint32_t* __restrict__ raw, uint32_t i, uint32_t nbytes, uint32_t bits) {
-    uint32_t b = (raw[i >> 2] >> (24u - 8u * (i & 3u))) & 255u;
-    if (i + 1 == nbytes && (bits & 7u)) b |= (1u << (8u - (bits & 7u))) - 1u;
-    return b;
+// word i (four stream bytes, first byte in the top bits) of an interval's bit buffer; the last byte is filled up with 1-bits (T.81 F.1.2.3)
+__device__ __forceinline__ uint32_t raw_word(const uint32_t* __restrict__ raw, uint32_t i, uint32_t nbytes, uint32_t bits) {
+    uint32_t w = raw[i];
+    if ((bits & 7u) && i == (nbytes - 1u) >> 2) w |= ((1u << (8u - (bits & 7u))) - 1u) << (24u - 8u * ((nbytes - 1u) & 3u));
+    return w;
+}
+// number of FF bytes among the first n (1..4) bytes of a word
+__device__ __forceinline__ uint32_t ff_bytes(uint32_t w, uint32_t n) {
+    uint32_t c = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 4; ++j) c += (j < n && ((w >> (24u - 8u * j)) & 255u) == 255u) ? 1u : 0u;
+    return c;
 }
 
 __global__ __launch_bounds__(256) void k_mj_size(const uint32_t* __restrict__ raw, MjGeom g, const uint32_t* __restrict__ ibits, uint32_t* __restrict__ isize) {
@@ -386,11 +438,11 @@ __global__ __launch_bounds__(256) void k_mj_size(const uint32_t* __restrict__ ra
     const int tid = threadIdx.x;
     const size_t interval = (size_t)blockIdx.y * g.mh + blockIdx.x;
     const uint32_t* in = raw + interval * (size_t)g.mw * 6 * MJ_BLOCK_WORDS;
-    const uint32_t bits = ibits[interval], nbytes = (bits + 7u) >> 3;
+    const uint32_t bits = ibits[interval], nbytes = (bits + 7u) >> 3, nwords = (nbytes + 3u) >> 2;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
     int cnt = 0;
-    for (uint32_t i = tid; i < nbytes; i += 256) cnt += raw_byte(in, i, nbytes, bits) == 255u;
+    for (uint32_t i = tid; i < nwords; i += 256) cnt += (int)ff_bytes(raw_word(in, i, nbytes, bits), nbytes - 4u * i < 4u ? nbytes - 4u * i : 4u);
     if (cnt) atomicAdd(&s_cnt, cnt);
     __syncthreads();
     if (tid == 0) isize[interval] = nbytes + (uint32_t)s_cnt;
@@ -436,10 +488,10 @@ __global__ __launch_bounds__(256) void k_mj_write(const uint32_t* __restrict__ r
     const uint32_t* in = raw + interval * (size_t)g.mw * 6 * MJ_BLOCK_WORDS;
     uint8_t* dst = jpeg + o;
     if (my == 0) for (int i = tid; i < header_bytes; i += 256) (dst - header_bytes)[i] = header[i];
-    const uint32_t bits = ibits[interval], nbytes = (bits + 7u) >> 3;
-    const uint32_t per = (nbytes + 255u) / 256u, lo = tid * per, hi = lo + per < nbytes ? lo + per : nbytes;
+    const uint32_t bits = ibits[interval], nbytes = (bits + 7u) >> 3, nwords = (nbytes + 3u) >> 2;
+    const uint32_t per = (nwords + 255u) / 256u, lo = tid * per, hi = lo + per < nwords ? lo + per : nwords;     // a run of words per thread
     uint32_t ff = 0;
-    for (uint32_t i = lo; i < hi; ++i) ff += raw_byte(in, i, nbytes, bits) == 255u;
+    for (uint32_t i = lo; i < hi; ++i) ff += ff_bytes(raw_word(in, i, nbytes, bits), nbytes - 4u * i < 4u ? nbytes - 4u * i : 4u);
     s_part[tid] = ff;
     __syncthreads();
     for (int d = 1; d < 256; d <<= 1) {
@@ -448,11 +500,14 @@ __global__ __launch_bounds__(256) void k_mj_write(const uint32_t* __restrict__ r
         s_part[tid] += t;
         __syncthreads();
     }
-    uint32_t pos = lo + (tid ? s_part[tid - 1] : 0u);
+    uint32_t pos = 4u * lo + (tid ? s_part[tid - 1] : 0u);
     for (uint32_t i = lo; i < hi; ++i) {
-        const uint32_t b = raw_byte(in, i, nbytes, bits);
-        dst[pos++] = (uint8_t)b;
-        if (b == 255u) dst[pos++] = 0;
+        const uint32_t w = raw_word(in, i, nbytes, bits), n = nbytes - 4u * i < 4u ? nbytes - 4u * i : 4u;
+        for (uint32_t j = 0; j < n; ++j) {
+            const uint32_t b = (w >> (24u - 8u * j)) & 255u;
+            dst[pos++] = (uint8_t)b;
+            if (b == 255u) dst[pos++] = 0;
+        }
     }
     if (tid == 0) {
         const uint32_t n = isize[interval];
@@ -481,6 +536,9 @@ void mjpeg_release(Ctx* c) {
     if (!st) return;
     void* ptrs[] = {st->d_tab, st->d_header, st->d_coef, st->d_raw, st->d_blk, st->d_ibits, st->d_isize, st->d_ioff, st->d_foff, st->d_run, st->d_jpeg};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    if (st->h_foff) (void)hipHostFree(st->h_foff);
+    for (hipEvent_t e : st->ev) (void)hipEventDestroy(e);
+    if (st->dl) (void)hipStreamDestroy(st->dl);
     delete st;
     c->mjpeg = nullptr;
 }
@@ -513,6 +571,7 @@ int mjpeg_begin(Ctx* c, int w, int h, int quality, int max_frames_per_call, size
             t.qr[0][i] = (uint32_t)(((1u << 24) + a - 1) / a); t.qr[1][i] = (uint32_t)(((1u << 24) + b - 1) / b);
             t.zz[i] = kZigzag[i];
         }
+        for (int i = 0; i < 512; ++i) t.aclen[i >> 8][i & 255] = (uint8_t)(t.ac[i >> 8][i & 255] & 255u);
         build_header(st->header, w, h, ql, qc, mw);
         if ((int)st->header.size() > MJ_MAX_HEADER) { c->err = "lvm_mjpeg: header too long"; return LVM_ERR_INVALID; }
         LVM_HIP_TRY(c, hipMemcpy(st->d_tab, &t, sizeof t, hipMemcpyHostToDevice));
@@ -537,6 +596,9 @@ int mjpeg_begin(Ctx* c, int w, int h, int quality, int max_frames_per_call, size
         LVM_HIP_TRY(c, hipStreamSynchronize(s));
         st->foff_cap = 0;
         if ((rc = mj_reserve(c, st->d_foff, total_frames + 1)) != LVM_OK) return rc;
+        if (st->h_foff) (void)hipHostFree(st->h_foff);
+        st->h_foff = nullptr;
+        LVM_HIP_TRY(c, hipHostMalloc((void**)&st->h_foff, (total_frames + 1) * sizeof(unsigned long long), 0));
         st->foff_cap = total_frames + 1;
     }
     if (st->jpeg_cap < capacity) {
@@ -546,6 +608,8 @@ int mjpeg_begin(Ctx* c, int w, int h, int quality, int max_frames_per_call, size
         st->jpeg_cap = capacity;
     }
     LVM_HIP_TRY(c, hipMemsetAsync(st->d_run, 0, 2 * sizeof(unsigned long long), s));
+    if (!st->dl) LVM_HIP_TRY(c, hipStreamCreateWithFlags(&st->dl, hipStreamNonBlocking));
+    st->calls.clear(); st->drained = 0; st->copied = 0;
     return LVM_OK;
 }
 
@@ -557,32 +621,53 @@ int mjpeg_encode_device(Ctx* c, const uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_
     MjGeom g;
     g.w = st->w; g.h = st->h; g.mw = (st->w + 15) / 16; g.mh = (st->h + 15) / 16; g.stride = (long)stride; g.fstride = (long)fstride;
     const dim3 blk(256);
-    LVM_LAUNCH(c, "mj_transform", k_mj_transform, dim3((g.mw + 3) / 4, g.mh, nframes), blk, s, d_bgr, g, (const MjTables*)st->d_tab, st->d_coef);
-    const long total_blocks = (long)nframes * g.mh * g.mw * 6;
-    const dim3 gcodes((unsigned)((total_blocks + 4 * MJ_NB - 1) / (4 * MJ_NB)));
-    LVM_LAUNCH(c, "mj_bits", k_mj_codes<false>, gcodes, blk, s, (const int16_t*)st->d_coef, g, total_blocks, (const MjTables*)st->d_tab, st->d_blk, st->d_raw);
-    LVM_LAUNCH(c, "mj_scan", k_mj_scan, dim3(g.mh, nframes), blk, s, g, st->d_blk, st->d_raw, st->d_ibits);
-    LVM_LAUNCH(c, "mj_pack", k_mj_codes<true>, gcodes, blk, s, (const int16_t*)st->d_coef, g, total_blocks, (const MjTables*)st->d_tab, st->d_blk, st->d_raw);
+    LVM_LAUNCH(c, "mj_transform", k_mj_transform, dim3((g.mw + 3) / 4, g.mh, nframes), blk, s, d_bgr, g, (const MjTables*)st->d_tab, st->d_coef, st->d_blk);
+    const uint32_t nint = (uint32_t)nframes * (uint32_t)g.mh, rpi = (uint32_t)(g.mw * 6 + MJ_NB - 1) / MJ_NB;
+    LVM_LAUNCH(c, "mj_scan", k_mj_scan, dim3(g.mh, nframes), blk, s, (const int16_t*)st->d_coef, g, (const MjTables*)st->d_tab, st->d_blk, st->d_raw, st->d_ibits);
+    LVM_LAUNCH(c, "mj_pack", k_mj_pack, dim3((nint * rpi + 3) / 4), blk, s, (const int16_t*)st->d_coef, g, nint, (const MjTables*)st->d_tab, (const uint32_t*)st->d_blk, st->d_raw);
     LVM_LAUNCH(c, "mj_size", k_mj_size, dim3(g.mh, nframes), blk, s, (const uint32_t*)st->d_raw, g, (const uint32_t*)st->d_ibits, st->d_isize);
     LVM_LAUNCH(c, "mj_offsets", k_mj_offsets, dim3(1), blk, s, g, nframes, st->header_bytes, (const uint32_t*)st->d_isize, st->d_ioff, st->d_foff + frame0, st->d_run,
                (unsigned long long)capacity);
     LVM_LAUNCH(c, "mj_write", k_mj_write, dim3(g.mh, nframes), blk, s, (const uint32_t*)st->d_raw, g, (const uint32_t*)st->d_ibits, (const uint32_t*)st->d_isize,
                (const unsigned long long*)st->d_ioff, (const uint8_t*)st->d_header, st->header_bytes, st->d_jpeg);
+    // where these frames ended up: to the page-locked mirror, then an event -- mjpeg_drain downloads finished frames while later calls run
+    LVM_HIP_TRY(c, hipMemcpyAsync(st->h_foff + frame0, st->d_foff + frame0, (size_t)(nframes + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    const size_t k = st->calls.size();
+    while (st->ev.size() <= k) { hipEvent_t e = nullptr; LVM_HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); st->ev.push_back(e); }
+    LVM_HIP_TRY(c, hipEventRecord(st->ev[k], s));
+    st->calls.push_back({frame0, nframes});
     return LVM_OK;
 }
 
-// Completes the sequence: waits for `s`, copies the offsets and the bytes to the host.  offsets[0 .. total_frames] (bytes)
+// Queues the download of the frames of the first `upto` encode calls since mjpeg_begin (those not queued yet): waits for each call's event
+// on the HOST (later calls keep the device busy meanwhile), then copies its bytes on the copy queue.
+int mjpeg_drain(Ctx* c, uint8_t* out_host, size_t upto) {
+    MjState* st = static_cast<MjState*>(c->mjpeg);
+    if (!st) return LVM_OK;
+    for (; st->drained < upto && st->drained < st->calls.size(); ++st->drained) {
+        const MjState::Call& k = st->calls[st->drained];
+        LVM_HIP_TRY(c, hipEventSynchronize(st->ev[st->drained]));
+        const size_t end = (size_t)st->h_foff[k.frame0 + k.nframes];
+        if (end > st->copied) {
+            LVM_HIP_TRY(c, hipMemcpyAsync(out_host + st->copied, st->d_jpeg + st->copied, end - st->copied, hipMemcpyDeviceToHost, st->dl));
+            st->copied = end;
+        }
+    }
+    return LVM_OK;
+}
+
+// Completes the sequence: the remaining downloads, the offsets.  offsets[0 .. total_frames] (bytes)
 int mjpeg_finish(Ctx* c, size_t total_frames, uint8_t* out_host, size_t* offsets, hipStream_t s) {
     MjState* st = static_cast<MjState*>(c->mjpeg);
     if (!st) { c->err = "lvm_mjpeg: finish without begin"; return LVM_ERR_INVALID; }
-    std::vector<unsigned long long> off(total_frames + 1), run(2);
-    LVM_HIP_TRY(c, hipMemcpyAsync(off.data(), st->d_foff, (total_frames + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    LVM_HIP_TRY(c, hipMemcpyAsync(run.data(), st->d_run, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    unsigned long long run[2] = {0, 0};
+    int rc = mjpeg_drain(c, out_host, st->calls.size());
+    if (rc != LVM_OK) { (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(st->dl); return rc; }
+    LVM_HIP_TRY(c, hipMemcpyAsync(run, st->d_run, sizeof run, hipMemcpyDeviceToHost, s));
     LVM_HIP_TRY(c, hipStreamSynchronize(s));
+    LVM_HIP_TRY(c, hipStreamSynchronize(st->dl));
     if (run[1]) { c->err = "lvm_mjpeg: output buffer too small (lvm_mjpeg_bound() bytes per frame always suffice)"; return LVM_ERR_INVALID; }
-    for (size_t i = 0; i <= total_frames; ++i) offsets[i] = (size_t)off[i];
-    if (off[total_frames]) LVM_HIP_TRY(c, hipMemcpyAsync(out_host, st->d_jpeg, (size_t)off[total_frames], hipMemcpyDeviceToHost, s));
-    LVM_HIP_TRY(c, hipStreamSynchronize(s));
+    for (size_t i = 0; i <= total_frames; ++i) offsets[i] = (size_t)st->h_foff[i];
     return LVM_OK;
 }
 

@@ -99,4 +99,13 @@ __device__ __forceinline__ uint32_t lut_mul24(uint32_t a, uint32_t b) { return (
 
 // a real cross-lane ballot (the header's __builtin_amdgcn_ballot_w64 stand-in is for wave-uniform predicates only)
 __device__ __forceinline__ unsigned long long lvm_ballot64(bool pred) { return hipemu::wave_ballot(pred ? 1 : 0); }
+__device__ __forceinline__ void lvm_wave_lds_sync() { hipemu::sync(); }
+__device__ __forceinline__ int lvm_wave_prefix_add(int v, int lane) {      // the same sums by ds_bpermute: lane i reads lane i - d
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __builtin_amdgcn_ds_bpermute((lane - d) * 4, v);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ int lvm_wave_last(int v) { return __builtin_amdgcn_ds_bpermute(63 * 4, v); }
 }  // namespace lvm
