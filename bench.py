@@ -798,12 +798,36 @@ def export_host_record(lvm, np, local_rank, cp_ref, host, Te=32, Kx=6):
             ex._check(lib.lvm_export_frames(ex.h, C.byref(cpre), cp_ref, 1, Te, pi, w, h, ch, w * ch, pc, cw.value * 3, prod))
         dx = time.perf_counter() - t0
         ex.close()
+        # the same loop body with the canvases JPEG-encoded on the device (ExportFormat::AviMjpg, Exporter.cpp:107-117 + :259): only the
+        # compressed frames come down (into the canvas slots), cv::VideoWriter's software codec is out of the loop
+        mj = None
+        try:
+            q = 85
+            ej = lvm.Context(local_rank, 1)
+            ej.set_max_frames(Te)
+            offs = (C.c_size_t * (Te + 1))()
+            for _ in range(2):
+                ej._check(lib.lvm_export_frames_mjpeg(ej.h, C.byref(cpre), cp_ref, 1, Te, pi, w, h, ch, w * ch, q, pout, cb * Te, offs, prod))
+            t0 = time.perf_counter()
+            for _ in range(Kx):
+                ej._check(lib.lvm_export_frames_mjpeg(ej.h, C.byref(cpre), cp_ref, 1, Te, pi, w, h, ch, w * ch, q, pout, cb * Te, offs, prod))
+            dj = time.perf_counter() - t0
+            ej.close()
+            jb = offs[Te] / Te
+            mj = {"value": round(Kx * Te / dj, 2), "unit": "frames/s", "us_per_frame": round(1e6 * dj / (Kx * Te), 1), "quality": q,
+                  "jpeg_bytes_per_frame": int(jb), "bits_per_canvas_pixel": round(8.0 * jb / (cb / 3), 3), "pcie_bytes_per_frame": int(fb + jb),
+                  "surface": "lvm_export_frames_mjpeg: the same loop body, canvases -> baseline JPEG (4:2:0, restart interval per MCU row) on the "
+                             "device, byte-identical to oracle/mjpeg_oracle.py and decoded by libjpeg in tests/test_mjpeg.py; "
+                             "host/HipMjpegWriter.hpp is the AVI container"}
+        except Exception as e:
+            mj = {"error": str(e)[:200]}
         del src
         lib.lvm_host_free(pin); lib.lvm_host_free(pout)
         return {"value": round(Kx * Te / dx, 2), "unit": "frames/s", "frames_per_call": Te, "us_per_frame": round(1e6 * dx / (Kx * Te), 1),
                 "pcie_bytes_per_frame": fb + cb, "pcie_gbs": round((fb + cb) * Kx * Te / dx / 1e9, 2),
                 "surface": "lvm_export_frames: pinned host frames in -> side-by-side canvases (original | processed) out; replaces the loop "
-                           "body of Exporter::run (Exporter.cpp:216-259: runChainOnce + compose), host/HipExportRunner.hpp is the loop"}
+                           "body of Exporter::run (Exporter.cpp:216-259: runChainOnce + compose), host/HipExportRunner.hpp is the loop",
+                "mjpeg": mj}
     except Exception as e:      # a sub-record must never take the headline line down
         return {"error": str(e)[:200]}
 

@@ -43,6 +43,8 @@ namespace lvm {
 //   using Sink = ...;    bool write(Sink&, std::uint64_t seq, std::int64_t pts_us, std::uint8_t* canvas, int cw, int ch, std::ptrdiff_t stride);
 //                        draws the overlay if any, opens the writer on the first canvas, writes; false = cannot write (stop)
 //   static bool aborted(const Sink&);
+//   (run_mjpeg only)     bool write_jpeg(Sink&, std::uint64_t seq, std::int64_t pts_us, const std::uint8_t* jpeg, std::size_t bytes, int cw, int ch);
+//                        the canvas as ONE complete JPEG frame, encoded on the device: what lvm::MjpegAviWriter::write takes
 template <class T>
 class ExportRunner {
 public:
@@ -57,6 +59,22 @@ public:
     // Exporter.cpp:283-288 turns any std::exception into the Error phase).
     std::uint64_t run(typename T::Source& src, typename T::Sink& sink, const lvm_preprocess_params& pre, const MagnificationParams& mag, int split,
                       double capture_fps) {
+        return run_impl<false>(src, sink, pre, mag, split, capture_fps, 0);
+    }
+    // The same loop for ExportFormat::AviMjpg (Exporter.cpp:107-117) without the text overlay: the canvases are JPEG-encoded on the device
+    // (lvm_export_frames_mjpeg, libjpeg's quality scale 1..100), only the compressed frames come down, the sink gets them through
+    // T::write_jpeg -- cv::VideoWriter's software codec is out of the loop.  A frame larger than its raw canvas (noise at quality 100)
+    // makes the call fail with lvm::Error: the slots are sized for the canvases.
+    std::uint64_t run_mjpeg(typename T::Source& src, typename T::Sink& sink, const lvm_preprocess_params& pre, const MagnificationParams& mag, int split,
+                            double capture_fps, int quality) {
+        return run_impl<true>(src, sink, pre, mag, split, capture_fps, quality);
+    }
+    int batch() const { return batch_; }
+
+private:
+    template <bool MJPEG>
+    std::uint64_t run_impl(typename T::Source& src, typename T::Sink& sink, const lvm_preprocess_params& pre, const MagnificationParams& mag, int split,
+                           double capture_fps, int quality) {
         const lvm_params c = to_c(mag, 0);
         const double interval_us = 1'000'000.0 / (capture_fps > 0.0 ? capture_fps : 30.0);     // Exporter.cpp:196-199, :214
         std::uint64_t seq = 0, written = 0;
@@ -81,13 +99,10 @@ public:
                 }
                 store(n, raw); seqs_[(std::size_t)n++] = seq++;
             }
-            if (n > 0) written += flush(n, sink, pre, c, split, interval_us);
+            if (n > 0) written += flush<MJPEG>(n, sink, pre, c, split, interval_us, quality);
         }
         return written;
     }
-    int batch() const { return batch_; }
-
-private:
     bool slots_ready(const typename T::View& v) const { return in_ && v.w == w_ && v.h == h_ && v.channels == ch_; }
     static bool canvas_empty(const typename T::View& v, const lvm_preprocess_params& pre, int split) {
         int cw = 0, ch = 0;
@@ -124,19 +139,30 @@ private:
         const std::size_t row = (std::size_t)w_ * ch_;
         for (int y = 0; y < h_; ++y) std::memcpy(d + (std::size_t)y * row, v.data + (std::ptrdiff_t)y * v.stride, row);
     }
-    std::uint64_t flush(int n, typename T::Sink& sink, const lvm_preprocess_params& pre, const lvm_params& c, int split, double interval_us) {
+    template <bool MJPEG>
+    std::uint64_t flush(int n, typename T::Sink& sink, const lvm_preprocess_params& pre, const lvm_params& c, int split, double interval_us, int quality) {
         std::vector<const std::uint8_t*> fin((std::size_t)n);
         std::vector<std::uint8_t*> can((std::size_t)n);
         std::vector<int> produced((std::size_t)n, 0);
+        std::vector<std::size_t> offs((std::size_t)n + 1, 0);
         for (int k = 0; k < n; ++k) { fin[(std::size_t)k] = in_ + (std::size_t)k * frame_bytes_; can[(std::size_t)k] = out_ + (std::size_t)k * canvas_bytes_; }
-        const int rc = lvm_export_frames(mag_.handle(), &pre, &c, split, n, fin.data(), w_, h_, ch_, (std::ptrdiff_t)w_ * ch_, can.data(),
-                                         (std::ptrdiff_t)cw_ * 3, produced.data());
+        int rc;
+        if constexpr (MJPEG)             // the canvas slots receive the JPEG frames back to back
+            rc = lvm_export_frames_mjpeg(mag_.handle(), &pre, &c, split, n, fin.data(), w_, h_, ch_, (std::ptrdiff_t)w_ * ch_, quality, out_,
+                                         canvas_bytes_ * (std::size_t)batch_, offs.data(), produced.data());
+        else
+            rc = lvm_export_frames(mag_.handle(), &pre, &c, split, n, fin.data(), w_, h_, ch_, (std::ptrdiff_t)w_ * ch_, can.data(),
+                                   (std::ptrdiff_t)cw_ * 3, produced.data());
         if (rc != LVM_OK) throw Error(rc, std::string("lvm: ") + lvm_last_error(mag_.handle()));
         std::uint64_t written = 0;
         for (int k = 0; k < n; ++k) {
             if (T::aborted(sink)) break;                                                         // "stops at the next frame boundary"
             const std::int64_t pts = static_cast<std::int64_t>(static_cast<double>(seqs_[(std::size_t)k]) * interval_us);   // :224
-            if (!T::write(sink, seqs_[(std::size_t)k], pts, can[(std::size_t)k], cw_, chh_, (std::ptrdiff_t)cw_ * 3)) return written;
+            if constexpr (MJPEG) {
+                if (!T::write_jpeg(sink, seqs_[(std::size_t)k], pts, out_ + offs[(std::size_t)k], offs[(std::size_t)k + 1] - offs[(std::size_t)k], cw_, chh_)) return written;
+            } else {
+                if (!T::write(sink, seqs_[(std::size_t)k], pts, can[(std::size_t)k], cw_, chh_, (std::ptrdiff_t)cw_ * 3)) return written;
+            }
             ++written;                                                                           // framesDone_ (:260)
         }
         return written;
@@ -169,6 +195,9 @@ namespace livim {
 // reference passes its own lambdas, so openWriter's fallback list and the cv::putText overlay stay in Exporter.cpp.
 struct LivimExportSink {
     std::function<bool(cv::Mat& canvas)> write_canvas;         // overlay + openWriter-on-first + writer.write; false = failed
+    // HipExportLoop::run_mjpeg (ExportFormat::AviMjpg without the text overlay): the canvas arrives as a finished JPEG frame -- open an
+    // lvm::MjpegAviWriter (HipMjpegWriter.hpp) of cw x ch on the first one instead of the cv::VideoWriter, write(jpeg, bytes)
+    std::function<bool(const std::uint8_t* jpeg, std::size_t bytes, int cw, int ch)> write_jpeg;
     const std::atomic<bool>* abort = nullptr;                  // Exporter::abort_
     std::atomic<int>* frames_done = nullptr;                   // Exporter::framesDone_
 };
@@ -184,6 +213,11 @@ struct LivimExportTraits {
     static bool write(Sink& k, std::uint64_t, std::int64_t, std::uint8_t* canvas, int cw, int ch, std::ptrdiff_t stride) {
         cv::Mat m(ch, cw, CV_8UC3, canvas, static_cast<size_t>(stride));      // a view of the pinned canvas slot
         if (!k.write_canvas(m)) return false;
+        if (k.frames_done) k.frames_done->fetch_add(1, std::memory_order_relaxed);
+        return true;
+    }
+    static bool write_jpeg(Sink& k, std::uint64_t, std::int64_t, const std::uint8_t* jpeg, std::size_t bytes, int cw, int ch) {
+        if (!k.write_jpeg || !k.write_jpeg(jpeg, bytes, cw, ch)) return false;
         if (k.frames_done) k.frames_done->fetch_add(1, std::memory_order_relaxed);
         return true;
     }

@@ -98,6 +98,7 @@ RUNNER_SRC = r'''
 #include <cstring>
 #include <vector>
 #include "HipExportRunner.hpp"
+#include "HipMjpegWriter.hpp"
 
 struct MockTraits {
     struct View { const std::uint8_t* data; int w, h, channels; std::ptrdiff_t stride; bool empty; };
@@ -115,7 +116,13 @@ struct MockTraits {
         v = View{s.raw.data(), w, s.h, 3, (std::ptrdiff_t)w * 3, false};
         return true;
     }
-    struct Sink { std::vector<std::vector<std::uint8_t>> canvases; std::vector<std::uint64_t> seqs; std::vector<long long> pts; int cw = 0, ch = 0, abort_after = -1; };
+    struct Sink { std::vector<std::vector<std::uint8_t>> canvases; std::vector<std::uint64_t> seqs; std::vector<long long> pts; int cw = 0, ch = 0, abort_after = -1;
+                  lvm::MjpegAviWriter avi; const char* avi_path = nullptr; };
+    static bool write_jpeg(Sink& k, std::uint64_t seq, std::int64_t, const std::uint8_t* jpeg, std::size_t bytes, int cw, int ch) {
+        if (!k.avi.isOpened() && !k.avi.open(k.avi_path, cw, ch, 25.0)) return false;     // the writer opens on the first frame, like Exporter.cpp:245-258
+        k.seqs.push_back(seq);
+        return k.avi.write(jpeg, bytes);
+    }
     static bool write(Sink& k, std::uint64_t seq, std::int64_t pts, std::uint8_t* canvas, int cw, int ch, std::ptrdiff_t stride) {
         std::vector<std::uint8_t> c((size_t)cw * ch * 3);
         for (int y = 0; y < ch; ++y) std::memcpy(c.data() + (size_t)y * cw * 3, canvas + y * stride, (size_t)cw * 3);
@@ -125,7 +132,8 @@ struct MockTraits {
     static bool aborted(const Sink& k) { return k.abort_after >= 0 && (int)k.canvases.size() >= k.abort_after; }
 };
 
-int main() {
+int main(int argc, char** argv) {
+    const char* avi_path = argc > 1 ? argv[1] : nullptr;
     const int W = 96, H = 64, N = 11;
     try {
         lvm_preprocess_params pre{}; pre.downscale = 2; pre.roiW = pre.roiH = 1.f;
@@ -163,6 +171,25 @@ int main() {
             const std::uint64_t written = runner.run(src, sink, pre, mag, LVM_SPLIT_NONE, 30.0);
             if (written != 7 || sink.cw != W / 4 || sink.canvases.size() != 7) { std::printf("case 2: written %llu canvas %dx%d\n", (unsigned long long)written, sink.cw, sink.ch); ++bad; }
         }
+        // (3) the same source through run_mjpeg into an AVI file (HipMjpegWriter.hpp): the frames are the JPEG encodings of case (1)'s canvases
+        //     (checked by the Python side of the test against the oracle's encoder and libjpeg), written in order
+        if (avi_path) {
+            lvm::ExportRunner<MockTraits> runner(0, 4);
+            MockTraits::Source src{W, H, N, 0, 3, -1, {}};
+            MockTraits::Sink sink;
+            sink.avi_path = avi_path;
+            const std::uint64_t written = runner.run_mjpeg(src, sink, pre, mag, LVM_SPLIT_LEFT_RIGHT, 25.0, 90);
+            if (written != N - 1 || sink.avi.frames() != N - 1 || !sink.avi.close()) { std::printf("case 3: written %llu frames %u\n", (unsigned long long)written, sink.avi.frames()); ++bad; }
+            // the raw canvases of case (1)'s configuration, for the Python side
+            lvm::ExportRunner<MockTraits> again(0, 4);
+            MockTraits::Source src2{W, H, N, 0, 3, -1, {}};
+            MockTraits::Sink raw;
+            again.run(src2, raw, pre, mag, LVM_SPLIT_LEFT_RIGHT, 25.0);
+            std::FILE* f = std::fopen((std::string(avi_path) + ".canvases").c_str(), "wb");
+            for (const auto& cv : raw.canvases) std::fwrite(cv.data(), 1, cv.size(), f);
+            std::fclose(f);
+            std::printf("canvas %d %d %zu\n", raw.cw, raw.ch, raw.canvases.size());
+        }
         std::printf("bad=%d\n", bad);
         return bad ? 4 : 0;
     } catch (const lvm::Error& e) { std::printf("lvm::Error %d: %s\n", e.status(), e.what()); return 3; }
@@ -177,7 +204,51 @@ def _run_runner(tmp_path, libdir, libname):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-pthread", str(src), "-I", os.path.join(ROOT, "include"),
                            "-I", os.path.join(PKG, "host"), "-L", libdir, "-l" + libname, "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
                            "-o", str(exe)])
-    return subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    avi = tmp_path / "out.avi"
+    r = subprocess.run([str(exe), str(avi)], capture_output=True, text=True, timeout=600)
+    if r.returncode == 0:
+        _check_avi(avi, r.stdout)
+    return r
+
+
+def _riff_chunks(buf, start, end):
+    i = start
+    while i + 8 <= end:
+        cid, n = buf[i:i + 4], int.from_bytes(buf[i + 4:i + 8], "little")
+        yield cid, i + 8, n
+        i += 8 + n + (n & 1)
+
+
+def _check_avi(path, stdout):
+    """The AVI the runner wrote: a well-formed RIFF (sizes, frame count, index), every frame = the oracle's JPEG of the matching canvas, and
+    libjpeg decodes it back to the canvas within the quantisation error."""
+    import io
+    from PIL import Image
+    from oracle import mjpeg_oracle as mo
+    buf = path.read_bytes()
+    cw, chh, n = [int(x) for x in stdout.split("canvas ")[1].split()[:3]]
+    canv = np.frombuffer((path.parent / (path.name + ".canvases")).read_bytes(), np.uint8).reshape(n, chh, cw, 3)
+    assert buf[:4] == b"RIFF" and buf[8:12] == b"AVI " and int.from_bytes(buf[4:8], "little") == len(buf) - 8
+    top = {cid: (o, sz) for cid, o, sz in _riff_chunks(buf, 12, len(buf))}
+    assert set(top) == {b"LIST", b"idx1"} or b"idx1" in top
+    lists = [(o, sz) for cid, o, sz in _riff_chunks(buf, 12, len(buf)) if cid == b"LIST"]
+    hdrl = next((o, sz) for o, sz in lists if buf[o:o + 4] == b"hdrl")
+    movi = next((o, sz) for o, sz in lists if buf[o:o + 4] == b"movi")
+    avih = next((o, sz) for cid, o, sz in _riff_chunks(buf, hdrl[0] + 4, hdrl[0] + hdrl[1]) if cid == b"avih")
+    f = lambda k: int.from_bytes(buf[avih[0] + 4 * k:avih[0] + 4 * k + 4], "little")
+    assert f(0) == 40000 and f(4) == n and f(8) == cw and f(9) == chh and f(3) & 0x10        # 25 fps, frame count, size, AVIF_HASINDEX
+    frames = [(o, sz) for cid, o, sz in _riff_chunks(buf, movi[0] + 4, movi[0] + movi[1]) if cid == b"00dc"]
+    assert len(frames) == n
+    idx = top[b"idx1"]
+    assert idx[1] == 16 * n
+    for k, (o, sz) in enumerate(frames):
+        e = buf[idx[0] + 16 * k:idx[0] + 16 * k + 16]
+        assert e[:4] == b"00dc" and int.from_bytes(e[8:12], "little") == o - 8 - movi[0] and int.from_bytes(e[12:16], "little") == sz
+        jpeg = buf[o:o + sz]
+        assert jpeg == mo.encode_frame(canv[k], 90), "frame %d" % k
+        im = Image.open(io.BytesIO(jpeg))
+        dec = np.array(im)[..., ::-1]
+        assert dec.shape == canv[k].shape and mo.psnr(dec, canv[k]) > 25.0        # (a per-byte sawtooth: hard on 4:2:0)
 
 
 def test_export_runner_with_mock_source_and_sink_on_the_emulation_build(tmp_path, emu):

@@ -256,7 +256,7 @@ def test_bench_driver_line_carries_every_config():
         assert r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["kind"] == "port"
         assert r["per_frame"]["B1"]["frames_per_call"] == 1 and r["per_frame"]["B1"]["value"] > 0 and r["per_frame"]["B4"]["value"] > 0
         assert r["e2e_host"]["pinned"]["value"] > 0 and r["e2e_host"]["pageable"]["value"] > 0
-    assert out["per_frame"]["value"] > 0 and out["e2e_host"]["pinned"]["value"] > 0 and out["export_host"]["value"] > 0
+    assert out["per_frame"]["value"] > 0 and out["e2e_host"]["pinned"]["value"] > 0 and out["export_host"]["value"] > 0 and out["export_host"]["mjpeg"]["value"] > 0
 
 
 def test_two_contexts_on_two_threads(lvm, po, hip):

@@ -55,6 +55,7 @@ SRC = r'''
 #include "HipProcessingStages.hpp"
 #include "HipBatchedProcessingChain.hpp"
 #include "HipExportRunner.hpp"
+#include "HipMjpegWriter.hpp"
 #include <cstdio>
 #include <vector>
 int main() {
@@ -94,6 +95,15 @@ int main() {
         HipExportLoop loop(0, 8);
         const auto written = loop.run(src, sink, export_pre_params(req.config), export_mag_params(req.config), export_split(req.split), 30.0);
         std::printf("export wrote %llu done %d\n", (unsigned long long)written, done.load());
+        // ExportFormat::AviMjpg without the overlay: the canvases arrive as JPEG frames (lvm_export_frames_mjpeg), lvm::MjpegAviWriter is the container
+        TwoFrames two_more;
+        LivimExportTraits::Source src_j{&two_more, cv::Mat()};
+        lvm::MjpegAviWriter avi;
+        sink.write_jpeg = [&avi](const std::uint8_t* jpeg, std::size_t bytes, int cw, int ch) {
+            return (avi.isOpened() || avi.open("/tmp/lvm_shim_test.avi", cw, ch, 30.0)) && avi.write(jpeg, bytes);
+        };
+        const auto jw = loop.run_mjpeg(src_j, sink, export_pre_params(req.config), export_mag_params(req.config), export_split(req.split), 30.0, 85);
+        std::printf("mjpeg wrote %llu frames %u closed %d\n", (unsigned long long)jw, avi.frames(), (int)avi.close());
     } catch (const std::exception& e) { std::printf("exception: %s\n", e.what()); return 3; }
     return 0;
 }
@@ -115,6 +125,6 @@ def test_shims_compile_against_the_reference_headers(tmp_path):
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     import torch
     if torch.cuda.is_available():
-        assert run.returncode == 0 and "out 64x48" in run.stdout and "sources 2" in run.stdout and "export wrote 2 done 2" in run.stdout, run.stdout + run.stderr
+        assert run.returncode == 0 and "out 64x48" in run.stdout and "sources 2" in run.stdout and "export wrote 2 done 2" in run.stdout and "mjpeg wrote 2 frames 2 closed 1" in run.stdout, run.stdout + run.stderr
     else:                                                               # no device here: the constructors fail loudly
         assert run.returncode == 3 and "lvm_create failed" in run.stdout, run.stdout + run.stderr
