@@ -214,7 +214,13 @@ int  lvm_export_frames(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_
  *                              offsets has n_frames + 1 entries.  LVM_ERR_INVALID when out_capacity is too small.  Synchronous.
  *   lvm_export_frames_mjpeg    lvm_export_frames with the canvases encoded on the device: only the ROI rows go up and only the compressed
  *                              frames come down.  host/HipMjpegWriter.hpp wraps the frames into the AVI container.                       */
+/*   lvm_mjpeg_decode_device    the other direction (cv::VideoCapture::read on an AVI / Motion-JPEG file, source/FileSource.cpp:99): n_frames
+ *                              JPEG frames in host memory (jpegs[offsets[i] .. offsets[i + 1])) -> BGR frames of w x h in DEVICE memory.
+ *                              Baseline 4:2:0 in one scan, any tables, with or without restart intervals; anything else, a size other
+ *                              than w x h or a malformed stream is LVM_ERR_INVALID (lvm_last_error says which frame and why).  Synchronous. */
 size_t lvm_mjpeg_bound(int w, int h);
+int  lvm_mjpeg_decode_device(lvm_ctx* ctx, const uint8_t* jpegs, const size_t* offsets, int n_frames, int w, int h, uint8_t* d_bgr,
+                             ptrdiff_t stride, ptrdiff_t frame_stride);
 int  lvm_mjpeg_encode_device(lvm_ctx* ctx, const uint8_t* d_bgr, int w, int h, ptrdiff_t stride, ptrdiff_t frame_stride, int n_frames,
                              int quality, uint8_t* out, size_t out_capacity, size_t* offsets);
 int  lvm_export_frames_mjpeg(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames,

@@ -225,6 +225,7 @@ void lvm_destroy(lvm_ctx* c) {
     if (c->d_float) (void)hipFree(c->d_float);
     lvm::preprocess_release(c);
     lvm::mjpeg_release(c);
+    lvm::mjpeg_decode_release(c);
     if (c->d_pre_in) (void)hipFree(c->d_pre_in);
     if (c->d_pre_out) (void)hipFree(c->d_pre_out);
     if (c->d_chain_out) (void)hipFree(c->d_chain_out);
@@ -649,6 +650,16 @@ int lvm_export_frames_mjpeg(lvm_ctx* c, const lvm_preprocess_params* pp, const l
                             uint8_t* out, size_t out_capacity, size_t* offsets, int* produced) {
     const MjpegSink mj{quality, out, out_capacity, offsets};
     return export_frames_impl(c, pp, p, split, n_frames, frames, w, h, channels, in_stride, nullptr, 0, produced, &mj);
+}
+
+int lvm_mjpeg_decode_device(lvm_ctx* c, const uint8_t* jpegs, const size_t* offsets, int n_frames, int w, int h, uint8_t* d_bgr, ptrdiff_t stride,
+                            ptrdiff_t frame_stride) {
+    if (!c || !jpegs || !offsets || !d_bgr || n_frames < 1) return LVM_ERR_INVALID;
+    if (stride < (ptrdiff_t)w * 3 || (n_frames > 1 && frame_stride < (ptrdiff_t)h * stride)) { c->err = "bad frame arguments"; return LVM_ERR_INVALID; }
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    const int rc = lvm::mjpeg_decode_device(c, jpegs, offsets, n_frames, w, h, d_bgr, stride, frame_stride, c->own_stream);
+    if (rc == LVM_OK) lvm::mark_enqueued(c, c->own_stream);
+    return rc;
 }
 
 size_t lvm_mjpeg_bound(int w, int h) { return (w < 1 || h < 1) ? 0 : lvm::mjpeg_bound(w, h); }

@@ -425,6 +425,7 @@ struct Ctx {
     hipStream_t up_stream = nullptr, down_stream = nullptr;
     std::vector<hipEvent_t> ev_up, ev_done;
     void* mjpeg = nullptr;            // mjpeg.hip: tables, header and scratch of the Motion-JPEG encoder
+    void* mjpeg_dec = nullptr;        // mjpeg_decode.hip: per-frame tables and scratch of the decoder
 };
 
 inline int lab_flavour(const Ctx* c) { return c->lab_analytic ? FL_ANALYTIC : (c->exact_lab ? FL_LUT_EXACT : FL_LUT_FAST); }
@@ -486,6 +487,8 @@ size_t mjpeg_bound(int w, int h);
 void mjpeg_release(Ctx* c);
 int mjpeg_begin(Ctx* c, int w, int h, int quality, int max_frames_per_call, size_t total_frames, size_t capacity, hipStream_t s);
 int mjpeg_encode_device(Ctx* c, const uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_t fstride, int nframes, int frame0, size_t capacity, hipStream_t s);
+void mjpeg_decode_release(Ctx* c);
+int mjpeg_decode_device(Ctx* c, const uint8_t* jpegs, const size_t* offsets, int n, int w, int h, uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_t fstride, hipStream_t s);
 int mjpeg_drain(Ctx* c, uint8_t* out_host, size_t upto_call);
 int mjpeg_finish(Ctx* c, size_t total_frames, uint8_t* out_host, size_t* offsets, hipStream_t s);
 int compose_device(Ctx* c, int split, const uint8_t* d_orig, int ow, int oh, int och, ptrdiff_t ostride, ptrdiff_t osstride,

@@ -1,0 +1,417 @@
+// mjpeg_decode.hip -- Motion-JPEG decode onto the device (the decode half).
+//
+// Replaces what `cv::VideoCapture::read(frame)` does for an AVI / Motion-JPEG file (reference: source/FileSource.cpp:99): the compressed
+// frames go up (a tenth of the pixels), the decoded BGR frames appear where the chain wants them -- in device memory.
+// Accepted: ITU-T T.81 baseline sequential, 8 bit, three components sampled 2x2 / 1x1 / 1x1 (YCbCr 4:2:0, JFIF) in one scan, any quantiser and
+// Huffman tables (frames without DHT get the Annex K tables, as AVI MJPEG implies), with or without restart intervals -- what this
+// repository's encoder, libjpeg and FFmpeg's mjpeg encoder write.  Everything else is refused (LVM_ERR_INVALID), nothing is guessed.
+// The entropy layer is exact by the standard; the arithmetic behind it is the decoder's choice and is restated line by line by
+// oracle/mjpeg_oracle.py::decode_frame (all integer; its header has the formulas): the frames are BIT-identical to the oracle's, and within
+// the bars of tests/test_mjpeg_decode.py of libjpeg's own decoder.
+//
+// Huffman decoding is serial inside a restart interval and nowhere else: a LANE per interval (k_mjd_huffman; 68 lanes per frame for this
+// repository's streams, one for a stream without restart markers -- then the frames of the batch are the parallelism).
+//   host              headers -> per-frame tables (quantisers, 9-bit look-up + canonical tables of the four Huffman codes)
+//   k_mjd_intervals   RSTn markers of the entropy-coded segment -> start / end of every interval            one workgroup per frame
+//   k_mjd_huffman     bits -> quantised coefficients (zigzag order, int16, zero-filled beforehand)           one lane per interval
+//   k_mjd_pixels      dequantise, IDCT, chroma replication, YCbCr -> BGR                                      one wave per 16 x 16 MCU
+#include <cstring>
+#include <vector>
+
+#include "lvm_internal.h"
+#include "mjpeg_tables.h"
+
+namespace lvm {
+namespace {
+
+constexpr int MJD_LUT_BITS = 9;
+struct MjdHuff {
+    uint16_t lut[1 << MJD_LUT_BITS];    // (length << 8) | symbol for codes of up to 9 bits, 0 = longer
+    int32_t maxcode[18];                // T.81 F.2.2.3, -1 where a length has no code; [17] = sentinel
+    int32_t mincode[17];
+    int32_t valptr[17];
+    uint8_t vals[256];
+};
+struct MjdFrame {
+    uint32_t data_off, data_len;        // the entropy-coded segment inside the uploaded bytes
+    uint32_t restart;                   // MCUs per restart interval (0: the whole scan)
+    uint32_t nintervals;                // expected
+    uint32_t tq[3], td[3], ta[3];
+    uint16_t q[4][64];                  // quantisers in ZIGZAG order
+    uint8_t zz[64];                     // zigzag index -> natural position
+    MjdHuff huff[2][2];                 // [class: 0 DC, 1 AC][id 0, 1]
+};
+
+struct MjdState {
+    int frames_cap = 0, w = 0, h = 0;
+    size_t bytes_cap = 0;
+    MjdFrame* d_frames = nullptr;
+    uint8_t* d_bytes = nullptr;
+    int16_t* d_coef = nullptr;
+    uint32_t *d_ivstart = nullptr, *d_ivend = nullptr, *d_err = nullptr;
+    int iv_cap = 0;
+    std::vector<MjdFrame> frames;
+};
+
+int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
+
+void build_decode_table(const uint8_t* bits, const uint8_t* vals, int nvals, MjdHuff& t) {
+    std::memset(&t, 0, sizeof t);
+    int code = 0, k = 0;
+    for (int len = 1; len <= 16; ++len) {
+        t.maxcode[len] = -1;
+        if (bits[len - 1]) {
+            t.valptr[len] = k; t.mincode[len] = code;
+            for (int i = 0; i < bits[len - 1] && k < nvals; ++i, ++k, ++code) {
+                if (len <= MJD_LUT_BITS)
+                    for (int f = 0; f < (1 << (MJD_LUT_BITS - len)); ++f) t.lut[(code << (MJD_LUT_BITS - len)) | f] = (uint16_t)((len << 8) | vals[k]);
+            }
+            t.maxcode[len] = code - 1;
+        }
+        code <<= 1;
+    }
+    t.maxcode[17] = 0x7FFFFFFF;
+    for (int i = 0; i < nvals && i < 256; ++i) t.vals[i] = vals[i];
+}
+
+// SOI .. SOS of one frame (oracle: parse_header).  Returns nullptr, or what is unsupported / malformed.
+const char* parse_frame(const uint8_t* j, size_t n, int w, int h, MjdFrame& f) {
+    if (n < 4 || j[0] != 0xFF || j[1] != 0xD8) return "no SOI";
+    bool have_q[4] = {false, false, false, false}, have_h[2][2] = {{false, false}, {false, false}}, sof = false;
+    uint32_t cid[3] = {0, 0, 0};
+    f.restart = 0;
+    for (int z = 0; z < 64; ++z) f.zz[z] = kZigzag[z];
+    size_t i = 2;
+    for (;;) {
+        if (i + 4 > n || j[i] != 0xFF) return "marker expected";
+        const int m = j[i + 1];
+        if (m == 0xFF) { ++i; continue; }
+        const size_t len = (size_t)be16(j + i + 2);
+        if (len < 2 || i + 2 + len > n) return "segment runs past the frame";
+        const uint8_t* p = j + i + 4;
+        const size_t pn = len - 2;
+        if (m == 0xDB) {
+            for (size_t k = 0; k < pn; k += 65) {
+                if (k + 65 > pn || (p[k] >> 4) || (p[k] & 15) > 3) return "quantiser table (16 bit or bad id)";
+                for (int z = 0; z < 64; ++z) f.q[p[k] & 15][z] = p[k + 1 + z];
+                have_q[p[k] & 15] = true;
+            }
+        } else if (m == 0xC4) {
+            for (size_t k = 0; k < pn;) {
+                if (k + 17 > pn) return "Huffman table";
+                int nv = 0;
+                for (int b = 0; b < 16; ++b) nv += p[k + 1 + b];
+                const int cls = p[k] >> 4, id = p[k] & 15;
+                if (cls > 1 || id > 1 || nv > 256 || k + 17 + (size_t)nv > pn) return "Huffman table (class / id / size)";
+                build_decode_table(p + k + 1, p + k + 17, nv, f.huff[cls][id]);
+                have_h[cls][id] = true;
+                k += 17 + (size_t)nv;
+            }
+        } else if (m == 0xC0) {
+            if (pn < 15 || p[0] != 8 || p[5] != 3) return "not 8-bit three-component";
+            if (be16(p + 1) != h || be16(p + 3) != w) return "frame size differs from the call's";
+            for (int c = 0; c < 3; ++c) { cid[c] = p[6 + 3 * c]; f.tq[c] = p[8 + 3 * c]; if (f.tq[c] > 3) return "quantiser id"; }
+            if (p[7] != 0x22 || p[10] != 0x11 || p[13] != 0x11) return "sampling is not 4:2:0";
+            sof = true;
+        } else if (m == 0xC1 || m == 0xC2 || m == 0xC3 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
+            return "not baseline sequential";
+        } else if (m == 0xDD) {
+            if (pn < 2) return "DRI";
+            f.restart = (uint32_t)be16(p);
+        } else if (m == 0xDA) {
+            if (!sof || pn < 10 || p[0] != 3) return "scan without frame header / not three components";
+            for (int c = 0; c < 3; ++c) {
+                if (p[1 + 2 * c] != cid[c]) return "scan component order";
+                f.td[c] = p[2 + 2 * c] >> 4; f.ta[c] = p[2 + 2 * c] & 15;
+                if (f.td[c] > 1 || f.ta[c] > 1) return "Huffman table id";
+            }
+            if (p[7] != 0 || p[8] != 63) return "not a full baseline scan";
+            for (int c = 0; c < 3; ++c) if (!have_q[f.tq[c]]) return "quantiser table missing";
+            // frames of an AVI may leave the Huffman tables out: the Annex K tables are implied
+            if (!have_h[0][0]) build_decode_table(kDcLumaBits, kDcVals, 12, f.huff[0][0]);
+            if (!have_h[1][0]) build_decode_table(kAcLumaBits, kAcLumaVals, 162, f.huff[1][0]);
+            if (!have_h[0][1]) build_decode_table(kDcChromaBits, kDcVals, 12, f.huff[0][1]);
+            if (!have_h[1][1]) build_decode_table(kAcChromaBits, kAcChromaVals, 162, f.huff[1][1]);
+            size_t start = i + 2 + len, end = n;
+            if (end >= start + 2 && j[end - 2] == 0xFF && j[end - 1] == 0xD9) end -= 2;      // EOI
+            f.data_off = (uint32_t)start; f.data_len = (uint32_t)(end - start);
+            return nullptr;
+        }
+        i += 2 + len;
+    }
+}
+
+// ---- kernels ----------------------------------------------------------------------------------------------------------------------------
+
+// One workgroup per frame: the k-th RSTn marker of the entropy-coded segment ends interval k and starts interval k + 1 (FF D0..D7 cannot
+// occur inside the data: an FF byte of the data is followed by 00).
+__global__ __launch_bounds__(256) void k_mjd_intervals(const uint8_t* __restrict__ bytes, const MjdFrame* __restrict__ frames, const uint32_t* __restrict__ foff,
+                                                       uint32_t* __restrict__ ivstart, uint32_t* __restrict__ ivend, int iv_cap, uint32_t* __restrict__ err) {
+    __shared__ uint32_t s_part[256];
+    const int tid = threadIdx.x, f = blockIdx.x;
+    const MjdFrame& fr = frames[f];
+    const uint8_t* d = bytes + foff[f] + fr.data_off;
+    const uint32_t n = fr.data_len;
+    const uint32_t per = (n + 255u) / 256u, lo = tid * per, hi = lo + per < n ? lo + per : n;
+    uint32_t cnt = 0;
+    for (uint32_t i = lo; i < hi; ++i) cnt += (d[i] == 0xFF && i + 1 < n && (d[i + 1] & 0xF8) == 0xD0) ? 1u : 0u;
+    s_part[tid] = cnt;
+    __syncthreads();
+    for (int dd = 1; dd < 256; dd <<= 1) {
+        const uint32_t t = tid >= dd ? s_part[tid - dd] : 0u;
+        __syncthreads();
+        s_part[tid] += t;
+        __syncthreads();
+    }
+    uint32_t k = tid ? s_part[tid - 1] : 0u;
+    uint32_t* st = ivstart + (size_t)f * iv_cap;
+    uint32_t* en = ivend + (size_t)f * iv_cap;
+    for (uint32_t i = lo; i < hi; ++i)
+        if (d[i] == 0xFF && i + 1 < n && (d[i + 1] & 0xF8) == 0xD0) {
+            if (k + 1 < (uint32_t)iv_cap) { en[k] = i; st[k + 1] = i + 2; }
+            ++k;
+        }
+    if (tid == 255) {
+        const uint32_t total = s_part[255] + 1u;
+        if (total != fr.nintervals) atomicOr(err + f, 1u);            // the markers do not match the restart interval of the header
+        else { st[0] = 0; en[total - 1] = n; }
+    }
+}
+
+// bit reader over [p, end): big-endian bits, FF 00 -> FF; behind the end the stream continues with 1-bits (a truncated interval decodes to
+// something and reads nothing outside)
+struct MjdBits {
+    const uint8_t* p; const uint8_t* end;
+    uint32_t acc; int cnt;               // the next bits are the top `cnt` bits of acc
+    __device__ __forceinline__ void fill() {
+        while (cnt <= 24) {
+            uint32_t b = 0xFFu;
+            if (p < end) { b = *p++; if (b == 0xFFu && p < end && *p == 0) ++p; }
+            acc |= b << (24 - cnt);
+            cnt += 8;
+        }
+    }
+    __device__ __forceinline__ uint32_t peek(int n) const { return acc >> (32 - n); }
+    __device__ __forceinline__ void skip(int n) { acc <<= n; cnt -= n; }
+    __device__ __forceinline__ uint32_t get(int n) { if (n == 0) return 0u; fill(); const uint32_t v = peek(n); skip(n); return v; }
+};
+
+// one Huffman symbol (T.81 F.2.2.3); -1 = no such code
+__device__ __forceinline__ int mjd_symbol(MjdBits& br, const uint16_t* lut, const MjdHuff& t) {
+    br.fill();
+    const uint32_t e = lut[br.peek(MJD_LUT_BITS)];
+    if (e) { br.skip((int)(e >> 8)); return (int)(e & 255u); }
+    int code = (int)br.peek(MJD_LUT_BITS);
+    for (int len = MJD_LUT_BITS + 1; len <= 16; ++len) {
+        code = (int)br.peek(len);
+        if (t.maxcode[len] >= 0 && code <= t.maxcode[len] && code >= t.mincode[len]) { br.skip(len); return t.vals[t.valptr[len] + code - t.mincode[len]]; }
+    }
+    return -1;
+}
+__device__ __forceinline__ int mjd_extend(uint32_t v, int s) { return (s == 0 || v >= (1u << (s - 1))) ? (int)v : (int)v - (1 << s) + 1; }
+
+// A lane per restart interval; the 64 lanes of a workgroup are consecutive intervals of ONE frame, whose look-up tables sit in LDS.
+__global__ __launch_bounds__(64) void k_mjd_huffman(const uint8_t* __restrict__ bytes, const MjdFrame* __restrict__ frames, const uint32_t* __restrict__ foff,
+                                                    const uint32_t* __restrict__ ivstart, const uint32_t* __restrict__ ivend, int iv_cap, int nmcu,
+                                                    int16_t* __restrict__ coef, uint32_t* __restrict__ err) {
+    __shared__ uint16_t s_lut[2][2][1 << MJD_LUT_BITS];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const MjdFrame& fr = frames[f];
+    for (int i = tid; i < 4 << MJD_LUT_BITS; i += 64) s_lut[i >> (MJD_LUT_BITS + 1)][(i >> MJD_LUT_BITS) & 1][i & ((1 << MJD_LUT_BITS) - 1)] =
+        fr.huff[i >> (MJD_LUT_BITS + 1)][(i >> MJD_LUT_BITS) & 1].lut[i & ((1 << MJD_LUT_BITS) - 1)];
+    __syncthreads();
+    const uint32_t k = blockIdx.x * 64u + (uint32_t)tid;
+    if (k >= fr.nintervals || err[f]) return;
+    const uint8_t* d = bytes + foff[f] + fr.data_off;
+    MjdBits br;
+    br.p = d + ivstart[(size_t)f * iv_cap + k]; br.end = d + ivend[(size_t)f * iv_cap + k]; br.acc = 0; br.cnt = 0;
+    const uint32_t ri = fr.restart ? fr.restart : (uint32_t)nmcu;
+    const uint32_t m0 = k * ri, m1 = m0 + ri < (uint32_t)nmcu ? m0 + ri : (uint32_t)nmcu;
+    int pred[3] = {0, 0, 0};
+    bool bad = false;
+    for (uint32_t m = m0; m < m1 && !bad; ++m) {
+        int16_t* out = coef + ((size_t)f * nmcu + m) * 384;
+        for (int bi = 0; bi < 6 && !bad; ++bi) {
+            const int comp = bi < 4 ? 0 : bi - 3;
+            const uint32_t td = fr.td[comp], ta = fr.ta[comp];
+            int s = mjd_symbol(br, s_lut[0][td], fr.huff[0][td]);
+            if (s < 0 || s > 11) { bad = true; break; }
+            pred[comp] += mjd_extend(br.get(s), s);
+            out[bi * 64] = (int16_t)pred[comp];
+            for (int kk = 1; kk < 64;) {
+                const int rs = mjd_symbol(br, s_lut[1][ta], fr.huff[1][ta]);
+                if (rs < 0) { bad = true; break; }
+                const int r = rs >> 4;
+                s = rs & 15;
+                if (s == 0) { if (r != 15) break; kk += 16; continue; }
+                kk += r;
+                if (kk > 63) { bad = true; break; }
+                out[bi * 64 + kk] = (int16_t)mjd_extend(br.get(s), s);
+                ++kk;
+            }
+        }
+    }
+    if (bad) atomicOr(err + f, 2u);
+}
+
+struct MjdGeom { int w, h, mw, mh; long stride, fstride; };
+
+// One wave per MCU (four per workgroup): dequantise + un-zigzag (lane = zigzag index), IDCT (48 of the 64 lanes: a column / row of one of
+// the six blocks each), then lane = one 2 x 2 pixel quad with its replicated chroma sample -> four BGR pixels.
+__global__ __launch_bounds__(256) void k_mjd_pixels(const int16_t* __restrict__ coef, const MjdFrame* __restrict__ frames, MjdGeom g, uint8_t* __restrict__ dst) {
+    __shared__ int s_a[4][6][64], s_b[4][6][64];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int mx = blockIdx.x * 4 + wave, my = blockIdx.y, f = blockIdx.z;
+    const bool act = mx < g.mw;
+    const MjdFrame& fr = frames[f];
+    if (act) {
+        const int16_t* in = coef + (((size_t)f * g.mh + my) * g.mw + mx) * 384;
+        const int nat = fr.zz[lane];
+#pragma unroll
+        for (int blk = 0; blk < 6; ++blk) {
+            const int q = fr.q[fr.tq[blk < 4 ? 0 : blk - 3]][lane];
+            int v = in[blk * 64 + lane] * q;
+            v = v < -4096 ? -4096 : (v > 4095 ? 4095 : v);
+            s_a[wave][blk][nat] = v;
+        }
+    }
+    __syncthreads();
+    if (act && lane < 48) {               // columns: t[y][u] = (sum_v M[v][y] S[v][u] + 512) >> 10
+        const int blk = lane >> 3, u = lane & 7;
+        int d[8];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) d[v] = s_a[wave][blk][v * 8 + u];
+#pragma unroll
+        for (int y = 0; y < 8; ++y) {
+            int acc = 0;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) acc += kDct[v][y] * d[v];
+            s_b[wave][blk][y * 8 + u] = (acc + 512) >> 10;
+        }
+    }
+    __syncthreads();
+    if (act && lane < 48) {               // rows: s[y][x] = (sum_u M[u][x] t[y][u] + 32768) >> 16; + 128; clamp
+        const int blk = lane >> 3, y = lane & 7;
+        int d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) d[u] = s_b[wave][blk][y * 8 + u];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            int acc = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += kDct[u][x] * d[u];
+            int p = ((acc + 32768) >> 16) + 128;
+            s_a[wave][blk][y * 8 + x] = p < 0 ? 0 : (p > 255 ? 255 : p);
+        }
+    }
+    __syncthreads();
+    if (act) {
+        const int qx = lane & 7, qy = lane >> 3;
+        const int cb = s_a[wave][4][lane] - 128, cr = s_a[wave][5][lane] - 128;
+        const int dr = (91881 * cr + 32768) >> 16, dg = (-22554 * cb - 46802 * cr + 32768) >> 16, db = (116130 * cb + 32768) >> 16;
+        uint8_t* fr_out = dst + (size_t)f * g.fstride;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const int ly = 2 * qy + dy, py = my * 16 + ly;
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int lx = 2 * qx + dx, px = mx * 16 + lx;
+                if (py < g.h && px < g.w) {
+                    const int y = s_a[wave][(ly >> 3) * 2 + (lx >> 3)][(ly & 7) * 8 + (lx & 7)];
+                    int r = y + dr, gg = y + dg, b = y + db;
+                    r = r < 0 ? 0 : (r > 255 ? 255 : r); gg = gg < 0 ? 0 : (gg > 255 ? 255 : gg); b = b < 0 ? 0 : (b > 255 ? 255 : b);
+                    uint8_t* o = fr_out + (size_t)py * g.stride + (size_t)px * 3;
+                    o[0] = (uint8_t)b; o[1] = (uint8_t)gg; o[2] = (uint8_t)r;
+                }
+            }
+        }
+    }
+}
+
+template <class T>
+int mjd_reserve(Ctx* c, T*& p, size_t count) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    LVM_HIP_TRY(c, hipMalloc((void**)&p, count * sizeof(T)));
+    return LVM_OK;
+}
+
+}  // namespace
+
+void mjpeg_decode_release(Ctx* c) {
+    MjdState* st = static_cast<MjdState*>(c->mjpeg_dec);
+    if (!st) return;
+    void* ptrs[] = {st->d_frames, st->d_bytes, st->d_coef, st->d_ivstart, st->d_ivend, st->d_err};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete st;
+    c->mjpeg_dec = nullptr;
+}
+
+// n frames (host bytes jpegs[offsets[i] .. offsets[i + 1])) -> BGR frames of w x h on the device, enqueued on s and completed before the
+// return (a malformed stream is an error of the call, not a picture).
+int mjpeg_decode_device(Ctx* c, const uint8_t* jpegs, const size_t* offsets, int n, int w, int h, uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_t fstride, hipStream_t s) {
+    if (w < 1 || h < 1 || w > 8192 || h > 16384) { c->err = "lvm_mjpeg_decode: frame size out of range (1..8192 x 1..16384)"; return LVM_ERR_INVALID; }
+    MjdState* st = static_cast<MjdState*>(c->mjpeg_dec);
+    if (!st) { st = new MjdState; c->mjpeg_dec = st; }
+    const int mw = (w + 15) / 16, mh = (h + 15) / 16, nmcu = mw * mh;
+    st->frames.resize((size_t)n);
+    std::vector<uint32_t> foff((size_t)n + 1);
+    int max_iv = 1;
+    for (int i = 0; i < n; ++i) {
+        if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[0] > 0xFFFFFFF0ull) { c->err = "lvm_mjpeg_decode: bad offsets"; return LVM_ERR_INVALID; }
+        MjdFrame& f = st->frames[(size_t)i];
+        const char* why = parse_frame(jpegs + offsets[i], offsets[i + 1] - offsets[i], w, h, f);
+        if (why) { c->err = std::string("lvm_mjpeg_decode: frame ") + std::to_string(i) + ": " + why; return LVM_ERR_INVALID; }
+        f.nintervals = f.restart ? (uint32_t)((nmcu + (int)f.restart - 1) / (int)f.restart) : 1u;
+        if ((int)f.nintervals > max_iv) max_iv = (int)f.nintervals;
+        foff[(size_t)i] = (uint32_t)(offsets[i] - offsets[0]);
+    }
+    foff[(size_t)n] = (uint32_t)(offsets[n] - offsets[0]);
+    const size_t nbytes = offsets[n] - offsets[0];
+    int rc;
+    if (st->frames_cap < n || st->w != w || st->h != h) {
+        LVM_HIP_TRY(c, hipStreamSynchronize(s));
+        st->frames_cap = 0;
+        if ((rc = mjd_reserve(c, st->d_frames, (size_t)n)) != LVM_OK) return rc;
+        if ((rc = mjd_reserve(c, st->d_coef, (size_t)n * nmcu * 384)) != LVM_OK) return rc;
+        if ((rc = mjd_reserve(c, st->d_err, (size_t)n * 2 + 2)) != LVM_OK) return rc;       // error flags, then the frame offsets (n + 1)
+        st->frames_cap = n; st->w = w; st->h = h; st->iv_cap = 0;
+    }
+    if (st->iv_cap < max_iv) {
+        LVM_HIP_TRY(c, hipStreamSynchronize(s));
+        st->iv_cap = 0;
+        if ((rc = mjd_reserve(c, st->d_ivstart, (size_t)st->frames_cap * max_iv)) != LVM_OK) return rc;
+        if ((rc = mjd_reserve(c, st->d_ivend, (size_t)st->frames_cap * max_iv)) != LVM_OK) return rc;
+        st->iv_cap = max_iv;
+    }
+    if (st->bytes_cap < nbytes + 8) {
+        LVM_HIP_TRY(c, hipStreamSynchronize(s));
+        st->bytes_cap = 0;
+        if ((rc = mjd_reserve(c, st->d_bytes, nbytes + 8)) != LVM_OK) return rc;
+        st->bytes_cap = nbytes + 8;
+    }
+    uint32_t* d_foff = st->d_err + n;
+    LVM_HIP_TRY(c, hipMemcpyAsync(st->d_bytes, jpegs + offsets[0], nbytes, hipMemcpyHostToDevice, s));
+    LVM_HIP_TRY(c, hipMemcpyAsync(st->d_frames, st->frames.data(), (size_t)n * sizeof(MjdFrame), hipMemcpyHostToDevice, s));
+    LVM_HIP_TRY(c, hipMemsetAsync(st->d_err, 0, (size_t)n * sizeof(uint32_t), s));
+    LVM_HIP_TRY(c, hipMemcpyAsync(d_foff, foff.data(), ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    LVM_HIP_TRY(c, hipMemsetAsync(st->d_coef, 0, (size_t)n * nmcu * 384 * sizeof(int16_t), s));
+    LVM_LAUNCH(c, "mjd_intervals", k_mjd_intervals, dim3(n), dim3(256), s, (const uint8_t*)st->d_bytes, (const MjdFrame*)st->d_frames, (const uint32_t*)d_foff,
+               st->d_ivstart, st->d_ivend, st->iv_cap, st->d_err);
+    LVM_LAUNCH(c, "mjd_huffman", k_mjd_huffman, dim3((max_iv + 63) / 64, n), dim3(64), s, (const uint8_t*)st->d_bytes, (const MjdFrame*)st->d_frames,
+               (const uint32_t*)d_foff, (const uint32_t*)st->d_ivstart, (const uint32_t*)st->d_ivend, st->iv_cap, nmcu, st->d_coef, st->d_err);
+    MjdGeom g;
+    g.w = w; g.h = h; g.mw = mw; g.mh = mh; g.stride = (long)stride; g.fstride = (long)fstride;
+    LVM_LAUNCH(c, "mjd_pixels", k_mjd_pixels, dim3((mw + 3) / 4, mh, n), dim3(256), s, (const int16_t*)st->d_coef, (const MjdFrame*)st->d_frames, g, d_bgr);
+    std::vector<uint32_t> err((size_t)n);
+    LVM_HIP_TRY(c, hipMemcpyAsync(err.data(), st->d_err, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    LVM_HIP_TRY(c, hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i)
+        if (err[(size_t)i]) {
+            c->err = std::string("lvm_mjpeg_decode: frame ") + std::to_string(i) + (err[(size_t)i] & 1u ? ": restart markers do not match the restart interval" : ": invalid Huffman code / coefficient index");
+            return LVM_ERR_INVALID;
+        }
+    return LVM_OK;
+}
+
+}  // namespace lvm

@@ -228,3 +228,216 @@ def psnr(a, b):
     d = a.astype(np.float64) - b.astype(np.float64)
     mse = float(np.mean(d * d))
     return 99.0 if mse == 0 else 10.0 * math.log10(255.0 * 255.0 / mse)
+
+
+# ---- decoder (the decode half: cv::VideoCapture::read on an AVI / Motion-JPEG file, source/FileSource.cpp:99) ----------
+# Baseline sequential, 8 bit, three components sampled 2x2 / 1x1 / 1x1, any quantiser and Huffman tables, with or without restart intervals
+# -- what this repo's encoder, libjpeg (4:2:0) and FFmpeg's mjpeg encoder (yuvj420p) write.  Again the standard fixes the entropy layer
+# exactly and leaves the arithmetic after it to the decoder; this one (all integer):
+#   dequantise   S = clamp(c * Q, -4096, 4095)
+#   IDCT         columns: t[y][u] = (sum_v M[v][y] S[v][u] + 512) >> 10; rows: s[y][x] = (sum_u M[u][x] t[y][u] + 32768) >> 16; + 128, clamp 0..255
+#   chroma       replicated 2 x 2 (no smoothing)
+#   colour       R = Y + ((91881 Cr' + 32768) >> 16), G = Y + ((-22554 Cb' - 46802 Cr' + 32768) >> 16), B = Y + ((116130 Cb' + 32768) >> 16),
+#                Cb' = Cb - 128, Cr' = Cr - 128; clamp 0..255
+# The HIP decoder is BIT-identical to decode_frame(); libjpeg's own decoder (slow integer IDCT, "fancy" chroma upsampling) agrees with it to
+# within the bars in tests/test_mjpeg_decode.py.
+
+class JpegError(ValueError):
+    pass
+
+
+def parse_header(j):
+    """-> dict(w, h, q[4] (natural order), huff {(class, id): (bits, vals)}, restart, comps [(id, h, v, tq)], scan [(cid, td, ta)], data_start)"""
+    if j[:2] != b"\xff\xd8":
+        raise JpegError("no SOI")
+    i, out = 2, {"q": {}, "huff": {}, "restart": 0}
+    while True:
+        if i + 4 > len(j) or j[i] != 0xFF:
+            raise JpegError("marker expected at %d" % i)
+        m = j[i + 1]
+        if m == 0xFF:
+            i += 1
+            continue
+        n = int.from_bytes(j[i + 2:i + 4], "big")
+        p = j[i + 4:i + 2 + n]
+        if m == 0xDB:
+            k = 0
+            while k < len(p):
+                if p[k] >> 4:
+                    raise JpegError("16-bit quantiser")
+                t = np.zeros(64, np.int32)
+                t[ZIGZAG] = np.frombuffer(p[k + 1:k + 65], np.uint8)
+                out["q"][p[k] & 15] = t
+                k += 65
+        elif m == 0xC4:
+            k = 0
+            while k < len(p):
+                bits = list(p[k + 1:k + 17])
+                nv = sum(bits)
+                out["huff"][(p[k] >> 4, p[k] & 15)] = (bits, list(p[k + 17:k + 17 + nv]))
+                k += 17 + nv
+        elif m == 0xC0:
+            if p[0] != 8:
+                raise JpegError("precision")
+            out["h"], out["w"] = int.from_bytes(p[1:3], "big"), int.from_bytes(p[3:5], "big")
+            out["comps"] = [(p[6 + 3 * c], p[7 + 3 * c] >> 4, p[7 + 3 * c] & 15, p[8 + 3 * c]) for c in range(p[5])]
+        elif m in (0xC1, 0xC2, 0xC3, 0xC5, 0xC6, 0xC7, 0xC9, 0xCA, 0xCB, 0xCD, 0xCE, 0xCF):
+            raise JpegError("not baseline")
+        elif m == 0xDD:
+            out["restart"] = int.from_bytes(p[:2], "big")
+        elif m == 0xDA:
+            out["scan"] = [(p[1 + 2 * c], p[2 + 2 * c] >> 4, p[2 + 2 * c] & 15) for c in range(p[0])]
+            out["data_start"] = i + 2 + n
+            return out
+        i += 2 + n
+
+
+def _decode_tables(spec):
+    """T.81 F.2.2.3: mincode / maxcode / valptr per code length"""
+    bits, vals = spec
+    mincode, maxcode, valptr, code, k = [0] * 17, [-1] * 17, [0] * 17, 0, 0
+    for length in range(1, 17):
+        if bits[length - 1]:
+            valptr[length], mincode[length] = k, code
+            code += bits[length - 1]
+            k += bits[length - 1]
+            maxcode[length] = code - 1
+        code <<= 1
+    return mincode, maxcode, valptr, vals
+
+
+class _BitReader:
+    def __init__(self, data):
+        self.d, self.i, self.acc, self.n = data, 0, 0, 0
+
+    def bit(self):
+        if self.n == 0:
+            if self.i >= len(self.d):
+                self.acc, self.n = 0xFF, 8            # past the end: 1-bits (a truncated stream decodes to something, never reads outside)
+            else:
+                b = self.d[self.i]
+                self.i += 1
+                if b == 0xFF and self.i < len(self.d) and self.d[self.i] == 0:
+                    self.i += 1
+                self.acc, self.n = b, 8
+        self.n -= 1
+        return (self.acc >> self.n) & 1
+
+    def bits(self, k):
+        v = 0
+        for _ in range(k):
+            v = (v << 1) | self.bit()
+        return v
+
+
+def _decode_symbol(br, tab):
+    mincode, maxcode, valptr, vals = tab
+    code = 0
+    for length in range(1, 17):
+        code = (code << 1) | br.bit()
+        if maxcode[length] >= 0 and code <= maxcode[length] and code >= mincode[length]:
+            return vals[valptr[length] + code - mincode[length]]
+    raise JpegError("invalid Huffman code")
+
+
+def _extend(v, s):
+    return v if s == 0 or v >= (1 << (s - 1)) else v - (1 << s) + 1
+
+
+def split_intervals(data):
+    """entropy-coded segment -> list of intervals (bytes between RSTn markers), the segment ends at the first other marker"""
+    out, start, i = [], 0, 0
+    while i + 1 < len(data):
+        if data[i] == 0xFF:
+            nx = data[i + 1]
+            if 0xD0 <= nx <= 0xD7:
+                out.append(data[start:i])
+                start = i + 2
+                i += 2
+                continue
+            if nx != 0:
+                break
+            i += 1
+        i += 1
+    else:
+        i = len(data)
+    out.append(data[start:i])
+    return out
+
+
+def decode_coefficients(j):
+    """-> (header, int32 [mh][mw][6][64] quantised coefficients in ZIGZAG order)"""
+    hd = parse_header(j)
+    if [c[1:3] for c in hd.get("comps", [])] != [(2, 2), (1, 1), (1, 1)] or len(hd["scan"]) != 3:
+        raise JpegError("only YCbCr 4:2:0 in one scan")
+    tabs = {}
+    for key, std in (((0, 0), DC_LUMA), ((1, 0), AC_LUMA), ((0, 1), DC_CHROMA), ((1, 1), AC_CHROMA)):
+        tabs[key] = _decode_tables(hd["huff"].get(key, std))          # AVI MJPEG frames may omit DHT: the Annex K tables are implied
+    for key, spec in hd["huff"].items():
+        tabs[key] = _decode_tables(spec)
+    w, h = hd["w"], hd["h"]
+    mw, mh = (w + 15) // 16, (h + 15) // 16
+    coef = np.zeros((mh * mw, 6, 64), np.int32)
+    ri = hd["restart"] if hd["restart"] else mh * mw
+    ivs = split_intervals(j[hd["data_start"]:])
+    sel = [hd["scan"][0]] * 4 + [hd["scan"][1], hd["scan"][2]]
+    for k, seg in enumerate(ivs):
+        br, pred = _BitReader(seg), [0, 0, 0]
+        for m in range(k * ri, min((k + 1) * ri, mh * mw)):
+            for bi in range(6):
+                comp = 0 if bi < 4 else bi - 3
+                _, td, ta = sel[bi]
+                s = _decode_symbol(br, tabs[(0, td)])
+                pred[comp] += _extend(br.bits(s), s)
+                coef[m, bi, 0] = pred[comp]
+                kk = 1
+                while kk < 64:
+                    rs = _decode_symbol(br, tabs[(1, ta)])
+                    r, s = rs >> 4, rs & 15
+                    if s == 0:
+                        if r != 15:
+                            break
+                        kk += 16
+                        continue
+                    kk += r
+                    if kk > 63:
+                        raise JpegError("coefficient index out of range")
+                    coef[m, bi, kk] = _extend(br.bits(s), s)
+                    kk += 1
+    return hd, coef.reshape(mh, mw, 6, 64)
+
+
+def reconstruct(hd, coef):
+    """quantised coefficients -> BGR u8 [h][w][3]"""
+    mh, mw = coef.shape[:2]
+    m = dct_matrix()
+    tq = [hd["comps"][0][3]] * 4 + [hd["comps"][1][3], hd["comps"][2][3]]
+    planes = []
+    for bi in range(6):
+        q = hd["q"][tq[bi]].astype(np.int64)
+        nat = np.zeros(coef.shape[:2] + (64,), np.int64)
+        nat[..., ZIGZAG] = coef[:, :, bi, :]
+        s = np.clip(nat * q, -4096, 4095).reshape(mh, mw, 8, 8)                       # [v][u]
+        t = (np.einsum("vy,...vu->...yu", m, s) + 512) >> 10                          # columns
+        p = (np.einsum("ux,...yu->...yx", m, t) + 32768) >> 16                        # rows
+        planes.append(np.clip(p + 128, 0, 255))
+    y = np.zeros((mh * 16, mw * 16), np.int64)
+    for bi in range(4):
+        blk = planes[bi]                                                              # [mh][mw][8][8]
+        oy, ox = (bi >> 1) * 8, (bi & 1) * 8
+        for r in range(8):
+            y[oy + r::16, :].reshape(mh, mw, 16)[:, :, ox:ox + 8] = blk[:, :, r, :]
+    def up(pl):
+        full = pl.transpose(0, 2, 1, 3).reshape(mh * 8, mw * 8)
+        return np.repeat(np.repeat(full, 2, axis=0), 2, axis=1)
+    cb, cr = up(planes[4]) - 128, up(planes[5]) - 128
+    r = y + ((91881 * cr + 32768) >> 16)
+    g = y + ((-22554 * cb - 46802 * cr + 32768) >> 16)
+    b = y + ((116130 * cb + 32768) >> 16)
+    out = np.clip(np.stack([b, g, r], -1), 0, 255).astype(np.uint8)
+    return out[:hd["h"], :hd["w"]]
+
+
+def decode_frame(j):
+    hd, coef = decode_coefficients(j)
+    return reconstruct(hd, coef)

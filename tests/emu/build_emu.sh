@@ -7,9 +7,9 @@ root=$(cd "$here/../.." && pwd)
 src="$root/live-video-magnification_amd/csrc"
 mkdir -p "$here/_build"
 objs=""
-for f in lvm_api.hip labconv.hip laplace.hip riesz.hip color.hip preprocess.hip compose.hip mjpeg.hip lab_tables.cpp; do
+for f in lvm_api.hip labconv.hip laplace.hip riesz.hip color.hip preprocess.hip compose.hip mjpeg.hip mjpeg_decode.hip lab_tables.cpp; do
   o="$here/_build/$f.o"
-  if [ ! -f "$o" ] || [ "$src/$f" -nt "$o" ] || [ "$src/lvm_internal.h" -nt "$o" ] || [ "$src/pyramid.h" -nt "$o" ] || [ "$src/lab_lut.h" -nt "$o" ] || [ "$here/include/hip/hip_runtime.h" -nt "$o" ] || [ "$here/include/lvm_gfx950.h" -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$src/$f" -nt "$o" ] || [ "$src/lvm_internal.h" -nt "$o" ] || [ "$src/pyramid.h" -nt "$o" ] || [ "$src/lab_lut.h" -nt "$o" ] || [ "$src/mjpeg_tables.h" -nt "$o" ] || [ "$here/include/hip/hip_runtime.h" -nt "$o" ] || [ "$here/include/lvm_gfx950.h" -nt "$o" ]; then
     g++ -x c++ -std=c++17 -O2 -march=x86-64-v3 -ffp-contract=off -fPIC -I"$here/include" -I"$root/include" -I"$src" \
         -Wno-unused-function -c "$src/$f" -o "$o" &
   fi

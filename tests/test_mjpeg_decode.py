@@ -1,0 +1,210 @@
+"""Motion-JPEG decode onto the device (the decode half): `cv::VideoCapture::read` on an AVI / Motion-JPEG file
+(source/FileSource.cpp:99).
+
+The entropy layer of JPEG is exact by the standard, the arithmetic behind it (IDCT, chroma upsampling, colour conversion) is the decoder's:
+oracle/mjpeg_oracle.py::decode_frame restates ONE such decoder in integers and is pinned here against Pillow's libjpeg -- on this
+repository's streams AND on libjpeg's own (no restart markers, per-image optimised Huffman tables): the two decoders agree to within the
+difference between libjpeg's smoothed and the oracle's replicated chroma (PSNR and largest-difference bars below), and both are equally
+close to the source.  The HIP decoder is BIT-identical to the oracle (emulation build here, the GPU through the C ABI)."""
+import ctypes
+import io
+
+import numpy as np
+import pytest
+
+from oracle import mjpeg_oracle as mo
+from test_mjpeg import decode as pil_decode, texture
+
+PIL_Image = pytest.importorskip("PIL.Image")
+
+
+def pil_encode(f, q, **kw):
+    buf = io.BytesIO()
+    PIL_Image.fromarray(f[..., ::-1]).save(buf, "JPEG", quality=q, **kw)
+    return buf.getvalue()
+
+
+STREAMS = [(64, 48, 75), (100, 70, 95), (33, 21, 50), (16, 16, 100), (17, 9, 30), (1, 1, 75), (130, 34, 100)]
+
+
+def streams_of(w, h, q, seed=0):
+    f = texture(w, h, seed=w + h + seed)
+    return f, [mo.encode_frame(f, q), pil_encode(f, q, subsampling=2), pil_encode(f, q, subsampling=2, optimize=True)]
+
+
+@pytest.mark.parametrize("w,h,q", STREAMS)
+def test_oracle_decoder_agrees_with_libjpeg(w, h, q):
+    f, js = streams_of(w, h, q)
+    for j in js:
+        mine, theirs = mo.decode_frame(j), pil_decode(j)
+        assert mine.shape == theirs.shape == f.shape
+        if w * h >= 256:
+            assert mo.psnr(mine, theirs) > 40.0 and np.abs(mine.astype(int) - theirs).max() <= 16
+            assert mo.psnr(mine, f) > mo.psnr(theirs, f) - 0.3
+    assert np.array_equal(mo.decode_coefficients(js[1])[1], mo.decode_coefficients(js[2])[1])      # the same coefficients under both Huffman codes
+
+
+def test_oracle_round_trip_is_the_quantiser_and_nothing_else():
+    f = texture(48, 32)
+    c = mo.coefficients(f, 90)
+    hd, got = mo.decode_coefficients(mo.encode_frame(f, 90))
+    assert np.array_equal(got, c) and hd["restart"] == 3 and (hd["w"], hd["h"]) == (48, 32)
+
+
+def _strip_dht(j):
+    """the frame without its Huffman tables (as AVI MJPEG frames may be stored)"""
+    out, i = bytearray(j[:2]), 2
+    while True:
+        m, n = j[i + 1], int.from_bytes(j[i + 2:i + 4], "big")
+        if m != 0xC4:
+            out += j[i:i + 2 + n]
+        i += 2 + n
+        if m == 0xDA:
+            return bytes(out + j[i:])
+
+
+def _decode_and_compare(lvm, lib, alloc, read):
+    ctx = lvm.Context(0, 1, lib)
+    try:
+        for (w, h, q) in STREAMS:
+            f, js = streams_of(w, h, q)
+            js.append(_strip_dht(js[0]))
+            f2, more = streams_of(w, h, max(1, q - 20), seed=5)                       # other tables in the same batch
+            js += more[:2]
+            pad = 5 if w % 2 else 0
+            buf = alloc(len(js), h, w * 3 + pad)
+            ctx.mjpeg_decode_device(js, w, h, buf[0], stride=w * 3 + pad, frame_stride=(w * 3 + pad) * h)
+            got = read(buf)
+            for k, j in enumerate(js):
+                want = mo.decode_frame(j)
+                assert np.array_equal(got[k, :, :w * 3].reshape(h, w, 3), want), "%dx%d q%d stream %d" % (w, h, q, k)
+                assert (got[k, :, w * 3:] == 0xEE).all()
+    finally:
+        ctx.close()
+
+
+def _numpy_alloc():
+    def alloc(n, h, row):
+        a = np.full((n, h, row), 0xEE, np.uint8)
+        return (ctypes.c_void_p(a.ctypes.data), a)
+    return alloc, (lambda b: b[1])
+
+
+def test_mjpeg_decode_emu_bit_identical_to_the_oracle(lvm, emu):
+    _decode_and_compare(lvm, emu, *_numpy_alloc())
+
+
+def test_mjpeg_decode_emu_refuses_what_it_does_not_decode(lvm, emu):
+    ctx = lvm.Context(0, 1, emu)
+    try:
+        f = texture(64, 48)
+        out = np.zeros((1, 48, 64 * 3), np.uint8)
+        p = ctypes.c_void_p(out.ctypes.data)
+        good = mo.encode_frame(f, 80)
+        for bad, why in [(pil_encode(f, 80, subsampling=0), "4:2:0"), (pil_encode(f, 80, subsampling=2, progressive=True), "baseline"),
+                         (mo.encode_frame(texture(32, 48), 80), "size"), (good[:200], "marker|segment"), (b"\x00\x01" + good, "SOI")]:
+            with pytest.raises(lvm.LvmError, match=why):
+                ctx.mjpeg_decode_device([bad], 64, 48, p)
+        # wrong restart-marker count
+        cut = good.replace(b"\xff\xd1", b"\xff\x00", 1)
+        with pytest.raises(lvm.LvmError, match="restart"):
+            ctx.mjpeg_decode_device([cut], 64, 48, p)
+        # entropy data overwritten with zeros: decodes (zeros are valid codes) or is refused, but never reads outside; then the context still works
+        hd = mo.parse_header(good)
+        junk = good[:hd["data_start"]] + bytes(len(good) - hd["data_start"] - 2) + good[-2:]
+        try:
+            ctx.mjpeg_decode_device([junk], 64, 48, p)
+        except lvm.LvmError:
+            pass
+        ctx.mjpeg_decode_device([good], 64, 48, p)
+        assert np.array_equal(out[0].reshape(48, 64, 3), mo.decode_frame(good))
+    finally:
+        ctx.close()
+
+
+def test_mjpeg_round_trip_emu(lvm, emu):
+    """encode on the device, decode on the device: the frame comes back within the quantisation error"""
+    ctx = lvm.Context(0, 1, emu)
+    try:
+        f = np.stack([texture(80, 48, seed=k) for k in range(3)])
+        js = ctx.mjpeg_encode_device(ctypes.c_void_p(f.ctypes.data), 80, 48, 3, quality=92)
+        out = np.zeros_like(f)
+        ctx.mjpeg_decode_device(js, 80, 48, ctypes.c_void_p(out.ctypes.data))
+        for k in range(3):
+            assert np.array_equal(out[k], mo.decode_frame(js[k])) and mo.psnr(out[k], f[k]) > 30.0
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_mjpeg_decode_gpu_bit_identical_to_the_oracle(lvm, hip):
+    import torch
+
+    def alloc(n, h, row):
+        t = torch.full((n, h, row), 0xEE, dtype=torch.uint8, device="cuda")
+        return (ctypes.c_void_p(t.data_ptr()), t)
+    _decode_and_compare(lvm, hip, alloc, lambda b: b[1].cpu().numpy())
+
+
+@pytest.mark.gpu
+def test_mjpeg_round_trip_gpu_1080p(lvm, hip):
+    """a batch of 1080p frames: GPU encode -> GPU decode, and libjpeg's stream of the same frame (one interval per frame) -> GPU decode"""
+    import torch
+    w, h, n = 1920, 1080, 4
+    f = np.stack([texture(w, h, seed=k) for k in range(n)])
+    ctx = lvm.Context(0, 1, hip)
+    try:
+        d = torch.from_numpy(f).cuda()
+        js = ctx.mjpeg_encode_device(ctypes.c_void_p(d.data_ptr()), w, h, n, quality=90)
+        out = torch.zeros_like(d)
+        ctx.mjpeg_decode_device(js, w, h, ctypes.c_void_p(out.data_ptr()))
+        got = out.cpu().numpy()
+        for k in range(n):
+            assert mo.psnr(got[k], f[k]) > 30.0 and mo.psnr(got[k], pil_decode(js[k])) > 40.0
+        lj = [pil_encode(f[k], 90, subsampling=2) for k in range(2)]
+        ctx.mjpeg_decode_device(lj, w, h, ctypes.c_void_p(out.data_ptr()))
+        got = out.cpu().numpy()
+        for k in range(2):
+            assert mo.psnr(got[k], pil_decode(lj[k])) > 40.0
+        assert np.array_equal(got[0][:32], mo.reconstruct(*_first_rows(lj[0], 2))[:32])
+    finally:
+        ctx.close()
+
+
+def _first_rows(j, mcu_rows):
+    """header + coefficients of the first MCU rows of a stream (the whole 1080p frame through the Python oracle would take minutes)"""
+    hd, coef = mo.decode_coefficients(j) if False else (mo.parse_header(j), None)
+    hd2 = dict(hd)
+    full = _decode_prefix(j, hd, mcu_rows)
+    hd2["h"] = mcu_rows * 16
+    return hd2, full
+
+
+def _decode_prefix(j, hd, mcu_rows):
+    tabs = {}
+    for key, std in (((0, 0), mo.DC_LUMA), ((1, 0), mo.AC_LUMA), ((0, 1), mo.DC_CHROMA), ((1, 1), mo.AC_CHROMA)):
+        tabs[key] = mo._decode_tables(hd["huff"].get(key, std))
+    mw = (hd["w"] + 15) // 16
+    coef = np.zeros((mcu_rows * mw, 6, 64), np.int32)
+    br, pred = mo._BitReader(mo.split_intervals(j[hd["data_start"]:])[0]), [0, 0, 0]
+    sel = [hd["scan"][0]] * 4 + [hd["scan"][1], hd["scan"][2]]
+    for m in range(mcu_rows * mw):
+        for bi in range(6):
+            comp = 0 if bi < 4 else bi - 3
+            _, td, ta = sel[bi]
+            s = mo._decode_symbol(br, tabs[(0, td)])
+            pred[comp] += mo._extend(br.bits(s), s)
+            coef[m, bi, 0] = pred[comp]
+            kk = 1
+            while kk < 64:
+                rs = mo._decode_symbol(br, tabs[(1, ta)])
+                r, s = rs >> 4, rs & 15
+                if s == 0:
+                    if r != 15:
+                        break
+                    kk += 16
+                    continue
+                kk += r
+                coef[m, bi, kk] = mo._extend(br.bits(s), s)
+                kk += 1
+    return coef.reshape(mcu_rows, mw, 6, 64)

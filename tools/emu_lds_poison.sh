@@ -8,7 +8,7 @@ set -e
 root=$(cd "$(dirname "$0")/.." && pwd); here=$root/tests/emu; src=$root/live-video-magnification_amd/csrc
 out=${LVM_LDSP_DIR:-/tmp/lvm_emu_ldspoison}; mkdir -p "$out"
 CXX=${LVM_CLANGXX:-/opt/rocm/lib/llvm/bin/clang++}
-for f in lvm_api.hip labconv.hip laplace.hip riesz.hip color.hip preprocess.hip compose.hip mjpeg.hip lab_tables.cpp; do
+for f in lvm_api.hip labconv.hip laplace.hip riesz.hip color.hip preprocess.hip compose.hip mjpeg.hip mjpeg_decode.hip lab_tables.cpp; do
   "$CXX" -x c++ -std=c++17 -O1 -march=x86-64-v3 -ffp-contract=off -fPIC -DHIPEMU_POISON_LDS=1 \
       -I"$here/include" -I"$root/include" -I"$src" -Wno-unused-function -c "$src/$f" -o "$out/$f.o" &
 done
