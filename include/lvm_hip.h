@@ -218,7 +218,11 @@ int  lvm_export_frames(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_
  *                              JPEG frames in host memory (jpegs[offsets[i] .. offsets[i + 1])) -> BGR frames of w x h in DEVICE memory.
  *                              Baseline 4:2:0 in one scan, any tables, with or without restart intervals; anything else, a size other
  *                              than w x h or a malformed stream is LVM_ERR_INVALID (lvm_last_error says which frame and why).  Synchronous. */
+/*   lvm_export_mjpeg_frames    lvm_export_frames_mjpeg with JPEG frames IN as well (an AVI / Motion-JPEG source file): decode, chain, compose and
+ *                              encode all on the device, only compressed bytes cross PCIe in either direction (file -> file export).           */
 size_t lvm_mjpeg_bound(int w, int h);
+int  lvm_export_mjpeg_frames(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames, const uint8_t* jpegs,
+                             const size_t* in_offsets, int w, int h, int quality, uint8_t* out, size_t out_capacity, size_t* offsets, int* produced);
 int  lvm_mjpeg_decode_device(lvm_ctx* ctx, const uint8_t* jpegs, const size_t* offsets, int n_frames, int w, int h, uint8_t* d_bgr,
                              ptrdiff_t stride, ptrdiff_t frame_stride);
 int  lvm_mjpeg_encode_device(lvm_ctx* ctx, const uint8_t* d_bgr, int w, int h, ptrdiff_t stride, ptrdiff_t frame_stride, int n_frames,

@@ -100,7 +100,7 @@ SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process
            "lvm_profile_entry", "lvm_algorithmic_bytes", "lvm_export_geometry", "lvm_export_frames",
            "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process", "lvm_chain_process_batch",
            "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free", "lvm_compose_geometry", "lvm_compose_device", "lvm_chain_process_batch_ex",
-           "lvm_chain_present", "lvm_mjpeg_bound", "lvm_mjpeg_encode_device", "lvm_export_frames_mjpeg", "lvm_mjpeg_decode_device"]
+           "lvm_chain_present", "lvm_mjpeg_bound", "lvm_mjpeg_encode_device", "lvm_export_frames_mjpeg", "lvm_mjpeg_decode_device", "lvm_export_mjpeg_frames"]
 
 
 def bind(lib):
@@ -158,6 +158,8 @@ def bind(lib):
     lib.lvm_mjpeg_bound.restype = C.c_size_t
     lib.lvm_mjpeg_encode_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.lvm_mjpeg_decode_device.argtypes = [vp, vp, C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, vp, C.c_ssize_t, C.c_ssize_t]
+    lib.lvm_export_mjpeg_frames.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), C.c_int, C.c_int, vp, C.POINTER(C.c_size_t), C.c_int, C.c_int,
+                                            C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t), ip]
     lib.lvm_export_frames_mjpeg.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), C.c_int, C.c_int, C.POINTER(vp), C.c_int, C.c_int,
                                             C.c_int, C.c_ssize_t, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t), ip]
     lib.lvm_compose_geometry.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, ip, ip]
@@ -335,6 +337,23 @@ class Context:
         blob = np.frombuffer(b"".join(jpegs), dtype=np.uint8)
         offs = (C.c_size_t * (len(jpegs) + 1))(*np.concatenate([[0], np.cumsum([len(j) for j in jpegs])]).tolist())
         self._check(self.lib.lvm_mjpeg_decode_device(self.h, blob.ctypes.data, offs, len(jpegs), w, h, d_ptr, stride, frame_stride))
+
+    def export_mjpeg_frames(self, jpegs, w, h, cpre, cparams, split, quality=75, capacity=None):
+        """lvm_export_mjpeg_frames: JPEG frames in, JPEG frames (of the composed canvases) out.  Returns (JPEG frames, produced flags)."""
+        cw, chh = C.c_int(0), C.c_int(0)
+        self._check(self.lib.lvm_export_geometry(C.byref(cpre), int(split), w, h, 3, C.byref(cw), C.byref(chh)))
+        if cw.value <= 0 or chh.value <= 0:
+            raise LvmError("export_mjpeg_frames: empty canvas for this geometry")
+        n = len(jpegs)
+        blob = np.frombuffer(b"".join(jpegs), dtype=np.uint8)
+        ioffs = (C.c_size_t * (n + 1))(*np.concatenate([[0], np.cumsum([len(j) for j in jpegs])]).tolist())
+        cap = int(self.lib.lvm_mjpeg_bound(cw.value, chh.value)) * n if capacity is None else int(capacity)
+        out = np.empty(cap, dtype=np.uint8)
+        offs = (C.c_size_t * (n + 1))()
+        produced = (C.c_int * n)()
+        self._check(self.lib.lvm_export_mjpeg_frames(self.h, C.byref(cpre), C.byref(cparams), int(split), n, blob.ctypes.data, ioffs, w, h, int(quality),
+                                                     out.ctypes.data, cap, offs, produced))
+        return [out[offs[i]:offs[i + 1]].tobytes() for i in range(n)], [bool(x) for x in produced]
 
     def export_frames_mjpeg(self, frames, cpre, cparams, split, quality=75, capacity=None):
         """lvm_export_frames_mjpeg: Exporter::run's loop body with the canvases encoded on the device.  Returns (JPEG frames, produced flags)."""

@@ -525,14 +525,19 @@ int lvm_export_geometry(const lvm_preprocess_params* pp, int split, int w, int h
 // single 32-frame batch -- or 32 per-frame calls -- gives.
 // lvm_export_frames and lvm_export_frames_mjpeg: the same three-queue loop; with `mj` the canvases stay on the device and are encoded there
 struct MjpegSink { int quality; uint8_t* out; size_t capacity; size_t* offsets; };
+// ... and with `js` the frames arrive as JPEG (lvm_export_mjpeg_frames): decoded on the device by the upload queue, the ROI is a view into
+// the decoded frame instead of the pitch of a copy
+struct JpegSource { const uint8_t* bytes; const size_t* offsets; };
 static int export_frames_impl(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames,
                               const uint8_t* const* frames, int w, int h, int channels, ptrdiff_t in_stride, uint8_t* const* canvases,
-                              ptrdiff_t canvas_stride, int* produced, const MjpegSink* mj) {
-    if (!c || !pp || !p || !frames || (!canvases && !mj) || !produced || n_frames < 1) return LVM_ERR_INVALID;
+                              ptrdiff_t canvas_stride, int* produced, const MjpegSink* mj, const JpegSource* js = nullptr) {
+    if (!c || !pp || !p || (!frames && !js) || (!canvases && !mj) || !produced || n_frames < 1) return LVM_ERR_INVALID;
     if (mj && (!mj->out || !mj->offsets)) return LVM_ERR_INVALID;
+    if (js && (!js->bytes || !js->offsets || channels != 3)) return LVM_ERR_INVALID;
+    if (js) in_stride = (ptrdiff_t)w * 3;
     if (c->nstreams != 1) { c->err = "lvm_export_frames needs a 1-stream context"; return LVM_ERR_INVALID; }
     if (w <= 0 || h <= 0 || (channels != 1 && channels != 3) || in_stride < (ptrdiff_t)w * channels) { c->err = "bad frame arguments"; return LVM_ERR_INVALID; }
-    for (int k = 0; k < n_frames; ++k) { produced[k] = 0; if (!frames[k] || (!mj && !canvases[k])) { c->err = "null frame pointer"; return LVM_ERR_INVALID; } }
+    for (int k = 0; k < n_frames; ++k) { produced[k] = 0; if ((!js && !frames[k]) || (!mj && !canvases[k])) { c->err = "null frame pointer"; return LVM_ERR_INVALID; } }
     LVM_HIP_TRY(c, hipSetDevice(c->device));
     int rx, ry, rw, rh, ow, oh, och, pw, ph, cw, chh;
     lvm::preprocess_geometry(*pp, w, h, channels, &rx, &ry, &rw, &rh, &ow, &oh, &och);
@@ -558,7 +563,11 @@ static int export_frames_impl(lvm_ctx* c, const lvm_preprocess_params* pp, const
     // (ChainBuilder.cpp:25).  With grayscale on a BGR source that is the cropped / decimated colour frame.
     const bool gray_tap = och == 1 && channels == 3 && split != LVM_SPLIT_NONE;
     const size_t tap_row = (size_t)ow * 3, tap_bytes = tap_row * oh;
-    int rc = reserve(c->d_pre_in, c->pre_in_cap, roi_bytes * n_frames); if (rc != LVM_OK) return rc;
+    // where stage 1 leaves frame k: the cropped copy (host frames), or the ROI inside the decoded frame (JPEG frames)
+    const size_t full_row = (size_t)w * channels, full_bytes = full_row * h;
+    const size_t src_row = js ? full_row : roi_row, src_fbytes = js ? full_bytes : roi_bytes;
+    int rc = reserve(c->d_pre_in, c->pre_in_cap, src_fbytes * n_frames); if (rc != LVM_OK) return rc;
+    const uint8_t* src_base = js ? c->d_pre_in + (size_t)ry * full_row + (size_t)rx * channels : c->d_pre_in;
     rc = reserve(c->d_pre_out, c->pre_out_cap, out_bytes * n_frames); if (rc != LVM_OK) return rc;
     rc = reserve(c->d_chain_out, c->chain_out_cap, out_bytes * n_frames); if (rc != LVM_OK) return rc;
     rc = reserve(c->d_canvas, c->canvas_cap, can_bytes * n_frames); if (rc != LVM_OK) return rc;
@@ -575,16 +584,26 @@ static int export_frames_impl(lvm_ctx* c, const lvm_preprocess_params* pp, const
     auto drain = [&]() { (void)hipStreamSynchronize(c->up_stream); (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(c->down_stream); };
 #define LVM_EXPORT_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e_); drain(); return LVM_ERR_HIP; } } while (0)
     const bool identity = ow == rw && oh == rh && och == channels;      // PreprocessProcessor.cpp:15, GrayscaleProcessor.cpp:8-9
-    const uint8_t* mag_base = identity ? c->d_pre_in : c->d_pre_out;
+    const uint8_t* mag_base = identity ? src_base : c->d_pre_out;
+    const size_t mag_row = identity ? src_row : out_row, mag_fbytes = identity ? src_fbytes : out_bytes;
     lvm_params mp = *p;
     mp.preprocess_key = preprocess_key_of(*pp);
     const int saved_depth = c->pipeline_depth;
+    if (js) {
+        // JPEG frames: only the compressed bytes cross PCIe, and ALL frames of the call are decoded by one set of launches -- Huffman decoding
+        // is serial inside a restart interval (a lane each), its time is a latency that does not grow with the number of frames
+        rc = lvm::mjpeg_decode_begin(c, js->bytes, js->offsets, n_frames, w, h, c->up_stream);
+        if (rc == LVM_OK) rc = lvm::mjpeg_decode_enqueue(c, 0, n_frames, c->d_pre_in, (ptrdiff_t)full_row, (ptrdiff_t)full_bytes, c->up_stream);
+        if (rc != LVM_OK) { drain(); return rc; }
+    }
     for (int q = 0; q < nchunks; ++q) {
         const int f0 = q * chunk, nf = (f0 + chunk <= n_frames) ? chunk : n_frames - f0;
         // stage 1 (up_stream): only the ROI rows cross PCIe (the crop is the pitch of the 2-D copy)
-        for (int k = f0; k < f0 + nf; ++k)
-            LVM_EXPORT_TRY(hipMemcpy2DAsync(c->d_pre_in + (size_t)k * roi_bytes, roi_row, frames[k] + (size_t)ry * in_stride + (size_t)rx * channels,
-                                            (size_t)in_stride, roi_row, (size_t)rh, hipMemcpyHostToDevice, c->up_stream));
+        if (!js) {
+            for (int k = f0; k < f0 + nf; ++k)
+                LVM_EXPORT_TRY(hipMemcpy2DAsync(c->d_pre_in + (size_t)k * roi_bytes, roi_row, frames[k] + (size_t)ry * in_stride + (size_t)rx * channels,
+                                                (size_t)in_stride, roi_row, (size_t)rh, hipMemcpyHostToDevice, c->up_stream));
+        }
         LVM_EXPORT_TRY(hipEventRecord(c->ev_up[q], c->up_stream));
         // stage 2 (the context's stream): Preprocess + Grayscale, the magnifier as one temporal batch, compose
         LVM_EXPORT_TRY(hipStreamWaitEvent(s, c->ev_up[q], 0));
@@ -592,23 +611,25 @@ static int export_frames_impl(lvm_ctx* c, const lvm_preprocess_params* pp, const
             lvm_preprocess_params qp = *pp;
             qp.roi_enabled = 0;                                          // already cropped by the copy
             for (int k = f0; k < f0 + nf; ++k) {                         // (stateless: a frame of the batch is one more "stream" of a 1-stream context)
-                rc = lvm::preprocess_device(c, qp, c->d_pre_in + (size_t)k * roi_bytes, rw, rh, channels, (ptrdiff_t)roi_row, (ptrdiff_t)roi_bytes,
+                rc = lvm::preprocess_device(c, qp, src_base + (size_t)k * src_fbytes, rw, rh, channels, (ptrdiff_t)src_row, (ptrdiff_t)src_fbytes,
                                             c->d_pre_out + (size_t)k * out_bytes, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, s,
                                             gray_tap ? c->d_pre_tap + (size_t)k * tap_bytes : nullptr, (ptrdiff_t)tap_row, (ptrdiff_t)tap_bytes);
                 if (rc != LVM_OK) { drain(); return rc; }
             }
         }
         c->pipeline_depth = 0;                                           // (the synchronous surface completes its own frames)
-        rc = lvm_process_device_frames(c, &mp, nf, mag_base + (size_t)f0 * out_bytes, ow, oh, och, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, (ptrdiff_t)out_bytes,
+        rc = lvm_process_device_frames(c, &mp, nf, mag_base + (size_t)f0 * mag_fbytes, ow, oh, och, (ptrdiff_t)mag_row, (ptrdiff_t)mag_fbytes, (ptrdiff_t)mag_fbytes,
                                        c->d_chain_out + (size_t)f0 * out_bytes, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, (ptrdiff_t)out_bytes, produced + f0, s);
         c->pipeline_depth = saved_depth;
         if (rc != LVM_OK) { drain(); return rc; }
         for (int k = f0; k < f0 + nf; ++k) {
-            const uint8_t* seen = mag_base + (size_t)k * out_bytes;                                 // what the magnifier saw
-            const uint8_t* proc = produced[k] ? c->d_chain_out + (size_t)k * out_bytes : seen;      // MagnificationProcessor.cpp:61
+            const uint8_t* seen = mag_base + (size_t)k * mag_fbytes;                                // what the magnifier saw
+            const bool pr = produced[k] != 0;
+            const uint8_t* proc = pr ? c->d_chain_out + (size_t)k * out_bytes : seen;               // MagnificationProcessor.cpp:61
             const uint8_t* orig = gray_tap ? c->d_pre_tap + (size_t)k * tap_bytes : seen;           // ChainBuilder.cpp:25
-            rc = lvm::compose_device(c, split, orig, ow, oh, gray_tap ? 3 : och, (ptrdiff_t)(gray_tap ? tap_row : out_row), (ptrdiff_t)(gray_tap ? tap_bytes : out_bytes),
-                                     proc, ow, oh, och, (ptrdiff_t)out_row, (ptrdiff_t)out_bytes, c->d_canvas + (size_t)k * can_bytes, (ptrdiff_t)can_row, (ptrdiff_t)can_bytes, s);
+            rc = lvm::compose_device(c, split, orig, ow, oh, gray_tap ? 3 : och, (ptrdiff_t)(gray_tap ? tap_row : mag_row), (ptrdiff_t)(gray_tap ? tap_bytes : mag_fbytes),
+                                     proc, ow, oh, och, (ptrdiff_t)(pr ? out_row : mag_row), (ptrdiff_t)(pr ? out_bytes : mag_fbytes), c->d_canvas + (size_t)k * can_bytes,
+                                     (ptrdiff_t)can_row, (ptrdiff_t)can_bytes, s);
             if (rc != LVM_OK) { drain(); return rc; }
         }
         LVM_EXPORT_TRY(hipEventRecord(c->ev_done[q], s));
@@ -627,15 +648,17 @@ static int export_frames_impl(lvm_ctx* c, const lvm_preprocess_params* pp, const
     }
 #undef LVM_EXPORT_TRY
     lvm::mark_enqueued(c, s);
+    int drc = LVM_OK;
+    if (js) drc = lvm::mjpeg_decode_finish(c, c->up_stream);                                    // a malformed input frame fails the call
     if (mj) {
         rc = lvm::mjpeg_finish(c, (size_t)n_frames, mj->out, mj->offsets, c->down_stream);       // waits for the encoder, then the compressed bytes come down in one copy
         (void)hipStreamSynchronize(s);
         (void)hipStreamSynchronize(c->up_stream);
-        return rc;
+        return drc != LVM_OK ? drc : rc;
     }
     LVM_HIP_TRY(c, hipStreamSynchronize(c->down_stream));     // (the last canvases: everything on `s` and `up_stream` precedes them)
     LVM_HIP_TRY(c, hipStreamSynchronize(s));
-    return LVM_OK;
+    return drc;
 }
 
 int lvm_export_frames(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames,
@@ -660,6 +683,13 @@ int lvm_mjpeg_decode_device(lvm_ctx* c, const uint8_t* jpegs, const size_t* offs
     const int rc = lvm::mjpeg_decode_device(c, jpegs, offsets, n_frames, w, h, d_bgr, stride, frame_stride, c->own_stream);
     if (rc == LVM_OK) lvm::mark_enqueued(c, c->own_stream);
     return rc;
+}
+
+int lvm_export_mjpeg_frames(lvm_ctx* c, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames, const uint8_t* jpegs,
+                            const size_t* in_offsets, int w, int h, int quality, uint8_t* out, size_t out_capacity, size_t* offsets, int* produced) {
+    const MjpegSink mj{quality, out, out_capacity, offsets};
+    const JpegSource js{jpegs, in_offsets};
+    return export_frames_impl(c, pp, p, split, n_frames, nullptr, w, h, 3, (ptrdiff_t)w * 3, nullptr, 0, produced, &mj, &js);
 }
 
 size_t lvm_mjpeg_bound(int w, int h) { return (w < 1 || h < 1) ? 0 : lvm::mjpeg_bound(w, h); }

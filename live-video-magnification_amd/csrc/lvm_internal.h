@@ -488,6 +488,9 @@ void mjpeg_release(Ctx* c);
 int mjpeg_begin(Ctx* c, int w, int h, int quality, int max_frames_per_call, size_t total_frames, size_t capacity, hipStream_t s);
 int mjpeg_encode_device(Ctx* c, const uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_t fstride, int nframes, int frame0, size_t capacity, hipStream_t s);
 void mjpeg_decode_release(Ctx* c);
+int mjpeg_decode_begin(Ctx* c, const uint8_t* jpegs, const size_t* offsets, int n, int w, int h, hipStream_t s);
+int mjpeg_decode_enqueue(Ctx* c, int f0, int nf, uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_t fstride, hipStream_t s);
+int mjpeg_decode_finish(Ctx* c, hipStream_t s);
 int mjpeg_decode_device(Ctx* c, const uint8_t* jpegs, const size_t* offsets, int n, int w, int h, uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_t fstride, hipStream_t s);
 int mjpeg_drain(Ctx* c, uint8_t* out_host, size_t upto_call);
 int mjpeg_finish(Ctx* c, size_t total_frames, uint8_t* out_host, size_t* offsets, hipStream_t s);

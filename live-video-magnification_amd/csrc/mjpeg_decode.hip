@@ -15,6 +15,7 @@
 //   k_mjd_intervals   RSTn markers of the entropy-coded segment -> start / end of every interval            one workgroup per frame
 //   k_mjd_huffman     bits -> quantised coefficients (zigzag order, int16, zero-filled beforehand)           one lane per interval
 //   k_mjd_pixels      dequantise, IDCT, chroma replication, YCbCr -> BGR                                      one wave per 16 x 16 MCU
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -50,7 +51,9 @@ struct MjdState {
     int16_t* d_coef = nullptr;
     uint32_t *d_ivstart = nullptr, *d_ivend = nullptr, *d_err = nullptr;
     int iv_cap = 0;
+    int n = 0, max_iv = 1;               // the frames of the current begin .. finish sequence
     std::vector<MjdFrame> frames;
+    std::vector<uint32_t> foff;
 };
 
 int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
@@ -152,9 +155,27 @@ __global__ __launch_bounds__(256) void k_mjd_intervals(const uint8_t* __restrict
     const MjdFrame& fr = frames[f];
     const uint8_t* d = bytes + foff[f] + fr.data_off;
     const uint32_t n = fr.data_len;
-    const uint32_t per = (n + 255u) / 256u, lo = tid * per, hi = lo + per < n ? lo + per : n;
+    // a run of aligned 32-bit words per thread (+ the first byte of the next one: a marker may straddle two words)
+    const uint32_t mis = (uint32_t)((uintptr_t)d & 3u);
+    const uint32_t* wbase = reinterpret_cast<const uint32_t*>(d - mis);
+    const uint32_t nwords = (n + mis + 3u) >> 2, per = (nwords + 255u) / 256u, lo = tid * per, hi = lo + per < nwords ? lo + per : nwords;
+    auto scan = [&](auto&& hit) {
+        if (lo >= hi) return;
+        uint32_t w = wbase[lo];
+        for (uint32_t i = lo; i < hi; ++i) {
+            const uint32_t wn = wbase[i + 1];                                   // (the buffer is padded: always readable)
+            const unsigned long long v = (unsigned long long)w | ((unsigned long long)wn << 32);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const long pos = (long)(4u * i + j) - (long)mis;                // byte position inside the segment
+                const uint32_t b0 = (uint32_t)(v >> (8u * j)) & 0xFFu, b1 = (uint32_t)(v >> (8u * j + 8u)) & 0xFFu;
+                if (pos >= 0 && pos + 1 < (long)n && b0 == 0xFFu && (b1 & 0xF8u) == 0xD0u) hit((uint32_t)pos);
+            }
+            w = wn;
+        }
+    };
     uint32_t cnt = 0;
-    for (uint32_t i = lo; i < hi; ++i) cnt += (d[i] == 0xFF && i + 1 < n && (d[i + 1] & 0xF8) == 0xD0) ? 1u : 0u;
+    scan([&](uint32_t) { ++cnt; });
     s_part[tid] = cnt;
     __syncthreads();
     for (int dd = 1; dd < 256; dd <<= 1) {
@@ -166,11 +187,10 @@ __global__ __launch_bounds__(256) void k_mjd_intervals(const uint8_t* __restrict
     uint32_t k = tid ? s_part[tid - 1] : 0u;
     uint32_t* st = ivstart + (size_t)f * iv_cap;
     uint32_t* en = ivend + (size_t)f * iv_cap;
-    for (uint32_t i = lo; i < hi; ++i)
-        if (d[i] == 0xFF && i + 1 < n && (d[i + 1] & 0xF8) == 0xD0) {
-            if (k + 1 < (uint32_t)iv_cap) { en[k] = i; st[k + 1] = i + 2; }
-            ++k;
-        }
+    scan([&](uint32_t pos) {
+        if (k + 1 < (uint32_t)iv_cap) { en[k] = pos; st[k + 1] = pos + 2; }
+        ++k;
+    });
     if (tid == 255) {
         const uint32_t total = s_part[255] + 1u;
         if (total != fr.nintervals) atomicOr(err + f, 1u);            // the markers do not match the restart interval of the header
@@ -178,15 +198,36 @@ __global__ __launch_bounds__(256) void k_mjd_intervals(const uint8_t* __restrict
     }
 }
 
-// bit reader over [p, end): big-endian bits, FF 00 -> FF; behind the end the stream continues with 1-bits (a truncated interval decodes to
-// something and reads nothing outside)
+// bit reader over `left` bytes from p: big-endian bits, FF 00 -> FF; behind the end the stream continues with 1-bits (a truncated interval
+// decodes to something and reads nothing outside).  The bytes come in aligned 64-bit words, the next word always in flight: a lane's reads are
+// a serial chain, and a byte-wise chain costs a memory latency per byte (1.85 ms per 1080p frame measured, against 0.1 with words).
 struct MjdBits {
-    const uint8_t* p; const uint8_t* end;
-    uint32_t acc; int cnt;               // the next bits are the top `cnt` bits of acc
+    const unsigned long long* wp;       // the word after `nxt`
+    unsigned long long cur, nxt;        // bytes are consumed from the low end of cur
+    int nb;                             // bytes left in cur
+    long left;                          // bytes left in the interval
+    uint32_t acc; int cnt;              // the next bits are the top `cnt` bits of acc
+    __device__ __forceinline__ void init(const uint8_t* base, uint32_t start, uint32_t end) {
+        const uint8_t* a = base + start;
+        const unsigned mis = (unsigned)((uintptr_t)a & 7u);
+        wp = reinterpret_cast<const unsigned long long*>(a - mis);
+        cur = *wp++ >> (8u * mis); nb = 8 - (int)mis;
+        nxt = *wp++;
+        left = (long)end - (long)start;
+        acc = 0; cnt = 0;
+    }
+    __device__ __forceinline__ void advance() { cur = nxt; nxt = *wp++; nb = 8; }
     __device__ __forceinline__ void fill() {
         while (cnt <= 24) {
             uint32_t b = 0xFFu;
-            if (p < end) { b = *p++; if (b == 0xFFu && p < end && *p == 0) ++p; }
+            if (left > 0) {
+                if (nb == 0) advance();
+                b = (uint32_t)cur & 0xFFu; cur >>= 8; --nb; --left;
+                if (b == 0xFFu && left > 0) {               // a stuffed zero behind it is dropped
+                    if (nb == 0) advance();
+                    if (((uint32_t)cur & 0xFFu) == 0u) { cur >>= 8; --nb; --left; }
+                }
+            }
             acc |= b << (24 - cnt);
             cnt += 8;
         }
@@ -224,7 +265,7 @@ __global__ __launch_bounds__(64) void k_mjd_huffman(const uint8_t* __restrict__ 
     if (k >= fr.nintervals || err[f]) return;
     const uint8_t* d = bytes + foff[f] + fr.data_off;
     MjdBits br;
-    br.p = d + ivstart[(size_t)f * iv_cap + k]; br.end = d + ivend[(size_t)f * iv_cap + k]; br.acc = 0; br.cnt = 0;
+    br.init(d, ivstart[(size_t)f * iv_cap + k], ivend[(size_t)f * iv_cap + k]);
     const uint32_t ri = fr.restart ? fr.restart : (uint32_t)nmcu;
     const uint32_t m0 = k * ri, m1 = m0 + ri < (uint32_t)nmcu ? m0 + ri : (uint32_t)nmcu;
     int pred[3] = {0, 0, 0};
@@ -347,9 +388,11 @@ void mjpeg_decode_release(Ctx* c) {
     c->mjpeg_dec = nullptr;
 }
 
-// n frames (host bytes jpegs[offsets[i] .. offsets[i + 1])) -> BGR frames of w x h on the device, enqueued on s and completed before the
-// return (a malformed stream is an error of the call, not a picture).
-int mjpeg_decode_device(Ctx* c, const uint8_t* jpegs, const size_t* offsets, int n, int w, int h, uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_t fstride, hipStream_t s) {
+// Three steps, so that a caller can decode sub-batch by sub-batch between other work on the same queue (lvm_export_mjpeg_frames):
+//   begin    parses every frame, uploads all bytes and tables (asynchronously on s)
+//   enqueue  the three kernels for frames [f0, f0 + nf) -> BGR frames at d_bgr
+//   finish   waits for s and turns the error flags into the status of the call (a malformed stream is an error, not a picture)
+int mjpeg_decode_begin(Ctx* c, const uint8_t* jpegs, const size_t* offsets, int n, int w, int h, hipStream_t s) {
     if (w < 1 || h < 1 || w > 8192 || h > 16384) { c->err = "lvm_mjpeg_decode: frame size out of range (1..8192 x 1..16384)"; return LVM_ERR_INVALID; }
     MjdState* st = static_cast<MjdState*>(c->mjpeg_dec);
     if (!st) { st = new MjdState; c->mjpeg_dec = st; }
@@ -384,34 +427,58 @@ int mjpeg_decode_device(Ctx* c, const uint8_t* jpegs, const size_t* offsets, int
         if ((rc = mjd_reserve(c, st->d_ivend, (size_t)st->frames_cap * max_iv)) != LVM_OK) return rc;
         st->iv_cap = max_iv;
     }
-    if (st->bytes_cap < nbytes + 8) {
+    if (st->bytes_cap < nbytes + 32) {
         LVM_HIP_TRY(c, hipStreamSynchronize(s));
         st->bytes_cap = 0;
-        if ((rc = mjd_reserve(c, st->d_bytes, nbytes + 8)) != LVM_OK) return rc;
-        st->bytes_cap = nbytes + 8;
+        if ((rc = mjd_reserve(c, st->d_bytes, nbytes + 32)) != LVM_OK) return rc;      // (+ 32: the word readers look one or two words ahead)
+        st->bytes_cap = nbytes + 32;
     }
-    uint32_t* d_foff = st->d_err + n;
+    st->n = n; st->max_iv = max_iv;
+    st->foff = foff;                                             // (stays alive until the copy below has run)
     LVM_HIP_TRY(c, hipMemcpyAsync(st->d_bytes, jpegs + offsets[0], nbytes, hipMemcpyHostToDevice, s));
     LVM_HIP_TRY(c, hipMemcpyAsync(st->d_frames, st->frames.data(), (size_t)n * sizeof(MjdFrame), hipMemcpyHostToDevice, s));
     LVM_HIP_TRY(c, hipMemsetAsync(st->d_err, 0, (size_t)n * sizeof(uint32_t), s));
-    LVM_HIP_TRY(c, hipMemcpyAsync(d_foff, foff.data(), ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    LVM_HIP_TRY(c, hipMemsetAsync(st->d_coef, 0, (size_t)n * nmcu * 384 * sizeof(int16_t), s));
-    LVM_LAUNCH(c, "mjd_intervals", k_mjd_intervals, dim3(n), dim3(256), s, (const uint8_t*)st->d_bytes, (const MjdFrame*)st->d_frames, (const uint32_t*)d_foff,
-               st->d_ivstart, st->d_ivend, st->iv_cap, st->d_err);
-    LVM_LAUNCH(c, "mjd_huffman", k_mjd_huffman, dim3((max_iv + 63) / 64, n), dim3(64), s, (const uint8_t*)st->d_bytes, (const MjdFrame*)st->d_frames,
-               (const uint32_t*)d_foff, (const uint32_t*)st->d_ivstart, (const uint32_t*)st->d_ivend, st->iv_cap, nmcu, st->d_coef, st->d_err);
+    LVM_HIP_TRY(c, hipMemcpyAsync(st->d_err + n, st->foff.data(), ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    return LVM_OK;
+}
+
+int mjpeg_decode_enqueue(Ctx* c, int f0, int nf, uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_t fstride, hipStream_t s) {
+    MjdState* st = static_cast<MjdState*>(c->mjpeg_dec);
+    if (!st || f0 < 0 || nf < 1 || f0 + nf > st->n) { c->err = "lvm_mjpeg_decode: enqueue without begin"; return LVM_ERR_INVALID; }
+    const int w = st->w, h = st->h, mw = (w + 15) / 16, mh = (h + 15) / 16, nmcu = mw * mh;
+    const MjdFrame* fr = st->d_frames + f0;
+    const uint32_t* d_foff = st->d_err + st->n + f0;
+    int16_t* coef = st->d_coef + (size_t)f0 * nmcu * 384;
+    uint32_t *ivs = st->d_ivstart + (size_t)f0 * st->iv_cap, *ive = st->d_ivend + (size_t)f0 * st->iv_cap, *err = st->d_err + f0;
+    LVM_HIP_TRY(c, hipMemsetAsync(coef, 0, (size_t)nf * nmcu * 384 * sizeof(int16_t), s));
+    LVM_LAUNCH(c, "mjd_intervals", k_mjd_intervals, dim3(nf), dim3(256), s, (const uint8_t*)st->d_bytes, fr, d_foff, ivs, ive, st->iv_cap, err);
+    LVM_LAUNCH(c, "mjd_huffman", k_mjd_huffman, dim3((st->max_iv + 63) / 64, nf), dim3(64), s, (const uint8_t*)st->d_bytes, fr, d_foff, (const uint32_t*)ivs,
+               (const uint32_t*)ive, st->iv_cap, nmcu, coef, err);
     MjdGeom g;
     g.w = w; g.h = h; g.mw = mw; g.mh = mh; g.stride = (long)stride; g.fstride = (long)fstride;
-    LVM_LAUNCH(c, "mjd_pixels", k_mjd_pixels, dim3((mw + 3) / 4, mh, n), dim3(256), s, (const int16_t*)st->d_coef, (const MjdFrame*)st->d_frames, g, d_bgr);
-    std::vector<uint32_t> err((size_t)n);
-    LVM_HIP_TRY(c, hipMemcpyAsync(err.data(), st->d_err, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    LVM_LAUNCH(c, "mjd_pixels", k_mjd_pixels, dim3((mw + 3) / 4, mh, nf), dim3(256), s, (const int16_t*)coef, fr, g, d_bgr);
+    return LVM_OK;
+}
+
+int mjpeg_decode_finish(Ctx* c, hipStream_t s) {
+    MjdState* st = static_cast<MjdState*>(c->mjpeg_dec);
+    if (!st) { c->err = "lvm_mjpeg_decode: finish without begin"; return LVM_ERR_INVALID; }
+    std::vector<uint32_t> err((size_t)st->n);
+    LVM_HIP_TRY(c, hipMemcpyAsync(err.data(), st->d_err, (size_t)st->n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     LVM_HIP_TRY(c, hipStreamSynchronize(s));
-    for (int i = 0; i < n; ++i)
+    for (int i = 0; i < st->n; ++i)
         if (err[(size_t)i]) {
             c->err = std::string("lvm_mjpeg_decode: frame ") + std::to_string(i) + (err[(size_t)i] & 1u ? ": restart markers do not match the restart interval" : ": invalid Huffman code / coefficient index");
             return LVM_ERR_INVALID;
         }
     return LVM_OK;
+}
+
+int mjpeg_decode_device(Ctx* c, const uint8_t* jpegs, const size_t* offsets, int n, int w, int h, uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_t fstride, hipStream_t s) {
+    int rc = mjpeg_decode_begin(c, jpegs, offsets, n, w, h, s);
+    if (rc == LVM_OK) rc = mjpeg_decode_enqueue(c, 0, n, d_bgr, stride, fstride, s);
+    if (rc != LVM_OK) { (void)hipStreamSynchronize(s); return rc; }
+    return mjpeg_decode_finish(c, s);
 }
 
 }  // namespace lvm

@@ -136,6 +136,41 @@ def test_mjpeg_round_trip_emu(lvm, emu):
         ctx.close()
 
 
+def _transcode_case(lvm, lib, w, h, n, split, pre_kw, q_in, q_out):
+    """lvm_export_mjpeg_frames == decode (oracle) -> lvm_export_frames -> encode (oracle)"""
+    from helpers import c_params
+    ck, pk = lvm.synth.config(0)
+    clip = lvm.synth.Clip(seed=7, **dict(ck, w=w, h=h))
+    jin = [mo.encode_frame(clip.frame(t), q_in) if t % 2 else pil_encode(clip.frame(t), q_in, subsampling=2) for t in range(n)]     # both kinds of stream
+    decoded = [mo.decode_frame(j) for j in jin]
+    pre = lvm.LvmPreprocessParams(1, 0, 0.0, 0.0, 1.0, 1.0, 0)
+    for k, v in pre_kw.items():
+        setattr(pre, k, v)
+    cp = c_params(lvm, pk)
+    a, b = lvm.Context(0, 1, lib), lvm.Context(0, 1, lib)
+    try:
+        canvases, prod_a = a.export_frames(decoded, pre, cp, split)
+        jout, prod_b = b.export_mjpeg_frames(jin, w, h, pre, cp, split, quality=q_out)
+        assert prod_a == prod_b
+        for k in range(n):
+            assert jout[k] == mo.encode_frame(canvases[k], q_out), "frame %d" % k
+    finally:
+        a.close()
+        b.close()
+
+
+def test_export_mjpeg_to_mjpeg_emu(lvm, emu):
+    _transcode_case(lvm, emu, 66, 38, 6, 1, {}, 90, 80)
+    _transcode_case(lvm, emu, 80, 60, 5, 2, dict(downscale=2, roi_enabled=1, roiX=0.1, roiY=0.2, roiW=0.7, roiH=0.6, grayscale=1), 85, 95)
+    _transcode_case(lvm, emu, 64, 48, 3, 0, dict(roi_enabled=1, roiX=0.25, roiY=0.25, roiW=0.5, roiH=0.5), 85, 75)     # ROI only: the magnifier reads a view of the decoded frame
+
+
+@pytest.mark.gpu
+def test_export_mjpeg_to_mjpeg_gpu(lvm, hip):
+    _transcode_case(lvm, hip, 640, 360, 9, 1, {}, 90, 85)
+    _transcode_case(lvm, hip, 322, 182, 5, 2, dict(downscale=2, roi_enabled=1, roiX=0.1, roiY=0.2, roiW=0.7, roiH=0.6, grayscale=1), 85, 90)
+
+
 @pytest.mark.gpu
 def test_mjpeg_decode_gpu_bit_identical_to_the_oracle(lvm, hip):
     import torch

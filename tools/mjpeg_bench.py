@@ -102,6 +102,62 @@ def main():
         print("export host -> host, %-14s: %7.0f frames/s (%.1f us per frame; %.2f MB up + %.2f MB down per frame)" % (
             name, Kx * Te / dx, 1e6 * dx / (Kx * Te), fb / 1e6, down / 1e6))
         ex.close()
+    # the decode half: 1080p frames as this repository's encoder writes them (68 restart intervals each) and as libjpeg writes them (none)
+    dctx = lvm.Context(0, 1)
+    dsrc = torch.from_numpy(frames).cuda()
+    own = dctx.mjpeg_encode_device(C.c_void_p(dsrc.data_ptr()), w, h, 8, quality=90)
+    kinds = [("this encoder's frames (restart interval = MCU row)", own)]
+    try:
+        from PIL import Image
+        lj = []
+        for k in range(8):
+            b = io.BytesIO()
+            Image.fromarray(frames[k][..., ::-1]).save(b, "JPEG", quality=90, subsampling=2)
+            lj.append(b.getvalue())
+        kinds.append(("libjpeg's frames (no restart markers: one lane per frame)", lj))
+    except Exception:
+        pass
+    # (Huffman decoding is serial inside a restart interval: a call's time is the latency of ONE interval, whatever the number of frames)
+    for label, js8 in kinds:
+        for nd in (8, 64):
+            js = (js8 * 8)[:nd]
+            dout = torch.zeros((nd, h, w, 3), dtype=torch.uint8, device="cuda")
+            blob = np.frombuffer(b"".join(js), np.uint8)
+            offsn = (C.c_size_t * (nd + 1))(*np.concatenate([[0], np.cumsum([len(j) for j in js])]).tolist())
+            dctx._check(lib.lvm_mjpeg_decode_device(dctx.h, blob.ctypes.data, offsn, nd, w, h, dout.data_ptr(), w * 3, w * 3 * h))
+            Kd = 3
+            t0 = time.perf_counter()
+            for _ in range(Kd):
+                dctx._check(lib.lvm_mjpeg_decode_device(dctx.h, blob.ctypes.data, offsn, nd, w, h, dout.data_ptr(), w * 3, w * 3 * h))
+            dt = time.perf_counter() - t0
+            dctx.profile(True)
+            dctx._check(lib.lvm_mjpeg_decode_device(dctx.h, blob.ctypes.data, offsn, nd, w, h, dout.data_ptr(), w * 3, w * 3 * h))
+            prof = dctx.profile_collect()
+            dctx.profile(False)
+            print("lvm_mjpeg_decode_device, %2d x 1080p, %s: %.0f frames/s (%.1f ms per call, %.0f KB per frame); kernels: %s" % (
+                nd, label, Kd * nd / dt, 1e3 * dt / Kd, len(blob) / nd / 1e3,
+                ", ".join("%s %.0f us" % (k, 1e3 * v[0] / max(v[1], 1)) for k, v in prof.items() if k.startswith("mjd_"))))
+            del dout
+    dctx.close()
+    # file -> file: JPEG frames in, JPEG frames of the composed canvases out
+    jin = (own * 4)[:Te]
+    blob = np.frombuffer(b"".join(jin), np.uint8)
+    pjin = C.c_void_p()
+    assert lib.lvm_host_alloc(len(blob), C.byref(pjin)) == 0
+    C.memmove(pjin, blob.ctypes.data, len(blob))
+    ioffs = (C.c_size_t * (Te + 1))(*np.concatenate([[0], np.cumsum([len(j) for j in jin])]).tolist())
+    os.environ["LVM_EXPORT_MJPEG_CHUNK"] = "4"
+    ex = lvm.Context(0, 1)
+    ex.set_max_frames(Te)
+    for _ in range(2):
+        ex._check(lib.lvm_export_mjpeg_frames(ex.h, C.byref(cpre), C.byref(cp), 1, Te, pjin, ioffs, w, h, q, pj, jcap, joffs, prod))
+    t0 = time.perf_counter()
+    for _ in range(6):
+        ex._check(lib.lvm_export_mjpeg_frames(ex.h, C.byref(cpre), C.byref(cp), 1, Te, pjin, ioffs, w, h, q, pj, jcap, joffs, prod))
+    dx = time.perf_counter() - t0
+    print("export JPEG -> JPEG (lvm_export_mjpeg_frames)  : %7.0f frames/s (%.1f us per frame; %.2f MB up + %.2f MB down per frame)" % (
+        6 * Te / dx, 1e6 * dx / (6 * Te), len(blob) / Te / 1e6, joffs[Te] / Te / 1e6))
+    ex.close()
     try:
         from PIL import Image
         im = Image.fromarray(canvas[0][..., ::-1])
