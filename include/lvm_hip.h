@@ -220,7 +220,11 @@ int  lvm_export_frames(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_
  *                              than w x h or a malformed stream is LVM_ERR_INVALID (lvm_last_error says which frame and why).  Synchronous. */
 /*   lvm_export_mjpeg_frames    lvm_export_frames_mjpeg with JPEG frames IN as well (an AVI / Motion-JPEG source file): decode, chain, compose and
  *                              encode all on the device, only compressed bytes cross PCIe in either direction (file -> file export).           */
+/*   lvm_mjpeg_set_restart_interval   MCUs (16 x 16 pixels) per restart interval of the frames this context encodes from now on; 0 (default) = one
+ *                              MCU row.  Entropy coding is serial inside an interval: short intervals cost ~1 % of bytes and make the frames
+ *                              decode in parallel -- lvm_mjpeg_decode_device gives every interval a lane.                                       */
 size_t lvm_mjpeg_bound(int w, int h);
+int  lvm_mjpeg_set_restart_interval(lvm_ctx* ctx, int mcus);
 int  lvm_export_mjpeg_frames(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames, const uint8_t* jpegs,
                              const size_t* in_offsets, int w, int h, int quality, uint8_t* out, size_t out_capacity, size_t* offsets, int* produced);
 int  lvm_mjpeg_decode_device(lvm_ctx* ctx, const uint8_t* jpegs, const size_t* offsets, int n_frames, int w, int h, uint8_t* d_bgr,

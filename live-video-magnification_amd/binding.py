@@ -100,7 +100,7 @@ SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process
            "lvm_profile_entry", "lvm_algorithmic_bytes", "lvm_export_geometry", "lvm_export_frames",
            "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process", "lvm_chain_process_batch",
            "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free", "lvm_compose_geometry", "lvm_compose_device", "lvm_chain_process_batch_ex",
-           "lvm_chain_present", "lvm_mjpeg_bound", "lvm_mjpeg_encode_device", "lvm_export_frames_mjpeg", "lvm_mjpeg_decode_device", "lvm_export_mjpeg_frames"]
+           "lvm_chain_present", "lvm_mjpeg_bound", "lvm_mjpeg_encode_device", "lvm_export_frames_mjpeg", "lvm_mjpeg_decode_device", "lvm_export_mjpeg_frames", "lvm_mjpeg_set_restart_interval"]
 
 
 def bind(lib):
@@ -157,6 +157,7 @@ def bind(lib):
     lib.lvm_mjpeg_bound.argtypes = [C.c_int, C.c_int]
     lib.lvm_mjpeg_bound.restype = C.c_size_t
     lib.lvm_mjpeg_encode_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.lvm_mjpeg_set_restart_interval.argtypes = [vp, C.c_int]
     lib.lvm_mjpeg_decode_device.argtypes = [vp, vp, C.POINTER(C.c_size_t), C.c_int, C.c_int, C.c_int, vp, C.c_ssize_t, C.c_ssize_t]
     lib.lvm_export_mjpeg_frames.argtypes = [vp, C.POINTER(LvmPreprocessParams), C.POINTER(LvmParams), C.c_int, C.c_int, vp, C.POINTER(C.c_size_t), C.c_int, C.c_int,
                                             C.c_int, vp, C.c_size_t, C.POINTER(C.c_size_t), ip]
@@ -329,6 +330,9 @@ class Context:
         offs = (C.c_size_t * (n_frames + 1))()
         self._check(self.lib.lvm_mjpeg_encode_device(self.h, d_ptr, w, h, stride, frame_stride, n_frames, int(quality), out.ctypes.data, cap, offs))
         return [out[offs[i]:offs[i + 1]].tobytes() for i in range(n_frames)]
+
+    def mjpeg_set_restart_interval(self, mcus):
+        self._check(self.lib.lvm_mjpeg_set_restart_interval(self.h, int(mcus)))
 
     def mjpeg_decode_device(self, jpegs, w, h, d_ptr, stride=None, frame_stride=None):
         """lvm_mjpeg_decode_device: a list of JPEG frames (bytes) -> BGR frames in device memory at d_ptr."""

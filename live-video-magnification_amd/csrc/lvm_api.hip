@@ -692,6 +692,12 @@ int lvm_export_mjpeg_frames(lvm_ctx* c, const lvm_preprocess_params* pp, const l
     return export_frames_impl(c, pp, p, split, n_frames, nullptr, w, h, 3, (ptrdiff_t)w * 3, nullptr, 0, produced, &mj, &js);
 }
 
+int lvm_mjpeg_set_restart_interval(lvm_ctx* c, int mcus) {
+    if (!c || mcus < 0) return LVM_ERR_INVALID;
+    lvm::mjpeg_set_restart(c, mcus);
+    return LVM_OK;
+}
+
 size_t lvm_mjpeg_bound(int w, int h) { return (w < 1 || h < 1) ? 0 : lvm::mjpeg_bound(w, h); }
 
 int lvm_mjpeg_encode_device(lvm_ctx* c, const uint8_t* d_bgr, int w, int h, ptrdiff_t stride, ptrdiff_t frame_stride, int n_frames, int quality,

@@ -485,6 +485,7 @@ int compose_geometry(int split, int ow, int oh, int pw, int ph, int* pane_w, int
 // mjpeg.hip: Motion-JPEG encode of device-resident BGR frames (cv::VideoWriter::write for ExportFormat::AviMjpg, Exporter.cpp:107-117, :259)
 size_t mjpeg_bound(int w, int h);
 void mjpeg_release(Ctx* c);
+void mjpeg_set_restart(Ctx* c, int mcus);
 int mjpeg_begin(Ctx* c, int w, int h, int quality, int max_frames_per_call, size_t total_frames, size_t capacity, hipStream_t s);
 int mjpeg_encode_device(Ctx* c, const uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_t fstride, int nframes, int frame0, size_t capacity, hipStream_t s);
 void mjpeg_decode_release(Ctx* c);

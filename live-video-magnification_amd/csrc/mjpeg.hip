@@ -48,10 +48,19 @@ constexpr int MJ_MAX_HEADER = 1024;
 struct MjGeom {
     int w, h, mw, mh;
     long stride, fstride;
+    int ri, nint;               // MCUs per restart interval (raster order, T.81 E.1.4), intervals per frame
 };
+// interval i of frame f: its first MCU in the [frame][MCU] arrays, its number of blocks
+__device__ __forceinline__ void mj_interval(const MjGeom& g, int f, int i, size_t& mcu0, int& nblk) {
+    const int nmcu = g.mw * g.mh, m0 = i * g.ri;
+    mcu0 = (size_t)f * nmcu + m0;
+    nblk = (nmcu - m0 < g.ri ? nmcu - m0 : g.ri) * 6;
+}
 
 struct MjState {
     int w = 0, h = 0, quality = -1, frames_cap = 0;
+    int restart = 0;            // wanted MCUs per restart interval (lvm_mjpeg_set_restart_interval; 0 = one MCU row)
+    int ri = 0, nint = 0;       // in effect for (w, h): MCUs per interval, intervals per frame
     MjTables* d_tab = nullptr;
     uint8_t* d_header = nullptr; int header_bytes = 0;
     std::vector<uint8_t> header;
@@ -289,19 +298,17 @@ __device__ __forceinline__ void load_huff(uint32_t (*s_ac)[256], uint32_t (*s_dc
 // word j IS word (position / 32) + j of the stream.  (One block per wave with two global atomics each measured 283 us per 8 canvases, a
 // run of 8 with two atomics per run 150 us; what remains is the loads and the code construction.)
 constexpr int MJ_NB = 8;
-struct MjFetch { int v; uint32_t base; uint32_t interval; int t; bool act; };
-// the loads of block b of an interval: the lane's coefficient (lane 0: minus the DC of the previous block of the same component -- the
-// predictor restarts at 0 with the interval), the block's bit position
-__device__ __forceinline__ MjFetch mj_fetch(const int16_t* __restrict__ coef, const uint32_t* __restrict__ blk, uint32_t interval, int b, bool act, int nblk, int mw, int lane) {
+struct MjFetch { int v; uint32_t base; int t; bool act; };
+// the loads of block b of an interval (cf, bp: its coefficients and bit positions): the lane's coefficient (lane 0: minus the DC of the previous
+// block of the same component -- the predictor restarts at 0 with the interval), the block's bit position
+__device__ __forceinline__ MjFetch mj_fetch(const int16_t* __restrict__ cf, const uint32_t* __restrict__ bp, int b, bool act, int lane) {
     MjFetch f;
     f.act = act;
-    f.interval = interval;
     const int m = b / 6, k = b - m * 6;
     f.t = k < 4 ? 0 : 1;
-    const int16_t* cf = coef + (size_t)interval * mw * 384;
     f.v = act ? cf[(size_t)b * 64 + lane] : 0;
     if (lane == 0 && act && ((k >= 1 && k <= 3) || m > 0)) f.v -= cf[(size_t)(k == 0 ? b - 3 : (k < 4 ? b - 1 : b - 6)) * 64];
-    f.base = act ? blk[(size_t)interval * nblk + b] : 0u;
+    f.base = act ? bp[b] : 0u;
     return f;
 }
 constexpr int MJ_RUN_WORDS = MJ_NB * (MJ_BLOCK_WORDS - 2) + 2;       // LDS words of a run of MJ_NB blocks at any bit phase
@@ -311,16 +318,20 @@ __global__ __launch_bounds__(256) void k_mj_pack(const int16_t* __restrict__ coe
     __shared__ uint32_t s_stage[4][MJ_RUN_WORDS];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     load_huff(s_ac, s_dc, tb, tid);
-    const int nblk = g.mw * 6;
     // A wave owns a run of MJ_NB consecutive blocks of ONE interval (the last run of an interval is shorter) and assembles it in LDS at the
     // bit phase the run has in the interval's stream.  All loads of the run are issued before the first block is coded.
-    const uint32_t rpi = (uint32_t)(nblk + MJ_NB - 1) / MJ_NB, run = (uint32_t)blockIdx.x * 4u + (uint32_t)wave;
-    const uint32_t iv = run / rpi;
-    const int b0 = (int)(run - iv * rpi) * MJ_NB;
-    const bool wact = iv < nintervals;
+    const uint32_t rpi = (uint32_t)(g.ri * 6 + MJ_NB - 1) / MJ_NB, run = (uint32_t)blockIdx.x * 4u + (uint32_t)wave;
+    const uint32_t gi = run / rpi;
+    const int b0 = (int)(run - gi * rpi) * MJ_NB;
+    const bool wact = gi < nintervals;
+    const int fr = wact ? (int)(gi / (uint32_t)g.nint) : 0, iv = wact ? (int)(gi - (uint32_t)fr * (uint32_t)g.nint) : 0;
+    size_t mcu0; int nblk;
+    mj_interval(g, fr, iv, mcu0, nblk);
+    const int16_t* cf = coef + mcu0 * 384;
+    const uint32_t* bp = blk + mcu0 * 6;
     MjFetch fs[MJ_NB];
 #pragma unroll
-    for (int it = 0; it < MJ_NB; ++it) fs[it] = mj_fetch(coef, blk, wact ? iv : 0u, wact && b0 + it < nblk ? b0 + it : 0, wact && b0 + it < nblk, nblk, g.mw, lane);
+    for (int it = 0; it < MJ_NB; ++it) fs[it] = mj_fetch(cf, bp, wact && b0 + it < nblk ? b0 + it : 0, wact && b0 + it < nblk, lane);
     for (int j = lane; j < MJ_RUN_WORDS; j += 64) s_stage[wave][j] = 0u;
     __syncthreads();
     const uint32_t word0 = fs[0].base >> 5;                 // (block b0 of an existing run always exists)
@@ -343,8 +354,8 @@ __global__ __launch_bounds__(256) void k_mj_pack(const int16_t* __restrict__ coe
     // LDS word j IS word word0 + j of the stream: the inner words are plain stores, only the first and the last one -- shared with the
     // neighbouring runs -- are atomic ORs into the zeroed buffer
     const int nwords = (int)(((end + 31u) >> 5) - word0);
-    if (wact) {
-        uint32_t* out = raw + (size_t)iv * g.mw * 6 * MJ_BLOCK_WORDS + word0;
+    if (wact && b0 < nblk) {
+        uint32_t* out = raw + mcu0 * 6 * MJ_BLOCK_WORDS + word0;
         for (int j = lane; j < nwords; j += 64) {
             const uint32_t v = s_stage[wave][j];
             if (j == 0 || j == nwords - 1) { if (v) atomicOr(out + j, v); }
@@ -360,12 +371,14 @@ __global__ __launch_bounds__(256) void k_mj_scan(const int16_t* __restrict__ coe
     __shared__ uint32_t s_off[MJ_MAX_MW * 6];
     __shared__ uint32_t s_part[256];
     __shared__ uint32_t s_dc[2][12];
-    const int tid = threadIdx.x, nblk = g.mw * 6;
-    const size_t interval = (size_t)blockIdx.y * g.mh + blockIdx.x;
+    const int tid = threadIdx.x;
+    const size_t interval = (size_t)blockIdx.y * g.nint + blockIdx.x;
+    size_t mcu0; int nblk;
+    mj_interval(g, blockIdx.y, blockIdx.x, mcu0, nblk);
     if (tid < 24) s_dc[tid / 12][tid % 12] = tb->dc[tid / 12][tid % 12];
     __syncthreads();
-    uint32_t* mine = blk + interval * nblk;
-    const int16_t* cf = coef + interval * (size_t)g.mw * 384;
+    uint32_t* mine = blk + mcu0 * 6;
+    const int16_t* cf = coef + mcu0 * 384;
     for (int b = tid; b < nblk; b += 256) {
         const int m = b / 6, k = b - m * 6;
         const bool has_pred = (k >= 1 && k <= 3) || m > 0;
@@ -378,7 +391,7 @@ __global__ __launch_bounds__(256) void k_mj_scan(const int16_t* __restrict__ coe
     const uint32_t total_bits = wg_exclusive_scan(s_off, nblk, s_part, tid);
     for (int i = tid; i < nblk; i += 256) mine[i] = s_off[i];
     if (tid == 0) ibits[interval] = total_bits;
-    uint32_t* out = raw + interval * (size_t)g.mw * 6 * MJ_BLOCK_WORDS;
+    uint32_t* out = raw + mcu0 * 6 * MJ_BLOCK_WORDS;
     const uint32_t nwords = (total_bits + 31u) / 32u + 1u;
     for (uint32_t i = tid; i < nwords; i += 256) out[i] = 0u;
 }
@@ -400,8 +413,10 @@ __device__ __forceinline__ uint32_t ff_bytes(uint32_t w, uint32_t n) {
 __global__ __launch_bounds__(256) void k_mj_size(const uint32_t* __restrict__ raw, MjGeom g, const uint32_t* __restrict__ ibits, uint32_t* __restrict__ isize) {
     __shared__ int s_cnt;
     const int tid = threadIdx.x;
-    const size_t interval = (size_t)blockIdx.y * g.mh + blockIdx.x;
-    const uint32_t* in = raw + interval * (size_t)g.mw * 6 * MJ_BLOCK_WORDS;
+    const size_t interval = (size_t)blockIdx.y * g.nint + blockIdx.x;
+    size_t mcu0; int nblk_unused;
+    mj_interval(g, blockIdx.y, blockIdx.x, mcu0, nblk_unused);
+    const uint32_t* in = raw + mcu0 * 6 * MJ_BLOCK_WORDS;
     const uint32_t bits = ibits[interval], nbytes = (bits + 7u) >> 3, nwords = (nbytes + 3u) >> 2;
     if (tid == 0) s_cnt = 0;
     __syncthreads();
@@ -417,20 +432,36 @@ __global__ __launch_bounds__(256) void k_mj_size(const uint32_t* __restrict__ ra
 // given the offset ~0 (k_mj_write skips it).
 __global__ __launch_bounds__(256) void k_mj_offsets(MjGeom g, int nframes, int header_bytes, const uint32_t* __restrict__ isize, unsigned long long* __restrict__ ioff,
                                                     unsigned long long* __restrict__ foff, unsigned long long* __restrict__ run, unsigned long long cap) {
-    __shared__ uint32_t s_sz[MJ_MAX_MW * 2 + 64];       // (mh <= 1024 intervals per frame: frames up to 16384 rows)
+    __shared__ uint32_t s_sz[1024];                      // the intervals of a frame, 1024 at a time
     __shared__ uint32_t s_part[256];
-    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_base, s_carry;
     const int tid = threadIdx.x;
     if (tid == 0) s_base = run[0];
     __syncthreads();
     for (int f = 0; f < nframes; ++f) {
-        for (int i = tid; i < g.mh; i += 256) s_sz[i] = isize[(size_t)f * g.mh + i] + 2u;
+        const uint32_t* sz = isize + (size_t)f * g.nint;
+        uint32_t part = 0;
+        for (int i = tid; i < g.nint; i += 256) part += sz[i] + 2u;
+        s_part[tid] = part;
         __syncthreads();
-        const uint32_t body = wg_exclusive_scan(s_sz, g.mh, s_part, tid);
-        const unsigned long long base = s_base, fsize = (unsigned long long)header_bytes + body;
+        if (tid == 0) { unsigned long long t = 0; for (int i = 0; i < 256; ++i) t += s_part[i]; s_carry = t; }
+        __syncthreads();
+        const unsigned long long base = s_base, fsize = (unsigned long long)header_bytes + s_carry;
         const bool fits = base + fsize <= cap;
-        for (int i = tid; i < g.mh; i += 256) ioff[(size_t)f * g.mh + i] = fits ? base + header_bytes + s_sz[i] : ~0ull;
         __syncthreads();
+        if (tid == 0) s_carry = 0;
+        __syncthreads();
+        for (int c0 = 0; c0 < g.nint; c0 += 1024) {
+            const int n = g.nint - c0 < 1024 ? g.nint - c0 : 1024;
+            for (int i = tid; i < n; i += 256) s_sz[i] = sz[c0 + i] + 2u;
+            __syncthreads();
+            const uint32_t body = wg_exclusive_scan(s_sz, n, s_part, tid);
+            const unsigned long long carry = s_carry;
+            for (int i = tid; i < n; i += 256) ioff[(size_t)f * g.nint + c0 + i] = fits ? base + header_bytes + carry + s_sz[i] : ~0ull;
+            __syncthreads();
+            if (tid == 0) s_carry = carry + body;
+            __syncthreads();
+        }
         if (tid == 0) {
             foff[f] = base;
             if (fits) s_base = base + fsize; else run[1] = 1ull;
@@ -445,11 +476,13 @@ __global__ __launch_bounds__(256) void k_mj_write(const uint32_t* __restrict__ r
                                                   uint8_t* __restrict__ jpeg) {
     __shared__ uint32_t s_part[256];
     const int tid = threadIdx.x;
-    const int my = blockIdx.x;
-    const size_t interval = (size_t)blockIdx.y * g.mh + my;
+    const int my = blockIdx.x;                            // (the interval's index in its frame)
+    const size_t interval = (size_t)blockIdx.y * g.nint + my;
     const unsigned long long o = ioff[interval];
     if (o == ~0ull) return;                               // (uniform: the frame did not fit)
-    const uint32_t* in = raw + interval * (size_t)g.mw * 6 * MJ_BLOCK_WORDS;
+    size_t mcu0; int nblk_unused;
+    mj_interval(g, blockIdx.y, my, mcu0, nblk_unused);
+    const uint32_t* in = raw + mcu0 * 6 * MJ_BLOCK_WORDS;
     uint8_t* dst = jpeg + o;
     if (my == 0) for (int i = tid; i < header_bytes; i += 256) (dst - header_bytes)[i] = header[i];
     const uint32_t bits = ibits[interval], nbytes = (bits + 7u) >> 3, nwords = (nbytes + 3u) >> 2;
@@ -476,7 +509,7 @@ __global__ __launch_bounds__(256) void k_mj_write(const uint32_t* __restrict__ r
     if (tid == 0) {
         const uint32_t n = isize[interval];
         dst[n] = 0xFF;
-        dst[n + 1] = (uint8_t)(my + 1 < g.mh ? 0xD0 + (my & 7) : 0xD9);      // RSTm between the intervals, EOI behind the last one
+        dst[n + 1] = (uint8_t)(my + 1 < g.nint ? 0xD0 + (my & 7) : 0xD9);      // RSTm between the intervals, EOI behind the last one
     }
 }
 
@@ -492,7 +525,13 @@ int mj_reserve(Ctx* c, T*& p, size_t count) {
 
 size_t mjpeg_bound(int w, int h) {
     const size_t mw = (size_t)(w + 15) / 16, mh = (size_t)(h + 15) / 16;
-    return (size_t)MJ_MAX_HEADER + mw * mh * 6 * MJ_BLOCK_WORDS * 4 * 2 + mh * 2;      // every entropy byte stuffed: a bound, not an estimate
+    return (size_t)MJ_MAX_HEADER + mw * mh * 6 * MJ_BLOCK_WORDS * 4 * 2 + mw * mh * 2;      // every entropy byte stuffed, a marker per MCU: a bound, not an estimate
+}
+
+void mjpeg_set_restart(Ctx* c, int mcus) {
+    MjState* st = static_cast<MjState*>(c->mjpeg);
+    if (!st) { st = new MjState; c->mjpeg = st; }
+    st->restart = mcus > 0 ? mcus : 0;
 }
 
 void mjpeg_release(Ctx* c) {
@@ -514,11 +553,17 @@ int mjpeg_begin(Ctx* c, int w, int h, int quality, int max_frames_per_call, size
     MjState* st = static_cast<MjState*>(c->mjpeg);
     if (!st) { st = new MjState; c->mjpeg = st; }
     const int mw = (w + 15) / 16, mh = (h + 15) / 16;
+    // MCUs per restart interval: what was asked for (default: one MCU row), at most what k_mj_scan's LDS holds, at least what keeps the
+    // interval count inside the DRI / grid range
+    int ri = st->restart > 0 ? st->restart : mw;
+    ri = ri > MJ_MAX_MW ? MJ_MAX_MW : ri;
+    if ((mw * mh + ri - 1) / ri > 65535) ri = (mw * mh + 65534) / 65535;
+    const int nintf = (mw * mh + ri - 1) / ri;
     int rc;
     if (!st->d_tab) { rc = mj_reserve(c, st->d_tab, 1); if (rc != LVM_OK) return rc; }
     if (!st->d_header) { rc = mj_reserve(c, st->d_header, (size_t)MJ_MAX_HEADER); if (rc != LVM_OK) return rc; }
     if (!st->d_run) { rc = mj_reserve(c, st->d_run, 2); if (rc != LVM_OK) return rc; }
-    if (st->quality != quality || st->w != w || st->h != h) {
+    if (st->quality != quality || st->w != w || st->h != h || st->ri != ri) {
         LVM_HIP_TRY(c, hipStreamSynchronize(s));                   // (earlier launches may still read the tables)
         MjTables t;
         std::memset(&t, 0, sizeof t);
@@ -536,17 +581,17 @@ int mjpeg_begin(Ctx* c, int w, int h, int quality, int max_frames_per_call, size
             t.zz[i] = kZigzag[i];
         }
         for (int i = 0; i < 512; ++i) t.aclen[i >> 8][i & 255] = (uint8_t)(t.ac[i >> 8][i & 255] & 255u);
-        build_header(st->header, w, h, ql, qc, mw);
+        build_header(st->header, w, h, ql, qc, ri);
         if ((int)st->header.size() > MJ_MAX_HEADER) { c->err = "lvm_mjpeg: header too long"; return LVM_ERR_INVALID; }
         LVM_HIP_TRY(c, hipMemcpy(st->d_tab, &t, sizeof t, hipMemcpyHostToDevice));
         LVM_HIP_TRY(c, hipMemcpy(st->d_header, st->header.data(), st->header.size(), hipMemcpyHostToDevice));
         st->header_bytes = (int)st->header.size();
-        if (st->w != w || st->h != h) st->frames_cap = 0;          // the scratch buffers are sized per geometry
-        st->quality = quality; st->w = w; st->h = h;
+        if (st->w != w || st->h != h || st->ri != ri) st->frames_cap = 0;          // the scratch buffers are sized per geometry
+        st->quality = quality; st->w = w; st->h = h; st->ri = ri; st->nint = nintf;
     }
     if (st->frames_cap < max_frames_per_call) {
         LVM_HIP_TRY(c, hipStreamSynchronize(s));
-        const size_t nint = (size_t)mh * max_frames_per_call, nmcu = nint * mw;
+        const size_t nint = (size_t)nintf * max_frames_per_call, nmcu = (size_t)mh * mw * max_frames_per_call;
         st->frames_cap = 0;
         if ((rc = mj_reserve(c, st->d_coef, nmcu * 384)) != LVM_OK) return rc;
         if ((rc = mj_reserve(c, st->d_raw, nmcu * 6 * MJ_BLOCK_WORDS)) != LVM_OK) return rc;
@@ -584,15 +629,16 @@ int mjpeg_encode_device(Ctx* c, const uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_
     if (!st || nframes < 1 || nframes > st->frames_cap || (size_t)(frame0 + nframes + 1) > st->foff_cap || capacity > st->jpeg_cap) { c->err = "lvm_mjpeg: encode without begin"; return LVM_ERR_INVALID; }
     MjGeom g;
     g.w = st->w; g.h = st->h; g.mw = (st->w + 15) / 16; g.mh = (st->h + 15) / 16; g.stride = (long)stride; g.fstride = (long)fstride;
+    g.ri = st->ri; g.nint = st->nint;
     const dim3 blk(256);
     LVM_LAUNCH(c, "mj_transform", k_mj_transform, dim3((g.mw + 3) / 4, g.mh, nframes), blk, s, d_bgr, g, (const MjTables*)st->d_tab, st->d_coef, st->d_blk);
-    const uint32_t nint = (uint32_t)nframes * (uint32_t)g.mh, rpi = (uint32_t)(g.mw * 6 + MJ_NB - 1) / MJ_NB;
-    LVM_LAUNCH(c, "mj_scan", k_mj_scan, dim3(g.mh, nframes), blk, s, (const int16_t*)st->d_coef, g, (const MjTables*)st->d_tab, st->d_blk, st->d_raw, st->d_ibits);
+    const uint32_t nint = (uint32_t)nframes * (uint32_t)g.nint, rpi = (uint32_t)(g.ri * 6 + MJ_NB - 1) / MJ_NB;
+    LVM_LAUNCH(c, "mj_scan", k_mj_scan, dim3(g.nint, nframes), blk, s, (const int16_t*)st->d_coef, g, (const MjTables*)st->d_tab, st->d_blk, st->d_raw, st->d_ibits);
     LVM_LAUNCH(c, "mj_pack", k_mj_pack, dim3((nint * rpi + 3) / 4), blk, s, (const int16_t*)st->d_coef, g, nint, (const MjTables*)st->d_tab, (const uint32_t*)st->d_blk, st->d_raw);
-    LVM_LAUNCH(c, "mj_size", k_mj_size, dim3(g.mh, nframes), blk, s, (const uint32_t*)st->d_raw, g, (const uint32_t*)st->d_ibits, st->d_isize);
+    LVM_LAUNCH(c, "mj_size", k_mj_size, dim3(g.nint, nframes), blk, s, (const uint32_t*)st->d_raw, g, (const uint32_t*)st->d_ibits, st->d_isize);
     LVM_LAUNCH(c, "mj_offsets", k_mj_offsets, dim3(1), blk, s, g, nframes, st->header_bytes, (const uint32_t*)st->d_isize, st->d_ioff, st->d_foff + frame0, st->d_run,
                (unsigned long long)capacity);
-    LVM_LAUNCH(c, "mj_write", k_mj_write, dim3(g.mh, nframes), blk, s, (const uint32_t*)st->d_raw, g, (const uint32_t*)st->d_ibits, (const uint32_t*)st->d_isize,
+    LVM_LAUNCH(c, "mj_write", k_mj_write, dim3(g.nint, nframes), blk, s, (const uint32_t*)st->d_raw, g, (const uint32_t*)st->d_ibits, (const uint32_t*)st->d_isize,
                (const unsigned long long*)st->d_ioff, (const uint8_t*)st->d_header, st->header_bytes, st->d_jpeg);
     // where these frames ended up: to the page-locked mirror, then an event -- mjpeg_drain downloads finished frames while later calls run
     LVM_HIP_TRY(c, hipMemcpyAsync(st->h_foff + frame0, st->d_foff + frame0, (size_t)(nframes + 1) * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));

@@ -209,16 +209,21 @@ def entropy_interval(mcus, tabs):
     return bytes(bw.out)
 
 
-def encode_frame(bgr, quality=75):
-    """BGR u8 frame -> one JPEG (bytes)"""
+def encode_frame(bgr, quality=75, restart=None):
+    """BGR u8 frame -> one JPEG (bytes); restart = MCUs per restart interval (raster order, T.81 E.1.4), default one MCU row"""
     h, w, _ = bgr.shape
     c = coefficients(bgr, quality)
     mh, mw = c.shape[:2]
+    ri = mw if not restart else min(int(restart), 512)
+    if (mh * mw + ri - 1) // ri > 65535:
+        ri = (mh * mw + 65534) // 65535
+    flat = c.reshape(mh * mw, 6, 64)
+    nint = (mh * mw + ri - 1) // ri
     tabs = tuple(huff_codes(s) for s in (DC_LUMA, AC_LUMA, DC_CHROMA, AC_CHROMA))
-    out = bytearray(header(w, h, quality, mw))
-    for r in range(mh):
-        out += entropy_interval(c[r], tabs)
-        if r + 1 < mh:
+    out = bytearray(header(w, h, quality, ri))
+    for r in range(nint):
+        out += entropy_interval(flat[r * ri:(r + 1) * ri], tabs)
+        if r + 1 < nint:
             out += bytes([0xFF, 0xD0 + (r & 7)])
     out += b"\xff\xd9"
     return bytes(out)

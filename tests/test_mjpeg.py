@@ -126,9 +126,10 @@ def test_oracle_restart_intervals_and_stuffing():
 CASES = [(64, 48, 75, 1), (100, 70, 95, 2), (333, 211, 50, 1), (16, 16, 100, 3), (17, 9, 30, 1), (1, 1, 75, 1), (130, 34, 100, 2), (72, 18, 1, 1)]
 
 
-def _encode_and_compare(lvm, lib, to_dev, cases, noise=12.0):
+def _encode_and_compare(lvm, lib, to_dev, cases, noise=12.0, restart=0):
     ctx = lvm.Context(0, 1, lib)
     try:
+        ctx.mjpeg_set_restart_interval(restart)
         for (w, h, q, n) in cases:
             frames = np.stack([texture(w, h, seed=11 * w + k, noise=noise) for k in range(n)])
             pad = 7 if w % 2 else 0                                                       # ragged rows on the odd widths
@@ -137,7 +138,7 @@ def _encode_and_compare(lvm, lib, to_dev, cases, noise=12.0):
             d = to_dev(staged)
             got = ctx.mjpeg_encode_device(d[0], w, h, n, quality=q, stride=w * 3 + pad, frame_stride=(w * 3 + pad) * h)
             for k in range(n):
-                want = mo.encode_frame(frames[k], q)
+                want = mo.encode_frame(frames[k], q, restart=restart)
                 assert got[k] == want, "frame %d of %dx%d q%d: %d vs %d bytes, first difference at %d" % (
                     k, w, h, q, len(got[k]), len(want), next((i for i, (a, b) in enumerate(zip(got[k], want)) if a != b), -1))
                 assert decode(got[k]).shape == (h, w, 3)
@@ -157,6 +158,13 @@ def _numpy_dev():
 
 def test_mjpeg_emu_byte_identical_to_the_oracle(lvm, emu):
     _encode_and_compare(lvm, emu, _numpy_dev(), CASES)
+
+
+@pytest.mark.parametrize("restart", [1, 3, 8, 1000])
+def test_mjpeg_emu_restart_intervals_of_any_length(lvm, emu, restart):
+    """lvm_mjpeg_set_restart_interval: intervals of 1, 3, 8 MCUs (crossing the MCU rows in raster order; the last one shorter) and one longer than
+    the frame (a single interval, no marker at all)"""
+    _encode_and_compare(lvm, emu, _numpy_dev(), [(64, 48, 75, 1), (100, 70, 95, 2), (17, 9, 30, 1), (130, 34, 100, 2)], restart=restart)
 
 
 def test_mjpeg_emu_noise_at_quality_100_long_codes_and_stuffing(lvm, emu):
@@ -235,6 +243,8 @@ def test_mjpeg_gpu_byte_identical_to_the_oracle(lvm, hip):
         return (ctypes.c_void_p(t.data_ptr()), t)
     _encode_and_compare(lvm, hip, to_dev, CASES + [(640, 360, 85, 3)])
     _encode_and_compare(lvm, hip, to_dev, [(96, 32, 100, 1), (200, 120, 98, 2)], noise=200.0)
+    for restart in (1, 8, 1000):
+        _encode_and_compare(lvm, hip, to_dev, [(100, 70, 95, 2), (333, 211, 50, 1), (640, 360, 85, 2)], restart=restart)
 
 
 @pytest.mark.gpu

@@ -29,7 +29,7 @@ STREAMS = [(64, 48, 75), (100, 70, 95), (33, 21, 50), (16, 16, 100), (17, 9, 30)
 
 def streams_of(w, h, q, seed=0):
     f = texture(w, h, seed=w + h + seed)
-    return f, [mo.encode_frame(f, q), pil_encode(f, q, subsampling=2), pil_encode(f, q, subsampling=2, optimize=True)]
+    return f, [mo.encode_frame(f, q), pil_encode(f, q, subsampling=2), pil_encode(f, q, subsampling=2, optimize=True), mo.encode_frame(f, q, restart=3)]
 
 
 @pytest.mark.parametrize("w,h,q", STREAMS)
@@ -127,7 +127,9 @@ def test_mjpeg_round_trip_emu(lvm, emu):
     ctx = lvm.Context(0, 1, emu)
     try:
         f = np.stack([texture(80, 48, seed=k) for k in range(3)])
+        ctx.mjpeg_set_restart_interval(4)
         js = ctx.mjpeg_encode_device(ctypes.c_void_p(f.ctypes.data), 80, 48, 3, quality=92)
+        assert js[0] == mo.encode_frame(f[0], 92, restart=4)
         out = np.zeros_like(f)
         ctx.mjpeg_decode_device(js, 80, 48, ctypes.c_void_p(out.ctypes.data))
         for k in range(3):

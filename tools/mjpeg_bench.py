@@ -106,7 +106,12 @@ def main():
     dctx = lvm.Context(0, 1)
     dsrc = torch.from_numpy(frames).cuda()
     own = dctx.mjpeg_encode_device(C.c_void_p(dsrc.data_ptr()), w, h, 8, quality=90)
-    kinds = [("this encoder's frames (restart interval = MCU row)", own)]
+    dctx.mjpeg_set_restart_interval(8)
+    own8 = dctx.mjpeg_encode_device(C.c_void_p(dsrc.data_ptr()), w, h, 8, quality=90)
+    dctx.mjpeg_set_restart_interval(0)
+    print("restart interval of 8 MCUs instead of an MCU row: %.0f KB per frame against %.0f (+%.2f %%)" % (
+        np.mean([len(x) for x in own8]) / 1e3, np.mean([len(x) for x in own]) / 1e3, 100.0 * (sum(len(x) for x in own8) / sum(len(x) for x in own) - 1)))
+    kinds = [("this encoder's frames, restart interval = MCU row (68 lanes per frame)", own), ("this encoder's frames, restart interval = 8 MCUs (1020 lanes per frame)", own8)]
     try:
         from PIL import Image
         lj = []
@@ -130,34 +135,31 @@ def main():
             for _ in range(Kd):
                 dctx._check(lib.lvm_mjpeg_decode_device(dctx.h, blob.ctypes.data, offsn, nd, w, h, dout.data_ptr(), w * 3, w * 3 * h))
             dt = time.perf_counter() - t0
-            dctx.profile(True)
-            dctx._check(lib.lvm_mjpeg_decode_device(dctx.h, blob.ctypes.data, offsn, nd, w, h, dout.data_ptr(), w * 3, w * 3 * h))
-            prof = dctx.profile_collect()
-            dctx.profile(False)
-            print("lvm_mjpeg_decode_device, %2d x 1080p, %s: %.0f frames/s (%.1f ms per call, %.0f KB per frame); kernels: %s" % (
-                nd, label, Kd * nd / dt, 1e3 * dt / Kd, len(blob) / nd / 1e3,
-                ", ".join("%s %.0f us" % (k, 1e3 * v[0] / max(v[1], 1)) for k, v in prof.items() if k.startswith("mjd_"))))
+            print("lvm_mjpeg_decode_device, %2d x 1080p, %s: %.0f frames/s (%.1f ms per call, %.0f KB per frame)" % (
+                nd, label, Kd * nd / dt, 1e3 * dt / Kd, len(blob) / nd / 1e3))
             del dout
     dctx.close()
     # file -> file: JPEG frames in, JPEG frames of the composed canvases out
-    jin = (own * 4)[:Te]
-    blob = np.frombuffer(b"".join(jin), np.uint8)
-    pjin = C.c_void_p()
-    assert lib.lvm_host_alloc(len(blob), C.byref(pjin)) == 0
-    C.memmove(pjin, blob.ctypes.data, len(blob))
-    ioffs = (C.c_size_t * (Te + 1))(*np.concatenate([[0], np.cumsum([len(j) for j in jin])]).tolist())
-    os.environ["LVM_EXPORT_MJPEG_CHUNK"] = "4"
-    ex = lvm.Context(0, 1)
-    ex.set_max_frames(Te)
-    for _ in range(2):
-        ex._check(lib.lvm_export_mjpeg_frames(ex.h, C.byref(cpre), C.byref(cp), 1, Te, pjin, ioffs, w, h, q, pj, jcap, joffs, prod))
-    t0 = time.perf_counter()
-    for _ in range(6):
-        ex._check(lib.lvm_export_mjpeg_frames(ex.h, C.byref(cpre), C.byref(cp), 1, Te, pjin, ioffs, w, h, q, pj, jcap, joffs, prod))
-    dx = time.perf_counter() - t0
-    print("export JPEG -> JPEG (lvm_export_mjpeg_frames)  : %7.0f frames/s (%.1f us per frame; %.2f MB up + %.2f MB down per frame)" % (
-        6 * Te / dx, 1e6 * dx / (6 * Te), len(blob) / Te / 1e6, joffs[Te] / Te / 1e6))
-    ex.close()
+    for label, ownk in (("inputs with one restart interval per MCU row", own), ("inputs with restart intervals of 8 MCUs", own8)):
+        jin = (ownk * 4)[:Te]
+        blob = np.frombuffer(b"".join(jin), np.uint8)
+        pjin = C.c_void_p()
+        assert lib.lvm_host_alloc(len(blob), C.byref(pjin)) == 0
+        C.memmove(pjin, blob.ctypes.data, len(blob))
+        ioffs = (C.c_size_t * (Te + 1))(*np.concatenate([[0], np.cumsum([len(j) for j in jin])]).tolist())
+        os.environ["LVM_EXPORT_MJPEG_CHUNK"] = "4"
+        ex = lvm.Context(0, 1)
+        ex.set_max_frames(Te)
+        for _ in range(2):
+            ex._check(lib.lvm_export_mjpeg_frames(ex.h, C.byref(cpre), C.byref(cp), 1, Te, pjin, ioffs, w, h, q, pj, jcap, joffs, prod))
+        t0 = time.perf_counter()
+        for _ in range(6):
+            ex._check(lib.lvm_export_mjpeg_frames(ex.h, C.byref(cpre), C.byref(cp), 1, Te, pjin, ioffs, w, h, q, pj, jcap, joffs, prod))
+        dx = time.perf_counter() - t0
+        print("export JPEG -> JPEG (lvm_export_mjpeg_frames), %s: %7.0f frames/s (%.1f us per frame; %.2f MB up + %.2f MB down per frame)" % (
+            label, 6 * Te / dx, 1e6 * dx / (6 * Te), len(blob) / Te / 1e6, joffs[Te] / Te / 1e6))
+        ex.close()
+        lib.lvm_host_free(pjin)
     try:
         from PIL import Image
         im = Image.fromarray(canvas[0][..., ::-1])
