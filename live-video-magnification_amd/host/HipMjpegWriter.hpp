@@ -12,6 +12,7 @@
 #pragma once
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -97,6 +98,93 @@ private:
     std::uint32_t rate_ = 30, scale_ = 1, frames_ = 0, max_chunk_ = 0;
     std::uint64_t pos_ = 0, movi_start_ = 0;
     std::vector<Entry> index_;
+};
+
+// The other direction (source/FileSource.cpp:99 `cap_.read(frame)` on an AVI / Motion-JPEG file): the frames as they lie in the file, for
+// lvm_mjpeg_decode_device / lvm_export_mjpeg_frames -- the decoder runs on the GPU, this class only finds the chunks.  AVI 1.0 files
+// ('00dc' / '00db' chunks in LIST 'movi', with or without 'idx1'; what this file's writer, OpenCV and FFmpeg write below 4 GiB).
+class MjpegAviReader {
+public:
+    MjpegAviReader() = default;
+    ~MjpegAviReader() { close(); }
+    MjpegAviReader(const MjpegAviReader&) = delete;
+    MjpegAviReader& operator=(const MjpegAviReader&) = delete;
+
+    bool open(const std::string& path) {
+        close();
+        f_ = std::fopen(path.c_str(), "rb");
+        if (!f_) return false;
+        std::uint8_t hd[12];
+        if (!at(0, hd, 12) || std::memcmp(hd, "RIFF", 4) != 0 || std::memcmp(hd + 8, "AVI ", 4) != 0) { close(); return false; }
+        const std::uint64_t end = 8ull + le32(hd + 4);
+        bool is_mjpg = false;
+        for (std::uint64_t p = 12; p + 8 <= end;) {
+            std::uint8_t ch[12];
+            if (!at(p, ch, 8)) break;
+            const std::uint64_t n = le32(ch + 4);
+            if (std::memcmp(ch, "LIST", 4) == 0 && at(p + 8, ch + 8, 4)) {
+                if (std::memcmp(ch + 8, "hdrl", 4) == 0) is_mjpg = parse_hdrl(p + 12, p + 8 + n);
+                else if (std::memcmp(ch + 8, "movi", 4) == 0) scan_movi(p + 12, p + 8 + n);
+            }
+            p += 8 + n + (n & 1);
+        }
+        if (!is_mjpg || frames_.empty() || w_ <= 0 || h_ <= 0) { close(); return false; }
+        return true;
+    }
+    void close() { if (f_) std::fclose(f_); f_ = nullptr; frames_.clear(); w_ = h_ = 0; fps_ = 0.0; }
+    bool isOpened() const { return f_ != nullptr; }
+    int width() const { return w_; }
+    int height() const { return h_; }
+    double fps() const { return fps_; }
+    std::size_t frames() const { return frames_.size(); }
+    std::size_t frame_bytes(std::size_t k) const { return k < frames_.size() ? frames_[k].bytes : 0; }
+    // frame k (a complete JPEG) into dst (frame_bytes(k) bytes)
+    bool read(std::size_t k, std::uint8_t* dst) { return k < frames_.size() && at(frames_[k].offset, dst, frames_[k].bytes); }
+
+private:
+    struct Chunk { std::uint64_t offset; std::uint32_t bytes; };
+    static std::uint32_t le32(const std::uint8_t* p) { return (std::uint32_t)p[0] | ((std::uint32_t)p[1] << 8) | ((std::uint32_t)p[2] << 16) | ((std::uint32_t)p[3] << 24); }
+    bool at(std::uint64_t pos, void* dst, std::size_t n) { return f_ && std::fseek(f_, (long)pos, SEEK_SET) == 0 && std::fread(dst, 1, n, f_) == n; }
+    bool parse_hdrl(std::uint64_t p, std::uint64_t end) {
+        bool mjpg = false;
+        while (p + 8 <= end) {
+            std::uint8_t ch[12];
+            if (!at(p, ch, 8)) break;
+            const std::uint64_t n = le32(ch + 4);
+            if (std::memcmp(ch, "avih", 4) == 0 && n >= 40) {
+                std::uint8_t a[40];
+                if (at(p + 8, a, 40)) { const std::uint32_t usec = le32(a); if (usec) fps_ = 1e6 / usec; w_ = (int)le32(a + 32); h_ = (int)le32(a + 36); }
+            } else if (std::memcmp(ch, "LIST", 4) == 0 && at(p + 8, ch + 8, 4) && std::memcmp(ch + 8, "strl", 4) == 0) {
+                mjpg = parse_hdrl(p + 12, p + 8 + n) || mjpg;
+            } else if (std::memcmp(ch, "strh", 4) == 0 && n >= 32) {
+                std::uint8_t a[32];
+                if (at(p + 8, a, 32) && std::memcmp(a, "vids", 4) == 0) {
+                    const std::uint32_t scale = le32(a + 20), rate = le32(a + 24);
+                    if (scale && rate) fps_ = (double)rate / (double)scale;
+                    if (std::memcmp(a + 4, "MJPG", 4) == 0 || std::memcmp(a + 4, "mjpg", 4) == 0) mjpg = true;
+                }
+            } else if (std::memcmp(ch, "strf", 4) == 0 && n >= 20) {
+                std::uint8_t a[20];
+                if (at(p + 8, a, 20) && (std::memcmp(a + 16, "MJPG", 4) == 0 || std::memcmp(a + 16, "mjpg", 4) == 0)) { mjpg = true; w_ = (int)le32(a + 4); h_ = (int)le32(a + 8); }
+            }
+            p += 8 + n + (n & 1);
+        }
+        return mjpg;
+    }
+    void scan_movi(std::uint64_t p, std::uint64_t end) {
+        while (p + 8 <= end) {
+            std::uint8_t ch[12];
+            if (!at(p, ch, 8)) break;
+            const std::uint64_t n = le32(ch + 4);
+            if (std::memcmp(ch, "LIST", 4) == 0) { scan_movi(p + 12, p + 8 + n); }             // 'rec ' groups
+            else if (ch[2] == 'd' && (ch[3] == 'c' || ch[3] == 'b') && n >= 4) frames_.push_back({p + 8, (std::uint32_t)n});
+            p += 8 + n + (n & 1);
+        }
+    }
+    std::FILE* f_ = nullptr;
+    int w_ = 0, h_ = 0;
+    double fps_ = 0.0;
+    std::vector<Chunk> frames_;
 };
 
 }  // namespace lvm

@@ -180,6 +180,13 @@ int main(int argc, char** argv) {
             sink.avi_path = avi_path;
             const std::uint64_t written = runner.run_mjpeg(src, sink, pre, mag, LVM_SPLIT_LEFT_RIGHT, 25.0, 90);
             if (written != N - 1 || sink.avi.frames() != N - 1 || !sink.avi.close()) { std::printf("case 3: written %llu frames %u\n", (unsigned long long)written, sink.avi.frames()); ++bad; }
+            // ... and lvm::MjpegAviReader finds the same frames again (size, rate, count, bytes)
+            lvm::MjpegAviReader rd;
+            if (!rd.open(avi_path) || rd.frames() != (size_t)(N - 1) || rd.width() != W || rd.height() != H / 2 || rd.fps() != 25.0) { std::printf("case 3: reader %zu frames %dx%d %.3f fps\n", rd.frames(), rd.width(), rd.height(), rd.fps()); ++bad; }
+            else {
+                std::vector<std::uint8_t> fr(rd.frame_bytes(2));
+                if (!rd.read(2, fr.data()) || fr.size() < 4 || fr[0] != 0xFF || fr[1] != 0xD8 || fr[fr.size() - 2] != 0xFF || fr[fr.size() - 1] != 0xD9) { std::printf("case 3: frame 2 is not a JPEG\n"); ++bad; }
+            }
             // the raw canvases of case (1)'s configuration, for the Python side
             lvm::ExportRunner<MockTraits> again(0, 4);
             MockTraits::Source src2{W, H, N, 0, 3, -1, {}};
