@@ -122,6 +122,47 @@ def test_mjpeg_decode_emu_refuses_what_it_does_not_decode(lvm, emu):
         ctx.close()
 
 
+def test_mjpeg_decode_emu_survives_corrupted_streams(lvm, emu):
+    """random damage to valid streams (flipped bytes in the entropy data and in the headers, truncation, inserted markers): the call decodes
+    something or fails with a message -- and the context decodes the intact stream afterwards.  (tools/emu_asan.sh runs this file under
+    AddressSanitizer: a read or write outside a buffer would stop it.)"""
+    rng = np.random.default_rng(3)
+    f = texture(96, 64)
+    streams = [mo.encode_frame(f, 85), mo.encode_frame(f, 85, restart=2), pil_encode(f, 85, subsampling=2)]
+    ctx = lvm.Context(0, 1, emu)
+    try:
+        out = np.zeros((1, 64, 96 * 3), np.uint8)
+        p = ctypes.c_void_p(out.ctypes.data)
+        failed = 0
+        for t in range(90):
+            j = bytearray(streams[t % 3])
+            kind = t % 5
+            if kind == 0:                                            # a few flipped bytes in the entropy-coded segment
+                for _ in range(1 + t % 4):
+                    j[int(rng.integers(len(j) // 2, len(j) - 2))] = int(rng.integers(0, 256))
+            elif kind == 1:                                          # ... anywhere behind SOI
+                j[int(rng.integers(2, len(j)))] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 2:                                          # truncated
+                del j[int(rng.integers(20, len(j))):]
+            elif kind == 3:                                          # a restart marker where none belongs
+                k = int(rng.integers(len(j) // 2, len(j) - 4))
+                j[k:k + 2] = b"\xff" + bytes([0xD0 + t % 8])
+            else:                                                    # entropy data replaced by noise
+                hd = mo.parse_header(bytes(j))
+                j[hd["data_start"]:-2] = rng.integers(0, 256, len(j) - 2 - hd["data_start"], dtype=np.uint8).tobytes()
+            try:
+                ctx.mjpeg_decode_device([bytes(j)], 96, 64, p)
+            except lvm.LvmError as e:
+                failed += 1
+                assert "lvm_mjpeg_decode" in str(e)
+        assert failed > 10
+        for j in streams:
+            ctx.mjpeg_decode_device([j], 96, 64, p)
+            assert np.array_equal(out[0].reshape(64, 96, 3), mo.decode_frame(j))
+    finally:
+        ctx.close()
+
+
 def test_mjpeg_round_trip_emu(lvm, emu):
     """encode on the device, decode on the device: the frame comes back within the quantisation error"""
     ctx = lvm.Context(0, 1, emu)

@@ -14,6 +14,6 @@ wait
 g++ -std=c++17 -O1 -g1 -fPIC -fsanitize=address --param asan-stack=0 -I"$here/include" -c "$here/hip_emu.cpp" -o "$out/hip_emu.o"
 g++ -shared -fPIC -fsanitize=address -Wl,-Bsymbolic -o "$out/liblvm_emu.so" "$out"/*.o
 cd "$root"
-[ $# -gt 0 ] || set -- tests/test_emu_parity.py tests/test_emu_random.py tests/test_compose.py tests/test_preprocess.py tests/test_export.py tests/test_host_display.py tests/test_mjpeg.py -m "not gpu"
+[ $# -gt 0 ] || set -- tests/test_emu_parity.py tests/test_emu_random.py tests/test_compose.py tests/test_preprocess.py tests/test_export.py tests/test_host_display.py tests/test_mjpeg.py tests/test_mjpeg_decode.py -m "not gpu"
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 LVM_EMU_LIB="$out/liblvm_emu.so" \
   python -m pytest -x -q "$@"

@@ -16,5 +16,5 @@ wait
 "$CXX" -std=c++17 -O1 -fPIC -DHIPEMU_POISON_LDS=1 -I"$here/include" -c "$here/hip_emu.cpp" -o "$out/hip_emu.o"
 "$CXX" -shared -fPIC -Wl,-Bsymbolic -o "$out/liblvm_emu.so" "$out"/*.o
 cd "$root"
-[ $# -gt 0 ] || set -- tests/test_emu_bench_pattern.py tests/test_emu_parity.py tests/test_compose.py tests/test_preprocess.py tests/test_export.py tests/test_mjpeg.py -m "not gpu" -n 7
+[ $# -gt 0 ] || set -- tests/test_emu_bench_pattern.py tests/test_emu_parity.py tests/test_compose.py tests/test_preprocess.py tests/test_export.py tests/test_mjpeg.py tests/test_mjpeg_decode.py -m "not gpu" -n 7
 LVM_EMU_LIB="$out/liblvm_emu.so" python -m pytest -x -q "$@"

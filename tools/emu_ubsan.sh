@@ -15,6 +15,6 @@ wait
 "$CXX" -std=c++17 -O1 -fPIC -fsanitize=undefined -fno-sanitize=vptr,pointer-overflow -I"$here/include" -c "$here/hip_emu.cpp" -o "$out/hip_emu.o"
 "$CXX" -shared -fPIC -fsanitize=undefined -fno-sanitize=vptr,pointer-overflow -Wl,-Bsymbolic -o "$out/liblvm_emu.so" "$out"/*.o
 cd "$root"
-[ $# -gt 0 ] || set -- tests/test_emu_bench_pattern.py tests/test_emu_parity.py tests/test_compose.py tests/test_preprocess.py tests/test_export.py tests/test_mjpeg.py -m "not gpu" -n 7
+[ $# -gt 0 ] || set -- tests/test_emu_bench_pattern.py tests/test_emu_parity.py tests/test_compose.py tests/test_preprocess.py tests/test_export.py tests/test_mjpeg.py tests/test_mjpeg_decode.py -m "not gpu" -n 7
 rt=$(ls "$(dirname "$CXX")"/../lib/clang/*/lib/linux/libclang_rt.ubsan_standalone-x86_64.so | head -1)
 LD_PRELOAD="$rt" UBSAN_OPTIONS=print_stacktrace=1 LVM_EMU_LIB="$out/liblvm_emu.so" python -m pytest -x -q "$@"
