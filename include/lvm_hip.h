@@ -207,7 +207,7 @@ int  lvm_export_frames(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_
 
 /* Motion-JPEG encode on the device (the encode half): what cv::VideoWriter::write(canvas) does for
  * ExportFormat::AviMjpg, the reference's AVI export format and the fallback of every other one (export/Exporter.cpp:107-117, :259).
- * Baseline JPEG (ITU-T T.81), 8 bit, YCbCr 4:2:0 (JFIF), Annex K Huffman tables, one restart interval per MCU row, libjpeg's quality scale
+ * Baseline JPEG (ITU-T T.81), 8 bit, YCbCr 4:2:0 (JFIF), Annex K Huffman tables, restart intervals of 8 MCUs, libjpeg's quality scale
  * (1..100).  Frames: BGR, 1..8192 x 1..16384.
  *   lvm_mjpeg_bound            bytes that always suffice for ONE encoded frame of this size (a bound; typical frames are 5-20 % of it)
  *   lvm_mjpeg_encode_device    n_frames device-resident BGR frames -> out[offsets[i] .. offsets[i + 1]) = frame i, a complete JPEG;
@@ -220,9 +220,10 @@ int  lvm_export_frames(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_
  *                              than w x h or a malformed stream is LVM_ERR_INVALID (lvm_last_error says which frame and why).  Synchronous. */
 /*   lvm_export_mjpeg_frames    lvm_export_frames_mjpeg with JPEG frames IN as well (an AVI / Motion-JPEG source file): decode, chain, compose and
  *                              encode all on the device, only compressed bytes cross PCIe in either direction (file -> file export).           */
-/*   lvm_mjpeg_set_restart_interval   MCUs (16 x 16 pixels) per restart interval of the frames this context encodes from now on; 0 (default) = one
- *                              MCU row.  Entropy coding is serial inside an interval: short intervals cost ~1 % of bytes and make the frames
- *                              decode in parallel -- lvm_mjpeg_decode_device gives every interval a lane.                                       */
+/*   lvm_mjpeg_set_restart_interval   MCUs (16 x 16 pixels, raster order) per restart interval of the frames this context encodes from now on;
+ *                              0 = the default, 8 (pass (w + 15) / 16 for one interval per MCU row).  Entropy coding is serial inside an
+ *                              interval: short intervals cost < 0.5 % of bytes and make the frames decode in parallel --
+ *                              lvm_mjpeg_decode_device gives every interval a lane.                                                              */
 size_t lvm_mjpeg_bound(int w, int h);
 int  lvm_mjpeg_set_restart_interval(lvm_ctx* ctx, int mcus);
 int  lvm_export_mjpeg_frames(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames, const uint8_t* jpegs,

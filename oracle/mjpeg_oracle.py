@@ -19,7 +19,7 @@ The arithmetic (every step integer, `>>` is the arithmetic shift):
   FDCT       samples - 128; rows: t[u] = (sum_x M[u][x] d[x] + 512) >> 10; columns: S[v] = (sum_y M[v][y] t[y] + 32768) >> 16,
              M[u][x] = round(8192 * C(u) / 2 * cos((2 x + 1) u pi / 16)), C(0) = 1 / sqrt 2
   quantiser  libjpeg's quality scaling of the Annex K tables; q(c) = sign(c) * ((|c| + Q / 2) // Q)
-  entropy    Annex K Huffman tables; restart interval = one MCU row, DC predictors reset there (T.81 F.1.1.5.1 / E.1.4);
+  entropy    Annex K Huffman tables; restart intervals of 8 MCUs (or as asked), DC predictors reset there (T.81 F.1.1.5.1 / E.1.4);
              byte stuffing FF -> FF 00, intervals padded with 1-bits, RST0..7 between them
 """
 import math
@@ -210,11 +210,11 @@ def entropy_interval(mcus, tabs):
 
 
 def encode_frame(bgr, quality=75, restart=None):
-    """BGR u8 frame -> one JPEG (bytes); restart = MCUs per restart interval (raster order, T.81 E.1.4), default one MCU row"""
+    """BGR u8 frame -> one JPEG (bytes); restart = MCUs per restart interval (raster order, T.81 E.1.4), default 8"""
     h, w, _ = bgr.shape
     c = coefficients(bgr, quality)
     mh, mw = c.shape[:2]
-    ri = mw if not restart else min(int(restart), 512)
+    ri = 8 if not restart else min(int(restart), 512)
     if (mh * mw + ri - 1) // ri > 65535:
         ri = (mh * mw + 65534) // 65535
     flat = c.reshape(mh * mw, 6, 64)

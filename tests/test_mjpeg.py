@@ -106,7 +106,7 @@ def test_oracle_dct_matrix_and_reciprocal_quantiser():
 
 def test_oracle_restart_intervals_and_stuffing():
     f = texture(48, 40, noise=60.0)
-    j = mo.encode_frame(f, 100)
+    j = mo.encode_frame(f, 100, restart=3)
     seg = segments(j)
     assert int.from_bytes(seg[0xDD][0], "big") == 3                                       # one MCU row of a 48-pixel frame
     body = j[j.index(b"\xff\xda"):]
@@ -257,6 +257,7 @@ def test_mjpeg_gpu_1080p_canvas_decodes_and_matches_the_oracle_rows(lvm, hip):
     ctx = lvm.Context(0, 1, hip)
     try:
         t = torch.from_numpy(f).cuda()
+        ctx.mjpeg_set_restart_interval(240)                                           # one interval per MCU row of this canvas
         j = ctx.mjpeg_encode_device(ctypes.c_void_p(t.data_ptr()), w, h, 1, quality=q)[0]
     finally:
         ctx.close()

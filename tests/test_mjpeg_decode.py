@@ -47,8 +47,9 @@ def test_oracle_decoder_agrees_with_libjpeg(w, h, q):
 def test_oracle_round_trip_is_the_quantiser_and_nothing_else():
     f = texture(48, 32)
     c = mo.coefficients(f, 90)
-    hd, got = mo.decode_coefficients(mo.encode_frame(f, 90))
+    hd, got = mo.decode_coefficients(mo.encode_frame(f, 90, restart=3))
     assert np.array_equal(got, c) and hd["restart"] == 3 and (hd["w"], hd["h"]) == (48, 32)
+    assert mo.parse_header(mo.encode_frame(f, 90))["restart"] == 8
 
 
 def _strip_dht(j):
@@ -106,7 +107,7 @@ def test_mjpeg_decode_emu_refuses_what_it_does_not_decode(lvm, emu):
             with pytest.raises(lvm.LvmError, match=why):
                 ctx.mjpeg_decode_device([bad], 64, 48, p)
         # wrong restart-marker count
-        cut = good.replace(b"\xff\xd1", b"\xff\x00", 1)
+        cut = good.replace(b"\xff\xd0", b"\xff\x00", 1)
         with pytest.raises(lvm.LvmError, match="restart"):
             ctx.mjpeg_decode_device([cut], 64, 48, p)
         # entropy data overwritten with zeros: decodes (zeros are valid codes) or is refused, but never reads outside; then the context still works

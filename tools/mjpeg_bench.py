@@ -105,13 +105,13 @@ def main():
     # the decode half: 1080p frames as this repository's encoder writes them (68 restart intervals each) and as libjpeg writes them (none)
     dctx = lvm.Context(0, 1)
     dsrc = torch.from_numpy(frames).cuda()
-    own = dctx.mjpeg_encode_device(C.c_void_p(dsrc.data_ptr()), w, h, 8, quality=90)
-    dctx.mjpeg_set_restart_interval(8)
-    own8 = dctx.mjpeg_encode_device(C.c_void_p(dsrc.data_ptr()), w, h, 8, quality=90)
+    own8 = dctx.mjpeg_encode_device(C.c_void_p(dsrc.data_ptr()), w, h, 8, quality=90)              # the default: restart intervals of 8 MCUs
+    dctx.mjpeg_set_restart_interval((w + 15) // 16)
+    own = dctx.mjpeg_encode_device(C.c_void_p(dsrc.data_ptr()), w, h, 8, quality=90)               # one interval per MCU row
     dctx.mjpeg_set_restart_interval(0)
-    print("restart interval of 8 MCUs instead of an MCU row: %.0f KB per frame against %.0f (+%.2f %%)" % (
+    print("restart intervals of 8 MCUs (default) against one per MCU row: %.0f KB per frame against %.0f (+%.2f %%)" % (
         np.mean([len(x) for x in own8]) / 1e3, np.mean([len(x) for x in own]) / 1e3, 100.0 * (sum(len(x) for x in own8) / sum(len(x) for x in own) - 1)))
-    kinds = [("this encoder's frames, restart interval = MCU row (68 lanes per frame)", own), ("this encoder's frames, restart interval = 8 MCUs (1020 lanes per frame)", own8)]
+    kinds = [("this encoder's frames, restart interval = 8 MCUs, the default (1020 lanes per frame)", own8), ("this encoder's frames, restart interval = MCU row (68 lanes per frame)", own)]
     try:
         from PIL import Image
         lj = []
@@ -140,7 +140,7 @@ def main():
             del dout
     dctx.close()
     # file -> file: JPEG frames in, JPEG frames of the composed canvases out
-    for label, ownk in (("inputs with one restart interval per MCU row", own), ("inputs with restart intervals of 8 MCUs", own8)):
+    for label, ownk in (("inputs with restart intervals of 8 MCUs (this encoder's default)", own8), ("inputs with one restart interval per MCU row", own)):
         jin = (ownk * 4)[:Te]
         blob = np.frombuffer(b"".join(jin), np.uint8)
         pjin = C.c_void_p()
