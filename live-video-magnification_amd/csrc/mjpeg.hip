@@ -18,7 +18,7 @@
 //
 //   k_mj_transform   BGR -> YCbCr 4:2:0 -> FDCT -> quantise -> zigzag, bits per block   one wave per 16 x 16 MCU
 //   k_mj_scan        bit position of every block, bit buffer zeroed               one workgroup per restart interval
-//   k_mj_pack        the code words, ORed into the bit buffer                     one wave per block
+//   k_mj_pack        the code words, ORed into the bit buffer                     one wave per run of 8 blocks (lane = coefficient)
 //   k_mj_size        stuffed size of every interval (FF -> FF 00)                one workgroup per restart interval
 //   k_mj_frame_offsets / k_mj_offsets   byte offsets of the intervals in their frame, of the frames in the output
 //   k_mj_write       header, stuffed intervals, RSTn / EOI markers               one workgroup per restart interval
@@ -42,7 +42,7 @@ struct MjTables {
     uint8_t zz[64];
     uint8_t aclen[2][256];    // the lengths of ac[][] alone (k_mj_transform counts bits, it does not build code words)
 };
-constexpr int MJ_MAX_MW = 512;                  // MCUs per row the entropy kernel's LDS holds (frames up to 8192 pixels wide)
+constexpr int MJ_MAX_MW = 512;                  // MCUs per restart interval k_mj_scan's LDS holds; also the widest frame in MCUs (8192 pixels)
 constexpr int MJ_BLOCK_WORDS = 54;              // worst case of one block: 20 + 63 * 26 bits = 1658 -> 52 words, + 2 for the straddling word and the pad
 constexpr int MJ_MAX_HEADER = 1024;
 constexpr int MJ_DEFAULT_RESTART = 8;
