@@ -37,6 +37,8 @@ struct MjdFrame {
     uint32_t data_off, data_len;        // the entropy-coded segment inside the uploaded bytes
     uint32_t restart;                   // MCUs per restart interval (0: the whole scan)
     uint32_t nintervals;                // expected
+    uint32_t par;                       // 1: no restart markers -> decoded by the self-synchronising kernels (k_mjp_*), not a lane per interval
+    uint32_t usub;                      // upper bound of its subsequences (from the stuffed length)
     uint32_t tq[3], td[3], ta[3];
     uint16_t q[4][64];                  // quantisers in ZIGZAG order
     uint8_t zz[64];                     // zigzag index -> natural position
@@ -52,6 +54,11 @@ struct MjdState {
     uint32_t *d_ivstart = nullptr, *d_ivend = nullptr, *d_err = nullptr;
     int iv_cap = 0;
     int n = 0, max_iv = 1;               // the frames of the current begin .. finish sequence
+    // self-synchronising path (frames without restart markers)
+    uint8_t* d_ubytes = nullptr; size_t ubytes_cap = 0;
+    uint32_t *d_ulen = nullptr, *d_before = nullptr, *d_changed = nullptr;
+    unsigned long long* d_exit[2] = {nullptr, nullptr};
+    int sub_cap = 0, par_frames_cap = 0, npar = 0;
     std::vector<MjdFrame> frames;
     std::vector<uint32_t> foff;
 };
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(64) void k_mjd_huffman(const uint8_t* __restrict__ 
         fr.huff[i >> (MJD_LUT_BITS + 1)][(i >> MJD_LUT_BITS) & 1].lut[i & ((1 << MJD_LUT_BITS) - 1)];
     __syncthreads();
     const uint32_t k = blockIdx.x * 64u + (uint32_t)tid;
-    if (k >= fr.nintervals || err[f]) return;
+    if (k >= fr.nintervals || err[f] || fr.par) return;
     const uint8_t* d = bytes + foff[f] + fr.data_off;
     MjdBits br;
     br.init(d, ivstart[(size_t)f * iv_cap + k], ivend[(size_t)f * iv_cap + k]);
@@ -293,6 +300,243 @@ __global__ __launch_bounds__(64) void k_mjd_huffman(const uint8_t* __restrict__ 
         }
     }
     if (bad) atomicOr(err + f, 2u);
+}
+
+// ---- streams WITHOUT restart markers: self-synchronising parallel decoding ------------------------------------------------------------------
+// A Huffman decoder that starts inside a stream at a wrong position almost always falls into step with the true code word boundaries after a
+// few symbols (the codes are not fixed-length and the run / size symbols keep re-aligning it).  So (Klein & Wiseman 2003; Weissenberger &
+// Schmidt 2018 for JPEG on GPUs): cut the unstuffed entropy segment into subsequences of 1024 bits, a lane each;
+//   k_mjp_unstuff   FF 00 -> FF, so that bit positions are plain arithmetic
+//   k_mjp_sync      lane i decodes subsequence i from where -- and in the state (block of the MCU, coefficient index) in which -- lane i - 1
+//                   last left ITS subsequence, and publishes its own exit (position, state, blocks completed).  First pass: every lane
+//                   guesses (start of its subsequence, start of an MCU).  Repeated until no exit changes: lane 0's entry is exact, hence by
+//                   induction every lane's; in practice two to four passes.
+//   k_mjp_scan      blocks completed before every lane (prefix sum)
+//   k_mjp_write     the same decoding once more from the exact entries, now storing coefficients (DC as differences)
+//   k_mjp_dc        DC prediction: prefix sums over the blocks of each component
+// The result is what the one-lane decoder produces (same tables, same rules), the tests compare both with the oracle.
+constexpr uint32_t MJP_SUB_BITS = 1024;
+struct MjpBits {
+    const uint32_t* w; uint32_t nwords, next;
+    unsigned long long acc; int cnt;
+    uint32_t pos;
+    __device__ __forceinline__ uint32_t word(uint32_t i) const { return i < nwords ? __builtin_bswap32(w[i]) : 0xFFFFFFFFu; }     // behind the end: 1-bits
+    __device__ __forceinline__ void init(const uint32_t* words, uint32_t n, uint32_t p0) {
+        w = words; nwords = n; pos = p0;
+        const uint32_t i = p0 >> 5, sh = p0 & 31u;
+        acc = (((unsigned long long)word(i) << 32) | word(i + 1)) << sh;
+        cnt = 64 - (int)sh; next = i + 2;
+    }
+    __device__ __forceinline__ void fill() { if (cnt <= 32) { acc |= (unsigned long long)word(next++) << (32 - cnt); cnt += 32; } }
+    __device__ __forceinline__ uint32_t peek(int n) const { return (uint32_t)(acc >> (64 - n)); }
+    __device__ __forceinline__ void skip(int n) { acc <<= n; cnt -= n; pos += (uint32_t)n; }
+    __device__ __forceinline__ uint32_t get(int n) { if (n == 0) return 0u; fill(); const uint32_t v = peek(n); skip(n); return v; }
+};
+__device__ __forceinline__ int mjp_symbol(MjpBits& br, const uint16_t* lut, const MjdHuff& t) {
+    br.fill();
+    const uint32_t e = lut[br.peek(MJD_LUT_BITS)];
+    if (e) { br.skip((int)(e >> 8)); return (int)(e & 255u); }
+    for (int len = MJD_LUT_BITS + 1; len <= 16; ++len) {
+        const int code = (int)br.peek(len);
+        if (t.maxcode[len] >= 0 && code <= t.maxcode[len] && code >= t.mincode[len]) { br.skip(len); return t.vals[t.valptr[len] + code - t.mincode[len]]; }
+    }
+    return -1;
+}
+// One symbol in state (bi = block of the MCU, kk = next coefficient index; kk == 0: a DC code comes next).  Returns the zigzag index of the
+// coefficient it produced (`value`), -1 for a symbol without one, -2 for what the one-lane decoder calls an error.  `done` = the block ended.
+__device__ __forceinline__ int mjp_step(MjpBits& br, int& bi, int& kk, const MjdFrame& fr, const uint16_t (*s_lut)[2][1 << MJD_LUT_BITS], int& value, bool& done) {
+    const int comp = bi < 4 ? 0 : bi - 3;
+    int ci = -1;
+    done = false;
+    if (kk == 0) {
+        const uint32_t td = fr.td[comp];
+        const int s = mjp_symbol(br, s_lut[0][td], fr.huff[0][td]);
+        if (s < 0 || s > 11) return -2;
+        value = mjd_extend(br.get(s), s);
+        ci = 0; kk = 1;
+    } else {
+        const uint32_t ta = fr.ta[comp];
+        const int rs = mjp_symbol(br, s_lut[1][ta], fr.huff[1][ta]);
+        if (rs < 0) return -2;
+        const int r = rs >> 4, s = rs & 15;
+        if (s == 0) {
+            if (r == 15) kk += 16; else kk = 64;                 // ZRL / EOB
+        } else {
+            if (kk + r > 63) return -2;                          // (the state stays what it was: the caller may go on from here)
+            kk += r;
+            value = mjd_extend(br.get(s), s);
+            ci = kk; ++kk;
+        }
+    }
+    if (kk >= 64) { kk = 0; bi = bi == 5 ? 0 : bi + 1; done = true; }
+    return ci;
+}
+
+// one workgroup per frame: the entropy-coded segment without its stuffed zeros, from a 4-byte aligned address, + its length
+__global__ __launch_bounds__(256) void k_mjp_unstuff(const uint8_t* __restrict__ bytes, const MjdFrame* __restrict__ frames, const uint32_t* __restrict__ foff,
+                                                     uint8_t* __restrict__ ubytes, uint32_t* __restrict__ ulen) {
+    __shared__ uint32_t s_part[256];
+    const int tid = threadIdx.x, f = blockIdx.x;
+    const MjdFrame& fr = frames[f];
+    if (!fr.par) return;
+    const uint32_t o = foff[f] + fr.data_off, n = fr.data_len;
+    const uint8_t* d = bytes + o;
+    uint8_t* u = ubytes + ((o + 3u) & ~3u);
+    const uint32_t per = (n + 255u) / 256u, lo = tid * per, hi = lo + per < n ? lo + per : n;
+    uint32_t keep = 0;
+    for (uint32_t i = lo; i < hi; ++i) keep += (d[i] == 0 && i > 0 && d[i - 1] == 0xFF) ? 0u : 1u;
+    s_part[tid] = keep;
+    __syncthreads();
+    for (int dd = 1; dd < 256; dd <<= 1) {
+        const uint32_t t = tid >= dd ? s_part[tid - dd] : 0u;
+        __syncthreads();
+        s_part[tid] += t;
+        __syncthreads();
+    }
+    uint32_t k = tid ? s_part[tid - 1] : 0u;
+    for (uint32_t i = lo; i < hi; ++i) if (!(d[i] == 0 && i > 0 && d[i - 1] == 0xFF)) u[k++] = d[i];
+    const uint32_t total = s_part[255];
+    if (tid < 8) u[total + tid] = 0xFF;                          // (the word readers look a little ahead)
+    if (tid == 0) ulen[f] = total;
+}
+
+// exit of a subsequence: bit position in the low half, state and the blocks completed on the way in the high half
+__device__ __forceinline__ unsigned long long mjp_pack(uint32_t pos, int bi, int kk, uint32_t blocks) { return (unsigned long long)pos | ((unsigned long long)(bi * 64 + kk) << 32) | ((unsigned long long)blocks << 41); }
+
+__global__ __launch_bounds__(64) void k_mjp_sync(const uint8_t* __restrict__ ubytes, const MjdFrame* __restrict__ frames, const uint32_t* __restrict__ foff,
+                                                 const uint32_t* __restrict__ ulen, int sub_cap, int first, const unsigned long long* __restrict__ ein,
+                                                 unsigned long long* __restrict__ eout, uint32_t* __restrict__ changed) {
+    __shared__ uint16_t s_lut[2][2][1 << MJD_LUT_BITS];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const MjdFrame& fr = frames[f];
+    for (int i = tid; i < 4 << MJD_LUT_BITS; i += 64) s_lut[i >> (MJD_LUT_BITS + 1)][(i >> MJD_LUT_BITS) & 1][i & ((1 << MJD_LUT_BITS) - 1)] =
+        fr.huff[i >> (MJD_LUT_BITS + 1)][(i >> MJD_LUT_BITS) & 1].lut[i & ((1 << MJD_LUT_BITS) - 1)];
+    __syncthreads();
+    if (!fr.par) return;
+    const uint32_t total_bits = ulen[f] * 8u, nsub = (total_bits + MJP_SUB_BITS - 1) / MJP_SUB_BITS, i = blockIdx.x * 64u + (uint32_t)tid;
+    if (i >= nsub) return;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(ubytes + ((foff[f] + fr.data_off + 3u) & ~3u));
+    uint32_t p0 = i * MJP_SUB_BITS;
+    int bi = 0, kk = 0;
+    if (!first && i > 0) { const unsigned long long e = ein[(size_t)f * sub_cap + i - 1]; p0 = (uint32_t)e; const int st = (int)((e >> 32) & 511u); bi = st >> 6; kk = st & 63; }
+    const uint32_t end = (i + 1) * MJP_SUB_BITS < total_bits ? (i + 1) * MJP_SUB_BITS : total_bits;
+    MjpBits br;
+    br.init(words, (ulen[f] + 3u) >> 2, p0);
+    uint32_t blocks = 0;
+    while (br.pos < end) {
+        int value; bool done;
+        if (mjp_step(br, bi, kk, fr, s_lut, value, done) == -2) { br.skip(1); continue; }     // (a wrong guess runs into impossible codes: move on)
+        blocks += done ? 1u : 0u;
+    }
+    const unsigned long long e = mjp_pack(br.pos, bi, kk, blocks);
+    if (first || e != ein[(size_t)f * sub_cap + i]) { if (!first) atomicOr(changed, 1u); }
+    eout[(size_t)f * sub_cap + i] = e;
+}
+
+// one workgroup per frame: blocks completed before every subsequence
+__global__ __launch_bounds__(256) void k_mjp_scan(const MjdFrame* __restrict__ frames, const uint32_t* __restrict__ ulen, int sub_cap, const unsigned long long* __restrict__ e,
+                                                  uint32_t* __restrict__ before) {
+    __shared__ uint32_t s_v[1024];
+    __shared__ uint32_t s_part[256];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, f = blockIdx.x;
+    if (!frames[f].par) return;
+    const int nsub = (int)((ulen[f] * 8u + MJP_SUB_BITS - 1) / MJP_SUB_BITS);
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < nsub; c0 += 1024) {
+        const int n = nsub - c0 < 1024 ? nsub - c0 : 1024;
+        for (int i = tid; i < n; i += 256) s_v[i] = (uint32_t)(e[(size_t)f * sub_cap + c0 + i] >> 41);
+        __syncthreads();
+        // exclusive scan of s_v[0 .. n)
+        const int per = (n + 255) / 256, lo = tid * per, hi = lo + per < n ? lo + per : n;
+        uint32_t sum = 0;
+        for (int i = lo; i < hi; ++i) sum += s_v[i];
+        s_part[tid] = sum;
+        __syncthreads();
+        for (int dd = 1; dd < 256; dd <<= 1) {
+            const uint32_t t = tid >= dd ? s_part[tid - dd] : 0u;
+            __syncthreads();
+            s_part[tid] += t;
+            __syncthreads();
+        }
+        const uint32_t carry = s_carry;
+        uint32_t run = carry + (tid ? s_part[tid - 1] : 0u);
+        for (int i = lo; i < hi; ++i) { before[(size_t)f * sub_cap + c0 + i] = run; run += s_v[i]; }
+        __syncthreads();
+        if (tid == 0) s_carry = carry + s_part[255];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void k_mjp_write(const uint8_t* __restrict__ ubytes, const MjdFrame* __restrict__ frames, const uint32_t* __restrict__ foff,
+                                                  const uint32_t* __restrict__ ulen, int sub_cap, const unsigned long long* __restrict__ e, const uint32_t* __restrict__ before,
+                                                  int nmcu, int16_t* __restrict__ coef, uint32_t* __restrict__ err) {
+    __shared__ uint16_t s_lut[2][2][1 << MJD_LUT_BITS];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const MjdFrame& fr = frames[f];
+    for (int i = tid; i < 4 << MJD_LUT_BITS; i += 64) s_lut[i >> (MJD_LUT_BITS + 1)][(i >> MJD_LUT_BITS) & 1][i & ((1 << MJD_LUT_BITS) - 1)] =
+        fr.huff[i >> (MJD_LUT_BITS + 1)][(i >> MJD_LUT_BITS) & 1].lut[i & ((1 << MJD_LUT_BITS) - 1)];
+    __syncthreads();
+    if (!fr.par) return;
+    const uint32_t total_bits = ulen[f] * 8u, nsub = (total_bits + MJP_SUB_BITS - 1) / MJP_SUB_BITS, i = blockIdx.x * 64u + (uint32_t)tid;
+    if (i >= nsub) return;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(ubytes + ((foff[f] + fr.data_off + 3u) & ~3u));
+    uint32_t p0 = 0;
+    int bi = 0, kk = 0;
+    if (i > 0) { const unsigned long long x = e[(size_t)f * sub_cap + i - 1]; p0 = (uint32_t)x; const int st = (int)((x >> 32) & 511u); bi = st >> 6; kk = st & 63; }
+    const bool last = i + 1 == nsub;
+    const uint32_t end = last ? total_bits + 64u : (uint32_t)e[(size_t)f * sub_cap + i];
+    const uint32_t nblk = (uint32_t)nmcu * 6u;
+    uint32_t b = before[(size_t)f * sub_cap + i];
+    bool bad = (uint32_t)bi != b % 6u;                                    // (the state and the count must tell the same story)
+    MjpBits br;
+    br.init(words, (ulen[f] + 3u) >> 2, p0);
+    int16_t* out = coef + (size_t)f * nmcu * 384;
+    while (!bad && b < nblk && br.pos < end) {
+        int value = 0; bool done;
+        const int ci = mjp_step(br, bi, kk, fr, s_lut, value, done);
+        if (ci == -2) { bad = true; break; }
+        if (ci >= 0) out[(size_t)b * 64 + ci] = (int16_t)value;
+        b += done ? 1u : 0u;
+    }
+    if (last && b < nblk) bad = true;                                     // the stream ended before the frame did
+    if (bad) atomicOr(err + f, 2u);
+}
+
+// one workgroup per (component, frame): DC coefficients = prefix sums of the differences over the blocks of the component, in scan order
+__global__ __launch_bounds__(256) void k_mjp_dc(const MjdFrame* __restrict__ frames, int nmcu, int16_t* __restrict__ coef) {
+    __shared__ int s_v[1024];
+    __shared__ int s_part[256];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, comp = blockIdx.x, f = blockIdx.y;
+    if (!frames[f].par) return;
+    int16_t* c = coef + (size_t)f * nmcu * 384;
+    const int n_all = comp == 0 ? nmcu * 4 : nmcu;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n_all; c0 += 1024) {
+        const int n = n_all - c0 < 1024 ? n_all - c0 : 1024;
+        for (int i = tid; i < n; i += 256) { const int el = c0 + i; const int b = comp == 0 ? (el >> 2) * 6 + (el & 3) : el * 6 + 3 + comp; s_v[i] = c[(size_t)b * 64]; }
+        __syncthreads();
+        const int per = (n + 255) / 256, lo = tid * per, hi = lo + per < n ? lo + per : n;
+        int sum = 0;
+        for (int i = lo; i < hi; ++i) sum += s_v[i];
+        s_part[tid] = sum;
+        __syncthreads();
+        for (int dd = 1; dd < 256; dd <<= 1) {
+            const int t = tid >= dd ? s_part[tid - dd] : 0;
+            __syncthreads();
+            s_part[tid] += t;
+            __syncthreads();
+        }
+        const int carry = s_carry;
+        int run = carry + (tid ? s_part[tid - 1] : 0);
+        for (int i = lo; i < hi; ++i) { run += s_v[i]; const int el = c0 + i; const int b = comp == 0 ? (el >> 2) * 6 + (el & 3) : el * 6 + 3 + comp; c[(size_t)b * 64] = (int16_t)run; }
+        __syncthreads();
+        if (tid == 0) s_carry = carry + s_part[255];
+        __syncthreads();
+    }
 }
 
 struct MjdGeom { int w, h, mw, mh; long stride, fstride; };
@@ -382,7 +626,7 @@ int mjd_reserve(Ctx* c, T*& p, size_t count) {
 void mjpeg_decode_release(Ctx* c) {
     MjdState* st = static_cast<MjdState*>(c->mjpeg_dec);
     if (!st) return;
-    void* ptrs[] = {st->d_frames, st->d_bytes, st->d_coef, st->d_ivstart, st->d_ivend, st->d_err};
+    void* ptrs[] = {st->d_frames, st->d_bytes, st->d_coef, st->d_ivstart, st->d_ivend, st->d_err, st->d_ubytes, st->d_ulen, st->d_before, st->d_changed, st->d_exit[0], st->d_exit[1]};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete st;
     c->mjpeg_dec = nullptr;
@@ -399,7 +643,7 @@ int mjpeg_decode_begin(Ctx* c, const uint8_t* jpegs, const size_t* offsets, int 
     const int mw = (w + 15) / 16, mh = (h + 15) / 16, nmcu = mw * mh;
     st->frames.resize((size_t)n);
     std::vector<uint32_t> foff((size_t)n + 1);
-    int max_iv = 1;
+    int max_iv = 1, max_sub = 1, npar = 0;
     for (int i = 0; i < n; ++i) {
         if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[0] > 0xFFFFFFF0ull) { c->err = "lvm_mjpeg_decode: bad offsets"; return LVM_ERR_INVALID; }
         MjdFrame& f = st->frames[(size_t)i];
@@ -407,6 +651,11 @@ int mjpeg_decode_begin(Ctx* c, const uint8_t* jpegs, const size_t* offsets, int 
         if (why) { c->err = std::string("lvm_mjpeg_decode: frame ") + std::to_string(i) + ": " + why; return LVM_ERR_INVALID; }
         f.nintervals = f.restart ? (uint32_t)((nmcu + (int)f.restart - 1) / (int)f.restart) : 1u;
         if ((int)f.nintervals > max_iv) max_iv = (int)f.nintervals;
+        // no restart markers: one lane would decode the whole frame -- the self-synchronising kernels take it (LVM_MJD_PARALLEL=0: never, =2: also tiny frames)
+        static const int par_mode = [] { const char* e = std::getenv("LVM_MJD_PARALLEL"); return e ? std::atoi(e) : 1; }();
+        f.par = (f.restart == 0 && par_mode != 0 && (f.data_len >= 2048u || par_mode == 2)) ? 1u : 0u;
+        f.usub = (f.data_len * 8u + MJP_SUB_BITS - 1) / MJP_SUB_BITS + 1u;
+        if (f.par) { ++npar; if ((int)f.usub > max_sub) max_sub = (int)f.usub; }
         foff[(size_t)i] = (uint32_t)(offsets[i] - offsets[0]);
     }
     foff[(size_t)n] = (uint32_t)(offsets[n] - offsets[0]);
@@ -433,6 +682,26 @@ int mjpeg_decode_begin(Ctx* c, const uint8_t* jpegs, const size_t* offsets, int 
         if ((rc = mjd_reserve(c, st->d_bytes, nbytes + 32)) != LVM_OK) return rc;      // (+ 32: the word readers look one or two words ahead)
         st->bytes_cap = nbytes + 32;
     }
+    st->npar = npar;
+    if (npar) {
+        if (st->ubytes_cap < nbytes + 64) {
+            LVM_HIP_TRY(c, hipStreamSynchronize(s));
+            st->ubytes_cap = 0;
+            if ((rc = mjd_reserve(c, st->d_ubytes, nbytes + 64)) != LVM_OK) return rc;
+            st->ubytes_cap = nbytes + 64;
+        }
+        if (st->par_frames_cap < n || st->sub_cap < max_sub) {
+            LVM_HIP_TRY(c, hipStreamSynchronize(s));
+            st->par_frames_cap = 0;
+            const int cap = max_sub > st->sub_cap ? max_sub : st->sub_cap;
+            if ((rc = mjd_reserve(c, st->d_ulen, (size_t)n)) != LVM_OK) return rc;
+            if ((rc = mjd_reserve(c, st->d_before, (size_t)n * cap)) != LVM_OK) return rc;
+            if ((rc = mjd_reserve(c, st->d_exit[0], (size_t)n * cap)) != LVM_OK) return rc;
+            if ((rc = mjd_reserve(c, st->d_exit[1], (size_t)n * cap)) != LVM_OK) return rc;
+            if (!st->d_changed && (rc = mjd_reserve(c, st->d_changed, (size_t)1)) != LVM_OK) return rc;
+            st->par_frames_cap = n; st->sub_cap = cap;
+        }
+    }
     st->n = n; st->max_iv = max_iv;
     st->foff = foff;                                             // (stays alive until the copy below has run)
     LVM_HIP_TRY(c, hipMemcpyAsync(st->d_bytes, jpegs + offsets[0], nbytes, hipMemcpyHostToDevice, s));
@@ -454,6 +723,31 @@ int mjpeg_decode_enqueue(Ctx* c, int f0, int nf, uint8_t* d_bgr, ptrdiff_t strid
     LVM_LAUNCH(c, "mjd_intervals", k_mjd_intervals, dim3(nf), dim3(256), s, (const uint8_t*)st->d_bytes, fr, d_foff, ivs, ive, st->iv_cap, err);
     LVM_LAUNCH(c, "mjd_huffman", k_mjd_huffman, dim3((st->max_iv + 63) / 64, nf), dim3(64), s, (const uint8_t*)st->d_bytes, fr, d_foff, (const uint32_t*)ivs,
                (const uint32_t*)ive, st->iv_cap, nmcu, coef, err);
+    bool any_par = false;
+    for (int i = f0; i < f0 + nf; ++i) any_par = any_par || st->frames[(size_t)i].par;
+    if (any_par) {
+        const uint32_t* ulen = st->d_ulen + f0;
+        unsigned long long* ex[2] = {st->d_exit[0] + (size_t)f0 * st->sub_cap, st->d_exit[1] + (size_t)f0 * st->sub_cap};
+        uint32_t* before = st->d_before + (size_t)f0 * st->sub_cap;
+        const dim3 gsub((unsigned)((st->sub_cap + 63) / 64), (unsigned)nf);
+        LVM_LAUNCH(c, "mjp_unstuff", k_mjp_unstuff, dim3(nf), dim3(256), s, (const uint8_t*)st->d_bytes, fr, d_foff, st->d_ubytes, st->d_ulen + f0);
+        LVM_LAUNCH(c, "mjp_sync", k_mjp_sync, gsub, dim3(64), s, (const uint8_t*)st->d_ubytes, fr, d_foff, ulen, st->sub_cap, 1, (const unsigned long long*)ex[1], ex[0], st->d_changed);
+        int cur = 0;                                               // ex[cur] holds the latest exits
+        for (int it = 0; it <= st->sub_cap; ++it) {                // (every pass makes at least one more lane exact: sub_cap passes always suffice)
+            uint32_t changed = 0;
+            LVM_HIP_TRY(c, hipMemsetAsync(st->d_changed, 0, sizeof(uint32_t), s));
+            LVM_LAUNCH(c, "mjp_sync", k_mjp_sync, gsub, dim3(64), s, (const uint8_t*)st->d_ubytes, fr, d_foff, ulen, st->sub_cap, 0, (const unsigned long long*)ex[cur], ex[cur ^ 1],
+                       st->d_changed);
+            LVM_HIP_TRY(c, hipMemcpyAsync(&changed, st->d_changed, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            LVM_HIP_TRY(c, hipStreamSynchronize(s));
+            cur ^= 1;
+            if (!changed) break;
+        }
+        LVM_LAUNCH(c, "mjp_scan", k_mjp_scan, dim3(nf), dim3(256), s, fr, ulen, st->sub_cap, (const unsigned long long*)ex[cur], before);
+        LVM_LAUNCH(c, "mjp_write", k_mjp_write, gsub, dim3(64), s, (const uint8_t*)st->d_ubytes, fr, d_foff, ulen, st->sub_cap, (const unsigned long long*)ex[cur],
+                   (const uint32_t*)before, nmcu, coef, err);
+        LVM_LAUNCH(c, "mjp_dc", k_mjp_dc, dim3(3, nf), dim3(256), s, fr, nmcu, coef);
+    }
     MjdGeom g;
     g.w = w; g.h = h; g.mw = mw; g.mh = mh; g.stride = (long)stride; g.fstride = (long)fstride;
     LVM_LAUNCH(c, "mjd_pixels", k_mjd_pixels, dim3((mw + 3) / 4, mh, nf), dim3(256), s, (const int16_t*)coef, fr, g, d_bgr);

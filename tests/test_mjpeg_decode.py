@@ -164,6 +164,20 @@ def test_mjpeg_decode_emu_survives_corrupted_streams(lvm, emu):
         ctx.close()
 
 
+def test_mjpeg_decode_emu_self_synchronising_path_on_every_stream_without_restart_markers():
+    """Frames without restart markers of 2 KB and more are decoded by the self-synchronising kernels (k_mjp_*: a lane per 1024 bits, iterated
+    until every lane starts where its predecessor ended); LVM_MJD_PARALLEL=2 sends the small ones there as well, =0 none: this file again
+    under both settings -- the same bits either way (the switch is read once per process, hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("2", "0"):
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "tests/test_mjpeg_decode.py", "-m", "not gpu", "-k", "emu and not self_synchronising"],
+                           capture_output=True, text=True, env=dict(os.environ, LVM_MJD_PARALLEL=mode), cwd=root, timeout=900)
+        assert r.returncode == 0 and "passed" in r.stdout, (mode, (r.stdout + r.stderr)[-3000:])
+
+
 def test_mjpeg_round_trip_emu(lvm, emu):
     """encode on the device, decode on the device: the frame comes back within the quantisation error"""
     ctx = lvm.Context(0, 1, emu)
