@@ -119,7 +119,7 @@ def main():
             b = io.BytesIO()
             Image.fromarray(frames[k][..., ::-1]).save(b, "JPEG", quality=90, subsampling=2)
             lj.append(b.getvalue())
-        kinds.append(("libjpeg's frames (no restart markers: one lane per frame)", lj))
+        kinds.append(("libjpeg's frames (no restart markers: self-synchronising lanes of 1024 bits)", lj))
     except Exception:
         pass
     # (Huffman decoding is serial inside a restart interval: a call's time is the latency of ONE interval, whatever the number of frames)
