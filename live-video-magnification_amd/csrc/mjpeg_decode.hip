@@ -310,7 +310,8 @@ __global__ __launch_bounds__(64) void k_mjd_huffman(const uint8_t* __restrict__ 
 //   k_mjp_sync      lane i decodes subsequence i from where -- and in the state (block of the MCU, coefficient index) in which -- lane i - 1
 //                   last left ITS subsequence, and publishes its own exit (position, state, blocks completed).  First pass: every lane
 //                   guesses (start of its subsequence, start of an MCU).  Repeated until no exit changes: lane 0's entry is exact, hence by
-//                   induction every lane's; in practice two to four passes.
+//                   induction every lane's.  Code word boundaries are found again within a few symbols, the position inside the MCU (the four
+//                   luminance blocks share their tables) takes longer: 6 / 16 / 29 changing passes for 102 / 581 / 1 116 subsequences measured.
 //   k_mjp_scan      blocks completed before every lane (prefix sum)
 //   k_mjp_write     the same decoding once more from the exact entries, now storing coefficients (DC as differences)
 //   k_mjp_dc        DC prediction: prefix sums over the blocks of each component
