@@ -311,12 +311,17 @@ __global__ __launch_bounds__(64) void k_mjd_huffman(const uint8_t* __restrict__ 
 //                   last left ITS subsequence, and publishes its own exit (position, state, blocks completed).  First pass: every lane
 //                   guesses (start of its subsequence, start of an MCU).  Repeated until no exit changes: lane 0's entry is exact, hence by
 //                   induction every lane's.  Code word boundaries are found again within a few symbols, the position inside the MCU (the four
-//                   luminance blocks share their tables) takes longer: 6 / 16 / 29 changing passes for 102 / 581 / 1 116 subsequences measured.
+//                   luminance blocks share their tables) takes longer -- hence the look-back of the first pass (8 subsequences): 6 / 16 / 29 changing passes for 102 / 581 / 1 116 subsequences
+//                   without it, 0 / 2 / 7 with it.
 //   k_mjp_scan      blocks completed before every lane (prefix sum)
 //   k_mjp_write     the same decoding once more from the exact entries, now storing coefficients (DC as differences)
 //   k_mjp_dc        DC prediction: prefix sums over the blocks of each component
 // The result is what the one-lane decoder produces (same tables, same rules), the tests compare both with the oracle.
 constexpr uint32_t MJP_SUB_BITS = 1024;
+#ifndef MJP_LOOKBACK_N
+#define MJP_LOOKBACK_N 8
+#endif
+constexpr uint32_t MJP_LOOKBACK = MJP_LOOKBACK_N;
 struct MjpBits {
     const uint32_t* w; uint32_t nwords, next;
     unsigned long long acc; int cnt;
@@ -417,12 +422,22 @@ __global__ __launch_bounds__(64) void k_mjp_sync(const uint8_t* __restrict__ uby
     const uint32_t total_bits = ulen[f] * 8u, nsub = (total_bits + MJP_SUB_BITS - 1) / MJP_SUB_BITS, i = blockIdx.x * 64u + (uint32_t)tid;
     if (i >= nsub) return;
     const uint32_t* words = reinterpret_cast<const uint32_t*>(ubytes + ((foff[f] + fr.data_off + 3u) & ~3u));
-    uint32_t p0 = i * MJP_SUB_BITS;
+    // first pass: the guess starts MJP_LOOKBACK subsequences EARLIER (start of an MCU assumed there) and runs up to the lane's own
+    // subsequence: by then it has usually fallen into step with the code words and with the blocks of the MCU, so that most lanes are
+    // exact after this pass already and the later passes only repair the chains of lanes that were not
+    uint32_t p0 = first ? (i > MJP_LOOKBACK ? (i - MJP_LOOKBACK) * MJP_SUB_BITS : 0u) : i * MJP_SUB_BITS;
     int bi = 0, kk = 0;
     if (!first && i > 0) { const unsigned long long e = ein[(size_t)f * sub_cap + i - 1]; p0 = (uint32_t)e; const int st = (int)((e >> 32) & 511u); bi = st >> 6; kk = st & 63; }
     const uint32_t end = (i + 1) * MJP_SUB_BITS < total_bits ? (i + 1) * MJP_SUB_BITS : total_bits;
     MjpBits br;
     br.init(words, (ulen[f] + 3u) >> 2, p0);
+    if (first) {
+        const uint32_t own = i * MJP_SUB_BITS;
+        while (br.pos < own) {
+            int value; bool done;
+            if (mjp_step(br, bi, kk, fr, s_lut, value, done) == -2) br.skip(1);
+        }
+    }
     uint32_t blocks = 0;
     while (br.pos < end) {
         int value; bool done;
