@@ -216,7 +216,8 @@ int  lvm_export_frames(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_
  *                              frames come down.  host/HipMjpegWriter.hpp wraps the frames into the AVI container.                       */
 /*   lvm_mjpeg_decode_device    the other direction (cv::VideoCapture::read on an AVI / Motion-JPEG file, source/FileSource.cpp:99): n_frames
  *                              JPEG frames in host memory (jpegs[offsets[i] .. offsets[i + 1])) -> BGR frames of w x h in DEVICE memory.
- *                              Baseline 4:2:0 in one scan, any tables, with or without restart intervals; anything else, a size other
+ *                              Baseline 4:2:0 in one scan, any tables; frames with restart intervals decode a lane per interval, frames
+ *                              without through self-synchronising lanes of 1024 bits (a call's time is mostly latency: pass many frames); anything else, a size other
  *                              than w x h or a malformed stream is LVM_ERR_INVALID (lvm_last_error says which frame and why).  Synchronous. */
 /*   lvm_export_mjpeg_frames    lvm_export_frames_mjpeg with JPEG frames IN as well (an AVI / Motion-JPEG source file): decode, chain, compose and
  *                              encode all on the device, only compressed bytes cross PCIe in either direction (file -> file export).           */
