@@ -221,6 +221,7 @@ def test_export_mjpeg_to_mjpeg_emu(lvm, emu):
     _transcode_case(lvm, emu, 66, 38, 6, 1, {}, 90, 80)
     _transcode_case(lvm, emu, 80, 60, 5, 2, dict(downscale=2, roi_enabled=1, roiX=0.1, roiY=0.2, roiW=0.7, roiH=0.6, grayscale=1), 85, 95)
     _transcode_case(lvm, emu, 64, 48, 3, 0, dict(roi_enabled=1, roiX=0.25, roiY=0.25, roiW=0.5, roiH=0.5), 85, 75)     # ROI only: the magnifier reads a view of the decoded frame
+    _transcode_case(lvm, emu, 160, 96, 4, 1, {}, 97, 85)                # libjpeg's frames of > 2 KB: the self-synchronising kernels in front of the chain
 
 
 @pytest.mark.gpu
