@@ -581,7 +581,7 @@ static int export_frames_impl(lvm_ctx* c, const lvm_preprocess_params* pp, const
     while ((int)c->ev_up.size() < nchunks) { hipEvent_t e = nullptr; LVM_HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_up.push_back(e); }
     while ((int)c->ev_done.size() < nchunks) { hipEvent_t e = nullptr; LVM_HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->ev_done.push_back(e); }
     if (mj) { rc = lvm::mjpeg_begin(c, cw, chh, mj->quality, chunk < n_frames ? chunk : n_frames, (size_t)n_frames, mj->capacity, c->down_stream); if (rc != LVM_OK) return rc; }
-    auto drain = [&]() { (void)hipStreamSynchronize(c->up_stream); (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(c->down_stream); };
+    auto drain = [&]() { (void)hipStreamSynchronize(c->up_stream); (void)hipStreamSynchronize(s); (void)hipStreamSynchronize(c->down_stream); if (mj) lvm::mjpeg_abort(c); };
 #define LVM_EXPORT_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { c->err = std::string(#expr) + ": " + hipGetErrorString(e_); drain(); return LVM_ERR_HIP; } } while (0)
     const bool identity = ow == rw && oh == rh && och == channels;      // PreprocessProcessor.cpp:15, GrayscaleProcessor.cpp:8-9
     const uint8_t* mag_base = identity ? src_base : c->d_pre_out;
@@ -713,7 +713,7 @@ int lvm_mjpeg_encode_device(lvm_ctx* c, const uint8_t* d_bgr, int w, int h, ptrd
         const int nf = f0 + per <= n_frames ? per : n_frames - f0;
         rc = lvm::mjpeg_encode_device(c, d_bgr + (size_t)f0 * frame_stride, stride, frame_stride, nf, f0, out_capacity, s);
         if (rc == LVM_OK && f0 >= 2 * per) rc = lvm::mjpeg_drain(c, out, (size_t)(f0 / per) - 1);
-        if (rc != LVM_OK) { (void)hipStreamSynchronize(s); return rc; }
+        if (rc != LVM_OK) { (void)hipStreamSynchronize(s); lvm::mjpeg_abort(c); return rc; }
     }
     lvm::mark_enqueued(c, s);
     return lvm::mjpeg_finish(c, (size_t)n_frames, out, offsets, s);

@@ -494,6 +494,7 @@ int mjpeg_decode_enqueue(Ctx* c, int f0, int nf, uint8_t* d_bgr, ptrdiff_t strid
 int mjpeg_decode_finish(Ctx* c, hipStream_t s);
 int mjpeg_decode_device(Ctx* c, const uint8_t* jpegs, const size_t* offsets, int n, int w, int h, uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_t fstride, hipStream_t s);
 int mjpeg_drain(Ctx* c, uint8_t* out_host, size_t upto_call);
+void mjpeg_abort(Ctx* c);   // error paths: waits for the downloads mjpeg_drain has queued
 int mjpeg_finish(Ctx* c, size_t total_frames, uint8_t* out_host, size_t* offsets, hipStream_t s);
 int compose_device(Ctx* c, int split, const uint8_t* d_orig, int ow, int oh, int och, ptrdiff_t ostride, ptrdiff_t osstride,
                    const uint8_t* d_proc, int pw, int ph, int pch, ptrdiff_t pstride, ptrdiff_t psstride, uint8_t* d_canvas,

@@ -655,6 +655,13 @@ int mjpeg_encode_device(Ctx* c, const uint8_t* d_bgr, ptrdiff_t stride, ptrdiff_
 
 // Queues the download of the frames of the first `upto` encode calls since mjpeg_begin (those not queued yet): waits for each call's event
 // on the HOST (later calls keep the device busy meanwhile), then copies its bytes on the copy queue.
+// error paths of the callers: nothing may still be copying into the caller's host buffer when the call returns (ADVICE round 5:
+// mjpeg_drain queues its downloads on the encoder's private stream, which the callers' own drains do not know)
+void mjpeg_abort(Ctx* c) {
+    MjState* st = static_cast<MjState*>(c->mjpeg);
+    if (st && st->dl) (void)hipStreamSynchronize(st->dl);
+}
+
 int mjpeg_drain(Ctx* c, uint8_t* out_host, size_t upto) {
     MjState* st = static_cast<MjState*>(c->mjpeg);
     if (!st) return LVM_OK;

@@ -65,11 +65,14 @@ struct MjdState {
 
 int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 
-void build_decode_table(const uint8_t* bits, const uint8_t* vals, int nvals, MjdHuff& t) {
+// false: the code counts do not fit the code space (T.81 Annex C: at every length the codes assigned so far must leave room,
+// code + bits[len] <= 2^len) -- an over-subscribed DHT would index past lut[]
+bool build_decode_table(const uint8_t* bits, const uint8_t* vals, int nvals, MjdHuff& t) {
     std::memset(&t, 0, sizeof t);
     int code = 0, k = 0;
     for (int len = 1; len <= 16; ++len) {
         t.maxcode[len] = -1;
+        if (code + (int)bits[len - 1] > (1 << len)) return false;
         if (bits[len - 1]) {
             t.valptr[len] = k; t.mincode[len] = code;
             for (int i = 0; i < bits[len - 1] && k < nvals; ++i, ++k, ++code) {
@@ -82,6 +85,7 @@ void build_decode_table(const uint8_t* bits, const uint8_t* vals, int nvals, Mjd
     }
     t.maxcode[17] = 0x7FFFFFFF;
     for (int i = 0; i < nvals && i < 256; ++i) t.vals[i] = vals[i];
+    return true;
 }
 
 // SOI .. SOS of one frame (oracle: parse_header).  Returns nullptr, or what is unsupported / malformed.
@@ -113,7 +117,7 @@ const char* parse_frame(const uint8_t* j, size_t n, int w, int h, MjdFrame& f) {
                 for (int b = 0; b < 16; ++b) nv += p[k + 1 + b];
                 const int cls = p[k] >> 4, id = p[k] & 15;
                 if (cls > 1 || id > 1 || nv > 256 || k + 17 + (size_t)nv > pn) return "Huffman table (class / id / size)";
-                build_decode_table(p + k + 1, p + k + 17, nv, f.huff[cls][id]);
+                if (!build_decode_table(p + k + 1, p + k + 17, nv, f.huff[cls][id])) return "Huffman table (code space)";
                 have_h[cls][id] = true;
                 k += 17 + (size_t)nv;
             }
@@ -135,7 +139,7 @@ const char* parse_frame(const uint8_t* j, size_t n, int w, int h, MjdFrame& f) {
                 f.td[c] = p[2 + 2 * c] >> 4; f.ta[c] = p[2 + 2 * c] & 15;
                 if (f.td[c] > 1 || f.ta[c] > 1) return "Huffman table id";
             }
-            if (p[7] != 0 || p[8] != 63) return "not a full baseline scan";
+            if (p[7] != 0 || p[8] != 63 || p[9] != 0) return "not a full baseline scan";        // Ss, Se, Ah | Al
             for (int c = 0; c < 3; ++c) if (!have_q[f.tq[c]]) return "quantiser table missing";
             // frames of an AVI may leave the Huffman tables out: the Annex K tables are implied
             if (!have_h[0][0]) build_decode_table(kDcLumaBits, kDcVals, 12, f.huff[0][0]);
@@ -144,6 +148,8 @@ const char* parse_frame(const uint8_t* j, size_t n, int w, int h, MjdFrame& f) {
             if (!have_h[1][1]) build_decode_table(kAcChromaBits, kAcChromaVals, 162, f.huff[1][1]);
             size_t start = i + 2 + len, end = n;
             if (end >= start + 2 && j[end - 2] == 0xFF && j[end - 1] == 0xD9) end -= 2;      // EOI
+            // (bit positions of a frame are 32-bit in the kernels: data_len * 8 must not wrap)
+            if (end - start >= ((size_t)1 << 28)) return "entropy-coded segment of 256 MiB or more";
             f.data_off = (uint32_t)start; f.data_len = (uint32_t)(end - start);
             return nullptr;
         }

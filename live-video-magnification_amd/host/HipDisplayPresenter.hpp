@@ -55,13 +55,18 @@ public:
             T::create(proc_, pb); T::create(orig_, ob);
             proc_bytes_ = pb; orig_bytes_ = ob; have_ = true;
         }
-        std::uint8_t* dp = T::map(proc_);
-        std::uint8_t* dorig = T::map(orig_);
-        const lvm_params c = to_c(mag, 0);
-        int produced = 0;
-        const int rc = lvm_chain_present(mag_.handle(), &pre, &c, frame, w, h, channels, stride, dp, (std::ptrdiff_t)ow * och, dorig,
-                                         (std::ptrdiff_t)ow * channels, &produced);
-        T::unmap(orig_); T::unmap(proc_);
+        int produced = 0, rc = LVM_OK;
+        {
+            // a buffer left mapped makes the following glTexSubImage2D and the next present() fail: whatever throws between the two
+            // maps and the two unmaps (a failing hipGraphicsMapResources on the second buffer, an unmap that throws), both buffers are
+            // unmapped when this block is left
+            Mapped mp(proc_);
+            Mapped mo(orig_);
+            const lvm_params c = to_c(mag, 0);
+            rc = lvm_chain_present(mag_.handle(), &pre, &c, frame, w, h, channels, stride, mp.ptr, (std::ptrdiff_t)ow * och, mo.ptr,
+                                   (std::ptrdiff_t)ow * channels, &produced);
+            mo.release(); mp.release();      // (the normal path reports an unmap failure; the destructors only clean up behind an exception)
+        }
         if (rc != LVM_OK) throw Error(rc, std::string("lvm: ") + lvm_last_error(mag_.handle()));
         T::upload(proc_, tex_proc, ow, oh, och);
         T::upload(orig_, tex_orig, ow, oh, channels);
@@ -71,6 +76,13 @@ public:
     void reset() { mag_.reset(); }
 
 private:
+    struct Mapped {                      // one mapped buffer; unmapped on scope exit, never throwing from the destructor
+        typename T::Buffer& b; std::uint8_t* ptr = nullptr; bool held = false;
+        explicit Mapped(typename T::Buffer& buf) : b(buf) { ptr = T::map(b); held = true; }
+        void release() { if (held) { held = false; T::unmap(b); } }
+        ~Mapped() { if (held) { try { T::unmap(b); } catch (...) {} } }
+        Mapped(const Mapped&) = delete; Mapped& operator=(const Mapped&) = delete;
+    };
     void release() {
         if (have_) { T::destroy(proc_); T::destroy(orig_); have_ = false; }
         proc_bytes_ = orig_bytes_ = 0;

@@ -91,7 +91,8 @@ private:
                 typename T::View raw{};
                 if (!T::next(src, raw)) { more = false; break; }                                // :217
                 if (raw.empty || !raw.data) continue;                                           // :218
-                if (canvas_empty(raw, pre, split)) continue;                                    // :243 `if (canvas.empty()) continue;` (the frame is consumed, nothing is written;
+                if (canvas_empty(raw, pre, split)) { ++seq; continue; }                         // :243 `if (canvas.empty()) continue;` (the frame is consumed, nothing is written --
+                                                                                                //  but it HAS taken its sequence number, :224 precedes :243: the pts of later frames count it;
                                                                                                 //  such a frame cannot pass the magnifier either: both of its sizes are < 2)
                 if (!slots_ready(raw)) {
                     if (n == 0) prepare(raw, pre, split);

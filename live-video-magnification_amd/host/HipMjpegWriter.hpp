@@ -131,7 +131,7 @@ public:
         if (!is_mjpg || frames_.empty() || w_ <= 0 || h_ <= 0) { close(); return false; }
         return true;
     }
-    void close() { if (f_) std::fclose(f_); f_ = nullptr; frames_.clear(); w_ = h_ = 0; fps_ = 0.0; }
+    void close() { if (f_) std::fclose(f_); f_ = nullptr; frames_.clear(); w_ = h_ = 0; fps_ = 0.0; strl_seen_ = 0; vid_stream_ = -1; }
     bool isOpened() const { return f_ != nullptr; }
     int width() const { return w_; }
     int height() const { return h_; }
@@ -145,7 +145,7 @@ private:
     struct Chunk { std::uint64_t offset; std::uint32_t bytes; };
     static std::uint32_t le32(const std::uint8_t* p) { return (std::uint32_t)p[0] | ((std::uint32_t)p[1] << 8) | ((std::uint32_t)p[2] << 16) | ((std::uint32_t)p[3] << 24); }
     bool at(std::uint64_t pos, void* dst, std::size_t n) { return f_ && std::fseek(f_, (long)pos, SEEK_SET) == 0 && std::fread(dst, 1, n, f_) == n; }
-    bool parse_hdrl(std::uint64_t p, std::uint64_t end) {
+    bool parse_hdrl(std::uint64_t p, std::uint64_t end, int depth = 0) {
         bool mjpg = false;
         while (p + 8 <= end) {
             std::uint8_t ch[12];
@@ -155,13 +155,15 @@ private:
                 std::uint8_t a[40];
                 if (at(p + 8, a, 40)) { const std::uint32_t usec = le32(a); if (usec) fps_ = 1e6 / usec; w_ = (int)le32(a + 32); h_ = (int)le32(a + 36); }
             } else if (std::memcmp(ch, "LIST", 4) == 0 && at(p + 8, ch + 8, 4) && std::memcmp(ch + 8, "strl", 4) == 0) {
-                mjpg = parse_hdrl(p + 12, p + 8 + n) || mjpg;
+                ++strl_seen_;                                                                    // stream number = position of its 'strl' list
+                if (depth < 4) mjpg = parse_hdrl(p + 12, p + 8 + n < end ? p + 8 + n : end, depth + 1) || mjpg;
             } else if (std::memcmp(ch, "strh", 4) == 0 && n >= 32) {
                 std::uint8_t a[32];
                 if (at(p + 8, a, 32) && std::memcmp(a, "vids", 4) == 0) {
                     const std::uint32_t scale = le32(a + 20), rate = le32(a + 24);
                     if (scale && rate) fps_ = (double)rate / (double)scale;
                     if (std::memcmp(a + 4, "MJPG", 4) == 0 || std::memcmp(a + 4, "mjpg", 4) == 0) mjpg = true;
+                    if (vid_stream_ < 0) vid_stream_ = strl_seen_ > 0 ? strl_seen_ - 1 : 0;     // the FIRST video stream is the one read
                 }
             } else if (std::memcmp(ch, "strf", 4) == 0 && n >= 20) {
                 std::uint8_t a[20];
@@ -171,13 +173,17 @@ private:
         }
         return mjpg;
     }
-    void scan_movi(std::uint64_t p, std::uint64_t end) {
+    // chunks '##dc' / '##db' of the video stream only (## = its two-digit stream number: another stream's chunks -- a second video
+    // track, audio mislabelled by a broken muxer -- are not frames of this one); 'rec ' groups nest at most a few levels in any real file
+    void scan_movi(std::uint64_t p, std::uint64_t end, int depth = 0) {
+        const int vs = vid_stream_ < 0 ? 0 : vid_stream_;
+        const std::uint8_t d0 = (std::uint8_t)('0' + (vs / 10) % 10), d1 = (std::uint8_t)('0' + vs % 10);
         while (p + 8 <= end) {
             std::uint8_t ch[12];
             if (!at(p, ch, 8)) break;
             const std::uint64_t n = le32(ch + 4);
-            if (std::memcmp(ch, "LIST", 4) == 0) { scan_movi(p + 12, p + 8 + n); }             // 'rec ' groups
-            else if (ch[2] == 'd' && (ch[3] == 'c' || ch[3] == 'b') && n >= 4) frames_.push_back({p + 8, (std::uint32_t)n});
+            if (std::memcmp(ch, "LIST", 4) == 0) { if (depth < 4) scan_movi(p + 12, p + 8 + n < end ? p + 8 + n : end, depth + 1); }
+            else if (ch[0] == d0 && ch[1] == d1 && ch[2] == 'd' && (ch[3] == 'c' || ch[3] == 'b') && n >= 4 && p + 8 + n <= end) frames_.push_back({p + 8, (std::uint32_t)n});
             p += 8 + n + (n & 1);
         }
     }
@@ -185,6 +191,7 @@ private:
     int w_ = 0, h_ = 0;
     double fps_ = 0.0;
     std::vector<Chunk> frames_;
+    int strl_seen_ = 0, vid_stream_ = -1;
 };
 
 }  // namespace lvm

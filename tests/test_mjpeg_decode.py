@@ -106,6 +106,23 @@ def test_mjpeg_decode_emu_refuses_what_it_does_not_decode(lvm, emu):
                          (mo.encode_frame(texture(32, 48), 80), "size"), (good[:200], "marker|segment"), (b"\x00\x01" + good, "SOI")]:
             with pytest.raises(lvm.LvmError, match=why):
                 ctx.mjpeg_decode_device([bad], 64, 48, p)
+        # a DHT whose code counts do not fit the code space (255 codes of length 1: ADVICE round 5 -- the look-up table build
+        # would have written ~130 KB past the table; tools/emu_asan.sh runs this file under AddressSanitizer), and scans with Ah | Al set
+        i = good.index(b"\xff\xc4")
+        n = (good[i + 2] << 8) | good[i + 3]
+        evil = b"\xff\xc4" + (2 + 17 + 255).to_bytes(2, "big") + b"\x00" + bytes([255] + [0] * 15) + bytes(range(255))
+        with pytest.raises(lvm.LvmError, match="code space"):
+            ctx.mjpeg_decode_device([good[:i] + evil + good[i + 2 + n:]], 64, 48, p)
+        for bits in ([3] + [0] * 15, [1, 3] + [0] * 14, [0, 0, 0, 0, 0, 0, 0, 0, 255, 2] + [0] * 6):        # over-subscribed at length 1, 2, 10
+            evil = b"\xff\xc4" + (2 + 17 + sum(bits)).to_bytes(2, "big") + b"\x10" + bytes(bits) + bytes(range(sum(bits) % 256)) + bytes(max(0, sum(bits) - 256 + 1))
+            evil = evil[:4 + 17 + sum(bits)]
+            with pytest.raises(lvm.LvmError, match="code space|Huffman"):
+                ctx.mjpeg_decode_device([good[:i] + evil + good[i + 2 + n:]], 64, 48, p)
+        hd0 = mo.parse_header(good)
+        sos = bytearray(good)
+        sos[hd0["data_start"] - 1] = 0x01
+        with pytest.raises(lvm.LvmError, match="baseline scan"):
+            ctx.mjpeg_decode_device([bytes(sos)], 64, 48, p)
         # wrong restart-marker count
         cut = good.replace(b"\xff\xd0", b"\xff\x00", 1)
         with pytest.raises(lvm.LvmError, match="restart"):
