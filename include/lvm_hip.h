@@ -273,6 +273,12 @@ int  lvm_debug_read_float(lvm_ctx* ctx, float* dst, size_t count);
  * well-conditioned math.  lvm_debug_lab_analytic(1): the cube-root form RGB2Lab_f computes when OpenCV's interpolation is
  * switched off (implies the exact operation order).                                                                    */
 int  lvm_debug_exact_lab(lvm_ctx* ctx, int on);
+/* The output quantiser of the Lab modes -- u8 = saturate_cast<uchar>(cvRound(255 * invGamma(clip01(c)) + 1/255)) per channel
+ * (Lab2RGBfloat + convertTo, MagnifyCore.hpp:152-153, :275-276) -- runs as a 4096-slice step table in the default flavour
+ * (lab_tables.cpp build_u8_steps).  This entry compares the table with the operations it replaces for every float whose bit
+ * pattern lies in [first_bits, first_bits + count) ON THE DEVICE: *mismatches = patterns where the bytes differ, *first_bad_bits =
+ * the smallest of them.  (0, 1 << 32) sweeps every binary32 value: negative, above 1, infinities, NaN included.             */
+int  lvm_debug_sweep_u8_steps(lvm_ctx* ctx, uint32_t first_bits, uint64_t count, uint64_t* mismatches, uint32_t* first_bad_bits);
 int  lvm_debug_lab_analytic(lvm_ctx* ctx, int on);
 /* The forward table: LVM_LAB_LUT_ENTRIES int16 values in OpenCV's RGB2Labprev order, index 3 (p + 33 q + 1089 r) + channel
  * with p, q, r the R, G, B grid indices and entries L / 100 * 16384, (a + 128) / 256 * 16384, (b + 128) / 256 * 16384.

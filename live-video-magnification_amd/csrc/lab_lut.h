@@ -29,6 +29,7 @@
 
 namespace lvm {
 
+constexpr int kU8StepSlices = 4096;       // slices of the output quantiser's step table (lab_tables.cpp build_u8_steps)
 constexpr int kLabLutDim = 33;
 constexpr int kLabLutNodes = kLabLutDim * kLabLutDim * kLabLutDim;
 // node index n = p + 33 q + 1089 r (p, q, r = R, G, B grid index).  Neighbours n + 1, n + 33, n + 34 of an edge cell carry

@@ -100,6 +100,56 @@ void build_lab_tables(float gamma_u8[256], float invgamma[4096], float fwd[9], f
     }
 }
 
+// ---- the output quantiser as a step function (round 6) ----------------------------------------------------------------------
+// The last thing the Lab modes do to a pixel is u8 = saturate_cast<uchar>(cvRound(255 * invGamma(clip01(c)) + 1/255)) per channel
+// (Lab2RGBfloat's splineInterpolate, then convertTo(CV_8U, 255, 1.0/255): MagnifyCore.hpp:152-153, :275-276) -- a monotone step
+// function of the clipped linear value c with exactly 255 steps (monotone over EVERY float in [0, 1]: checked exhaustively by
+// tests/test_u8_steps.py on the CPU and by lvm_debug_sweep_u8_steps on the GPU; the cubic's rounding noise never straddles a
+// rounding boundary twice).  Its 255 thresholds, found by bisection against the exact code above, replace spline evaluation + scale +
+// round + clamp in the output kernels by one table hit and one compare: [0, 1) is cut into 4096 slices of 1/4096 (the smallest gap
+// between two thresholds is 1.24 slices, in the linear segment of the sRGB curve), entry i = { the threshold inside slice i scaled
+// by 4096, or +inf ; the value at the slice's start }.  Bit-exact u8 by construction.
+namespace {
+inline int u8_of_linear(float c, const float* invgamma, float a255) {
+    const float cc = c < 0.f ? 0.f : (c > 1.f ? 1.f : c);
+    const float o = spline_eval(cc * (float)kTab, invgamma, kTab);
+    const float v = o * 255.0f + a255;
+    const float r = std::nearbyint(v);           // cvRound: round half to even (the default rounding mode)
+    return r < 0.f ? 0 : (r > 255.f ? 255 : (int)r);
+}
+}  // namespace
+
+bool build_u8_steps(const float invgamma[4096], uint32_t steps[2 * kU8StepSlices]) {
+    const float a255 = (float)(1.0 / 255.0f);
+    uint32_t one_bits; { const float one = 1.0f; std::memcpy(&one_bits, &one, 4); }
+    auto at_bits = [&](uint32_t b) { float c; std::memcpy(&c, &b, 4); return u8_of_linear(c, invgamma, a255); };
+    if (at_bits(0) != 0 || at_bits(one_bits) != 255) return false;
+    float thr[256];                              // thr[k] = the smallest c with u8(c) >= k (non-negative floats order like their bit patterns)
+    for (int k = 1; k <= 255; ++k) {
+        uint32_t lo = 0, hi = one_bits;          // u8(lo) < k <= u8(hi)
+        while (hi - lo > 1) { const uint32_t mid = lo + (hi - lo) / 2; if (at_bits(mid) >= k) hi = mid; else lo = mid; }
+        std::memcpy(&thr[k], &hi, 4);
+        if (at_bits(hi) != k || at_bits(hi - 1) != k - 1) return false;      // a step of more than one level, or not monotone here
+        if (k > 1 && !(thr[k] > thr[k - 1])) return false;
+    }
+    const uint32_t inf_bits = 0x7f800000u;
+    for (int i = 0; i < kU8StepSlices; ++i) { steps[2 * i] = inf_bits; steps[2 * i + 1] = 0; }
+    int k = 1;
+    for (int i = 0; i < kU8StepSlices; ++i) {
+        steps[2 * i + 1] = (uint32_t)(k - 1);                               // value on [i / 4096, first threshold inside the slice)
+        int inside = 0;
+        while (k <= 255 && thr[k] * (float)kU8StepSlices < (float)(i + 1)) {   // (the scaling is a power of two: exact)
+            const float t = thr[k] * (float)kU8StepSlices;
+            std::memcpy(&steps[2 * i], &t, 4);
+            ++k; ++inside;
+        }
+        if (inside > 1) return false;
+    }
+    // the kernels clamp to the largest float below 4096: it must already give what 1.0 (and everything above) gives
+    if (k != 256) return false;
+    return true;
+}
+
 // ---- OpenCV 4's RGB2Lab interpolation table (color_lab.cpp initLabTabs, the enableRGB2LabInterpolation block) ----------
 // OpenCV builds the 33^3 table with its softfloat type, i.e. IEEE binary32 operations rounded one by one; the same
 // sequence is restated here on native floats (this translation unit is built with -ffp-contract=off):

@@ -113,4 +113,51 @@ void lab_lut_planes(Ctx* c, const uint8_t* d_in, long in_stride, long in_sstride
     LVM_LAUNCH(c, "lab_lut", k, dim3((unsigned)blocks), dim3(LC_THREADS), s, d_in, in_stride, in_sstride, w, h, nframes, c->lab_lut, iL, Lf, iab, (int)per);
 }
 
+// ---- lvm_debug_sweep_u8_steps: the step table against the operations it replaces, float by float ---------------------------------
+// Thread i of the grid takes the bit patterns first + i, first + i + stride, ...: c = the float with that pattern; reference = OpenCV's
+// operations one by one (clip01, x 1024, splineInterpolate, x 255 + 1/255, cvRound + saturate -- the EXACT flavour's code); candidate =
+// u8_step(4096 c).  Counts the patterns where the two bytes differ and keeps the smallest such pattern.
+__global__ __launch_bounds__(256) void k_sweep_u8_steps(LabCoef lab, unsigned long long first, unsigned long long count, unsigned long long* bad, unsigned long long* first_bad) {
+    __shared__ __attribute__((aligned(16))) float s_igt[4096];
+    __shared__ uint2 s_steps[kU8StepSlices];
+    load_invgamma(s_igt, lab.invgamma);
+    load_u8steps(s_steps, lab.u8steps);
+    __syncthreads();
+    unsigned long long nbad = 0, fb = ~0ull;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint32_t bits = (uint32_t)(first + i);
+        const float c = __uint_as_float(bits);
+        uint32_t want = 0;
+        if (c == c) {                                                       // (NaN: both sides give 0 -- the reference's (int)NaN is not C)
+            const float o = spline1024<true>(clip01(c) * 1024.f, s_igt);
+            want = __builtin_amdgcn_cvt_pk_u8_f32(o * 255.0f + lab.a255, 0, 0);
+        }
+        const uint32_t got = u8_step(c * 4096.0f, s_steps);
+        if (got != want) { ++nbad; if (first + i < fb) fb = first + i; }
+    }
+    if (nbad) { atomicAdd(bad, nbad); atomicMin(first_bad, fb); }
+}
+
+int sweep_u8_steps(Ctx* c, unsigned long long first, unsigned long long count, unsigned long long* bad, unsigned long long* first_bad, hipStream_t s) {
+    unsigned long long* d = nullptr;
+    LVM_HIP_TRY(c, hipMalloc((void**)&d, 16));
+    const unsigned long long init[2] = {0ull, ~0ull};
+    hipError_t e = hipMemcpyAsync(d, init, 16, hipMemcpyHostToDevice, s);
+    long blocks = (long)((count + 255) / 256);
+    if (blocks > 8L * c->num_cus) blocks = 8L * c->num_cus;
+    if (blocks < 1) blocks = 1;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_sweep_u8_steps, dim3((unsigned)blocks), dim3(256), 0, s, c->lab, first, count, d, d + 1);
+        e = hipGetLastError();
+    }
+    unsigned long long out[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, 16, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d);
+    if (e != hipSuccess) { c->err = std::string("sweep_u8_steps: ") + hipGetErrorString(e); return LVM_ERR_HIP; }
+    *bad = out[0]; *first_bad = out[1];
+    return LVM_OK;
+}
+
 }  // namespace lvm

@@ -649,12 +649,27 @@ struct FinArgs {
 // One output row of 4 pixels: Lab(in) + [1, ca, ca] * motion -> Lab2BGR -> u8 (MagnifyCore.hpp:143-153).  m = the motion image of the
 // row (EXACT: scaled by 1/64 as pyrUp does; otherwise the unscaled vertical sum, whose power-of-two scale `msc` is folded into the
 // add -- fma(m, 2^-k, L) rounds exactly like L + m * 2^-k).  dbg_px: where the float pixels go (lvm_debug_keep_float) or null.
+// STEPS (the default flavour without the float frame): s_igt points at the u8 step table instead of the spline (lab_to_u8)
 template <bool MOTION, bool DBG, int FL>
 __device__ __forceinline__ B96 lap_emit_row(const Raw4 pin, const float (&m)[3][4], const float msc, const float ca, const LabCoef& lab,
                                             const float* s_igt, const float* s_gam, float* dbg_px) {
     constexpr bool EXACT = fl_exact(FL);
+    constexpr bool STEPS = fin_steps(FL, DBG);
     float L4[4], a4[4], b4[4];
     raw4_to_lab<FL>(pin, s_gam, lab, L4, a4, b4);
+    if (STEPS) {
+        uint32_t u[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float L = L4[k], a = a4[k], bb = b4[k];
+            if (MOTION) {
+                L = __builtin_fmaf(m[0][k], msc, L);
+                a = __builtin_fmaf(m[1][k], msc * ca, a); bb = __builtin_fmaf(m[2][k], msc * ca, bb);
+            }
+            lab_to_u8(L, a, bb, lab.inv4096, reinterpret_cast<const uint2*>(s_igt), u[3 * k], u[3 * k + 1], u[3 * k + 2]);
+        }
+        return B96{lvm_pack_b4(u[0], u[1], u[2], u[3]), lvm_pack_b4(u[4], u[5], u[6], u[7]), lvm_pack_b4(u[8], u[9], u[10], u[11])};
+    }
     float ov[12];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -746,6 +761,8 @@ __device__ __forceinline__ void lap_final_strip(const FinArgs& q, int task, int 
     };
     // two output rows (2j, 2j+1) from the window rows A = j-1, B = j, C = j+1; afterwards A holds row
     // j+2, i.e. the window has rotated to (B, C, A).  Returns false when the strip is finished.
+    // (round 6, measured and NOT taken: the input rows of a step loaded one step ahead -- 12 more VGPRs, 3.5 % more instructions for the
+    //  register rotation -- made the kernel SLOWER, 188-191 -> 199-202 us per 32 frames: it is not waiting for its own loads)
     auto step = [&](Row3& A, const Row3& B, const Row3& C) __attribute__((always_inline)) {
         const Raw4 pe = ld_in(gy);
         const bool has_odd = gy + 1 < yend;
@@ -795,9 +812,11 @@ __device__ __forceinline__ void lap_final_strip(const FinArgs& q, int task, int 
 }
 template <bool MOTION, bool DBG, int FL>
 __global__ LVM_FIN_BOUNDS void k_lap_final_v4(FinArgs q) {
-    __shared__ __attribute__((aligned(16))) float s_igt[4096];
+    constexpr bool STEPS = fin_steps(FL, DBG);
+    __shared__ __attribute__((aligned(16))) float s_igt[STEPS ? 2 * kU8StepSlices : 4096];      // the inverse-gamma spline | the u8 step table
     __shared__ float s_gam[fl_lut(FL) ? 1 : 256];
-    {
+    if (STEPS) load_u8steps(reinterpret_cast<uint2*>(s_igt), q.lab.u8steps);
+    else {
         const float4* src = reinterpret_cast<const float4*>(q.lab.invgamma);
         for (int i = threadIdx.x; i < 1024; i += FIN_THREADS) reinterpret_cast<float4*>(s_igt)[i] = src[i];
         if (!fl_lut(FL) && threadIdx.x < 256) s_gam[threadIdx.x] = q.lab.gamma_u8[threadIdx.x];

@@ -186,7 +186,9 @@ int lvm_create(int device, int n_streams, lvm_ctx** out) {
     { int n = 0; if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && n > 0) c->num_cus = n; }
     float g[256] = {}, ig[4096] = {};
     lvm::build_lab_tables(g, ig, c->lab.fwd, c->lab.inv);
-    for (int i = 0; i < 9; ++i) c->lab.inv1024[i] = c->lab.inv[i] * 1024.0f;
+    for (int i = 0; i < 9; ++i) { c->lab.inv1024[i] = c->lab.inv[i] * 1024.0f; c->lab.inv4096[i] = c->lab.inv[i] * 4096.0f; }
+    std::vector<uint32_t> steps(2 * lvm::kU8StepSlices);
+    if (!lvm::build_u8_steps(ig, steps.data())) { delete c; return LVM_ERR_INVALID; }      // (cannot happen with OpenCV's spline: checked by the tests)
     bool ok = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess;
@@ -195,6 +197,8 @@ int lvm_create(int device, int n_streams, lvm_ctx** out) {
     ok = ok && hipMalloc((void**)&c->d_invgamma, sizeof(ig)) == hipSuccess;
     ok = ok && hipMemcpy(c->d_gamma_u8, g, sizeof(g), hipMemcpyHostToDevice) == hipSuccess;
     ok = ok && hipMemcpy(c->d_invgamma, ig, sizeof(ig), hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->d_u8steps, steps.size() * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemcpy(c->d_u8steps, steps.data(), steps.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
     if (ok) {
         // OpenCV's forward Lab table (lab_tables.cpp) and the closed form of its cell index (lab_lut.h)
         if (!lvm::lab_lut_fine_index_ok()) { lvm_destroy(c); return LVM_ERR_INVALID; }
@@ -205,6 +209,7 @@ int lvm_create(int device, int n_streams, lvm_ctx** out) {
     if (!ok) { lvm_destroy(c); return LVM_ERR_HIP; }
     c->lab.gamma_u8 = c->d_gamma_u8;
     c->lab.invgamma = c->d_invgamma;
+    c->lab.u8steps = c->d_u8steps;
     c->lab.a255 = (float)(1.0 / 255.0f);
     *out = c;
     return LVM_OK;
@@ -218,6 +223,7 @@ void lvm_destroy(lvm_ctx* c) {
     for (auto& e : c->prof_events) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); }
     if (c->d_gamma_u8) (void)hipFree(c->d_gamma_u8);
     if (c->d_invgamma) (void)hipFree(c->d_invgamma);
+    if (c->d_u8steps) (void)hipFree(c->d_u8steps);
     if (c->d_lab_ab) (void)hipFree(c->d_lab_ab);
     if (c->d_lab_Lcells) (void)hipFree(c->d_lab_Lcells);
     if (c->d_in) (void)hipFree(c->d_in);
@@ -812,6 +818,17 @@ const char* lvm_last_error(lvm_ctx* c) { return c ? c->err.c_str() : "null conte
 int lvm_debug_keep_float(lvm_ctx* c, int on) { if (!c) return LVM_ERR_INVALID; c->keep_float = on != 0; return LVM_OK; }
 
 int lvm_debug_exact_lab(lvm_ctx* c, int on) { if (!c) return LVM_ERR_INVALID; c->exact_lab = on != 0; return LVM_OK; }
+
+int lvm_debug_sweep_u8_steps(lvm_ctx* c, uint32_t first_bits, uint64_t count, uint64_t* mismatches, uint32_t* first_bad_bits) {
+    if (!c || !mismatches || (uint64_t)first_bits + count > (1ull << 32)) return LVM_ERR_INVALID;
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    unsigned long long bad = 0, fb = 0;
+    const int rc = lvm::sweep_u8_steps(c, first_bits, count, &bad, &fb, c->own_stream);
+    if (rc != LVM_OK) return rc;
+    *mismatches = bad;
+    if (first_bad_bits) *first_bad_bits = bad ? (uint32_t)fb : 0u;
+    return LVM_OK;
+}
 
 int lvm_debug_lab_analytic(lvm_ctx* c, int on) { if (!c) return LVM_ERR_INVALID; c->lab_analytic = on != 0; return LVM_OK; }
 

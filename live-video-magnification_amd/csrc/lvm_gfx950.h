@@ -182,6 +182,13 @@ __device__ __forceinline__ uint32_t lut_hi2(uint32_t d, uint32_t e) { return __b
 // four of them per pixel in round 3's ISA, ~12 issue slots of the conversion's ~94
 __device__ __forceinline__ uint32_t lut_mul24(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// four values < 256 -> one dword (a in byte 0) as three v_perm_b32: a | b << 8 | c << 16 | d << 24 is otherwise built from two shifts, a
+// v_or3_b32 and a v_lshl_or_b32; an inline-asm v_lshl_or_b32 chain costs an s_nop per statement (the hazard recogniser pads what it cannot see)
+__device__ __forceinline__ uint32_t lvm_pack_b4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    const uint32_t lo = __builtin_amdgcn_perm(b, a, 0x0c0c0400u), hi = __builtin_amdgcn_perm(d, c, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
 // the lanes of the wave whose predicate holds (v_cmp into an SGPR pair); every lane of the wave must execute it
 __device__ __forceinline__ unsigned long long lvm_ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 // Orders the LDS accesses of ONE wave: what its lanes wrote before is what its lanes read after (the LDS serves a wave's requests in

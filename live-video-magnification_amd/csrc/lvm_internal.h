@@ -105,6 +105,8 @@ struct LabCoef {
     float fwd[9];             // BGR(linear) -> XYZ/white, row-major, column 0 multiplies B
     float inv[9];             // XYZ -> BGR(linear), row 0 produces B
     float inv1024[9];         // inv * 1024 (exact): the fast flavour gets the spline coordinate straight out of the matrix
+    float inv4096[9];         // inv * 4096 (exact): ... and the slice coordinate of the u8 step table (u8_step)
+    const uint2* u8steps;     // [kU8StepSlices] { threshold * 4096 | +inf, value at the slice's start } (device; lab_tables.cpp build_u8_steps)
     const float* gamma_u8;    // [256]  sRGB gamma of u8/255 (device)
     const float* invgamma;    // [1024*4] cubic-spline coefficients of the inverse gamma (device)
     float a255;               // float(1.0/255.0f)
@@ -206,8 +208,37 @@ __device__ __forceinline__ float clip01_fast(float v) { return __builtin_amdgcn_
 // lets spline1024 skip the knot clamp
 __device__ __forceinline__ float clip01_open(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 0.99999994f); }
 __device__ __forceinline__ float clip1024_open(float v) { return __builtin_amdgcn_fmed3f(v, 0.f, 1023.99994f); }   // = clip01_open(v / 1024) * 1024
+// The output quantiser u8 = cvRound(255 * invGamma(clip01(c)) + 1/255) as a table hit + a compare (lab_tables.cpp build_u8_steps): c4096 = 4096 c;
+// s_steps = the table in LDS.  NaN -> 0 like the spline path (v_med3_f32 returns the minimum when an input is NaN).
+__device__ __forceinline__ uint32_t u8_step(float c4096, const uint2* s_steps) {
+    const float cc = __builtin_amdgcn_fmed3f(c4096, 0.f, 4095.99976f);
+    const uint2 e = s_steps[(int)cc];
+    return e.y + (cc >= __uint_as_float(e.x) ? 1u : 0u);
+}
 // convertTo(CV_8U) for finite input: round-half-even, clamp, convert (3 instructions)
 __device__ __forceinline__ uint32_t sat_u8_fast(float v) { return (uint32_t)__builtin_amdgcn_fmed3f(rintf(v), 0.f, 255.f); }
+// The default flavour's Lab -> linear BGR: reciprocal multiplies, fma chains, selects.  iv = inv scaled by a power of two (inv1024 /
+// inv4096): the scale commutes with every rounding, so the spline coordinate 1024 c / the step-table coordinate 4096 c comes out directly.
+__device__ __forceinline__ void lab_to_linear_fast(float li, float ai, float bi, const float* iv, float& c0, float& c1, float& c2) {
+    const float lThresh = 0.008856f * 903.3f;
+    const float fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
+    const float ylin = li * (1.0f / 903.3f), fyc = (li + 16.0f) * (1.0f / 116.0f);
+    const bool lo = li <= lThresh;
+    const float fy = lo ? __builtin_fmaf(7.787f, ylin, 16.0f / 116.0f) : fyc;
+    const float y = lo ? ylin : fyc * fyc * fyc;
+    float fx = __builtin_fmaf(ai, 1.0f / 500.0f, fy), fz = __builtin_fmaf(bi, -1.0f / 200.0f, fy);
+    fx = (fx <= fThresh) ? (fx - 16.0f / 116.0f) * (1.0f / 7.787f) : fx * fx * fx;
+    fz = (fz <= fThresh) ? (fz - 16.0f / 116.0f) * (1.0f / 7.787f) : fz * fz * fz;
+    c0 = __builtin_fmaf(iv[0], fx, __builtin_fmaf(iv[1], y, iv[2] * fz));
+    c1 = __builtin_fmaf(iv[3], fx, __builtin_fmaf(iv[4], y, iv[5] * fz));
+    c2 = __builtin_fmaf(iv[6], fx, __builtin_fmaf(iv[7], y, iv[8] * fz));
+}
+// ... and straight on to the three output bytes (round 6): the quantiser as a step table instead of spline + scale + round + clamp
+__device__ __forceinline__ void lab_to_u8(float li, float ai, float bi, const float* iv4096, const uint2* s_steps, uint32_t& u0, uint32_t& u1, uint32_t& u2) {
+    float c0, c1, c2;
+    lab_to_linear_fast(li, ai, bi, iv4096, c0, c1, c2);
+    u0 = u8_step(c0, s_steps); u1 = u8_step(c1, s_steps); u2 = u8_step(c2, s_steps);
+}
 // Lab2RGBfloat::process + inverse gamma; igt = inverse-gamma spline table (LDS).  EXACT keeps
 // OpenCV's divisions by 903.3 / 116 / 500 / 200 / 7.787 and its unfused products; otherwise
 // reciprocal multiplies, fma chains and selects.
@@ -227,17 +258,7 @@ __device__ __forceinline__ void lab_to_bgr(float li, float ai, float bi, const f
         c1 = iv[3] * fx + iv[4] * y + iv[5] * fz;
         c2 = iv[6] * fx + iv[7] * y + iv[8] * fz;
     } else {
-        const float ylin = li * (1.0f / 903.3f), fyc = (li + 16.0f) * (1.0f / 116.0f);
-        const bool lo = li <= lThresh;
-        fy = lo ? __builtin_fmaf(7.787f, ylin, 16.0f / 116.0f) : fyc;
-        y = lo ? ylin : fyc * fyc * fyc;
-        fx = __builtin_fmaf(ai, 1.0f / 500.0f, fy); fz = __builtin_fmaf(bi, -1.0f / 200.0f, fy);
-        fx = (fx <= fThresh) ? (fx - 16.0f / 116.0f) * (1.0f / 7.787f) : fx * fx * fx;
-        fz = (fz <= fThresh) ? (fz - 16.0f / 116.0f) * (1.0f / 7.787f) : fz * fz * fz;
-        // iv = inv1024 here: a power-of-two scale commutes with every rounding, so c * 1024 comes out directly
-        c0 = __builtin_fmaf(iv[0], fx, __builtin_fmaf(iv[1], y, iv[2] * fz));
-        c1 = __builtin_fmaf(iv[3], fx, __builtin_fmaf(iv[4], y, iv[5] * fz));
-        c2 = __builtin_fmaf(iv[6], fx, __builtin_fmaf(iv[7], y, iv[8] * fz));
+        lab_to_linear_fast(li, ai, bi, iv, c0, c1, c2);      // iv = inv1024 here
     }
     if (EXACT) {
         o0 = spline1024<true>(clip01(c0) * 1024.f, igt);
@@ -255,7 +276,7 @@ __device__ __forceinline__ void lab_to_bgr(float li, float ai, float bi, const f
 // (lvm_f2 / f2_fma: lvm_gfx950.h -- v_pk_fma_f32)
 __device__ __forceinline__ lvm_f2 f2_set(float a, float b) { lvm_f2 v = {a, b}; return v; }
 __device__ __forceinline__ lvm_f2 f2_all(float a) { lvm_f2 v = {a, a}; return v; }
-__device__ __forceinline__ void lab_to_bgr_pair(lvm_f2 li, lvm_f2 ai, lvm_f2 bi, const float* iv, const float* igt, lvm_f2& o0, lvm_f2& o1, lvm_f2& o2) {
+__device__ __forceinline__ void lab_to_linear_pair(lvm_f2 li, lvm_f2 ai, lvm_f2 bi, const float* iv, lvm_f2& c0, lvm_f2& c1, lvm_f2& c2) {
     const float lThresh = 0.008856f * 903.3f;
     const float fThresh = 7.787f * 0.008856f + 16.0f / 116.0f;
     const lvm_f2 ylin = li * f2_all(1.0f / 903.3f), fyc = (li + f2_all(16.0f)) * f2_all(1.0f / 116.0f);
@@ -268,9 +289,13 @@ __device__ __forceinline__ void lab_to_bgr_pair(lvm_f2 li, lvm_f2 ai, lvm_f2 bi,
     const lvm_f2 fzl = (fz - f2_all(16.0f / 116.0f)) * f2_all(1.0f / 7.787f), fzc = fz * fz * fz;
 #pragma unroll
     for (int k = 0; k < 2; ++k) { fx[k] = (fx[k] <= fThresh) ? fxl[k] : fxc[k]; fz[k] = (fz[k] <= fThresh) ? fzl[k] : fzc[k]; }
-    const lvm_f2 c0 = f2_fma(f2_all(iv[0]), fx, f2_fma(f2_all(iv[1]), y, f2_all(iv[2]) * fz));
-    const lvm_f2 c1 = f2_fma(f2_all(iv[3]), fx, f2_fma(f2_all(iv[4]), y, f2_all(iv[5]) * fz));
-    const lvm_f2 c2 = f2_fma(f2_all(iv[6]), fx, f2_fma(f2_all(iv[7]), y, f2_all(iv[8]) * fz));
+    c0 = f2_fma(f2_all(iv[0]), fx, f2_fma(f2_all(iv[1]), y, f2_all(iv[2]) * fz));
+    c1 = f2_fma(f2_all(iv[3]), fx, f2_fma(f2_all(iv[4]), y, f2_all(iv[5]) * fz));
+    c2 = f2_fma(f2_all(iv[6]), fx, f2_fma(f2_all(iv[7]), y, f2_all(iv[8]) * fz));
+}
+__device__ __forceinline__ void lab_to_bgr_pair(lvm_f2 li, lvm_f2 ai, lvm_f2 bi, const float* iv, const float* igt, lvm_f2& o0, lvm_f2& o1, lvm_f2& o2) {
+    lvm_f2 c0, c1, c2;
+    lab_to_linear_pair(li, ai, bi, iv, c0, c1, c2);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         o0[k] = spline1024<false>(clip1024_open(c0[k]), igt);
@@ -288,6 +313,12 @@ __device__ __forceinline__ void lab_to_bgr_pair(lvm_f2 li, lvm_f2 ai, lvm_f2 bi,
 enum { FL_LUT_FAST = 0, FL_LUT_EXACT = 1, FL_ANALYTIC = 2 };
 constexpr bool fl_exact(int FL) { return FL != FL_LUT_FAST; }
 constexpr bool fl_lut(int FL) { return FL != FL_ANALYTIC; }
+// Output kernels: the default flavour quantises through the u8 step table (u8_step) unless the float frame is asked for
+// (lvm_debug_keep_float: the spline's float values are the product then); the two debug flavours keep OpenCV's operations one by one.
+#ifndef LVM_U8_STEPS
+#define LVM_U8_STEPS 1       // 0: spline + scale + round in every flavour (A/B measurements)
+#endif
+constexpr bool fin_steps(int FL, bool DBG) { return LVM_U8_STEPS && FL == FL_LUT_FAST && !DBG; }
 // Lab of pixel (gy, gx) of frame b.  LUT flavours: the integer planes written by labconv.hip (every frame is converted
 // once); analytic flavour: the u8 frame + the 256-entry gamma table in LDS (s_gam).
 template <int FL>
@@ -338,6 +369,12 @@ __device__ __forceinline__ void raw4_to_lab(const Raw4& r, const float* s_gam, c
 #pragma unroll
         for (int k = 0; k < 4; ++k) lin_bgr_to_lab<true>(s_gam[B[k]], s_gam[G[k]], s_gam[R[k]], lab.fwd, L[k], a[k], b[k]);
     }
+}
+// the u8 step table into LDS (any workgroup size)
+__device__ __forceinline__ void load_u8steps(uint2* s_steps, const uint2* g) {
+    const uint4* src = reinterpret_cast<const uint4*>(g);
+    uint4* dst = reinterpret_cast<uint4*>(s_steps);
+    for (int i = threadIdx.x; i < kU8StepSlices / 2; i += blockDim.x) dst[i] = src[i];
 }
 // cooperative loads of the two Lab tables into LDS (256 threads)
 __device__ __forceinline__ void load_gamma_u8(float* s_gam, const float* g) { s_gam[threadIdx.x] = g[threadIdx.x]; }
@@ -391,6 +428,7 @@ struct Ctx {
     // constant tables
     float* d_gamma_u8 = nullptr;
     float* d_invgamma = nullptr;
+    uint2* d_u8steps = nullptr;
     LabCoef lab{};
     // per-mode state (allocated for the tracked geometry)
     ModeState* state = nullptr;
@@ -517,6 +555,8 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
 
 // host tables (lab_tables.cpp)
 void build_lab_tables(float gamma_u8[256], float invgamma[4096], float fwd[9], float inv[9]);
+int sweep_u8_steps(Ctx* c, unsigned long long first, unsigned long long count, unsigned long long* bad, unsigned long long* first_bad, hipStream_t s);   // labconv.hip
+bool build_u8_steps(const float invgamma[4096], uint32_t steps[2 * kU8StepSlices]);   // false: the quantiser is not the step function the kernels assume
 void build_lab_lut_compact(std::vector<int16_t>& compact);
 void lab_lut_device_tables(const int16_t* compact, std::vector<uint32_t>& ab, std::vector<int16_t>& lcells);
 bool lab_lut_fine_index_ok();

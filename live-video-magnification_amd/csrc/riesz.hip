@@ -1357,6 +1357,24 @@ __device__ __forceinline__ void collapse_emit(float L0, float L1, float L2, floa
     constexpr bool EXACT = fl_exact(FL);
     const float Lc[4] = {L0, L1, L2, L3};
     const uint32_t q[4] = {__float_as_uint(iabq.x), __float_as_uint(iabq.y), __float_as_uint(iabq.z), __float_as_uint(iabq.w)};
+    if (fin_steps(FL, DBG)) {        // s_igt = the u8 step table: linear BGR -> byte by a table hit and a compare (lvm_internal.h u8_step)
+        const uint2* steps = reinterpret_cast<const uint2*>(s_igt);
+        uint32_t u[4][3];
+#pragma unroll
+        for (int m = 0; m < 4; m += 2) {
+            lvm_f2 c0, c1, c2;
+            lab_to_linear_pair(f2_set(Lc[m], Lc[m + 1]), f2_set(lut_ab((int)(q[m] & 0xffffu)), lut_ab((int)(q[m + 1] & 0xffffu))),
+                               f2_set(lut_ab((int)(q[m] >> 16)), lut_ab((int)(q[m + 1] >> 16))), lab.inv4096, c0, c1, c2);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { u[m + k][0] = u8_step(c0[k], steps); u[m + k][1] = u8_step(c1[k], steps); u[m + k][2] = u8_step(c2[k], steps); }
+        }
+        B96 v;
+        v.a = lvm_pack_b4(u[0][0], u[0][1], u[0][2], u[1][0]);
+        v.b = lvm_pack_b4(u[1][1], u[1][2], u[2][0], u[2][1]);
+        v.c = lvm_pack_b4(u[2][2], u[3][0], u[3][1], u[3][2]);
+        buf_sts_b96(v, ro, voff, soff);
+        return;
+    }
     float o[4][3];
     if (EXACT) {
 #pragma unroll
@@ -1390,8 +1408,11 @@ __device__ __forceinline__ void collapse_emit(float L0, float L1, float L2, floa
 template <bool FINAL, int FL, bool DBG>
 __global__ __launch_bounds__(CS_THREADS, 3) void k_rz_collapse_strips(CollapseStripArgs a) {
     constexpr bool EXACT = fl_exact(FL);
-    __shared__ __attribute__((aligned(16))) float s_igt[FINAL ? 4096 : 4];
-    if (FINAL) { load_invgamma(s_igt, a.lab.invgamma); __syncthreads(); }
+    __shared__ __attribute__((aligned(16))) float s_igt[FINAL ? (fin_steps(FL, DBG) ? 2 * kU8StepSlices : 4096) : 4];      // spline | u8 step table
+    if (FINAL) {
+        if (fin_steps(FL, DBG)) load_u8steps(reinterpret_cast<uint2*>(s_igt), a.lab.u8steps); else load_invgamma(s_igt, a.lab.invgamma);
+        __syncthreads();
+    }
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int task = blockIdx.x * (CS_THREADS / 64) + wave;
     if (task >= a.ntasks) return;

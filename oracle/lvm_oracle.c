@@ -554,6 +554,54 @@ void lvmo_lab2bgr(const float* src, int npix, float* dst) {
     }
 }
 
+/* The output quantiser of the Lab modes as a function of ONE clipped linear channel value c: what lab2bgr_px's last three lines and
+ * float_to_u8(255, 1/255) do to it (MagnifyCore.hpp:152-153, :275-276).  lvmo_u8_of_linear_sweep walks over every float whose bit
+ * pattern lies in [first, first + count) -- non-negative floats order like their patterns -- and reports: descents (places where the
+ * byte DROPS as c grows: the step-table form of the library's output kernels is exact iff there are none), steps (places where it
+ * rises), jumps (rises by more than one level), and thr[k] = the smallest pattern whose byte is >= k (k = 1..255; 0xffffffff if none).
+ * tests/test_u8_steps.py runs it over [0, 1.0f]: 1 065 353 217 floats, a few seconds with OpenMP. */
+uint8_t lvmo_u8_of_linear(float c) {
+    lab_init();
+    const float o = spline_interp(clip01(c) * (float)GAMMA_TAB_SIZE, g_invgamma_tab, GAMMA_TAB_SIZE);
+    return sat_u8(o * 255.0f + (float)(1.0 / 255.0f));
+}
+void lvmo_u8_of_linear_sweep(uint32_t first, uint64_t count, uint64_t* descents, uint64_t* steps, uint64_t* jumps, uint32_t* thr /* [256] */) {
+    lab_init();
+    const float a255 = (float)(1.0 / 255.0f);
+    const uint64_t CH = 1u << 20;
+    const uint64_t nch = (count + CH - 1) / CH;
+    uint64_t nd = 0, ns = 0, nj = 0;
+    int* first_v = (int*)malloc(sizeof(int) * (nch ? nch : 1));
+    int* last_v = (int*)malloc(sizeof(int) * (nch ? nch : 1));
+    uint32_t* t_all = (uint32_t*)malloc(sizeof(uint32_t) * 256 * (nch ? nch : 1));
+#pragma omp parallel for schedule(dynamic) reduction(+ : nd, ns, nj)
+    for (int64_t k = 0; k < (int64_t)nch; ++k) {
+        uint32_t* t = t_all + 256 * k;
+        for (int i = 0; i < 256; ++i) t[i] = 0xffffffffu;
+        const uint64_t b0 = first + (uint64_t)k * CH, b1 = (b0 + CH < first + count) ? b0 + CH : first + count;
+        int prev = -1;
+        for (uint64_t b = b0; b < b1; ++b) {
+            const uint32_t bits = (uint32_t)b;
+            float c; memcpy(&c, &bits, 4);
+            const float o = spline_interp(clip01(c) * (float)GAMMA_TAB_SIZE, g_invgamma_tab, GAMMA_TAB_SIZE);
+            const int g = sat_u8(o * 255.0f + a255);
+            if (prev < 0) first_v[k] = g;
+            else { if (g < prev) ++nd; if (g > prev) ++ns; if (g > prev + 1) ++nj; }
+            if (t[g] == 0xffffffffu) t[g] = bits;
+            prev = g;
+        }
+        last_v[k] = prev;
+    }
+    for (int i = 0; i < 256; ++i) thr[i] = 0xffffffffu;
+    for (uint64_t k = 0; k < nch; ++k) {
+        if (k > 0) { if (first_v[k] < last_v[k - 1]) ++nd; if (first_v[k] > last_v[k - 1]) ++ns; if (first_v[k] > last_v[k - 1] + 1) ++nj; }
+        for (int i = 0; i < 256; ++i) if (t_all[256 * k + i] < thr[i]) thr[i] = t_all[256 * k + i];
+    }
+    /* thr[k] so far = first pattern whose byte EQUALS k; with no descents that is also the first pattern whose byte is >= k */
+    free(first_v); free(last_v); free(t_all);
+    *descents = nd; *steps = ns; *jumps = nj;
+}
+
 /* ------------------------------------------------------------------------------------- */
 /* [cv] filter2D (direct path: correlation, centre anchor, REFLECT_101, non-zero taps in    */
 /* row-major order), sepFilter2D / GaussianBlur, getGaussianKernel, resize.                 */

@@ -75,6 +75,9 @@ void lvmo_ideal_filter(const float* win, int rows, int cols, int cn, double lo, 
 void lvmo_riesz_kernels(float lp[81], float hp[81]);                  /* RieszPyramid.cpp:146-167 */
 float lvmo_cube_root(float v);
 const float* lvmo_gamma_tab(int inverse);  /* 1024*4 spline coefficients */
+/* the output quantiser cvRound(255 * invGamma(clip01(c)) + 1/255) of one channel, and its exhaustive sweep (lvm_oracle.c) */
+uint8_t lvmo_u8_of_linear(float c);
+void lvmo_u8_of_linear_sweep(uint32_t first_bits, uint64_t count, uint64_t* descents, uint64_t* steps, uint64_t* jumps, uint32_t* thr /* [256] */);
 
 /* ---- the two stages in front of the magnifier --------------------------------
  * PreprocessProcessor::process (processing/PreprocessProcessor.cpp:10-51): ROI crop in normalised

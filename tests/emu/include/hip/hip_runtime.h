@@ -78,7 +78,10 @@ template <class T, class U> static inline void __builtin_nontemporal_store(U v, 
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline float __builtin_amdgcn_logf(float x) { return log2f(x); }
-static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return a < b ? (b < c ? b : (a < c ? c : a)) : (a < c ? a : (b < c ? c : b)); }
+static inline float __builtin_amdgcn_fmed3f(float a, float b, float c) {      // v_med3_f32: the MINIMUM of the non-NaN inputs when an input is NaN
+    if (a != a || b != b || c != c) return fminf(fminf(a, b), c);
+    return a < b ? (b < c ? b : (a < c ? c : a)) : (a < c ? a : (b < c ? c : b));
+}
 static inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 static inline float __builtin_amdgcn_fractf(float x) { float f = x - floorf(x); return f < 0.99999994f ? f : 0.99999994f; }   // v_fract_f32
 static inline unsigned __builtin_amdgcn_cvt_pk_u8_f32(float v, unsigned byte, unsigned old) {   // RNE, saturating, NaN -> 0
@@ -158,6 +161,8 @@ static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }
 static inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
 static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
 static inline unsigned atomicOr(unsigned* p, unsigned v) { unsigned o = *p; *p = o | v; return o; }
+static inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; *p = o + v; return o; }
+static inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v) { unsigned long long o = *p; if (v < o) *p = v; return o; }
 static inline void __threadfence() {}
 // graphs are not emulated: capture reports failure and the library falls back to plain launches
 typedef struct ihipGraph_t* hipGraph_t;

@@ -97,6 +97,8 @@ __device__ __forceinline__ uint32_t lut_lo2(uint32_t d, uint32_t e) { return (d 
 __device__ __forceinline__ uint32_t lut_hi2(uint32_t d, uint32_t e) { return (d >> 16) | (e & 0xffff0000u); }
 __device__ __forceinline__ uint32_t lut_mul24(uint32_t a, uint32_t b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 
+__device__ __forceinline__ uint32_t lvm_pack_b4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return (a & 255u) | ((b & 255u) << 8) | ((c & 255u) << 16) | (d << 24); }
+
 // a real cross-lane ballot (the header's __builtin_amdgcn_ballot_w64 stand-in is for wave-uniform predicates only)
 __device__ __forceinline__ unsigned long long lvm_ballot64(bool pred) { return hipemu::wave_ballot(pred ? 1 : 0); }
 __device__ __forceinline__ void lvm_wave_lds_sync() { hipemu::sync(); }
