@@ -4,24 +4,28 @@
     python bench.py --gpus N --steps K --warmup W [--mode laplace|riesz|color] [--streams B]
                     [--frames-per-call T] [--no-verify] [--no-subrecords]
 
-A "step" is one frame of the hot path for each of the B streams of the context, over synthetic frames that
-are already resident in HBM; outputs stay in HBM.  The K steps are issued through lvm_process_device_frames
-in calls of T consecutive frames of the same stream(s) -- the reference's export loop
-(export/Exporter.cpp:216-259) sees its frames in exactly this order; every frame's result is what K
-per-frame calls give (T = 1 selects those: the live, one-frame-latency schedule).  Headline workload =
-BASELINE.json configs[1]: Laplace motion, 1920x1080, 6 levels, IIR 0.4-3 Hz, alpha 20, one stream per GPU.
+A "step" is ONE PASS of the hot path over one batch: one lvm_process_device_frames call of T = --frames-per-call
+consecutive frames (default 32) of each of the B streams of the context, over synthetic frames that are already
+resident in HBM; outputs stay in HBM.  K steps = K * T frames per stream -- the production shape of the batched
+surface: the reference's export loop (export/Exporter.cpp:216-259) sees its frames in exactly this order, and every
+frame's result is what per-frame calls give.  `value` stays in frames/s, `frames_per_step` = T, `ms_per_step` = one call.
+(Until round 5 a step was a frame, so that `--steps 20` timed ONE 20-frame call, fill and drain included.)  The
+schedule MagnificationProcessor::process itself runs -- T = 1, one stream -- is reported beside it as
+`process_schedule`.  Headline workload = BASELINE.json configs[1]: Laplace motion, 1920x1080, 6 levels, IIR 0.4-3 Hz,
+alpha 20, one stream per GPU.
 
 Sequence of one run (global frame index i reads input ring slot i % ring and writes output slot i):
     priming   untimed, the SAME call shape as the timed region (first frame seeds, then whole calls of
-              min(T, K) frames; colour mode: until the rolling window is full) -- every buffer the timed
+              T frames; colour mode: until the rolling window is full) -- every buffer the timed
               calls need exists afterwards (lvm_set_max_frames sizes the batch arenas when the state is created)
-    warmup    W untimed steps
-    timed     EXACTLY K steps, bracketed by barrier + device synchronisation, MAX over ranks
-    probe     one more call with the float frame kept (parity metric (i) of SURVEY.md 8c)
+    warmup    W untimed steps (calls)
+    probe     one more call with the float frame kept (parity metric (i) of SURVEY.md 8c), then the clock ramp
+    timed     EXACTLY K steps, bracketed by barrier + device synchronisation, MAX over ranks; a one-lane kernel on a
+              second stream reads the shader-clock and the 100 MHz counters at both ends -> `clock_mhz`
     verify    rank 0 (N = 1; every rank with --verify-all-ranks): the CPU oracle replays the same frames from
-              frame 0 and the bench's OWN output frames -- >= 8 spread over the timed calls -- are compared with it
-              (u8 <= 1 LSB and >= 99.9 % identical; float probe <= 1e-4 relative).  The replay doubles as the
-              cpu_baseline sample.
+              frame 0 through the first <= 12 timed calls, and the bench's OWN output frames of those calls -- >= 8 --
+              are compared with it (u8 <= 1 LSB and >= 99.9 % identical; float probe <= 1e-4 relative).  The replay
+              doubles as the cpu_baseline sample (~20 s of CPU work whatever K is).
     profile   per-kernel HIP-event pass (two whole calls) -> roofline of the dominant kernel
     sub-records (N = 1 unless --subrecords): per-frame schedule (T = 1), host-to-host lvm_process (pageable and
               pinned frames), B = 4 / 16 streams per launch, BASELINE configs[4] (Riesz 3840x2160 L8, one stream per
@@ -49,7 +53,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MODES = {"laplace": 1, "riesz": 2, "color": 3}  # -> BASELINE.json configs index
-PROFILE_ROUND = "r05"
+PROFILE_ROUND = "r06"
 
 
 def level_sizes(w, h, levels):
@@ -94,10 +98,12 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, S, T, Twin=0):
         if base == "lap_up" and lvl is not None:
             per_frame = 4 * P * (n[lvl] + n[lvl + 1] + (n[lvl + 1] if lvl + 1 <= levels - 1 else 0) + n[lvl])
             return T * per_frame + 16 * P * n[lvl]                            # hi/lo read + written once per launch
-        if base == "lap_iir":        # levels 2 .. L-1 in one launch: G_l, G_{l+1} read, m_l written per frame; states once
-            return sum(T * 4 * P * (2 * n[l] + n[l + 1]) + 16 * P * n[l] for l in range(2, levels))
-        if base == "lap_collapse":   # m_2 .. m_{L-1} read, cur_2 written
-            return T * 4 * P * (sum(n[l] for l in range(2, levels)) + n[2])
+        # round 6: the IIR + collapse launches start at level F = 3 when the pyramid has >= 5 levels (level 2 is a fused lap_up step then)
+        F = 3 if (levels >= 5 and os.environ.get("LVM_LAP_SPLIT_FROM", "3") != "2") else 2
+        if base == "lap_iir":        # levels F .. L-1 in one launch: G_l, G_{l+1} read, m_l written per frame; states once
+            return sum(T * 4 * P * (2 * n[l] + n[l + 1]) + 16 * P * n[l] for l in range(F, levels))
+        if base == "lap_collapse":   # m_F .. m_{L-1} read, cur_F written
+            return T * 4 * P * (sum(n[l] for l in range(F, levels)) + n[F])
         if base == "lap_seed" and lvl is not None:
             return 4 * P * (n[lvl] * 3 + n[lvl + 1])
         return None
@@ -188,8 +194,8 @@ def reexec_under_torchrun(args):
 
 
 def prime_total(lvm, pk, T, K, W):
-    """priming + warm-up frames in front of the timed region: a multiple of T"""
-    need = 1 + min(T, K)
+    """priming + warm-up FRAMES (W frames of warm-up) in front of the timed region: a multiple of T"""
+    need = 1 + T
     if pk["mode"] == lvm.synth.MODE_COLOR:     # the rolling window must be full before the steady state
         need = max(need, lvm.load().lvm_optimal_buffer_size(int(pk["framerate"])) + 32 + 1)
     if pk["mode"] == lvm.synth.MODE_PHASE:
@@ -225,9 +231,10 @@ class Runner:
                 clip = lvm.synth.Clip(seed=lvm.sharding.stream_seed(sid), **{k: v for k, v in ck.items() if k != "seed"})
                 for t in range(ring):
                     self.d_in[t, s] = clip.frame_torch(t, dev)
-        self.oring = max(ring, out_frames)
-        self.oring = ((self.oring + ring - 1) // ring) * ring
-        self.d_out = torch.zeros((self.oring, B, h, w, ch), dtype=torch.uint8, device=dev)
+        # outputs: frames 0 .. keep-1 each keep their own slot (what the verification reads back); later frames share a ring behind them
+        self.keep = ((max(out_frames, 0) + T - 1) // T) * T if out_frames > ring else 0
+        self.oring = ring
+        self.d_out = torch.zeros((self.keep + self.oring, B, h, w, ch), dtype=torch.uint8, device=dev)
         self.ctx = lvm.Context(device, B)
         self.ctx.set_max_frames(T)
         self.cp = lvm.LvmParams(pk["mode"], pk["levels"], pk["amplification"], pk["coWavelength"], pk["coLow"], pk["coHigh"],
@@ -247,8 +254,13 @@ class Runner:
         i, end = self.n, self.n + count
         w, h, ch, fb, fs = self.w, self.h, self.ch, self.frame_bytes, self.fstride
         while i < end:
-            t, o = i % self.ring, i % self.oring
-            nf = min(self.T, end - i, self.ring - t, self.oring - o)
+            t = i % self.ring
+            if i < self.keep:
+                o, room = i, self.keep - i
+            else:
+                o = self.keep + (i - self.keep) % self.oring
+                room = self.keep + self.oring - o
+            nf = min(self.T, end - i, self.ring - t, room)
             if nf == 1:
                 rc = self.fast(self.in0 + t * fs, self.out0 + o * fs)
             else:
@@ -261,10 +273,16 @@ class Runner:
 
     def prime(self, K, W):
         """untimed: the first frame (seeds the state) and whole calls of the timed shape; ends so that the timed
-        region starts on a multiple of T (ring % T == 0: timed calls are never cut by the ring)"""
+        region starts on a multiple of T (ring % T == 0: timed calls are never cut by the ring).  W = warm-up FRAMES."""
         n = prime_total(self.lvm, self.pk, self.T, K, W) - W
         self.run(n)
         return n
+
+    def out_slot(self, i):
+        """where output frame i lies in d_out (None: overwritten by a later frame)"""
+        if i < self.keep:
+            return i
+        return self.keep + (i - self.keep) % self.oring if i >= self.n - self.oring else None
 
     def ramp(self, seconds):
         """Untimed: keeps the GPU busy with the SAME workload on a scratch context (own state, scratch output) for `seconds`
@@ -331,8 +349,8 @@ CLIP_NOISE = None     # --clip-noise
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=20, help="timed steps; a step = one call of --frames-per-call frames per stream")
+    ap.add_argument("--warmup", type=int, default=5, help="untimed warm-up steps (calls) in front of the timed region")
     ap.add_argument("--ramp-ms", type=float, default=40.0,
                     help="untimed GPU load (same workload, scratch context) in front of the timed region, milliseconds")
     ap.add_argument("--mode", default="laplace", choices=list(MODES))
@@ -410,33 +428,31 @@ def main():
     do_sub = (world == 1 or args.subrecords) and not args.no_subrecords
 
     ids = lvm.sharding.stream_ids(rank, world, B)
-    # every output frame of the run is kept (HBM is 288 GB: 530 frames of 1080p are 3.3 GB) so that the verification can look
-    # at the timed region's own output; capped, beyond the cap the output ring wraps and only its last frames are checked
-    ck_s, _ = lvm.synth.config(cfg_idx, small)
-    fb = ck_s["w"] * ck_s["h"] * 3 * B
-    expect_frames = prime_total(lvm, lvm.synth.config(cfg_idx, small)[1], T, K, W) + K + T
-    out_frames = expect_frames if verify and expect_frames * fb <= (24 << 30) else ring
-    R = Runner(lvm, torch, np, cfg_idx, small, B, ring, T, local_rank, ids, out_frames)
+    # K steps = K calls of T frames; W warm-up steps likewise.  Outputs of every frame up to the end of the verified span keep their own
+    # slot in HBM (the verification reads the timed region's OWN output back); later frames share a ring.
+    Kf, Wf = K * T, W * T                                            # frames
+    pk_s = lvm.synth.config(cfg_idx, small)[1]
+    base_expected = prime_total(lvm, pk_s, T, K, Wf) + T             # priming + warm-up + the float-probe call
+    v_calls = min(K, 12) if T > 1 else min(K, 384)                   # timed calls the oracle replays through (bounds the CPU work)
+    v_end = base_expected + v_calls * T
+    R = Runner(lvm, torch, np, cfg_idx, small, B, ring, T, local_rank, ids, v_end if verify else ring)
     w, h, levels, ch, pk = R.w, R.h, R.levels, R.ch, R.pk
     R.ctx.set_pipeline(args.pipeline)
     stream = R.stream
 
-    primed = R.prime(K, W)
-    R.run(W)
-    base = R.n
-    ramp_frames = R.ramp(args.ramp_ms * 1e-3)
-    dt = lvm.sharding.timed_steps(lambda i: R.run(K), 1, dist, torch.cuda.synchronize, red_dev, finish=lambda: R.ctx.flush(stream))
-    host_enqueue = getattr(lvm.sharding.timed_steps, "host_seconds", 0.0)
-    fps = lvm.sharding.aggregate_fps(world, B, K, dt)
-
-    # ---- float probe: one more call with the pre-quantisation frame kept (stream 0, last frame of the call) ----
+    primed = R.prime(K, Wf)
+    R.run(Wf)
+    # ---- float probe: one more call with the pre-quantisation frame kept (stream 0); in front of the timed region so that the oracle
+    # replay can stop after the verified span ----
     probe_n = 0
     float_gpu = None
+    probe_first = -1
     if verify:
         R.ctx.flush(stream)
+        pd = args.pipeline
         R.ctx.set_pipeline(0)
         R.ctx.keep_float(True)
-        probe_n = min(T, ring - R.n % ring)          # ONE call (not cut by the input ring)
+        probe_n = T
         probe_first = R.n                # the kernels keep the float frame of the FIRST frame of a batch (stream 0)
         if args.mode == "color":
             probe_first += 32 * ((probe_n - 1) // 32)      # the colour mode cuts a call into chunks of <= 32 frames
@@ -444,7 +460,39 @@ def main():
         torch.cuda.synchronize()
         float_gpu = R.ctx.read_float((h, w, ch))
         R.ctx.keep_float(False)
-    n_verify = R.n
+        R.ctx.set_pipeline(pd)
+    base = R.n
+    assert not verify or base == base_expected, (base, base_expected)
+    ramp_frames = R.ramp(args.ramp_ms * 1e-3)
+    # ---- the timed region: K calls; the clock probe's lane sits on the auxiliary stream from just before the first call until the main
+    # stream has drained (it is stopped BEFORE the closing device synchronisation, which would otherwise wait for it) ----
+    clock = {"mhz": None}
+
+    def finish():
+        R.ctx.flush(stream)
+        if clock.get("on"):
+            # the stream the calls were enqueued on: handle 0 (torch's default stream) makes the library use the context's own stream
+            if stream == 0:
+                R.ctx.synchronize()
+            else:
+                torch.cuda.current_stream().synchronize()
+            try:
+                clock["mhz"], clock["seconds"] = R.ctx.clock_probe_stop()
+            except Exception as e:      # a measurement aid must never take the headline down
+                clock["error"] = str(e)[:120]
+
+    def steps(_):
+        try:
+            R.ctx.clock_probe_start(5.0)
+            clock["on"] = True
+        except Exception as e:
+            clock["error"] = str(e)[:120]
+        R.run(Kf)
+
+    dt = lvm.sharding.timed_steps(steps, 1, dist, torch.cuda.synchronize, red_dev, finish=finish)
+    host_enqueue = getattr(lvm.sharding.timed_steps, "host_seconds", 0.0)
+    fps = lvm.sharding.aggregate_fps(world, B, Kf, dt)
+    n_verify = min(R.n, v_end)
 
     # ---- verification against the CPU oracle (also the cpu_baseline sample) ----
     cpu = None
@@ -454,11 +502,8 @@ def main():
         from oracle import pyoracle as po
         nthreads = max(1, min(16, os.cpu_count() or 1))   # beyond ~16 threads fork/join over small levels dominates
         host = R.d_in[:, 0].cpu().numpy()                 # stream 0 of this rank
-        lo = max(0, n_verify - R.oring)                   # frames still present in the output ring
-        timed_idx = sorted(set(int(round(x)) for x in np.linspace(base, base + K - 1, 12)))
-        check = [i for i in timed_idx if i >= lo] + [n_verify - 1]
-        if lo == 0:
-            check = [1, primed - 1] + check
+        timed_idx = sorted(set(int(round(x)) for x in np.linspace(base, n_verify - 1, 12)))
+        check = [1, primed - 1] + timed_idx
         keep, fl_ref, cdt = oracle_replay(po, np, host, pk, ring, n_verify, check, nthreads, float_at=probe_first)
         worst_du, worst_frac, ok = 0, 1.0, True
         n_cmp = 0
@@ -466,7 +511,7 @@ def main():
             ref, produced = keep[i]
             if not produced:
                 continue
-            got = R.d_out[i % R.oring, 0].cpu().numpy()
+            got = R.d_out[i, 0].cpu().numpy()             # (i < R.keep: every verified frame has its own slot)
             du = np.abs(ref.astype(np.int16) - got.astype(np.int16))
             worst_du = max(worst_du, int(du.max()))
             worst_frac = min(worst_frac, float((du == 0).mean()))
@@ -474,8 +519,8 @@ def main():
         rel = float(np.abs(fl_ref - float_gpu).max() / max(float(np.abs(fl_ref).max()), 1e-30))
         ok = n_cmp >= 8 and worst_du <= 1 and worst_frac >= 0.999 and rel <= 1e-4 and bool(np.isfinite(float_gpu).all())
         verified = bool(ok)
-        vinfo = {"frames_compared": n_cmp, "timed_frames_compared": len([i for i in check if base <= i < base + K]),
-                 "u8_max_diff": worst_du, "u8_identical_min": round(worst_frac, 6), "float_rel_err_probe": rel,
+        vinfo = {"frames_compared": n_cmp, "timed_frames_compared": len([i for i in check if base <= i < base + Kf]),
+                 "timed_calls_covered": v_calls, "u8_max_diff": worst_du, "u8_identical_min": round(worst_frac, 6), "float_rel_err_probe": rel,
                  "bars": "u8 <= 1 LSB, >= 99.9 % identical; float <= 1e-4 of max|ref|", "oracle_frames_replayed": n_verify}
         if not np.isfinite(float_gpu).all() or not np.isfinite(fl_ref).all():      # say where: a non-finite probe must be diagnosable from the record
             bad = np.argwhere(~np.isfinite(float_gpu))
@@ -486,12 +531,12 @@ def main():
             # the REAL reference stage (oracle/_ref/libref_magnify.so, built where OpenCV 4 exists): reported next to
             # `verified`.  Since round 3 the library computes OpenCV's interpolated forward Lab; whether its restated table
             # equals the one of this OpenCV build is reported too (a differing table can be installed with lvm_set_lab_lut)
-            nref = min(n_verify, base + min(K, 64))
+            nref = min(n_verify, base + 64)
             rkeep, _, rdt = oracle_replay(po, np, host, pk, ring, nref, [i for i in check if i < nref], nthreads, real_reference=True)
             dmax, fmin = 0, 1.0
             for i, (ref, produced) in rkeep.items():
                 if produced:
-                    du = np.abs(ref.astype(np.int16) - R.d_out[i % R.oring, 0].cpu().numpy().astype(np.int16))
+                    du = np.abs(ref.astype(np.int16) - R.d_out[i, 0].cpu().numpy().astype(np.int16))
                     dmax, fmin = max(dmax, int(du.max())), min(fmin, float((du == 0).mean()))
             ref_check = {"frames": len(rkeep), "u8_max_diff": dmax, "u8_identical_min": round(fmin, 6), "fps": round(nref / rdt, 3)}
             rt = po.RefOracle.recover_lab_lut()
@@ -551,8 +596,8 @@ def main():
     if not args.no_subrecords:
         Rc = Runner(lvm, torch, np, cfg_idx, small, B, ring, T, local_rank, ids, ring)
         Rc.ctx.set_pipeline(args.pipeline)
-        dtc = timed_run(lvm, torch, Rc, K, W, dist, red_dev, ramp=0.0)
-        value_cold = {"value": round(lvm.sharding.aggregate_fps(world, B, K, dtc), 2), "unit": "frames/s", "steps": K, "warmup": W, "ramp_ms": 0.0,
+        dtc = timed_run(lvm, torch, Rc, Kf, Wf, dist, red_dev, ramp=0.0)
+        value_cold = {"value": round(lvm.sharding.aggregate_fps(world, B, Kf, dtc), 2), "unit": "frames/s", "steps": K, "warmup": W, "ramp_ms": 0.0,
                       "note": "same call shape as `value`, priming + warm-up only: the clocks have not ramped"}
         Rc.close()
         del Rc
@@ -571,7 +616,13 @@ def main():
             "metric": "magnified frames/sec at 1080p, Laplace-motion 6 levels; % HBM roofline" if args.mode == "laplace"
                       else "magnified frames/sec (%s)" % args.mode,
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(1e3 * dt / K, 5), "value_cold": value_cold,
+            "ms_per_step": round(1e3 * dt / K, 5), "frames_per_step": T, "timed_frames_per_stream": Kf, "us_per_frame": round(1e6 * dt / Kf, 4),
+            "step_definition": "one lvm_process_device_frames call of frames_per_step consecutive frames per stream (one pass of the hot path over one batch)",
+            "clock_mhz": (round(clock["mhz"], 1) if clock.get("mhz") else None),
+            "clock": {"mhz": (round(clock["mhz"], 1) if clock.get("mhz") else None), "seconds_covered": clock.get("seconds"), "error": clock.get("error"),
+                      "how": "average shader clock over the timed region: s_memtime / s_memrealtime x 100 MHz, read by a one-lane kernel on a second stream "
+                             "at both ends of the region (lvm_debug_clock_probe_*)"},
+            "value_cold": value_cold,
             "host_enqueue_ms_per_step": round(1e3 * host_enqueue / K, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic" if CLIP_NOISE is None else "synthetic (clip noise +-%g levels instead of +-12)" % CLIP_NOISE,
             "config": {"workload": "%s %dx%d, %d levels, %d stream(s)/GPU, device-resident u8 BGR in/out" %
@@ -589,6 +640,11 @@ def main():
             "kernels": kernels,
         }
         out.update(sub)
+        if "per_frame" in sub:      # what MagnificationProcessor::process itself runs (MagnificationProcessor.cpp:17-67): T = 1, one stream
+            pf = sub["per_frame"]
+            out["process_schedule"] = {"value": pf.get("value"), "unit": "frames/s", "us_per_frame": pf.get("us_per_frame"), "frames_per_call": 1, "streams": 1,
+                                       "frame_roofline_frac": pf.get("frame_roofline_frac"), "launches_per_frame": pf.get("launches_per_frame"),
+                                       "note": "one lvm_process_device call per frame, device-resident: the reference's per-frame process() schedule; the headline is the batched surface"}
         print(json.dumps(out))
     if dist:
         dist.destroy_process_group()
@@ -691,6 +747,7 @@ RAMP_SECONDS = 0.04      # set from --ramp-ms in main()
 
 
 def timed_run(lvm, torch, R, K, W, dist, red_dev, ramp=None):
+    """K timed FRAMES after W warm-up frames, in calls of R.T (the sub-records count frames)"""
     R.prime(K, W)
     R.run(W)
     R.ramp(RAMP_SECONDS if ramp is None else ramp)
@@ -916,7 +973,7 @@ def config_record(lvm, torch, np, cfg_idx, local_rank, rank, world, dist, red_de
     rec = {"workload": "%s %dx%d, %d levels, 1 stream per GPU, %d frames per call%s" % (mode, R.w, R.h, R.levels, T, clip_tag),
            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": K, "us_per_frame": round(1e6 * dt / K, 2),
            "ms_per_step": round(1e3 * dt / K, 4), "frame_alg_bytes": b_alg, "frame_roofline_frac": frame_frac}
-    if rank == 0 and R.oring >= R.n:
+    if rank == 0 and R.keep >= R.n:
         from oracle import pyoracle as po
         nthreads = max(1, min(16, os.cpu_count() or 1))
         host = R.d_in[:, 0].cpu().numpy()
@@ -929,7 +986,7 @@ def config_record(lvm, torch, np, cfg_idx, local_rank, rank, world, dist, red_de
         for i in check:
             ref, produced = keep[i]
             if produced:
-                du = np.abs(ref.astype(np.int16) - R.d_out[i % R.oring, 0].cpu().numpy().astype(np.int16))
+                du = np.abs(ref.astype(np.int16) - R.d_out[i, 0].cpu().numpy().astype(np.int16))
                 dmax, fmin, ncmp = max(dmax, int(du.max())), min(fmin, float((du == 0).mean())), ncmp + 1
         rec["verified"] = bool(ncmp >= 8 and dmax <= 1 and fmin >= 0.999)
         rec["verification"] = {"timed_frames_compared": ncmp, "u8_max_diff": dmax, "u8_identical_min": round(fmin, 6),
@@ -970,6 +1027,17 @@ def sub_records(lvm, torch, np, args, cfg_idx, small, local_rank, rank, world, d
     out["per_frame"] = {"schedule": "T = 1: one lvm_process_device call per frame, device-resident", "value": round(world * Kp / dt, 2),
                         "unit": "frames/s", "steps": Kp, "us_per_frame": round(1e6 * dt / Kp, 2),
                         "host_enqueue_us_per_frame": round(1e6 * lvm.sharding.timed_steps.host_seconds / Kp, 2)}
+    try:        # kernel launches one frame costs on this surface (the profiler counts every LVM_LAUNCH)
+        R.ctx.profile(True)
+        R.run(20)
+        torch.cuda.synchronize()
+        prof = R.ctx.profile_collect()
+        R.ctx.profile(False)
+        out["per_frame"]["launches_per_frame"] = round(sum(v[1] for v in prof.values()) / 20.0, 2)
+        out["per_frame"]["kernels_us"] = {k: round(1e3 * v[0] / max(v[1], 1), 2) for k, v in prof.items()}
+    except Exception as e:
+        out["per_frame"]["launches_per_frame"] = None
+        out["per_frame"]["profile_error"] = str(e)[:120]
     b_alg1 = lvm.load().lvm_algorithmic_bytes(R.pk["mode"], R.w, R.h, R.ch, R.levels, R.pk["framerate"])
     out["per_frame"]["frame_roofline_frac"] = round(b_alg1 * out["per_frame"]["value"] / world / (HBM_PEAK_GBS * 1e9), 5)
     # (1b) the same per-frame schedule with B streams in every launch (B in {1, 4, 16}, T = 1)

@@ -278,6 +278,12 @@ int  lvm_debug_exact_lab(lvm_ctx* ctx, int on);
  * (lab_tables.cpp build_u8_steps).  This entry compares the table with the operations it replaces for every float whose bit
  * pattern lies in [first_bits, first_bits + count) ON THE DEVICE: *mismatches = patterns where the bytes differ, *first_bad_bits =
  * the smallest of them.  (0, 1 << 32) sweeps every binary32 value: negative, above 1, infinities, NaN included.             */
+/* Measurement aid (bench.py `clock_mhz`): a one-lane kernel on the context's auxiliary stream reads the shader-clock counter
+ * (s_memtime) and the constant 100 MHz counter (s_memrealtime), waits -- beside whatever runs on the other streams -- until _stop is
+ * called (or max_seconds, <= 5, have passed), and reads them again: *mhz = the AVERAGE shader clock over that interval, *seconds its
+ * length.  One probe at a time per context.                                                                                        */
+int  lvm_debug_clock_probe_start(lvm_ctx* ctx, double max_seconds);
+int  lvm_debug_clock_probe_stop(lvm_ctx* ctx, double* mhz, double* seconds);
 int  lvm_debug_sweep_u8_steps(lvm_ctx* ctx, uint32_t first_bits, uint64_t count, uint64_t* mismatches, uint32_t* first_bad_bits);
 int  lvm_debug_lab_analytic(lvm_ctx* ctx, int on);
 /* The forward table: LVM_LAB_LUT_ENTRIES int16 values in OpenCV's RGB2Labprev order, index 3 (p + 33 q + 1089 r) + channel

@@ -96,7 +96,7 @@ class LvmError(RuntimeError):
 
 SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process_device", "lvm_process_device_frames", "lvm_set_pipeline", "lvm_flush", "lvm_synchronize",
            "lvm_last_error", "lvm_max_levels", "lvm_optimal_buffer_size", "lvm_butterworth2",
-           "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_debug_sweep_u8_steps", "lvm_debug_lab_analytic", "lvm_get_lab_lut", "lvm_set_lab_lut", "lvm_profile_enable", "lvm_profile_collect", "lvm_profile_only",
+           "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_debug_sweep_u8_steps", "lvm_debug_clock_probe_start", "lvm_debug_clock_probe_stop", "lvm_debug_lab_analytic", "lvm_get_lab_lut", "lvm_set_lab_lut", "lvm_profile_enable", "lvm_profile_collect", "lvm_profile_only",
            "lvm_profile_entry", "lvm_algorithmic_bytes", "lvm_export_geometry", "lvm_export_frames",
            "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process", "lvm_chain_process_batch",
            "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free", "lvm_compose_geometry", "lvm_compose_device", "lvm_chain_process_batch_ex",
@@ -130,6 +130,8 @@ def bind(lib):
     lib.lvm_debug_read_float.argtypes = [vp, vp, C.c_size_t]
     lib.lvm_debug_exact_lab.argtypes = [vp, C.c_int]
     lib.lvm_debug_lab_analytic.argtypes = [vp, C.c_int]
+    lib.lvm_debug_clock_probe_start.argtypes = [vp, C.c_double]
+    lib.lvm_debug_clock_probe_stop.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.lvm_debug_sweep_u8_steps.argtypes = [vp, C.c_uint32, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     lib.lvm_get_lab_lut.argtypes = [vp, vp]
     lib.lvm_set_lab_lut.argtypes = [vp, vp]
@@ -465,6 +467,16 @@ class Context:
 
     def exact_lab(self, on=True):
         self._check(self.lib.lvm_debug_exact_lab(self.h, int(on)))
+
+    def clock_probe_start(self, max_seconds=2.0):
+        """starts the shader-clock probe beside the work on the other streams (lvm_debug_clock_probe_start)"""
+        self._check(self.lib.lvm_debug_clock_probe_start(self.h, float(max_seconds)))
+
+    def clock_probe_stop(self):
+        """-> (average shader clock in MHz, seconds covered)"""
+        mhz, sec = C.c_double(0), C.c_double(0)
+        self._check(self.lib.lvm_debug_clock_probe_stop(self.h, C.byref(mhz), C.byref(sec)))
+        return float(mhz.value), float(sec.value)
 
     def sweep_u8_steps(self, first_bits=0, count=1 << 32):
         """(mismatches, first bad bit pattern) of the u8 step table against spline + scale + round over the floats with bit patterns

@@ -160,4 +160,52 @@ int sweep_u8_steps(Ctx* c, unsigned long long first, unsigned long long count, u
     return LVM_OK;
 }
 
+// ---- lvm_debug_clock_probe_*: the average shader clock over an interval the HOST chooses ------------------------------------------------
+// One lane reads both counters, sleeps and polls a flag in page-locked host memory until the host sets it (or `max_ticks` of the
+// 100 MHz counter have passed: the kernel can never hang the device), reads both again.  Launched on the context's auxiliary stream it
+// runs beside whatever the main stream executes: one wave slot, a handful of SGPRs.
+__global__ void k_clock_probe(const int* stop, unsigned long long* out, unsigned long long max_ticks) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long r0 = lvm_clock_real(), c0 = lvm_clock_core();
+    __atomic_store_n(out + 3, 1ull, __ATOMIC_RELEASE);       // "running": the host waits for it before it enqueues what is to be measured
+    unsigned long long r = r0;
+    while (r - r0 < max_ticks) {
+        if (__atomic_load_n(stop, __ATOMIC_RELAXED) != 0) break;
+        for (int i = 0; i < 8; ++i) lvm_sleep();             // ~8 x 127 x 64 clocks between two reads over PCIe
+        r = lvm_clock_real();
+    }
+    const unsigned long long c1 = lvm_clock_core();
+    r = lvm_clock_real();
+    out[0] = c1 - c0; out[1] = r - r0;
+}
+
+int clock_probe_start(Ctx* c, double max_seconds) {
+    if (!c->h_probe) {
+        LVM_HIP_TRY(c, hipHostMalloc((void**)&c->h_probe, 64, 0));
+    }
+    if (c->probe_running) { c->err = "clock probe already running"; return LVM_ERR_INVALID; }
+    volatile unsigned long long* h = c->h_probe;
+    h[0] = 0; h[1] = 0; h[2] = 0; h[3] = 0;                  // [0] cycles, [1] ticks, [2] stop flag, [3] running
+    if (max_seconds <= 0.0 || max_seconds > 5.0) max_seconds = 5.0;
+    hipLaunchKernelGGL(k_clock_probe, dim3(1), dim3(64), 0, c->aux_stream, reinterpret_cast<const int*>(c->h_probe + 2), c->h_probe,
+                       (unsigned long long)(max_seconds * 1e8));
+    LVM_HIP_TRY(c, hipGetLastError());
+    c->probe_running = true;
+    // The lane must be ON the device before the measured work is enqueued: behind a busy queue of full-chip launches it is dispatched
+    // only when they drain (measured: started with the work, it covered the last 0.5 ms of a 13.5 ms region).  A few microseconds on an idle device.
+    for (int spin = 0; spin < 2000000 && __atomic_load_n(h + 3, __ATOMIC_ACQUIRE) == 0; ++spin) {}
+    return LVM_OK;
+}
+
+int clock_probe_stop(Ctx* c, double* mhz, double* seconds) {
+    if (!c->probe_running) { c->err = "no clock probe running"; return LVM_ERR_INVALID; }
+    __atomic_store_n(reinterpret_cast<int*>(c->h_probe + 2), 1, __ATOMIC_RELEASE);
+    c->probe_running = false;
+    LVM_HIP_TRY(c, hipStreamSynchronize(c->aux_stream));
+    const double cyc = (double)c->h_probe[0], tk = (double)c->h_probe[1];
+    if (mhz) *mhz = tk > 0.0 ? cyc / tk * 100.0 : 0.0;
+    if (seconds) *seconds = tk * 1e-8;
+    return LVM_OK;
+}
+
 }  // namespace lvm

@@ -966,6 +966,8 @@ struct LaplaceState : ModeState {
     long fin_min_tasks = 4096;            // strips are shortened until a launch has this many of them (LVM_FIN_MIN_TASKS)
     long rows_min_elems = 2000000;        // planes x pixels from which pyrDown uses k_pyr_down_rows (LVM_ROWS_MIN_ELEMS): 32-frame batches keep the strips on
                                           // levels 1-3 (3.1 M at level 3), four streams per per-frame call take the two-level kernel from level 2 (one launch less)
+    int split_from = 3;                   // first level of the IIR + collapse launches: 3 (round 6; with >= 5 levels) = level 2 as a fused step like level 1, its m_2 neither
+                                          // written nor read back (34 + 41 -> 20 + 14 + 34 us per 32 frames at 1080p); LVM_LAP_SPLIT_FROM=2: levels 2 .. L-1 decoupled
     int split_levels = 1;                 // temporal batches: levels >= 2 as one IIR launch + one collapse launch (LVM_LAP_SPLIT=0: level-by-level chain)
     int up_rows = 1;                      // barrier-free k_lap_up_rows for the steady state (LVM_UP_ROWS=0: tiled k_lap_up)
     long up_rows_max_blocks = 1024;       // launches with fewer tiled workgroups than this use k_lap_up_rows (LVM_UP_ROWS_MAX_BLOCKS)
@@ -1038,6 +1040,7 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     if (const char* e = std::getenv("LVM_UP_ROWS")) st->up_rows = std::atoi(e);
     if (const char* e = std::getenv("LVM_UP_ROWS_MAX_BLOCKS")) st->up_rows_max_blocks = std::atol(e);
     if (const char* e = std::getenv("LVM_ROWS_MIN_ELEMS")) st->rows_min_elems = std::atol(e);
+    if (const char* e = std::getenv("LVM_LAP_SPLIT_FROM")) { const int v = std::atoi(e); if (v == 2 || v == 3) st->split_from = v; }
     if (const char* e = std::getenv("LVM_FIN_MIN_TASKS")) st->fin_min_tasks = std::atol(e);
     if (const char* e = std::getenv("LVM_FIN_GROUPS")) st->fin_groups = std::atol(e);
     if (const char* e = std::getenv("LVM_FIN_ROWS")) { const int v = std::atoi(e); if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32) st->fin_rows = v; }
@@ -1233,14 +1236,16 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     const bool split = lap_split_now(st, B, first);
     const bool use_tail = st->tailT && B.nt == 1 && !B.no_tail && !split;
     int up_start = use_tail ? st->tailT - 1 : levels - 1;
-    // levels 2 .. L-1 decoupled (one IIR launch for all of them + one stateless collapse launch)
+    // levels F .. L-1 decoupled (one IIR launch for all of them + one stateless collapse launch); F = 2, or 3 (round 6, LVM_LAP_SPLIT_FROM)
+    // where level 2 then takes the fused band / IIR / collapse step like level 1: its m_2 is neither written nor read back
     if (split) {
+        const int F = (st->split_from == 3 && levels >= 5) ? 3 : 2;
         IirArgs ia;
-        ia.nlv = levels - 2; ia.nt = B.nt;
+        ia.nlv = levels - F; ia.nt = B.nt;
         ia.aHi = (float)(1 - cHi); ia.bHi = (float)cHi; ia.aLo = (float)(1 - cLo); ia.bLo = (float)cLo;
         int blocks = 0;
-        for (int l = 2; l <= levels - 1; ++l) {          // finest level first: its blocks are the long ones
-            IirLevel& v = ia.lv[l - 2];
+        for (int l = F; l <= levels - 1; ++l) {          // finest level first: its blocks are the long ones
+            IirLevel& v = ia.lv[l - F];
             v.Gl = G[l]; v.Gn = G[l + 1]; v.hi = st->hi[l]; v.lo = st->lo[l]; v.out = B.cur[l];
             v.w = st->g[l].w; v.h = st->g[l].h; v.wn = st->g[l + 1].w; v.hn = st->g[l + 1].h;
             v.gain = gains[l]; v.fsl = (long)st->planes * (long)st->g[l].n; v.fsn = (long)st->planes * (long)st->g[l + 1].n;
@@ -1251,11 +1256,11 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
         while (depth > 1 && B.nt % depth != 0) depth >>= 1;
         auto ki = depth == 8 ? k_lap_iir_levels<8> : (depth == 4 ? k_lap_iir_levels<4> : (depth == 2 ? k_lap_iir_levels<2> : k_lap_iir_levels<1>));
         LVM_LAUNCH(c, "lap_iir", ki, dim3((unsigned)blocks, (unsigned)st->planes), blk, s, ia);
-        if (levels >= 4) {
+        if (levels >= F + 2) {
             CollapseArgs ca;
-            ca.nlv = levels - 2;
-            for (int l = 2; l <= levels - 1; ++l) { ca.cur[l - 2] = B.cur[l]; ca.w[l - 2] = st->g[l].w; ca.h[l - 2] = st->g[l].h; }
-            const dim3 gridc((st->g[2].w + CT_W - 1) / CT_W, (st->g[2].h + CT_H - 1) / CT_H, (unsigned)(st->planes * B.nt));
+            ca.nlv = levels - F;
+            for (int l = F; l <= levels - 1; ++l) { ca.cur[l - F] = B.cur[l]; ca.w[l - F] = st->g[l].w; ca.h[l - F] = st->g[l].h; }
+            const dim3 gridc((st->g[F].w + CT_W - 1) / CT_W, (st->g[F].h + CT_H - 1) / CT_H, (unsigned)(st->planes * B.nt));
             void (*kc)(CollapseArgs) = nullptr;
             switch (ca.nlv) {
             case 2: kc = k_lap_collapse<2>; break; case 3: kc = k_lap_collapse<3>; break; case 4: kc = k_lap_collapse<4>; break;
@@ -1264,7 +1269,7 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
             }
             LVM_LAUNCH(c, "lap_collapse", kc, gridc, blk, s, ca);
         }
-        up_start = 1;
+        up_start = F - 1;
     }
     for (int l = up_start; l >= 1; --l) {
         UpArgs a;

@@ -224,6 +224,8 @@ void lvm_destroy(lvm_ctx* c) {
     if (c->d_gamma_u8) (void)hipFree(c->d_gamma_u8);
     if (c->d_invgamma) (void)hipFree(c->d_invgamma);
     if (c->d_u8steps) (void)hipFree(c->d_u8steps);
+    if (c->probe_running) { double m = 0; (void)lvm::clock_probe_stop(c, &m, nullptr); }
+    if (c->h_probe) (void)hipHostFree(c->h_probe);
     if (c->d_lab_ab) (void)hipFree(c->d_lab_ab);
     if (c->d_lab_Lcells) (void)hipFree(c->d_lab_Lcells);
     if (c->d_in) (void)hipFree(c->d_in);
@@ -828,6 +830,18 @@ int lvm_debug_sweep_u8_steps(lvm_ctx* c, uint32_t first_bits, uint64_t count, ui
     *mismatches = bad;
     if (first_bad_bits) *first_bad_bits = bad ? (uint32_t)fb : 0u;
     return LVM_OK;
+}
+
+int lvm_debug_clock_probe_start(lvm_ctx* c, double max_seconds) {
+    if (!c) return LVM_ERR_INVALID;
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    return lvm::clock_probe_start(c, max_seconds);
+}
+
+int lvm_debug_clock_probe_stop(lvm_ctx* c, double* mhz, double* seconds) {
+    if (!c) return LVM_ERR_INVALID;
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    return lvm::clock_probe_stop(c, mhz, seconds);
 }
 
 int lvm_debug_lab_analytic(lvm_ctx* c, int on) { if (!c) return LVM_ERR_INVALID; c->lab_analytic = on != 0; return LVM_OK; }

@@ -189,6 +189,12 @@ __device__ __forceinline__ uint32_t lvm_pack_b4(uint32_t a, uint32_t b, uint32_t
     return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
+// the two counters of a wave: s_memtime ticks with the shader clock (it slows down when the part throttles), s_memrealtime at a
+// constant 100 MHz -- their ratio over an interval is the average shader clock of that interval (lvm_debug_clock_probe_*)
+__device__ __forceinline__ unsigned long long lvm_clock_core() { return __builtin_readcyclecounter(); }
+__device__ __forceinline__ unsigned long long lvm_clock_real() { return __builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ void lvm_sleep() { __builtin_amdgcn_s_sleep(127); }
+
 // the lanes of the wave whose predicate holds (v_cmp into an SGPR pair); every lane of the wave must execute it
 __device__ __forceinline__ unsigned long long lvm_ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 // Orders the LDS accesses of ONE wave: what its lanes wrote before is what its lanes read after (the LDS serves a wave's requests in

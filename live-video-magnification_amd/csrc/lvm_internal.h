@@ -429,6 +429,7 @@ struct Ctx {
     float* d_gamma_u8 = nullptr;
     float* d_invgamma = nullptr;
     uint2* d_u8steps = nullptr;
+    unsigned long long* h_probe = nullptr; bool probe_running = false;      // lvm_debug_clock_probe_* (page-locked: cycles, ticks, stop flag)
     LabCoef lab{};
     // per-mode state (allocated for the tracked geometry)
     ModeState* state = nullptr;
@@ -555,6 +556,8 @@ int color_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
 
 // host tables (lab_tables.cpp)
 void build_lab_tables(float gamma_u8[256], float invgamma[4096], float fwd[9], float inv[9]);
+int clock_probe_start(Ctx* c, double max_seconds);            // labconv.hip
+int clock_probe_stop(Ctx* c, double* mhz, double* seconds);
 int sweep_u8_steps(Ctx* c, unsigned long long first, unsigned long long count, unsigned long long* bad, unsigned long long* first_bad, hipStream_t s);   // labconv.hip
 bool build_u8_steps(const float invgamma[4096], uint32_t steps[2 * kU8StepSlices]);   // false: the quantiser is not the step function the kernels assume
 void build_lab_lut_compact(std::vector<int16_t>& compact);

@@ -99,6 +99,12 @@ __device__ __forceinline__ uint32_t lut_mul24(uint32_t a, uint32_t b) { return (
 
 __device__ __forceinline__ uint32_t lvm_pack_b4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return (a & 255u) | ((b & 255u) << 8) | ((c & 255u) << 16) | (d << 24); }
 
+// (no clocks on the CPU: two counters at a fixed ratio of 20 : 1, so that the probe's plumbing reports "2000 MHz")
+inline unsigned long long& emu_ticks() { static unsigned long long t = 0; return t; }
+__device__ __forceinline__ unsigned long long lvm_clock_real() { return emu_ticks() += 100; }
+__device__ __forceinline__ unsigned long long lvm_clock_core() { return emu_ticks() * 20; }
+__device__ __forceinline__ void lvm_sleep() {}
+
 // a real cross-lane ballot (the header's __builtin_amdgcn_ballot_w64 stand-in is for wave-uniform predicates only)
 __device__ __forceinline__ unsigned long long lvm_ballot64(bool pred) { return hipemu::wave_ballot(pred ? 1 : 0); }
 __device__ __forceinline__ void lvm_wave_lds_sync() { hipemu::sync(); }

@@ -47,3 +47,18 @@ def test_emu_laplace_batches_from_the_first_frame_on_poisoned_memory(lvm, po, em
                 assert du.max() <= 1 and (du == 0).mean() >= 0.999, (k, int(du.max()), float((du == 0).mean()))
     finally:
         ctx.close(); orc.close()
+
+
+def test_emu_clock_probe_plumbing(lvm, emu):
+    """lvm_debug_clock_probe_start / _stop (bench.py's `clock_mhz`): start, stop, the ratio of the two counters x 100 MHz; one probe at a
+    time; a context destroyed with a probe running.  (The emulation's counters tick at a fixed 20 : 1, i.e. "2000 MHz".)"""
+    ctx = lvm.Context(0, 1, emu)
+    ctx.clock_probe_start(0.0005)
+    with pytest.raises(lvm.LvmError):
+        ctx.clock_probe_start(0.0005)
+    mhz, sec = ctx.clock_probe_stop()
+    assert abs(mhz - 2000.0) < 200.0 and sec > 0.0        # (the two reads at each end are not simultaneous)
+    with pytest.raises(lvm.LvmError):
+        ctx.clock_probe_stop()
+    ctx.clock_probe_start(0.0005)
+    ctx.close()

@@ -412,6 +412,14 @@ def test_laplace_emu_split_levels_iir_and_collapse(lvm, po, emu, w, h, levels, n
     _frames_clip(lvm, po, emu, 0, w, h, levels, ns, calls)
 
 
+@pytest.mark.parametrize("w,h,levels,ns,calls", [(640, 360, 5, 1, (1, 8, 4)), (256, 256, 6, 1, (1, 4, 6)), (320, 182, 5, 2, (1, 5, 16))])
+def test_laplace_emu_split_from_level_2_still_matches(lvm, po, emu, w, h, levels, ns, calls, monkeypatch):
+    """LVM_LAP_SPLIT_FROM=2: levels 2 .. L-1 all in the IIR + collapse launches (the default until round 6; since then level 2 is a fused
+    band / IIR / collapse step when the pyramid has >= 5 levels and the two launches start at level 3)."""
+    monkeypatch.setenv("LVM_LAP_SPLIT_FROM", "2")
+    _frames_clip(lvm, po, emu, 0, w, h, levels, ns, calls)
+
+
 def test_laplace_emu_level_chain_still_matches(lvm, po, emu, monkeypatch):
     """LVM_LAP_SPLIT=0 keeps the level-by-level chain of fused launches in temporal batches."""
     monkeypatch.setenv("LVM_LAP_SPLIT", "0")

@@ -155,20 +155,25 @@ def _bench(args, timeout=900):
 def test_bench_verifies_itself_and_prices_kernels_below_peak():
     """bench.py at a reduced size: the timed region's own output matches the oracle, the JSON carries the contract's
     fields, and no per-kernel GB/s exceeds the HBM peak (a figure above peak means the byte model is wrong)."""
-    out = _bench(["--width", "640", "--height", "360", "--levels", "4", "--steps", "64", "--warmup", "8", "--no-subrecords"])
+    out = _bench(["--width", "640", "--height", "360", "--levels", "4", "--steps", "6", "--warmup", "2", "--no-subrecords"])
     assert out["verified"] is True, out["verification"]
     assert out["verification"]["timed_frames_compared"] >= 8
-    assert out["n_gpus"] == 1 and out["steps"] == 64 and out["warmup"] == 8
+    assert out["n_gpus"] == 1 and out["steps"] == 6 and out["warmup"] == 2 and out["frames_per_step"] == 32
     assert out["roofline"] and out["cpu_baseline"] and out["cpu_baseline"]["kind"] == "port"
     for name, k in out["kernels"].items():
         assert k["alg_bytes"] is not None, name
         assert k["gbs"] <= 8000.0, (name, k)
-    assert abs(out["value"] - out["steps"] / out["timed_seconds_max_over_ranks"]) <= 1e-6 * out["value"] + 0.01
+    # a step = one call of frames_per_step frames: value (frames/s) = steps x frames_per_step / the timed seconds
+    assert abs(out["value"] - out["steps"] * out["frames_per_step"] / out["timed_seconds_max_over_ranks"]) <= 1e-6 * out["value"] + 0.01
+    assert abs(out["ms_per_step"] - 1e3 * out["timed_seconds_max_over_ranks"] / out["steps"]) <= 1e-3
+    # the shader clock over the timed region (s_memtime / s_memrealtime): a plausible MI355X figure, covering about the timed region
+    assert out["clock"]["error"] is None and 500.0 < out["clock_mhz"] < 3000.0, out["clock"]
+    assert 0.5 * out["timed_seconds_max_over_ranks"] < out["clock"]["seconds_covered"] < 1.5 * out["timed_seconds_max_over_ranks"] + 1e-3, out["clock"]
 
 
 @pytest.mark.parametrize("mode", ["riesz", "color"])
 def test_bench_other_modes_verify(mode):
-    out = _bench(["--mode", mode, "--width", "640", "--height", "360", "--levels", "4", "--steps", "32", "--warmup", "8", "--no-subrecords"])
+    out = _bench(["--mode", mode, "--width", "640", "--height", "360", "--levels", "4", "--steps", "4", "--warmup", "2", "--no-subrecords"])
     assert out["verified"] is True, out["verification"]
     for name, k in out["kernels"].items():
         assert k["gbs"] is None or k["gbs"] <= 8000.0, (name, k)
@@ -185,7 +190,7 @@ def test_bench_two_ranks_from_a_plain_shell():
     assert [r["rank"] for r in ranks] == [0, 1]
     assert [r["stream_ids"] for r in ranks] == [[0], [1]]
     assert not [r for r in ranks if r["verified"] is not True], "UNVERIFIED RANKS " + json.dumps([(r["rank"], r.get("verification")) for r in ranks if r["verified"] is not True])
-    expect = 2 * 1 * 8 / out["timed_seconds_max_over_ranks"]
+    expect = 2 * 1 * 8 * 4 / out["timed_seconds_max_over_ranks"]       # ranks x streams x steps x frames per step
     assert abs(out["value"] - expect) <= 1e-6 * expect + 0.01
     assert out["cfg4_riesz_4k"]["n_gpus"] == 2 and out["cfg4_riesz_4k"]["verified"] is True
     assert len(out["host_fed"]["per_rank"]) == 2
@@ -230,7 +235,7 @@ def test_bench_eight_ranks_dry_run():
     assert [r["rank"] for r in ranks] == list(range(8))
     assert [r["stream_ids"] for r in ranks] == [[i] for i in range(8)]
     assert not [r for r in ranks if r["verified"] is not True], "UNVERIFIED RANKS " + json.dumps([(r["rank"], r.get("verification")) for r in ranks if r["verified"] is not True])
-    expect = 8 * 1 * 8 / out["timed_seconds_max_over_ranks"]
+    expect = 8 * 1 * 8 * 4 / out["timed_seconds_max_over_ranks"]       # ranks x streams x steps x frames per step
     assert abs(out["value"] - expect) <= 1e-6 * expect + 0.01
     c4 = out["cfg4_riesz_4k"]
     assert c4["n_gpus"] == 8 and c4["verified"] is True and c4["roofline"]["frame_frac"] > 0 and c4["cpu_baseline"]["kind"] == "port", c4
@@ -249,6 +254,9 @@ def test_bench_driver_line_carries_every_config():
     out = _bench(["--steps", "20", "--warmup", "5"], timeout=1500)
     assert out["verified"] is True and out["roofline"]["frame_frac"] > 0 and out["roofline"]["frac"] <= 1.0
     assert out["value_cold"]["value"] > 0 and out["value_cold"]["steps"] == 20
+    # round 6: a step is a whole 32-frame call (20 steps = 640 timed frames), the per-frame schedule rides beside it, the clock is recorded
+    assert out["frames_per_step"] == 32 and out["timed_frames_per_stream"] == 640 and out["clock_mhz"] > 500.0
+    assert out["process_schedule"]["value"] > 0 and out["process_schedule"]["frames_per_call"] == 1 and out["process_schedule"]["launches_per_frame"] >= 1
     for key in ("cfg2_riesz_1080p", "cfg3_color_1080p", "cfg4_riesz_4k"):
         r = out[key]
         assert r["verified"] is True, (key, r.get("verification"))
