@@ -973,6 +973,7 @@ struct LaplaceState : ModeState {
     long up_rows_max_blocks = 1024;       // launches with fewer tiled workgroups than this use k_lap_up_rows (LVM_UP_ROWS_MAX_BLOCKS)
     bool d0_rows_on = true;               // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
     bool d0_fused = true;                 // table conversion fused into the first kernel on large launches (LVM_D0_FUSED=0: separate kernels)
+    long d0_fused_groups = 0;             // persistent workgroups of the fused first kernel (LVM_D0_FUSED_GROUPS; 0 = one per CU)
     long d0_fused_waves = 0;              // ... = launches with at least this many strips (LVM_D0_FUSED_WAVES; 0 = one per resident wave)
     long d0_min_tasks = 4096;             // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
     long fin_groups = 0;                  // workgroups of the persistent last kernel (LVM_FIN_GROUPS; 0 = 1024)
@@ -1034,6 +1035,7 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     if (const char* e = std::getenv("LVM_D0_ROWS")) st->d0_rows_on = std::atoi(e) != 0;
     if (const char* e = std::getenv("LVM_D0_FUSED")) st->d0_fused = std::atoi(e) != 0;
     if (const char* e = std::getenv("LVM_D0_FUSED_WAVES")) st->d0_fused_waves = std::atol(e);
+    if (const char* e = std::getenv("LVM_D0_FUSED_GROUPS")) st->d0_fused_groups = std::atol(e);
     if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
     if (const char* e = std::getenv("LVM_LAP_SPLIT")) st->split_levels = std::atoi(e);
     if (const char* e = std::getenv("LVM_LAP_SPLIT_MIN_NT")) st->split_min_nt = std::atoi(e);
@@ -1116,13 +1118,18 @@ static bool lap_split_now(const LaplaceState* st, const LapBufs& B, bool first) 
     return split;
 }
 
+// persistent workgroups of k_down0_lut_rows: one per CU (its table takes the CU's LDS), or fewer (LVM_D0_FUSED_GROUPS / the pipelined
+// batch schedule: the CUs left free take the other stream's launches)
+static int lap_d0l_groups(const Ctx* c, const LaplaceState* st) {
+    return (st->d0_fused_groups > 0 && st->d0_fused_groups < c->num_cus) ? (int)st->d0_fused_groups : c->num_cus;
+}
 // arguments of k_down0_lut_rows for the frames of B (false: this launch does not take the fused first kernel)
 static bool lap_d0l_args(Ctx* c, LaplaceState* st, const FrameIO& io, const LapBufs& B, D0LArgs* out) {
     const int NS = c->nstreams * B.nt, levels = st->levels;
     const LabPlanes lp = lap_planes(c, io, B);
     if (!(lp.iab && levels >= 2 && st->d0_fused && lap_vec4(io) && st->g[1].w % 2 == 0)) return false;
     long dl_tasks = 0;
-    const long dl_waves = st->d0_fused_waves > 0 ? st->d0_fused_waves : (long)c->num_cus * (D0L_THREADS / 64);
+    const long dl_waves = st->d0_fused_waves > 0 ? st->d0_fused_waves : (long)lap_d0l_groups(c, st) * (D0L_THREADS / 64);
     const int dl_rows = down0_lut_rows_choice(st->g[1].w, st->g[1].h, NS, dl_waves, &dl_tasks);
     if (dl_tasks <= 0) return false;
     const LevelGeom& g1 = st->g[1];
@@ -1154,7 +1161,7 @@ static void lap_stage_b(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     const int fl = lab_flavour(c);
     if (fused) {
         auto kdl = fl == FL_LUT_EXACT ? k_down0_lut_rows<FL_LUT_EXACT> : k_down0_lut_rows<FL_LUT_FAST>;
-        LVM_LAUNCH(c, "lap_down0_lut", kdl, dim3((unsigned)c->num_cus), dim3(D0L_THREADS), s, da);
+        LVM_LAUNCH(c, "lap_down0_lut", kdl, dim3((unsigned)lap_d0l_groups(c, st)), dim3(D0L_THREADS), s, da);
     } else if (lap_vec4(io) && st->d0_rows_on && d0_tasks > 0) {
         auto kd0 = LVM_FL_PICK(fl, k_down0_rows, true);
         const dim3 gridr((unsigned)((d0_tasks + D0R_THREADS / 64 - 1) / (D0R_THREADS / 64)));

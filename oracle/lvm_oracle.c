@@ -609,7 +609,31 @@ void lvmo_u8_of_linear_sweep(uint32_t first, uint64_t count, uint64_t* descents,
 /* inner loops are v_muladd == v_fma, a true FMA in the AVX2 dispatch every current x86 host */
 /* takes (the SSE-only dispatch would round the product first; unpinned either way).         */
 /* ------------------------------------------------------------------------------------- */
+/* LVMO_VAR_FILTER_DFT -- the OTHER path of cv::filter2D.  filter.dispatch.cpp sends a kernel of kw * kh >= dft_filter_size elements
+ * through crossCorr (templmatch.cpp) instead of the FilterEngine; dft_filter_size is 130 where checkHardwareSupport(CV_CPU_SSE3)
+ * holds for 8U / 32F images and 50 everywhere else -- i.e. on every ARM build (the reference builds for macOS, CMakeLists.txt:10,
+ * :142-163) the 9 x 9 kernels of RieszPyramid.cpp:227-232, :316-319 (81 taps) take it; the 1 x 5 / 5 x 1 Riesz kernels and
+ * sepFilter2D do not.  crossCorr pads the image block with copyMakeBorder(borderType) -- the same REFLECT_101 samples -- and, for images
+ * deeper than CV_8S, transforms in CV_64F ("maxDepth = depth > CV_8S ? CV_64F : ..."): block sizes 256 - 9 + 1 rounded up to
+ * getOptimalDFTSize, spectra multiplied with mulSpectrums(conj), inverse transform scaled, ONE convertTo(CV_32F) at the end.  In
+ * float64 the FFT's error against the exact sum is ~1e-14 absolute on planes of magnitude <= 100 -- far below the binary32 rounding
+ * that follows -- so the path is restated as what it computes: the float64 sum of the 81 exact products, rounded once
+ * (tests/test_oracle_variants.py checks this model against a numpy float64 FFT correlation with crossCorr's block sizes).           */
+static void filter2d_f64_sum(const float* src, int w, int h, const float* k, int kw, int kh, float* dst) {
+    const int ax = kw / 2, ay = kh / 2;
+#pragma omp parallel for schedule(static)
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            double s = 0.0;
+            for (int i = 0; i < kh; ++i) {
+                const float* row = src + (size_t)reflect101(y + i - ay, h) * w;
+                for (int j = 0; j < kw; ++j) s += (double)k[i * kw + j] * (double)row[reflect101(x + j - ax, w)];
+            }
+            dst[(size_t)y * w + x] = (float)s;
+        }
+}
 void lvmo_filter2d(const float* src, int w, int h, const float* k, int kw, int kh, float* dst) {
+    if ((g_var & LVMO_VAR_FILTER_DFT) && kw * kh >= 50) { filter2d_f64_sum(src, w, h, k, kw, kh, dst); return; }
     const int ax = kw / 2, ay = kh / 2;
     int nt = 0;
     int* tx = (int*)malloc(sizeof(int) * kw * kh);

@@ -122,7 +122,9 @@ enum {
     LVMO_VAR_LUT_NUDGE_DOWN  = 64,   /* ... one step down */
     LVMO_VAR_SPLINE_CV3      = 128,  /* gamma / inverse-gamma splines in the OpenCV 3.x form of splineBuild (forward sweep to n-2, x 0.3333333333333333f) instead of
                                         OpenCV 4's (sweep to n-1, / 3): what rounds 1-4 restated */
-    LVMO_VAR_DFT_F32         = 256   /* Color band-pass: both transforms in binary32 (radix-2 FFT for power-of-two windows) instead of float64 direct sums */
+    LVMO_VAR_DFT_F32         = 256,  /* Color band-pass: both transforms in binary32 (radix-2 FFT for power-of-two windows) instead of float64 direct sums */
+    LVMO_VAR_FILTER_DFT      = 512   /* filter2D with kw * kh >= 50 through its DFT path (crossCorr; builds without SSE3 = every ARM build): the 9 x 9 Riesz kernels as
+                                        float64 sums rounded once instead of binary32 fma chains */
 };
 void     lvmo_set_variant(unsigned mask);
 unsigned lvmo_get_variant(void);

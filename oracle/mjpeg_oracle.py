@@ -412,8 +412,31 @@ def decode_coefficients(j):
     return hd, coef.reshape(mh, mw, 6, 64)
 
 
-def reconstruct(hd, coef):
-    """quantised coefficients -> BGR u8 [h][w][3]"""
+def upsample_fancy(c):
+    """libjpeg's h2v2_fancy_upsample (jdsample.c; do_fancy_upsampling, its default): triangle filter -- the nearer chroma sample weighs 3/4,
+    the farther 1/4 in each direction (9 : 3 : 3 : 1), rounding constants 8 / 7 alternating by column, the edge samples replicated.
+    c [H][W] -> [2 H][2 W].  What Pillow's decoder (and most software decoders) do where `reconstruct` replicates."""
+    c = c.astype(np.int64)
+    H, W = c.shape
+    above = np.vstack([c[:1], c[:-1]])
+    below = np.vstack([c[1:], c[-1:]])
+    out = np.empty((2 * H, 2 * W), np.int64)
+    for v, nb in ((0, above), (1, below)):
+        cs = 3 * c + nb
+        last = np.hstack([cs[:, :1], cs[:, :-1]])
+        nxt = np.hstack([cs[:, 1:], cs[:, -1:]])
+        even = (3 * cs + last + 8) >> 4
+        odd = (3 * cs + nxt + 7) >> 4
+        even[:, 0] = (cs[:, 0] * 4 + 8) >> 4
+        odd[:, -1] = (cs[:, -1] * 4 + 7) >> 4
+        out[v::2, 0::2] = even
+        out[v::2, 1::2] = odd
+    return out
+
+
+def reconstruct(hd, coef, fancy=False):
+    """quantised coefficients -> BGR u8 [h][w][3].  fancy: chroma through libjpeg's triangle filter (upsample_fancy) instead of replication --
+    a VARIANT for tests (what the decode step in front of the reference, FFmpeg / libjpeg, would feed the chain); the kernels replicate."""
     mh, mw = coef.shape[:2]
     m = dct_matrix()
     tq = [hd["comps"][0][3]] * 4 + [hd["comps"][1][3], hd["comps"][2][3]]
@@ -434,6 +457,11 @@ def reconstruct(hd, coef):
             y[oy + r::16, :].reshape(mh, mw, 16)[:, :, ox:ox + 8] = blk[:, :, r, :]
     def up(pl):
         full = pl.transpose(0, 2, 1, 3).reshape(mh * 8, mw * 8)
+        if fancy:
+            ch, cw = (hd["h"] + 1) // 2, (hd["w"] + 1) // 2        # the component's own size: the filter replicates ITS edge samples
+            o = np.zeros((mh * 16, mw * 16), np.int64)
+            o[:2 * ch, :2 * cw] = upsample_fancy(full[:ch, :cw])
+            return o
         return np.repeat(np.repeat(full, 2, axis=0), 2, axis=1)
     cb, cr = up(planes[4]) - 128, up(planes[5]) - 128
     r = y + ((91881 * cr + 32768) >> 16)
@@ -443,6 +471,6 @@ def reconstruct(hd, coef):
     return out[:hd["h"], :hd["w"]]
 
 
-def decode_frame(j):
+def decode_frame(j, fancy=False):
     hd, coef = decode_coefficients(j)
-    return reconstruct(hd, coef)
+    return reconstruct(hd, coef, fancy)

@@ -108,7 +108,7 @@ def lib():
 
 # lvm_oracle.h LVMO_VAR_*: the unpinned OpenCV build choices as switches (0 = the restatement the parity tests use)
 VARIANTS = {"pyr_simd": 1, "filter_unfused": 2, "addw_fused": 4, "mul_f32": 8, "gamma_f32": 16, "lut_nudge_up": 32,
-            "lut_nudge_down": 64, "spline_cv3": 128, "dft_f32": 256}
+            "lut_nudge_down": 64, "spline_cv3": 128, "dft_f32": 256, "filter_dft": 512}
 
 
 def set_variant(mask):

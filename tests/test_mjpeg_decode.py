@@ -319,3 +319,60 @@ def _decode_prefix(j, hd, mcu_rows):
                 coef[m, bi, kk] = mo._extend(br.bits(s), s)
                 kk += 1
     return coef.reshape(mcu_rows, mw, 6, 64)
+
+
+# ---- what the decoder's chroma upsampling does to a MAGNIFIED frame (Missing 5 / Next 4b) -----------------------------------
+# The decode step in front of the reference is cv::VideoCapture (FileSource.cpp:99): FFmpeg's mjpeg decoder or libjpeg, both of which INTERPOLATE
+# the 4:2:0 chroma planes; k_mjd_pixels replicates them (bit-identical to mjpeg_oracle.reconstruct).  mjpeg_oracle.reconstruct(fancy=True) is the
+# variant with libjpeg's triangle filter.  The magnifier then amplifies whatever difference the two inputs have; this measures how much.
+def test_oracle_fancy_upsampling_is_what_libjpeg_decodes():
+    """the variant against the independent decoder in the image (Pillow = libjpeg-turbo, fancy upsampling on): closer to it than the
+    replicating decoder by ~6 dB, what is left is the two inverse DCTs' rounding"""
+    for (w, h, q) in [(96, 64, 90), (160, 90, 75), (37, 29, 95)]:
+        f = texture(w, h)
+        j = pil_encode(f, q, subsampling=2)
+        pil = pil_decode(j).astype(int)
+        rep, fan = mo.decode_frame(j).astype(int), mo.decode_frame(j, fancy=True).astype(int)
+        e_rep, e_fan = float(np.mean((rep - pil) ** 2)), float(np.mean((fan - pil) ** 2))
+        assert np.abs(fan - pil).max() <= 4 and e_fan < 0.5 * e_rep, (w, h, q, np.abs(fan - pil).max(), e_fan, e_rep)
+
+
+@pytest.mark.parametrize("cfg", [0, 2])
+def test_chroma_upsampling_variant_through_the_magnifier(lvm, po, cfg):
+    """BASELINE config 0 (Laplace) / 2 (Riesz) at 320 x 180 for 48 frames, every frame JPEG-coded (libjpeg, quality 90, 4:2:0) and decoded twice:
+    replicated chroma (the kernels' decoder) and triangle-filtered chroma (libjpeg's / FFmpeg's).  Both sequences go through the CPU oracle of the
+    magnifier; reported: how far the INPUTS are apart and how far the MAGNIFIED frames are (`-s` prints the line DESIGN.md quotes)."""
+    size = (320, 180, 4 if cfg == 0 else 5)
+    ck, pk = lvm.synth.config(cfg, size)
+    clip = lvm.synth.Clip(**ck)
+    P = po.make_params(**pk)
+    oa, ob = po.Oracle(), po.Oracle()
+    din, dout, dmax_in, dmax_out, same = [], [], 0, 0, []
+    try:
+        for t in range(48):
+            j = pil_encode(clip.frame(t), 90, subsampling=2)
+            hd, coef = mo.decode_coefficients(j)
+            a, b = mo.reconstruct(hd, coef), mo.reconstruct(hd, coef, fancy=True)
+            ra, pa = oa.process(a, P)
+            rb, pb = ob.process(b, P)
+            assert pa == pb
+            d_in = np.abs(a.astype(int) - b.astype(int))
+            dmax_in = max(dmax_in, int(d_in.max())); din.append(float(np.mean(d_in.astype(float) ** 2)))
+            if pa:
+                d = np.abs(ra.astype(int) - rb.astype(int))
+                dmax_out = max(dmax_out, int(d.max())); dout.append(float(np.mean(d.astype(float) ** 2))); same.append(float((d == 0).mean()))
+    finally:
+        oa.close(); ob.close()
+    psnr = lambda mse: 10 * np.log10(255.0 ** 2 / max(mse, 1e-12))      # noqa: E731
+    p_in, p_out = psnr(np.mean(din)), psnr(np.mean(dout))
+    print("cfg%d decoded inputs (replicated vs triangle chroma): max %d levels, PSNR %.1f dB | magnified outputs: max %d levels, PSNR %.1f dB, "
+          "%.1f %% identical bytes" % (cfg, dmax_in, p_in, dmax_out, p_out, 100 * np.mean(same)))
+    assert dmax_in <= 12 and p_in >= 44.0
+    if cfg == 0:
+        # Laplace (alpha 20 on band-passed Lab pyramids): the decode difference passes through essentially unchanged (measured 55.1 -> 54.9 dB, max 6 -> 7 levels)
+        assert p_out >= p_in - 1.5 and dmax_out <= 2 * dmax_in + 2, (p_in, p_out, dmax_in, dmax_out)
+    else:
+        # Riesz (alpha 50 on the PHASE of the luminance bands): the same 55 dB input difference comes out at ~40 dB, single pixels up to ~90 levels apart
+        # (the ill-conditioned phase step of RieszPyramid.cpp:93-97 again): a file -> file export whose frames are decoded on the GPU matches the
+        # reference's frame only as far as the two decoders match -- stated in DESIGN.md section 8.4; bounded here so that a regression shows
+        assert p_out >= 36.0 and dmax_out <= 160, (p_in, p_out, dmax_out)

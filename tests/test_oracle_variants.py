@@ -26,7 +26,7 @@ SIZE = {0: (320, 180, 4), 2: (320, 180, 5), 3: (320, 180, 4)}        # cfg -> (w
 # variants that can touch a mode at all (the others are skipped: identical code path)
 APPLIES = {
     0: ["pyr_simd", "addw_fused", "gamma_f32", "lut_nudge_up", "lut_nudge_down", "spline_cv3"],
-    2: ["filter_unfused", "mul_f32", "gamma_f32", "lut_nudge_up", "lut_nudge_down", "spline_cv3"],
+    2: ["filter_unfused", "filter_dft", "mul_f32", "gamma_f32", "lut_nudge_up", "lut_nudge_down", "spline_cv3"],
     3: ["pyr_simd", "dft_f32"],
 }
 
@@ -71,7 +71,7 @@ def base():
     return {cfg: run_clip(cfg, 0) for cfg in SIZE}
 
 
-BUILD_CHOICES = ("pyr_simd", "filter_unfused", "addw_fused", "mul_f32", "dft_f32")      # depend on the OpenCV build a maintainer links
+BUILD_CHOICES = ("pyr_simd", "filter_unfused", "filter_dft", "addw_fused", "mul_f32", "dft_f32")      # depend on the OpenCV build a maintainer links
 TABLE_RESIDUALS = ("gamma_f32", "lut_nudge_up", "lut_nudge_down")            # forward-table restatement: removed by lvm_set_lab_lut
 RESTATEMENT_RESIDUALS = ("spline_cv3",)    # round 5: splineBuild in its OpenCV 3.x form (what rounds 1-4 restated) against OpenCV 4's (the default now)
 
@@ -171,6 +171,50 @@ def test_variant_switches_change_the_primitives():
     finally:
         po.set_variant(0)
     assert not np.array_equal(y0, y1) and np.abs(y0 - y1).max() <= 1e-4, float(np.abs(y0 - y1).max())
+
+
+def test_filter_dft_variant_is_what_crosscorr_computes():
+    """LVMO_VAR_FILTER_DFT restates filter2D's DFT path (templmatch.cpp crossCorr; every 9 x 9 kernel on builds without SSE3) as the float64
+    sum of the 81 products rounded once.  Checked against the path itself: a float64 FFT correlation over blocks of crossCorr's sizes
+    (blockScale 4.5, minBlockSize 256, getOptimalDFTSize), REFLECT_101 padding, one rounding to binary32 at the end."""
+    rng = np.random.default_rng(11)
+    w, h = 331, 207
+    a = (rng.uniform(0, 100, (h, w)) + 20 * np.sin(np.arange(w) / 9.0)[None, :]).astype(np.float32)
+    k = rng.uniform(-0.2, 0.2, (9, 9)).astype(np.float32)
+    po.set_variant(po.VARIANTS["filter_dft"])
+    try:
+        got = po.filter2d(a, k)
+        small = po.filter2d(a, k[4:5, 2:7].copy())          # 1 x 5: below dft_filter_size, the direct path even on such builds
+    finally:
+        po.set_variant(0)
+    assert np.array_equal(small, po.filter2d(a, k[4:5, 2:7].copy()))
+    # crossCorr's block decomposition
+    def optimal_dft(n):
+        while True:
+            m = n
+            for p in (2, 3, 5):
+                while m % p == 0:
+                    m //= p
+            if m == 1:
+                return n
+            n += 1
+    bw = min(max(int(round(9 * 4.5)), 256 - 9 + 1), w); bh = min(max(int(round(9 * 4.5)), 256 - 9 + 1), h)
+    dw, dh = max(optimal_dft(bw + 8), 2), optimal_dft(bh + 8)
+    bw, bh = min(dw - 8, w), min(dh - 8, h)
+    pad = np.pad(a.astype(np.float64), 4, mode="reflect")               # numpy "reflect" = BORDER_REFLECT_101
+    K = np.fft.rfft2(k.astype(np.float64), s=(dh, dw))
+    want = np.empty((h, w), np.float32)
+    for y0 in range(0, h, bh):
+        for x0 in range(0, w, bw):
+            y1, x1 = min(y0 + bh, h), min(x0 + bw, w)
+            blk = pad[y0:y1 + 8, x0:x1 + 8]
+            c = np.fft.irfft2(np.fft.rfft2(blk, s=(dh, dw)) * np.conj(K), s=(dh, dw))      # correlation: conj(kernel spectrum)
+            want[y0:y1, x0:x1] = c[:y1 - y0, :x1 - x0].astype(np.float32)
+    same = float((want == got).mean())
+    print("float64 sum rounded once vs float64 FFT correlation in crossCorr's blocks: %.6f of the pixels identical, max |d| %.2e" % (same, float(np.abs(want - got).max())))
+    assert same >= 0.9999 and np.abs(want - got).max() <= 1.6e-5          # (one binary32 step at magnitude <= 128 where the two disagree at all)
+    d = po.filter2d(a, k)
+    assert not np.array_equal(d, got) and np.abs(d - got).max() <= 1e-4
 
 
 def test_table_entries_near_a_rounding_boundary():
