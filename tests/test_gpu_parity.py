@@ -467,8 +467,8 @@ def test_variant_envelope_gpu(lvm, po, hip):
     sanity-bounded -- they are the oracle's own distance to that variant, to which the library adds ~4e-6."""
     sizes = {0: (320, 180, 4), 2: (320, 180, 5), 3: (320, 180, 4)}
     applies = {0: ["pyr_simd", "addw_fused", "gamma_f32", "lut_nudge_up", "lut_nudge_down", "spline_cv3"],
-               2: ["filter_unfused", "mul_f32", "gamma_f32", "lut_nudge_up", "lut_nudge_down", "spline_cv3"], 3: ["pyr_simd", "dft_f32"]}
-    build_choices = ("pyr_simd", "filter_unfused", "addw_fused", "mul_f32", "dft_f32")
+               2: ["filter_unfused", "filter_dft", "mul_f32", "gamma_f32", "lut_nudge_up", "lut_nudge_down", "spline_cv3"], 3: ["pyr_simd", "dft_f32"]}
+    build_choices = ("pyr_simd", "filter_unfused", "filter_dft", "addw_fused", "mul_f32", "dft_f32")
     nframes = {0: 64, 2: 64, 3: 150}      # colour: past its 128-frame window (the power-of-two transform length)
     for cfg in (0, 2, 3):
         ck, pk = lvm.synth.config(cfg, sizes[cfg])
