@@ -99,7 +99,7 @@ def kernel_alg_bytes(mode, name, w, h, ch, levels, S, T, Twin=0):
             per_frame = 4 * P * (n[lvl] + n[lvl + 1] + (n[lvl + 1] if lvl + 1 <= levels - 1 else 0) + n[lvl])
             return T * per_frame + 16 * P * n[lvl]                            # hi/lo read + written once per launch
         # round 6: the IIR + collapse launches start at level F = 3 when the pyramid has >= 5 levels (level 2 is a fused lap_up step then)
-        F = 3 if (levels >= 5 and os.environ.get("LVM_LAP_SPLIT_FROM", "3") != "2") else 2
+        F = 3 if (levels >= 5 and T >= 4 and os.environ.get("LVM_LAP_SPLIT_FROM", "3") != "2") else 2
         if base == "lap_iir":        # levels F .. L-1 in one launch: G_l, G_{l+1} read, m_l written per frame; states once
             return sum(T * 4 * P * (2 * n[l] + n[l + 1]) + 16 * P * n[l] for l in range(F, levels))
         if base == "lap_collapse":   # m_F .. m_{L-1} read, cur_F written

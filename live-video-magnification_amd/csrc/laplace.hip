@@ -1246,7 +1246,7 @@ static void lap_stage_a(Ctx* c, LaplaceState* st, const lvm_params& p, const Fra
     // levels F .. L-1 decoupled (one IIR launch for all of them + one stateless collapse launch); F = 2, or 3 (round 6, LVM_LAP_SPLIT_FROM)
     // where level 2 then takes the fused band / IIR / collapse step like level 1: its m_2 is neither written nor read back
     if (split) {
-        const int F = (st->split_from == 3 && levels >= 5) ? 3 : 2;
+        const int F = (st->split_from == 3 && levels >= 5 && B.nt >= 4) ? 3 : 2;      // (per-frame calls: one launch more would cost more than m_2's round trip)
         IirArgs ia;
         ia.nlv = levels - F; ia.nt = B.nt;
         ia.aHi = (float)(1 - cHi); ia.bHi = (float)cHi; ia.aLo = (float)(1 - cLo); ia.bLo = (float)cLo;
