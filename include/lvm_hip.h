@@ -184,11 +184,34 @@ int  lvm_compose_geometry(int split, int ow, int oh, int pw, int ph, int* pane_w
 /* Exporter::compose on DEVICE memory for all n_streams streams: toBgr (gray -> b = g = r, Exporter.cpp:22-34), crop,
  * and the side-by-side / stacked / single-pane BGR canvas (3 bytes per pixel, canvas_stride >= 3 * canvas_w).  d_orig
  * may be NULL (the reference falls back to the processed frame, :62).  Enqueued on hip_stream, not synchronised.  The
- * text overlay (:36-50, cv::putText) is not part of this entry point: labels are drawn on the downloaded canvas. */
+ * text overlay (:36-50) is lvm_overlay_device's job (below). */
 int  lvm_compose_device(lvm_ctx* ctx, int split, const uint8_t* d_orig, int ow, int oh, int och,
                         ptrdiff_t orig_stride, ptrdiff_t orig_stream_stride, const uint8_t* d_proc, int pw, int ph,
                         int pch, ptrdiff_t proc_stride, ptrdiff_t proc_stream_stride, uint8_t* d_canvas,
                         ptrdiff_t canvas_stride, ptrdiff_t canvas_stream_stride, void* hip_stream);
+
+/* The export's text overlay (drawLabel, export/Exporter.cpp:36-50: the rectangle behind a caption darkened with
+ * cv::addWeighted(roi, 0.35, black, 0.65), then cv::putText(FONT_HERSHEY_SIMPLEX, white, LINE_AA); called from compose, :74-77 / :82-85)
+ * as PER-PIXEL TABLES.  Both steps read-modify-write single pixels with the same arithmetic for B, G and R, so what a label does to a
+ * canvas pixel is a function of that pixel's byte; the label itself depends only on the canvas size, i.e. it is fixed for an export.
+ * The reference-side shim renders each label ONCE with the reference's own calls onto 256 constant canvases
+ * (value v = 0..255) and reads the function off them -- exact for whatever the linked OpenCV draws; nothing of cv::putText is restated
+ * in this library.  Pixels with equal functions share a class:
+ *   x, y, w, h   the rectangle on the canvas (`bg` of drawLabel after its clip, :43-44)
+ *   cls[h][w]    class of every pixel;   fn[n_classes][256]   new byte = fn[cls][old byte]
+ * lvm_export_set_overlay copies up to 4 labels into device memory (0 labels: overlay off); lvm_export_frames / _mjpeg /
+ * lvm_export_mjpeg_frames then apply them to every composed canvas ON THE DEVICE, so an export with `textOverlay` keeps the device and the
+ * Motion-JPEG paths.  A label that does not fit the canvas of a later call fails that call (LVM_ERR_INVALID: it was rendered for another
+ * canvas size).  lvm_overlay_device: the same on caller-owned device canvases (enqueued, not synchronised).                        */
+typedef struct lvm_overlay_label {
+    int32_t x, y, w, h;
+    int32_t n_classes;
+    const uint16_t* cls;
+    const uint8_t* fn;
+} lvm_overlay_label;
+int  lvm_export_set_overlay(lvm_ctx* ctx, int n_labels, const lvm_overlay_label* labels);
+int  lvm_overlay_device(lvm_ctx* ctx, uint8_t* d_canvas, int canvas_w, int canvas_h, ptrdiff_t canvas_stride, ptrdiff_t frame_stride,
+                        int n_frames, void* hip_stream);
 
 /* The loop body of Exporter::run (export/Exporter.cpp:216-259) for n_frames CONSECUTIVE host frames of a 1-stream context:
  *   runChainOnce (ChainBuilder.cpp:19-29: PreprocessProcessor -> GrayscaleProcessor -> MagnificationProcessor) on every frame in
@@ -198,8 +221,8 @@ int  lvm_compose_device(lvm_ctx* ctx, int split, const uint8_t* d_orig, int ow, 
  * frames[i] -> canvases[i]: canvas_w x canvas_h x 3 bytes (lvm_export_geometry), row stride canvas_stride.  Only the ROI rows of
  * the inputs and the canvases cross PCIe, in both directions at once: the frames go through in sub-batches of 8 (each ONE temporal
  * batch of the magnifier, lvm_process_device_frames), sub-batch k + 1 uploading and sub-batch k - 1 downloading while sub-batch k is
- * magnified and composed on the device (lvm_compose_device).  The text overlay (Exporter.cpp:36-50) and cv::VideoWriter::write (:259) stay on
- * the host: host/HipExportRunner.hpp is the reference-side loop around this call.  Synchronous.                               */
+ * magnified and composed on the device (lvm_compose_device), the labels of lvm_export_set_overlay applied there too.
+ * cv::VideoWriter::write (:259) stays on the host: host/HipExportRunner.hpp is the reference-side loop around this call.  Synchronous. */
 int  lvm_export_geometry(const lvm_preprocess_params* pp, int split, int w, int h, int channels, int* canvas_w, int* canvas_h);
 int  lvm_export_frames(lvm_ctx* ctx, const lvm_preprocess_params* pp, const lvm_params* p, int split, int n_frames,
                        const uint8_t* const* frames, int w, int h, int channels, ptrdiff_t in_stride,

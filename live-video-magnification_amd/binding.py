@@ -79,6 +79,12 @@ class LvmParams(C.Structure):
                 ("preprocess_key", C.c_uint64)]
 
 
+class LvmOverlayLabel(C.Structure):
+    """lvm_overlay_label (include/lvm_hip.h): one caption of the export's text overlay as per-pixel tables"""
+    _fields_ = [("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32), ("n_classes", C.c_int32),
+                ("cls", C.c_void_p), ("fn", C.c_void_p)]
+
+
 class LvmPreprocessParams(C.Structure):
     """lvm_preprocess_params (include/lvm_hip.h): PreprocessParams + ProcessorConfig::grayscale."""
     _fields_ = [("downscale", C.c_int32), ("roi_enabled", C.c_int32), ("roiX", C.c_float), ("roiY", C.c_float),
@@ -97,7 +103,7 @@ class LvmError(RuntimeError):
 SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process_device", "lvm_process_device_frames", "lvm_set_pipeline", "lvm_flush", "lvm_synchronize",
            "lvm_last_error", "lvm_max_levels", "lvm_optimal_buffer_size", "lvm_butterworth2",
            "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_debug_sweep_u8_steps", "lvm_debug_clock_probe_start", "lvm_debug_clock_probe_stop", "lvm_debug_lab_analytic", "lvm_get_lab_lut", "lvm_set_lab_lut", "lvm_profile_enable", "lvm_profile_collect", "lvm_profile_only",
-           "lvm_profile_entry", "lvm_algorithmic_bytes", "lvm_export_geometry", "lvm_export_frames",
+           "lvm_profile_entry", "lvm_algorithmic_bytes", "lvm_export_geometry", "lvm_export_frames", "lvm_export_set_overlay", "lvm_overlay_device",
            "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process", "lvm_chain_process_batch",
            "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free", "lvm_compose_geometry", "lvm_compose_device", "lvm_chain_process_batch_ex",
            "lvm_chain_present", "lvm_mjpeg_bound", "lvm_mjpeg_encode_device", "lvm_export_frames_mjpeg", "lvm_mjpeg_decode_device", "lvm_export_mjpeg_frames", "lvm_mjpeg_set_restart_interval"]
@@ -170,6 +176,8 @@ def bind(lib):
     lib.lvm_compose_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, C.c_int, C.c_int, C.c_int,
                                        C.c_ssize_t, C.c_ssize_t, vp, C.c_ssize_t, C.c_ssize_t, vp]
     lib.lvm_set_max_frames.argtypes = [vp, C.c_int]
+    lib.lvm_export_set_overlay.argtypes = [vp, C.c_int, C.POINTER(LvmOverlayLabel)]
+    lib.lvm_overlay_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int, vp]
     lib.lvm_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
     lib.lvm_host_free.argtypes = [vp]
     lib.lvm_host_free.restype = None
@@ -323,6 +331,25 @@ class Context:
         self._check(self.lib.lvm_export_frames(self.h, C.byref(cpre), C.byref(cparams), int(split), len(frames), pin, w, h, ch, w * ch,
                                                pout, cw.value * 3, produced))
         return canvases, [bool(x) for x in produced]
+
+    def export_set_overlay(self, labels):
+        """lvm_export_set_overlay: labels = [(x, y, cls uint16 [h][w], fn uint8 [n_classes][256]), ...] (at most 4; [] switches the overlay
+        off).  The tables are copied into device memory; every later export call of this context applies them to its canvases."""
+        arr = (LvmOverlayLabel * max(len(labels), 1))()
+        keep = []
+        for i, (x, y, cls, fn) in enumerate(labels):
+            cls = np.ascontiguousarray(cls, dtype=np.uint16)
+            fn = np.ascontiguousarray(fn, dtype=np.uint8)
+            assert cls.ndim == 2 and fn.ndim == 2 and fn.shape[1] == 256
+            keep += [cls, fn]
+            arr[i] = LvmOverlayLabel(int(x), int(y), cls.shape[1], cls.shape[0], fn.shape[0], cls.ctypes.data, fn.ctypes.data)
+        self._check(self.lib.lvm_export_set_overlay(self.h, len(labels), arr))
+
+    def overlay_device(self, d_ptr, cw, chh, n_frames=1, stride=None, frame_stride=None, stream=0):
+        """lvm_overlay_device: the labels onto device-resident canvases (address)."""
+        stride = cw * 3 if stride is None else stride
+        frame_stride = stride * chh if frame_stride is None else frame_stride
+        self._check(self.lib.lvm_overlay_device(self.h, d_ptr, cw, chh, stride, frame_stride, n_frames, stream))
 
     def mjpeg_encode_device(self, d_ptr, w, h, n_frames, quality=75, stride=None, frame_stride=None, capacity=None):
         """lvm_mjpeg_encode_device: device-resident BGR frames (address) -> list of JPEG frames (bytes)."""

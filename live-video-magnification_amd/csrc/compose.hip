@@ -5,8 +5,15 @@
 // size, and written next to each other (LeftRight), above each other (TopBottom) or alone (None) into one BGR canvas.
 // Inputs are the magnifier's device output and the device copy of the original, so an export that encodes on the
 // device -- or downloads ONE canvas instead of two frames -- needs no second PCIe crossing of the original.
-// Byte work, bit-exact against the oracle.  The text overlay (cv::putText with anti-aliased Hershey strokes,
-// Exporter.cpp:36-50) is not restated: a caller that wants labels draws them on the downloaded canvas as before.
+// Byte work, bit-exact against the oracle.
+//
+// The text overlay (drawLabel, Exporter.cpp:36-50: addWeighted(roi, 0.35, black, 0.65) + cv::putText(LINE_AA, white)) is NOT restated
+// -- OpenCV's anti-aliased Hershey strokes are not something to reproduce from memory -- and need not be: both steps read-modify-write
+// single pixels, so what a label does to a canvas pixel is a FUNCTION OF THAT PIXEL'S BYTE, the same for B, G and R (white on black),
+// fixed for the whole export (the label depends on the canvas size only).  Round 6: the reference-side shim renders the label once per
+// export with the reference's own calls onto 256 constant canvases, which yields that function for every pixel of the label's rectangle
+// exactly, whatever the OpenCV build does; pixels with the same function share a class.  k_overlay_labels applies the tables to the
+// composed canvases where they lie: exact by construction, and an export with `textOverlay` stays on the device (and on the MJPEG path).
 #include "lvm_internal.h"
 
 namespace lvm {
@@ -45,6 +52,78 @@ __global__ __launch_bounds__(256) void k_compose(ComposeArgs a) {
     } else {
         for (int k = 0; k < 3 * n; ++k) q[k] = v[k];
     }
+}
+
+// ---- the text overlay as per-pixel tables (lvm_export_set_overlay) ----------------------------------------------------------------
+constexpr int kMaxOverlayLabels = 4;
+struct OverlayArgs {
+    int n; int x[kMaxOverlayLabels], y[kMaxOverlayLabels], w[kMaxOverlayLabels], h[kMaxOverlayLabels];
+    int first[kMaxOverlayLabels + 1];                   // prefix sums of w * h: thread index -> label
+    const uint16_t* cls[kMaxOverlayLabels]; const uint8_t* fn[kMaxOverlayLabels];
+    uint8_t* canvas; long stride, fstride;
+};
+// one thread per label pixel, blockIdx.y = frame: the three bytes of the pixel through the pixel's table
+__global__ __launch_bounds__(256) void k_overlay_labels(OverlayArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.first[a.n]) return;
+    int l = 0;
+    while (l + 1 < a.n && i >= a.first[l + 1]) ++l;
+    const int k = i - a.first[l], ly = k / a.w[l], lx = k - ly * a.w[l];
+    const uint8_t* f = a.fn[l] + (size_t)a.cls[l][k] * 256;
+    uint8_t* q = a.canvas + (size_t)blockIdx.y * a.fstride + (size_t)(a.y[l] + ly) * a.stride + (size_t)(a.x[l] + lx) * 3;
+    q[0] = f[q[0]]; q[1] = f[q[1]]; q[2] = f[q[2]];
+}
+
+void overlay_release(Ctx* c) {
+    if (c->d_overlay) (void)hipFree(c->d_overlay);
+    c->d_overlay = nullptr; c->overlay_n = 0;
+}
+
+int overlay_set(Ctx* c, int n, const lvm_overlay_label* labels) {
+    sync_streams(c);                                    // (a running export may still read the old tables)
+    (void)hipStreamSynchronize(c->own_stream);
+    overlay_release(c);
+    if (n == 0) return LVM_OK;
+    if (n < 0 || n > kMaxOverlayLabels || !labels) { c->err = "overlay: 0..4 labels"; return LVM_ERR_INVALID; }
+    size_t total = 0;
+    for (int l = 0; l < n; ++l) {
+        const lvm_overlay_label& L = labels[l];
+        if (L.w < 1 || L.h < 1 || L.x < 0 || L.y < 0 || L.n_classes < 1 || L.n_classes > 65536 || !L.cls || !L.fn || (long)L.w * L.h > (1L << 24)) { c->err = "overlay: bad label"; return LVM_ERR_INVALID; }
+        for (long k = 0; k < (long)L.w * L.h; ++k) if (L.cls[k] >= L.n_classes) { c->err = "overlay: class index outside the label's tables"; return LVM_ERR_INVALID; }
+        total += (((size_t)L.w * L.h * 2 + 255) & ~(size_t)255) + (size_t)L.n_classes * 256;
+    }
+    std::vector<uint8_t> host(total);
+    LVM_HIP_TRY(c, hipMalloc((void**)&c->d_overlay, total));
+    size_t off = 0;
+    for (int l = 0; l < n; ++l) {
+        const lvm_overlay_label& L = labels[l];
+        c->ov_x[l] = L.x; c->ov_y[l] = L.y; c->ov_w[l] = L.w; c->ov_h[l] = L.h;
+        c->ov_cls[l] = off; std::memcpy(host.data() + off, L.cls, (size_t)L.w * L.h * 2); off += ((size_t)L.w * L.h * 2 + 255) & ~(size_t)255;
+        c->ov_fn[l] = off; std::memcpy(host.data() + off, L.fn, (size_t)L.n_classes * 256); off += (size_t)L.n_classes * 256;
+    }
+    if (hipMemcpy(c->d_overlay, host.data(), total, hipMemcpyHostToDevice) != hipSuccess) { overlay_release(c); c->err = "overlay: upload failed"; return LVM_ERR_HIP; }
+    c->overlay_n = n;
+    return LVM_OK;
+}
+
+// the labels onto n_frames canvases of cw x chh (nothing to do without labels)
+int overlay_device(Ctx* c, uint8_t* d_canvas, int cw, int chh, ptrdiff_t stride, ptrdiff_t fstride, int n_frames, hipStream_t s) {
+    if (c->overlay_n == 0 || n_frames < 1) return LVM_OK;
+    if (!d_canvas || stride < (ptrdiff_t)cw * 3 || (n_frames > 1 && fstride < (ptrdiff_t)chh * stride)) { c->err = "overlay: bad canvas arguments"; return LVM_ERR_INVALID; }
+    OverlayArgs a{};
+    a.n = c->overlay_n; a.first[0] = 0;
+    for (int l = 0; l < a.n; ++l) {
+        // drawLabel clips its rectangle to the canvas BEFORE it draws (Exporter.cpp:44): the tables describe the clipped rectangle of ONE
+        // canvas size -- a label that does not fit this canvas was rendered for another geometry
+        if (c->ov_x[l] + c->ov_w[l] > cw || c->ov_y[l] + c->ov_h[l] > chh) { c->err = "overlay: a label lies outside the canvas (rendered for another canvas size?)"; return LVM_ERR_INVALID; }
+        a.x[l] = c->ov_x[l]; a.y[l] = c->ov_y[l]; a.w[l] = c->ov_w[l]; a.h[l] = c->ov_h[l];
+        a.first[l + 1] = a.first[l] + a.w[l] * a.h[l];
+        a.cls[l] = reinterpret_cast<const uint16_t*>(c->d_overlay + c->ov_cls[l]); a.fn[l] = c->d_overlay + c->ov_fn[l];
+    }
+    a.canvas = d_canvas; a.stride = (long)stride; a.fstride = (long)fstride;
+    LVM_LAUNCH(c, "overlay", k_overlay_labels, dim3((unsigned)((a.first[a.n] + 255) / 256), (unsigned)n_frames), dim3(256), s, a);
+    LVM_HIP_TRY(c, hipGetLastError());
+    return LVM_OK;
 }
 
 // Exporter.cpp:55-66: canvas size and pane size for the two frame sizes

@@ -224,6 +224,7 @@ void lvm_destroy(lvm_ctx* c) {
     if (c->d_gamma_u8) (void)hipFree(c->d_gamma_u8);
     if (c->d_invgamma) (void)hipFree(c->d_invgamma);
     if (c->d_u8steps) (void)hipFree(c->d_u8steps);
+    lvm::overlay_release(c);
     if (c->probe_running) { double m = 0; (void)lvm::clock_probe_stop(c, &m, nullptr); }
     if (c->h_probe) (void)hipHostFree(c->h_probe);
     if (c->d_lab_ab) (void)hipFree(c->d_lab_ab);
@@ -362,6 +363,21 @@ int lvm_compose_device(lvm_ctx* c, int split, const uint8_t* d_orig, int ow, int
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     const int rc = lvm::compose_device(c, split, d_orig, ow, oh, och, orig_stride, orig_stream_stride, d_proc, pw, ph, pch, proc_stride,
                                        proc_stream_stride, d_canvas, canvas_stride, canvas_stream_stride, s);
+    lvm::mark_enqueued(c, s);
+    return rc;
+}
+
+int lvm_export_set_overlay(lvm_ctx* c, int n_labels, const lvm_overlay_label* labels) {
+    if (!c) return LVM_ERR_INVALID;
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    return lvm::overlay_set(c, n_labels, labels);
+}
+
+int lvm_overlay_device(lvm_ctx* c, uint8_t* d_canvas, int canvas_w, int canvas_h, ptrdiff_t canvas_stride, ptrdiff_t frame_stride, int n_frames, void* hip_stream) {
+    if (!c) return LVM_ERR_INVALID;
+    LVM_HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    const int rc = lvm::overlay_device(c, d_canvas, canvas_w, canvas_h, canvas_stride, frame_stride, n_frames, s);
     lvm::mark_enqueued(c, s);
     return rc;
 }
@@ -640,6 +656,9 @@ static int export_frames_impl(lvm_ctx* c, const lvm_preprocess_params* pp, const
                                      (ptrdiff_t)can_row, (ptrdiff_t)can_bytes, s);
             if (rc != LVM_OK) { drain(); return rc; }
         }
+        // drawLabel on every canvas of the sub-batch (Exporter.cpp:74-77, :82-85), from the tables of lvm_export_set_overlay
+        rc = lvm::overlay_device(c, c->d_canvas + (size_t)f0 * can_bytes, cw, chh, (ptrdiff_t)can_row, (ptrdiff_t)can_bytes, nf, s);
+        if (rc != LVM_OK) { drain(); return rc; }
         LVM_EXPORT_TRY(hipEventRecord(c->ev_done[q], s));
         LVM_EXPORT_TRY(hipStreamWaitEvent(c->down_stream, c->ev_done[q], 0));
         if (mj) {       // stage 3 stays on the device (down_stream, next to the magnifier of the following sub-batch): the canvases become JPEG

@@ -429,6 +429,8 @@ struct Ctx {
     float* d_gamma_u8 = nullptr;
     float* d_invgamma = nullptr;
     uint2* d_u8steps = nullptr;
+    // the export's text overlay as per-pixel tables (compose.hip, lvm_export_set_overlay): one device block, per label the offsets of its classes / tables
+    uint8_t* d_overlay = nullptr; int overlay_n = 0; int ov_x[4] = {}, ov_y[4] = {}, ov_w[4] = {}, ov_h[4] = {}; size_t ov_cls[4] = {}, ov_fn[4] = {};
     unsigned long long* h_probe = nullptr; bool probe_running = false;      // lvm_debug_clock_probe_* (page-locked: cycles, ticks, stop flag)
     LabCoef lab{};
     // per-mode state (allocated for the tracked geometry)
@@ -535,6 +537,9 @@ int mjpeg_decode_device(Ctx* c, const uint8_t* jpegs, const size_t* offsets, int
 int mjpeg_drain(Ctx* c, uint8_t* out_host, size_t upto_call);
 void mjpeg_abort(Ctx* c);   // error paths: waits for the downloads mjpeg_drain has queued
 int mjpeg_finish(Ctx* c, size_t total_frames, uint8_t* out_host, size_t* offsets, hipStream_t s);
+int overlay_set(Ctx* c, int n, const lvm_overlay_label* labels);
+int overlay_device(Ctx* c, uint8_t* d_canvas, int cw, int chh, ptrdiff_t stride, ptrdiff_t fstride, int n_frames, hipStream_t s);
+void overlay_release(Ctx* c);
 int compose_device(Ctx* c, int split, const uint8_t* d_orig, int ow, int oh, int och, ptrdiff_t ostride, ptrdiff_t osstride,
                    const uint8_t* d_proc, int pw, int ph, int pch, ptrdiff_t pstride, ptrdiff_t psstride, uint8_t* d_canvas,
                    ptrdiff_t cstride, ptrdiff_t csstride, hipStream_t s);

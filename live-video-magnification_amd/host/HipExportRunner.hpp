@@ -17,8 +17,11 @@
 //                                                                 only ROI rows go up, only canvases come down
 //     if (preview_) preview_->publish({cur, original})(:235-240) preview: the canvas of the LAST frame of the batch (latest wins)
 //     open the writer on the first canvas            (:245-258)   the same, through the traits (first canvas of the run)
-//     writer.write(canvas); framesDone_++            (:259-260)   per canvas, in order; the text overlay (:36-50) is drawn by
-//   }                                                             the traits on the host canvas before it is written
+//     writer.write(canvas); framesDone_++            (:259-260)   per canvas, in order.  The text overlay (:36-50): with
+//   }                                                             set_canvas_drawer() the reference's own label code is turned into
+//                                                                 per-pixel tables once per geometry (HipExportOverlay.hpp) and applied
+//                                                                 on the device -- also on the Motion-JPEG path; without it the traits
+//                                                                 draw on the host canvas before it is written, as before round 6
 //
 // Frames stay strictly in order (the temporal filters are stateful, Exporter.hpp:18-20); a batch is n consecutive frames, so the
 // results are those of the frame-by-frame loop (tests/test_export.py::test_export_runner_*: canvases byte-equal to runChainOnce + compose of
@@ -34,6 +37,7 @@
 #include <vector>
 
 #include "lvm.hpp"
+#include "HipExportOverlay.hpp"
 
 namespace lvm {
 
@@ -70,6 +74,10 @@ public:
         return run_impl<true>(src, sink, pre, mag, split, capture_fps, quality);
     }
     int batch() const { return batch_; }
+    // request.textOverlay (ExportTypes.hpp:22): `draw` = the reference's label code for one canvas (what compose does for overlay == true,
+    // Exporter.cpp:74-77 / :82-85).  It is run on constant canvases whenever the canvas geometry is (re)established and never on a frame:
+    // the device applies the resulting tables (lvm_export_set_overlay).  An empty function switches the overlay off.
+    void set_canvas_drawer(CanvasDrawer draw) { drawer_ = std::move(draw); overlay_dirty_ = true; }
 
 private:
     template <bool MJPEG>
@@ -104,7 +112,7 @@ private:
         }
         return written;
     }
-    bool slots_ready(const typename T::View& v) const { return in_ && v.w == w_ && v.h == h_ && v.channels == ch_; }
+    bool slots_ready(const typename T::View& v) const { return in_ && !overlay_dirty_ && v.w == w_ && v.h == h_ && v.channels == ch_; }
     static bool canvas_empty(const typename T::View& v, const lvm_preprocess_params& pre, int split) {
         int cw = 0, ch = 0;
         return lvm_export_geometry(&pre, split, v.w, v.h, v.channels, &cw, &ch) != LVM_OK || cw <= 0 || ch <= 0;
@@ -127,6 +135,9 @@ private:
         if (lvm_export_geometry(&pre, split, w_, h_, ch_, &cw_, &chh_) != LVM_OK || cw_ <= 0 || chh_ <= 0)
             throw Error(LVM_ERR_INVALID, "export: empty canvas for this geometry");
         frame_bytes_ = (std::size_t)w_ * h_ * ch_; canvas_bytes_ = (std::size_t)cw_ * chh_ * 3;
+        if (drawer_) set_overlay(mag_.handle(), overlay_tables(cw_, chh_, drawer_));        // the labels of THIS canvas size
+        else if (overlay_dirty_) set_overlay(mag_.handle(), {});
+        overlay_dirty_ = false;
         void* a = nullptr; void* b = nullptr;
         if (lvm_host_alloc(frame_bytes_ * batch_, &a) != LVM_OK || lvm_host_alloc(canvas_bytes_ * batch_, &b) != LVM_OK) {
             if (a) lvm_host_free(a);
@@ -176,6 +187,7 @@ private:
     std::uint8_t *in_ = nullptr, *out_ = nullptr;
     std::vector<std::uint64_t> seqs_;
     std::vector<std::uint8_t> carry_; bool has_carry_ = false; int cw0_ = 0, ch0_ = 0, cc0_ = 0;
+    CanvasDrawer drawer_; bool overlay_dirty_ = false;
 };
 
 }  // namespace lvm
@@ -225,6 +237,15 @@ struct LivimExportTraits {
     static bool aborted(const Sink& k) { return k.abort && k.abort->load(std::memory_order_acquire); }
 };
 using HipExportLoop = lvm::ExportRunner<LivimExportTraits>;
+
+// request.textOverlay: the reference's label code (drawLabel twice, as compose does it; INTEGRATION.md section 5 moves those lines into
+// `drawLabels(cv::Mat&, SplitMode)`) as the runner's canvas drawer -- a cv::Mat view around the raw canvas, nothing else
+inline lvm::CanvasDrawer export_canvas_drawer(std::function<void(cv::Mat& canvas)> draw_labels) {
+    return [draw_labels](std::uint8_t* canvas, int cw, int ch, std::ptrdiff_t stride) {
+        cv::Mat m(ch, cw, CV_8UC3, canvas, static_cast<size_t>(stride));
+        draw_labels(m);
+    };
+}
 
 // ProcessorConfig / SplitMode -> the C structs (the same mapping HipProcessingStages.hpp uses)
 inline lvm_preprocess_params export_pre_params(const ProcessorConfig& cfg) {

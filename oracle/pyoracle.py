@@ -357,6 +357,40 @@ def bgr2gray_u8(a):
     return out
 
 
+def apply_overlay(canvas, labels):
+    """What the tables of lvm_export_set_overlay say a label does to a canvas (the reference: drawLabel, export/Exporter.cpp:36-50, whose
+    effect on a pixel is a function of that pixel's byte): labels = [(x, y, cls [h][w], fn [n_classes][256]), ...]; returns a new canvas."""
+    out = np.array(canvas, dtype=np.uint8, copy=True)
+    for x, y, cls, fn in labels:
+        cls = np.asarray(cls); fn = np.asarray(fn, dtype=np.uint8)
+        h, w = cls.shape
+        region = out[y:y + h, x:x + w]
+        region[...] = fn[cls[:, :, None].astype(np.int64), region.astype(np.int64)]
+    return out
+
+
+def standin_label_tables(text_w, text_h, pad, x, y, canvas_w, canvas_h, seed=0):
+    """A STAND-IN for the reference-side renderer (INTEGRATION.md section 5 renders the real tables with cv::getTextSize / addWeighted /
+    putText, none of which exists in this image): a rectangle of drawLabel's geometry (Exporter.cpp:41-44: text size + 2 pad, clipped to the
+    canvas), darkened by the binary32 product v * 0.35f rounded half to even, with synthetic "strokes" of 255 coverage levels blended as
+    d + ((255 - d) * a + 127 >> 8).  Only the PLUMBING is under test with it (tables -> device -> canvas == apply_overlay); whether the
+    tables equal OpenCV's drawing is the renderer's business, and it reads them off OpenCV itself."""
+    w = min(text_w + 2 * pad, canvas_w - x); h = min(text_h + 2 * pad, canvas_h - y)
+    assert w > 0 and h > 0
+    rng = np.random.default_rng(seed)
+    v = np.arange(256, dtype=np.float32)
+    dark = np.clip(np.rint(v * np.float32(0.35)), 0, 255).astype(np.int64)               # np.rint: half to even, like cvRound
+    cov = np.zeros((h, w), np.int64)
+    for k in range(6):                                                                   # a few anti-aliased "strokes"
+        cx = rng.integers(pad, max(pad + 1, w - pad)); yy = np.arange(h)[:, None]; xx = np.arange(w)[None, :]
+        d = np.abs(xx - cx - 0.37 * (yy - h / 2))
+        cov = np.maximum(cov, np.clip(np.rint(255 * (1.6 - d)), 0, 255).astype(np.int64) * ((yy >= pad) & (yy < h - pad)))
+    levels = np.unique(cov)
+    cls = np.searchsorted(levels, cov).astype(np.uint16)
+    fn = np.stack([np.clip(dark + (((255 - dark) * int(a) + 127) >> 8), 0, 255) for a in levels]).astype(np.uint8)
+    return (x, y, cls, fn)
+
+
 def compose(split, orig, proc):
     """Exporter::compose (export/Exporter.cpp:53-88, no text overlay): returns the BGR canvas or None (empty Mat)."""
     proc = np.ascontiguousarray(proc, dtype=np.uint8)

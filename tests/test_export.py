@@ -68,6 +68,77 @@ def test_export_frames_emu_bit_exact(lvm, po, emu, cfg, size, pre, split, batche
     _check(lvm, po, emu, cfg, size, pre, split, batches, True)
 
 
+def _check_overlay(lvm, po, lib, size, pre, split, nb, exact, mjpeg_quality=None):
+    """lvm_export_set_overlay (round 6): the export's captions (drawLabel, Exporter.cpp:36-50, :74-77 / :82-85) as per-pixel tables, applied to
+    the composed canvases on the device.  Tables here = the stand-in renderer of oracle/pyoracle.py (no OpenCV in the image; the real ones are
+    read off cv::putText by the shim of INTEGRATION.md section 5): canvases with labels == po.apply_overlay(canvases without labels) byte for
+    byte, also through the Motion-JPEG sink (the frames the device encodes == the oracle encoder on the overlaid canvas)."""
+    ck, pk = lvm.synth.config(0, size)
+    clip = lvm.synth.Clip(**ck)
+    cpre, opre = _pre(lvm, po, *pre)
+    frames = [clip.frame(t) for t in range(nb)]
+    a, b = lvm.Context(0, 1, lib), lvm.Context(0, 1, lib)
+    a.exact_lab(exact); b.exact_lab(exact)
+    try:
+        plain, prod_a = a.export_frames(frames, cpre, c_params(lvm, pk), split)
+        chh, cw = plain[0].shape[:2]
+        pane_w = cw // 2 if split == LR else cw
+        pane_h = chh // 2 if split == TB else chh
+        scale = min(max(pane_w / 800.0, 0.4), 1.5)                                       # Exporter.cpp:69
+        pad = max(2, int(round(scale * 4)))
+        tw, th = int(round(150 * scale)), int(round(30 * scale))
+        second = (pane_w + 6, 6) if split == LR else (6, pane_h + 6)                      # :75-76 / :83-84
+        labels = [po.standin_label_tables(tw, th, pad, 6, 6, cw, chh, seed=1), po.standin_label_tables(tw + 11, th, pad, second[0], second[1], cw, chh, seed=2)]
+        b.export_set_overlay(labels)
+        got, prod_b = b.export_frames(frames, cpre, c_params(lvm, pk), split)
+        assert prod_a == prod_b
+        for k in range(nb):
+            want = po.apply_overlay(plain[k], labels)
+            assert not np.array_equal(want, plain[k])
+            assert np.array_equal(got[k], want), "frame %d" % k
+        if mjpeg_quality:
+            from oracle import mjpeg_oracle as mo
+            b.reset()
+            js, _ = b.export_frames_mjpeg(frames, cpre, c_params(lvm, pk), split, mjpeg_quality)
+            for k in range(nb):
+                assert js[k] == mo.encode_frame(po.apply_overlay(plain[k], labels), mjpeg_quality), "JPEG frame %d" % k
+        # switched off again: the plain canvases; a label rendered for a larger canvas fails the call with a message
+        b.reset()
+        b.export_set_overlay([])
+        again, _ = b.export_frames(frames, cpre, c_params(lvm, pk), split)
+        assert all(np.array_equal(x, y) for x, y in zip(again, plain))
+        b.export_set_overlay([po.standin_label_tables(tw, th, pad, cw - 8, 6, cw + 400, chh, seed=3)])
+        with pytest.raises(lvm.LvmError, match="outside the canvas"):
+            b.export_frames(frames, cpre, c_params(lvm, pk), split)
+    finally:
+        a.close(); b.close()
+
+
+@pytest.mark.parametrize("size,pre,split,nb", [((256, 96, 3), (1, None, False), LR, 5), ((128, 128, 2), (2, None, True), TB, 3)])
+def test_export_overlay_tables_emu(lvm, po, emu, size, pre, split, nb):
+    _check_overlay(lvm, po, emu, size, pre, split, nb, True, mjpeg_quality=85)
+
+
+def test_export_overlay_rejects_bad_tables(lvm, po, emu):
+    ctx = lvm.Context(0, 1, emu)
+    try:
+        x, y, cls, fn = po.standin_label_tables(60, 12, 2, 6, 6, 200, 100)
+        bad = cls.copy(); bad[0, 0] = fn.shape[0]                       # a class without a table
+        with pytest.raises(lvm.LvmError, match="class index"):
+            ctx.export_set_overlay([(x, y, bad, fn)])
+        with pytest.raises(lvm.LvmError):
+            ctx.export_set_overlay([(x, y, cls, fn)] * 5)               # more than four labels
+        with pytest.raises(lvm.LvmError):
+            ctx.export_set_overlay([(-1, y, cls, fn)])
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_export_overlay_tables_gpu(lvm, po, hip):
+    _check_overlay(lvm, po, hip, (1920, 1080, 6), (1, None, False), LR, 9, False, mjpeg_quality=85)
+
+
 def test_export_frames_rejects_bad_arguments(lvm, po, emu):
     cpre, _ = _pre(lvm, po, 1, None, False)
     ck, pk = lvm.synth.config(0, (64, 48, 2))
@@ -94,6 +165,7 @@ def test_export_frames_gpu(lvm, po, hip, cfg, size, pre, split, batches):
 
 
 RUNNER_SRC = r'''
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -196,6 +268,47 @@ int main(int argc, char** argv) {
             for (const auto& cv : raw.canvases) std::fwrite(cv.data(), 1, cv.size(), f);
             std::fclose(f);
             std::printf("canvas %d %d %zu\n", raw.cw, raw.ch, raw.canvases.size());
+        }
+        // (4) request.textOverlay (round 6): a drawer of drawLabel's kind -- darken a rectangle, blend anti-aliased "strokes" into it, per pixel and
+        //     equally for B, G, R -- handed to the runner: the canvases it delivers == the plain canvases with the drawer run ON THEM on the host
+        //     (the tables are read off constant canvases, HipExportOverlay.hpp; the device applies them).  Top / bottom panes: two labels in one column run.
+        {
+            auto label = [](std::uint8_t* cv, int cw, int ch, std::ptrdiff_t stride, int x0, int y0, int w, int h, int seed) {
+                for (int y = y0; y < y0 + h && y < ch; ++y)
+                    for (int x = x0; x < x0 + w && x < cw; ++x)
+                        for (int c = 0; c < 3; ++c) {
+                            std::uint8_t& p = cv[(size_t)y * stride + (size_t)x * 3 + c];
+                            int d = (int)std::lrintf((float)p * 0.35f);                                            // addWeighted(roi, 0.35, black, 0.65)
+                            const int a = ((x * 5 + y * (3 + seed)) % 11 == 0) ? 255 : (((x + y * seed) % 7 == 0) ? 90 + 13 * ((x + y) % 9) : 0);   // "stroke" coverage
+                            d += ((255 - d) * a + 127) >> 8;
+                            p = (std::uint8_t)d;
+                        }
+            };
+            const int oh = H / 2;
+            lvm::CanvasDrawer draw = [&](std::uint8_t* cv, int cw, int ch, std::ptrdiff_t stride) {
+                label(cv, cw, ch, stride, 6, 6, 31, 9, 1);
+                label(cv, cw, ch, stride, 6, oh + 6, 37, 9, 2);
+            };
+            lvm::ExportRunner<MockTraits> plain(0, 4), labelled(0, 4);
+            labelled.set_canvas_drawer(draw);
+            MockTraits::Source s1{W, H, N, 0, -1, -1, {}}, s2{W, H, N, 0, -1, -1, {}};
+            MockTraits::Sink k1, k2;
+            plain.run(s1, k1, pre, mag, LVM_SPLIT_TOP_BOTTOM, 25.0);
+            labelled.run(s2, k2, pre, mag, LVM_SPLIT_TOP_BOTTOM, 25.0);
+            if (k1.canvases.size() != (size_t)N || k2.canvases.size() != (size_t)N) { std::printf("case 4: %zu / %zu canvases\n", k1.canvases.size(), k2.canvases.size()); ++bad; }
+            size_t changed = 0;
+            for (size_t k = 0; k < k1.canvases.size() && k < k2.canvases.size(); ++k) {
+                std::vector<std::uint8_t> want = k1.canvases[k];
+                draw(want.data(), k1.cw, k1.ch, (std::ptrdiff_t)k1.cw * 3);
+                if (want != k2.canvases[k]) { std::printf("case 4: canvas %zu differs from the drawer run on the host\n", k); ++bad; }
+                if (want != k1.canvases[k]) ++changed;
+            }
+            if (changed != k1.canvases.size()) { std::printf("case 4: the drawer changed %zu canvases\n", changed); ++bad; }
+            // a drawer that reads its neighbours is refused (the tables could not be exact)
+            lvm::CanvasDrawer blur = [](std::uint8_t* cv, int cw, int, std::ptrdiff_t stride) { for (int x = 8; x < 20 && x + 1 < cw; ++x) for (int c = 0; c < 3; ++c) cv[(size_t)7 * stride + x * 3 + c] = (std::uint8_t)((cv[(size_t)7 * stride + x * 3 + c] + cv[(size_t)7 * stride + (x + 1) * 3 + c]) / 2 + 1); };
+            bool refused = false;
+            try { (void)lvm::overlay_tables(48, 32, blur); } catch (const lvm::Error&) { refused = true; }
+            if (!refused) { std::printf("case 4: a neighbour-reading drawer was accepted\n"); ++bad; }
         }
         std::printf("bad=%d\n", bad);
         return bad ? 4 : 0;

@@ -93,6 +93,8 @@ int main() {
         sink.write_canvas = [](cv::Mat& canvas) { return canvas.cols == 128 && canvas.rows == 48; };
         LivimExportTraits::Source src{&two, cv::Mat()};
         HipExportLoop loop(0, 8);
+        // request.textOverlay: the reference's label code as the loop's canvas drawer (a cv::Mat view around the raw canvas; HipExportOverlay.hpp)
+        loop.set_canvas_drawer(export_canvas_drawer([](cv::Mat& canvas) { if (canvas.rows > 8 && canvas.cols > 40) std::memset(canvas.ptr(6) + 18, 255, 30); }));
         const auto written = loop.run(src, sink, export_pre_params(req.config), export_mag_params(req.config), export_split(req.split), 30.0);
         std::printf("export wrote %llu done %d\n", (unsigned long long)written, done.load());
         // ExportFormat::AviMjpg without the overlay: the canvases arrive as JPEG frames (lvm_export_frames_mjpeg), lvm::MjpegAviWriter is the container
