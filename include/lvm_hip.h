@@ -190,6 +190,28 @@ int  lvm_compose_device(lvm_ctx* ctx, int split, const uint8_t* d_orig, int ow, 
                         int pch, ptrdiff_t proc_stride, ptrdiff_t proc_stream_stride, uint8_t* d_canvas,
                         ptrdiff_t canvas_stride, ptrdiff_t canvas_stream_stride, void* hip_stream);
 
+/* Spatial tiling of ONE Riesz stream over several devices: a CORRECTNESS DEMONSTRATOR, not a throughput path (DESIGN.md section 7:
+ * a frame needs a handful of small exchanges, each a latency, against ~230 us of work on one MI355X -- independent streams, one per GPU, are
+ * the production answer).  The frame is cut into horizontal stripes; rank r runs a stripe context on its rows extended by a halo (tiling.py:
+ * 64 rows for 2 fine levels) with `levels` = F + 1, F = the fine levels it owns entirely:
+ *   lvm_tile_riesz_stage1   Lab, pyramid, phase, temporal filters, normalize + amplify of the stripe (MagnifyCore.hpp:218-267, RieszPyramid.cpp
+ *                           :114-144) -- everything up to the collapse; copies the stripe's residual octave (octave F of the full pyramid,
+ *                           residual_w x residual_h floats) to d_residual_out.  The owned rows of it go to the rank that holds the coarse levels
+ *                           (RCCL send / hipMemcpyPeer: the caller's exchange).
+ *   lvm_tile_riesz_planes   that rank: the Riesz chain on a FLOAT PLANE -- the gathered octave F as level 0 of a pyramid with the remaining
+ *                           levels -- collapsed back into a float plane: res_F of the full pyramid (RieszPyramid.cpp:304-325).  Rows of it go back.
+ *   lvm_tile_riesz_stage2   collapse of the fine levels from the received rows of res_F instead of the stripe's own residual, Lab2BGR, u8
+ *                           (MagnifyCore.hpp:269-277) for the extended stripe; the owned rows are the result.
+ * Rows closer than the halo to an artificial stripe edge are computed from reflected instead of real neighbours and discarded; with the halo
+ * of tiling.py the owned rows are BIT-IDENTICAL to the unsplit context's (tests/test_tiling.py).  produced follows the per-frame rules (first
+ * frame: 0 -- every rank passes its rows through).  All calls enqueue on hip_stream without synchronising.                          */
+int  lvm_tile_riesz_stage1(lvm_ctx* ctx, const lvm_params* p, const uint8_t* d_in, int w, int h, ptrdiff_t in_stride, int* produced,
+                           float* d_residual_out, int* residual_w, int* residual_h, void* hip_stream);
+int  lvm_tile_riesz_planes(lvm_ctx* ctx, const lvm_params* p, const float* d_plane_in, int w, int h, float* d_plane_out, int* produced,
+                           void* hip_stream);
+int  lvm_tile_riesz_stage2(lvm_ctx* ctx, const lvm_params* p, const uint8_t* d_in, int w, int h, ptrdiff_t in_stride,
+                           const float* d_residual_in, uint8_t* d_out, ptrdiff_t out_stride, void* hip_stream);
+
 /* The export's text overlay (drawLabel, export/Exporter.cpp:36-50: the rectangle behind a caption darkened with
  * cv::addWeighted(roi, 0.35, black, 0.65), then cv::putText(FONT_HERSHEY_SIMPLEX, white, LINE_AA); called from compose, :74-77 / :82-85)
  * as PER-PIXEL TABLES.  Both steps read-modify-write single pixels with the same arithmetic for B, G and R, so what a label does to a

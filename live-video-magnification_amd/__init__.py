@@ -6,7 +6,7 @@ Import with importlib (the directory name contains a hyphen):
 
     lvm = importlib.import_module("live-video-magnification_amd")
 """
-from .binding import (Context, LvmError, LvmParams, LvmPreprocessParams, MagnificationMode, MagnificationParams,  # noqa: F401
+from .binding import (Context, LvmError, LvmOverlayLabel, LvmParams, LvmPreprocessParams, MagnificationMode, MagnificationParams,  # noqa: F401
                       MagnificationProcessor, PreprocessParams, ProcessingChain, ProcessorConfig, bind, load, to_c_params,
                       to_c_preprocess)
-from . import sharding, synth  # noqa: F401
+from . import sharding, synth, tiling  # noqa: F401

@@ -103,7 +103,7 @@ class LvmError(RuntimeError):
 SYMBOLS = ["lvm_create", "lvm_destroy", "lvm_reset", "lvm_process", "lvm_process_device", "lvm_process_device_frames", "lvm_set_pipeline", "lvm_flush", "lvm_synchronize",
            "lvm_last_error", "lvm_max_levels", "lvm_optimal_buffer_size", "lvm_butterworth2",
            "lvm_debug_keep_float", "lvm_debug_read_float", "lvm_debug_exact_lab", "lvm_debug_sweep_u8_steps", "lvm_debug_clock_probe_start", "lvm_debug_clock_probe_stop", "lvm_debug_lab_analytic", "lvm_get_lab_lut", "lvm_set_lab_lut", "lvm_profile_enable", "lvm_profile_collect", "lvm_profile_only",
-           "lvm_profile_entry", "lvm_algorithmic_bytes", "lvm_export_geometry", "lvm_export_frames", "lvm_export_set_overlay", "lvm_overlay_device",
+           "lvm_profile_entry", "lvm_algorithmic_bytes", "lvm_export_geometry", "lvm_export_frames", "lvm_export_set_overlay", "lvm_overlay_device", "lvm_tile_riesz_stage1", "lvm_tile_riesz_planes", "lvm_tile_riesz_stage2",
            "lvm_preprocess_geometry", "lvm_preprocess_device", "lvm_chain_process", "lvm_chain_process_batch",
            "lvm_set_max_frames", "lvm_host_alloc", "lvm_host_free", "lvm_compose_geometry", "lvm_compose_device", "lvm_chain_process_batch_ex",
            "lvm_chain_present", "lvm_mjpeg_bound", "lvm_mjpeg_encode_device", "lvm_export_frames_mjpeg", "lvm_mjpeg_decode_device", "lvm_export_mjpeg_frames", "lvm_mjpeg_set_restart_interval"]
@@ -176,6 +176,9 @@ def bind(lib):
     lib.lvm_compose_device.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, vp, C.c_int, C.c_int, C.c_int,
                                        C.c_ssize_t, C.c_ssize_t, vp, C.c_ssize_t, C.c_ssize_t, vp]
     lib.lvm_set_max_frames.argtypes = [vp, C.c_int]
+    lib.lvm_tile_riesz_stage1.argtypes = [vp, C.POINTER(LvmParams), vp, C.c_int, C.c_int, C.c_ssize_t, ip, vp, ip, ip, vp]
+    lib.lvm_tile_riesz_planes.argtypes = [vp, C.POINTER(LvmParams), vp, C.c_int, C.c_int, vp, ip, vp]
+    lib.lvm_tile_riesz_stage2.argtypes = [vp, C.POINTER(LvmParams), vp, C.c_int, C.c_int, C.c_ssize_t, vp, vp, C.c_ssize_t, vp]
     lib.lvm_export_set_overlay.argtypes = [vp, C.c_int, C.POINTER(LvmOverlayLabel)]
     lib.lvm_overlay_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_ssize_t, C.c_ssize_t, C.c_int, vp]
     lib.lvm_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]

@@ -429,6 +429,9 @@ struct Ctx {
     float* d_gamma_u8 = nullptr;
     float* d_invgamma = nullptr;
     uint2* d_u8steps = nullptr;
+    // spatial tiling demonstrator (lvm_tile_riesz_*): 1 = stripe context, the frame stops after normalize + amplify; 2 = coarse context, the "frame" is a
+    // float plane (tile_plane_in) and the collapse of level 0 goes to tile_plane_out instead of through Lab2BGR
+    int tile_mode = 0; const float* tile_plane_in = nullptr; float* tile_plane_out = nullptr;
     // the export's text overlay as per-pixel tables (compose.hip, lvm_export_set_overlay): one device block, per label the offsets of its classes / tables
     uint8_t* d_overlay = nullptr; int overlay_n = 0; int ov_x[4] = {}, ov_y[4] = {}, ov_w[4] = {}, ov_h[4] = {}; size_t ov_cls[4] = {}, ov_fn[4] = {};
     unsigned long long* h_probe = nullptr; bool probe_running = false;      // lvm_debug_clock_probe_* (page-locked: cycles, ticks, stop flag)
@@ -552,6 +555,8 @@ int laplace_flush(Ctx* c, hipStream_t s);
 int laplace_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int nt, hipStream_t s);
 bool laplace_can_batch(const Ctx* c);
 int riesz_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int nt, hipStream_t s);
+int riesz_tile_residual(Ctx* c, float* d_dst, int* rw, int* rh, hipStream_t s);
+int riesz_tile_finish(Ctx* c, const lvm_params& p, const FrameIO& io, const float* d_residual, hipStream_t s);
 bool riesz_can_batch(const Ctx* c, const lvm_params& p);
 int color_process_frames(Ctx* c, const lvm_params& p, const FrameIO& io, int nt, hipStream_t s);
 bool color_can_batch(const Ctx* c, const lvm_params& p, int nt);

@@ -1601,7 +1601,10 @@ static int strip_rows_by_work(int sx, int h, int NZ) {
 static void rz_build(Ctx* c, RieszState* st, const FrameIO& io, const RzBufs& B, hipStream_t s) {
     const int NZ = c->nstreams * B.nt, w = io.w, h = io.h, nb = st->levels - 1;
     const dim3 blk(256);
-    if (fl_lut(lab_flavour(c))) {
+    if (c->tile_mode == 2) {
+        // spatial tiling, the gathered coarse levels (lvm_tile_riesz_planes): the "frame" IS an octave of another context's pyramid
+        (void)hipMemcpyAsync(B.oct[0], c->tile_plane_in, (size_t)w * h * sizeof(float), hipMemcpyDeviceToDevice, s);
+    } else if (fl_lut(lab_flavour(c))) {
         // OpenCV's forward table, once per frame: the float L plane for the pyramid and (ia, ib) for the output kernel
         lab_lut_planes(c, io.d_in, (long)io.in_stride, (long)io.in_sstride, w, h, NZ, nullptr, B.oct[0], B.iab, s);
     } else if (w % 4 == 0 && io.in_stride % 4 == 0 && io.in_sstride % 4 == 0 && ((uintptr_t)io.d_in % 4) == 0) {
@@ -1676,8 +1679,18 @@ static bool rz_level_uses_strips(const RieszState* st, int l, int NZ) {
 }
 
 // amplify + collapse + output of the nt frames (RieszPyramid.cpp:248-252, 304-325; MagnifyCore.hpp:269-277)
+// rz_finish = rz_amplify (normalize + amplify, RieszPyramid.cpp:114-144) + rz_collapse_out (collapsePyramid :304-325 + the epilogue).  The two
+// halves are separate entry points for the spatial-tiling demonstrator (lvm_tile_riesz_*): a stripe context stops after the first, the
+// collapse then starts from a residual that another context computed.
+static void rz_collapse_out(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO& io, const RzBufs& B, hipStream_t s, const float* residual, float* plane_out);
+static void rz_amplify(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO& io, const RzBufs& B, hipStream_t s);
 static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO& io, const RzBufs& B, hipStream_t s) {
-    const int NZ = c->nstreams * B.nt, w = io.w, h = io.h, levels = st->levels, nb = levels - 1;
+    rz_amplify(c, st, p, io, B, s);
+    if (c->tile_mode == 1) return;                                   // stripe context, stage 1: lvm_tile_riesz_stage2 collapses
+    rz_collapse_out(c, st, p, io, B, s, B.oct[st->levels - 1], c->tile_mode == 2 ? c->tile_plane_out : nullptr);
+}
+static void rz_amplify(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO& io, const RzBufs& B, hipStream_t s) {
+    const int NZ = c->nstreams * B.nt, levels = st->levels, nb = levels - 1;
     const dim3 blk(256);
     if (nb >= 1) {
         BlurArgs a;
@@ -1723,7 +1736,13 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
         if (n4) LVM_LAUNCH(c, as.nlv ? "rz_blur_amp_tiles" : "rz_blur_amp", (lab_flavour(c) != FL_LUT_FAST) ? k_rz_blur_amp4<true> : k_rz_blur_amp4<false>, dim3(blocks4), dim3(B2T), s, a4);
         if (n1) LVM_LAUNCH(c, "rz_blur_amp_small", (lab_flavour(c) != FL_LUT_FAST) ? k_rz_blur_amp<true> : k_rz_blur_amp<false>, dim3(blocks), blk, s, a);
     }
-    const float* resn = B.oct[levels - 1];       // res_{L-1} = residual octave
+}
+// residual = res_{L-1} (the context's own residual octave, or -- tiling -- the collapsed coarse levels of another context);
+// plane_out != null: level 0 is collapsed into this float plane instead of passing through Lab2BGR (tiling, the coarse context)
+static void rz_collapse_out(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO& io, const RzBufs& B, hipStream_t s, const float* residual, float* plane_out) {
+    const int NZ = c->nstreams * B.nt, w = io.w, h = io.h, levels = st->levels, nb = levels - 1;
+    const dim3 blk(256);
+    const float* resn = residual;
     // wave strips (k_rz_collapse_strips) for large launches on planes with even sizes and a width that is a multiple of 4
     auto strips_ok = [&](const LevelGeom& a, const LevelGeom& b) {
         return st->collapse_strips && a.w % 4 == 0 && a.w >= 8 && a.h % 2 == 0 && a.h >= 2 && b.w == a.w / 2 && b.h == a.h / 2 &&
@@ -1736,23 +1755,25 @@ static void rz_finish(Ctx* c, RieszState* st, const lvm_params& p, const FrameIO
         ca.strips_y = (a.h + ca.rows - 1) / ca.rows;
         ca.ntasks = ca.strips_x * ca.strips_y * NZ;
     };
-    for (int l = nb - 1; l >= 1; --l) {
+    for (int l = nb - 1; l >= (plane_out ? 0 : 1); --l) {
         const LevelGeom &a = st->g[l], &b = st->g[l + 1];
+        float* res_l = (l == 0) ? plane_out : B.res[l];
         if (strips_ok(a, b)) {
             CollapseStripArgs ca{};
-            ca.bandA = B.pf[l][F_BANDA]; ca.resn = resn; ca.res = B.res[l];
+            ca.bandA = B.pf[l][F_BANDA]; ca.resn = resn; ca.res = res_l;
             strips_geom(ca, a, b);
             LVM_LAUNCH(c, LName("rz_collapse", l), (k_rz_collapse_strips<false, FL_LUT_FAST, false>),
                        dim3((unsigned)((ca.ntasks + CS_THREADS / 64 - 1) / (CS_THREADS / 64))), dim3(CS_THREADS), s, ca);
-            resn = B.res[l];
+            resn = res_l;
             continue;
         }
         const dim3 grid((a.w + CW - 1) / CW, (a.h + CH - 1) / CH, NZ);
         const bool compact = st->compact && a.w % 2 == 0 && a.h % 2 == 0;
         LVM_LAUNCH(c, LName("rz_collapse", l), compact ? k_rz_collapse<true> : k_rz_collapse<false>, grid, blk, s, (const float*)B.pf[l][F_BANDA], resn,
-                   B.res[l], a.w, a.h, b.w, b.h);
-        resn = B.res[l];
+                   res_l, a.w, a.h, b.w, b.h);
+        resn = res_l;
     }
+    if (plane_out) return;
     const int tx = (w + CW - 1) / CW, ty = (h + CH - 1) / CH;
     const int ntiles = tx * ty * NZ;
     // persistent workgroups (the two Lab tables, 17 KB, are loaded once per workgroup), but many more of them than fit on the
@@ -1846,6 +1867,27 @@ int riesz_process(Ctx* c, const lvm_params& p, int levels, const FrameIO& io, hi
     rz_finish(c, st, p, io, B, s);                                               // :269-277
     LVM_HIP_TRY(c, hipGetLastError());
     *produced = 1;
+    return LVM_OK;
+}
+
+// ---- spatial tiling of one stream (lvm_tile_riesz_*, a correctness demonstrator: SURVEY.md 8e) -------------------------------------------
+// the residual octave of the context's pyramid (octave_{levels-1}): what a stripe context hands to the coarse context
+int riesz_tile_residual(Ctx* c, float* d_dst, int* rw, int* rh, hipStream_t s) {
+    RieszState* st = dynamic_cast<RieszState*>(c->state);
+    if (!st) { c->err = "tiling: no Riesz state"; return LVM_ERR_INVALID; }
+    const LevelGeom& g = st->g[st->levels - 1];
+    if (rw) *rw = g.w;
+    if (rh) *rh = g.h;
+    if (d_dst) LVM_HIP_TRY(c, hipMemcpyAsync(d_dst, st->oct[st->levels - 1], g.n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return LVM_OK;
+}
+// stage 2 of a stripe context: collapse from `d_residual` (the coarse context's result, rows of this stripe) + Lab2BGR + u8
+int riesz_tile_finish(Ctx* c, const lvm_params& p, const FrameIO& io, const float* d_residual, hipStream_t s) {
+    RieszState* st = dynamic_cast<RieszState*>(c->state);
+    if (!st || !st->inited || io.w != st->g[0].w || io.h != st->g[0].h) { c->err = "tiling: stage 2 without a matching stage 1"; return LVM_ERR_INVALID; }
+    const RzBufs B{st->oct, st->res, st->f, 1, st->iab};
+    rz_collapse_out(c, st, p, io, B, s, d_residual, nullptr);
+    LVM_HIP_TRY(c, hipGetLastError());
     return LVM_OK;
 }
 
