@@ -371,6 +371,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=-1, help="frames of the per-kernel timing pass (default: two calls of T frames; 0 = skip)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, one GPU per rank) or gloo (smoke-testing the N > 1 path)")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses cuda:0")
+    ap.add_argument("--no-clock-probe", action="store_true", help="no shader-clock probe beside the timed region (a profiler that serialises kernels would "
+                    "make the timed calls wait for the probe's time-out: tools/pmc.sh passes this)")
     args = ap.parse_args()
     global CLIP_NOISE
     CLIP_NOISE = args.clip_noise
@@ -482,11 +484,12 @@ def main():
                 clock["error"] = str(e)[:120]
 
     def steps(_):
-        try:
-            R.ctx.clock_probe_start(5.0)
-            clock["on"] = True
-        except Exception as e:
-            clock["error"] = str(e)[:120]
+        if not args.no_clock_probe:
+            try:
+                R.ctx.clock_probe_start(2.0)
+                clock["on"] = True
+            except Exception as e:
+                clock["error"] = str(e)[:120]
         R.run(Kf)
 
     dt = lvm.sharding.timed_steps(steps, 1, dist, torch.cuda.synchronize, red_dev, finish=finish)

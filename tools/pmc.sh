@@ -3,7 +3,7 @@
 # Pass 0 is always a plain --kernel-trace --stats run; counter passes never combine with other trace domains.
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; ARGS="$2"; shift 2
 mkdir -p $OUT; cd /tmp; export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-subrecords --profile-steps 0 $ARGS"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-subrecords --no-clock-probe --profile-steps 0 $ARGS"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p0 -o t -- $B > $OUT/p0.log 2>&1
 i=0
 for c in "$@"; do

@@ -2,7 +2,7 @@
 # L2 / fabric-side (TCC_EA) counters of the big kernels against the SAME counters of the streaming microbenchmark at its ceiling:
 # is a kernel waiting for HBM?  Credit stalls (requests held back because the memory side has no credit = saturation), read-request
 # occupancy (LEVEL / RDREQ = average latency in TCC cycles) and L2 hit rate, per kernel.   gpurun -- 'bash tools/tcc_pass.sh'
-O=$GRAFT_REPO_ROOT/gpurun_out/r5_tcc; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+O=$GRAFT_REPO_ROOT/gpurun_out/r6_tcc; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 A="TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum"
 B="TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_RDREQ_LEVEL_sum TCC_CYCLE_sum"
 run() {   # name, command...
@@ -14,7 +14,7 @@ S=$GRAFT_REPO_ROOT/tools/ubench_stream
 run stream_copy $S only 2 16 1 1 8 3 20
 run stream_read $S only 0 16 4 1 8 3 20
 run stream_planes $S only 4 16 1 1 8 4 20
-BN="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-subrecords --profile-steps 0 --steps 128 --warmup 32"
+BN="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-subrecords --no-clock-probe --profile-steps 0 --steps 6 --warmup 2"
 run laplace $BN --mode laplace
 run riesz $BN --mode riesz
 run color $BN --mode color

@@ -126,6 +126,29 @@ __global__ __launch_bounds__(256) void k_fma_ilp(float* out, float a, float b) {
     if (s == 12345.678f) out[0] = s;
 }
 
+// The same v_fma_f32 loop with both counters read around it (round 6): s_memtime ticks with the shader clock, s_memrealtime at 100 MHz.  A wave's
+// elapsed shader cycles / (instructions it issued x waves sharing its SIMD) = issue cycles per wave-instruction WITHOUT assuming a clock, and
+// the ratio of the two counters is the clock the part really ran at under this load.
+__global__ __launch_bounds__(256) void k_fma_clock(float* out, float a, float b, unsigned long long* stamps) {
+    float r[CHAINS];
+#pragma unroll
+    for (int k = 0; k < CHAINS; ++k) r[k] = a * (threadIdx.x + k) + b;
+    const unsigned long long c0 = __builtin_readcyclecounter(), t0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int k = 0; k < CHAINS; ++k) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(r[k]) : "v"(a), "v"(b));
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), t1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < CHAINS; ++k) s += r[k];
+    if (s == 12345.678f) out[0] = s;
+    if ((threadIdx.x & 63) == 0) {
+        const size_t w = ((size_t)blockIdx.x * 256 + threadIdx.x) / 64;
+        stamps[2 * w] = c1 - c0; stamps[2 * w + 1] = t1 - t0;
+    }
+}
+
 typedef void (*kern_t)(float*, float, float);
 struct Entry { const char* name; kern_t k; };
 
@@ -149,6 +172,31 @@ int main() {
         {"v_fma_f64", k_fma64}, {"v_mul_f64", k_mul64}, {"v_add_f64", k_add64},
     };
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    {   // the clock first: every later line quotes "cycles at 2.4 GHz", this block says what a cycle really was under an all-fma load
+        const size_t nw = (size_t)blocks * 4;
+        unsigned long long* d_st; hipMalloc(&d_st, nw * 16);
+        hipLaunchKernelGGL(k_fma_clock, dim3(blocks), dim3(256), 0, 0, d_out, 1.0001f, 0.5f, d_st);
+        hipDeviceSynchronize();
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0, 0);
+            hipLaunchKernelGGL(k_fma_clock, dim3(blocks), dim3(256), 0, 0, d_out, 1.0001f, 0.5f, d_st);
+            hipEventRecord(e1, 0);
+            hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        std::vector<unsigned long long> st(nw * 2);
+        hipMemcpy(st.data(), d_st, nw * 16, hipMemcpyDeviceToHost);
+        double cyc = 0, tick = 0;
+        for (size_t w = 0; w < nw; ++w) { cyc += (double)st[2 * w]; tick += (double)st[2 * w + 1]; }
+        cyc /= nw; tick /= nw;
+        const double mhz = cyc / tick * 100.0, ns = (double)best * 1e6 / (8.0 * ITERS * CHAINS);
+        printf("clock under the all-v_fma_f32 kernel: %.0f MHz (s_memtime / s_memrealtime x 100 MHz, mean over %zu waves); kernel %.3f ms = %.3f ns per "
+               "wave-instruction per SIMD = %.2f shader cycles at that clock; a wave was resident for %.0f %% of the kernel's duration\n",
+               mhz, nw, best, ns, ns * mhz * 1e-3, 100.0 * (tick * 1e-5) / best);
+        hipFree(d_st);
+    }
     double base = 0;
     for (auto& e : es) {
         hipLaunchKernelGGL(e.k, dim3(blocks), dim3(256), 0, 0, d_out, 1.0001f, 0.5f);

@@ -9,8 +9,14 @@ import re
 import sys
 
 SIMDS, GHZ = 1024, 2.4
+args = sys.argv[1:]
+clock_src = "assumed: the part's maximum"
+if len(args) >= 2 and args[0] == "--clock-mhz":          # round 6: the clock bench.py measured over its timed region (lvm_debug_clock_probe_*)
+    GHZ = float(args[1]) / 1000.0
+    clock_src = "measured by bench.py over its timed region: s_memtime / s_memrealtime (clock_mhz of the same refresh run)"
+    args = args[2:]
 out = {}
-for path in sys.argv[1:]:
+for path in args:
     lines = open(path).read().splitlines()
     hdr = lines[0]
     # fixed-width columns: find the column starts of the numeric fields from the header
@@ -22,10 +28,10 @@ for path in sys.argv[1:]:
         kern, calls, avg_us, rest = m.group(1).strip(), int(m.group(2)), float(m.group(3)), m.group(4).split()
         cols = dict(zip(names[3:], rest))
         valu = next((float(v) for k, v in cols.items() if k.endswith("SQ_INSTS_VALU")), None)
-        if valu is None or not kern.startswith("k_") or calls < 50:
+        if valu is None or not kern.startswith("k_") or kern.startswith("k_clock_probe") or calls < 4:
             continue
         lo = valu * 3.0 / SIMDS / (GHZ * 1e3)
         ty = valu * 4.2 / SIMDS / (GHZ * 1e3)
         out[kern] = {"rocprof_avg_us": avg_us, "valu_wave_instructions_per_launch": valu, "valu_issue_us_at_3.0_cycles": round(lo, 1),
                      "valu_issue_us_at_4.2_cycles": round(ty, 1), "valu_issue_share_floor": round(lo / avg_us, 3), "valu_issue_share_typical": round(min(ty / avg_us, 1.0), 3)}
-print(json.dumps({"note": __doc__.strip().split("\n\n")[0], "simds": SIMDS, "clock_ghz": GHZ, "kernels": out}, indent=1))
+print(json.dumps({"note": __doc__.strip().split("\n\n")[0], "simds": SIMDS, "clock_ghz": GHZ, "clock_source": clock_src, "kernels": out}, indent=1))
