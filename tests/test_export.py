@@ -119,6 +119,30 @@ def test_export_overlay_tables_emu(lvm, po, emu, size, pre, split, nb):
     _check_overlay(lvm, po, emu, size, pre, split, nb, True, mjpeg_quality=85)
 
 
+def test_overlay_device_on_caller_canvases_emu(lvm, po, emu):
+    """lvm_overlay_device: the same tables on caller-owned canvases (two frames, a padded row stride); the padding stays untouched"""
+    rng = np.random.default_rng(9)
+    cw, chh, stride = 200, 64, 200 * 3 + 8
+    buf = rng.integers(0, 256, (2, chh, stride), dtype=np.uint8)
+    before = buf.copy()
+    labels = [po.standin_label_tables(70, 14, 3, 6, 6, cw, chh, seed=4), po.standin_label_tables(80, 14, 3, 106, 6, cw, chh, seed=5)]
+    ctx = lvm.Context(0, 1, emu)
+    try:
+        ctx.overlay_device(buf.ctypes.data, cw, chh, 2, stride, stride * chh)             # no labels set: nothing happens
+        assert np.array_equal(buf, before)
+        ctx.export_set_overlay(labels)
+        ctx.overlay_device(buf.ctypes.data, cw, chh, 2, stride, stride * chh)
+        ctx.synchronize()
+        for k in range(2):
+            want = po.apply_overlay(before[k, :, :cw * 3].reshape(chh, cw, 3), labels)
+            assert np.array_equal(buf[k, :, :cw * 3].reshape(chh, cw, 3), want)
+            assert np.array_equal(buf[k, :, cw * 3:], before[k, :, cw * 3:])
+        with pytest.raises(lvm.LvmError, match="outside the canvas"):
+            ctx.overlay_device(buf.ctypes.data, 150, chh, 1, stride, stride * chh)
+    finally:
+        ctx.close()
+
+
 def test_export_overlay_rejects_bad_tables(lvm, po, emu):
     ctx = lvm.Context(0, 1, emu)
     try:

@@ -40,5 +40,7 @@ python tools/valu_issue.py --clock-mhz $CLK $O/${R}_rocprof_laplace_kernels_and_
 [ -x tools/ubench_stream ] || hipcc --offload-arch=gfx950 -O3 tools/ubench_stream.hip -o tools/ubench_stream
 bash tools/tcc_pass.sh > $O/${R}_tcc_ea_counters.txt 2>&1
 rm -rf $ROOT/gpurun_out/r6_tcc
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k variant_envelope 2>&1 | grep "HIP vs oracle" > $O/${R}_variant_envelope_gpu.txt
+timeout 300 python tools/tiling_bench.py 2>&1 | grep -v amdgpu.ids > $O/${R}_tiling_one_gpu.txt
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/${R}_pytest_gpu.txt
 ls -la $O | head -40
