@@ -973,6 +973,7 @@ struct LaplaceState : ModeState {
     long up_rows_max_blocks = 1024;       // launches with fewer tiled workgroups than this use k_lap_up_rows (LVM_UP_ROWS_MAX_BLOCKS)
     bool d0_rows_on = true;               // wave-strip first kernel (LVM_D0_ROWS=0: LDS-tiled k_down0_v4 always)
     bool d0_fused = true;                 // table conversion fused into the first kernel on large launches (LVM_D0_FUSED=0: separate kernels)
+    int d0_fused_rows = 0;                // force the fused first kernel with strips of this many rows (LVM_D0_FUSED_ROWS; measurement only)
     long d0_fused_groups = 0;             // persistent workgroups of the fused first kernel (LVM_D0_FUSED_GROUPS; 0 = one per CU)
     long d0_fused_waves = 0;              // ... = launches with at least this many strips (LVM_D0_FUSED_WAVES; 0 = one per resident wave)
     long d0_min_tasks = 4096;             // ... for launches with at least this many strips (LVM_D0_MIN_TASKS)
@@ -1036,6 +1037,7 @@ static int laplace_alloc(Ctx* c, LaplaceState* st, int w, int h, int channels, i
     if (const char* e = std::getenv("LVM_D0_FUSED")) st->d0_fused = std::atoi(e) != 0;
     if (const char* e = std::getenv("LVM_D0_FUSED_WAVES")) st->d0_fused_waves = std::atol(e);
     if (const char* e = std::getenv("LVM_D0_FUSED_GROUPS")) st->d0_fused_groups = std::atol(e);
+    if (const char* e = std::getenv("LVM_D0_FUSED_ROWS")) st->d0_fused_rows = std::atoi(e);
     if (const char* e = std::getenv("LVM_D0_MIN_TASKS")) st->d0_min_tasks = std::atol(e);
     if (const char* e = std::getenv("LVM_LAP_SPLIT")) st->split_levels = std::atoi(e);
     if (const char* e = std::getenv("LVM_LAP_SPLIT_MIN_NT")) st->split_min_nt = std::atoi(e);
@@ -1130,7 +1132,11 @@ static bool lap_d0l_args(Ctx* c, LaplaceState* st, const FrameIO& io, const LapB
     if (!(lp.iab && levels >= 2 && st->d0_fused && lap_vec4(io) && st->g[1].w % 2 == 0)) return false;
     long dl_tasks = 0;
     const long dl_waves = st->d0_fused_waves > 0 ? st->d0_fused_waves : (long)lap_d0l_groups(c, st) * (D0L_THREADS / 64);
-    const int dl_rows = down0_lut_rows_choice(st->g[1].w, st->g[1].h, NS, dl_waves, &dl_tasks);
+    int dl_rows = down0_lut_rows_choice(st->g[1].w, st->g[1].h, NS, dl_waves, &dl_tasks);
+    if (st->d0_fused_rows > 0) {            // measurement switch (LVM_D0_FUSED_ROWS): strips of this many output rows whatever the launch size
+        dl_rows = st->d0_fused_rows;
+        dl_tasks = (long)((st->g[1].w + D0R_OUT - 1) / D0R_OUT) * ((st->g[1].h + dl_rows - 1) / dl_rows) * NS;
+    }
     if (dl_tasks <= 0) return false;
     const LevelGeom& g1 = st->g[1];
     const int sx = (g1.w + D0R_OUT - 1) / D0R_OUT, sy = (g1.h + dl_rows - 1) / dl_rows;
